@@ -1,0 +1,127 @@
+/*
+ * csnet_hip.h -- C ABI of the MI355X-native CSNet engine (libcsnet_hip.so).
+ *
+ * This is the drop-in boundary for the reference's model seam
+ *     model_lib = importlib.import_module("model." + cfg.MODEL.ARCH)      (CSNet/test.py:37-39,
+ *     model = model_lib.build_model(...); predict = model(input_var)       CSNet_training/train.py:70-80,203)
+ * i.e. everything `CSNet.forward` (CSNet/model/csnet.py:365-387) and its autograd backward do on the
+ * device.  The reference itself has no FFI (pure Python over torch/ATen); the host mirror
+ * `sod100k_amd/model/csnet.py` keeps the reference's nn.Module parameter tree and binds these entry
+ * points through ctypes.
+ *
+ * Conventions
+ *  - plain C types only; every function returns an int status (0 = CSN_OK) and never throws;
+ *  - the library owns the plan (and the packed-parameter buffer inside it); the CALLER owns the input,
+ *    output, parameter arena and workspace device buffers (e.g. torch tensors -> data_ptr());
+ *  - all launches go to the caller's stream (`void* stream` is a hipStream_t); no hidden
+ *    synchronisation and no allocation after csn_plan_create();
+ *  - a plan is not re-entrant: one plan per (device, stream); data parallel = one process per GPU;
+ *  - external tensor layout is the reference's: contiguous NCHW float32.  Internally every activation
+ *    is also planar [B][C][H][W] per resolution branch (channel is wave-uniform -> weights, BN and
+ *    PReLU parameters live in SGPRs; no channel padding traffic).
+ *
+ * A network is described as a list of *units*; a unit is one of the reference's sub-modules that owns
+ * an activation boundary in HBM (SURVEY.md section 8(d) "unit"):
+ *   CSN_UNIT_GOCT  gOctaveCBR            csnet.py:729-792 (gOctaveConv 604-726 + BN + PReLU per branch)
+ *   CSN_UNIT_DW    SimplifiedGOctConvBR  csnet.py:795-851 (depthwise 3x3, weight x100, + BN + PReLU)
+ *   CSN_UNIT_MS    MSBlock               csnet.py:116-149 (dilated 3x3 group, weight x100, cat, BN, PReLU)
+ *   CSN_UNIT_CLS   cls_layer + F.interpolate(size=input)   csnet.py:306-308,381-385
+ */
+#ifndef CSNET_HIP_H
+#define CSNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSN_ABI_VERSION 1
+#define CSN_MAX_BRANCH 3
+#define CSN_NDIL 5
+
+enum csn_status {
+  CSN_OK = 0,
+  CSN_E_INVALID = 1,      /* bad argument / inconsistent descriptor            */
+  CSN_E_UNSUPPORTED = 2,  /* valid reference configuration not implemented yet */
+  CSN_E_HIP = 3,          /* a HIP runtime call failed (see csn_last_hip_error)*/
+  CSN_E_NOMEM = 4,
+  CSN_E_STATE = 5         /* call order violated (e.g. forward before refresh) */
+};
+
+enum csn_unit_kind { CSN_UNIT_GOCT = 1, CSN_UNIT_DW = 2, CSN_UNIT_MS = 3, CSN_UNIT_CLS = 4 };
+
+/* One activation tensor [B][channels][H >> lvl][W >> lvl].  id 0 is always the network input. */
+typedef struct csn_act_desc {
+  int32_t channels;
+  int32_t lvl;
+} csn_act_desc;
+
+/* Offsets are in floats into the caller's parameter arena (csn_plan_refresh_params); -1 = absent. */
+typedef struct csn_bn_off {
+  int64_t weight, bias, running_mean, running_var; /* nn.BatchNorm2d, eps 1e-5        */
+  int64_t prelu;                                   /* nn.PReLU(C) weight              */
+} csn_bn_off;
+
+typedef struct csn_unit_desc {
+  int32_t kind;                    /* csn_unit_kind                                                     */
+  int32_t n_in, n_out;             /* number of branches (hi-res first); DW/MS: n_in == n_out            */
+  int32_t cin[CSN_MAX_BRANCH];     /* channels per input branch; 0 = branch absent (None)               */
+  int32_t cout[CSN_MAX_BRANCH];    /* channels per output branch; 0 = absent                            */
+  int32_t in_act[CSN_MAX_BRANCH];  /* activation ids, -1 = absent                                       */
+  int32_t out_act[CSN_MAX_BRANCH]; /* CLS: out_act[0] is ignored (result goes to the caller's y)        */
+  int32_t ksize;                   /* GOCT: 1 or 3 (padding = ksize/2), csnet.py:33-48                   */
+  int32_t stride;                  /* GOCT: 1, or 2 = 2x2 avg-pool of every input first, csnet.py:679-680 */
+  int32_t dil_ch[CSN_NDIL];        /* MS: output channels of dilation 1,2,4,8,16 (0 = absent)            */
+  int64_t w_off[CSN_NDIL];         /* GOCT/CLS: [0] = weight [sum cout][sum cin][k][k]; DW: per branch
+                                      [C][1][3][3]; MS: per dilation [dil_ch][cin][3][3]                 */
+  int64_t bias_off;                /* CLS bias, else -1                                                  */
+  csn_bn_off bn[CSN_MAX_BRANCH];   /* per output branch (MS: [0])                                        */
+} csn_unit_desc;
+
+typedef struct csn_act_info {
+  int64_t ws_offset_bytes; /* offset inside the workspace, -1 for the external input */
+  int32_t channels, height, width, batch;
+} csn_act_info;
+
+typedef struct csn_plan csn_plan;
+
+int csn_abi_version(void);
+const char* csn_strerror(int status);
+/* Text of the last failing HIP call of this thread (empty string if none). */
+const char* csn_last_hip_error(void);
+
+/* Build a plan for a fixed (B, H, W).  H and W must be multiples of 16 (CSNet/test.py:80-85).
+ * `sub_batch` (0 = B) makes csn_forward walk the batch in slices of that many images so that a
+ * unit's output is still resident in the 256 MiB Infinity Cache when the next unit reads it. */
+int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_desc* acts, int32_t n_acts,
+                    int32_t B, int32_t H, int32_t W, int32_t sub_batch, csn_plan** out_plan);
+void csn_plan_destroy(csn_plan* plan);
+
+size_t csn_plan_workspace_bytes(const csn_plan* plan);
+int csn_plan_act_info(const csn_plan* plan, int32_t act_id, csn_act_info* out);
+int32_t csn_plan_num_units(const csn_plan* plan);
+
+/* (Re)pack parameters: folds BN running stats + affine into per-channel scale/shift, applies the x100
+ * of Conv2dX100 (CSNet/model/conv2d.py:104) and re-lays the gOctConv weight blocks for scalar loads.
+ * Must be called after every parameter change and before csn_forward.  `arena` is a device pointer. */
+int csn_plan_refresh_params(csn_plan* plan, const float* arena, int64_t arena_floats, void* stream);
+
+/* Eval-mode forward: x [B][3][H][W] -> y [B][1][H][W] logits (no sigmoid), csnet.py:365-387. */
+int csn_forward(csn_plan* plan, const float* x, float* y, void* workspace, void* stream);
+
+/* Same as csn_forward but brackets every unit with HIP events on `stream` and returns the mean
+ * duration per unit over `iters` passes (unit_ms[n_units], milliseconds).  Synchronises. */
+int csn_forward_profile(csn_plan* plan, const float* x, float* y, void* workspace, void* stream,
+                        int32_t iters, float* unit_ms);
+
+/* Name of the dominant kernel of unit `u` (static string) and the algorithmic bytes it moves per
+ * csn_forward (sum of unit input + output activation bytes). */
+const char* csn_unit_kernel_name(const csn_plan* plan, int32_t u);
+int64_t csn_unit_algorithmic_bytes(const csn_plan* plan, int32_t u);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSNET_HIP_H */

@@ -1,0 +1,144 @@
+"""ctypes binding of the C ABI in ``include/csnet_hip.h`` (libcsnet_hip.so) and its build recipe.
+
+The product path has exactly one backend: the hand-written HIP library compiled for gfx950.
+``load()`` raises ``RuntimeError`` if it is missing -- there is no CPU or PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+from typing import Optional, Sequence
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libcsnet_hip.so")
+SOURCES = ("csn_plan.hip", "k_misc.hip", "k_goct_pw.hip", "k_conv3.hip")
+
+MAX_BRANCH = 3
+NDIL = 5
+UNIT_GOCT, UNIT_DW, UNIT_MS, UNIT_CLS = 1, 2, 3, 4
+
+
+class ActDesc(C.Structure):
+    _fields_ = [("channels", C.c_int32), ("lvl", C.c_int32)]
+
+
+class BnOff(C.Structure):
+    _fields_ = [("weight", C.c_int64), ("bias", C.c_int64), ("running_mean", C.c_int64),
+                ("running_var", C.c_int64), ("prelu", C.c_int64)]
+
+
+class UnitDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n_in", C.c_int32), ("n_out", C.c_int32),
+                ("cin", C.c_int32 * MAX_BRANCH), ("cout", C.c_int32 * MAX_BRANCH),
+                ("in_act", C.c_int32 * MAX_BRANCH), ("out_act", C.c_int32 * MAX_BRANCH),
+                ("ksize", C.c_int32), ("stride", C.c_int32),
+                ("dil_ch", C.c_int32 * NDIL), ("w_off", C.c_int64 * NDIL), ("bias_off", C.c_int64),
+                ("bn", BnOff * MAX_BRANCH)]
+
+
+class ActInfo(C.Structure):
+    _fields_ = [("ws_offset_bytes", C.c_int64), ("channels", C.c_int32), ("height", C.c_int32),
+                ("width", C.c_int32), ("batch", C.c_int32)]
+
+
+def new_unit(kind: int) -> UnitDesc:
+    u = UnitDesc()
+    u.kind = kind
+    u.ksize, u.stride, u.bias_off = 1, 1, -1
+    for i in range(MAX_BRANCH):
+        u.in_act[i] = -1
+        u.out_act[i] = -1
+        for f in ("weight", "bias", "running_mean", "running_var", "prelu"):
+            setattr(u.bn[i], f, -1)
+    for i in range(NDIL):
+        u.w_off[i] = -1
+    return u
+
+
+def hipcc_path() -> Optional[str]:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into ``csrc/libcsnet_hip.so`` (in-tree, not installed)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("csn_device.h", "csn_kernels.h")] + \
+        [os.path.join(os.path.dirname(HERE), "include", "csnet_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and all(
+            os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = hipcc_path()
+    if hipcc is None:
+        raise RuntimeError("hipcc not found: cannot build libcsnet_hip.so")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wno-unused-result", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB_PATH
+
+
+def bind(lib: C.CDLL) -> C.CDLL:
+    """Attach argument / result types of every entry point declared in include/csnet_hip.h."""
+    lib.csn_abi_version.restype = C.c_int
+    lib.csn_strerror.restype = C.c_char_p
+    lib.csn_strerror.argtypes = [C.c_int]
+    lib.csn_last_hip_error.restype = C.c_char_p
+    lib.csn_plan_create.restype = C.c_int
+    lib.csn_plan_create.argtypes = [C.POINTER(UnitDesc), C.c_int32, C.POINTER(ActDesc), C.c_int32,
+                                    C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.csn_plan_destroy.restype = None
+    lib.csn_plan_destroy.argtypes = [C.c_void_p]
+    lib.csn_plan_workspace_bytes.restype = C.c_size_t
+    lib.csn_plan_workspace_bytes.argtypes = [C.c_void_p]
+    lib.csn_plan_num_units.restype = C.c_int32
+    lib.csn_plan_num_units.argtypes = [C.c_void_p]
+    lib.csn_plan_act_info.restype = C.c_int
+    lib.csn_plan_act_info.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ActInfo)]
+    lib.csn_plan_refresh_params.restype = C.c_int
+    lib.csn_plan_refresh_params.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.csn_forward.restype = C.c_int
+    lib.csn_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.csn_forward_profile.restype = C.c_int
+    lib.csn_forward_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int32, C.POINTER(C.c_float)]
+    lib.csn_unit_kernel_name.restype = C.c_char_p
+    lib.csn_unit_kernel_name.argtypes = [C.c_void_p, C.c_int32]
+    lib.csn_unit_algorithmic_bytes.restype = C.c_int64
+    lib.csn_unit_algorithmic_bytes.argtypes = [C.c_void_p, C.c_int32]
+    return lib
+
+
+EXPORTS: Sequence[str] = (
+    "csn_abi_version", "csn_strerror", "csn_last_hip_error", "csn_plan_create", "csn_plan_destroy",
+    "csn_plan_workspace_bytes", "csn_plan_act_info", "csn_plan_num_units", "csn_plan_refresh_params",
+    "csn_forward", "csn_forward_profile", "csn_unit_kernel_name", "csn_unit_algorithmic_bytes")
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libcsnet_hip.so.  Raises if it has not been built: the HIP path is the only path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing.  Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  sod100k_amd has no CPU / PyTorch fallback by design.")
+        _lib = bind(C.CDLL(LIB_PATH))
+        if _lib.csn_abi_version() != 1:
+            raise RuntimeError("libcsnet_hip.so ABI version mismatch")
+    return _lib
+
+
+def check(lib: C.CDLL, status: int, what: str) -> None:
+    if status != 0:
+        msg = lib.csn_strerror(status).decode()
+        hip = lib.csn_last_hip_error().decode()
+        raise RuntimeError(f"{what}: {msg}" + (f" [{hip}]" if hip else ""))

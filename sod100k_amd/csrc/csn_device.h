@@ -1,0 +1,47 @@
+// csn_device.h -- shared device-side helpers for the csnet HIP kernels (gfx950 / CDNA4).
+//
+// All activations are planar [B][C][H][W] fp32.  Within a kernel the channel index is wave-uniform,
+// so conv weights and the folded BN/PReLU parameters are read through the scalar path (s_load) and
+// feed v_fmac as SGPR operands; only activations travel through VGPRs / LDS.
+#pragma once
+
+#ifdef CSN_CPU_EMU
+#include "hip_cpu_shim.h"
+#define CSN_LAUNCH(kern, grid, block, smem, stream, ...) \
+  csn_emu::launch((grid), (block), (smem), [&]() { kern(__VA_ARGS__); })
+#define CSN_DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(csn_emu::g.smem)
+#else
+#include <hip/hip_runtime.h>
+#define CSN_LAUNCH(kern, grid, block, smem, stream, ...) \
+  hipLaunchKernelGGL(kern, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__)
+#define CSN_DYN_SMEM(type, name)                                                  \
+  extern __shared__ __attribute__((aligned(16))) unsigned char name##_raw_lds[];  \
+  type* name = reinterpret_cast<type*>(name##_raw_lds)
+#endif
+
+#include <stdint.h>
+
+#define CSN_BLOCK 256
+
+// Folded epilogue of one output channel: y = z*scale + shift; y = y >= 0 ? y : alpha*y
+// (nn.BatchNorm2d in eval mode followed by nn.PReLU; for cls_layer scale=1, shift=bias, alpha=1).
+struct CsnEpi {
+  const float* scale;
+  const float* shift;
+  const float* alpha;
+};
+
+__device__ __forceinline__ float csn_epi(float z, float sc, float sh, float al) {
+  float y = fmaf(z, sc, sh);
+  return y >= 0.f ? y : al * y;
+}
+
+// PyTorch's area_pixel_compute_source_index for align_corners=False (upsample_bilinear2d):
+// src = (dst + 0.5) * (1/f) - 0.5, clamped at 0; i1 = min(i0 + 1, n - 1).
+__device__ __forceinline__ void csn_bilin(int dst, float inv_f, int n, int& i0, int& i1, float& l1) {
+  float src = (static_cast<float>(dst) + 0.5f) * inv_f - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = static_cast<int>(src);
+  i1 = i0 + (i0 < n - 1 ? 1 : 0);
+  l1 = src - static_cast<float>(i0);
+}

@@ -1,0 +1,150 @@
+// csn_kernels.h -- argument blocks of the csnet kernels + host-side launch prototypes.
+#pragma once
+#include "csn_device.h"
+
+// ---------------------------------------------------------------------------------------------
+// prep: parameter packing jobs (one block per job)
+// ---------------------------------------------------------------------------------------------
+enum CsnPrepKind {
+  CSN_PREP_COPY = 0,      // dst[i] = p0f * src0[i]                                   (n elements)
+  CSN_PREP_BN_SCALE = 1,  // dst[i] = gamma[i] / sqrt(var[i] + eps)                   src0=gamma src1=var
+  CSN_PREP_BN_SHIFT = 2,  // dst[i] = beta[i] - mean[i] * gamma[i]/sqrt(var[i]+eps)   src0=gamma src1=var src2=beta src3=mean
+  CSN_PREP_FILL = 3,      // dst[i] = p0f
+  // gOctConv 1x1 block -> rows [nrow][cin4]: dst[r*p2 + p3 + c] = src0[(row0+r)*ld + col0 + c]
+  // (p0=ld in floats, p1 = ncol, p2 = dst row stride, p3 = dst col offset; src0 pre-offset to row0/col0)
+  CSN_PREP_ROWS = 4,
+  // 3x3 block -> [co/8][ci][9][8]: dst[((co/8)*ncol + ci)*72 + t*8 + co%8] = p0f * src0[(co*ld + ci)*9 + t]
+  // (n = nrow, p1 = ncol(ci), p0 = ld (total cin of the source weight), p3 = ci offset inside dst, p2 = dst cin total)
+  CSN_PREP_C3 = 5,
+};
+struct CsnPrepJob {
+  int32_t kind, n, p0, p1, p2, p3;
+  float p0f;
+  int64_t src0, src1, src2, src3;  // float offsets into the caller's arena (-1 unused)
+  int64_t dst;                     // float offset into the plan's packed buffer
+};
+
+// ---------------------------------------------------------------------------------------------
+// depthwise 3x3 (x100 already folded into w9) + BN + PReLU, up to 3 resolution branches per launch
+// ---------------------------------------------------------------------------------------------
+struct DwBranch {
+  const float* in;
+  float* out;
+  const float* w9;  // [C][9]
+  const float* scale;
+  const float* shift;
+  const float* alpha;
+  int32_t C, H, W;
+  int32_t LX, NY, R;          // lanes per row (4 px each), lane rows per block, rows per lane
+  int32_t tiles_x, tiles_y;   // tiles per plane
+  int32_t blk_end;            // exclusive prefix sum of blocks over branches
+};
+struct DwArgs {
+  DwBranch br[3];
+  int32_t nbr, B;
+};
+
+// ---------------------------------------------------------------------------------------------
+// gOctConv 1x1 (+BN+PReLU), all output branches of a unit in one block (see k_goct_pw.hip)
+// ---------------------------------------------------------------------------------------------
+#define PW_TY0 16
+#define PW_TX0 32
+#define PW_MAX_PASS 5
+struct PwSrc {
+  const float* ptr;  // [B][C][H_s][W_s], branch (r - shift)
+  int32_t C;
+  int32_t shift;     // log2 of the max-pool window that brings it to the pass resolution (0,1,2)
+};
+struct PwZAdd {
+  int32_t z_off;   // float offset of the region [nrows][ring px of branch rs] in LDS
+  int32_t rs;      // source branch of the region
+};
+struct PwPass {
+  int32_t r;        // branch whose pixels this pass walks
+  int32_t nsrc;
+  PwSrc src[3];     // src[0] is the own-resolution input, the others are max-pooled on the fly
+  int32_t cin4;     // gathered channels rounded up to 4 (row stride of w)
+  int32_t nrows;
+  const float* w;   // packed [nrows][cin4]
+  int32_t dest;     // 0: LDS z region (ring tile, no epilogue)   1: global output with epilogue
+  int32_t z_off;    // dest 0: float offset in LDS
+  float* out;       // dest 1
+  const float* scale;
+  const float* shift;
+  const float* alpha;
+  int32_t nz;
+  PwZAdd zadd[2];
+};
+struct PwArgs {
+  PwPass pass[PW_MAX_PASS];
+  int32_t npass;       // z passes first, then main passes from the lowest resolution up; last = branch 0
+  int32_t nz_pass;     // number of leading z passes
+  int32_t H0, W0;      // resolution of branch 0
+  int32_t B;
+  int32_t top_ppl2;    // 1: the last pass (branch 0) runs two pixels per lane with MAXC_TOP registers
+};
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 conv of ONE output branch (LDS staged), optional max-pool-2 on a source, optional bilinear x2
+// add of a half-resolution tensor, optional epilogue (see k_conv3.hip)
+// ---------------------------------------------------------------------------------------------
+struct C3Src {
+  const float* ptr;  // [B][C][H<<shift][W<<shift]
+  int32_t C;
+  int32_t shift;     // 0, or 1 = 2x2 max-pool while staging
+};
+struct C3Args {
+  C3Src src[2];
+  int32_t nsrc, cin;   // gathered input channels
+  const float* w;      // packed [ceil(cout/8)][cin][9][8]
+  int32_t cout;
+  float* out;          // [B][cout][H][W]
+  const float* scale;  // null -> raw conv result (used for the low->high partial sums)
+  const float* shift;
+  const float* alpha;
+  const float* zadd;   // [B][cout][H/2][W/2] or null: bilinear x2 of it is added before the epilogue
+  int32_t H, W, B;
+};
+
+// ---------------------------------------------------------------------------------------------
+// MSBlock: five dilated 3x3 convs (x100 folded) -> channel concat -> BN -> PReLU, direct
+// ---------------------------------------------------------------------------------------------
+struct MsArgs {
+  const float* in;     // [B][cin][H][W]
+  float* out;          // [B][cout][H][W]
+  const float* w[5];   // packed [ceil(dch/8)][cin][9][8] per dilation (null if absent)
+  int32_t dch[5];
+  int32_t cobase[5];   // first output channel of each dilation inside the concat
+  int32_t cin, cout, H, W, B;
+  const float* scale;
+  const float* shift;
+  const float* alpha;
+};
+
+// ---------------------------------------------------------------------------------------------
+// 2x2 average pool of up to 3 tensors; bilinear x2 of one tensor
+// ---------------------------------------------------------------------------------------------
+struct PoolArgs {
+  const float* in[3];
+  float* out[3];
+  int32_t planes[3];    // B*C
+  int32_t Ho[3], Wo[3]; // output size
+  int32_t blk_end[3];
+  int32_t n;
+};
+struct Up2Args {
+  const float* in;  // [planes][H/2][W/2]
+  float* out;       // [planes][H][W]
+  int32_t planes, H, W;
+};
+
+// launchers (implemented next to the kernels)
+int csn_launch_prep(const CsnPrepJob* jobs_dev, int njobs, const float* arena, float* packed, void* stream);
+int csn_launch_dw(const DwArgs& a, void* stream);
+int csn_launch_pw(const PwArgs& a, int maxc_top, int maxc_low, void* stream);
+int csn_launch_c3(const C3Args& a, void* stream);
+int csn_launch_ms(const MsArgs& a, void* stream);
+int csn_launch_pool(const PoolArgs& a, void* stream);
+int csn_launch_up2(const Up2Args& a, void* stream);
+size_t csn_pw_lds_bytes(const PwArgs& a);
+int csn_kernels_init(void);  // function attributes (max dynamic LDS)

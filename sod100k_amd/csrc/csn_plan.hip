@@ -1,0 +1,722 @@
+// csn_plan.hip -- host side of libcsnet_hip.so: plan construction, parameter packing jobs, workspace
+// layout and the launch sequence of CSNet.forward (CSNet/model/csnet.py:365-387) behind the C ABI of
+// include/csnet_hip.h.  No torch types; the caller owns every tensor.
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/csnet_hip.h"
+#include "csn_kernels.h"
+
+namespace {
+
+thread_local std::string g_hip_err;
+thread_local std::string g_why;
+#define FAIL(code, why) do { g_why = (why); return (code); } while (0)
+
+int hip_fail(hipError_t e, const char* what) {
+  g_hip_err = std::string(what) + ": " + hipGetErrorString(e);
+  return CSN_E_HIP;
+}
+#define HIP_TRY(expr)                                     \
+  do {                                                    \
+    hipError_t _e = (expr);                               \
+    if (_e != hipSuccess) return hip_fail(_e, #expr);     \
+  } while (0)
+#define LAUNCH_TRY(expr)                                                  \
+  do {                                                                    \
+    int _e = (expr);                                                      \
+    if (_e < 0) { g_hip_err = #expr ": no kernel instantiation"; return CSN_E_UNSUPPORTED; } \
+    if (_e != 0) return hip_fail((hipError_t)_e, #expr);                  \
+  } while (0)
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+inline int round4(int v) { return (v + 3) & ~3; }
+
+struct Act {
+  int channels = 0, lvl = 0;
+  int64_t ws_off = -1;  // bytes; -1 = external input
+};
+
+struct Epi {  // float offsets into the packed buffer
+  int64_t scale = -1, shift = -1, alpha = -1;
+};
+
+struct PwPassPlan {
+  int r = 0;
+  int nsrc = 0;
+  int src_branch[3] = {-1, -1, -1};
+  int src_C[3] = {0, 0, 0};
+  int src_shift[3] = {0, 0, 0};
+  int cin4 = 0, nrows = 0;
+  int64_t w = -1;
+  int dest = 1, z_off = 0;
+  int out_branch = -1;
+  Epi epi;
+  int nz = 0;
+  int zadd_off[2] = {0, 0};
+  int zadd_rs[2] = {0, 0};
+};
+
+struct C3Plan {
+  int res_branch = 0;  // output resolution: unit branch index
+  int nsrc = 0;
+  int src_branch[2] = {-1, -1};
+  int src_C[2] = {0, 0};
+  int src_shift[2] = {0, 0};
+  int cin = 0, cout = 0;
+  int64_t w = -1;
+  bool to_z = false;       // writes the raw partial sums into the unit's Z scratch
+  bool add_z = false;      // adds bilinear x2 of the Z scratch
+  int out_branch = -1;
+  Epi epi;
+};
+
+struct UnitPlan {
+  csn_unit_desc d;
+  int base_lvl = 0;                  // lvl of branch 0 of the unit's compute resolution
+  // inputs after the optional avg-pool: pointers are either the acts themselves or pooled scratch
+  int64_t pooled_off[3] = {-1, -1, -1};  // workspace byte offsets of pooled copies (stride 2)
+  int64_t z_off = -1;                    // workspace byte offset of the 3x3 low->high scratch
+  int64_t logits_off = -1;               // CLS: logits at H/2
+  // GOCT 1x1 / CLS
+  std::vector<PwPassPlan> pw;
+  int pw_nz = 0, maxc_top = 4, maxc_low = 4, top_ppl2 = 0;
+  // GOCT 3x3
+  std::vector<C3Plan> c3;
+  // DW
+  int64_t dw_w[3] = {-1, -1, -1};
+  Epi dw_epi[3];
+  // MS
+  int64_t ms_w[5] = {-1, -1, -1, -1, -1};
+  Epi ms_epi;
+  const char* kname = "";
+  int64_t alg_bytes = 0;
+};
+
+}  // namespace
+
+struct csn_plan {
+  int B = 0, H = 0, W = 0, S = 0;  // S = images per slice
+  std::vector<Act> acts;
+  std::vector<UnitPlan> units;
+  int64_t ws_bytes = 0;
+  int64_t packed_floats = 0;
+  float* packed = nullptr;  // device
+  std::vector<CsnPrepJob> jobs;
+  CsnPrepJob* jobs_dev = nullptr;
+  bool params_ready = false;
+  std::vector<hipEvent_t> ev;
+};
+
+namespace {
+
+struct Builder {
+  csn_plan& P;
+  explicit Builder(csn_plan& p) : P(p) {}
+
+  int64_t alloc_packed(int64_t n) {
+    const int64_t off = P.packed_floats;
+    P.packed_floats += align_up(n > 0 ? n : 1, 4);
+    return off;
+  }
+  int64_t alloc_ws(int64_t bytes) {
+    const int64_t off = P.ws_bytes;
+    P.ws_bytes += align_up(bytes, 256);
+    return off;
+  }
+  void job(int kind, int n, int64_t dst, int64_t s0 = -1, int64_t s1 = -1, int64_t s2 = -1, int64_t s3 = -1,
+           float p0f = 1.f, int p0 = 0, int p1 = 0, int p2 = 0, int p3 = 0) {
+    CsnPrepJob j;
+    j.kind = kind; j.n = n; j.p0 = p0; j.p1 = p1; j.p2 = p2; j.p3 = p3; j.p0f = p0f;
+    j.src0 = s0; j.src1 = s1; j.src2 = s2; j.src3 = s3; j.dst = dst;
+    P.jobs.push_back(j);
+  }
+  Epi bn_epi(const csn_bn_off& bn, int C) {
+    Epi e;
+    e.scale = alloc_packed(C); e.shift = alloc_packed(C); e.alpha = alloc_packed(C);
+    job(CSN_PREP_BN_SCALE, C, e.scale, bn.weight, bn.running_var);
+    job(CSN_PREP_BN_SHIFT, C, e.shift, bn.weight, bn.running_var, bn.bias, bn.running_mean);
+    job(CSN_PREP_COPY, C, e.alpha, bn.prelu);
+    return e;
+  }
+  int64_t act_bytes(int C, int lvl) const {
+    return (int64_t)P.S * C * (P.H >> lvl) * (P.W >> lvl) * (int64_t)sizeof(float);
+  }
+};
+
+bool bn_ok(const csn_bn_off& b) {
+  return b.weight >= 0 && b.bias >= 0 && b.running_mean >= 0 && b.running_var >= 0 && b.prelu >= 0;
+}
+
+int plan_goct(Builder& bl, UnitPlan& u) {
+  csn_plan& P = bl.P;
+  const csn_unit_desc& d = u.d;
+  if (d.n_in < 1 || d.n_in > 3 || d.n_out < 1 || d.n_out > 3) FAIL(CSN_E_INVALID, "csn_plan.hip:155");
+  if (!(d.ksize == 1 || d.ksize == 3) || !(d.stride == 1 || d.stride == 2)) FAIL(CSN_E_INVALID, "csn_plan.hip:156");
+  if (d.n_in == 1 && d.n_out == 1) FAIL(CSN_E_UNSUPPORTED, "csn_plan.hip:157");  // std_conv (Conv2dX100) path, csnet.py:751-754
+  int cin_tot = 0, cout_tot = 0, ci_off[4] = {0}, co_off[4] = {0};
+  for (int i = 0; i < d.n_in; ++i) { ci_off[i] = cin_tot; cin_tot += d.cin[i]; }
+  for (int j = 0; j < d.n_out; ++j) { co_off[j] = cout_tot; cout_tot += d.cout[j]; }
+  // resolution bookkeeping
+  int base = -1;
+  for (int j = 0; j < d.n_out; ++j)
+    if (d.cout[j] > 0) {
+      if (d.out_act[j] < 0 || d.out_act[j] >= (int)P.acts.size()) FAIL(CSN_E_INVALID, "csn_plan.hip:165");
+      const Act& a = P.acts[d.out_act[j]];
+      if (a.channels != d.cout[j]) FAIL(CSN_E_INVALID, "csn_plan.hip:167");
+      const int b0 = a.lvl - j;
+      if (base >= 0 && b0 != base) FAIL(CSN_E_INVALID, "csn_plan.hip:169");
+      base = b0;
+      if (!bn_ok(d.bn[j])) FAIL(CSN_E_INVALID, "csn_plan.hip:171");
+    }
+  if (base < 0) FAIL(CSN_E_INVALID, "csn_plan.hip:173");
+  u.base_lvl = base;
+  const int ds = d.stride == 2 ? 1 : 0;
+  for (int i = 0; i < d.n_in; ++i)
+    if (d.cin[i] > 0) {
+      if (d.in_act[i] < 0 || d.in_act[i] >= (int)P.acts.size()) FAIL(CSN_E_INVALID, "csn_plan.hip:178");
+      const Act& a = P.acts[d.in_act[i]];
+      if (a.channels != d.cin[i] || a.lvl + ds != base + i) FAIL(CSN_E_INVALID, "csn_plan.hip:180");
+      if (ds) u.pooled_off[i] = bl.alloc_ws(bl.act_bytes(d.cin[i], base + i));
+    }
+  const int nb = d.n_in > d.n_out ? d.n_in : d.n_out;
+  if (((P.H >> (base + nb - 1)) << (base + nb - 1)) != P.H || ((P.W >> (base + nb - 1)) << (base + nb - 1)) != P.W)
+    FAIL(CSN_E_INVALID, "csn_plan.hip:185");
+  Epi epi[3];
+  for (int j = 0; j < d.n_out; ++j)
+    if (d.cout[j] > 0) epi[j] = bl.bn_epi(d.bn[j], d.cout[j]);
+  const int64_t ld = (int64_t)cin_tot * d.ksize * d.ksize;
+
+  if (d.ksize == 1) {
+    u.kname = "goct_pw_kernel";
+    int lds_fl = 0;
+    int z_region[3][3];  // [i][j] float offset in LDS
+    for (auto& r : z_region) for (int& v : r) v = -1;
+    // z passes
+    for (int i = 1; i < d.n_in; ++i) {
+      if (d.cin[i] == 0) continue;
+      PwPassPlan ps;
+      ps.r = i; ps.nsrc = 1; ps.src_branch[0] = i; ps.src_C[0] = d.cin[i]; ps.src_shift[0] = 0;
+      ps.cin4 = round4(d.cin[i]); ps.dest = 0; ps.z_off = lds_fl;
+      const int ring = ((PW_TY0 >> i) + 2) * ((PW_TX0 >> i) + 2);
+      int nrows = 0;
+      for (int j = 0; j < i && j < d.n_out; ++j) nrows += d.cout[j];
+      if (nrows == 0) continue;
+      ps.nrows = nrows;
+      ps.w = bl.alloc_packed((int64_t)nrows * ps.cin4);
+      int row = 0;
+      for (int j = 0; j < i && j < d.n_out; ++j) {
+        if (d.cout[j] == 0) continue;
+        z_region[i][j] = lds_fl + row * ring;
+        bl.job(CSN_PREP_ROWS, d.cout[j], ps.w + (int64_t)row * ps.cin4, d.w_off[0] + (int64_t)co_off[j] * ld + ci_off[i],
+               -1, -1, -1, 1.f, (int)ld, d.cin[i], ps.cin4, 0);
+        row += d.cout[j];
+      }
+      lds_fl += nrows * ring;
+      u.pw.push_back(ps);
+    }
+    u.pw_nz = (int)u.pw.size();
+    int max_low = 0, top_c = 0;
+    bool has_top = false;
+    for (int j = d.n_out - 1; j >= 0; --j) {
+      if (d.cout[j] == 0) continue;
+      PwPassPlan ps;
+      ps.r = j; ps.dest = 1; ps.out_branch = j; ps.nrows = d.cout[j]; ps.epi = epi[j];
+      // src[0] = own resolution (may be absent), then pooled higher-resolution inputs
+      ps.nsrc = 1; ps.src_branch[0] = j; ps.src_C[0] = (j < d.n_in) ? d.cin[j] : 0; ps.src_shift[0] = 0;
+      int cols = ps.src_C[0];
+      for (int i = 0; i < j && i < d.n_in; ++i) {
+        if (d.cin[i] == 0) continue;
+        if (ps.nsrc >= 3) FAIL(CSN_E_UNSUPPORTED, "csn_plan.hip:231");
+        ps.src_branch[ps.nsrc] = i; ps.src_C[ps.nsrc] = d.cin[i]; ps.src_shift[ps.nsrc] = j - i;
+        cols += d.cin[i];
+        ++ps.nsrc;
+      }
+      ps.cin4 = round4(cols);
+      ps.w = bl.alloc_packed((int64_t)ps.nrows * (ps.cin4 > 0 ? ps.cin4 : 4));
+      int col = 0;
+      for (int s = 0; s < ps.nsrc; ++s) {
+        if (ps.src_C[s] == 0) continue;
+        const int i = ps.src_branch[s];
+        bl.job(CSN_PREP_ROWS, ps.nrows, ps.w, d.w_off[0] + (int64_t)co_off[j] * ld + ci_off[i], -1, -1, -1, 1.f,
+               (int)ld, d.cin[i], ps.cin4, col);
+        col += d.cin[i];
+      }
+      for (int i = j + 1; i < d.n_in; ++i) {
+        if (d.cin[i] == 0 || z_region[i][j] < 0) continue;
+        if (ps.nz >= 2) FAIL(CSN_E_UNSUPPORTED, "csn_plan.hip:248");
+        ps.zadd_off[ps.nz] = z_region[i][j]; ps.zadd_rs[ps.nz] = i; ++ps.nz;
+      }
+      if (j == 0) { has_top = true; top_c = ps.cin4; }
+      else if (ps.cin4 > max_low) max_low = ps.cin4;
+      u.pw.push_back(ps);
+    }
+    for (int q = 0; q < u.pw_nz; ++q) if (u.pw[q].cin4 > max_low) max_low = u.pw[q].cin4;
+    u.top_ppl2 = 0; u.maxc_top = 4;
+    if (has_top && top_c <= 80) {
+      u.top_ppl2 = 1;
+      u.maxc_top = top_c <= 16 ? 16 : top_c <= 32 ? 32 : top_c <= 64 ? 64 : 80;
+    } else if (has_top && top_c > max_low) {
+      max_low = top_c;
+    }
+    if (max_low > 160) FAIL(CSN_E_UNSUPPORTED, "csn_plan.hip:263");
+    u.maxc_low = max_low == 0 ? 4 : max_low <= 32 ? 32 : max_low <= 64 ? 64 : max_low <= 96 ? 96 : 160;
+    if (!u.top_ppl2 && u.maxc_low == 4) u.maxc_low = 32;
+    if ((int)u.pw.size() > PW_MAX_PASS) FAIL(CSN_E_UNSUPPORTED, "csn_plan.hip:266");
+    if ((int64_t)lds_fl * 4 > 160 * 1024) FAIL(CSN_E_UNSUPPORTED, "csn_plan.hip:267");
+  } else {
+    u.kname = "conv3x3_kernel";
+    if (d.n_in > 2 || d.n_out > 2) FAIL(CSN_E_UNSUPPORTED, "csn_plan.hip:270");
+    const bool lo_to_hi = d.n_in == 2 && d.cin[1] > 0 && d.cout[0] > 0;
+    if (lo_to_hi) {
+      u.z_off = bl.alloc_ws(bl.act_bytes(d.cout[0], base + 1));
+      C3Plan c;
+      c.res_branch = 1; c.nsrc = 1; c.src_branch[0] = 1; c.src_C[0] = d.cin[1]; c.cin = d.cin[1];
+      c.cout = d.cout[0]; c.to_z = true;
+      c.w = bl.alloc_packed((int64_t)((c.cout + 7) / 8) * c.cin * 72);
+      bl.job(CSN_PREP_C3, c.cout, c.w, d.w_off[0] + ((int64_t)co_off[0] * cin_tot + ci_off[1]) * 9, -1, -1, -1, 1.f,
+             cin_tot, c.cin, c.cin, 0);
+      u.c3.push_back(c);
+    }
+    for (int j = d.n_out - 1; j >= 0; --j) {
+      if (d.cout[j] == 0) continue;
+      C3Plan c;
+      c.res_branch = j; c.cout = d.cout[j]; c.out_branch = j; c.epi = epi[j];
+      if (j < d.n_in && d.cin[j] > 0) { c.src_branch[c.nsrc] = j; c.src_C[c.nsrc] = d.cin[j]; c.src_shift[c.nsrc] = 0; ++c.nsrc; }
+      if (j == 1 && d.cin[0] > 0) { c.src_branch[c.nsrc] = 0; c.src_C[c.nsrc] = d.cin[0]; c.src_shift[c.nsrc] = 1; ++c.nsrc; }
+      for (int s = 0; s < c.nsrc; ++s) c.cin += c.src_C[s];
+      if (c.cin == 0) FAIL(CSN_E_UNSUPPORTED, "csn_plan.hip:289");
+      c.w = bl.alloc_packed((int64_t)((c.cout + 7) / 8) * c.cin * 72);
+      int col = 0;
+      for (int s = 0; s < c.nsrc; ++s) {
+        const int i = c.src_branch[s];
+        bl.job(CSN_PREP_C3, c.cout, c.w, d.w_off[0] + ((int64_t)co_off[j] * cin_tot + ci_off[i]) * 9, -1, -1, -1, 1.f,
+               cin_tot, c.src_C[s], c.cin, col);
+        col += c.src_C[s];
+      }
+      c.add_z = (j == 0) && lo_to_hi;
+      u.c3.push_back(c);
+    }
+  }
+  return CSN_OK;
+}
+
+int plan_dw(Builder& bl, UnitPlan& u) {
+  csn_plan& P = bl.P;
+  const csn_unit_desc& d = u.d;
+  if (d.n_in != d.n_out || d.n_in < 1 || d.n_in > 3) FAIL(CSN_E_INVALID, "csn_plan.hip:308");
+  u.kname = "dw3x3_bn_prelu_kernel";
+  for (int k = 0; k < d.n_in; ++k) {
+    if (d.cout[k] == 0) continue;
+    if (d.cin[k] != d.cout[k] || d.in_act[k] < 0 || d.out_act[k] < 0) FAIL(CSN_E_INVALID, "csn_plan.hip:312");
+    const Act& ai = P.acts[d.in_act[k]];
+    const Act& ao = P.acts[d.out_act[k]];
+    if (ai.channels != d.cin[k] || ao.channels != d.cout[k] || ai.lvl != ao.lvl) FAIL(CSN_E_INVALID, "csn_plan.hip:315");
+    if (!bn_ok(d.bn[k]) || d.w_off[k] < 0) FAIL(CSN_E_INVALID, "csn_plan.hip:316");
+    u.dw_w[k] = bl.alloc_packed((int64_t)d.cout[k] * 9);
+    bl.job(CSN_PREP_COPY, d.cout[k] * 9, u.dw_w[k], d.w_off[k], -1, -1, -1, 100.0f);  // conv2d.py:104
+    u.dw_epi[k] = bl.bn_epi(d.bn[k], d.cout[k]);
+  }
+  return CSN_OK;
+}
+
+int plan_ms(Builder& bl, UnitPlan& u) {
+  csn_plan& P = bl.P;
+  const csn_unit_desc& d = u.d;
+  u.kname = "msblock_kernel";
+  if (d.in_act[0] < 0 || d.out_act[0] < 0) FAIL(CSN_E_INVALID, "csn_plan.hip:328");
+  const Act& ai = P.acts[d.in_act[0]];
+  const Act& ao = P.acts[d.out_act[0]];
+  int tot = 0;
+  for (int k = 0; k < CSN_NDIL; ++k) tot += d.dil_ch[k];
+  if (ai.channels != d.cin[0] || ao.channels != d.cout[0] || tot != d.cout[0] || ai.lvl != ao.lvl) FAIL(CSN_E_INVALID, "csn_plan.hip:333");
+  if (!bn_ok(d.bn[0])) FAIL(CSN_E_INVALID, "csn_plan.hip:334");
+  for (int k = 0; k < CSN_NDIL; ++k) {
+    if (d.dil_ch[k] == 0) continue;
+    if (d.w_off[k] < 0) FAIL(CSN_E_INVALID, "csn_plan.hip:337");
+    u.ms_w[k] = bl.alloc_packed((int64_t)((d.dil_ch[k] + 7) / 8) * d.cin[0] * 72);
+    bl.job(CSN_PREP_C3, d.dil_ch[k], u.ms_w[k], d.w_off[k], -1, -1, -1, 100.0f, d.cin[0], d.cin[0], d.cin[0], 0);
+  }
+  u.ms_epi = bl.bn_epi(d.bn[0], d.cout[0]);
+  return CSN_OK;
+}
+
+int plan_cls(Builder& bl, UnitPlan& u) {
+  csn_plan& P = bl.P;
+  const csn_unit_desc& d = u.d;
+  u.kname = "goct_pw_kernel";
+  if (d.in_act[0] < 0 || d.w_off[0] < 0 || d.bias_off < 0) FAIL(CSN_E_INVALID, "csn_plan.hip:349");
+  const Act& ai = P.acts[d.in_act[0]];
+  if (ai.channels != d.cin[0] || ai.lvl != 1) FAIL(CSN_E_INVALID, "csn_plan.hip:351");  // csnet.py:380-385: fuse @ H/2
+  u.base_lvl = 1;
+  u.logits_off = bl.alloc_ws(bl.act_bytes(1, 1));
+  PwPassPlan ps;
+  ps.r = 0; ps.dest = 1; ps.nrows = 1; ps.nsrc = 1; ps.src_branch[0] = 0; ps.src_C[0] = d.cin[0];
+  ps.cin4 = round4(d.cin[0]);
+  ps.w = bl.alloc_packed(ps.cin4);
+  bl.job(CSN_PREP_ROWS, 1, ps.w, d.w_off[0], -1, -1, -1, 1.f, d.cin[0], d.cin[0], ps.cin4, 0);
+  ps.epi.scale = bl.alloc_packed(1); ps.epi.shift = bl.alloc_packed(1); ps.epi.alpha = bl.alloc_packed(1);
+  bl.job(CSN_PREP_FILL, 1, ps.epi.scale, -1, -1, -1, -1, 1.f);
+  bl.job(CSN_PREP_COPY, 1, ps.epi.shift, d.bias_off);
+  bl.job(CSN_PREP_FILL, 1, ps.epi.alpha, -1, -1, -1, -1, 1.f);
+  u.pw.push_back(ps);
+  u.pw_nz = 0;
+  if (ps.cin4 <= 80) {
+    u.top_ppl2 = 1; u.maxc_low = 4;
+    u.maxc_top = ps.cin4 <= 16 ? 16 : ps.cin4 <= 32 ? 32 : ps.cin4 <= 64 ? 64 : 80;
+  } else if (ps.cin4 <= 160) {
+    u.top_ppl2 = 0; u.maxc_top = 4; u.maxc_low = ps.cin4 <= 96 ? 96 : 160;
+  } else {
+    FAIL(CSN_E_UNSUPPORTED, "csn_plan.hip:371");
+  }
+  return CSN_OK;
+}
+
+// ------------------------------------------------------------------------------------ execution
+struct Ctx {
+  const csn_plan& P;
+  const float* x;  // slice pointers
+  float* y;
+  char* ws;
+  void* stream;
+  const float* act_in(int id) const {
+    const Act& a = P.acts[id];
+    return a.ws_off < 0 ? x : reinterpret_cast<const float*>(ws + a.ws_off);
+  }
+  float* act_out(int id) const { return reinterpret_cast<float*>(ws + P.acts[id].ws_off); }
+  const float* pk(int64_t off) const { return P.packed + off; }
+};
+
+int choose_dw_rows(int H, int NY) {
+  int best = 4;
+  double best_s = -1;
+  for (int R = 4; R <= 16; ++R) {
+    const int rows = NY * R;
+    const int tiles = (H + rows - 1) / rows;
+    const double eff = (double)H / ((double)tiles * rows);
+    const double s = eff * R / (R + 2.0);
+    if (s > best_s + 1e-9) { best_s = s; best = R; }
+  }
+  return best;
+}
+
+int run_unit(const Ctx& c, const UnitPlan& u) {
+  const csn_plan& P = c.P;
+  const csn_unit_desc& d = u.d;
+  const int S = P.S;
+  switch (d.kind) {
+    case CSN_UNIT_DW: {
+      DwArgs a;
+      a.nbr = 0; a.B = S;
+      int blk = 0;
+      for (int k = 0; k < d.n_in; ++k) {
+        if (d.cout[k] == 0) continue;
+        DwBranch& br = a.br[a.nbr++];
+        const Act& act = P.acts[d.in_act[k]];
+        br.in = c.act_in(d.in_act[k]); br.out = c.act_out(d.out_act[k]);
+        br.w9 = c.pk(u.dw_w[k]);
+        br.scale = c.pk(u.dw_epi[k].scale); br.shift = c.pk(u.dw_epi[k].shift); br.alpha = c.pk(u.dw_epi[k].alpha);
+        br.C = d.cout[k]; br.H = P.H >> act.lvl; br.W = P.W >> act.lvl;
+        const int cols = (br.W + 3) / 4;
+        br.LX = cols < 64 ? cols : 64;
+        br.NY = CSN_BLOCK / br.LX;
+        br.tiles_x = (cols + br.LX - 1) / br.LX;
+        br.R = choose_dw_rows(br.H, br.NY);
+        br.tiles_y = (br.H + br.NY * br.R - 1) / (br.NY * br.R);
+        blk += br.tiles_x * br.tiles_y * br.C * S;
+        br.blk_end = blk;
+      }
+      if (a.nbr == 0) return CSN_OK;
+      LAUNCH_TRY(csn_launch_dw(a, c.stream));
+    } break;
+    case CSN_UNIT_GOCT: {
+      // optional 2x2 avg-pool prologue of every input branch (csnet.py:679-680)
+      const float* xin[3] = {nullptr, nullptr, nullptr};
+      if (d.stride == 2) {
+        PoolArgs pa;
+        pa.n = 0;
+        int blk = 0;
+        for (int i = 0; i < d.n_in; ++i) {
+          if (d.cin[i] == 0) continue;
+          const int k = pa.n++;
+          pa.in[k] = c.act_in(d.in_act[i]);
+          pa.out[k] = reinterpret_cast<float*>(c.ws + u.pooled_off[i]);
+          xin[i] = pa.out[k];
+          pa.planes[k] = S * d.cin[i];
+          pa.Ho[k] = P.H >> (u.base_lvl + i); pa.Wo[k] = P.W >> (u.base_lvl + i);
+          const int64_t lanes = (int64_t)pa.planes[k] * pa.Ho[k] * ((pa.Wo[k] + 1) / 2);
+          blk += (int)((lanes + CSN_BLOCK - 1) / CSN_BLOCK);
+          pa.blk_end[k] = blk;
+        }
+        LAUNCH_TRY(csn_launch_pool(pa, c.stream));
+      } else {
+        for (int i = 0; i < d.n_in; ++i)
+          if (d.cin[i] > 0) xin[i] = c.act_in(d.in_act[i]);
+      }
+      if (d.ksize == 1) {
+        PwArgs a;
+        a.npass = (int)u.pw.size(); a.nz_pass = u.pw_nz; a.top_ppl2 = u.top_ppl2;
+        a.H0 = P.H >> u.base_lvl; a.W0 = P.W >> u.base_lvl; a.B = S;
+        for (int q = 0; q < a.npass; ++q) {
+          const PwPassPlan& pp = u.pw[q];
+          PwPass& ps = a.pass[q];
+          ps.r = pp.r; ps.nsrc = pp.nsrc;
+          for (int s = 0; s < 3; ++s) {
+            ps.src[s].ptr = (s < pp.nsrc && pp.src_C[s] > 0) ? xin[pp.src_branch[s]] : nullptr;
+            ps.src[s].C = s < pp.nsrc ? pp.src_C[s] : 0;
+            ps.src[s].shift = pp.src_shift[s];
+          }
+          ps.cin4 = pp.cin4; ps.nrows = pp.nrows; ps.w = c.pk(pp.w); ps.dest = pp.dest; ps.z_off = pp.z_off;
+          ps.out = pp.dest ? c.act_out(d.out_act[pp.out_branch]) : nullptr;
+          ps.scale = pp.dest ? c.pk(pp.epi.scale) : nullptr;
+          ps.shift = pp.dest ? c.pk(pp.epi.shift) : nullptr;
+          ps.alpha = pp.dest ? c.pk(pp.epi.alpha) : nullptr;
+          ps.nz = pp.nz;
+          for (int z = 0; z < 2; ++z) { ps.zadd[z].z_off = pp.zadd_off[z]; ps.zadd[z].rs = pp.zadd_rs[z]; }
+        }
+        LAUNCH_TRY(csn_launch_pw(a, u.maxc_top, u.maxc_low, c.stream));
+      } else {
+        for (const C3Plan& cp : u.c3) {
+          C3Args a;
+          a.nsrc = cp.nsrc; a.cin = cp.cin; a.cout = cp.cout; a.w = c.pk(cp.w);
+          for (int s = 0; s < 2; ++s) {
+            a.src[s].ptr = s < cp.nsrc ? xin[cp.src_branch[s]] : nullptr;
+            a.src[s].C = s < cp.nsrc ? cp.src_C[s] : 0;
+            a.src[s].shift = cp.src_shift[s];
+          }
+          a.H = P.H >> (u.base_lvl + cp.res_branch); a.W = P.W >> (u.base_lvl + cp.res_branch); a.B = S;
+          if (cp.to_z) {
+            a.out = reinterpret_cast<float*>(c.ws + u.z_off);
+            a.scale = a.shift = a.alpha = nullptr; a.zadd = nullptr;
+          } else {
+            a.out = c.act_out(d.out_act[cp.out_branch]);
+            a.scale = c.pk(cp.epi.scale); a.shift = c.pk(cp.epi.shift); a.alpha = c.pk(cp.epi.alpha);
+            a.zadd = cp.add_z ? reinterpret_cast<const float*>(c.ws + u.z_off) : nullptr;
+          }
+          LAUNCH_TRY(csn_launch_c3(a, c.stream));
+        }
+      }
+    } break;
+    case CSN_UNIT_MS: {
+      MsArgs a;
+      const Act& act = P.acts[d.in_act[0]];
+      a.in = c.act_in(d.in_act[0]); a.out = c.act_out(d.out_act[0]);
+      int base = 0;
+      for (int k = 0; k < 5; ++k) {
+        a.dch[k] = d.dil_ch[k]; a.cobase[k] = base; base += d.dil_ch[k];
+        a.w[k] = d.dil_ch[k] ? c.pk(u.ms_w[k]) : nullptr;
+      }
+      a.cin = d.cin[0]; a.cout = d.cout[0]; a.H = P.H >> act.lvl; a.W = P.W >> act.lvl; a.B = S;
+      a.scale = c.pk(u.ms_epi.scale); a.shift = c.pk(u.ms_epi.shift); a.alpha = c.pk(u.ms_epi.alpha);
+      LAUNCH_TRY(csn_launch_ms(a, c.stream));
+    } break;
+    case CSN_UNIT_CLS: {
+      PwArgs a;
+      a.npass = 1; a.nz_pass = 0; a.top_ppl2 = u.top_ppl2;
+      a.H0 = P.H >> 1; a.W0 = P.W >> 1; a.B = S;
+      const PwPassPlan& pp = u.pw[0];
+      PwPass& ps = a.pass[0];
+      ps.r = 0; ps.nsrc = 1;
+      ps.src[0].ptr = c.act_in(d.in_act[0]); ps.src[0].C = pp.src_C[0]; ps.src[0].shift = 0;
+      ps.src[1].ptr = ps.src[2].ptr = nullptr; ps.src[1].C = ps.src[2].C = 0; ps.src[1].shift = ps.src[2].shift = 0;
+      ps.cin4 = pp.cin4; ps.nrows = 1; ps.w = c.pk(pp.w); ps.dest = 1; ps.z_off = 0;
+      ps.out = reinterpret_cast<float*>(c.ws + u.logits_off);
+      ps.scale = c.pk(pp.epi.scale); ps.shift = c.pk(pp.epi.shift); ps.alpha = c.pk(pp.epi.alpha);
+      ps.nz = 0;
+      for (int z = 0; z < 2; ++z) { ps.zadd[z].z_off = 0; ps.zadd[z].rs = 0; }
+      LAUNCH_TRY(csn_launch_pw(a, u.maxc_top, u.maxc_low, c.stream));
+      Up2Args ua;
+      ua.in = ps.out; ua.out = c.y; ua.planes = S; ua.H = P.H; ua.W = P.W;
+      LAUNCH_TRY(csn_launch_up2(ua, c.stream));
+    } break;
+    default:
+      return CSN_E_INVALID;
+  }
+  return CSN_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int csn_abi_version(void) { return CSN_ABI_VERSION; }
+
+const char* csn_strerror(int s) {
+  switch (s) {
+    case CSN_OK: return "ok";
+    case CSN_E_INVALID: return "invalid argument or inconsistent unit descriptor";
+    case CSN_E_UNSUPPORTED: return "configuration not supported by this build";
+    case CSN_E_HIP: return "HIP runtime error";
+    case CSN_E_NOMEM: return "out of memory";
+    case CSN_E_STATE: return "call order violated (refresh parameters before forward)";
+    default: return "unknown status";
+  }
+}
+
+const char* csn_last_hip_error(void) { return g_hip_err.c_str(); }
+
+int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_desc* acts, int32_t n_acts,
+                    int32_t B, int32_t H, int32_t W, int32_t sub_batch, csn_plan** out_plan) {
+  if (!units || !acts || !out_plan || n_units <= 0 || n_acts <= 0 || B <= 0) return CSN_E_INVALID;
+  if (H <= 0 || W <= 0 || (H % 16) != 0 || (W % 16) != 0) return CSN_E_INVALID;
+  csn_plan* P = new (std::nothrow) csn_plan();
+  if (!P) return CSN_E_NOMEM;
+  P->B = B; P->H = H; P->W = W;
+  P->S = (sub_batch <= 0 || sub_batch > B) ? B : sub_batch;
+  Builder bl(*P);
+  P->acts.resize(n_acts);
+  for (int i = 0; i < n_acts; ++i) {
+    P->acts[i].channels = acts[i].channels;
+    P->acts[i].lvl = acts[i].lvl;
+    if (acts[i].channels <= 0 || acts[i].lvl < 0 || acts[i].lvl > 4) { delete P; return CSN_E_INVALID; }
+    P->acts[i].ws_off = (i == 0) ? -1 : bl.alloc_ws(bl.act_bytes(acts[i].channels, acts[i].lvl));
+  }
+  P->units.resize(n_units);
+  for (int k = 0; k < n_units; ++k) {
+    UnitPlan& u = P->units[k];
+    u.d = units[k];
+    int st = CSN_E_INVALID;
+    for (int i = 0; i < CSN_MAX_BRANCH; ++i) {
+      if (u.d.in_act[i] >= n_acts || u.d.out_act[i] >= n_acts) { delete P; return CSN_E_INVALID; }
+    }
+    switch (u.d.kind) {
+      case CSN_UNIT_GOCT: st = plan_goct(bl, u); break;
+      case CSN_UNIT_DW: st = plan_dw(bl, u); break;
+      case CSN_UNIT_MS: st = plan_ms(bl, u); break;
+      case CSN_UNIT_CLS: st = plan_cls(bl, u); break;
+      default: st = CSN_E_INVALID;
+    }
+    if (st != CSN_OK) {
+      g_hip_err = "unit " + std::to_string(k) + " (kind " + std::to_string(u.d.kind) + "): " + g_why;
+      delete P;
+      return st;
+    }
+    // algorithmic bytes: unit inputs read once + outputs written once, whole batch
+    int64_t bytes = 0;
+    for (int i = 0; i < u.d.n_in; ++i)
+      if (u.d.cin[i] > 0 && u.d.in_act[i] >= 0) {
+        const Act& a = P->acts[u.d.in_act[i]];
+        bytes += (int64_t)B * a.channels * (H >> a.lvl) * (W >> a.lvl) * 4;
+      }
+    if (u.d.kind == CSN_UNIT_CLS) {
+      bytes += (int64_t)B * H * W * 4;
+    } else {
+      for (int j = 0; j < u.d.n_out; ++j)
+        if (u.d.cout[j] > 0 && u.d.out_act[j] >= 0) {
+          const Act& a = P->acts[u.d.out_act[j]];
+          bytes += (int64_t)B * a.channels * (H >> a.lvl) * (W >> a.lvl) * 4;
+        }
+    }
+    u.alg_bytes = bytes;
+  }
+  if (csn_kernels_init() != 0) { delete P; return CSN_E_HIP; }
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&P->packed), (size_t)(P->packed_floats + 4) * sizeof(float));
+  if (e != hipSuccess) { delete P; hip_fail(e, "hipMalloc(packed)"); return CSN_E_NOMEM; }
+  e = hipMemsetAsync(P->packed, 0, (size_t)(P->packed_floats + 4) * sizeof(float), nullptr);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&P->jobs_dev), P->jobs.size() * sizeof(CsnPrepJob));
+  if (e == hipSuccess)
+    e = hipMemcpy(P->jobs_dev, P->jobs.data(), P->jobs.size() * sizeof(CsnPrepJob), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { hip_fail(e, "plan upload"); csn_plan_destroy(P); return CSN_E_HIP; }
+  *out_plan = P;
+  return CSN_OK;
+}
+
+void csn_plan_destroy(csn_plan* P) {
+  if (!P) return;
+  for (hipEvent_t ev : P->ev) (void)hipEventDestroy(ev);
+  if (P->packed) (void)hipFree(P->packed);
+  if (P->jobs_dev) (void)hipFree(P->jobs_dev);
+  delete P;
+}
+
+size_t csn_plan_workspace_bytes(const csn_plan* P) { return P ? (size_t)P->ws_bytes : 0; }
+int32_t csn_plan_num_units(const csn_plan* P) { return P ? (int32_t)P->units.size() : 0; }
+
+int csn_plan_act_info(const csn_plan* P, int32_t id, csn_act_info* out) {
+  if (!P || !out || id < 0 || id >= (int)P->acts.size()) return CSN_E_INVALID;
+  const Act& a = P->acts[id];
+  out->ws_offset_bytes = a.ws_off;
+  out->channels = a.channels;
+  out->height = P->H >> a.lvl;
+  out->width = P->W >> a.lvl;
+  out->batch = P->S;
+  return CSN_OK;
+}
+
+int csn_plan_refresh_params(csn_plan* P, const float* arena, int64_t arena_floats, void* stream) {
+  if (!P || !arena) return CSN_E_INVALID;
+  for (const CsnPrepJob& j : P->jobs) {
+    const int64_t srcs[4] = {j.src0, j.src1, j.src2, j.src3};
+    for (int64_t s : srcs)
+      if (s >= arena_floats) return CSN_E_INVALID;
+  }
+  LAUNCH_TRY(csn_launch_prep(P->jobs_dev, (int)P->jobs.size(), arena, P->packed, stream));
+  P->params_ready = true;
+  return CSN_OK;
+}
+
+static int forward_impl(csn_plan* P, const float* x, float* y, void* workspace, void* stream, int32_t iters,
+                        float* unit_ms) {
+  if (!P || !x || !y || !workspace) return CSN_E_INVALID;
+  if (!P->params_ready) return CSN_E_STATE;
+  const int nu = (int)P->units.size();
+  const bool prof = unit_ms != nullptr;
+  if (prof) {
+    while ((int)P->ev.size() < nu + 1) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreate(&e));
+      P->ev.push_back(e);
+    }
+    for (int u = 0; u < nu; ++u) unit_ms[u] = 0.f;
+  }
+  const int64_t in_stride = (int64_t)3 * P->H * P->W, out_stride = (int64_t)P->H * P->W;
+  const int reps = prof ? (iters > 0 ? iters : 1) : 1;
+  for (int it = 0; it < reps; ++it) {
+    for (int b0 = 0; b0 < P->B; b0 += P->S) {
+      // the last slice may overlap the previous one when S does not divide B (same results, written twice)
+      const int start = (b0 + P->S <= P->B) ? b0 : P->B - P->S;
+      Ctx c{*P, x + start * in_stride, y + start * out_stride, static_cast<char*>(workspace), stream};
+      if (prof) HIP_TRY(hipEventRecord(P->ev[0], (hipStream_t)stream));
+      for (int u = 0; u < nu; ++u) {
+        const int st = run_unit(c, P->units[u]);
+        if (st != CSN_OK) return st;
+        if (prof) HIP_TRY(hipEventRecord(P->ev[u + 1], (hipStream_t)stream));
+      }
+      if (prof) {
+        HIP_TRY(hipEventSynchronize(P->ev[nu]));
+        for (int u = 0; u < nu; ++u) {
+          float ms = 0.f;
+          HIP_TRY(hipEventElapsedTime(&ms, P->ev[u], P->ev[u + 1]));
+          unit_ms[u] += ms;
+        }
+      }
+    }
+  }
+  if (prof)
+    for (int u = 0; u < nu; ++u) unit_ms[u] /= (float)reps;
+  return CSN_OK;
+}
+
+int csn_forward(csn_plan* P, const float* x, float* y, void* workspace, void* stream) {
+  return forward_impl(P, x, y, workspace, stream, 1, nullptr);
+}
+
+int csn_forward_profile(csn_plan* P, const float* x, float* y, void* workspace, void* stream, int32_t iters,
+                        float* unit_ms) {
+  if (!unit_ms) return CSN_E_INVALID;
+  return forward_impl(P, x, y, workspace, stream, iters, unit_ms);
+}
+
+const char* csn_unit_kernel_name(const csn_plan* P, int32_t u) {
+  if (!P || u < 0 || u >= (int)P->units.size()) return "";
+  return P->units[u].kname;
+}
+
+int64_t csn_unit_algorithmic_bytes(const csn_plan* P, int32_t u) {
+  if (!P || u < 0 || u >= (int)P->units.size()) return 0;
+  return P->units[u].alg_bytes;
+}
+
+}  // extern "C"

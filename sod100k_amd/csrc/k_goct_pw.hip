@@ -1,0 +1,295 @@
+// k_goct_pw.hip -- gOctConv with 1x1 kernels + BN + PReLU, ALL output branches of a unit per block.
+//
+// Reference semantics (CSNet/model/csnet.py):
+//   gOctaveConv.forward 664-726:  y_j = sum_i T_ij(x_i), weight block W[co_j, ci_i];
+//       i == j : conv(x_i)                                     (716-717)
+//       i >  j : bilinear_up_{2^(i-j)}( conv(x_i) )            (702-707)  "low -> high"
+//       i <  j : conv( max_pool_{2^(j-i)}(x_i) )               (708-714)  "high -> low"
+//   gOctaveCBR.forward 778-792:   PReLU_j(BN_j(y_j)) per output branch (eval BN folded to scale/shift)
+//   also used for cls_layer (1x1 + bias, csnet.py:306-308,381) with scale=1, shift=bias, alpha=1.
+//
+// MI355X mapping.  A block owns a 16x32 tile of branch 0 and the matching 8x16 / 4x8 tiles of
+// branches 1 / 2.  Work is a short list of *passes*; a pass walks the pixels of one branch, gathers
+// the input channels of that pixel into VGPRs exactly once (own-resolution channels plus channels
+// max-pooled on the fly from the higher-resolution inputs), and then produces output rows one pair at
+// a time: every row is a dot product of the register-resident inputs with a weight row that the whole
+// wave shares, so weights stream through the scalar cache (s_load) and feed v_fmac as SGPR operands.
+//   z pass   (branch i > 0): rows of the low->high blocks W[co_j, ci_i] evaluated at low resolution
+//            on the tile plus a 1-pixel ring, written to LDS (never to HBM);
+//   main pass (branch j)   : rows of [W_jj | W_ij (i<j, pooled)] + bilinear taps of the LDS z regions
+//            (i>j) -> folded BN -> PReLU -> one coalesced store per output channel.
+// Every input element is fetched from HBM once per unit (the high-res input is read by the branch-0
+// pass and again, max-pooled, by the lower pass of the same block -> L2 hit), every output element is
+// written once: algorithmic bytes == HBM bytes.
+#include "csn_kernels.h"
+
+template <int R>
+struct PwTile {
+  static constexpr int TY = PW_TY0 >> R;
+  static constexpr int TX = PW_TX0 >> R;
+  static constexpr int RY = TY + 2;
+  static constexpr int RX = TX + 2;
+  static constexpr int RING = RY * RX;
+};
+
+__device__ __forceinline__ int pw_ring_px(int r) {
+  return ((PW_TY0 >> r) + 2) * ((PW_TX0 >> r) + 2);
+}
+__device__ __forceinline__ int pw_ring_rx(int r) { return (PW_TX0 >> r) + 2; }
+
+// Gather the MAXC-bounded channel vector of pixel (y,x) (branch resolution Hr x Wr) of image b.
+template <int MAXC>
+__device__ __forceinline__ void pw_gather1(const PwPass& ps, int b, int y, int x, int Hr, int Wr,
+                                           float (&v)[MAXC]) {
+  const int c1 = ps.src[0].C;
+  const int c2 = c1 + (ps.nsrc > 1 ? ps.src[1].C : 0);
+  const int c3 = c2 + (ps.nsrc > 2 ? ps.src[2].C : 0);
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    float val = 0.f;
+    if (k < c1) {
+      val = ps.src[0].ptr[(((int64_t)b * c1 + k) * Hr + y) * Wr + x];
+    } else if (k < c3) {
+      const int s = (k < c2) ? 1 : 2;
+      const PwSrc sr = ps.src[s];
+      const int ch = k - (s == 1 ? c1 : c2);
+      const int f = 1 << sr.shift;
+      const int Ws = Wr << sr.shift;
+      const float* __restrict__ p =
+          sr.ptr + (((int64_t)b * sr.C + ch) * (Hr << sr.shift) + (int64_t)y * f) * Ws + x * f;
+      if (sr.shift == 1) {
+        const float2 a0 = *reinterpret_cast<const float2*>(p);
+        const float2 a1 = *reinterpret_cast<const float2*>(p + Ws);
+        val = fmaxf(fmaxf(a0.x, a0.y), fmaxf(a1.x, a1.y));
+      } else {
+        float m = -3.402823466e+38f;
+        for (int yy = 0; yy < 4; ++yy) {
+          const float4 q = *reinterpret_cast<const float4*>(p + (int64_t)yy * Ws);
+          m = fmaxf(m, fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)));
+        }
+        val = m;
+      }
+    }
+    v[k] = val;
+  }
+}
+
+// Two horizontally adjacent pixels (x even) of the own-resolution source only (branch-0 pass).
+template <int MAXC>
+__device__ __forceinline__ void pw_gather2(const PwPass& ps, int b, int y, int x, int Hr, int Wr,
+                                           float (&v0)[MAXC], float (&v1)[MAXC]) {
+  const int c1 = ps.src[0].C;
+  const float* __restrict__ base = ps.src[0].ptr + ((int64_t)b * c1 * Hr + y) * Wr + x;
+  const int64_t cs = (int64_t)Hr * Wr;
+#pragma unroll
+  for (int k = 0; k < MAXC; ++k) {
+    float2 q = make_float2(0.f, 0.f);
+    if (k < c1) q = *reinterpret_cast<const float2*>(base + k * cs);
+    v0[k] = q.x;
+    v1[k] = q.y;
+  }
+}
+
+template <int MAXC>
+__device__ __forceinline__ float pw_dot(const float* __restrict__ wr, int cin4, const float (&v)[MAXC]) {
+  float acc = 0.f;
+#pragma unroll
+  for (int k0 = 0; k0 < MAXC; k0 += 4) {
+    if (k0 < cin4) {
+      acc = fmaf(wr[k0 + 0], v[k0 + 0], acc);
+      acc = fmaf(wr[k0 + 1], v[k0 + 1], acc);
+      acc = fmaf(wr[k0 + 2], v[k0 + 2], acc);
+      acc = fmaf(wr[k0 + 3], v[k0 + 3], acc);
+    }
+  }
+  return acc;
+}
+
+// Bilinear tap set of one destination pixel into an LDS z region of source branch rs.
+struct PwTap {
+  int i00, i01, i10, i11;
+  float w00, w01, w10, w11;
+};
+
+__device__ __forceinline__ PwTap pw_tap(int y, int x, int r, int rs, int H0, int W0, int ty0, int tx0) {
+  const int d = rs - r;
+  const float inv_f = d == 1 ? 0.5f : 0.25f;
+  int y0, y1, x0, x1;
+  float ly, lx;
+  csn_bilin(y, inv_f, H0 >> rs, y0, y1, ly);
+  csn_bilin(x, inv_f, W0 >> rs, x0, x1, lx);
+  const int oy = (ty0 >> rs) - 1, ox = (tx0 >> rs) - 1;  // image coords of ring cell (0,0)
+  const int rx = pw_ring_rx(rs);
+  PwTap t;
+  t.i00 = (y0 - oy) * rx + (x0 - ox);
+  t.i01 = (y0 - oy) * rx + (x1 - ox);
+  t.i10 = (y1 - oy) * rx + (x0 - ox);
+  t.i11 = (y1 - oy) * rx + (x1 - ox);
+  t.w00 = (1.f - ly) * (1.f - lx);
+  t.w01 = (1.f - ly) * lx;
+  t.w10 = ly * (1.f - lx);
+  t.w11 = ly * lx;
+  return t;
+}
+
+__device__ __forceinline__ float pw_tap_eval(const float* __restrict__ z, const PwTap& t) {
+  return t.w00 * z[t.i00] + t.w01 * z[t.i01] + t.w10 * z[t.i10] + t.w11 * z[t.i11];
+}
+
+template <int MAXC_TOP, int MAXC_LOW>
+__global__ __launch_bounds__(CSN_BLOCK) void goct_pw_kernel(PwArgs a) {
+  CSN_DYN_SMEM(float, lds);
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z;
+  const int ty0 = blockIdx.y * PW_TY0, tx0 = blockIdx.x * PW_TX0;  // tile origin at branch 0
+  const int H0 = a.H0, W0 = a.W0;
+
+  // ---- z passes: low->high partial sums at low resolution, tile + ring, into LDS ----
+  for (int pi = 0; pi < a.nz_pass; ++pi) {
+    const PwPass& ps = a.pass[pi];
+    const int r = ps.r;
+    const int Hr = H0 >> r, Wr = W0 >> r;
+    const int rx = pw_ring_rx(r), npx = pw_ring_px(r);
+    const int oy = (ty0 >> r) - 1, ox = (tx0 >> r) - 1;
+    for (int p = tid; p < npx; p += CSN_BLOCK) {
+      const int py = p / rx, px = p - py * rx;
+      const int y = oy + py, x = ox + px;
+      if (y < 0 || y >= Hr || x < 0 || x >= Wr) continue;  // never sampled (indices are clamped)
+      float v[MAXC_LOW];
+      pw_gather1<MAXC_LOW>(ps, b, y, x, Hr, Wr, v);
+      float* __restrict__ zp = lds + ps.z_off + p;
+      for (int row = 0; row < ps.nrows; ++row)
+        zp[row * npx] = pw_dot<MAXC_LOW>(ps.w + (int64_t)row * ps.cin4, ps.cin4, v);
+    }
+  }
+  if (a.nz_pass > 0) __syncthreads();
+
+  // ---- main passes, one pixel per lane (all branches below 0; branch 0 too when !a.top_ppl2) ----
+  const int n_low = a.top_ppl2 ? a.npass - 1 : a.npass;
+  for (int pi = a.nz_pass; pi < n_low; ++pi) {
+    const PwPass& ps = a.pass[pi];
+    const int r = ps.r;
+    const int Hr = H0 >> r, Wr = W0 >> r;
+    const int tx = PW_TX0 >> r, npx = (PW_TY0 >> r) * tx;
+    for (int p = tid; p < npx; p += CSN_BLOCK) {
+      const int py = p / tx, px = p - py * tx;
+      const int y = (ty0 >> r) + py, x = (tx0 >> r) + px;
+      if (y >= Hr || x >= Wr) continue;
+      float v[MAXC_LOW];
+      pw_gather1<MAXC_LOW>(ps, b, y, x, Hr, Wr, v);
+      PwTap tap0, tap1;
+      int zs0 = 0, zs1 = 0;
+      if (ps.nz > 0) { tap0 = pw_tap(y, x, r, ps.zadd[0].rs, H0, W0, ty0, tx0); zs0 = pw_ring_px(ps.zadd[0].rs); }
+      if (ps.nz > 1) { tap1 = pw_tap(y, x, r, ps.zadd[1].rs, H0, W0, ty0, tx0); zs1 = pw_ring_px(ps.zadd[1].rs); }
+      float* __restrict__ op = ps.out + ((int64_t)b * ps.nrows * Hr + y) * Wr + x;
+      const int64_t cs = (int64_t)Hr * Wr;
+      for (int row = 0; row < ps.nrows; ++row) {
+        float acc = pw_dot<MAXC_LOW>(ps.w + (int64_t)row * ps.cin4, ps.cin4, v);
+        if (ps.nz > 0) acc += pw_tap_eval(lds + ps.zadd[0].z_off + row * zs0, tap0);
+        if (ps.nz > 1) acc += pw_tap_eval(lds + ps.zadd[1].z_off + row * zs1, tap1);
+        op[row * cs] = csn_epi(acc, ps.scale[row], ps.shift[row], ps.alpha[row]);
+      }
+    }
+  }
+
+  // ---- main pass of branch 0: two pixels per lane (float2 loads / stores) ----
+  if (a.top_ppl2) {
+    const PwPass& ps = a.pass[a.npass - 1];
+    constexpr int LXN = PW_TX0 / 2;
+    const int py = tid / LXN, px = (tid - py * LXN) * 2;
+    const int y = ty0 + py, x = tx0 + px;
+    if (y < H0 && x < W0) {
+      float v0[MAXC_TOP], v1[MAXC_TOP];
+      pw_gather2<MAXC_TOP>(ps, b, y, x, H0, W0, v0, v1);
+      PwTap ta0, tb0, ta1, tb1;
+      int zs0 = 0, zs1 = 0;
+      if (ps.nz > 0) {
+        ta0 = pw_tap(y, x, 0, ps.zadd[0].rs, H0, W0, ty0, tx0);
+        tb0 = pw_tap(y, x + 1, 0, ps.zadd[0].rs, H0, W0, ty0, tx0);
+        zs0 = pw_ring_px(ps.zadd[0].rs);
+      }
+      if (ps.nz > 1) {
+        ta1 = pw_tap(y, x, 0, ps.zadd[1].rs, H0, W0, ty0, tx0);
+        tb1 = pw_tap(y, x + 1, 0, ps.zadd[1].rs, H0, W0, ty0, tx0);
+        zs1 = pw_ring_px(ps.zadd[1].rs);
+      }
+      float* __restrict__ op = ps.out + ((int64_t)b * ps.nrows * H0 + y) * W0 + x;
+      const int64_t cs = (int64_t)H0 * W0;
+      for (int row = 0; row < ps.nrows; ++row) {
+        const float* __restrict__ wr = ps.w + (int64_t)row * ps.cin4;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int k0 = 0; k0 < MAXC_TOP; k0 += 4) {
+          if (k0 < ps.cin4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const float w = wr[k0 + u];
+              a0 = fmaf(w, v0[k0 + u], a0);
+              a1 = fmaf(w, v1[k0 + u], a1);
+            }
+          }
+        }
+        if (ps.nz > 0) {
+          const float* __restrict__ z = lds + ps.zadd[0].z_off + row * zs0;
+          a0 += pw_tap_eval(z, ta0);
+          a1 += pw_tap_eval(z, tb0);
+        }
+        if (ps.nz > 1) {
+          const float* __restrict__ z = lds + ps.zadd[1].z_off + row * zs1;
+          a0 += pw_tap_eval(z, ta1);
+          a1 += pw_tap_eval(z, tb1);
+        }
+        const float sc = ps.scale[row], sh = ps.shift[row], al = ps.alpha[row];
+        *reinterpret_cast<float2*>(op + row * cs) = make_float2(csn_epi(a0, sc, sh, al), csn_epi(a1, sc, sh, al));
+      }
+    }
+  }
+}
+
+size_t csn_pw_lds_bytes(const PwArgs& a) {
+  size_t fl = 0;
+  for (int pi = 0; pi < a.nz_pass; ++pi) {
+    const PwPass& ps = a.pass[pi];
+    const size_t ring = (size_t)((PW_TY0 >> ps.r) + 2) * ((PW_TX0 >> ps.r) + 2);
+    const size_t end = (size_t)ps.z_off + ring * ps.nrows;
+    if (end > fl) fl = end;
+  }
+  return fl * sizeof(float);
+}
+
+#ifdef CSN_CPU_EMU
+#define PW_ATTR(T, L)
+#else
+// instantiations that need more than the default 64 KiB of dynamic LDS (fuse1x1: 79 rows x (180+60) ring
+// cells) are allowed the full 160 KiB of a CDNA4 CU; set once per instantiation
+#define PW_ATTR(T, L)                                                                             \
+  {                                                                                               \
+    static bool done = false;                                                                     \
+    if (!done && lds > 64 * 1024) {                                                               \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&goct_pw_kernel<T, L>),    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      if (e != hipSuccess) return (int)e;                                                         \
+      done = true;                                                                                \
+    }                                                                                             \
+  }
+#endif
+#define PW_CASE(T, L)                                                                             \
+  if (maxc_top == T && maxc_low == L) {                                                           \
+    PW_ATTR(T, L)                                                                                 \
+    CSN_LAUNCH((goct_pw_kernel<T, L>), grid, dim3(CSN_BLOCK), lds, stream, a);                    \
+    return (int)hipGetLastError();                                                                \
+  }
+
+// maxc_top in {16, 32, 64, 80} (4: branch 0 handled by the one-pixel-per-lane path, !top_ppl2);
+// maxc_low in {32, 64, 96, 160} (4: unit without lower branches)
+int csn_launch_pw(const PwArgs& a, int maxc_top, int maxc_low, void* stream) {
+  const dim3 grid((a.W0 + PW_TX0 - 1) / PW_TX0, (a.H0 + PW_TY0 - 1) / PW_TY0, a.B);
+  const size_t lds = csn_pw_lds_bytes(a);
+  PW_CASE(16, 4) PW_CASE(32, 4) PW_CASE(64, 4) PW_CASE(80, 4)
+  PW_CASE(4, 32) PW_CASE(4, 64) PW_CASE(4, 96) PW_CASE(4, 160)
+  PW_CASE(16, 32) PW_CASE(32, 32) PW_CASE(64, 32)
+  PW_CASE(16, 64) PW_CASE(32, 64) PW_CASE(64, 64) PW_CASE(80, 64)
+  PW_CASE(16, 96) PW_CASE(32, 96) PW_CASE(64, 96) PW_CASE(80, 96)
+  PW_CASE(16, 160) PW_CASE(32, 160) PW_CASE(64, 160) PW_CASE(80, 160)
+  return -1;
+}

@@ -1,0 +1,225 @@
+// k_misc.hip -- parameter packing, depthwise 3x3+BN+PReLU, 2x2 avg-pool, final bilinear x2.
+//
+// Reference semantics:
+//   depthwise unit   SimplifiedGOctConvBR.forward  CSNet/model/csnet.py:838-851
+//                    (Conv2dX100: conv2d(x, 100.0*w), CSNet/model/conv2d.py:104; BN eval; PReLU)
+//   avg-pool 2x2/2   gOctaveConv stride==2 prologue  csnet.py:679-680
+//   bilinear         F.interpolate(size=x.size()[2:], 'bilinear', align_corners=False)  csnet.py:382-385
+#include "csn_kernels.h"
+
+// ------------------------------------------------------------------------------------------ prep
+__global__ __launch_bounds__(CSN_BLOCK) void csn_prep_kernel(const CsnPrepJob* __restrict__ jobs,
+                                                              const float* __restrict__ arena,
+                                                              float* __restrict__ packed) {
+  const CsnPrepJob j = jobs[blockIdx.x];
+  const int tid = threadIdx.x;
+  float* dst = packed + j.dst;
+  const float eps = 1e-5f;  // nn.BatchNorm2d default
+  switch (j.kind) {
+    case CSN_PREP_COPY:
+      for (int i = tid; i < j.n; i += CSN_BLOCK) dst[i] = j.p0f * arena[j.src0 + i];
+      break;
+    case CSN_PREP_FILL:
+      for (int i = tid; i < j.n; i += CSN_BLOCK) dst[i] = j.p0f;
+      break;
+    case CSN_PREP_BN_SCALE:
+      for (int i = tid; i < j.n; i += CSN_BLOCK)
+        dst[i] = arena[j.src0 + i] / sqrtf(arena[j.src1 + i] + eps);
+      break;
+    case CSN_PREP_BN_SHIFT:
+      for (int i = tid; i < j.n; i += CSN_BLOCK) {
+        const float sc = arena[j.src0 + i] / sqrtf(arena[j.src1 + i] + eps);
+        dst[i] = arena[j.src2 + i] - arena[j.src3 + i] * sc;
+      }
+      break;
+    case CSN_PREP_ROWS: {
+      const int ncol = j.p1;
+      const int tot = j.n * ncol;
+      for (int i = tid; i < tot; i += CSN_BLOCK) {
+        const int r = i / ncol, c = i - r * ncol;
+        dst[(int64_t)r * j.p2 + j.p3 + c] = j.p0f * arena[j.src0 + (int64_t)r * j.p0 + c];
+      }
+    } break;
+    case CSN_PREP_C3: {
+      const int ncol = j.p1;
+      const int tot = j.n * ncol * 9;
+      for (int i = tid; i < tot; i += CSN_BLOCK) {
+        const int t = i % 9;
+        const int rc = i / 9;
+        const int ci = rc % ncol, co = rc / ncol;
+        dst[((int64_t)(co >> 3) * j.p2 + j.p3 + ci) * 72 + t * 8 + (co & 7)] =
+            j.p0f * arena[j.src0 + ((int64_t)co * j.p0 + ci) * 9 + t];
+      }
+    } break;
+    default:
+      break;
+  }
+}
+
+int csn_launch_prep(const CsnPrepJob* jobs_dev, int njobs, const float* arena, float* packed, void* stream) {
+  if (njobs <= 0) return 0;
+  CSN_LAUNCH(csn_prep_kernel, dim3(njobs), dim3(CSN_BLOCK), 0, stream, jobs_dev, arena, packed);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------- depthwise
+// One block = one (image, channel) plane tile of LX*4 columns x NY*R rows.  A lane owns a 4-wide
+// column strip and walks R rows with a rolling 3-row register window, so every input row is loaded
+// once per lane (float4 + the two edge scalars); the vertical halo between tiles hits L2.
+struct DwRow {
+  float v[6];  // [0]=x0-1, [1..4]=x0..x0+3, [5]=x0+4
+};
+
+__device__ __forceinline__ DwRow dw_load_row(const float* __restrict__ plane, int y, int x0, int H, int W,
+                                             bool vec) {
+  DwRow r;
+  if (y < 0 || y >= H) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) r.v[i] = 0.f;
+    return r;
+  }
+  const float* p = plane + (int64_t)y * W;
+  if (vec && x0 + 3 < W) {
+    const float4 c = *reinterpret_cast<const float4*>(p + x0);
+    r.v[1] = c.x; r.v[2] = c.y; r.v[3] = c.z; r.v[4] = c.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[1 + i] = (x0 + i < W) ? p[x0 + i] : 0.f;
+  }
+  r.v[0] = (x0 > 0) ? p[x0 - 1] : 0.f;
+  r.v[5] = (x0 + 4 < W) ? p[x0 + 4] : 0.f;
+  return r;
+}
+
+__global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
+  int bid = blockIdx.x;
+  int k = 0;
+  if (a.nbr > 1 && bid >= a.br[0].blk_end) k = 1;
+  if (a.nbr > 2 && bid >= a.br[1].blk_end) k = 2;
+  const DwBranch br = a.br[k];
+  if (k > 0) bid -= a.br[k - 1].blk_end;
+  const int tiles = br.tiles_x * br.tiles_y;
+  const int tile = bid % tiles;
+  const int pc = bid / tiles;  // b*C + c
+  const int c = pc % br.C;
+  const int tx = tile % br.tiles_x, ty = tile / br.tiles_x;
+  const int tid = threadIdx.x;
+  const int lx = tid % br.LX, ly = tid / br.LX;
+  if (ly >= br.NY) return;
+  const int H = br.H, W = br.W;
+  const int x0 = (tx * br.LX + lx) * 4;
+  const int y0 = (ty * br.NY + ly) * br.R;
+  if (x0 >= W || y0 >= H) return;
+  const bool vec = (W & 3) == 0;
+  const float* __restrict__ ip = br.in + (int64_t)pc * H * W;
+  float* __restrict__ op = br.out + (int64_t)pc * H * W;
+  float w[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) w[i] = br.w9[c * 9 + i];
+  const float sc = br.scale[c], sh = br.shift[c], al = br.alpha[c];
+
+  DwRow top = dw_load_row(ip, y0 - 1, x0, H, W, vec);
+  DwRow mid = dw_load_row(ip, y0, x0, H, W, vec);
+  const int yend = min(y0 + br.R, H);
+  for (int y = y0; y < yend; ++y) {
+    const DwRow bot = dw_load_row(ip, y + 1, x0, H, W, vec);
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float acc = w[0] * top.v[j];
+      acc = fmaf(w[1], top.v[j + 1], acc);
+      acc = fmaf(w[2], top.v[j + 2], acc);
+      acc = fmaf(w[3], mid.v[j], acc);
+      acc = fmaf(w[4], mid.v[j + 1], acc);
+      acc = fmaf(w[5], mid.v[j + 2], acc);
+      acc = fmaf(w[6], bot.v[j], acc);
+      acc = fmaf(w[7], bot.v[j + 1], acc);
+      acc = fmaf(w[8], bot.v[j + 2], acc);
+      o[j] = csn_epi(acc, sc, sh, al);
+    }
+    float* q = op + (int64_t)y * W + x0;
+    if (vec && x0 + 3 < W) {
+      *reinterpret_cast<float4*>(q) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (x0 + j < W) q[j] = o[j];
+    }
+    top = mid;
+    mid = bot;
+  }
+}
+
+int csn_launch_dw(const DwArgs& a, void* stream) {
+  const int nblk = a.br[a.nbr - 1].blk_end;
+  if (nblk <= 0) return 0;
+  CSN_LAUNCH(dw3x3_bn_prelu_kernel, dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------- avg-pool
+// out[y][x] = mean of the 2x2 input window.  A lane produces 2 output pixels from two float4 loads.
+__global__ __launch_bounds__(CSN_BLOCK) void avgpool2_kernel(PoolArgs a) {
+  int bid = blockIdx.x;
+  int k = 0;
+  if (a.n > 1 && bid >= a.blk_end[0]) k = 1;
+  if (a.n > 2 && bid >= a.blk_end[1]) k = 2;
+  if (k > 0) bid -= a.blk_end[k - 1];
+  const int Ho = a.Ho[k], Wo = a.Wo[k];
+  const int Wp = (Wo + 1) >> 1;  // lane columns (2 outputs each)
+  const int64_t per_plane = (int64_t)Ho * Wp;
+  const int64_t total = per_plane * a.planes[k];
+  const int64_t idx = (int64_t)bid * CSN_BLOCK + threadIdx.x;
+  if (idx >= total) return;
+  const int plane = (int)(idx / per_plane);
+  const int rem = (int)(idx - (int64_t)plane * per_plane);
+  const int y = rem / Wp, xp = rem - y * Wp;
+  const int Wi = Wo * 2;
+  const float* __restrict__ ip = a.in[k] + ((int64_t)plane * Ho * 2 + 2 * y) * Wi + 4 * xp;
+  float* __restrict__ op = a.out[k] + ((int64_t)plane * Ho + y) * Wo + 2 * xp;
+  if ((Wo & 1) == 0) {
+    const float4 r0 = *reinterpret_cast<const float4*>(ip);
+    const float4 r1 = *reinterpret_cast<const float4*>(ip + Wi);
+    float2 o;
+    o.x = (r0.x + r0.y + r1.x + r1.y) * 0.25f;
+    o.y = (r0.z + r0.w + r1.z + r1.w) * 0.25f;
+    *reinterpret_cast<float2*>(op) = o;
+  } else {
+    op[0] = (ip[0] + ip[1] + ip[Wi] + ip[Wi + 1]) * 0.25f;
+    if (2 * xp + 1 < Wo) op[1] = (ip[2] + ip[3] + ip[Wi + 2] + ip[Wi + 3]) * 0.25f;
+  }
+}
+
+int csn_launch_pool(const PoolArgs& a, void* stream) {
+  const int nblk = a.blk_end[a.n - 1];
+  if (nblk <= 0) return 0;
+  CSN_LAUNCH(avgpool2_kernel, dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ final bilinear x2
+__global__ __launch_bounds__(CSN_BLOCK) void bilinear_up2_kernel(Up2Args a) {
+  const int H = a.H, W = a.W, Hi = H >> 1, Wi = W >> 1;
+  const int64_t idx = (int64_t)blockIdx.x * CSN_BLOCK + threadIdx.x;
+  const int64_t total = (int64_t)a.planes * H * W;
+  if (idx >= total) return;
+  const int x = (int)(idx % W);
+  const int y = (int)((idx / W) % H);
+  const int plane = (int)(idx / ((int64_t)W * H));
+  int y0, y1, x0, x1;
+  float ly, lx;
+  csn_bilin(y, 0.5f, Hi, y0, y1, ly);
+  csn_bilin(x, 0.5f, Wi, x0, x1, lx);
+  const float* __restrict__ p = a.in + (int64_t)plane * Hi * Wi;
+  const float v0 = (1.f - lx) * p[y0 * Wi + x0] + lx * p[y0 * Wi + x1];
+  const float v1 = (1.f - lx) * p[y1 * Wi + x0] + lx * p[y1 * Wi + x1];
+  a.out[idx] = (1.f - ly) * v0 + ly * v1;
+}
+
+int csn_launch_up2(const Up2Args& a, void* stream) {
+  const int64_t total = (int64_t)a.planes * a.H * a.W;
+  const int nblk = (int)((total + CSN_BLOCK - 1) / CSN_BLOCK);
+  if (nblk <= 0) return 0;
+  CSN_LAUNCH(bilinear_up2_kernel, dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,153 @@
+"""Host-side runtime around the C ABI: flat parameter arena, plan cache, workspace, launches.
+
+PyTorch is used here for device memory and streams only (``tensor.data_ptr()``,
+``torch.cuda.current_stream()``); all arithmetic happens in libcsnet_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _native as N
+
+
+def _align4(n: int) -> int:
+    return (n + 3) & ~3
+
+
+class ParamArena:
+    """All float parameters and BN running buffers of a module in ONE contiguous fp32 tensor.
+
+    ``param.data`` / buffers become views into the arena, so ``load_state_dict``, optimizers and
+    ``state_dict`` keep working on the reference's names while the kernels (and, for training, the RCCL
+    gradient all-reduce) see a single flat buffer.  Offsets are in floats.
+    """
+
+    def __init__(self, module: nn.Module):
+        self.module = module
+        self.offsets: Dict[str, int] = {}
+        self.flat: Optional[torch.Tensor] = None
+        self.n_param_floats = 0
+        self.rebuild()
+
+    def rebuild(self) -> None:
+        items: List[Tuple[str, torch.Tensor, object, str, bool]] = []
+        for mname, mod in self.module.named_modules():
+            for pname, p in mod._parameters.items():
+                if p is not None:
+                    items.append((f"{mname}.{pname}" if mname else pname, p, mod, pname, True))
+        n_params = len(items)
+        for mname, mod in self.module.named_modules():
+            for bname, b in mod._buffers.items():
+                if b is not None and b.is_floating_point():
+                    items.append((f"{mname}.{bname}" if mname else bname, b, mod, bname, False))
+        if not items:
+            raise ValueError("module has no parameters")
+        dev = items[0][1].device
+        total = 0
+        offs = []
+        for k, (_, t, _, _, _) in enumerate(items):
+            if k == n_params:
+                self.n_param_floats = total
+            offs.append(total)
+            total += _align4(t.numel())
+        if n_params == len(items):
+            self.n_param_floats = total
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.offsets = {}
+        with torch.no_grad():
+            for (name, t, mod, key, is_param), off in zip(items, offs):
+                view = flat[off:off + t.numel()].view(t.shape)
+                view.copy_(t.detach().to(torch.float32))
+                if is_param:
+                    t.data = view
+                else:
+                    mod._buffers[key] = view
+                self.offsets[name] = off
+        self.flat = flat
+
+    def is_current(self) -> bool:
+        """True if the module's tensors still alias the arena (``.cuda()``/``.to()`` break the views)."""
+        flat = self.flat
+        if flat is None:
+            return False
+        base = flat.data_ptr()
+        for mname, mod in self.module.named_modules():
+            for pname, p in mod._parameters.items():
+                if p is None:
+                    continue
+                name = f"{mname}.{pname}" if mname else pname
+                if p.device != flat.device or p.data_ptr() != base + 4 * self.offsets.get(name, -1):
+                    return False
+        return True
+
+
+class Engine:
+    """One compiled plan (fixed B, H, W) + its workspace."""
+
+    def __init__(self, lib: C.CDLL, units: Sequence[N.UnitDesc], acts: Sequence[Tuple[int, int]],
+                 B: int, H: int, W: int, device: torch.device, sub_batch: int = 0,
+                 unit_names: Optional[Sequence[str]] = None):
+        self.lib = lib
+        self.B, self.H, self.W = B, H, W
+        self.device = device
+        self.unit_names = list(unit_names) if unit_names is not None else [str(i) for i in range(len(units))]
+        ua = (N.UnitDesc * len(units))(*units)
+        aa = (N.ActDesc * len(acts))(*[N.ActDesc(c, l) for c, l in acts])
+        plan = C.c_void_p()
+        N.check(lib, lib.csn_plan_create(ua, len(units), aa, len(acts), B, H, W, sub_batch, C.byref(plan)),
+                "csn_plan_create")
+        self.plan = plan
+        self.n_units = len(units)
+        self.n_acts = len(acts)
+        nbytes = int(lib.csn_plan_workspace_bytes(plan))
+        self.workspace = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
+
+    def __del__(self):
+        plan = getattr(self, "plan", None)
+        if plan is not None and plan.value:
+            self.lib.csn_plan_destroy(plan)
+            self.plan = None
+
+    def _stream(self) -> int:
+        if self.device.type == "cuda":
+            return torch.cuda.current_stream(self.device).cuda_stream
+        return 0
+
+    def refresh(self, arena: torch.Tensor) -> None:
+        assert arena.dtype == torch.float32 and arena.is_contiguous() and arena.device == self.workspace.device
+        N.check(self.lib, self.lib.csn_plan_refresh_params(self.plan, arena.data_ptr(), arena.numel(),
+                                                           self._stream()), "csn_plan_refresh_params")
+
+    def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        assert x.dtype == torch.float32 and x.shape == (self.B, 3, self.H, self.W), (x.shape, x.dtype)
+        x = x.contiguous()
+        y = out if out is not None else torch.empty((self.B, 1, self.H, self.W), dtype=torch.float32, device=x.device)
+        N.check(self.lib, self.lib.csn_forward(self.plan, x.data_ptr(), y.data_ptr(), self.workspace.data_ptr(),
+                                               self._stream()), "csn_forward")
+        return y
+
+    def profile(self, x: torch.Tensor, iters: int = 10):
+        """Mean milliseconds per unit (HIP events on the launch stream), kernel names, algorithmic bytes."""
+        y = torch.empty((self.B, 1, self.H, self.W), dtype=torch.float32, device=x.device)
+        ms = (C.c_float * self.n_units)()
+        N.check(self.lib, self.lib.csn_forward_profile(self.plan, x.contiguous().data_ptr(), y.data_ptr(),
+                                                       self.workspace.data_ptr(), self._stream(), iters, ms),
+                "csn_forward_profile")
+        names = [self.lib.csn_unit_kernel_name(self.plan, u).decode() for u in range(self.n_units)]
+        nbytes = [int(self.lib.csn_unit_algorithmic_bytes(self.plan, u)) for u in range(self.n_units)]
+        return list(ms), names, nbytes
+
+    def activation(self, act_id: int) -> torch.Tensor:
+        """View of an internal activation of the LAST processed batch slice (debug / parity probes)."""
+        info = N.ActInfo()
+        N.check(self.lib, self.lib.csn_plan_act_info(self.plan, act_id, C.byref(info)), "csn_plan_act_info")
+        if info.ws_offset_bytes < 0:
+            raise ValueError("activation 0 is the caller's input tensor")
+        n = info.batch * info.channels * info.height * info.width
+        off = info.ws_offset_bytes
+        return self.workspace[off:off + 4 * n].view(torch.float32).view(info.batch, info.channels, info.height,
+                                                                         info.width)

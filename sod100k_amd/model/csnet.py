@@ -1,0 +1,568 @@
+"""Drop-in ``model.csnet`` for the MI355X-native CSNet engine.
+
+Mirrors the public surface of the reference module (CSNet/model/csnet.py; training copy
+CSNet_training/model/csnet.py): ``build_model``, ``CSNet``, ``ILBlock``, ``gOctaveCBR``, ``gOctaveConv``,
+``SimplifiedGOctConvBR``, ``CSFHead``, ``PallMSBlock``, ``MSBlock``, ``init_layers``,
+``load_layer_config``, ``save_layer_config``, ``Oct_bn_hook``.  The module tree, parameter names,
+shapes, dtypes and default initialisers are the reference's (checked key-for-key against the 737-key
+manifest in tests/golden/g6_simplesum_keys.json), so ``load_state_dict(strict=True)``, optimizers that
+pattern-match parameter names (train.py:101-107) and ``isinstance`` walks (train.py:320-330) keep working.
+
+What differs is WHO computes: the sub-modules are parameter containers and ``CSNet.forward`` hands the
+whole network to one fused plan of hand-written HIP kernels (libcsnet_hip.so, include/csnet_hip.h).
+There is no PyTorch / CPU fallback: a missing library or a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import pickle
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn import init
+
+from .conv2d import Conv2dX100
+from .. import _native as N
+from ..engine import Engine, ParamArena
+
+DILATIONS = (1, 2, 4, 8, 16)      # csnet.py:121
+
+
+def _split_fractions(split):
+    """``alpha = split / int(round(sum(split)))`` as python floats (csnet.py:26-31, 157-165)."""
+    split = np.asarray(split)
+    total = int(round(float(np.sum(split))))
+    return (split * 1.0 / total).tolist(), total
+
+
+def _cumulative(alphas: Sequence[float]) -> List[float]:
+    cum, run = [0], 0
+    for a in alphas:
+        run += a
+        cum.append(run)
+    return cum
+
+
+def _container_forward(self, *args, **kwargs):
+    raise RuntimeError(f"{type(self).__name__} is a parameter container in sod100k_amd; the fused HIP plan behind "
+                       "CSNet.forward executes it (there is no per-layer PyTorch path).")
+
+
+class gOctaveConv(nn.Module):
+    """Weight holder of the generalized OctConv (csnet.py:604-726): one ``[Cout, Cin/groups, k, k]`` tensor
+    block-partitioned ``[out-branch j][in-branch i]`` at ``int(round(C * cumsum(alpha)))`` (csnet.py:683-691)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, alpha_in=[0.5, 0.5], alpha_out=[0.5, 0.5],
+                 stride=1, padding=1, dilation=1, groups=1, bias=False, up_kwargs=None):
+        super().__init__()
+        self.stride, self.padding, self.dilation, self.groups = stride, padding, dilation, groups
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = nn.Parameter(torch.empty(out_channels, round(in_channels / groups),
+                                               kernel_size[0], kernel_size[1]))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.alpha_in = _cumulative(alpha_in)
+        self.alpha_out = _cumulative(alpha_out)
+        self.inbranch, self.outbranch = len(alpha_in), len(alpha_out)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = init._calculate_fan_in_and_fan_out(self.weight)
+            init.uniform_(self.bias, -1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in))
+
+    def in_bounds(self):
+        return [int(round(self.in_channels * a / self.groups)) for a in self.alpha_in]
+
+    def out_bounds(self):
+        return [int(round(self.out_channels * a)) for a in self.alpha_out]
+
+    forward = _container_forward
+
+
+class gOctaveCBR(nn.Module):
+    """gOctConv + BatchNorm2d + PReLU per output branch (csnet.py:729-792)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=(3, 3), alpha_in=[0.5, 0.5], alpha_out=[0.5, 0.5],
+                 stride=1, padding=1, dilation=1, groups=1, bias=False, up_kwargs=None, norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = tuple(kernel_size), stride
+        self.std_conv = len(alpha_in) == 1 and len(alpha_out) == 1            # csnet.py:751-754
+        if self.std_conv:
+            self.conv = Conv2dX100(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
+        else:
+            self.conv = gOctaveConv(in_channels, out_channels, kernel_size, alpha_in, alpha_out, stride, padding,
+                                    dilation, groups, bias, up_kwargs)
+        self.bns = nn.ModuleList()
+        self.prelus = nn.ModuleList()
+        for a in alpha_out:
+            c = int(round(out_channels * a))
+            self.bns.append(norm_layer(c) if c != 0 else None)
+            self.prelus.append(nn.PReLU(c) if c != 0 else None)
+        self.outbranch = len(alpha_out)
+        self.alpha_in, self.alpha_out = alpha_in, alpha_out
+        self.all_flops = 0
+        self.baseflop = None
+        self.expandflop = None
+
+    forward = _container_forward
+
+
+class SimplifiedGOctConvBR(nn.Module):
+    """Per-branch depthwise 3x3 (Conv2dX100) + BatchNorm2d + PReLU (csnet.py:795-851)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=(3, 3), alpha=[0.5, 0.5], stride=1, padding=1,
+                 dilation=1, groups=1, bias=False, norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        self.std_conv = False
+        self.convs, self.bns, self.prelus = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        for a in alpha:
+            cin, cout = int(round(in_channels * a)), int(round(out_channels * a))
+            if cin >= 1:
+                self.convs.append(Conv2dX100(cin, cout, kernel_size=(3, 3), groups=cout, padding=padding,
+                                             dilation=dilation, bias=bias))
+                self.bns.append(norm_layer(cout))
+                self.prelus.append(nn.PReLU(cout))
+            else:
+                self.convs.append(None)
+                self.bns.append(None)
+                self.prelus.append(None)
+        self.outbranch = len(alpha)
+        self.all_flops = 0
+        self.baseflop = None
+        self.expandflop = None
+
+    forward = _container_forward
+
+
+class ILBlock(nn.Module):
+    """gOctaveCBR (3x3 when first / stride 2, else 1x1) followed by two depthwise units (csnet.py:17-76)."""
+
+    def __init__(self, inlist, outlist, stride=1, nextstride=1, nextoutlist=None, first=False):
+        super().__init__()
+        alpha_in, ninput = _split_fractions(inlist)
+        alpha_out, noutput = _split_fractions(outlist)
+        self.first = first
+        k = 3 if (first or stride == 2) else 1                                  # csnet.py:33-48
+        self.conv1x1 = gOctaveCBR(ninput, noutput, kernel_size=(k, k), padding=k // 2, alpha_in=alpha_in,
+                                  alpha_out=alpha_out, stride=stride if k == 3 else 1)
+        self.conv3x3_1 = SimplifiedGOctConvBR(noutput, noutput, stride=1, kernel_size=(3, 3), padding=1,
+                                              alpha=alpha_out, groups=noutput)
+        self.conv3x3_2 = SimplifiedGOctConvBR(noutput, noutput, stride=1, kernel_size=(3, 3), padding=1,
+                                              alpha=alpha_out, groups=noutput)
+        self.all_flops = 0
+        self.stride, self.nextstride, self.nextoutlist = stride, nextstride, nextoutlist
+        self.baseflop = None
+        self.expandflop = None
+
+    forward = _container_forward
+
+
+class MSBlock(nn.Module):
+    """Five dilated 3x3 Conv2dX100 (absent when 0 channels) -> cat -> BN -> PReLU (csnet.py:116-149)."""
+
+    def __init__(self, in_channels, out_channels, dil_channels, dilations=[1, 2, 4, 8, 16]):
+        super().__init__()
+        self.dilations = dilations
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.dil_channels = [int(c) for c in dil_channels]
+        self.msconv = nn.ModuleList()
+        self.real_dil_branch = len(dilations)
+        for d, c in zip(dilations, self.dil_channels):
+            self.msconv.append(Conv2dX100(in_channels, c, 3, padding=d, dilation=d, bias=False) if c != 0 else None)
+        self.bn = nn.BatchNorm2d(out_channels)
+        self.prelu = nn.PReLU(out_channels)
+
+    forward = _container_forward
+
+
+class PallMSBlock(nn.Module):
+    """One MSBlock per resolution branch; ``None`` where every dilation has 0 channels (csnet.py:79-113)."""
+
+    def __init__(self, in_channels, out_channels, dil_channels, alpha_in=[0.5, 0.5], alpha_out=[0.5, 0.5],
+                 bias=False, norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        self.std_conv = False
+        self.convs = nn.ModuleList()
+        for i in range(len(alpha_in)):
+            if max(dil_channels[i]) != 0:
+                self.convs.append(MSBlock(int(round(in_channels * alpha_in[i])),
+                                          int(round(out_channels * alpha_out[i])), dil_channels[i]))
+            else:
+                self.convs.append(None)
+        self.outbranch = len(alpha_in)
+
+    forward = _container_forward
+
+
+class CSFHead(nn.Module):
+    """Cross-stage fusion decoder: gOctaveCBR 3->3 (1x1) -> PallMSBlock -> gOctaveCBR 3->1 (csnet.py:152-206)."""
+
+    def __init__(self, fuse_layer_config):
+        super().__init__()
+        self.layer_config = fuse_layer_config
+        in_split, in_ch = _split_fractions(fuse_layer_config[0][0])
+        mid_in_split, mid_in_ch = _split_fractions(fuse_layer_config[1][0])
+        mid_out_split, mid_out_ch = _split_fractions(fuse_layer_config[1][1])
+        dils = fuse_layer_config[1][2]
+        out_ch = int(round(float(np.sum(fuse_layer_config[2][1]))))
+        self.fuse = gOctaveCBR(in_ch, mid_in_ch, kernel_size=(1, 1), padding=0, alpha_in=in_split,
+                               alpha_out=mid_in_split, stride=1)
+        self.ms = PallMSBlock(mid_in_ch, mid_out_ch, alpha_in=mid_in_split, alpha_out=mid_out_split,
+                              dil_channels=dils)
+        self.fuse1x1 = gOctaveCBR(mid_out_ch, out_ch, kernel_size=(1, 1), padding=0, alpha_in=mid_out_split,
+                                  alpha_out=[1], stride=1)
+
+    forward = _container_forward
+
+
+class CSNet(nn.Module):
+    """CSNet (csnet.py:209-387): stage0 (1 ILBlock) + 4 stages + CSF head + 1x1 classifier + bilinear up.
+
+    ``forward(x)``: ``x`` float32 ``B x 3 x H x W`` on a ROCm device (H, W multiples of 16) ->
+    float32 ``B x 1 x H x W`` logits, exactly the reference's tensor contract (csnet.py:365-387).
+    """
+
+    def __init__(self, layer_config, num_classes=1):
+        super().__init__()
+        if num_classes != 1:
+            raise ValueError("sod100k_amd implements the shipped single-class saliency head (num_classes=1)")
+        self.stages = list(layer_config[-1])
+        self.layer_config = layer_config
+        idx = 0
+        self.stage0 = nn.ModuleList([ILBlock(np.array([3]), layer_config[0][1],
+                                             nextoutlist=layer_config[1][1], stride=1, first=True)])
+        idx = 1
+        stage_lists = []
+        for s, n in enumerate(self.stages):
+            blocks = nn.ModuleList()
+            for b in range(n):
+                last = b == n - 1
+                blocks.append(ILBlock(layer_config[idx][0], layer_config[idx][1],
+                                      nextoutlist=None if (s == 3 and b > 0) else layer_config[idx + 1][1],
+                                      stride=2 if (s >= 1 and b == 0) else 1,
+                                      nextstride=1 if (b == 0 or s == 3) else (2 if last else 1)))
+                idx += 1
+            stage_lists.append(blocks)
+        self.stage1, self.stage2, self.stage3, self.stage4 = stage_lists
+        self.oct_fuse = CSFHead(layer_config[idx:idx + 3])
+        fuse_out = int(round(float(np.sum(layer_config[-2][1]))))
+        self.cls_layer = nn.Conv2d(fuse_out, num_classes, kernel_size=1)
+        self.all_flops = 0
+        self.batchsize = 0
+        # engine state (not part of state_dict)
+        self._arena: Optional[ParamArena] = None
+        self._engines = {}
+        self._lib = None            # tests may inject another build of the same C ABI; None -> libcsnet_hip.so
+        self._sub_batch = int(os.environ.get("CSN_SUB_BATCH", "0"))
+        self._penalty_cfg = None    # set by flops_hook()
+
+    # ---- dynamic-weight-decay API (csnet.py:313-363) --------------------------------------------------
+    def set_batchsize(self, batchsize):
+        self.batchsize = batchsize
+
+    def clear_flops(self):
+        self.all_flops = 0
+        for m in self.modules():
+            if isinstance(m, ILBlock):
+                m.conv1x1.all_flops = 0
+                m.conv3x3_1.all_flops = 0
+                m.conv3x3_2.all_flops = 0
+
+    def get_flops(self):
+        for m in self.modules():
+            if isinstance(m, ILBlock):
+                self.all_flops = m.conv1x1.all_flops + m.conv3x3_1.all_flops + m.conv3x3_2.all_flops + self.all_flops
+        return self.all_flops / self.batchsize
+
+    def flops_hook(self, expandflop=2):
+        """Assign the per-stage penalty weights of the reference hook (csnet.py:332-355).
+
+        The penalty itself (Oct_bn_hook, csnet.py:391-410) needs train-mode activations; the train-mode
+        kernels are not part of this build yet, so only the weights are recorded here."""
+        baseflop = expandflop ** (len(self.stages) - 1)
+        real_stages = list(self.stages)
+        real_stages[0] += 1
+        stage = in_stage = 0
+        for m in self.modules():
+            if isinstance(m, ILBlock):
+                for sub in (m.conv1x1, m.conv3x3_1, m.conv3x3_2):
+                    sub.baseflop, sub.expandflop = baseflop, expandflop
+                in_stage += 1
+                if in_stage == real_stages[stage]:
+                    baseflop /= expandflop
+                    stage += 1
+                    in_stage = 0
+        self._penalty_cfg = dict(expandflop=expandflop)
+
+    def updateWeight(self, s=0.001):
+        for m in self.modules():
+            if isinstance(m, gOctaveCBR):
+                for n in m.modules():
+                    if isinstance(n, nn.BatchNorm2d):
+                        n.weight.grad.data.add_(s * torch.sign(n.weight.data))
+
+    # ---- plan description -------------------------------------------------------------------------------
+    def _blocks(self) -> List[ILBlock]:
+        out = [self.stage0[0]]
+        for st in (self.stage1, self.stage2, self.stage3, self.stage4):
+            out.extend(st)
+        return out
+
+    def describe(self, offsets):
+        """Translate the module tree into the unit / activation descriptors of include/csnet_hip.h.
+
+        ``offsets``: parameter / buffer name -> float offset in the arena.  Returns (units, acts, names).
+        """
+        acts = [(3, 0)]                       # id 0 = network input
+        units, names = [], []
+
+        def new_act(c, lvl):
+            acts.append((int(c), int(lvl)))
+            return len(acts) - 1
+
+        def bn_fill(u, j, prefix_bn, prefix_prelu):
+            u.bn[j].weight = offsets[prefix_bn + ".weight"]
+            u.bn[j].bias = offsets[prefix_bn + ".bias"]
+            u.bn[j].running_mean = offsets[prefix_bn + ".running_mean"]
+            u.bn[j].running_var = offsets[prefix_bn + ".running_var"]
+            u.bn[j].prelu = offsets[prefix_prelu + ".weight"]
+
+        def add_goct(name, cbr: gOctaveCBR, cur):
+            """cur: list of (act_id | None, channels, lvl) per input branch."""
+            if cbr.std_conv:
+                raise NotImplementedError("single-branch gOctaveCBR (Conv2dX100 std_conv, csnet.py:751-754) is "
+                                          "not supported by the HIP plan yet")
+            conv = cbr.conv
+            bi, bo = conv.in_bounds(), conv.out_bounds()
+            u = N.new_unit(N.UNIT_GOCT)
+            u.n_in, u.n_out = conv.inbranch, conv.outbranch
+            u.ksize, u.stride = cbr.kernel_size[0], conv.stride
+            u.w_off[0] = offsets[name + ".conv.weight"]
+            lvl0 = None
+            for i in range(conv.inbranch):
+                c = bi[i + 1] - bi[i]
+                present = cur[i] is not None and cur[i][0] is not None and c > 0
+                u.cin[i] = c if present else 0
+                u.in_act[i] = cur[i][0] if present else -1
+                if present:
+                    assert cur[i][1] == c, (name, i, cur[i], c)
+                    if lvl0 is None:
+                        lvl0 = cur[i][2] - i
+            base = lvl0 + (1 if conv.stride == 2 else 0)
+            outs = []
+            for j in range(conv.outbranch):
+                c = bo[j + 1] - bo[j]
+                if c > 0 and cbr.bns[j] is not None:
+                    assert cbr.bns[j].num_features == c
+                    a = new_act(c, base + j)
+                    u.cout[j], u.out_act[j] = c, a
+                    bn_fill(u, j, f"{name}.bns.{j}", f"{name}.prelus.{j}")
+                    outs.append((a, c, base + j))
+                else:
+                    outs.append(None)
+            units.append(u)
+            names.append(name)
+            return outs
+
+        def add_dw(name, dw: SimplifiedGOctConvBR, cur):
+            u = N.new_unit(N.UNIT_DW)
+            u.n_in = u.n_out = dw.outbranch
+            outs = []
+            for k in range(dw.outbranch):
+                if cur[k] is None or dw.convs[k] is None:
+                    outs.append(None)
+                    continue
+                a_in, c, lvl = cur[k]
+                assert dw.convs[k].out_channels == c
+                a = new_act(c, lvl)
+                u.cin[k] = u.cout[k] = c
+                u.in_act[k], u.out_act[k] = a_in, a
+                u.w_off[k] = offsets[f"{name}.convs.{k}.weight"]
+                bn_fill(u, k, f"{name}.bns.{k}", f"{name}.prelus.{k}")
+                outs.append((a, c, lvl))
+            units.append(u)
+            names.append(name)
+            return outs
+
+        cur = [(0, 3, 0)]
+        heads = []
+        blocks = self._blocks()
+        block_names = ["stage0.0"] + [f"stage{s + 1}.{b}" for s, n in enumerate(self.stages) for b in range(n)]
+        ends = np.cumsum([1] + self.stages)          # block index after which a stage ends
+        for bi_, (blk, bname) in enumerate(zip(blocks, block_names)):
+            cur = add_goct(bname + ".conv1x1", blk.conv1x1, cur)
+            cur = add_dw(bname + ".conv3x3_1", blk.conv3x3_1, cur)
+            cur = add_dw(bname + ".conv3x3_2", blk.conv3x3_2, cur)
+            if (bi_ + 1) in ends[2:]:                 # end of stage2 / stage3 / stage4  (csnet.py:380)
+                heads.append(cur[0])
+        fuse = add_goct("oct_fuse.fuse", self.oct_fuse.fuse, heads)
+        mids = []
+        for i, ms in enumerate(self.oct_fuse.ms.convs):
+            if ms is None or fuse[i] is None:
+                mids.append(None)
+                continue
+            a_in, c, lvl = fuse[i]
+            assert ms.in_channels == c
+            u = N.new_unit(N.UNIT_MS)
+            u.n_in = u.n_out = 1
+            u.cin[0], u.cout[0] = c, ms.out_channels
+            a = new_act(ms.out_channels, lvl)
+            u.in_act[0], u.out_act[0] = a_in, a
+            for d in range(N.NDIL):
+                u.dil_ch[d] = ms.dil_channels[d]
+                if ms.dil_channels[d]:
+                    u.w_off[d] = offsets[f"oct_fuse.ms.convs.{i}.msconv.{d}.weight"]
+            bn_fill(u, 0, f"oct_fuse.ms.convs.{i}.bn", f"oct_fuse.ms.convs.{i}.prelu")
+            units.append(u)
+            names.append(f"oct_fuse.ms.convs.{i}")
+            mids.append((a, ms.out_channels, lvl))
+        last = add_goct("oct_fuse.fuse1x1", self.oct_fuse.fuse1x1, mids)
+        a_in, c, lvl = last[0]
+        u = N.new_unit(N.UNIT_CLS)
+        u.n_in = u.n_out = 1
+        u.cin[0], u.cout[0] = c, 1
+        u.in_act[0] = a_in
+        u.w_off[0] = offsets["cls_layer.weight"]
+        u.bias_off = offsets["cls_layer.bias"]
+        units.append(u)
+        names.append("cls_layer")
+        return units, acts, names
+
+    # ---- execution -----------------------------------------------------------------------------------------
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._arena = None        # .cuda()/.to() re-allocate parameters: rebuild the arena lazily
+        self._engines = {}
+        return out
+
+    def _ensure_arena(self) -> ParamArena:
+        if self._arena is None or not self._arena.is_current():
+            self._arena = ParamArena(self)
+            self._engines = {}
+        return self._arena
+
+    def engine_for(self, x: torch.Tensor) -> Engine:
+        arena = self._ensure_arena()
+        if x.device != arena.flat.device:
+            raise RuntimeError(f"input on {x.device} but model parameters on {arena.flat.device}")
+        lib = self._lib
+        if lib is None:
+            if not x.is_cuda:
+                raise RuntimeError("sod100k_amd.CSNet runs on ROCm devices only (hand-written HIP kernels); "
+                                   "move the model and the input to the GPU (`model.cuda()`, `x.cuda()`).")
+            lib = N.load()
+        key = (tuple(x.shape), x.device)
+        eng = self._engines.get(key)
+        if eng is None:
+            B, _, H, W = x.shape
+            if H % 16 or W % 16:
+                raise ValueError("CSNet needs H and W to be multiples of 16 (cf. test.py:80-85)")
+            units, acts, names = self.describe(arena.offsets)
+            eng = Engine(lib, units, acts, B, H, W, x.device, sub_batch=self._sub_batch, unit_names=names)
+            self._engines[key] = eng
+        return eng
+
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32:
+            raise ValueError("expected a float32 tensor of shape B x 3 x H x W")
+        if self.training:
+            raise NotImplementedError("train-mode forward/backward (batch-stat BN, dynamic weight decay) is not "
+                                      "part of this build yet; call model.eval()")
+        eng = self.engine_for(x)
+        eng.refresh(self._arena.flat)
+        return eng.forward(x)
+
+
+# ---- dynamic weight decay hook (csnet.py:391-410) -----------------------------------------------------------
+def Oct_bn_hook(module, input, output):
+    """Same signature and arithmetic as the reference hook, for callers that register it themselves on a
+    module whose forward they drive; CSNet.flops_hook() does not need it (the plan fuses the GAP)."""
+    branches = len(output)
+    w = module.baseflop * (module.expandflop ** (branches - 1))
+    weights = []
+    for _ in range(branches):
+        weights.append(w)
+        w /= module.expandflop
+    terms = []
+    gap_id = 0
+    for name, m in module.named_modules():
+        if isinstance(m, nn.BatchNorm2d):
+            gap = torch.nn.functional.adaptive_avg_pool2d(output[gap_id].detach(), 1).squeeze().abs()
+            gap_id += 1
+            terms.append((weights[int(name.split('.')[-1])] * gap * torch.pow(m.weight, 2)).sum())
+    module.all_flops += 0.5 * sum(terms)
+
+
+# ---- layer_config helpers (csnet.py:414-568) ----------------------------------------------------------------
+def init_layers(basewidth, basic_split=[1, ]):
+    """Un-pruned channel plan for stages [3,4,6,4] + CSF head (csnet.py:414-518)."""
+    sp = np.array([float(v) for v in basic_split])
+    one = np.array([1.0])
+    stages = [3, 4, 6, 4]
+    w = basewidth
+    cfg = [[np.array([3, ]), w * sp], [w * sp, w * sp]]
+    cfg += [[w * sp, w * sp] for _ in range(1, stages[0])]
+    cfg += [[w * sp, w * 2 * sp]] + [[w * 2 * sp, w * 2 * sp] for _ in range(1, stages[1] - 1)] + [[w * 2 * sp, w * 2 * one]]
+    cfg += [[w * 2 * one, w * 4 * sp]] + [[w * 4 * sp, w * 4 * sp] for _ in range(1, stages[2] - 1)] + [[w * 4 * sp, w * 4 * one]]
+    cfg += [[w * 4 * one, w * 4 * sp]] + [[w * 4 * sp, w * 4 * sp] for _ in range(1, stages[3] - 1)] + [[w * 4 * sp, w * 4 * one]]
+    sides = np.array([w * 2, w * 4, w * 4])
+    mid = sides // 3
+    cfg.append([sides.copy(), mid.copy()])
+    dil = []
+    for br in mid:
+        each = br // len(DILATIONS)
+        dil.append([each] * (len(DILATIONS) - 1) + [br - each * (len(DILATIONS) - 1)])
+    cfg.append([mid.copy(), mid.copy(), np.array(dil)])
+    cfg.append([mid.copy(), np.array([mid.sum(), ])])
+    for e in cfg:
+        e[0] = np.round(e[0]).astype(np.int32)
+        e[1] = np.round(e[1]).astype(np.int32)
+    cfg.append(stages)
+    return cfg
+
+
+def load_layer_config(predefine):
+    """Reference ``.bin`` pickle (csnet.py:521-523) or this repo's JSON manifest (``*.json``)."""
+    if str(predefine).endswith(".json"):
+        with open(predefine) as f:
+            raw = json.load(f)["layer_config"]
+        return [[np.asarray(v, dtype=np.float64) for v in e] for e in raw[:-1]] + [[int(v) for v in raw[-1]]]
+    with open(predefine, "rb") as data:
+        return pickle.load(data)
+
+
+def save_layer_config(layer_config, save_path, epoch, latest=False, finetune=False):
+    os.makedirs(save_path, exist_ok=True)
+    stem = ("layer_config_finetune_" if finetune else "layer_config_") + str(epoch) + ".bin"
+    targets = [os.path.join(save_path, stem)]
+    if latest and not finetune:
+        targets.append(os.path.join(save_path, "layer_config_latest.bin"))
+    for t in targets:
+        with open(t, "wb") as f:
+            pickle.dump(layer_config, f)
+    print("Saved in:", targets[0])
+
+
+def build_model(epoch=0, predefine='', basic_split=[1, ], save_path='tmp', expand=1.0, model=None,
+                load_weight="NO", finetune_thres='1e-20', finetune=False):
+    """Inference signature csnet.py:571-597; the extra keyword arguments of the training copy
+    (CSNet_training/model/csnet.py:882-892) are accepted, pruning surgery (finetune=True) is out of scope."""
+    if finetune:
+        raise NotImplementedError("prune-and-finetune model surgery (CSNet_training/model/csnet.py:571-879) "
+                                  "is outside the accelerated hot path")
+    basewidth = 20
+    real_width = int(round(basewidth * expand)) if expand > 1 else basewidth
+    if os.path.isfile(predefine):
+        layer_config = load_layer_config(predefine)
+    else:
+        layer_config = init_layers(real_width, basic_split)
+    return CSNet(layer_config=layer_config)
