@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec through CSNet-100K (csnet-L-x2) eval forward on synthetic 3x224x224 batches.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A step = one pass of the hot path (``CSNet.forward``, csnet.py:365-387) over one batch of 64 images per
+GPU that is already resident in HBM (BASELINE.json configs[1]: fp32 forward, batch 64, 1 MI355X).  The path
+shards by image with no data-path collective, so N>1 runs N independent shards ("weak" scaling); the only
+cross-rank operations are the barrier around the timed region and the MAX-reduce of the elapsed time.
+
+Rank 0 prints ONE JSON line with, besides the driver's contract fields:
+  roofline      for the kernel that dominates the step: algorithmic bytes per launch (unit inputs read
+                once + outputs written once) / mean launch duration measured with HIP
+                events on the launch stream, against the 8 TB/s HBM3E peak;
+  cpu_baseline  the CPU oracle (a port of the reference path onto the same ATen CPU kernels) timed on the
+                host cores of this box on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ALG_BYTES_PER_IMAGE = 169_704_640   # SURVEY.md 8(d), csnet-L-x2 fp32 224x224 (cross-checked below)
+
+
+def cpu_baseline(man, batch=8, target_s=15.0):
+    """Time the CPU oracle on a bounded sample (about 10-30 s of CPU work)."""
+    from oracle import csnet_oracle as O, inputs as I
+    sd = O.load_weights(man)
+    lc = O.load_layer_config_json(man)
+    x = torch.from_numpy(I.randn_batch(0, batch))
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        O.csnet_forward(lc, sd, x)          # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            O.csnet_forward(lc, sd, x)
+            n += 1
+            if time.perf_counter() - t0 > target_s or n >= 20:
+                break
+        dt = time.perf_counter() - t0
+    return dict(value=round(batch * n / dt, 3), unit="images/sec", cores=cores, kind="port",
+                sample=f"{n} eval forwards of batch {batch} (3x224x224, seed 0) through oracle/csnet_oracle.py "
+                       f"(torch {torch.__version__} CPU ops, {cores} threads), {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--sub-batch", type=int, default=int(os.environ.get("CSN_SUB_BATCH", "0")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-iters", type=int, default=5)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", device_id=dev)
+        dist = dist_mod
+
+    from sod100k_amd.model import csnet as M
+    from sod100k_amd.checkpoint import load_manifest_state_dict
+    man = os.path.join(ROOT, "sod100k_amd", "data", "csnet-L-x2.json")
+    model = M.build_model(predefine=man)
+    sd = load_manifest_state_dict(man)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    model._sub_batch = args.sub_batch
+
+    B = args.batch
+    g = torch.Generator(device="cpu").manual_seed(rank)
+    x = torch.randn(B, 3, 224, 224, generator=g).to(dev)        # synthetic, resident in HBM before timing
+    eng = model.engine_for(x)
+    eng.refresh(model._arena.flat)
+    y = torch.empty(B, 1, 224, 224, device=dev)
+
+    def step():
+        eng.forward(x, out=y)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- per-kernel roofline (HIP events around every unit, same stream) ----
+    ms, names, nbytes = eng.profile(x, iters=args.profile_iters)
+    n_slices = (B + eng_sub(eng, B) - 1) // eng_sub(eng, B)
+    agg = {}
+    for m, n, nb in zip(ms, names, nbytes):
+        a = agg.setdefault(n, dict(ms=0.0, bytes=0, launches=0))
+        a["ms"] += m
+        a["bytes"] += nb
+        a["launches"] += n_slices
+    dom = max(agg, key=lambda k: agg[k]["ms"])
+    d = agg[dom]
+    bytes_per_launch = d["bytes"] / d["launches"]
+    us_per_launch = d["ms"] * 1e3 / d["launches"]
+    achieved = bytes_per_launch / (us_per_launch * 1e-6) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    total_alg = sum(nbytes)
+    roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                    bytes_per_launch=int(bytes_per_launch), us_per_launch=round(us_per_launch, 2),
+                    launches_per_step=d["launches"],
+                    whole_step=dict(algorithmic_bytes=int(total_alg), events_ms=round(sum(ms), 3),
+                                    achieved=round(total_alg / (sum(ms) * 1e-3) / 1e9, 1),
+                                    frac=round(total_alg / (sum(ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
+                    per_kernel={k: dict(ms=round(v["ms"], 3), GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1))
+                                for k, v in agg.items()})
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        out = {
+            "metric": "images/sec CSNet-100K 3x224x224 fwd (and fwd+bwd) at 1/2/4/8 GPU",
+            "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "CSNet-100K (csnet-L-x2 shipped checkpoint) fp32 eval forward, "
+                                   f"batch {B} x 3x224x224 per GPU, inputs resident in HBM",
+                       "batch_per_gpu": B, "global_batch": B * world, "sub_batch": eng_sub(eng, B),
+                       "parallelism": f"image shards x{world}, no data-path collective",
+                       "algorithmic_bytes_per_image": int(total_alg // B)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(man)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def eng_sub(eng, B):
+    info = eng.activation(1).shape[0]
+    return int(info)
+
+
+if __name__ == "__main__":
+    main()

@@ -21,6 +21,26 @@
 
 #include <stdint.h>
 
+// Constant address space (4) views.  Packed weights / folded BN tables are written by csn_prep_kernel in
+// an EARLIER launch and never by the kernels that consume them, so they may be read through the scalar
+// cache (s_load) and used as SGPR operands of v_fmac; the by-value argument block is read in place
+// from the kernarg segment (dynamic indexing of a by-value struct would otherwise be copied to scratch).
+#ifdef CSN_CPU_EMU
+#define CSN_CONST_AS
+#define CSN_KERNARG(T, a) (&(a))
+#else
+#define CSN_CONST_AS __attribute__((address_space(4)))
+#define CSN_KERNARG(T, a) ((const CSN_CONST_AS T*)__builtin_amdgcn_kernarg_segment_ptr())
+#endif
+typedef const CSN_CONST_AS float* csn_cfp;
+__device__ __forceinline__ csn_cfp csn_const(const float* p) {
+#ifdef CSN_CPU_EMU
+  return p;
+#else
+  return (csn_cfp)(p);
+#endif
+}
+
 #define CSN_BLOCK 256
 
 // Folded epilogue of one output channel: y = z*scale + shift; y = y >= 0 ? y : alpha*y

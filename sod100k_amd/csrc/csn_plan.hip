@@ -256,7 +256,7 @@ int plan_goct(Builder& bl, UnitPlan& u) {
     u.top_ppl2 = 0; u.maxc_top = 4;
     if (has_top && top_c <= 80) {
       u.top_ppl2 = 1;
-      u.maxc_top = top_c <= 16 ? 16 : top_c <= 32 ? 32 : top_c <= 64 ? 64 : 80;
+      u.maxc_top = top_c <= 16 ? 16 : top_c <= 32 ? 32 : top_c <= 48 ? 48 : top_c <= 64 ? 64 : 80;
     } else if (has_top && top_c > max_low) {
       max_low = top_c;
     }
@@ -364,7 +364,7 @@ int plan_cls(Builder& bl, UnitPlan& u) {
   u.pw_nz = 0;
   if (ps.cin4 <= 80) {
     u.top_ppl2 = 1; u.maxc_low = 4;
-    u.maxc_top = ps.cin4 <= 16 ? 16 : ps.cin4 <= 32 ? 32 : ps.cin4 <= 64 ? 64 : 80;
+    u.maxc_top = ps.cin4 <= 16 ? 16 : ps.cin4 <= 32 ? 32 : ps.cin4 <= 48 ? 48 : ps.cin4 <= 64 ? 64 : 80;
   } else if (ps.cin4 <= 160) {
     u.top_ppl2 = 0; u.maxc_top = 4; u.maxc_low = ps.cin4 <= 96 ? 96 : 160;
   } else {
@@ -671,7 +671,7 @@ static int forward_impl(csn_plan* P, const float* x, float* y, void* workspace, 
     }
     for (int u = 0; u < nu; ++u) unit_ms[u] = 0.f;
   }
-  const int64_t in_stride = (int64_t)3 * P->H * P->W, out_stride = (int64_t)P->H * P->W;
+  const int64_t in_stride = (int64_t)P->acts[0].channels * P->H * P->W, out_stride = (int64_t)P->H * P->W;
   const int reps = prof ? (iters > 0 ? iters : 1) : 1;
   for (int it = 0; it < reps; ++it) {
     for (int b0 = 0; b0 < P->B; b0 += P->S) {

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(TY* TX / PPL) void conv3x3_kernel(C3Args a) {
     for (int co = 0; co < 8; ++co)
 #pragma unroll
       for (int p = 0; p < PPL; ++p) acc[co][p] = 0.f;
-    const float* __restrict__ wg = a.w + (int64_t)g * a.cin * 72;
+    csn_cfp wg = csn_const(a.w) + (int64_t)g * a.cin * 72;
     for (int ci = 0; ci < a.cin; ++ci) {
       float win[3][PPL + 2];
       const float* __restrict__ wp = win0 + ci * PLANE;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(TY* TX / PPL) void conv3x3_kernel(C3Args a) {
       for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < PPL + 2; ++c) win[r][c] = wp[r * SXP + c];
-      const float* __restrict__ wc = wg + ci * 72;
+      csn_cfp wc = wg + ci * 72;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
 #pragma unroll
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(TY* TX / PPL) void conv3x3_kernel(C3Args a) {
             const float* __restrict__ z = a.zadd + ((int64_t)b * a.cout + oc) * Hz * Wz;
             v += zw[p][0] * z[zi[p][0]] + zw[p][1] * z[zi[p][1]] + zw[p][2] * z[zi[p][2]] + zw[p][3] * z[zi[p][3]];
           }
-          if (a.scale != nullptr) v = csn_epi(v, a.scale[oc], a.shift[oc], a.alpha[oc]);
+          if (a.scale != nullptr) v = csn_epi(v, csn_const(a.scale)[oc], csn_const(a.shift)[oc], csn_const(a.alpha)[oc]);
           o[p] = v;
         }
         float* __restrict__ q = a.out + (((int64_t)b * a.cout + oc) * H + y) * W + x;
@@ -191,10 +191,10 @@ __global__ __launch_bounds__(CSN_BLOCK) void msblock_kernel(MsArgs a) {
       float acc[8];
 #pragma unroll
       for (int co = 0; co < 8; ++co) acc[co] = 0.f;
-      const float* __restrict__ wg = a.w[d] + (int64_t)g * a.cin * 72;
+      csn_cfp wg = csn_const(a.w[d]) + (int64_t)g * a.cin * 72;
       for (int ci = 0; ci < a.cin; ++ci) {
         const float* __restrict__ pl = ip + ci * hw;
-        const float* __restrict__ wc = wg + ci * 72;
+        csn_cfp wc = wg + ci * 72;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
           const float v = ok[t] ? pl[off[t]] : 0.f;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void msblock_kernel(MsArgs a) {
         const int lc = g * 8 + co;
         if (lc < nco) {
           const int oc = a.cobase[d] + lc;
-          op[oc * hw] = csn_epi(acc[co], a.scale[oc], a.shift[oc], a.alpha[oc]);
+          op[oc * hw] = csn_epi(acc[co], csn_const(a.scale)[oc], csn_const(a.shift)[oc], csn_const(a.alpha)[oc]);
         }
       }
     }

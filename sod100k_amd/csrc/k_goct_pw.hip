@@ -37,32 +37,35 @@ __device__ __forceinline__ int pw_ring_px(int r) {
 }
 __device__ __forceinline__ int pw_ring_rx(int r) { return (PW_TX0 >> r) + 2; }
 
+typedef const CSN_CONST_AS PwPass* PwPassP;
+
 // Gather the MAXC-bounded channel vector of pixel (y,x) (branch resolution Hr x Wr) of image b.
 template <int MAXC>
-__device__ __forceinline__ void pw_gather1(const PwPass& ps, int b, int y, int x, int Hr, int Wr,
-                                           float (&v)[MAXC]) {
-  const int c1 = ps.src[0].C;
-  const int c2 = c1 + (ps.nsrc > 1 ? ps.src[1].C : 0);
-  const int c3 = c2 + (ps.nsrc > 2 ? ps.src[2].C : 0);
+__device__ __forceinline__ void pw_gather1(PwPassP ps, int b, int y, int x, int Hr, int Wr, float (&v)[1][MAXC]) {
+  const int c1 = ps->src[0].C;
+  const int c2 = c1 + (ps->nsrc > 1 ? ps->src[1].C : 0);
+  const int c3 = c2 + (ps->nsrc > 2 ? ps->src[2].C : 0);
+  const float* __restrict__ p0 = ps->src[0].ptr + ((int64_t)b * c1 * Hr + y) * Wr + x;
+  const int64_t cs0 = (int64_t)Hr * Wr;
 #pragma unroll
   for (int k = 0; k < MAXC; ++k) {
     float val = 0.f;
     if (k < c1) {
-      val = ps.src[0].ptr[(((int64_t)b * c1 + k) * Hr + y) * Wr + x];
+      val = p0[k * cs0];
     } else if (k < c3) {
       const int s = (k < c2) ? 1 : 2;
-      const PwSrc sr = ps.src[s];
+      const int sC = ps->src[s].C, sh = ps->src[s].shift;
       const int ch = k - (s == 1 ? c1 : c2);
-      const int f = 1 << sr.shift;
-      const int Ws = Wr << sr.shift;
+      const int Ws = Wr << sh;
       const float* __restrict__ p =
-          sr.ptr + (((int64_t)b * sr.C + ch) * (Hr << sr.shift) + (int64_t)y * f) * Ws + x * f;
-      if (sr.shift == 1) {
+          ps->src[s].ptr + (((int64_t)b * sC + ch) * (Hr << sh) + ((int64_t)y << sh)) * Ws + (x << sh);
+      if (sh == 1) {
         const float2 a0 = *reinterpret_cast<const float2*>(p);
         const float2 a1 = *reinterpret_cast<const float2*>(p + Ws);
         val = fmaxf(fmaxf(a0.x, a0.y), fmaxf(a1.x, a1.y));
       } else {
         float m = -3.402823466e+38f;
+#pragma unroll
         for (int yy = 0; yy < 4; ++yy) {
           const float4 q = *reinterpret_cast<const float4*>(p + (int64_t)yy * Ws);
           m = fmaxf(m, fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)));
@@ -70,39 +73,72 @@ __device__ __forceinline__ void pw_gather1(const PwPass& ps, int b, int y, int x
         val = m;
       }
     }
-    v[k] = val;
+    v[0][k] = val;
   }
 }
 
 // Two horizontally adjacent pixels (x even) of the own-resolution source only (branch-0 pass).
 template <int MAXC>
-__device__ __forceinline__ void pw_gather2(const PwPass& ps, int b, int y, int x, int Hr, int Wr,
-                                           float (&v0)[MAXC], float (&v1)[MAXC]) {
-  const int c1 = ps.src[0].C;
-  const float* __restrict__ base = ps.src[0].ptr + ((int64_t)b * c1 * Hr + y) * Wr + x;
+__device__ __forceinline__ void pw_gather2(PwPassP ps, int b, int y, int x, int Hr, int Wr, float (&v)[2][MAXC]) {
+  const int c1 = ps->src[0].C;
+  const float* __restrict__ base = ps->src[0].ptr + ((int64_t)b * c1 * Hr + y) * Wr + x;
   const int64_t cs = (int64_t)Hr * Wr;
 #pragma unroll
   for (int k = 0; k < MAXC; ++k) {
     float2 q = make_float2(0.f, 0.f);
     if (k < c1) q = *reinterpret_cast<const float2*>(base + k * cs);
-    v0[k] = q.x;
-    v1[k] = q.y;
+    v[0][k] = q.x;
+    v[1][k] = q.y;
   }
 }
 
-template <int MAXC>
-__device__ __forceinline__ float pw_dot(const float* __restrict__ wr, int cin4, const float (&v)[MAXC]) {
-  float acc = 0.f;
+// Row engine.  Output rows are produced two at a time from the register-resident channel vectors of
+// NPX pixels (2*NPX independent accumulation chains); the weight rows are wave-uniform and stream
+// through the scalar cache.  Channel groups of 4 beyond cin4 are skipped by a uniform branch.
+template <int MAXC, int NPX, class Sink>
+__device__ __forceinline__ void pw_rows(csn_cfp w, int cin4, int nrows, const float (&v)[NPX][MAXC], Sink& sink) {
+  int row = 0;
+  for (; row + 2 <= nrows; row += 2) {
+    float a0[NPX], a1[NPX];
 #pragma unroll
-  for (int k0 = 0; k0 < MAXC; k0 += 4) {
-    if (k0 < cin4) {
-      acc = fmaf(wr[k0 + 0], v[k0 + 0], acc);
-      acc = fmaf(wr[k0 + 1], v[k0 + 1], acc);
-      acc = fmaf(wr[k0 + 2], v[k0 + 2], acc);
-      acc = fmaf(wr[k0 + 3], v[k0 + 3], acc);
+    for (int p = 0; p < NPX; ++p) a0[p] = a1[p] = 0.f;
+    csn_cfp w0 = w + row * cin4;
+    csn_cfp w1 = w0 + cin4;
+#pragma unroll
+    for (int k0 = 0; k0 < MAXC; k0 += 4) {
+      if (k0 < cin4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float wa = w0[k0 + u], wb = w1[k0 + u];
+#pragma unroll
+          for (int p = 0; p < NPX; ++p) {
+            a0[p] = fmaf(wa, v[p][k0 + u], a0[p]);
+            a1[p] = fmaf(wb, v[p][k0 + u], a1[p]);
+          }
+        }
+      }
     }
+    sink(row, a0);
+    sink(row + 1, a1);
   }
-  return acc;
+  if (row < nrows) {
+    float a0[NPX];
+#pragma unroll
+    for (int p = 0; p < NPX; ++p) a0[p] = 0.f;
+    csn_cfp w0 = w + row * cin4;
+#pragma unroll
+    for (int k0 = 0; k0 < MAXC; k0 += 4) {
+      if (k0 < cin4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float wa = w0[k0 + u];
+#pragma unroll
+          for (int p = 0; p < NPX; ++p) a0[p] = fmaf(wa, v[p][k0 + u], a0[p]);
+        }
+      }
+    }
+    sink(row, a0);
+  }
 }
 
 // Bilinear tap set of one destination pixel into an LDS z region of source branch rs.
@@ -137,111 +173,113 @@ __device__ __forceinline__ float pw_tap_eval(const float* __restrict__ z, const 
 }
 
 template <int MAXC_TOP, int MAXC_LOW>
-__global__ __launch_bounds__(CSN_BLOCK) void goct_pw_kernel(PwArgs a) {
+__global__ __launch_bounds__(CSN_BLOCK) void goct_pw_kernel(PwArgs a_byval) {
   CSN_DYN_SMEM(float, lds);
+  const CSN_CONST_AS PwArgs* a = CSN_KERNARG(PwArgs, a_byval);
   const int tid = threadIdx.x;
   const int b = blockIdx.z;
   const int ty0 = blockIdx.y * PW_TY0, tx0 = blockIdx.x * PW_TX0;  // tile origin at branch 0
-  const int H0 = a.H0, W0 = a.W0;
+  const int H0 = a->H0, W0 = a->W0;
+  const int nz_pass = a->nz_pass, npass = a->npass, top_ppl2 = a->top_ppl2;
 
   // ---- z passes: low->high partial sums at low resolution, tile + ring, into LDS ----
-  for (int pi = 0; pi < a.nz_pass; ++pi) {
-    const PwPass& ps = a.pass[pi];
-    const int r = ps.r;
+  for (int pi = 0; pi < nz_pass; ++pi) {
+    PwPassP ps = &a->pass[pi];
+    const int r = ps->r;
     const int Hr = H0 >> r, Wr = W0 >> r;
     const int rx = pw_ring_rx(r), npx = pw_ring_px(r);
     const int oy = (ty0 >> r) - 1, ox = (tx0 >> r) - 1;
+    const int cin4 = ps->cin4, nrows = ps->nrows;
+    csn_cfp w = csn_const(ps->w);
     for (int p = tid; p < npx; p += CSN_BLOCK) {
       const int py = p / rx, px = p - py * rx;
       const int y = oy + py, x = ox + px;
       if (y < 0 || y >= Hr || x < 0 || x >= Wr) continue;  // never sampled (indices are clamped)
-      float v[MAXC_LOW];
+      float v[1][MAXC_LOW];
       pw_gather1<MAXC_LOW>(ps, b, y, x, Hr, Wr, v);
-      float* __restrict__ zp = lds + ps.z_off + p;
-      for (int row = 0; row < ps.nrows; ++row)
-        zp[row * npx] = pw_dot<MAXC_LOW>(ps.w + (int64_t)row * ps.cin4, ps.cin4, v);
+      float* __restrict__ zp = lds + ps->z_off + p;
+      auto sink = [&](int row, const float (&acc)[1]) { zp[row * npx] = acc[0]; };
+      pw_rows<MAXC_LOW, 1>(w, cin4, nrows, v, sink);
     }
   }
-  if (a.nz_pass > 0) __syncthreads();
+  if (nz_pass > 0) __syncthreads();
 
-  // ---- main passes, one pixel per lane (all branches below 0; branch 0 too when !a.top_ppl2) ----
-  const int n_low = a.top_ppl2 ? a.npass - 1 : a.npass;
-  for (int pi = a.nz_pass; pi < n_low; ++pi) {
-    const PwPass& ps = a.pass[pi];
-    const int r = ps.r;
+  // ---- main passes, one pixel per lane (all branches below 0; branch 0 too when !top_ppl2) ----
+  const int n_low = top_ppl2 ? npass - 1 : npass;
+  for (int pi = nz_pass; pi < n_low; ++pi) {
+    PwPassP ps = &a->pass[pi];
+    const int r = ps->r;
     const int Hr = H0 >> r, Wr = W0 >> r;
     const int tx = PW_TX0 >> r, npx = (PW_TY0 >> r) * tx;
+    const int cin4 = ps->cin4, nrows = ps->nrows, nz = ps->nz;
+    csn_cfp w = csn_const(ps->w);
+    csn_cfp scale = csn_const(ps->scale), shift = csn_const(ps->shift), alpha = csn_const(ps->alpha);
+    const int zrs0 = ps->zadd[0].rs, zrs1 = ps->zadd[1].rs;
+    const float* __restrict__ zb0 = lds + ps->zadd[0].z_off;
+    const float* __restrict__ zb1 = lds + ps->zadd[1].z_off;
+    const int zs0 = pw_ring_px(zrs0), zs1 = pw_ring_px(zrs1);
     for (int p = tid; p < npx; p += CSN_BLOCK) {
       const int py = p / tx, px = p - py * tx;
       const int y = (ty0 >> r) + py, x = (tx0 >> r) + px;
       if (y >= Hr || x >= Wr) continue;
-      float v[MAXC_LOW];
+      float v[1][MAXC_LOW];
       pw_gather1<MAXC_LOW>(ps, b, y, x, Hr, Wr, v);
       PwTap tap0, tap1;
-      int zs0 = 0, zs1 = 0;
-      if (ps.nz > 0) { tap0 = pw_tap(y, x, r, ps.zadd[0].rs, H0, W0, ty0, tx0); zs0 = pw_ring_px(ps.zadd[0].rs); }
-      if (ps.nz > 1) { tap1 = pw_tap(y, x, r, ps.zadd[1].rs, H0, W0, ty0, tx0); zs1 = pw_ring_px(ps.zadd[1].rs); }
-      float* __restrict__ op = ps.out + ((int64_t)b * ps.nrows * Hr + y) * Wr + x;
+      if (nz > 0) tap0 = pw_tap(y, x, r, zrs0, H0, W0, ty0, tx0);
+      if (nz > 1) tap1 = pw_tap(y, x, r, zrs1, H0, W0, ty0, tx0);
+      float* __restrict__ op = ps->out + ((int64_t)b * nrows * Hr + y) * Wr + x;
       const int64_t cs = (int64_t)Hr * Wr;
-      for (int row = 0; row < ps.nrows; ++row) {
-        float acc = pw_dot<MAXC_LOW>(ps.w + (int64_t)row * ps.cin4, ps.cin4, v);
-        if (ps.nz > 0) acc += pw_tap_eval(lds + ps.zadd[0].z_off + row * zs0, tap0);
-        if (ps.nz > 1) acc += pw_tap_eval(lds + ps.zadd[1].z_off + row * zs1, tap1);
-        op[row * cs] = csn_epi(acc, ps.scale[row], ps.shift[row], ps.alpha[row]);
-      }
+      auto sink = [&](int row, const float (&a)[1]) {
+        float acc = a[0];
+        if (nz > 0) acc += pw_tap_eval(zb0 + row * zs0, tap0);
+        if (nz > 1) acc += pw_tap_eval(zb1 + row * zs1, tap1);
+        op[row * cs] = csn_epi(acc, scale[row], shift[row], alpha[row]);
+      };
+      pw_rows<MAXC_LOW, 1>(w, cin4, nrows, v, sink);
     }
   }
 
   // ---- main pass of branch 0: two pixels per lane (float2 loads / stores) ----
-  if (a.top_ppl2) {
-    const PwPass& ps = a.pass[a.npass - 1];
+  if (top_ppl2) {
+    PwPassP ps = &a->pass[npass - 1];
     constexpr int LXN = PW_TX0 / 2;
     const int py = tid / LXN, px = (tid - py * LXN) * 2;
     const int y = ty0 + py, x = tx0 + px;
+    const int cin4 = ps->cin4, nrows = ps->nrows, nz = ps->nz;
+    csn_cfp w = csn_const(ps->w);
+    csn_cfp scale = csn_const(ps->scale), shift = csn_const(ps->shift), alpha = csn_const(ps->alpha);
+    const int zrs0 = ps->zadd[0].rs, zrs1 = ps->zadd[1].rs;
+    const float* __restrict__ zb0 = lds + ps->zadd[0].z_off;
+    const float* __restrict__ zb1 = lds + ps->zadd[1].z_off;
+    const int zs0 = pw_ring_px(zrs0), zs1 = pw_ring_px(zrs1);
     if (y < H0 && x < W0) {
-      float v0[MAXC_TOP], v1[MAXC_TOP];
-      pw_gather2<MAXC_TOP>(ps, b, y, x, H0, W0, v0, v1);
+      float v[2][MAXC_TOP];
+      pw_gather2<MAXC_TOP>(ps, b, y, x, H0, W0, v);
       PwTap ta0, tb0, ta1, tb1;
-      int zs0 = 0, zs1 = 0;
-      if (ps.nz > 0) {
-        ta0 = pw_tap(y, x, 0, ps.zadd[0].rs, H0, W0, ty0, tx0);
-        tb0 = pw_tap(y, x + 1, 0, ps.zadd[0].rs, H0, W0, ty0, tx0);
-        zs0 = pw_ring_px(ps.zadd[0].rs);
+      if (nz > 0) {
+        ta0 = pw_tap(y, x, 0, zrs0, H0, W0, ty0, tx0);
+        tb0 = pw_tap(y, x + 1, 0, zrs0, H0, W0, ty0, tx0);
       }
-      if (ps.nz > 1) {
-        ta1 = pw_tap(y, x, 0, ps.zadd[1].rs, H0, W0, ty0, tx0);
-        tb1 = pw_tap(y, x + 1, 0, ps.zadd[1].rs, H0, W0, ty0, tx0);
-        zs1 = pw_ring_px(ps.zadd[1].rs);
+      if (nz > 1) {
+        ta1 = pw_tap(y, x, 0, zrs1, H0, W0, ty0, tx0);
+        tb1 = pw_tap(y, x + 1, 0, zrs1, H0, W0, ty0, tx0);
       }
-      float* __restrict__ op = ps.out + ((int64_t)b * ps.nrows * H0 + y) * W0 + x;
+      float* __restrict__ op = ps->out + ((int64_t)b * nrows * H0 + y) * W0 + x;
       const int64_t cs = (int64_t)H0 * W0;
-      for (int row = 0; row < ps.nrows; ++row) {
-        const float* __restrict__ wr = ps.w + (int64_t)row * ps.cin4;
-        float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-        for (int k0 = 0; k0 < MAXC_TOP; k0 += 4) {
-          if (k0 < ps.cin4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const float w = wr[k0 + u];
-              a0 = fmaf(w, v0[k0 + u], a0);
-              a1 = fmaf(w, v1[k0 + u], a1);
-            }
-          }
+      auto sink = [&](int row, const float (&a)[2]) {
+        float a0 = a[0], a1 = a[1];
+        if (nz > 0) {
+          a0 += pw_tap_eval(zb0 + row * zs0, ta0);
+          a1 += pw_tap_eval(zb0 + row * zs0, tb0);
         }
-        if (ps.nz > 0) {
-          const float* __restrict__ z = lds + ps.zadd[0].z_off + row * zs0;
-          a0 += pw_tap_eval(z, ta0);
-          a1 += pw_tap_eval(z, tb0);
+        if (nz > 1) {
+          a0 += pw_tap_eval(zb1 + row * zs1, ta1);
+          a1 += pw_tap_eval(zb1 + row * zs1, tb1);
         }
-        if (ps.nz > 1) {
-          const float* __restrict__ z = lds + ps.zadd[1].z_off + row * zs1;
-          a0 += pw_tap_eval(z, ta1);
-          a1 += pw_tap_eval(z, tb1);
-        }
-        const float sc = ps.scale[row], sh = ps.shift[row], al = ps.alpha[row];
+        const float sc = scale[row], sh = shift[row], al = alpha[row];
         *reinterpret_cast<float2*>(op + row * cs) = make_float2(csn_epi(a0, sc, sh, al), csn_epi(a1, sc, sh, al));
-      }
+      };
+      pw_rows<MAXC_TOP, 2>(w, cin4, nrows, v, sink);
     }
   }
 }
@@ -280,16 +318,16 @@ size_t csn_pw_lds_bytes(const PwArgs& a) {
     return (int)hipGetLastError();                                                                \
   }
 
-// maxc_top in {16, 32, 64, 80} (4: branch 0 handled by the one-pixel-per-lane path, !top_ppl2);
+// maxc_top in {16, 32, 48, 64, 80} (4: branch 0 handled by the one-pixel-per-lane path, !top_ppl2);
 // maxc_low in {32, 64, 96, 160} (4: unit without lower branches)
 int csn_launch_pw(const PwArgs& a, int maxc_top, int maxc_low, void* stream) {
   const dim3 grid((a.W0 + PW_TX0 - 1) / PW_TX0, (a.H0 + PW_TY0 - 1) / PW_TY0, a.B);
   const size_t lds = csn_pw_lds_bytes(a);
-  PW_CASE(16, 4) PW_CASE(32, 4) PW_CASE(64, 4) PW_CASE(80, 4)
+  PW_CASE(16, 4) PW_CASE(32, 4) PW_CASE(48, 4) PW_CASE(64, 4) PW_CASE(80, 4)
   PW_CASE(4, 32) PW_CASE(4, 64) PW_CASE(4, 96) PW_CASE(4, 160)
-  PW_CASE(16, 32) PW_CASE(32, 32) PW_CASE(64, 32)
-  PW_CASE(16, 64) PW_CASE(32, 64) PW_CASE(64, 64) PW_CASE(80, 64)
-  PW_CASE(16, 96) PW_CASE(32, 96) PW_CASE(64, 96) PW_CASE(80, 96)
-  PW_CASE(16, 160) PW_CASE(32, 160) PW_CASE(64, 160) PW_CASE(80, 160)
+  PW_CASE(16, 32) PW_CASE(32, 32) PW_CASE(48, 32) PW_CASE(64, 32)
+  PW_CASE(16, 64) PW_CASE(32, 64) PW_CASE(48, 64) PW_CASE(64, 64) PW_CASE(80, 64)
+  PW_CASE(16, 96) PW_CASE(32, 96) PW_CASE(48, 96) PW_CASE(64, 96) PW_CASE(80, 96)
+  PW_CASE(16, 160) PW_CASE(32, 160) PW_CASE(48, 160) PW_CASE(64, 160) PW_CASE(80, 160)
   return -1;
 }

@@ -114,9 +114,10 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
   const float* __restrict__ ip = br.in + (int64_t)pc * H * W;
   float* __restrict__ op = br.out + (int64_t)pc * H * W;
   float w[9];
+  csn_cfp w9 = csn_const(br.w9);
 #pragma unroll
-  for (int i = 0; i < 9; ++i) w[i] = br.w9[c * 9 + i];
-  const float sc = br.scale[c], sh = br.shift[c], al = br.alpha[c];
+  for (int i = 0; i < 9; ++i) w[i] = w9[c * 9 + i];
+  const float sc = csn_const(br.scale)[c], sh = csn_const(br.shift)[c], al = csn_const(br.alpha)[c];
 
   DwRow top = dw_load_row(ip, y0 - 1, x0, H, W, vec);
   DwRow mid = dw_load_row(ip, y0, x0, H, W, vec);

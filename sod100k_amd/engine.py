@@ -123,7 +123,8 @@ class Engine:
                                                            self._stream()), "csn_plan_refresh_params")
 
     def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        assert x.dtype == torch.float32 and x.shape == (self.B, 3, self.H, self.W), (x.shape, x.dtype)
+        assert x.dtype == torch.float32 and x.shape[0] == self.B and tuple(x.shape[2:]) == (self.H, self.W), \
+            (x.shape, x.dtype)
         x = x.contiguous()
         y = out if out is not None else torch.empty((self.B, 1, self.H, self.W), dtype=torch.float32, device=x.device)
         N.check(self.lib, self.lib.csn_forward(self.plan, x.data_ptr(), y.data_ptr(), self.workspace.data_ptr(),

@@ -1,0 +1,217 @@
+"""Parity checks shared by the CPU-emulation tests (``-m "not gpu"``) and the MI355X tests (``-m gpu``).
+
+Every function takes the bound C-ABI library (``tests/emu/libcsnet_emu.so`` or ``libcsnet_hip.so``) and a
+torch device and drives the kernels ONLY through the C ABI (sod100k_amd.engine.Engine / CSNet.forward).
+The oracle (oracle/csnet_oracle.py) and the committed goldens are the checkers.
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import csnet_oracle as O, inputs as I
+from sod100k_amd import _native as N
+from sod100k_amd.engine import Engine
+from sod100k_amd.model import csnet as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+TOL = 1e-4          # north_star: saliency logits within 1e-4 max-abs of the reference CPU forward (fp32)
+UNIT_TOL = 2e-5     # a single unit on O(1) data: fp32 accumulation-order noise only
+
+
+def make_model(lib, manifest, device, sub_batch=0):
+    sd = O.load_weights(manifest)
+    m = M.build_model(predefine=manifest)
+    m.load_state_dict(sd)
+    m = m.to(device).eval()
+    m._lib = lib if device.type == "cpu" else None      # GPU: the product's own loader (libcsnet_hip.so)
+    if device.type == "cuda":
+        assert lib is N.load()
+    m._sub_batch = sub_batch
+    return m, sd
+
+
+def oracle_forward(manifest, sd, x, taps=None):
+    with torch.no_grad():
+        return O.csnet_forward(O.load_layer_config_json(manifest), sd, x, taps=taps)
+
+
+def check_golden_logits(lib, device, manifest, golden_file, x, tol=TOL):
+    m, _ = make_model(lib, manifest, device)
+    y = m(x.to(device)).cpu()
+    g = torch.from_numpy(np.load(os.path.join(GOLD, golden_file)))
+    assert y.shape == g.shape
+    err = (y - g).abs().max().item()
+    assert err <= tol, f"{golden_file}: max-abs {err:.3e} > {tol}"
+    return err
+
+
+def check_unit_probes(lib, device, manifest):
+    """G3: every unit's output against the reference's probes (localises a mismatch to a kernel)."""
+    m, _ = make_model(lib, manifest, device)
+    x = torch.from_numpy(I.randn_batch(0, 2)).to(device)
+    m(x)
+    eng = m.engine_for(x)
+    units, acts, names = m.describe(m._arena.offsets)
+    probes = json.load(open(os.path.join(GOLD, "g3_unit_probes_x2.json")))
+    worst = 0.0
+    for u, name in zip(units, names):
+        if name == "cls_layer":
+            continue
+        for j in range(N.MAX_BRANCH):
+            a = u.out_act[j]
+            if a < 0:
+                continue
+            pr = probes[name][j]
+            got = eng.activation(a).cpu().numpy()
+            assert list(got.shape) == pr["shape"], (name, j)
+            flat = got.reshape(-1)
+            s = flat[I.probe_indices(flat.size)]
+            ref = np.array(pr["samples"], dtype=np.float32)
+            scale = max(1.0, pr["absmax"])
+            err = float(np.abs(s - ref).max()) / scale
+            assert err <= UNIT_TOL, f"{name} branch {j}: rel err {err:.3e}"
+            l2 = float(np.sqrt((flat.astype(np.float64) ** 2).sum()))
+            assert abs(l2 - pr["l2"]) <= 1e-4 * max(1.0, pr["l2"]), (name, j, l2, pr["l2"])
+            worst = max(worst, err)
+    return worst
+
+
+def check_vs_oracle(lib, device, manifest, x, sub_batch=0, tol=TOL):
+    m, sd = make_model(lib, manifest, device, sub_batch=sub_batch)
+    y = m(x.to(device)).cpu()
+    ref = oracle_forward(manifest, sd, x)
+    err = (y - ref).abs().max().item()
+    assert err <= tol, f"max-abs {err:.3e} > {tol}"
+    return y, err
+
+
+# ---------------------------------------------------------------------------------------------------
+# single-unit plans for the op-level micro-goldens (G4)
+# ---------------------------------------------------------------------------------------------------
+class _Arena:
+    def __init__(self):
+        self.chunks, self.off, self.n = [], {}, 0
+
+    def add(self, name, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
+        self.off[name] = self.n
+        pad = (-arr.size) % 4
+        self.chunks.append(np.concatenate([arr, np.zeros(pad, np.float32)]))
+        self.n += arr.size + pad
+        return self.off[name]
+
+    def tensor(self, device):
+        return torch.from_numpy(np.concatenate(self.chunks)).to(device)
+
+
+def _bn(u, j, ar, arrs, tag, bn_prefix, prelu_key):
+    u.bn[j].weight = ar.add(f"{j}w", arrs[f"{tag}/sd/{bn_prefix}.weight"])
+    u.bn[j].bias = ar.add(f"{j}b", arrs[f"{tag}/sd/{bn_prefix}.bias"])
+    u.bn[j].running_mean = ar.add(f"{j}m", arrs[f"{tag}/sd/{bn_prefix}.running_mean"])
+    u.bn[j].running_var = ar.add(f"{j}v", arrs[f"{tag}/sd/{bn_prefix}.running_var"])
+    u.bn[j].prelu = ar.add(f"{j}a", arrs[f"{tag}/sd/{prelu_key}"])
+
+
+def run_g4_case(lib, device, tag, meta, arrs):
+    """Returns list of (got, expected) per output branch."""
+    kind = meta["kind"]
+    ar = _Arena()
+    acts = [(1, 0)]
+    if kind == "cbr":
+        cin, cout, k, stride = meta["cin"], meta["cout"], meta["k"], meta["stride"]
+        xs = [arrs[f"{tag}/x{i}"] for i in range(len(cin))]
+        B, _, H, W = xs[0].shape
+        u = N.new_unit(N.UNIT_GOCT)
+        u.n_in, u.n_out, u.ksize, u.stride = len(cin), len(cout), k, stride
+        u.w_off[0] = ar.add("w", arrs[f"{tag}/sd/conv.weight"])
+        in_ids, out_ids = [], []
+        for i, c in enumerate(cin):
+            acts.append((c, i)); in_ids.append(len(acts) - 1)
+            u.cin[i], u.in_act[i] = c, in_ids[-1]
+        base = 1 if stride == 2 else 0
+        for j, c in enumerate(cout):
+            acts.append((c, base + j)); out_ids.append(len(acts) - 1)
+            u.cout[j], u.out_act[j] = c, out_ids[-1]
+            _bn(u, j, ar, arrs, tag, f"bns.{j}", f"prelus.{j}.weight")
+        eng = Engine(lib, [u], acts, B, H, W, device)
+        for i, a in enumerate(in_ids):
+            eng.activation(a).copy_(torch.from_numpy(xs[i]))
+        eng.refresh(ar.tensor(device))
+        eng.forward(torch.zeros(B, 1, H, W, device=device))
+        return [(eng.activation(a).cpu().numpy(), arrs[f"{tag}/y{j}"]) for j, a in enumerate(out_ids)]
+    if kind == "dw":
+        ch = meta["ch"]
+        xs = [arrs[f"{tag}/x{i}"] for i in range(len(ch))]
+        B, _, H, W = xs[0].shape
+        u = N.new_unit(N.UNIT_DW)
+        u.n_in = u.n_out = len(ch)
+        in_ids, out_ids = [], []
+        for i, c in enumerate(ch):
+            acts.append((c, i)); in_ids.append(len(acts) - 1)
+            acts.append((c, i)); out_ids.append(len(acts) - 1)
+            u.cin[i] = u.cout[i] = c
+            u.in_act[i], u.out_act[i] = in_ids[-1], out_ids[-1]
+            u.w_off[i] = ar.add(f"w{i}", arrs[f"{tag}/sd/convs.{i}.weight"])
+            _bn(u, i, ar, arrs, tag, f"bns.{i}", f"prelus.{i}.weight")
+        eng = Engine(lib, [u], acts, B, H, W, device)
+        for i, a in enumerate(in_ids):
+            eng.activation(a).copy_(torch.from_numpy(xs[i]))
+        eng.refresh(ar.tensor(device))
+        eng.forward(torch.zeros(B, 1, H, W, device=device))
+        return [(eng.activation(a).cpu().numpy(), arrs[f"{tag}/y{j}"]) for j, a in enumerate(out_ids)]
+    if kind == "ms":
+        x = arrs[f"{tag}/x0"]
+        B, cin, H, W = x.shape
+        dil = meta["dil"]
+        u = N.new_unit(N.UNIT_MS)
+        u.n_in = u.n_out = 1
+        u.cin[0], u.cout[0] = cin, sum(dil)
+        acts.append((cin, 0)); acts.append((sum(dil), 0))
+        u.in_act[0], u.out_act[0] = 1, 2
+        for d, c in enumerate(dil):
+            u.dil_ch[d] = c
+            if c:
+                u.w_off[d] = ar.add(f"w{d}", arrs[f"{tag}/sd/msconv.{d}.weight"])
+        _bn(u, 0, ar, arrs, tag, "bn", "prelu.weight")
+        eng = Engine(lib, [u], acts, B, H, W, device)
+        eng.activation(1).copy_(torch.from_numpy(x))
+        eng.refresh(ar.tensor(device))
+        eng.forward(torch.zeros(B, 1, H, W, device=device))
+        return [(eng.activation(2).cpu().numpy(), arrs[f"{tag}/y0"])]
+    if kind == "cls":
+        x = arrs[f"{tag}/x0"]
+        B, cin, h, w = x.shape
+        u = N.new_unit(N.UNIT_CLS)
+        u.n_in = u.n_out = 1
+        u.cin[0], u.cout[0] = cin, 1
+        acts.append((cin, 1))
+        u.in_act[0] = 1
+        u.w_off[0] = ar.add("w", arrs[f"{tag}/w"])
+        u.bias_off = ar.add("b", arrs[f"{tag}/b"])
+        eng = Engine(lib, [u], acts, B, 2 * h, 2 * w, device)
+        eng.activation(1).copy_(torch.from_numpy(x))
+        eng.refresh(ar.tensor(device))
+        y = eng.forward(torch.zeros(B, 1, 2 * h, 2 * w, device=device))
+        return [(y.cpu().numpy(), arrs[f"{tag}/y0"])]
+    raise ValueError(kind)
+
+
+def check_g4(lib, device):
+    meta = json.load(open(os.path.join(GOLD, "g4_ops_meta.json")))
+    arrs = np.load(os.path.join(GOLD, "g4_ops.npz"))
+    report = {}
+    for tag, mt in meta.items():
+        if mt["kind"] == "cbr" and len(mt["cin"]) == 1 and len(mt["cout"]) == 1:
+            continue  # Conv2dX100 std_conv branch: not on the shipped configs' path (checked separately)
+        worst = 0.0
+        for got, exp in run_g4_case(lib, device, tag, mt, arrs):
+            assert got.shape == exp.shape, (tag, got.shape, exp.shape)
+            scale = max(1.0, float(np.abs(exp).max()))
+            err = float(np.abs(got - exp).max()) / scale
+            assert err <= UNIT_TOL, f"{tag}: rel err {err:.3e}"
+            worst = max(worst, err)
+        report[tag] = worst
+    return report

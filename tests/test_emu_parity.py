@@ -1,0 +1,51 @@
+"""CPU-emulated kernels (same sources as libcsnet_hip.so, g++ + fibers) against goldens and oracle.
+
+No GPU is needed: this checks the index arithmetic / data flow of every kernel and of the plan before the
+MI355X run; the ``-m gpu`` twins in test_gpu_parity.py are the parity tests proper."""
+import torch
+
+from oracle import inputs as I
+
+import parity_cases as P
+
+CPU = torch.device("cpu")
+
+
+def test_emu_small_vs_oracle(emu_lib, x2_manifest):
+    P.check_vs_oracle(emu_lib, CPU, x2_manifest, torch.from_numpy(I.randn_batch(5, 2, 32, 48)))
+
+
+def test_emu_minimum_size_16(emu_lib, x2_manifest):
+    """16x16 input: the lowest branch is a single pixel (test.py:80-85 only demands multiples of 16)."""
+    P.check_vs_oracle(emu_lib, CPU, x2_manifest, torch.from_numpy(I.randn_batch(6, 3, 16, 16)))
+
+
+def test_emu_golden_224(emu_lib, x2_manifest):
+    x = torch.from_numpy(I.randn_batch(0, 2))
+    P.check_golden_logits(emu_lib, CPU, x2_manifest, "g2_logits_x2_randn_b2.npy", x)
+
+
+def test_emu_golden_nonsquare(emu_lib, x2_manifest):
+    x = torch.from_numpy(I.randn_batch(3, 2, 96, 160))
+    P.check_golden_logits(emu_lib, CPU, x2_manifest, "g2_logits_x2_randn_b2_96x160.npy", x)
+
+
+def test_emu_x1_config(emu_lib, x1_manifest):
+    x = torch.from_numpy(I.randn_batch(0, 2))[:1]
+    P.check_golden_logits(emu_lib, CPU, x1_manifest, "g2_logits_x1_randn_b1.npy", x)
+
+
+def test_emu_unit_probes(emu_lib, x2_manifest):
+    P.check_unit_probes(emu_lib, CPU, x2_manifest)
+
+
+def test_emu_op_goldens(emu_lib):
+    rep = P.check_g4(emu_lib, CPU)
+    assert len(rep) >= 11
+
+
+def test_emu_sub_batch_slicing(emu_lib, x2_manifest):
+    x = torch.from_numpy(I.randn_batch(7, 5, 32, 32))
+    y_full, _ = P.check_vs_oracle(emu_lib, CPU, x2_manifest, x, sub_batch=0)
+    y_sl, _ = P.check_vs_oracle(emu_lib, CPU, x2_manifest, x, sub_batch=2)   # 2+2+(overlapping last) slices
+    assert torch.equal(y_full, y_sl)
