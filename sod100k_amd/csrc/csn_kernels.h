@@ -49,11 +49,13 @@ struct DwArgs {
 // ---------------------------------------------------------------------------------------------
 #define PW_TY0 16
 #define PW_TX0 32
-#define PW_MAX_PASS 5
+#define PW_MAX_PASS 12
 struct PwSrc {
-  const float* ptr;  // [B][C][H_s][W_s], branch (r - shift)
-  int32_t C;
+  const float* ptr;  // first channel of the slice inside [B][Ctot][H_s][W_s], branch (r - shift)
+  int32_t C;         // channels of the slice
+  int32_t Ctot;      // channels of the whole tensor (image stride)
   int32_t shift;     // log2 of the max-pool window that brings it to the pass resolution (0,1,2)
+  int32_t pad;
 };
 struct PwZAdd {
   int32_t z_off;   // float offset of the region [nrows][ring px of branch rs] in LDS
@@ -62,7 +64,7 @@ struct PwZAdd {
 struct PwPass {
   int32_t r;        // branch whose pixels this pass walks
   int32_t nsrc;
-  PwSrc src[3];     // src[0] is the own-resolution input, the others are max-pooled on the fly
+  PwSrc src[3];     // channel slices; shift > 0 slices are max-pooled on the fly
   int32_t cin4;     // gathered channels rounded up to 4 (row stride of w)
   int32_t nrows;
   const float* w;   // packed [nrows][cin4]
@@ -74,14 +76,16 @@ struct PwPass {
   const float* alpha;
   int32_t nz;
   PwZAdd zadd[2];
+  int32_t acc_in;     // add the partial sums already stored at the destination (channel segments)
+  int32_t final_seg;  // last segment: add the z terms and apply the epilogue
 };
 struct PwArgs {
   PwPass pass[PW_MAX_PASS];
-  int32_t npass;       // z passes first, then main passes from the lowest resolution up; last = branch 0
+  int32_t npass;       // z passes first, then main passes from the lowest resolution up; branch 0 last
   int32_t nz_pass;     // number of leading z passes
   int32_t H0, W0;      // resolution of branch 0
   int32_t B;
-  int32_t top_ppl2;    // 1: the last pass (branch 0) runs two pixels per lane with MAXC_TOP registers
+  int32_t n_top;       // trailing passes of branch 0: two pixels per lane with MAXC_TOP registers
 };
 
 // ---------------------------------------------------------------------------------------------

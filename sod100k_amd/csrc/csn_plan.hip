@@ -1,6 +1,7 @@
 // csn_plan.hip -- host side of libcsnet_hip.so: plan construction, parameter packing jobs, workspace
 // layout and the launch sequence of CSNet.forward (CSNet/model/csnet.py:365-387) behind the C ABI of
 // include/csnet_hip.h.  No torch types; the caller owns every tensor.
+#include <algorithm>
 #include <new>
 #include <string>
 #include <vector>
@@ -45,8 +46,9 @@ struct Epi {  // float offsets into the packed buffer
 struct PwPassPlan {
   int r = 0;
   int nsrc = 0;
-  int src_branch[3] = {-1, -1, -1};
-  int src_C[3] = {0, 0, 0};
+  int src_branch[3] = {-1, -1, -1};  // unit input branch the channels come from
+  int src_c0[3] = {0, 0, 0};         // first channel of the slice inside that input
+  int src_C[3] = {0, 0, 0};          // channels of the slice
   int src_shift[3] = {0, 0, 0};
   int cin4 = 0, nrows = 0;
   int64_t w = -1;
@@ -56,6 +58,7 @@ struct PwPassPlan {
   int nz = 0;
   int zadd_off[2] = {0, 0};
   int zadd_rs[2] = {0, 0};
+  int acc_in = 0, final_seg = 1;     // channel segments: partial sums are accumulated in place
 };
 
 struct C3Plan {
@@ -81,7 +84,7 @@ struct UnitPlan {
   int64_t logits_off = -1;               // CLS: logits at H/2
   // GOCT 1x1 / CLS
   std::vector<PwPassPlan> pw;
-  int pw_nz = 0, maxc_top = 4, maxc_low = 4, top_ppl2 = 0;
+  int pw_nz = 0, maxc_top = 4, maxc_low = 4, n_top = 0;
   // GOCT 3x3
   std::vector<C3Plan> c3;
   // DW
@@ -149,6 +152,118 @@ bool bn_ok(const csn_bn_off& b) {
   return b.weight >= 0 && b.bias >= 0 && b.running_mean >= 0 && b.running_var >= 0 && b.prelu >= 0;
 }
 
+// Pass list of a 1x1 gOctConv unit (also cls_layer).  Gathered channels of a pass are cut into
+// segments of <= PW_SEG channels (register budget of the kernel); later segments accumulate in place.
+constexpr int PW_SEG = 64;
+
+struct PwChunk { int branch, c0, n, shift; };
+
+int build_pw_passes(Builder& bl, UnitPlan& u, int n_in, int n_out, const int32_t* cin, const int32_t* cout,
+                    int64_t w_off, int64_t ld, const Epi* epi) {
+  int ci_off[4] = {0}, co_off[4] = {0};
+  { int t = 0; for (int i = 0; i < n_in; ++i) { ci_off[i] = t; t += cin[i]; } }
+  { int t = 0; for (int j = 0; j < n_out; ++j) { co_off[j] = t; t += cout[j]; } }
+  int lds_fl = 0;
+  int z_region[3][3];
+  for (auto& r : z_region) for (int& v : r) v = -1;
+
+  auto split = [](const std::vector<PwChunk>& srcs) {
+    std::vector<PwChunk> chunks;
+    for (const PwChunk& s : srcs)
+      for (int c0 = 0; c0 < s.n; c0 += PW_SEG)
+        chunks.push_back(PwChunk{s.branch, s.c0 + c0, std::min(PW_SEG, s.n - c0), s.shift});
+    std::vector<std::vector<PwChunk>> segs;
+    for (const PwChunk& c : chunks) {
+      int tot = 0;
+      if (!segs.empty()) for (const PwChunk& q : segs.back()) tot += q.n;
+      if (segs.empty() || tot + c.n > PW_SEG || segs.back().size() >= 3) segs.emplace_back();
+      segs.back().push_back(c);
+    }
+    if (segs.empty()) segs.emplace_back();  // no input channels at all: rows come from the z terms only
+    return segs;
+  };
+  // rows [row0, row0+nr) of output branch j against the chunk's columns
+  auto pack = [&](PwPassPlan& ps, const std::vector<PwChunk>& seg, int j_first, int j_last_excl) {
+    int cols = 0;
+    ps.nsrc = (int)seg.size();
+    for (int s = 0; s < ps.nsrc; ++s) {
+      ps.src_branch[s] = seg[s].branch; ps.src_c0[s] = seg[s].c0; ps.src_C[s] = seg[s].n; ps.src_shift[s] = seg[s].shift;
+      cols += seg[s].n;
+    }
+    ps.cin4 = round4(cols);
+    ps.w = bl.alloc_packed((int64_t)ps.nrows * (ps.cin4 > 0 ? ps.cin4 : 4));
+    int row = 0;
+    for (int j = j_first; j < j_last_excl; ++j) {
+      if (cout[j] == 0) continue;
+      int col = 0;
+      for (int s = 0; s < ps.nsrc; ++s) {
+        bl.job(CSN_PREP_ROWS, cout[j], ps.w + (int64_t)row * ps.cin4,
+               w_off + (int64_t)co_off[j] * ld + ci_off[seg[s].branch] + seg[s].c0, -1, -1, -1, 1.f, (int)ld,
+               seg[s].n, ps.cin4, col);
+        col += seg[s].n;
+      }
+      row += cout[j];
+    }
+  };
+
+  // z passes: low->high blocks evaluated at the low resolution
+  for (int i = 1; i < n_in; ++i) {
+    if (cin[i] == 0) continue;
+    int nrows = 0;
+    for (int j = 0; j < i && j < n_out; ++j) nrows += cout[j];
+    if (nrows == 0) continue;
+    const int ring = ((PW_TY0 >> i) + 2) * ((PW_TX0 >> i) + 2);
+    int row = 0;
+    for (int j = 0; j < i && j < n_out; ++j) {
+      if (cout[j] == 0) continue;
+      z_region[i][j] = lds_fl + row * ring;
+      row += cout[j];
+    }
+    const auto segs = split({PwChunk{i, 0, cin[i], 0}});
+    for (size_t q = 0; q < segs.size(); ++q) {
+      PwPassPlan ps;
+      ps.r = i; ps.dest = 0; ps.z_off = lds_fl; ps.nrows = nrows;
+      ps.acc_in = q > 0; ps.final_seg = q + 1 == segs.size();
+      pack(ps, segs[q], 0, i < n_out ? i : n_out);
+      u.pw.push_back(ps);
+    }
+    lds_fl += nrows * ring;
+  }
+  u.pw_nz = (int)u.pw.size();
+  int max_low = 0, max_top = 0;
+  for (const PwPassPlan& ps : u.pw) max_low = std::max(max_low, ps.cin4);
+  for (int j = n_out - 1; j >= 0; --j) {
+    if (cout[j] == 0) continue;
+    std::vector<PwChunk> srcs;
+    if (j < n_in && cin[j] > 0) srcs.push_back(PwChunk{j, 0, cin[j], 0});
+    for (int i = 0; i < j && i < n_in; ++i)
+      if (cin[i] > 0) srcs.push_back(PwChunk{i, 0, cin[i], j - i});
+    const auto segs = split(srcs);
+    for (size_t q = 0; q < segs.size(); ++q) {
+      PwPassPlan ps;
+      ps.r = j; ps.dest = 1; ps.out_branch = j; ps.nrows = cout[j]; ps.epi = epi[j];
+      ps.acc_in = q > 0; ps.final_seg = q + 1 == segs.size();
+      pack(ps, segs[q], j, j + 1);
+      if (ps.final_seg)
+        for (int i = j + 1; i < n_in; ++i) {
+          if (cin[i] == 0 || z_region[i][j] < 0) continue;
+          if (ps.nz >= 2) FAIL(CSN_E_UNSUPPORTED, "more than two low->high sources");
+          ps.zadd_off[ps.nz] = z_region[i][j]; ps.zadd_rs[ps.nz] = i; ++ps.nz;
+        }
+      if (j == 0) max_top = std::max(max_top, ps.cin4); else max_low = std::max(max_low, ps.cin4);
+      u.pw.push_back(ps);
+    }
+  }
+  // branch-0 passes run two pixels per lane (MAXC_TOP registers each); everything else one pixel per lane
+  u.n_top = 0;
+  for (const PwPassPlan& ps : u.pw) if (ps.dest == 1 && ps.r == 0) ++u.n_top;
+  u.maxc_top = u.n_top == 0 ? 4 : max_top <= 16 ? 16 : max_top <= 32 ? 32 : max_top <= 48 ? 48 : 64;
+  u.maxc_low = ((int)u.pw.size() == u.n_top) ? 4 : max_low <= 32 ? 32 : 64;
+  if ((int)u.pw.size() > PW_MAX_PASS) FAIL(CSN_E_UNSUPPORTED, "too many passes");
+  if ((int64_t)lds_fl * 4 > 160 * 1024) FAIL(CSN_E_UNSUPPORTED, "LDS z regions exceed 160 KiB");
+  return CSN_OK;
+}
+
 int plan_goct(Builder& bl, UnitPlan& u) {
   csn_plan& P = bl.P;
   const csn_unit_desc& d = u.d;
@@ -190,81 +305,8 @@ int plan_goct(Builder& bl, UnitPlan& u) {
 
   if (d.ksize == 1) {
     u.kname = "goct_pw_kernel";
-    int lds_fl = 0;
-    int z_region[3][3];  // [i][j] float offset in LDS
-    for (auto& r : z_region) for (int& v : r) v = -1;
-    // z passes
-    for (int i = 1; i < d.n_in; ++i) {
-      if (d.cin[i] == 0) continue;
-      PwPassPlan ps;
-      ps.r = i; ps.nsrc = 1; ps.src_branch[0] = i; ps.src_C[0] = d.cin[i]; ps.src_shift[0] = 0;
-      ps.cin4 = round4(d.cin[i]); ps.dest = 0; ps.z_off = lds_fl;
-      const int ring = ((PW_TY0 >> i) + 2) * ((PW_TX0 >> i) + 2);
-      int nrows = 0;
-      for (int j = 0; j < i && j < d.n_out; ++j) nrows += d.cout[j];
-      if (nrows == 0) continue;
-      ps.nrows = nrows;
-      ps.w = bl.alloc_packed((int64_t)nrows * ps.cin4);
-      int row = 0;
-      for (int j = 0; j < i && j < d.n_out; ++j) {
-        if (d.cout[j] == 0) continue;
-        z_region[i][j] = lds_fl + row * ring;
-        bl.job(CSN_PREP_ROWS, d.cout[j], ps.w + (int64_t)row * ps.cin4, d.w_off[0] + (int64_t)co_off[j] * ld + ci_off[i],
-               -1, -1, -1, 1.f, (int)ld, d.cin[i], ps.cin4, 0);
-        row += d.cout[j];
-      }
-      lds_fl += nrows * ring;
-      u.pw.push_back(ps);
-    }
-    u.pw_nz = (int)u.pw.size();
-    int max_low = 0, top_c = 0;
-    bool has_top = false;
-    for (int j = d.n_out - 1; j >= 0; --j) {
-      if (d.cout[j] == 0) continue;
-      PwPassPlan ps;
-      ps.r = j; ps.dest = 1; ps.out_branch = j; ps.nrows = d.cout[j]; ps.epi = epi[j];
-      // src[0] = own resolution (may be absent), then pooled higher-resolution inputs
-      ps.nsrc = 1; ps.src_branch[0] = j; ps.src_C[0] = (j < d.n_in) ? d.cin[j] : 0; ps.src_shift[0] = 0;
-      int cols = ps.src_C[0];
-      for (int i = 0; i < j && i < d.n_in; ++i) {
-        if (d.cin[i] == 0) continue;
-        if (ps.nsrc >= 3) FAIL(CSN_E_UNSUPPORTED, "csn_plan.hip:231");
-        ps.src_branch[ps.nsrc] = i; ps.src_C[ps.nsrc] = d.cin[i]; ps.src_shift[ps.nsrc] = j - i;
-        cols += d.cin[i];
-        ++ps.nsrc;
-      }
-      ps.cin4 = round4(cols);
-      ps.w = bl.alloc_packed((int64_t)ps.nrows * (ps.cin4 > 0 ? ps.cin4 : 4));
-      int col = 0;
-      for (int s = 0; s < ps.nsrc; ++s) {
-        if (ps.src_C[s] == 0) continue;
-        const int i = ps.src_branch[s];
-        bl.job(CSN_PREP_ROWS, ps.nrows, ps.w, d.w_off[0] + (int64_t)co_off[j] * ld + ci_off[i], -1, -1, -1, 1.f,
-               (int)ld, d.cin[i], ps.cin4, col);
-        col += d.cin[i];
-      }
-      for (int i = j + 1; i < d.n_in; ++i) {
-        if (d.cin[i] == 0 || z_region[i][j] < 0) continue;
-        if (ps.nz >= 2) FAIL(CSN_E_UNSUPPORTED, "csn_plan.hip:248");
-        ps.zadd_off[ps.nz] = z_region[i][j]; ps.zadd_rs[ps.nz] = i; ++ps.nz;
-      }
-      if (j == 0) { has_top = true; top_c = ps.cin4; }
-      else if (ps.cin4 > max_low) max_low = ps.cin4;
-      u.pw.push_back(ps);
-    }
-    for (int q = 0; q < u.pw_nz; ++q) if (u.pw[q].cin4 > max_low) max_low = u.pw[q].cin4;
-    u.top_ppl2 = 0; u.maxc_top = 4;
-    if (has_top && top_c <= 80) {
-      u.top_ppl2 = 1;
-      u.maxc_top = top_c <= 16 ? 16 : top_c <= 32 ? 32 : top_c <= 48 ? 48 : top_c <= 64 ? 64 : 80;
-    } else if (has_top && top_c > max_low) {
-      max_low = top_c;
-    }
-    if (max_low > 160) FAIL(CSN_E_UNSUPPORTED, "csn_plan.hip:263");
-    u.maxc_low = max_low == 0 ? 4 : max_low <= 32 ? 32 : max_low <= 64 ? 64 : max_low <= 96 ? 96 : 160;
-    if (!u.top_ppl2 && u.maxc_low == 4) u.maxc_low = 32;
-    if ((int)u.pw.size() > PW_MAX_PASS) FAIL(CSN_E_UNSUPPORTED, "csn_plan.hip:266");
-    if ((int64_t)lds_fl * 4 > 160 * 1024) FAIL(CSN_E_UNSUPPORTED, "csn_plan.hip:267");
+    const int st = build_pw_passes(bl, u, d.n_in, d.n_out, d.cin, d.cout, d.w_off[0], ld, epi);
+    if (st != CSN_OK) return st;
   } else {
     u.kname = "conv3x3_kernel";
     if (d.n_in > 2 || d.n_out > 2) FAIL(CSN_E_UNSUPPORTED, "csn_plan.hip:270");
@@ -346,31 +388,18 @@ int plan_cls(Builder& bl, UnitPlan& u) {
   csn_plan& P = bl.P;
   const csn_unit_desc& d = u.d;
   u.kname = "goct_pw_kernel";
-  if (d.in_act[0] < 0 || d.w_off[0] < 0 || d.bias_off < 0) FAIL(CSN_E_INVALID, "csn_plan.hip:349");
+  if (d.in_act[0] < 0 || d.w_off[0] < 0 || d.bias_off < 0) FAIL(CSN_E_INVALID, "cls: missing tensors");
   const Act& ai = P.acts[d.in_act[0]];
-  if (ai.channels != d.cin[0] || ai.lvl != 1) FAIL(CSN_E_INVALID, "csn_plan.hip:351");  // csnet.py:380-385: fuse @ H/2
+  if (ai.channels != d.cin[0] || ai.lvl != 1) FAIL(CSN_E_INVALID, "cls: input must be at H/2");  // csnet.py:380-385
   u.base_lvl = 1;
   u.logits_off = bl.alloc_ws(bl.act_bytes(1, 1));
-  PwPassPlan ps;
-  ps.r = 0; ps.dest = 1; ps.nrows = 1; ps.nsrc = 1; ps.src_branch[0] = 0; ps.src_C[0] = d.cin[0];
-  ps.cin4 = round4(d.cin[0]);
-  ps.w = bl.alloc_packed(ps.cin4);
-  bl.job(CSN_PREP_ROWS, 1, ps.w, d.w_off[0], -1, -1, -1, 1.f, d.cin[0], d.cin[0], ps.cin4, 0);
-  ps.epi.scale = bl.alloc_packed(1); ps.epi.shift = bl.alloc_packed(1); ps.epi.alpha = bl.alloc_packed(1);
-  bl.job(CSN_PREP_FILL, 1, ps.epi.scale, -1, -1, -1, -1, 1.f);
-  bl.job(CSN_PREP_COPY, 1, ps.epi.shift, d.bias_off);
-  bl.job(CSN_PREP_FILL, 1, ps.epi.alpha, -1, -1, -1, -1, 1.f);
-  u.pw.push_back(ps);
-  u.pw_nz = 0;
-  if (ps.cin4 <= 80) {
-    u.top_ppl2 = 1; u.maxc_low = 4;
-    u.maxc_top = ps.cin4 <= 16 ? 16 : ps.cin4 <= 32 ? 32 : ps.cin4 <= 48 ? 48 : ps.cin4 <= 64 ? 64 : 80;
-  } else if (ps.cin4 <= 160) {
-    u.top_ppl2 = 0; u.maxc_top = 4; u.maxc_low = ps.cin4 <= 96 ? 96 : 160;
-  } else {
-    FAIL(CSN_E_UNSUPPORTED, "csn_plan.hip:371");
-  }
-  return CSN_OK;
+  Epi epi[3];
+  epi[0].scale = bl.alloc_packed(1); epi[0].shift = bl.alloc_packed(1); epi[0].alpha = bl.alloc_packed(1);
+  bl.job(CSN_PREP_FILL, 1, epi[0].scale, -1, -1, -1, -1, 1.f);
+  bl.job(CSN_PREP_COPY, 1, epi[0].shift, d.bias_off);
+  bl.job(CSN_PREP_FILL, 1, epi[0].alpha, -1, -1, -1, -1, 1.f);
+  const int32_t cin[3] = {d.cin[0], 0, 0}, cout[3] = {1, 0, 0};
+  return build_pw_passes(bl, u, 1, 1, cin, cout, d.w_off[0], d.cin[0], epi);
 }
 
 // ------------------------------------------------------------------------------------ execution
@@ -399,6 +428,39 @@ int choose_dw_rows(int H, int NY) {
     if (s > best_s + 1e-9) { best_s = s; best = R; }
   }
   return best;
+}
+
+int launch_pw(const Ctx& c, const UnitPlan& u, const float* const xin[3], float* const outp[3], int H0, int W0) {
+  PwArgs a;
+  a.npass = (int)u.pw.size(); a.nz_pass = u.pw_nz; a.n_top = u.n_top;
+  a.H0 = H0; a.W0 = W0; a.B = c.P.S;
+  for (int q = 0; q < a.npass; ++q) {
+    const PwPassPlan& pp = u.pw[q];
+    PwPass& ps = a.pass[q];
+    ps.r = pp.r; ps.nsrc = pp.nsrc;
+    for (int s = 0; s < 3; ++s) {
+      ps.src[s].ptr = nullptr; ps.src[s].C = 0; ps.src[s].Ctot = 0; ps.src[s].shift = 0; ps.src[s].pad = 0;
+      if (s < pp.nsrc && pp.src_C[s] > 0) {
+        const int br = pp.src_branch[s];
+        const int rs = pp.r - pp.src_shift[s];   // branch (resolution) of the source tensor
+        const int64_t hw = (int64_t)(H0 >> rs) * (W0 >> rs);
+        ps.src[s].ptr = xin[br] + (int64_t)pp.src_c0[s] * hw;
+        ps.src[s].C = pp.src_C[s];
+        ps.src[s].Ctot = u.d.kind == CSN_UNIT_CLS ? u.d.cin[0] : u.d.cin[br];
+        ps.src[s].shift = pp.src_shift[s];
+      }
+    }
+    ps.cin4 = pp.cin4; ps.nrows = pp.nrows; ps.w = c.pk(pp.w); ps.dest = pp.dest; ps.z_off = pp.z_off;
+    ps.out = pp.dest ? outp[pp.out_branch] : nullptr;
+    ps.scale = pp.dest ? c.pk(pp.epi.scale) : nullptr;
+    ps.shift = pp.dest ? c.pk(pp.epi.shift) : nullptr;
+    ps.alpha = pp.dest ? c.pk(pp.epi.alpha) : nullptr;
+    ps.nz = pp.nz;
+    for (int z = 0; z < 2; ++z) { ps.zadd[z].z_off = pp.zadd_off[z]; ps.zadd[z].rs = pp.zadd_rs[z]; }
+    ps.acc_in = pp.acc_in; ps.final_seg = pp.final_seg;
+  }
+  LAUNCH_TRY(csn_launch_pw(a, u.maxc_top, u.maxc_low, c.stream));
+  return CSN_OK;
 }
 
 int run_unit(const Ctx& c, const UnitPlan& u) {
@@ -455,27 +517,11 @@ int run_unit(const Ctx& c, const UnitPlan& u) {
           if (d.cin[i] > 0) xin[i] = c.act_in(d.in_act[i]);
       }
       if (d.ksize == 1) {
-        PwArgs a;
-        a.npass = (int)u.pw.size(); a.nz_pass = u.pw_nz; a.top_ppl2 = u.top_ppl2;
-        a.H0 = P.H >> u.base_lvl; a.W0 = P.W >> u.base_lvl; a.B = S;
-        for (int q = 0; q < a.npass; ++q) {
-          const PwPassPlan& pp = u.pw[q];
-          PwPass& ps = a.pass[q];
-          ps.r = pp.r; ps.nsrc = pp.nsrc;
-          for (int s = 0; s < 3; ++s) {
-            ps.src[s].ptr = (s < pp.nsrc && pp.src_C[s] > 0) ? xin[pp.src_branch[s]] : nullptr;
-            ps.src[s].C = s < pp.nsrc ? pp.src_C[s] : 0;
-            ps.src[s].shift = pp.src_shift[s];
-          }
-          ps.cin4 = pp.cin4; ps.nrows = pp.nrows; ps.w = c.pk(pp.w); ps.dest = pp.dest; ps.z_off = pp.z_off;
-          ps.out = pp.dest ? c.act_out(d.out_act[pp.out_branch]) : nullptr;
-          ps.scale = pp.dest ? c.pk(pp.epi.scale) : nullptr;
-          ps.shift = pp.dest ? c.pk(pp.epi.shift) : nullptr;
-          ps.alpha = pp.dest ? c.pk(pp.epi.alpha) : nullptr;
-          ps.nz = pp.nz;
-          for (int z = 0; z < 2; ++z) { ps.zadd[z].z_off = pp.zadd_off[z]; ps.zadd[z].rs = pp.zadd_rs[z]; }
-        }
-        LAUNCH_TRY(csn_launch_pw(a, u.maxc_top, u.maxc_low, c.stream));
+        float* outp[3] = {nullptr, nullptr, nullptr};
+        for (int j = 0; j < d.n_out; ++j)
+          if (d.cout[j] > 0) outp[j] = c.act_out(d.out_act[j]);
+        const int st = launch_pw(c, u, xin, outp, P.H >> u.base_lvl, P.W >> u.base_lvl);
+        if (st != CSN_OK) return st;
       } else {
         for (const C3Plan& cp : u.c3) {
           C3Args a;
@@ -512,22 +558,13 @@ int run_unit(const Ctx& c, const UnitPlan& u) {
       LAUNCH_TRY(csn_launch_ms(a, c.stream));
     } break;
     case CSN_UNIT_CLS: {
-      PwArgs a;
-      a.npass = 1; a.nz_pass = 0; a.top_ppl2 = u.top_ppl2;
-      a.H0 = P.H >> 1; a.W0 = P.W >> 1; a.B = S;
-      const PwPassPlan& pp = u.pw[0];
-      PwPass& ps = a.pass[0];
-      ps.r = 0; ps.nsrc = 1;
-      ps.src[0].ptr = c.act_in(d.in_act[0]); ps.src[0].C = pp.src_C[0]; ps.src[0].shift = 0;
-      ps.src[1].ptr = ps.src[2].ptr = nullptr; ps.src[1].C = ps.src[2].C = 0; ps.src[1].shift = ps.src[2].shift = 0;
-      ps.cin4 = pp.cin4; ps.nrows = 1; ps.w = c.pk(pp.w); ps.dest = 1; ps.z_off = 0;
-      ps.out = reinterpret_cast<float*>(c.ws + u.logits_off);
-      ps.scale = c.pk(pp.epi.scale); ps.shift = c.pk(pp.epi.shift); ps.alpha = c.pk(pp.epi.alpha);
-      ps.nz = 0;
-      for (int z = 0; z < 2; ++z) { ps.zadd[z].z_off = 0; ps.zadd[z].rs = 0; }
-      LAUNCH_TRY(csn_launch_pw(a, u.maxc_top, u.maxc_low, c.stream));
+      const float* xin[3] = {c.act_in(d.in_act[0]), nullptr, nullptr};
+      float* logits = reinterpret_cast<float*>(c.ws + u.logits_off);
+      float* outp[3] = {logits, nullptr, nullptr};
+      const int st = launch_pw(c, u, xin, outp, P.H >> 1, P.W >> 1);
+      if (st != CSN_OK) return st;
       Up2Args ua;
-      ua.in = ps.out; ua.out = c.y; ua.planes = S; ua.H = P.H; ua.W = P.W;
+      ua.in = logits; ua.out = c.y; ua.planes = S; ua.H = P.H; ua.W = P.W;
       LAUNCH_TRY(csn_launch_up2(ua, c.stream));
     } break;
     default:

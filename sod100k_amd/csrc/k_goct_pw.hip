@@ -39,27 +39,27 @@ __device__ __forceinline__ int pw_ring_rx(int r) { return (PW_TX0 >> r) + 2; }
 
 typedef const CSN_CONST_AS PwPass* PwPassP;
 
-// Gather the MAXC-bounded channel vector of pixel (y,x) (branch resolution Hr x Wr) of image b.
+// Gather the (<= MAXC) channel vector of pixel (y,x) (branch resolution Hr x Wr) of image b from up to three
+// channel slices; a slice with shift s lives at 2^s times the resolution and is max-pooled on the fly.
 template <int MAXC>
 __device__ __forceinline__ void pw_gather1(PwPassP ps, int b, int y, int x, int Hr, int Wr, float (&v)[1][MAXC]) {
   const int c1 = ps->src[0].C;
-  const int c2 = c1 + (ps->nsrc > 1 ? ps->src[1].C : 0);
-  const int c3 = c2 + (ps->nsrc > 2 ? ps->src[2].C : 0);
-  const float* __restrict__ p0 = ps->src[0].ptr + ((int64_t)b * c1 * Hr + y) * Wr + x;
-  const int64_t cs0 = (int64_t)Hr * Wr;
+  const int c2 = c1 + ps->src[1].C;
+  const int c3 = c2 + ps->src[2].C;
 #pragma unroll
   for (int k = 0; k < MAXC; ++k) {
     float val = 0.f;
-    if (k < c1) {
-      val = p0[k * cs0];
-    } else if (k < c3) {
-      const int s = (k < c2) ? 1 : 2;
-      const int sC = ps->src[s].C, sh = ps->src[s].shift;
-      const int ch = k - (s == 1 ? c1 : c2);
+    if (k < c3) {
+      const int s = (k < c1) ? 0 : (k < c2) ? 1 : 2;
+      const int ch = k - (s == 0 ? 0 : s == 1 ? c1 : c2);
+      const int sh = ps->src[s].shift;
       const int Ws = Wr << sh;
+      const int64_t hw = (int64_t)(Hr << sh) * Ws;
       const float* __restrict__ p =
-          ps->src[s].ptr + (((int64_t)b * sC + ch) * (Hr << sh) + ((int64_t)y << sh)) * Ws + (x << sh);
-      if (sh == 1) {
+          ps->src[s].ptr + ((int64_t)b * ps->src[s].Ctot + ch) * hw + ((int64_t)y << sh) * Ws + (x << sh);
+      if (sh == 0) {
+        val = p[0];
+      } else if (sh == 1) {
         const float2 a0 = *reinterpret_cast<const float2*>(p);
         const float2 a1 = *reinterpret_cast<const float2*>(p + Ws);
         val = fmaxf(fmaxf(a0.x, a0.y), fmaxf(a1.x, a1.y));
@@ -81,8 +81,8 @@ __device__ __forceinline__ void pw_gather1(PwPassP ps, int b, int y, int x, int 
 template <int MAXC>
 __device__ __forceinline__ void pw_gather2(PwPassP ps, int b, int y, int x, int Hr, int Wr, float (&v)[2][MAXC]) {
   const int c1 = ps->src[0].C;
-  const float* __restrict__ base = ps->src[0].ptr + ((int64_t)b * c1 * Hr + y) * Wr + x;
   const int64_t cs = (int64_t)Hr * Wr;
+  const float* __restrict__ base = ps->src[0].ptr + (int64_t)b * ps->src[0].Ctot * cs + (int64_t)y * Wr + x;
 #pragma unroll
   for (int k = 0; k < MAXC; ++k) {
     float2 q = make_float2(0.f, 0.f);
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void goct_pw_kernel(PwArgs a_byval) {
   const int b = blockIdx.z;
   const int ty0 = blockIdx.y * PW_TY0, tx0 = blockIdx.x * PW_TX0;  // tile origin at branch 0
   const int H0 = a->H0, W0 = a->W0;
-  const int nz_pass = a->nz_pass, npass = a->npass, top_ppl2 = a->top_ppl2;
+  const int nz_pass = a->nz_pass, npass = a->npass, n_top = a->n_top;
 
   // ---- z passes: low->high partial sums at low resolution, tile + ring, into LDS ----
   for (int pi = 0; pi < nz_pass; ++pi) {
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void goct_pw_kernel(PwArgs a_byval) {
     const int Hr = H0 >> r, Wr = W0 >> r;
     const int rx = pw_ring_rx(r), npx = pw_ring_px(r);
     const int oy = (ty0 >> r) - 1, ox = (tx0 >> r) - 1;
-    const int cin4 = ps->cin4, nrows = ps->nrows;
+    const int cin4 = ps->cin4, nrows = ps->nrows, acc_in = ps->acc_in;
     csn_cfp w = csn_const(ps->w);
     for (int p = tid; p < npx; p += CSN_BLOCK) {
       const int py = p / rx, px = p - py * rx;
@@ -198,20 +198,23 @@ __global__ __launch_bounds__(CSN_BLOCK) void goct_pw_kernel(PwArgs a_byval) {
       float v[1][MAXC_LOW];
       pw_gather1<MAXC_LOW>(ps, b, y, x, Hr, Wr, v);
       float* __restrict__ zp = lds + ps->z_off + p;
-      auto sink = [&](int row, const float (&acc)[1]) { zp[row * npx] = acc[0]; };
+      auto sink = [&](int row, const float (&acc)[1]) {
+        zp[row * npx] = acc_in ? zp[row * npx] + acc[0] : acc[0];
+      };
       pw_rows<MAXC_LOW, 1>(w, cin4, nrows, v, sink);
     }
   }
   if (nz_pass > 0) __syncthreads();
 
-  // ---- main passes, one pixel per lane (all branches below 0; branch 0 too when !top_ppl2) ----
-  const int n_low = top_ppl2 ? npass - 1 : npass;
-  for (int pi = nz_pass; pi < n_low; ++pi) {
+  // ---- main passes of the branches below 0: one pixel per lane ----
+  for (int pi = nz_pass; pi < npass - n_top; ++pi) {
     PwPassP ps = &a->pass[pi];
     const int r = ps->r;
     const int Hr = H0 >> r, Wr = W0 >> r;
     const int tx = PW_TX0 >> r, npx = (PW_TY0 >> r) * tx;
-    const int cin4 = ps->cin4, nrows = ps->nrows, nz = ps->nz;
+    const int cin4 = ps->cin4, nrows = ps->nrows;
+    const int acc_in = ps->acc_in, fin = ps->final_seg;
+    const int nz = fin ? ps->nz : 0;
     csn_cfp w = csn_const(ps->w);
     csn_cfp scale = csn_const(ps->scale), shift = csn_const(ps->shift), alpha = csn_const(ps->alpha);
     const int zrs0 = ps->zadd[0].rs, zrs1 = ps->zadd[1].rs;
@@ -229,23 +232,26 @@ __global__ __launch_bounds__(CSN_BLOCK) void goct_pw_kernel(PwArgs a_byval) {
       if (nz > 1) tap1 = pw_tap(y, x, r, zrs1, H0, W0, ty0, tx0);
       float* __restrict__ op = ps->out + ((int64_t)b * nrows * Hr + y) * Wr + x;
       const int64_t cs = (int64_t)Hr * Wr;
-      auto sink = [&](int row, const float (&a)[1]) {
-        float acc = a[0];
+      auto sink = [&](int row, const float (&acc_)[1]) {
+        float acc = acc_[0];
+        if (acc_in) acc += op[row * cs];
         if (nz > 0) acc += pw_tap_eval(zb0 + row * zs0, tap0);
         if (nz > 1) acc += pw_tap_eval(zb1 + row * zs1, tap1);
-        op[row * cs] = csn_epi(acc, scale[row], shift[row], alpha[row]);
+        op[row * cs] = fin ? csn_epi(acc, scale[row], shift[row], alpha[row]) : acc;
       };
       pw_rows<MAXC_LOW, 1>(w, cin4, nrows, v, sink);
     }
   }
 
-  // ---- main pass of branch 0: two pixels per lane (float2 loads / stores) ----
-  if (top_ppl2) {
-    PwPassP ps = &a->pass[npass - 1];
+  // ---- passes of branch 0: two pixels per lane (float2 loads / stores) ----
+  for (int pi = npass - n_top; pi < npass; ++pi) {
+    PwPassP ps = &a->pass[pi];
     constexpr int LXN = PW_TX0 / 2;
     const int py = tid / LXN, px = (tid - py * LXN) * 2;
     const int y = ty0 + py, x = tx0 + px;
-    const int cin4 = ps->cin4, nrows = ps->nrows, nz = ps->nz;
+    const int cin4 = ps->cin4, nrows = ps->nrows;
+    const int acc_in = ps->acc_in, fin = ps->final_seg;
+    const int nz = fin ? ps->nz : 0;
     csn_cfp w = csn_const(ps->w);
     csn_cfp scale = csn_const(ps->scale), shift = csn_const(ps->shift), alpha = csn_const(ps->alpha);
     const int zrs0 = ps->zadd[0].rs, zrs1 = ps->zadd[1].rs;
@@ -266,8 +272,13 @@ __global__ __launch_bounds__(CSN_BLOCK) void goct_pw_kernel(PwArgs a_byval) {
       }
       float* __restrict__ op = ps->out + ((int64_t)b * nrows * H0 + y) * W0 + x;
       const int64_t cs = (int64_t)H0 * W0;
-      auto sink = [&](int row, const float (&a)[2]) {
-        float a0 = a[0], a1 = a[1];
+      auto sink = [&](int row, const float (&acc_)[2]) {
+        float a0 = acc_[0], a1 = acc_[1];
+        if (acc_in) {
+          const float2 prev = *reinterpret_cast<const float2*>(op + row * cs);
+          a0 += prev.x;
+          a1 += prev.y;
+        }
         if (nz > 0) {
           a0 += pw_tap_eval(zb0 + row * zs0, ta0);
           a1 += pw_tap_eval(zb0 + row * zs0, tb0);
@@ -276,8 +287,12 @@ __global__ __launch_bounds__(CSN_BLOCK) void goct_pw_kernel(PwArgs a_byval) {
           a0 += pw_tap_eval(zb1 + row * zs1, ta1);
           a1 += pw_tap_eval(zb1 + row * zs1, tb1);
         }
-        const float sc = scale[row], sh = shift[row], al = alpha[row];
-        *reinterpret_cast<float2*>(op + row * cs) = make_float2(csn_epi(a0, sc, sh, al), csn_epi(a1, sc, sh, al));
+        if (fin) {
+          const float sc = scale[row], sh = shift[row], al = alpha[row];
+          a0 = csn_epi(a0, sc, sh, al);
+          a1 = csn_epi(a1, sc, sh, al);
+        }
+        *reinterpret_cast<float2*>(op + row * cs) = make_float2(a0, a1);
       };
       pw_rows<MAXC_TOP, 2>(w, cin4, nrows, v, sink);
     }
@@ -318,16 +333,12 @@ size_t csn_pw_lds_bytes(const PwArgs& a) {
     return (int)hipGetLastError();                                                                \
   }
 
-// maxc_top in {16, 32, 48, 64, 80} (4: branch 0 handled by the one-pixel-per-lane path, !top_ppl2);
-// maxc_low in {32, 64, 96, 160} (4: unit without lower branches)
+// maxc_top in {16, 32, 48, 64} (4: no branch-0 output); maxc_low in {32, 64} (4: unit without lower passes)
 int csn_launch_pw(const PwArgs& a, int maxc_top, int maxc_low, void* stream) {
   const dim3 grid((a.W0 + PW_TX0 - 1) / PW_TX0, (a.H0 + PW_TY0 - 1) / PW_TY0, a.B);
   const size_t lds = csn_pw_lds_bytes(a);
-  PW_CASE(16, 4) PW_CASE(32, 4) PW_CASE(48, 4) PW_CASE(64, 4) PW_CASE(80, 4)
-  PW_CASE(4, 32) PW_CASE(4, 64) PW_CASE(4, 96) PW_CASE(4, 160)
-  PW_CASE(16, 32) PW_CASE(32, 32) PW_CASE(48, 32) PW_CASE(64, 32)
-  PW_CASE(16, 64) PW_CASE(32, 64) PW_CASE(48, 64) PW_CASE(64, 64) PW_CASE(80, 64)
-  PW_CASE(16, 96) PW_CASE(32, 96) PW_CASE(48, 96) PW_CASE(64, 96) PW_CASE(80, 96)
-  PW_CASE(16, 160) PW_CASE(32, 160) PW_CASE(48, 160) PW_CASE(64, 160) PW_CASE(80, 160)
+  PW_CASE(16, 4) PW_CASE(32, 4) PW_CASE(48, 4) PW_CASE(64, 4)
+  PW_CASE(4, 32) PW_CASE(16, 32) PW_CASE(32, 32) PW_CASE(48, 32) PW_CASE(64, 32)
+  PW_CASE(4, 64) PW_CASE(16, 64) PW_CASE(32, 64) PW_CASE(48, 64) PW_CASE(64, 64)
   return -1;
 }

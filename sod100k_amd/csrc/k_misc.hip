@@ -91,6 +91,34 @@ __device__ __forceinline__ DwRow dw_load_row(const float* __restrict__ plane, in
   return r;
 }
 
+__device__ __forceinline__ void dw_emit(float* __restrict__ op, int y, int yend, int x0, int W, bool vec,
+                                        const float (&w)[9], float sc, float sh, float al, const DwRow& top,
+                                        const DwRow& mid, const DwRow& bot) {
+  if (y >= yend) return;
+  float o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float acc = w[0] * top.v[j];
+    acc = fmaf(w[1], top.v[j + 1], acc);
+    acc = fmaf(w[2], top.v[j + 2], acc);
+    acc = fmaf(w[3], mid.v[j], acc);
+    acc = fmaf(w[4], mid.v[j + 1], acc);
+    acc = fmaf(w[5], mid.v[j + 2], acc);
+    acc = fmaf(w[6], bot.v[j], acc);
+    acc = fmaf(w[7], bot.v[j + 1], acc);
+    acc = fmaf(w[8], bot.v[j + 2], acc);
+    o[j] = csn_epi(acc, sc, sh, al);
+  }
+  float* q = op + (int64_t)y * W + x0;
+  if (vec && x0 + 3 < W) {
+    *reinterpret_cast<float4*>(q) = make_float4(o[0], o[1], o[2], o[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (x0 + j < W) q[j] = o[j];
+  }
+}
+
 __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
   int bid = blockIdx.x;
   int k = 0;
@@ -119,35 +147,22 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
   for (int i = 0; i < 9; ++i) w[i] = w9[c * 9 + i];
   const float sc = csn_const(br.scale)[c], sh = csn_const(br.shift)[c], al = csn_const(br.alpha)[c];
 
-  DwRow top = dw_load_row(ip, y0 - 1, x0, H, W, vec);
-  DwRow mid = dw_load_row(ip, y0, x0, H, W, vec);
+  // rows are processed in chunks of 4 with all 4 new input rows (12 loads per lane) issued before the
+  // first FMA, so each lane keeps >= 12 vector loads in flight (latency-bound otherwise: SQ_WAIT_ANY 88 %)
+  DwRow r0 = dw_load_row(ip, y0 - 1, x0, H, W, vec);
+  DwRow r1 = dw_load_row(ip, y0, x0, H, W, vec);
   const int yend = min(y0 + br.R, H);
-  for (int y = y0; y < yend; ++y) {
-    const DwRow bot = dw_load_row(ip, y + 1, x0, H, W, vec);
-    float o[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float acc = w[0] * top.v[j];
-      acc = fmaf(w[1], top.v[j + 1], acc);
-      acc = fmaf(w[2], top.v[j + 2], acc);
-      acc = fmaf(w[3], mid.v[j], acc);
-      acc = fmaf(w[4], mid.v[j + 1], acc);
-      acc = fmaf(w[5], mid.v[j + 2], acc);
-      acc = fmaf(w[6], bot.v[j], acc);
-      acc = fmaf(w[7], bot.v[j + 1], acc);
-      acc = fmaf(w[8], bot.v[j + 2], acc);
-      o[j] = csn_epi(acc, sc, sh, al);
-    }
-    float* q = op + (int64_t)y * W + x0;
-    if (vec && x0 + 3 < W) {
-      *reinterpret_cast<float4*>(q) = make_float4(o[0], o[1], o[2], o[3]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (x0 + j < W) q[j] = o[j];
-    }
-    top = mid;
-    mid = bot;
+  for (int y = y0; y < yend; y += 4) {
+    const DwRow n0 = dw_load_row(ip, y + 1, x0, H, W, vec);
+    const DwRow n1 = dw_load_row(ip, y + 2, x0, H, W, vec);
+    const DwRow n2 = dw_load_row(ip, y + 3, x0, H, W, vec);
+    const DwRow n3 = dw_load_row(ip, y + 4, x0, H, W, vec);
+    dw_emit(op, y, yend, x0, W, vec, w, sc, sh, al, r0, r1, n0);
+    dw_emit(op, y + 1, yend, x0, W, vec, w, sc, sh, al, r1, n0, n1);
+    dw_emit(op, y + 2, yend, x0, W, vec, w, sc, sh, al, n0, n1, n2);
+    dw_emit(op, y + 3, yend, x0, W, vec, w, sc, sh, al, n1, n2, n3);
+    r0 = n2;
+    r1 = n3;
   }
 }
 
