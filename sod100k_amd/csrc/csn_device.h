@@ -43,6 +43,38 @@ __device__ __forceinline__ csn_cfp csn_const(const float* p) {
 
 #define CSN_BLOCK 256
 
+// Buffer-resource loads (CDNA "SRSRC" addressing): the wave-uniform base lives in 4 SGPRs, the per-lane
+// part is ONE 32-bit VGPR byte offset and a per-channel uniform byte offset rides in an SGPR, so a lane
+// needs a single address register for all channels of a gather.
+#ifdef CSN_CPU_EMU
+struct csn_buf { const char* p; };
+static inline csn_buf csn_make_buf(const float* p) { return csn_buf{reinterpret_cast<const char*>(p)}; }
+static inline float csn_ld1(csn_buf b, unsigned voff, unsigned soff) { return *reinterpret_cast<const float*>(b.p + voff + soff); }
+static inline float2 csn_ld2(csn_buf b, unsigned voff, unsigned soff) { return *reinterpret_cast<const float2*>(b.p + voff + soff); }
+static inline float4 csn_ld4(csn_buf b, unsigned voff, unsigned soff) {
+  const float* q = reinterpret_cast<const float*>(b.p + voff + soff);
+  return make_float4(q[0], q[1], q[2], q[3]);
+}
+#else
+typedef __amdgpu_buffer_rsrc_t csn_buf;
+typedef unsigned csn_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned csn_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ csn_buf csn_make_buf(const float* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0xffffffff, 0x00020000);
+}
+__device__ __forceinline__ float csn_ld1(csn_buf b, unsigned voff, unsigned soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b, voff, soff, 0));
+}
+__device__ __forceinline__ float2 csn_ld2(csn_buf b, unsigned voff, unsigned soff) {
+  const csn_u2 v = __builtin_amdgcn_raw_buffer_load_b64(b, voff, soff, 0);
+  return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+__device__ __forceinline__ float4 csn_ld4(csn_buf b, unsigned voff, unsigned soff) {
+  const csn_u4 v = __builtin_amdgcn_raw_buffer_load_b128(b, voff, soff, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+#endif
+
 // Folded epilogue of one output channel: y = z*scale + shift; y = y >= 0 ? y : alpha*y
 // (nn.BatchNorm2d in eval mode followed by nn.PReLU; for cls_layer scale=1, shift=bias, alpha=1).
 struct CsnEpi {

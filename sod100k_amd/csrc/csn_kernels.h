@@ -49,43 +49,38 @@ struct DwArgs {
 // ---------------------------------------------------------------------------------------------
 #define PW_TY0 16
 #define PW_TX0 32
-#define PW_MAX_PASS 12
+#define PW_MAX_PASS 3
+#define PW_MAX_GRID 2048
+enum PwMode { PW_OWN = 0, PW_POOL2 = 1, PW_POOL4 = 2, PW_UP2 = 3, PW_UP4 = 4 };
 struct PwSrc {
-  const float* ptr;  // first channel of the slice inside [B][Ctot][H_s][W_s], branch (r - shift)
+  const float* ptr;  // first channel of the slice inside [B][Ctot][H_s][W_s]
   int32_t C;         // channels of the slice
   int32_t Ctot;      // channels of the whole tensor (image stride)
-  int32_t shift;     // log2 of the max-pool window that brings it to the pass resolution (0,1,2)
+  int32_t mode;      // PwMode: how the slice is brought to the pass resolution
   int32_t pad;
 };
-struct PwZAdd {
-  int32_t z_off;   // float offset of the region [nrows][ring px of branch rs] in LDS
-  int32_t rs;      // source branch of the region
-};
 struct PwPass {
-  int32_t r;        // branch whose pixels this pass walks
+  int32_t r;          // branch whose pixels this pass walks (resolution H0>>r)
   int32_t nsrc;
-  PwSrc src[3];     // channel slices; shift > 0 slices are max-pooled on the fly
-  int32_t cin4;     // gathered channels rounded up to 4 (row stride of w)
-  int32_t nrows;
-  const float* w;   // packed [nrows][cin4]
-  int32_t dest;     // 0: LDS z region (ring tile, no epilogue)   1: global output with epilogue
-  int32_t z_off;    // dest 0: float offset in LDS
-  float* out;       // dest 1
+  PwSrc src[3];       // channel slices gathered per pixel, in weight-column order
+  int32_t cin;        // gathered channels
+  int32_t cin4;       // ... rounded up to 4
+  int32_t nrows;      // output channels
+  int32_t w_off;      // float offset of this pass's rows inside the unit's weight image
+  int32_t w_stride;   // row pitch of the weight image (floats): cin4 + 2, conflict-free A-operand reads
+  float* out;         // [B][nrows][H0>>r][W0>>r]
   const float* scale;
   const float* shift;
   const float* alpha;
-  int32_t nz;
-  PwZAdd zadd[2];
-  int32_t acc_in;     // add the partial sums already stored at the destination (channel segments)
-  int32_t final_seg;  // last segment: add the z terms and apply the epilogue
 };
 struct PwArgs {
   PwPass pass[PW_MAX_PASS];
-  int32_t npass;       // z passes first, then main passes from the lowest resolution up; branch 0 last
-  int32_t nz_pass;     // number of leading z passes
+  int32_t npass;
   int32_t H0, W0;      // resolution of branch 0
   int32_t B;
-  int32_t n_top;       // trailing passes of branch 0: two pixels per lane with MAXC_TOP registers
+  int32_t tiles_x, tiles_y;
+  int32_t wimg_floats; // multiple of 4
+  const float* wimg;   // weight image of all passes: rows padded to 16, pitch w_stride, zero filled
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -145,10 +140,9 @@ struct Up2Args {
 // launchers (implemented next to the kernels)
 int csn_launch_prep(const CsnPrepJob* jobs_dev, int njobs, const float* arena, float* packed, void* stream);
 int csn_launch_dw(const DwArgs& a, void* stream);
-int csn_launch_pw(const PwArgs& a, int maxc_top, int maxc_low, void* stream);
+int csn_launch_pw(const PwArgs& a, int maxnt, void* stream);
 int csn_launch_c3(const C3Args& a, void* stream);
 int csn_launch_ms(const MsArgs& a, void* stream);
 int csn_launch_pool(const PoolArgs& a, void* stream);
 int csn_launch_up2(const Up2Args& a, void* stream);
-size_t csn_pw_lds_bytes(const PwArgs& a);
 int csn_kernels_init(void);  // function attributes (max dynamic LDS)

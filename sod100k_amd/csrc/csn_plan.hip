@@ -47,18 +47,12 @@ struct PwPassPlan {
   int r = 0;
   int nsrc = 0;
   int src_branch[3] = {-1, -1, -1};  // unit input branch the channels come from
-  int src_c0[3] = {0, 0, 0};         // first channel of the slice inside that input
-  int src_C[3] = {0, 0, 0};          // channels of the slice
-  int src_shift[3] = {0, 0, 0};
-  int cin4 = 0, nrows = 0;
-  int64_t w = -1;
-  int dest = 1, z_off = 0;
+  int src_C[3] = {0, 0, 0};
+  int src_mode[3] = {0, 0, 0};       // PwMode
+  int cin = 0, cin4 = 0, nrows = 0;
+  int w_off = 0, w_stride = 0;       // inside the unit's weight image
   int out_branch = -1;
   Epi epi;
-  int nz = 0;
-  int zadd_off[2] = {0, 0};
-  int zadd_rs[2] = {0, 0};
-  int acc_in = 0, final_seg = 1;     // channel segments: partial sums are accumulated in place
 };
 
 struct C3Plan {
@@ -84,7 +78,8 @@ struct UnitPlan {
   int64_t logits_off = -1;               // CLS: logits at H/2
   // GOCT 1x1 / CLS
   std::vector<PwPassPlan> pw;
-  int pw_nz = 0, maxc_top = 4, maxc_low = 4, n_top = 0;
+  int64_t wimg = -1;   // packed-buffer offset of the weight image
+  int wimg_floats = 0;
   // GOCT 3x3
   std::vector<C3Plan> c3;
   // DW
@@ -152,115 +147,59 @@ bool bn_ok(const csn_bn_off& b) {
   return b.weight >= 0 && b.bias >= 0 && b.running_mean >= 0 && b.running_var >= 0 && b.prelu >= 0;
 }
 
-// Pass list of a 1x1 gOctConv unit (also cls_layer).  Gathered channels of a pass are cut into
-// segments of <= PW_SEG channels (register budget of the kernel); later segments accumulate in place.
-constexpr int PW_SEG = 64;
-
-struct PwChunk { int branch, c0, n, shift; };
-
+// Pass list of a 1x1 gOctConv unit (also cls_layer): one contraction per output branch over the gathered
+// vector [own ; max-pooled higher-resolution inputs ; bilinearly upsampled lower-resolution inputs].
+// All passes' weights live in ONE image (rows padded to 16, pitch cin4+2) that the kernel copies to LDS.
 int build_pw_passes(Builder& bl, UnitPlan& u, int n_in, int n_out, const int32_t* cin, const int32_t* cout,
                     int64_t w_off, int64_t ld, const Epi* epi) {
   int ci_off[4] = {0}, co_off[4] = {0};
   { int t = 0; for (int i = 0; i < n_in; ++i) { ci_off[i] = t; t += cin[i]; } }
   { int t = 0; for (int j = 0; j < n_out; ++j) { co_off[j] = t; t += cout[j]; } }
-  int lds_fl = 0;
-  int z_region[3][3];
-  for (auto& r : z_region) for (int& v : r) v = -1;
-
-  auto split = [](const std::vector<PwChunk>& srcs) {
-    std::vector<PwChunk> chunks;
-    for (const PwChunk& s : srcs)
-      for (int c0 = 0; c0 < s.n; c0 += PW_SEG)
-        chunks.push_back(PwChunk{s.branch, s.c0 + c0, std::min(PW_SEG, s.n - c0), s.shift});
-    std::vector<std::vector<PwChunk>> segs;
-    for (const PwChunk& c : chunks) {
-      int tot = 0;
-      if (!segs.empty()) for (const PwChunk& q : segs.back()) tot += q.n;
-      if (segs.empty() || tot + c.n > PW_SEG || segs.back().size() >= 3) segs.emplace_back();
-      segs.back().push_back(c);
-    }
-    if (segs.empty()) segs.emplace_back();  // no input channels at all: rows come from the z terms only
-    return segs;
-  };
-  // rows [row0, row0+nr) of output branch j against the chunk's columns
-  auto pack = [&](PwPassPlan& ps, const std::vector<PwChunk>& seg, int j_first, int j_last_excl) {
-    int cols = 0;
-    ps.nsrc = (int)seg.size();
-    for (int s = 0; s < ps.nsrc; ++s) {
-      ps.src_branch[s] = seg[s].branch; ps.src_c0[s] = seg[s].c0; ps.src_C[s] = seg[s].n; ps.src_shift[s] = seg[s].shift;
-      cols += seg[s].n;
-    }
-    ps.cin4 = round4(cols);
-    ps.w = bl.alloc_packed((int64_t)ps.nrows * (ps.cin4 > 0 ? ps.cin4 : 4));
-    int row = 0;
-    for (int j = j_first; j < j_last_excl; ++j) {
-      if (cout[j] == 0) continue;
-      int col = 0;
-      for (int s = 0; s < ps.nsrc; ++s) {
-        bl.job(CSN_PREP_ROWS, cout[j], ps.w + (int64_t)row * ps.cin4,
-               w_off + (int64_t)co_off[j] * ld + ci_off[seg[s].branch] + seg[s].c0, -1, -1, -1, 1.f, (int)ld,
-               seg[s].n, ps.cin4, col);
-        col += seg[s].n;
-      }
-      row += cout[j];
-    }
-  };
-
-  // z passes: low->high blocks evaluated at the low resolution
-  for (int i = 1; i < n_in; ++i) {
-    if (cin[i] == 0) continue;
-    int nrows = 0;
-    for (int j = 0; j < i && j < n_out; ++j) nrows += cout[j];
-    if (nrows == 0) continue;
-    const int ring = ((PW_TY0 >> i) + 2) * ((PW_TX0 >> i) + 2);
-    int row = 0;
-    for (int j = 0; j < i && j < n_out; ++j) {
-      if (cout[j] == 0) continue;
-      z_region[i][j] = lds_fl + row * ring;
-      row += cout[j];
-    }
-    const auto segs = split({PwChunk{i, 0, cin[i], 0}});
-    for (size_t q = 0; q < segs.size(); ++q) {
-      PwPassPlan ps;
-      ps.r = i; ps.dest = 0; ps.z_off = lds_fl; ps.nrows = nrows;
-      ps.acc_in = q > 0; ps.final_seg = q + 1 == segs.size();
-      pack(ps, segs[q], 0, i < n_out ? i : n_out);
-      u.pw.push_back(ps);
-    }
-    lds_fl += nrows * ring;
-  }
-  u.pw_nz = (int)u.pw.size();
-  int max_low = 0, max_top = 0;
-  for (const PwPassPlan& ps : u.pw) max_low = std::max(max_low, ps.cin4);
+  int img = 0;  // floats
   for (int j = n_out - 1; j >= 0; --j) {
     if (cout[j] == 0) continue;
-    std::vector<PwChunk> srcs;
-    if (j < n_in && cin[j] > 0) srcs.push_back(PwChunk{j, 0, cin[j], 0});
+    PwPassPlan ps;
+    ps.r = j; ps.out_branch = j; ps.nrows = cout[j]; ps.epi = epi[j];
+    auto add = [&](int branch, int mode) {
+      if (ps.nsrc >= 3) return false;
+      ps.src_branch[ps.nsrc] = branch; ps.src_C[ps.nsrc] = cin[branch]; ps.src_mode[ps.nsrc] = mode;
+      ps.cin += cin[branch];
+      ++ps.nsrc;
+      return true;
+    };
+    bool ok = true;
+    if (j < n_in && cin[j] > 0) ok = ok && add(j, PW_OWN);
     for (int i = 0; i < j && i < n_in; ++i)
-      if (cin[i] > 0) srcs.push_back(PwChunk{i, 0, cin[i], j - i});
-    const auto segs = split(srcs);
-    for (size_t q = 0; q < segs.size(); ++q) {
-      PwPassPlan ps;
-      ps.r = j; ps.dest = 1; ps.out_branch = j; ps.nrows = cout[j]; ps.epi = epi[j];
-      ps.acc_in = q > 0; ps.final_seg = q + 1 == segs.size();
-      pack(ps, segs[q], j, j + 1);
-      if (ps.final_seg)
-        for (int i = j + 1; i < n_in; ++i) {
-          if (cin[i] == 0 || z_region[i][j] < 0) continue;
-          if (ps.nz >= 2) FAIL(CSN_E_UNSUPPORTED, "more than two low->high sources");
-          ps.zadd_off[ps.nz] = z_region[i][j]; ps.zadd_rs[ps.nz] = i; ++ps.nz;
-        }
-      if (j == 0) max_top = std::max(max_top, ps.cin4); else max_low = std::max(max_low, ps.cin4);
-      u.pw.push_back(ps);
+      if (cin[i] > 0) {
+        if (j - i > 2) FAIL(CSN_E_UNSUPPORTED, "max-pool factor > 4");
+        ok = ok && add(i, j - i == 1 ? PW_POOL2 : PW_POOL4);
+      }
+    for (int i = j + 1; i < n_in; ++i)
+      if (cin[i] > 0) {
+        if (i - j > 2) FAIL(CSN_E_UNSUPPORTED, "bilinear factor > 4");
+        ok = ok && add(i, i - j == 1 ? PW_UP2 : PW_UP4);
+      }
+    if (!ok || ps.nsrc == 0) FAIL(CSN_E_INVALID, "output branch without inputs / too many inputs");
+    ps.cin4 = round4(ps.cin);
+    ps.w_stride = ps.cin4 + 2;   // == 2 (mod 4): the 64 A-operand addresses of an MFMA hit 32 distinct banks twice
+    ps.w_off = img;
+    img += ((ps.nrows + 15) & ~15) * ps.w_stride;
+    img = (img + 3) & ~3;
+    u.pw.push_back(ps);
+  }
+  if ((int)u.pw.size() > PW_MAX_PASS) FAIL(CSN_E_UNSUPPORTED, "too many passes");
+  if (((int64_t)img + 4 * 16 * 64) * 4 > 160 * 1024) FAIL(CSN_E_UNSUPPORTED, "weight image exceeds the LDS of a CU");
+  u.wimg_floats = img;
+  u.wimg = bl.alloc_packed(img);
+  for (const PwPassPlan& ps : u.pw) {
+    int col = 0;
+    for (int s = 0; s < ps.nsrc; ++s) {
+      const int br = ps.src_branch[s];
+      bl.job(CSN_PREP_ROWS, ps.nrows, u.wimg + ps.w_off, w_off + (int64_t)co_off[ps.out_branch] * ld + ci_off[br],
+             -1, -1, -1, 1.f, (int)ld, cin[br], ps.w_stride, col);
+      col += cin[br];
     }
   }
-  // branch-0 passes run two pixels per lane (MAXC_TOP registers each); everything else one pixel per lane
-  u.n_top = 0;
-  for (const PwPassPlan& ps : u.pw) if (ps.dest == 1 && ps.r == 0) ++u.n_top;
-  u.maxc_top = u.n_top == 0 ? 4 : max_top <= 16 ? 16 : max_top <= 32 ? 32 : max_top <= 48 ? 48 : 64;
-  u.maxc_low = ((int)u.pw.size() == u.n_top) ? 4 : max_low <= 32 ? 32 : 64;
-  if ((int)u.pw.size() > PW_MAX_PASS) FAIL(CSN_E_UNSUPPORTED, "too many passes");
-  if ((int64_t)lds_fl * 4 > 160 * 1024) FAIL(CSN_E_UNSUPPORTED, "LDS z regions exceed 160 KiB");
   return CSN_OK;
 }
 
@@ -432,34 +371,48 @@ int choose_dw_rows(int H, int NY) {
 
 int launch_pw(const Ctx& c, const UnitPlan& u, const float* const xin[3], float* const outp[3], int H0, int W0) {
   PwArgs a;
-  a.npass = (int)u.pw.size(); a.nz_pass = u.pw_nz; a.n_top = u.n_top;
+  a.npass = (int)u.pw.size();
   a.H0 = H0; a.W0 = W0; a.B = c.P.S;
+  a.tiles_x = (W0 + PW_TX0 - 1) / PW_TX0; a.tiles_y = (H0 + PW_TY0 - 1) / PW_TY0;
+  a.wimg = c.pk(u.wimg); a.wimg_floats = u.wimg_floats;
   for (int q = 0; q < a.npass; ++q) {
     const PwPassPlan& pp = u.pw[q];
     PwPass& ps = a.pass[q];
     ps.r = pp.r; ps.nsrc = pp.nsrc;
     for (int s = 0; s < 3; ++s) {
-      ps.src[s].ptr = nullptr; ps.src[s].C = 0; ps.src[s].Ctot = 0; ps.src[s].shift = 0; ps.src[s].pad = 0;
-      if (s < pp.nsrc && pp.src_C[s] > 0) {
+      ps.src[s].ptr = nullptr; ps.src[s].C = 0; ps.src[s].Ctot = 0; ps.src[s].mode = PW_OWN; ps.src[s].pad = 0;
+      if (s < pp.nsrc) {
         const int br = pp.src_branch[s];
-        const int rs = pp.r - pp.src_shift[s];   // branch (resolution) of the source tensor
-        const int64_t hw = (int64_t)(H0 >> rs) * (W0 >> rs);
-        ps.src[s].ptr = xin[br] + (int64_t)pp.src_c0[s] * hw;
-        ps.src[s].C = pp.src_C[s];
-        ps.src[s].Ctot = u.d.kind == CSN_UNIT_CLS ? u.d.cin[0] : u.d.cin[br];
-        ps.src[s].shift = pp.src_shift[s];
+        ps.src[s].ptr = xin[br]; ps.src[s].C = pp.src_C[s]; ps.src[s].Ctot = pp.src_C[s]; ps.src[s].mode = pp.src_mode[s];
       }
     }
-    ps.cin4 = pp.cin4; ps.nrows = pp.nrows; ps.w = c.pk(pp.w); ps.dest = pp.dest; ps.z_off = pp.z_off;
-    ps.out = pp.dest ? outp[pp.out_branch] : nullptr;
-    ps.scale = pp.dest ? c.pk(pp.epi.scale) : nullptr;
-    ps.shift = pp.dest ? c.pk(pp.epi.shift) : nullptr;
-    ps.alpha = pp.dest ? c.pk(pp.epi.alpha) : nullptr;
-    ps.nz = pp.nz;
-    for (int z = 0; z < 2; ++z) { ps.zadd[z].z_off = pp.zadd_off[z]; ps.zadd[z].rs = pp.zadd_rs[z]; }
-    ps.acc_in = pp.acc_in; ps.final_seg = pp.final_seg;
+    ps.cin = pp.cin; ps.cin4 = pp.cin4; ps.nrows = pp.nrows; ps.w_off = pp.w_off; ps.w_stride = pp.w_stride;
+    ps.out = outp[pp.out_branch];
+    ps.scale = c.pk(pp.epi.scale); ps.shift = c.pk(pp.epi.shift); ps.alpha = c.pk(pp.epi.alpha);
   }
-  LAUNCH_TRY(csn_launch_pw(a, u.maxc_top, u.maxc_low, c.stream));
+  int maxrows = 0;
+  for (const PwPassPlan& pp : u.pw) maxrows = std::max(maxrows, pp.nrows);
+  (void)maxrows;
+  if (a.npass > 1 && (int64_t)u.wimg_floats * 4 > 24 * 1024) {
+    // a large weight image would cap the occupancy through LDS: one launch per output branch instead
+    // (the shared high-resolution input is then re-read through L2 / Infinity Cache)
+    for (int q = 0; q < (int)u.pw.size(); ++q) {
+      PwArgs one = a;
+      one.npass = 1;
+      one.pass[0] = a.pass[q];
+      const int rows16 = (one.pass[0].nrows + 15) & ~15;
+      one.wimg = a.wimg + one.pass[0].w_off;
+      one.wimg_floats = (rows16 * one.pass[0].w_stride + 3) & ~3;
+      one.pass[0].w_off = 0;
+      // re-base the launch on this pass's own resolution so that its tiles are full 16x32 tiles
+      one.H0 = H0 >> one.pass[0].r; one.W0 = W0 >> one.pass[0].r;
+      one.pass[0].r = 0;
+      one.tiles_x = (one.W0 + PW_TX0 - 1) / PW_TX0; one.tiles_y = (one.H0 + PW_TY0 - 1) / PW_TY0;
+      LAUNCH_TRY(csn_launch_pw(one, 2, c.stream));
+    }
+    return CSN_OK;
+  }
+  LAUNCH_TRY(csn_launch_pw(a, 2, c.stream));
   return CSN_OK;
 }
 

@@ -7,338 +7,313 @@
 //       i <  j : conv( max_pool_{2^(j-i)}(x_i) )               (708-714)  "high -> low"
 //   gOctaveCBR.forward 778-792:   PReLU_j(BN_j(y_j)) per output branch (eval BN folded to scale/shift)
 //   also used for cls_layer (1x1 + bias, csnet.py:306-308,381) with scale=1, shift=bias, alpha=1.
+// A 1x1 convolution commutes with bilinear interpolation (both linear, the conv acts on channels only), so
+// the low->high term is evaluated as conv(bilinear_up(x_i)): every output branch becomes ONE contraction
+// over the gathered vector [x_j ; maxpool(x_i<j) ; bilinear(x_i>j)] of its pixel -- no partial sums to
+// exchange between resolutions and no barrier in the main loop.
 //
-// MI355X mapping.  A block owns a 16x32 tile of branch 0 and the matching 8x16 / 4x8 tiles of
-// branches 1 / 2.  Work is a short list of *passes*; a pass walks the pixels of one branch, gathers
-// the input channels of that pixel into VGPRs exactly once (own-resolution channels plus channels
-// max-pooled on the fly from the higher-resolution inputs), and then produces output rows one pair at
-// a time: every row is a dot product of the register-resident inputs with a weight row that the whole
-// wave shares, so weights stream through the scalar cache (s_load) and feed v_fmac as SGPR operands.
-//   z pass   (branch i > 0): rows of the low->high blocks W[co_j, ci_i] evaluated at low resolution
-//            on the tile plus a 1-pixel ring, written to LDS (never to HBM);
-//   main pass (branch j)   : rows of [W_jj | W_ij (i<j, pooled)] + bilinear taps of the LDS z regions
-//            (i>j) -> folded BN -> PReLU -> one coalesced store per output channel.
-// Every input element is fetched from HBM once per unit (the high-res input is read by the branch-0
-// pass and again, max-pooled, by the lower pass of the same block -> L2 hit), every output element is
-// written once: algorithmic bytes == HBM bytes.
+// MI355X mapping.  A block owns a 16x32 tile of branch 0 plus the matching 8x16 / 4x8 tiles of branches
+// 1 / 2 and walks tiles grid-stride.  Work items are 64-pixel groups; the 4 waves of a block take groups
+// round-robin and never synchronise with each other after the weight image has been staged in LDS:
+//   gather   16 input channels at a time: every lane fetches ITS pixel (own resolution: one coalesced dword
+//            per channel; max-pool / bilinear taps hit L1/L2 -- their HBM bytes are paid by the pass that
+//            owns that resolution) in straight-line, unrolled loops so that 8-16 loads are in flight per
+//            lane, and drops the values into the wave's private LDS panel x[k][64 px];
+//   contract v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain): A = W[row0 + (lane&15)][k0 + (lane>>4)] and
+//            B = x[k0 + (lane>>4)][16 s + (lane&15)] are single conflict-free ds_read_b32 each, one A
+//            register feeds the 4 pixel sub-groups, accumulators (<= 64 rows x 64 px) stay in VGPRs across
+//            the channel chunks; the matrix pipe does the FMAs, VALU only addressing + epilogue;
+//   store    folded BN + PReLU, 16 consecutive pixels of a row per 16-lane group.
+// All loops are run-time: one kernel for every channel plan.  HBM traffic = unit inputs once + outputs once.
 #include "csn_kernels.h"
 
-template <int R>
-struct PwTile {
-  static constexpr int TY = PW_TY0 >> R;
-  static constexpr int TX = PW_TX0 >> R;
-  static constexpr int RY = TY + 2;
-  static constexpr int RX = TX + 2;
-  static constexpr int RING = RY * RX;
+#ifdef CSN_CPU_EMU
+struct csn_f4 {
+  float v[4];
+  float& operator[](int i) { return v[i]; }
+  float operator[](int i) const { return v[i]; }
 };
+// lanes of a wave run as sequential fibers: make LDS hand-offs inside a wave visible
+#define CSN_WAVE_SYNC() __syncthreads()
+#else
+typedef float csn_f4 __attribute__((ext_vector_type(4)));
+// a wave executes in lockstep and its LDS operations retire in order: only stop the compiler from
+// moving LDS accesses across the hand-off
+#define CSN_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
 
-__device__ __forceinline__ int pw_ring_px(int r) {
-  return ((PW_TY0 >> r) + 2) * ((PW_TX0 >> r) + 2);
+#define PW_KC 16  // channels per LDS panel
+
+// acc[i] += sum_{u<4} W[row0 + (lane>>4)*4 + i][k0 + u] * x[k0 + u][16 s + (lane&15)]
+// wt = &W[row0][k0] in the LDS weight image (row pitch `stride`), xs = &x[k0][16 s] in the wave's panel.
+__device__ __forceinline__ void pw_mfma16(const float* wt, int stride, const float* xs, int lane, csn_f4& acc) {
+#ifdef CSN_CPU_EMU
+  const int col = lane & 15;
+  for (int i = 0; i < 4; ++i) {
+    const int row = (lane >> 4) * 4 + i;
+    float a = acc[i];
+    for (int u = 0; u < 4; ++u) a = fmaf(wt[row * stride + u], xs[u * 64 + col], a);
+    acc[i] = a;
+  }
+#else
+  const float av = wt[(lane & 15) * stride + (lane >> 4)];
+  const float bv = xs[(lane >> 4) * 64 + (lane & 15)];
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+#endif
 }
-__device__ __forceinline__ int pw_ring_rx(int r) { return (PW_TX0 >> r) + 2; }
 
 typedef const CSN_CONST_AS PwPass* PwPassP;
 
-// Gather the (<= MAXC) channel vector of pixel (y,x) (branch resolution Hr x Wr) of image b from up to three
-// channel slices; a slice with shift s lives at 2^s times the resolution and is max-pooled on the fly.
-template <int MAXC>
-__device__ __forceinline__ void pw_gather1(PwPassP ps, int b, int y, int x, int Hr, int Wr, float (&v)[1][MAXC]) {
-  const int c1 = ps->src[0].C;
-  const int c2 = c1 + ps->src[1].C;
-  const int c3 = c2 + ps->src[2].C;
+// Gather channels [c_lo, c_hi) of one slice for this lane's pixel into the panel rows starting at xrow
+// (`rmax` rows are left in the panel).  Loads go through a buffer resource whose base is channel c_lo of
+// image b (wave-uniform, SGPRs); the lane contributes one 32-bit byte offset, the channel a uniform SGPR
+// offset.  Every batch issues ALL its loads before the first use (fixed trip count, channel index clamped
+// instead of predicated: a predicated load would be waited for at the join), so a lane has 16-32 loads
+// in flight; rows written past the slice are overwritten by the next slice / the zero padding.
+template <int NB>
+__device__ __forceinline__ void pw_batch_own(csn_buf rb, unsigned lo, unsigned cs4, int k0, int n, int rmax,
+                                             float* xrow) {
+  float v[NB];
 #pragma unroll
-  for (int k = 0; k < MAXC; ++k) {
-    float val = 0.f;
-    if (k < c3) {
-      const int s = (k < c1) ? 0 : (k < c2) ? 1 : 2;
-      const int ch = k - (s == 0 ? 0 : s == 1 ? c1 : c2);
-      const int sh = ps->src[s].shift;
-      const int Ws = Wr << sh;
-      const int64_t hw = (int64_t)(Hr << sh) * Ws;
-      const float* __restrict__ p =
-          ps->src[s].ptr + ((int64_t)b * ps->src[s].Ctot + ch) * hw + ((int64_t)y << sh) * Ws + (x << sh);
-      if (sh == 0) {
-        val = p[0];
-      } else if (sh == 1) {
-        const float2 a0 = *reinterpret_cast<const float2*>(p);
-        const float2 a1 = *reinterpret_cast<const float2*>(p + Ws);
-        val = fmaxf(fmaxf(a0.x, a0.y), fmaxf(a1.x, a1.y));
-      } else {
-        float m = -3.402823466e+38f;
+  for (int j = 0; j < NB; ++j) v[j] = csn_ld1(rb, lo, (unsigned)min(k0 + j, n - 1) * cs4);
 #pragma unroll
-        for (int yy = 0; yy < 4; ++yy) {
-          const float4 q = *reinterpret_cast<const float4*>(p + (int64_t)yy * Ws);
-          m = fmaxf(m, fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)));
-        }
-        val = m;
-      }
+  for (int j = 0; j < NB; ++j)
+    if (k0 + j < rmax) xrow[(k0 + j) * 64] = v[j];
+}
+
+template <int NB>
+__device__ __forceinline__ void pw_batch_pool2(csn_buf rb, unsigned lo, unsigned cs4, unsigned ws4, int k0, int n,
+                                               int rmax, float* xrow) {
+  float2 a0[NB], a1[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const unsigned so = (unsigned)min(k0 + j, n - 1) * cs4;
+    a0[j] = csn_ld2(rb, lo, so);
+    a1[j] = csn_ld2(rb, lo, so + ws4);
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+    if (k0 + j < rmax) xrow[(k0 + j) * 64] = fmaxf(fmaxf(a0[j].x, a0[j].y), fmaxf(a1[j].x, a1[j].y));
+}
+
+template <int NB>
+__device__ __forceinline__ void pw_batch_pool4(csn_buf rb, unsigned lo, unsigned cs4, unsigned ws4, int k0, int n,
+                                               int rmax, float* xrow) {
+  float4 q[NB][4];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const unsigned so = (unsigned)min(k0 + j, n - 1) * cs4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) q[j][r] = csn_ld4(rb, lo, so + r * ws4);
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    float m = -3.402823466e+38f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m = fmaxf(m, fmaxf(fmaxf(q[j][r].x, q[j][r].y), fmaxf(q[j][r].z, q[j][r].w)));
+    if (k0 + j < rmax) xrow[(k0 + j) * 64] = m;
+  }
+}
+
+template <int NB>
+__device__ __forceinline__ void pw_batch_up(csn_buf rb, unsigned o00, unsigned o01, unsigned o10, unsigned o11,
+                                            float w00, float w01, float w10, float w11, unsigned cs4, int k0, int n,
+                                            int rmax, float* xrow) {
+  float t0[NB], t1[NB], t2[NB], t3[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const unsigned so = (unsigned)min(k0 + j, n - 1) * cs4;
+    t0[j] = csn_ld1(rb, o00, so);
+    t1[j] = csn_ld1(rb, o01, so);
+    t2[j] = csn_ld1(rb, o10, so);
+    t3[j] = csn_ld1(rb, o11, so);
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+    if (k0 + j < rmax) xrow[(k0 + j) * 64] = w00 * t0[j] + w01 * t1[j] + w10 * t2[j] + w11 * t3[j];
+}
+
+__device__ __forceinline__ void pw_gather_slice(PwPassP ps, int s, int c_lo, int c_hi, float* xrow, int rmax, int b,
+                                                int y, int x, int Hr, int Wr) {
+  const int mode = ps->src[s].mode;
+  const int n = c_hi - c_lo;   // 1..16
+  if (mode == PW_OWN) {
+    const unsigned cs = (unsigned)(Hr * Wr);
+    const csn_buf rb = csn_make_buf(ps->src[s].ptr + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
+    const unsigned lo = (unsigned)(y * Wr + x) * 4u;
+    if (n <= 8) pw_batch_own<8>(rb, lo, cs * 4u, 0, n, rmax, xrow);
+    else pw_batch_own<16>(rb, lo, cs * 4u, 0, n, rmax, xrow);
+  } else if (mode == PW_POOL2) {
+    const unsigned Ws = (unsigned)Wr * 2u;
+    const unsigned cs = (unsigned)(Hr * 2) * Ws;
+    const csn_buf rb = csn_make_buf(ps->src[s].ptr + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
+    const unsigned lo = ((unsigned)(2 * y) * Ws + 2u * x) * 4u;
+    for (int k0 = 0; k0 < n; k0 += 8) pw_batch_pool2<8>(rb, lo, cs * 4u, Ws * 4u, k0, n, rmax, xrow);
+  } else if (mode == PW_POOL4) {
+    const unsigned Ws = (unsigned)Wr * 4u;
+    const unsigned cs = (unsigned)(Hr * 4) * Ws;
+    const csn_buf rb = csn_make_buf(ps->src[s].ptr + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
+    const unsigned lo = ((unsigned)(4 * y) * Ws + 4u * x) * 4u;
+    for (int k0 = 0; k0 < n; k0 += 2) pw_batch_pool4<2>(rb, lo, cs * 4u, Ws * 4u, k0, n, rmax, xrow);
+  } else {  // bilinear from a 2x / 4x coarser branch, align_corners=False
+    const int sh = mode == PW_UP2 ? 1 : 2;
+    const int Hs = Hr >> sh, Ws = Wr >> sh;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    csn_bilin(y, mode == PW_UP2 ? 0.5f : 0.25f, Hs, y0, y1, ly);
+    csn_bilin(x, mode == PW_UP2 ? 0.5f : 0.25f, Ws, x0, x1, lx);
+    const unsigned cs = (unsigned)(Hs * Ws);
+    const csn_buf rb = csn_make_buf(ps->src[s].ptr + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
+    const unsigned o00 = (unsigned)(y0 * Ws + x0) * 4u, o01 = (unsigned)(y0 * Ws + x1) * 4u,
+                   o10 = (unsigned)(y1 * Ws + x0) * 4u, o11 = (unsigned)(y1 * Ws + x1) * 4u;
+    const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+    for (int k0 = 0; k0 < n; k0 += 8)
+      pw_batch_up<8>(rb, o00, o01, o10, o11, w00, w01, w10, w11, cs * 4u, k0, n, rmax, xrow);
+  }
+}
+
+// NT row tiles (16 rows each) x 4 pixel sub-groups against the `kn` (multiple of 4) channels of the panel.
+template <int NT, int MAXNT>
+__device__ __forceinline__ void pw_contract(const float* wl, int stride, const float* xb, int kn, int lane,
+                                            csn_f4 (&acc)[MAXNT][4]) {
+  for (int k0 = 0; k0 < kn; k0 += 4) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) pw_mfma16(wl + (16 * t) * stride + k0, stride, xb + k0 * 64 + 16 * s, lane, acc[t][s]);
     }
-    v[0][k] = val;
   }
 }
 
-// Two horizontally adjacent pixels (x even) of the own-resolution source only (branch-0 pass).
-template <int MAXC>
-__device__ __forceinline__ void pw_gather2(PwPassP ps, int b, int y, int x, int Hr, int Wr, float (&v)[2][MAXC]) {
-  const int c1 = ps->src[0].C;
-  const int64_t cs = (int64_t)Hr * Wr;
-  const float* __restrict__ base = ps->src[0].ptr + (int64_t)b * ps->src[0].Ctot * cs + (int64_t)y * Wr + x;
-#pragma unroll
-  for (int k = 0; k < MAXC; ++k) {
-    float2 q = make_float2(0.f, 0.f);
-    if (k < c1) q = *reinterpret_cast<const float2*>(base + k * cs);
-    v[0][k] = q.x;
-    v[1][k] = q.y;
-  }
-}
-
-// Row engine.  Output rows are produced two at a time from the register-resident channel vectors of
-// NPX pixels (2*NPX independent accumulation chains); the weight rows are wave-uniform and stream
-// through the scalar cache.  Channel groups of 4 beyond cin4 are skipped by a uniform branch.
-template <int MAXC, int NPX, class Sink>
-__device__ __forceinline__ void pw_rows(csn_cfp w, int cin4, int nrows, const float (&v)[NPX][MAXC], Sink& sink) {
-  int row = 0;
-  for (; row + 2 <= nrows; row += 2) {
-    float a0[NPX], a1[NPX];
-#pragma unroll
-    for (int p = 0; p < NPX; ++p) a0[p] = a1[p] = 0.f;
-    csn_cfp w0 = w + row * cin4;
-    csn_cfp w1 = w0 + cin4;
-#pragma unroll
-    for (int k0 = 0; k0 < MAXC; k0 += 4) {
-      if (k0 < cin4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float wa = w0[k0 + u], wb = w1[k0 + u];
-#pragma unroll
-          for (int p = 0; p < NPX; ++p) {
-            a0[p] = fmaf(wa, v[p][k0 + u], a0[p]);
-            a1[p] = fmaf(wb, v[p][k0 + u], a1[p]);
-          }
-        }
-      }
-    }
-    sink(row, a0);
-    sink(row + 1, a1);
-  }
-  if (row < nrows) {
-    float a0[NPX];
-#pragma unroll
-    for (int p = 0; p < NPX; ++p) a0[p] = 0.f;
-    csn_cfp w0 = w + row * cin4;
-#pragma unroll
-    for (int k0 = 0; k0 < MAXC; k0 += 4) {
-      if (k0 < cin4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float wa = w0[k0 + u];
-#pragma unroll
-          for (int p = 0; p < NPX; ++p) a0[p] = fmaf(wa, v[p][k0 + u], a0[p]);
-        }
-      }
-    }
-    sink(row, a0);
-  }
-}
-
-// Bilinear tap set of one destination pixel into an LDS z region of source branch rs.
-struct PwTap {
-  int i00, i01, i10, i11;
-  float w00, w01, w10, w11;
-};
-
-__device__ __forceinline__ PwTap pw_tap(int y, int x, int r, int rs, int H0, int W0, int ty0, int tx0) {
-  const int d = rs - r;
-  const float inv_f = d == 1 ? 0.5f : 0.25f;
-  int y0, y1, x0, x1;
-  float ly, lx;
-  csn_bilin(y, inv_f, H0 >> rs, y0, y1, ly);
-  csn_bilin(x, inv_f, W0 >> rs, x0, x1, lx);
-  const int oy = (ty0 >> rs) - 1, ox = (tx0 >> rs) - 1;  // image coords of ring cell (0,0)
-  const int rx = pw_ring_rx(rs);
-  PwTap t;
-  t.i00 = (y0 - oy) * rx + (x0 - ox);
-  t.i01 = (y0 - oy) * rx + (x1 - ox);
-  t.i10 = (y1 - oy) * rx + (x0 - ox);
-  t.i11 = (y1 - oy) * rx + (x1 - ox);
-  t.w00 = (1.f - ly) * (1.f - lx);
-  t.w01 = (1.f - ly) * lx;
-  t.w10 = ly * (1.f - lx);
-  t.w11 = ly * lx;
-  return t;
-}
-
-__device__ __forceinline__ float pw_tap_eval(const float* __restrict__ z, const PwTap& t) {
-  return t.w00 * z[t.i00] + t.w01 * z[t.i01] + t.w10 * z[t.i10] + t.w11 * z[t.i11];
-}
-
-template <int MAXC_TOP, int MAXC_LOW>
-__global__ __launch_bounds__(CSN_BLOCK) void goct_pw_kernel(PwArgs a_byval) {
+template <int MAXNT>
+__global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
   CSN_DYN_SMEM(float, lds);
   const CSN_CONST_AS PwArgs* a = CSN_KERNARG(PwArgs, a_byval);
   const int tid = threadIdx.x;
-  const int b = blockIdx.z;
-  const int ty0 = blockIdx.y * PW_TY0, tx0 = blockIdx.x * PW_TX0;  // tile origin at branch 0
-  const int H0 = a->H0, W0 = a->W0;
-  const int nz_pass = a->nz_pass, npass = a->npass, n_top = a->n_top;
-
-  // ---- z passes: low->high partial sums at low resolution, tile + ring, into LDS ----
-  for (int pi = 0; pi < nz_pass; ++pi) {
-    PwPassP ps = &a->pass[pi];
-    const int r = ps->r;
-    const int Hr = H0 >> r, Wr = W0 >> r;
-    const int rx = pw_ring_rx(r), npx = pw_ring_px(r);
-    const int oy = (ty0 >> r) - 1, ox = (tx0 >> r) - 1;
-    const int cin4 = ps->cin4, nrows = ps->nrows, acc_in = ps->acc_in;
-    csn_cfp w = csn_const(ps->w);
-    for (int p = tid; p < npx; p += CSN_BLOCK) {
-      const int py = p / rx, px = p - py * rx;
-      const int y = oy + py, x = ox + px;
-      if (y < 0 || y >= Hr || x < 0 || x >= Wr) continue;  // never sampled (indices are clamped)
-      float v[1][MAXC_LOW];
-      pw_gather1<MAXC_LOW>(ps, b, y, x, Hr, Wr, v);
-      float* __restrict__ zp = lds + ps->z_off + p;
-      auto sink = [&](int row, const float (&acc)[1]) {
-        zp[row * npx] = acc_in ? zp[row * npx] + acc[0] : acc[0];
-      };
-      pw_rows<MAXC_LOW, 1>(w, cin4, nrows, v, sink);
-    }
+  // ---- stage the unit's weight image (all passes, rows padded to 16, zero filled) into LDS once ----
+  {
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(a->wimg);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    const int n4 = a->wimg_floats >> 2;
+    for (int i = tid; i < n4; i += CSN_BLOCK) dst[i] = src[i];
   }
-  if (nz_pass > 0) __syncthreads();
+  __syncthreads();
 
-  // ---- main passes of the branches below 0: one pixel per lane ----
-  for (int pi = nz_pass; pi < npass - n_top; ++pi) {
-    PwPassP ps = &a->pass[pi];
-    const int r = ps->r;
-    const int Hr = H0 >> r, Wr = W0 >> r;
-    const int tx = PW_TX0 >> r, npx = (PW_TY0 >> r) * tx;
-    const int cin4 = ps->cin4, nrows = ps->nrows;
-    const int acc_in = ps->acc_in, fin = ps->final_seg;
-    const int nz = fin ? ps->nz : 0;
-    csn_cfp w = csn_const(ps->w);
-    csn_cfp scale = csn_const(ps->scale), shift = csn_const(ps->shift), alpha = csn_const(ps->alpha);
-    const int zrs0 = ps->zadd[0].rs, zrs1 = ps->zadd[1].rs;
-    const float* __restrict__ zb0 = lds + ps->zadd[0].z_off;
-    const float* __restrict__ zb1 = lds + ps->zadd[1].z_off;
-    const int zs0 = pw_ring_px(zrs0), zs1 = pw_ring_px(zrs1);
-    for (int p = tid; p < npx; p += CSN_BLOCK) {
-      const int py = p / tx, px = p - py * tx;
-      const int y = (ty0 >> r) + py, x = (tx0 >> r) + px;
-      if (y >= Hr || x >= Wr) continue;
-      float v[1][MAXC_LOW];
-      pw_gather1<MAXC_LOW>(ps, b, y, x, Hr, Wr, v);
-      PwTap tap0, tap1;
-      if (nz > 0) tap0 = pw_tap(y, x, r, zrs0, H0, W0, ty0, tx0);
-      if (nz > 1) tap1 = pw_tap(y, x, r, zrs1, H0, W0, ty0, tx0);
-      float* __restrict__ op = ps->out + ((int64_t)b * nrows * Hr + y) * Wr + x;
-      const int64_t cs = (int64_t)Hr * Wr;
-      auto sink = [&](int row, const float (&acc_)[1]) {
-        float acc = acc_[0];
-        if (acc_in) acc += op[row * cs];
-        if (nz > 0) acc += pw_tap_eval(zb0 + row * zs0, tap0);
-        if (nz > 1) acc += pw_tap_eval(zb1 + row * zs1, tap1);
-        op[row * cs] = fin ? csn_epi(acc, scale[row], shift[row], alpha[row]) : acc;
-      };
-      pw_rows<MAXC_LOW, 1>(w, cin4, nrows, v, sink);
-    }
-  }
-
-  // ---- passes of branch 0: two pixels per lane (float2 loads / stores) ----
-  for (int pi = npass - n_top; pi < npass; ++pi) {
-    PwPassP ps = &a->pass[pi];
-    constexpr int LXN = PW_TX0 / 2;
-    const int py = tid / LXN, px = (tid - py * LXN) * 2;
-    const int y = ty0 + py, x = tx0 + px;
-    const int cin4 = ps->cin4, nrows = ps->nrows;
-    const int acc_in = ps->acc_in, fin = ps->final_seg;
-    const int nz = fin ? ps->nz : 0;
-    csn_cfp w = csn_const(ps->w);
-    csn_cfp scale = csn_const(ps->scale), shift = csn_const(ps->shift), alpha = csn_const(ps->alpha);
-    const int zrs0 = ps->zadd[0].rs, zrs1 = ps->zadd[1].rs;
-    const float* __restrict__ zb0 = lds + ps->zadd[0].z_off;
-    const float* __restrict__ zb1 = lds + ps->zadd[1].z_off;
-    const int zs0 = pw_ring_px(zrs0), zs1 = pw_ring_px(zrs1);
-    if (y < H0 && x < W0) {
-      float v[2][MAXC_TOP];
-      pw_gather2<MAXC_TOP>(ps, b, y, x, H0, W0, v);
-      PwTap ta0, tb0, ta1, tb1;
-      if (nz > 0) {
-        ta0 = pw_tap(y, x, 0, zrs0, H0, W0, ty0, tx0);
-        tb0 = pw_tap(y, x + 1, 0, zrs0, H0, W0, ty0, tx0);
+  const int wave = tid >> 6, lane = tid & 63;
+  float* xb = lds + a->wimg_floats + wave * (PW_KC * 64);   // this wave's x[k][64] panel
+  const int H0 = a->H0, W0 = a->W0, npass = a->npass;
+  const int tiles_xy = a->tiles_x * a->tiles_y;
+  const int ntiles = tiles_xy * a->B;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / tiles_xy;
+    const int txy = tile - b * tiles_xy;
+    const int ty0 = (txy / a->tiles_x) * PW_TY0, tx0 = (txy % a->tiles_x) * PW_TX0;
+    int gbase = 0;  // running group index over the outputs of the unit -> wave assignment
+    for (int pi = 0; pi < npass; ++pi) {
+      PwPassP ps = &a->pass[pi];
+      const int r = ps->r;
+      const int Hr = H0 >> r, Wr = W0 >> r;
+      const int txl = 5 - r;  // log2(PW_TX0 >> r)
+      const int npx = (PW_TY0 >> r) << txl;
+      const int ng = (npx + 63) >> 6;
+      const int cin = ps->cin, cin4 = ps->cin4, nrows = ps->nrows, stride = ps->w_stride;
+      const float* wl0 = lds + ps->w_off;
+      const int c1 = ps->src[0].C, c2 = c1 + ps->src[1].C;
+      for (int c = 0; c < ng; ++c) {
+        if (((gbase + c) & 3) != wave) continue;
+        // pixel this lane gathers
+        const int p = (c << 6) + lane;
+        const int gy = min((ty0 >> r) + (p >> txl), Hr - 1), gx = min((tx0 >> r) + (p & ((1 << txl) - 1)), Wr - 1);
+        const int py_ = (ty0 >> r) + (p >> txl), px_ = (tx0 >> r) + (p & ((1 << txl) - 1));
+        const bool valid = p < npx && py_ < Hr && px_ < Wr;
+        const int64_t cs = (int64_t)Hr * Wr;
+        float* __restrict__ ob = ps->out + (int64_t)b * nrows * cs + (int64_t)gy * Wr + gx;
+        for (int row0 = 0; row0 < nrows; row0 += 16 * MAXNT) {
+          csn_f4 acc[MAXNT][4];
+#pragma unroll
+          for (int t = 0; t < MAXNT; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[t][s][i] = 0.f;
+          const int nt = min(MAXNT, (nrows - row0 + 15) >> 4);
+          for (int kc = 0; kc < cin4; kc += PW_KC) {
+            const int kend = min(kc + PW_KC, cin4);
+            CSN_WAVE_SYNC();  // previous panel fully consumed
+            // channels [kc, kend) of the gathered vector -> panel rows 0..
+            if (kc < c1) pw_gather_slice(ps, 0, kc, min(kend, c1), xb + lane, PW_KC, b, gy, gx, Hr, Wr);
+            if (max(kc, c1) < min(kend, c2)) {
+              const int r0 = max(kc, c1) - kc;
+              pw_gather_slice(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xb + r0 * 64 + lane, PW_KC - r0, b, gy, gx,
+                              Hr, Wr);
+            }
+            if (max(kc, c2) < min(kend, cin)) {
+              const int r0 = max(kc, c2) - kc;
+              pw_gather_slice(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xb + r0 * 64 + lane, PW_KC - r0, b, gy, gx,
+                              Hr, Wr);
+            }
+            for (int k = max(cin, kc); k < kend; ++k) xb[(k - kc) * 64 + lane] = 0.f;  // pad to a multiple of 4
+            CSN_WAVE_SYNC();  // panel complete
+            const float* wl = wl0 + row0 * stride + kc;
+            if (nt == 1) pw_contract<1, MAXNT>(wl, stride, xb, kend - kc, lane, acc);
+            else if (nt == 2) pw_contract<2, MAXNT>(wl, stride, xb, kend - kc, lane, acc);
+            else if constexpr (MAXNT > 2) {
+              if (nt == 3) pw_contract<3, MAXNT>(wl, stride, xb, kend - kc, lane, acc);
+              else pw_contract<4, MAXNT>(wl, stride, xb, kend - kc, lane, acc);
+            }
+          }
+          // epilogue: transpose each 16-row tile through the (now free) panel so that every lane gets ITS
+          // pixel back and a wave stores 256 contiguous bytes per output channel
+#pragma unroll
+          for (int t = 0; t < MAXNT; ++t) {
+            if (t < nt) {
+              CSN_WAVE_SYNC();
+#pragma unroll
+              for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xb[((lane >> 4) * 4 + i) * 64 + 16 * s + (lane & 15)] = acc[t][s][i];
+              CSN_WAVE_SYNC();
+              const int rbase = row0 + 16 * t;
+              const int rn = min(16, nrows - rbase);
+              csn_cfp scale = csn_const(ps->scale) + rbase, shift = csn_const(ps->shift) + rbase,
+                      alpha = csn_const(ps->alpha) + rbase;
+              float* __restrict__ orow = ob + (int64_t)rbase * cs;
+#pragma unroll 4
+              for (int rr = 0; rr < rn; ++rr) {
+                const float val = csn_epi(xb[rr * 64 + lane], scale[rr], shift[rr], alpha[rr]);
+                if (valid) orow[rr * cs] = val;
+              }
+            }
+          }
+        }
       }
-      if (nz > 1) {
-        ta1 = pw_tap(y, x, 0, zrs1, H0, W0, ty0, tx0);
-        tb1 = pw_tap(y, x + 1, 0, zrs1, H0, W0, ty0, tx0);
-      }
-      float* __restrict__ op = ps->out + ((int64_t)b * nrows * H0 + y) * W0 + x;
-      const int64_t cs = (int64_t)H0 * W0;
-      auto sink = [&](int row, const float (&acc_)[2]) {
-        float a0 = acc_[0], a1 = acc_[1];
-        if (acc_in) {
-          const float2 prev = *reinterpret_cast<const float2*>(op + row * cs);
-          a0 += prev.x;
-          a1 += prev.y;
-        }
-        if (nz > 0) {
-          a0 += pw_tap_eval(zb0 + row * zs0, ta0);
-          a1 += pw_tap_eval(zb0 + row * zs0, tb0);
-        }
-        if (nz > 1) {
-          a0 += pw_tap_eval(zb1 + row * zs1, ta1);
-          a1 += pw_tap_eval(zb1 + row * zs1, tb1);
-        }
-        if (fin) {
-          const float sc = scale[row], sh = shift[row], al = alpha[row];
-          a0 = csn_epi(a0, sc, sh, al);
-          a1 = csn_epi(a1, sc, sh, al);
-        }
-        *reinterpret_cast<float2*>(op + row * cs) = make_float2(a0, a1);
-      };
-      pw_rows<MAXC_TOP, 2>(w, cin4, nrows, v, sink);
+      gbase += ng;
     }
   }
 }
 
-size_t csn_pw_lds_bytes(const PwArgs& a) {
-  size_t fl = 0;
-  for (int pi = 0; pi < a.nz_pass; ++pi) {
-    const PwPass& ps = a.pass[pi];
-    const size_t ring = (size_t)((PW_TY0 >> ps.r) + 2) * ((PW_TX0 >> ps.r) + 2);
-    const size_t end = (size_t)ps.z_off + ring * ps.nrows;
-    if (end > fl) fl = end;
-  }
-  return fl * sizeof(float);
-}
-
-#ifdef CSN_CPU_EMU
-#define PW_ATTR(T, L)
-#else
-// instantiations that need more than the default 64 KiB of dynamic LDS (fuse1x1: 79 rows x (180+60) ring
-// cells) are allowed the full 160 KiB of a CDNA4 CU; set once per instantiation
-#define PW_ATTR(T, L)                                                                             \
-  {                                                                                               \
-    static bool done = false;                                                                     \
-    if (!done && lds > 64 * 1024) {                                                               \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&goct_pw_kernel<T, L>),    \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      if (e != hipSuccess) return (int)e;                                                         \
-      done = true;                                                                                \
-    }                                                                                             \
+// maxnt: 2 (every pass has <= 32 output channels: 32 accumulator VGPRs) or 4 (<= 64 per sweep)
+int csn_launch_pw(const PwArgs& a, int maxnt, void* stream) {
+  const int ntiles = a.tiles_x * a.tiles_y * a.B;
+  const dim3 grid(ntiles < PW_MAX_GRID ? ntiles : PW_MAX_GRID);
+  const size_t lds = ((size_t)a.wimg_floats + 4 * PW_KC * 64) * sizeof(float);
+#ifndef CSN_CPU_EMU
+  static bool attr_done = false;
+  if (!attr_done) {
+    // units with a large weight image may use the full 160 KiB of LDS of a CDNA4 CU
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&goct_pw_kernel<2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&goct_pw_kernel<4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
   }
 #endif
-#define PW_CASE(T, L)                                                                             \
-  if (maxc_top == T && maxc_low == L) {                                                           \
-    PW_ATTR(T, L)                                                                                 \
-    CSN_LAUNCH((goct_pw_kernel<T, L>), grid, dim3(CSN_BLOCK), lds, stream, a);                    \
-    return (int)hipGetLastError();                                                                \
+  if (maxnt <= 2) {
+    CSN_LAUNCH((goct_pw_kernel<2>), grid, dim3(CSN_BLOCK), lds, stream, a);
+  } else {
+    CSN_LAUNCH((goct_pw_kernel<4>), grid, dim3(CSN_BLOCK), lds, stream, a);
   }
-
-// maxc_top in {16, 32, 48, 64} (4: no branch-0 output); maxc_low in {32, 64} (4: unit without lower passes)
-int csn_launch_pw(const PwArgs& a, int maxc_top, int maxc_low, void* stream) {
-  const dim3 grid((a.W0 + PW_TX0 - 1) / PW_TX0, (a.H0 + PW_TY0 - 1) / PW_TY0, a.B);
-  const size_t lds = csn_pw_lds_bytes(a);
-  PW_CASE(16, 4) PW_CASE(32, 4) PW_CASE(48, 4) PW_CASE(64, 4)
-  PW_CASE(4, 32) PW_CASE(16, 32) PW_CASE(32, 32) PW_CASE(48, 32) PW_CASE(64, 32)
-  PW_CASE(4, 64) PW_CASE(16, 64) PW_CASE(32, 64) PW_CASE(48, 64) PW_CASE(64, 64)
-  return -1;
+  return (int)hipGetLastError();
 }
