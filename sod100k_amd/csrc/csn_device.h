@@ -47,12 +47,23 @@ __device__ __forceinline__ csn_cfp csn_const(const float* p) {
 // part is ONE 32-bit VGPR byte offset and a per-channel uniform byte offset rides in an SGPR, so a lane
 // needs a single address register for all channels of a gather.
 #ifdef CSN_CPU_EMU
-struct csn_buf { const char* p; };
-static inline csn_buf csn_make_buf(const float* p) { return csn_buf{reinterpret_cast<const char*>(p)}; }
-static inline float csn_ld1(csn_buf b, unsigned voff, unsigned soff) { return *reinterpret_cast<const float*>(b.p + voff + soff); }
-static inline float2 csn_ld2(csn_buf b, unsigned voff, unsigned soff) { return *reinterpret_cast<const float2*>(b.p + voff + soff); }
+struct csn_buf { const char* p; unsigned n; };
+static inline csn_buf csn_make_buf(const float* p) { return csn_buf{reinterpret_cast<const char*>(p), 0xffffffffu}; }
+// bounded resource: loads whose byte offset is >= nbytes return 0 (the hardware's out-of-range rule)
+static inline csn_buf csn_make_buf_n(const float* p, unsigned nbytes) { return csn_buf{reinterpret_cast<const char*>(p), nbytes}; }
+static inline float csn_ld1(csn_buf b, unsigned voff, unsigned soff) {
+  const unsigned o = voff + soff;
+  return o + 4u <= b.n && o + 4u > o ? *reinterpret_cast<const float*>(b.p + o) : 0.f;
+}
+static inline float2 csn_ld2(csn_buf b, unsigned voff, unsigned soff) {
+  const unsigned o = voff + soff;
+  if (!(o + 8u <= b.n && o + 8u > o)) return make_float2(0.f, 0.f);
+  return *reinterpret_cast<const float2*>(b.p + o);
+}
 static inline float4 csn_ld4(csn_buf b, unsigned voff, unsigned soff) {
-  const float* q = reinterpret_cast<const float*>(b.p + voff + soff);
+  const unsigned o = voff + soff;
+  if (!(o + 16u <= b.n && o + 16u > o)) return make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* q = reinterpret_cast<const float*>(b.p + o);
   return make_float4(q[0], q[1], q[2], q[3]);
 }
 #else
@@ -61,6 +72,9 @@ typedef unsigned csn_u2 __attribute__((ext_vector_type(2)));
 typedef unsigned csn_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ csn_buf csn_make_buf(const float* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0xffffffff, 0x00020000);
+}
+__device__ __forceinline__ csn_buf csn_make_buf_n(const float* p, unsigned nbytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, nbytes, 0x00020000);
 }
 __device__ __forceinline__ float csn_ld1(csn_buf b, unsigned voff, unsigned soff) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b, voff, soff, 0));

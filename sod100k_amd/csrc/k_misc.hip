@@ -65,33 +65,37 @@ int csn_launch_prep(const CsnPrepJob* jobs_dev, int njobs, const float* arena, f
 // ------------------------------------------------------------------------------------- depthwise
 // One block = one (image, channel) plane tile of LX*4 columns x NY*R rows.  A lane owns a 4-wide
 // column strip and walks R rows with a rolling 3-row register window, so every input row is loaded
-// once per lane (float4 + the two edge scalars); the vertical halo between tiles hits L2.
+// once per lane (one b128 + the two edge dwords); the vertical halo between tiles hits L2.
+// All loads are buffer loads on a resource bounded to the plane: rows above / below the image fall
+// out of range and return 0 (= the conv's zero padding) without any branch, so the 12 loads of a
+// 4-row chunk are issued back to back (a predicated load would be waited for at the join).
 struct DwRow {
   float v[6];  // [0]=x0-1, [1..4]=x0..x0+3, [5]=x0+4
 };
 
-__device__ __forceinline__ DwRow dw_load_row(const float* __restrict__ plane, int y, int x0, int H, int W,
-                                             bool vec) {
+template <bool VEC>
+__device__ __forceinline__ DwRow dw_load_row(csn_buf rb, int y, int x0, int W, bool has_l, bool has_r) {
   DwRow r;
-  if (y < 0 || y >= H) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) r.v[i] = 0.f;
-    return r;
-  }
-  const float* p = plane + (int64_t)y * W;
-  if (vec && x0 + 3 < W) {
-    const float4 c = *reinterpret_cast<const float4*>(p + x0);
+  const unsigned o = (unsigned)(y * W + x0) * 4u;   // y = -1 wraps to a huge offset -> out of range -> 0
+  if (VEC) {
+    const float4 c = csn_ld4(rb, o, 0);
     r.v[1] = c.x; r.v[2] = c.y; r.v[3] = c.z; r.v[4] = c.w;
+    const float l = csn_ld1(rb, o - 4u, 0), rr = csn_ld1(rb, o + 16u, 0);
+    r.v[0] = has_l ? l : 0.f;
+    r.v[5] = has_r ? rr : 0.f;
   } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r.v[1 + i] = (x0 + i < W) ? p[x0 + i] : 0.f;
+    for (int i = 0; i < 6; ++i) {
+      const float t = csn_ld1(rb, o + (unsigned)(i - 1) * 4u, 0);
+      const int xx = x0 + i - 1;
+      r.v[i] = (xx >= 0 && xx < W) ? t : 0.f;
+    }
   }
-  r.v[0] = (x0 > 0) ? p[x0 - 1] : 0.f;
-  r.v[5] = (x0 + 4 < W) ? p[x0 + 4] : 0.f;
   return r;
 }
 
-__device__ __forceinline__ void dw_emit(float* __restrict__ op, int y, int yend, int x0, int W, bool vec,
+template <bool VEC>
+__device__ __forceinline__ void dw_emit(float* __restrict__ op, int y, int yend, int x0, int W,
                                         const float (&w)[9], float sc, float sh, float al, const DwRow& top,
                                         const DwRow& mid, const DwRow& bot) {
   if (y >= yend) return;
@@ -110,7 +114,7 @@ __device__ __forceinline__ void dw_emit(float* __restrict__ op, int y, int yend,
     o[j] = csn_epi(acc, sc, sh, al);
   }
   float* q = op + (int64_t)y * W + x0;
-  if (vec && x0 + 3 < W) {
+  if (VEC) {
     *reinterpret_cast<float4*>(q) = make_float4(o[0], o[1], o[2], o[3]);
   } else {
 #pragma unroll
@@ -119,6 +123,7 @@ __device__ __forceinline__ void dw_emit(float* __restrict__ op, int y, int yend,
   }
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
   int bid = blockIdx.x;
   int k = 0;
@@ -138,29 +143,27 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
   const int x0 = (tx * br.LX + lx) * 4;
   const int y0 = (ty * br.NY + ly) * br.R;
   if (x0 >= W || y0 >= H) return;
-  const bool vec = (W & 3) == 0;
-  const float* __restrict__ ip = br.in + (int64_t)pc * H * W;
+  const csn_buf rb = csn_make_buf_n(br.in + (int64_t)pc * H * W, (unsigned)(H * W) * 4u);
   float* __restrict__ op = br.out + (int64_t)pc * H * W;
   float w[9];
   csn_cfp w9 = csn_const(br.w9);
 #pragma unroll
   for (int i = 0; i < 9; ++i) w[i] = w9[c * 9 + i];
   const float sc = csn_const(br.scale)[c], sh = csn_const(br.shift)[c], al = csn_const(br.alpha)[c];
+  const bool has_l = x0 > 0, has_r = x0 + 4 < W;
 
-  // rows are processed in chunks of 4 with all 4 new input rows (12 loads per lane) issued before the
-  // first FMA, so each lane keeps >= 12 vector loads in flight (latency-bound otherwise: SQ_WAIT_ANY 88 %)
-  DwRow r0 = dw_load_row(ip, y0 - 1, x0, H, W, vec);
-  DwRow r1 = dw_load_row(ip, y0, x0, H, W, vec);
+  DwRow r0 = dw_load_row<VEC>(rb, y0 - 1, x0, W, has_l, has_r);
+  DwRow r1 = dw_load_row<VEC>(rb, y0, x0, W, has_l, has_r);
   const int yend = min(y0 + br.R, H);
   for (int y = y0; y < yend; y += 4) {
-    const DwRow n0 = dw_load_row(ip, y + 1, x0, H, W, vec);
-    const DwRow n1 = dw_load_row(ip, y + 2, x0, H, W, vec);
-    const DwRow n2 = dw_load_row(ip, y + 3, x0, H, W, vec);
-    const DwRow n3 = dw_load_row(ip, y + 4, x0, H, W, vec);
-    dw_emit(op, y, yend, x0, W, vec, w, sc, sh, al, r0, r1, n0);
-    dw_emit(op, y + 1, yend, x0, W, vec, w, sc, sh, al, r1, n0, n1);
-    dw_emit(op, y + 2, yend, x0, W, vec, w, sc, sh, al, n0, n1, n2);
-    dw_emit(op, y + 3, yend, x0, W, vec, w, sc, sh, al, n1, n2, n3);
+    const DwRow n0 = dw_load_row<VEC>(rb, y + 1, x0, W, has_l, has_r);
+    const DwRow n1 = dw_load_row<VEC>(rb, y + 2, x0, W, has_l, has_r);
+    const DwRow n2 = dw_load_row<VEC>(rb, y + 3, x0, W, has_l, has_r);
+    const DwRow n3 = dw_load_row<VEC>(rb, y + 4, x0, W, has_l, has_r);
+    dw_emit<VEC>(op, y, yend, x0, W, w, sc, sh, al, r0, r1, n0);
+    dw_emit<VEC>(op, y + 1, yend, x0, W, w, sc, sh, al, r1, n0, n1);
+    dw_emit<VEC>(op, y + 2, yend, x0, W, w, sc, sh, al, n0, n1, n2);
+    dw_emit<VEC>(op, y + 3, yend, x0, W, w, sc, sh, al, n1, n2, n3);
     r0 = n2;
     r1 = n3;
   }
@@ -169,7 +172,13 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
 int csn_launch_dw(const DwArgs& a, void* stream) {
   const int nblk = a.br[a.nbr - 1].blk_end;
   if (nblk <= 0) return 0;
-  CSN_LAUNCH(dw3x3_bn_prelu_kernel, dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+  bool vec = true;  // float4 path needs every branch width to be a multiple of 4
+  for (int k = 0; k < a.nbr; ++k) vec = vec && (a.br[k].W % 4 == 0);
+  if (vec) {
+    CSN_LAUNCH((dw3x3_bn_prelu_kernel<true>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+  } else {
+    CSN_LAUNCH((dw3x3_bn_prelu_kernel<false>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+  }
   return (int)hipGetLastError();
 }
 
