@@ -14,7 +14,7 @@ from typing import Optional, Sequence
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libcsnet_hip.so")
-SOURCES = ("csn_plan.hip", "k_misc.hip", "k_goct_pw.hip", "k_conv3.hip")
+SOURCES = ("csn_plan.hip", "k_misc.hip", "k_goct_pw.hip", "k_ms.hip")
 
 MAX_BRANCH = 3
 NDIL = 5

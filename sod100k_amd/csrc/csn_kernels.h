@@ -16,6 +16,7 @@ enum CsnPrepKind {
   // 3x3 block -> [co/8][ci][9][8]: dst[((co/8)*ncol + ci)*72 + t*8 + co%8] = p0f * src0[(co*ld + ci)*9 + t]
   // (n = nrow, p1 = ncol(ci), p0 = ld (total cin of the source weight), p3 = ci offset inside dst, p2 = dst cin total)
   CSN_PREP_C3 = 5,
+  CSN_PREP_EYE = 6,       // dst[r*p2 + p3 + r] = p0f  for r < n (identity block inside packed rows)
 };
 struct CsnPrepJob {
   int32_t kind, n, p0, p1, p2, p3;
@@ -49,14 +50,18 @@ struct DwArgs {
 // ---------------------------------------------------------------------------------------------
 #define PW_TY0 16
 #define PW_TX0 32
-#define PW_MAX_PASS 3
+#define PW_MAX_PASS 6
 #define PW_MAX_GRID 2048
-enum PwMode { PW_OWN = 0, PW_POOL2 = 1, PW_POOL4 = 2, PW_UP2 = 3, PW_UP4 = 4 };
+// how a channel slice is brought to the pass resolution; the *_TAPS modes contribute 9 gathered
+// entries per channel (k = 9*ch + 3*(dy+1) + (dx+1), zero padded) = a 3x3 convolution as a contraction
+enum PwMode { PW_OWN = 0, PW_POOL2 = 1, PW_POOL4 = 2, PW_UP2 = 3, PW_UP4 = 4, PW_TAPS = 5, PW_POOL2_TAPS = 6 };
 struct PwSrc {
   const float* ptr;  // first channel of the slice inside [B][Ctot][H_s][W_s]
   int32_t C;         // channels of the slice
   int32_t Ctot;      // channels of the whole tensor (image stride)
-  int32_t mode;      // PwMode: how the slice is brought to the pass resolution
+  int32_t mode;      // PwMode
+  int32_t K;         // gathered entries of the slice: C, or 9*C for the *_TAPS modes
+  int32_t dil;       // PW_TAPS: dilation (1, 2, 4, 8, 16); padding = dilation
   int32_t pad;
 };
 struct PwPass {
@@ -68,7 +73,9 @@ struct PwPass {
   int32_t nrows;      // output channels
   int32_t w_off;      // float offset of this pass's rows inside the unit's weight image
   int32_t w_stride;   // row pitch of the weight image (floats): cin4 + 2, conflict-free A-operand reads
-  float* out;         // [B][nrows][H0>>r][W0>>r]
+  float* out;         // first of the nrows channels written, inside [B][out_ctot][H0>>r][W0>>r]
+  int32_t out_ctot;
+  int32_t pad2;
   const float* scale;
   const float* shift;
   const float* alpha;
@@ -84,34 +91,12 @@ struct PwArgs {
 };
 
 // ---------------------------------------------------------------------------------------------
-// 3x3 conv of ONE output branch (LDS staged), optional max-pool-2 on a source, optional bilinear x2
-// add of a half-resolution tensor, optional epilogue (see k_conv3.hip)
-// ---------------------------------------------------------------------------------------------
-struct C3Src {
-  const float* ptr;  // [B][C][H<<shift][W<<shift]
-  int32_t C;
-  int32_t shift;     // 0, or 1 = 2x2 max-pool while staging
-};
-struct C3Args {
-  C3Src src[2];
-  int32_t nsrc, cin;   // gathered input channels
-  const float* w;      // packed [ceil(cout/8)][cin][9][8]
-  int32_t cout;
-  float* out;          // [B][cout][H][W]
-  const float* scale;  // null -> raw conv result (used for the low->high partial sums)
-  const float* shift;
-  const float* alpha;
-  const float* zadd;   // [B][cout][H/2][W/2] or null: bilinear x2 of it is added before the epilogue
-  int32_t H, W, B;
-};
-
-// ---------------------------------------------------------------------------------------------
-// MSBlock: five dilated 3x3 convs (x100 folded) -> channel concat -> BN -> PReLU, direct
+// MSBlock: five dilated 3x3 convs (x100 folded) -> channel concat -> BN -> PReLU (see k_ms.hip)
 // ---------------------------------------------------------------------------------------------
 struct MsArgs {
   const float* in;     // [B][cin][H][W]
   float* out;          // [B][cout][H][W]
-  const float* w[5];   // packed [ceil(dch/8)][cin][9][8] per dilation (null if absent)
+  const float* w[5];   // packed [ceil(dch/8)][cin rounded up to 2][9][8] per dilation (null if absent)
   int32_t dch[5];
   int32_t cobase[5];   // first output channel of each dilation inside the concat
   int32_t cin, cout, H, W, B;
@@ -141,7 +126,6 @@ struct Up2Args {
 int csn_launch_prep(const CsnPrepJob* jobs_dev, int njobs, const float* arena, float* packed, void* stream);
 int csn_launch_dw(const DwArgs& a, void* stream);
 int csn_launch_pw(const PwArgs& a, int maxnt, void* stream);
-int csn_launch_c3(const C3Args& a, void* stream);
 int csn_launch_ms(const MsArgs& a, void* stream);
 int csn_launch_pool(const PoolArgs& a, void* stream);
 int csn_launch_up2(const Up2Args& a, void* stream);

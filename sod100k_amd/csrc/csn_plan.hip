@@ -43,45 +43,47 @@ struct Epi {  // float offsets into the packed buffer
   int64_t scale = -1, shift = -1, alpha = -1;
 };
 
-struct PwPassPlan {
-  int r = 0;
-  int nsrc = 0;
-  int src_branch[3] = {-1, -1, -1};  // unit input branch the channels come from
-  int src_C[3] = {0, 0, 0};
-  int src_mode[3] = {0, 0, 0};       // PwMode
-  int cin = 0, cin4 = 0, nrows = 0;
-  int w_off = 0, w_stride = 0;       // inside the unit's weight image
-  int out_branch = -1;
-  Epi epi;
+// ---- plan of the panel + MFMA contraction kernel (k_goct_pw.hip) --------------------------------------
+enum SrcKind { SRC_IN = 0, SRC_Z = 1 };     // unit input branch (pooled copy when stride 2) / unit-private scratch
+enum OutKind { OUT_ACT = 0, OUT_Z = 1, OUT_LOGITS = 2 };
+
+struct WBlock {           // one rectangular block of a pass's weight rows
+  int eye = 0;            // 1: identity block (adds an already convolved tensor through the contraction)
+  int64_t src = -1;       // arena offset of W[row 0][col 0] of the block
+  int ld = 0, ncol = 0, col = 0;
+  float scale = 1.f;
 };
 
-struct C3Plan {
-  int res_branch = 0;  // output resolution: unit branch index
+struct PwPassPlan {
+  int r = 0;                           // resolution of the pass relative to the launch (H0 >> r)
   int nsrc = 0;
-  int src_branch[2] = {-1, -1};
-  int src_C[2] = {0, 0};
-  int src_shift[2] = {0, 0};
-  int cin = 0, cout = 0;
-  int64_t w = -1;
-  bool to_z = false;       // writes the raw partial sums into the unit's Z scratch
-  bool add_z = false;      // adds bilinear x2 of the Z scratch
-  int out_branch = -1;
-  Epi epi;
+  int src_kind[3] = {0, 0, 0};
+  int src_branch[3] = {-1, -1, -1};
+  int src_C[3] = {0, 0, 0};
+  int src_mode[3] = {0, 0, 0};         // PwMode
+  int src_dil[3] = {1, 1, 1};
+  int K = 0, K4 = 0, nrows = 0;
+  int w_off = 0, w_stride = 0;         // inside the launch's weight image
+  int out_kind = OUT_ACT, out_branch = 0, out_c0 = 0, out_ctot = 0;
+  Epi epi;                             // tables already offset to the first row of the pass
+  std::vector<WBlock> wb;
+};
+
+struct PwLaunchPlan {
+  std::vector<PwPassPlan> passes;
+  int lvl = 0;                         // activation level (H >> lvl) of r = 0
+  int64_t wimg = -1;                   // packed-buffer offset of the weight image
+  int wimg_floats = 0;
 };
 
 struct UnitPlan {
   csn_unit_desc d;
-  int base_lvl = 0;                  // lvl of branch 0 of the unit's compute resolution
-  // inputs after the optional avg-pool: pointers are either the acts themselves or pooled scratch
-  int64_t pooled_off[3] = {-1, -1, -1};  // workspace byte offsets of pooled copies (stride 2)
-  int64_t z_off = -1;                    // workspace byte offset of the 3x3 low->high scratch
+  int base_lvl = 0;                      // lvl of branch 0 of the unit's compute resolution
+  int64_t pooled_off[3] = {-1, -1, -1};  // workspace byte offsets of the 2x2 avg-pooled inputs (stride 2)
+  int64_t z_off = -1;                    // workspace byte offset of the 3x3 low->high partial sums
+  int z_C = 0;
   int64_t logits_off = -1;               // CLS: logits at H/2
-  // GOCT 1x1 / CLS
-  std::vector<PwPassPlan> pw;
-  int64_t wimg = -1;   // packed-buffer offset of the weight image
-  int wimg_floats = 0;
-  // GOCT 3x3
-  std::vector<C3Plan> c3;
+  std::vector<PwLaunchPlan> pwl;         // GOCT / MS / CLS
   // DW
   int64_t dw_w[3] = {-1, -1, -1};
   Epi dw_epi[3];
@@ -147,138 +149,155 @@ bool bn_ok(const csn_bn_off& b) {
   return b.weight >= 0 && b.bias >= 0 && b.running_mean >= 0 && b.running_var >= 0 && b.prelu >= 0;
 }
 
-// Pass list of a 1x1 gOctConv unit (also cls_layer): one contraction per output branch over the gathered
-// vector [own ; max-pooled higher-resolution inputs ; bilinearly upsampled lower-resolution inputs].
-// All passes' weights live in ONE image (rows padded to 16, pitch cin4+2) that the kernel copies to LDS.
-int build_pw_passes(Builder& bl, UnitPlan& u, int n_in, int n_out, const int32_t* cin, const int32_t* cout,
-                    int64_t w_off, int64_t ld, const Epi* epi) {
-  int ci_off[4] = {0}, co_off[4] = {0};
-  { int t = 0; for (int i = 0; i < n_in; ++i) { ci_off[i] = t; t += cin[i]; } }
-  { int t = 0; for (int j = 0; j < n_out; ++j) { co_off[j] = t; t += cout[j]; } }
-  int img = 0;  // floats
-  for (int j = n_out - 1; j >= 0; --j) {
-    if (cout[j] == 0) continue;
-    PwPassPlan ps;
-    ps.r = j; ps.out_branch = j; ps.nrows = cout[j]; ps.epi = epi[j];
-    auto add = [&](int branch, int mode) {
-      if (ps.nsrc >= 3) return false;
-      ps.src_branch[ps.nsrc] = branch; ps.src_C[ps.nsrc] = cin[branch]; ps.src_mode[ps.nsrc] = mode;
-      ps.cin += cin[branch];
-      ++ps.nsrc;
-      return true;
-    };
-    bool ok = true;
-    if (j < n_in && cin[j] > 0) ok = ok && add(j, PW_OWN);
-    for (int i = 0; i < j && i < n_in; ++i)
-      if (cin[i] > 0) {
-        if (j - i > 2) FAIL(CSN_E_UNSUPPORTED, "max-pool factor > 4");
-        ok = ok && add(i, j - i == 1 ? PW_POOL2 : PW_POOL4);
-      }
-    for (int i = j + 1; i < n_in; ++i)
-      if (cin[i] > 0) {
-        if (i - j > 2) FAIL(CSN_E_UNSUPPORTED, "bilinear factor > 4");
-        ok = ok && add(i, i - j == 1 ? PW_UP2 : PW_UP4);
-      }
-    if (!ok || ps.nsrc == 0) FAIL(CSN_E_INVALID, "output branch without inputs / too many inputs");
-    ps.cin4 = round4(ps.cin);
-    ps.w_stride = ps.cin4 + 2;   // == 2 (mod 4): the 64 A-operand addresses of an MFMA hit 32 distinct banks twice
+// Lay out the weight image of a launch (rows padded to 16, pitch K4 + 2 floats) and emit the packing jobs.
+int finish_launch(Builder& bl, PwLaunchPlan& L) {
+  int img = 0;
+  for (PwPassPlan& ps : L.passes) {
+    ps.K4 = round4(ps.K);
+    ps.w_stride = ps.K4 + 2;   // == 2 (mod 4): the 64 A-operand addresses of an MFMA hit 32 distinct banks twice
     ps.w_off = img;
     img += ((ps.nrows + 15) & ~15) * ps.w_stride;
     img = (img + 3) & ~3;
-    u.pw.push_back(ps);
   }
-  if ((int)u.pw.size() > PW_MAX_PASS) FAIL(CSN_E_UNSUPPORTED, "too many passes");
+  if ((int)L.passes.size() > PW_MAX_PASS) FAIL(CSN_E_UNSUPPORTED, "too many passes in one launch");
   if (((int64_t)img + 4 * 16 * 64) * 4 > 160 * 1024) FAIL(CSN_E_UNSUPPORTED, "weight image exceeds the LDS of a CU");
-  u.wimg_floats = img;
-  u.wimg = bl.alloc_packed(img);
-  for (const PwPassPlan& ps : u.pw) {
-    int col = 0;
-    for (int s = 0; s < ps.nsrc; ++s) {
-      const int br = ps.src_branch[s];
-      bl.job(CSN_PREP_ROWS, ps.nrows, u.wimg + ps.w_off, w_off + (int64_t)co_off[ps.out_branch] * ld + ci_off[br],
-             -1, -1, -1, 1.f, (int)ld, cin[br], ps.w_stride, col);
-      col += cin[br];
+  L.wimg_floats = img;
+  L.wimg = bl.alloc_packed(img);
+  for (const PwPassPlan& ps : L.passes)
+    for (const WBlock& w : ps.wb) {
+      if (w.eye)
+        bl.job(CSN_PREP_EYE, w.ncol, L.wimg + ps.w_off, -1, -1, -1, -1, 1.f, 0, 0, ps.w_stride, w.col);
+      else
+        bl.job(CSN_PREP_ROWS, ps.nrows, L.wimg + ps.w_off, w.src, -1, -1, -1, w.scale, w.ld, w.ncol, ps.w_stride, w.col);
     }
-  }
   return CSN_OK;
+}
+
+// Split a launch whose weight image would cap the occupancy through LDS into one launch per pass, each
+// re-based on its own resolution (the shared inputs are then re-read through L2 / Infinity Cache).
+void add_launch(UnitPlan& u, PwLaunchPlan L) {
+  int64_t img = 0;
+  for (const PwPassPlan& ps : L.passes) img += (int64_t)((ps.nrows + 15) & ~15) * (round4(ps.K) + 2);
+  if (L.passes.size() > 1 && img * 4 > 24 * 1024) {
+    for (const PwPassPlan& ps : L.passes) {
+      PwLaunchPlan one;
+      one.lvl = L.lvl + ps.r;
+      one.passes.push_back(ps);
+      one.passes[0].r = 0;
+      u.pwl.push_back(one);
+    }
+  } else {
+    u.pwl.push_back(L);
+  }
 }
 
 int plan_goct(Builder& bl, UnitPlan& u) {
   csn_plan& P = bl.P;
   const csn_unit_desc& d = u.d;
-  if (d.n_in < 1 || d.n_in > 3 || d.n_out < 1 || d.n_out > 3) FAIL(CSN_E_INVALID, "csn_plan.hip:155");
-  if (!(d.ksize == 1 || d.ksize == 3) || !(d.stride == 1 || d.stride == 2)) FAIL(CSN_E_INVALID, "csn_plan.hip:156");
-  if (d.n_in == 1 && d.n_out == 1) FAIL(CSN_E_UNSUPPORTED, "csn_plan.hip:157");  // std_conv (Conv2dX100) path, csnet.py:751-754
+  if (d.n_in < 1 || d.n_in > 3 || d.n_out < 1 || d.n_out > 3) FAIL(CSN_E_INVALID, "branch count");
+  if (!(d.ksize == 1 || d.ksize == 3) || !(d.stride == 1 || d.stride == 2)) FAIL(CSN_E_INVALID, "ksize/stride");
+  if (d.n_in == 1 && d.n_out == 1) FAIL(CSN_E_UNSUPPORTED, "std_conv (Conv2dX100) unit, csnet.py:751-754");
   int cin_tot = 0, cout_tot = 0, ci_off[4] = {0}, co_off[4] = {0};
   for (int i = 0; i < d.n_in; ++i) { ci_off[i] = cin_tot; cin_tot += d.cin[i]; }
   for (int j = 0; j < d.n_out; ++j) { co_off[j] = cout_tot; cout_tot += d.cout[j]; }
-  // resolution bookkeeping
   int base = -1;
   for (int j = 0; j < d.n_out; ++j)
     if (d.cout[j] > 0) {
-      if (d.out_act[j] < 0 || d.out_act[j] >= (int)P.acts.size()) FAIL(CSN_E_INVALID, "csn_plan.hip:165");
+      if (d.out_act[j] < 0 || d.out_act[j] >= (int)P.acts.size()) FAIL(CSN_E_INVALID, "out_act");
       const Act& a = P.acts[d.out_act[j]];
-      if (a.channels != d.cout[j]) FAIL(CSN_E_INVALID, "csn_plan.hip:167");
+      if (a.channels != d.cout[j]) FAIL(CSN_E_INVALID, "out channels");
       const int b0 = a.lvl - j;
-      if (base >= 0 && b0 != base) FAIL(CSN_E_INVALID, "csn_plan.hip:169");
+      if (base >= 0 && b0 != base) FAIL(CSN_E_INVALID, "output resolutions are not octave spaced");
       base = b0;
-      if (!bn_ok(d.bn[j])) FAIL(CSN_E_INVALID, "csn_plan.hip:171");
+      if (!bn_ok(d.bn[j])) FAIL(CSN_E_INVALID, "missing BN/PReLU offsets");
     }
-  if (base < 0) FAIL(CSN_E_INVALID, "csn_plan.hip:173");
+  if (base < 0) FAIL(CSN_E_INVALID, "no outputs");
   u.base_lvl = base;
   const int ds = d.stride == 2 ? 1 : 0;
   for (int i = 0; i < d.n_in; ++i)
     if (d.cin[i] > 0) {
-      if (d.in_act[i] < 0 || d.in_act[i] >= (int)P.acts.size()) FAIL(CSN_E_INVALID, "csn_plan.hip:178");
+      if (d.in_act[i] < 0 || d.in_act[i] >= (int)P.acts.size()) FAIL(CSN_E_INVALID, "in_act");
       const Act& a = P.acts[d.in_act[i]];
-      if (a.channels != d.cin[i] || a.lvl + ds != base + i) FAIL(CSN_E_INVALID, "csn_plan.hip:180");
+      if (a.channels != d.cin[i] || a.lvl + ds != base + i) FAIL(CSN_E_INVALID, "input resolution/channels");
       if (ds) u.pooled_off[i] = bl.alloc_ws(bl.act_bytes(d.cin[i], base + i));
     }
   const int nb = d.n_in > d.n_out ? d.n_in : d.n_out;
   if (((P.H >> (base + nb - 1)) << (base + nb - 1)) != P.H || ((P.W >> (base + nb - 1)) << (base + nb - 1)) != P.W)
-    FAIL(CSN_E_INVALID, "csn_plan.hip:185");
+    FAIL(CSN_E_INVALID, "H/W not divisible for the lowest branch");
   Epi epi[3];
   for (int j = 0; j < d.n_out; ++j)
     if (d.cout[j] > 0) epi[j] = bl.bn_epi(d.bn[j], d.cout[j]);
-  const int64_t ld = (int64_t)cin_tot * d.ksize * d.ksize;
+  const int kk = d.ksize * d.ksize;
+  const int ld = cin_tot * kk;
+  u.kname = "goct_pw_kernel";
 
-  if (d.ksize == 1) {
-    u.kname = "goct_pw_kernel";
-    const int st = build_pw_passes(bl, u, d.n_in, d.n_out, d.cin, d.cout, d.w_off[0], ld, epi);
-    if (st != CSN_OK) return st;
-  } else {
-    u.kname = "conv3x3_kernel";
-    if (d.n_in > 2 || d.n_out > 2) FAIL(CSN_E_UNSUPPORTED, "csn_plan.hip:270");
-    const bool lo_to_hi = d.n_in == 2 && d.cin[1] > 0 && d.cout[0] > 0;
-    if (lo_to_hi) {
-      u.z_off = bl.alloc_ws(bl.act_bytes(d.cout[0], base + 1));
-      C3Plan c;
-      c.res_branch = 1; c.nsrc = 1; c.src_branch[0] = 1; c.src_C[0] = d.cin[1]; c.cin = d.cin[1];
-      c.cout = d.cout[0]; c.to_z = true;
-      c.w = bl.alloc_packed((int64_t)((c.cout + 7) / 8) * c.cin * 72);
-      bl.job(CSN_PREP_C3, c.cout, c.w, d.w_off[0] + ((int64_t)co_off[0] * cin_tot + ci_off[1]) * 9, -1, -1, -1, 1.f,
-             cin_tot, c.cin, c.cin, 0);
-      u.c3.push_back(c);
-    }
-    for (int j = d.n_out - 1; j >= 0; --j) {
-      if (d.cout[j] == 0) continue;
-      C3Plan c;
-      c.res_branch = j; c.cout = d.cout[j]; c.out_branch = j; c.epi = epi[j];
-      if (j < d.n_in && d.cin[j] > 0) { c.src_branch[c.nsrc] = j; c.src_C[c.nsrc] = d.cin[j]; c.src_shift[c.nsrc] = 0; ++c.nsrc; }
-      if (j == 1 && d.cin[0] > 0) { c.src_branch[c.nsrc] = 0; c.src_C[c.nsrc] = d.cin[0]; c.src_shift[c.nsrc] = 1; ++c.nsrc; }
-      for (int s = 0; s < c.nsrc; ++s) c.cin += c.src_C[s];
-      if (c.cin == 0) FAIL(CSN_E_UNSUPPORTED, "csn_plan.hip:289");
-      c.w = bl.alloc_packed((int64_t)((c.cout + 7) / 8) * c.cin * 72);
-      int col = 0;
-      for (int s = 0; s < c.nsrc; ++s) {
-        const int i = c.src_branch[s];
-        bl.job(CSN_PREP_C3, c.cout, c.w, d.w_off[0] + ((int64_t)co_off[j] * cin_tot + ci_off[i]) * 9, -1, -1, -1, 1.f,
-               cin_tot, c.src_C[s], c.cin, col);
-        col += c.src_C[s];
+  // 3x3 low->high term: conv at the low resolution into a scratch (its own launch: the high-resolution pass
+  // samples it bilinearly across tile borders), then added through an identity block of the contraction
+  const bool z_path = d.ksize == 3 && d.n_in >= 2 && d.cout[0] > 0 && d.cin[1] > 0;
+  if (d.ksize == 3 && (d.n_in > 2 || d.n_out > 2)) FAIL(CSN_E_UNSUPPORTED, "3x3 gOctConv with three branches");
+  if (z_path) {
+    u.z_C = d.cout[0];
+    u.z_off = bl.alloc_ws(bl.act_bytes(u.z_C, base + 1));
+    PwLaunchPlan L;
+    L.lvl = base + 1;
+    PwPassPlan ps;
+    ps.r = 0; ps.nsrc = 1; ps.src_kind[0] = SRC_IN; ps.src_branch[0] = 1; ps.src_C[0] = d.cin[1]; ps.src_mode[0] = PW_TAPS;
+    ps.K = d.cin[1] * 9; ps.nrows = u.z_C; ps.out_kind = OUT_Z; ps.out_ctot = u.z_C;
+    ps.epi.scale = bl.alloc_packed(u.z_C); ps.epi.shift = bl.alloc_packed(u.z_C); ps.epi.alpha = bl.alloc_packed(u.z_C);
+    bl.job(CSN_PREP_FILL, u.z_C, ps.epi.scale, -1, -1, -1, -1, 1.f);
+    bl.job(CSN_PREP_FILL, u.z_C, ps.epi.shift, -1, -1, -1, -1, 0.f);
+    bl.job(CSN_PREP_FILL, u.z_C, ps.epi.alpha, -1, -1, -1, -1, 1.f);
+    WBlock w; w.src = d.w_off[0] + ((int64_t)co_off[0] * cin_tot + ci_off[1]) * 9; w.ld = ld; w.ncol = d.cin[1] * 9; w.col = 0;
+    ps.wb.push_back(w);
+    L.passes.push_back(ps);
+    u.pwl.push_back(L);
+  }
+  PwLaunchPlan L;
+  L.lvl = base;
+  for (int j = d.n_out - 1; j >= 0; --j) {
+    if (d.cout[j] == 0) continue;
+    PwPassPlan ps;
+    ps.r = j; ps.nrows = d.cout[j]; ps.out_kind = OUT_ACT; ps.out_branch = j; ps.out_ctot = d.cout[j]; ps.epi = epi[j];
+    auto add = [&](int kind, int branch, int C, int mode, const WBlock& wproto) {
+      if (ps.nsrc >= 3) return false;
+      const int s = ps.nsrc++;
+      ps.src_kind[s] = kind; ps.src_branch[s] = branch; ps.src_C[s] = C; ps.src_mode[s] = mode;
+      WBlock w = wproto;
+      w.col = ps.K;
+      ps.wb.push_back(w);
+      ps.K += (mode == PW_TAPS || mode == PW_POOL2_TAPS) ? 9 * C : C;
+      return true;
+    };
+    auto wblk = [&](int i) {
+      WBlock w;
+      w.src = d.w_off[0] + ((int64_t)co_off[j] * cin_tot + ci_off[i]) * kk;
+      w.ld = ld; w.ncol = d.cin[i] * kk;
+      return w;
+    };
+    bool ok = true;
+    if (j < d.n_in && d.cin[j] > 0) ok = ok && add(SRC_IN, j, d.cin[j], d.ksize == 3 ? PW_TAPS : PW_OWN, wblk(j));
+    for (int i = 0; i < j && i < d.n_in; ++i)
+      if (d.cin[i] > 0) {
+        if (j - i > 2 || (d.ksize == 3 && j - i > 1)) FAIL(CSN_E_UNSUPPORTED, "max-pool factor");
+        ok = ok && add(SRC_IN, i, d.cin[i], d.ksize == 3 ? PW_POOL2_TAPS : (j - i == 1 ? PW_POOL2 : PW_POOL4), wblk(i));
       }
-      c.add_z = (j == 0) && lo_to_hi;
-      u.c3.push_back(c);
-    }
+    for (int i = j + 1; i < d.n_in; ++i)
+      if (d.cin[i] > 0) {
+        if (d.ksize == 1) {
+          if (i - j > 2) FAIL(CSN_E_UNSUPPORTED, "bilinear factor > 4");
+          ok = ok && add(SRC_IN, i, d.cin[i], i - j == 1 ? PW_UP2 : PW_UP4, wblk(i));
+        } else {   // the scratch written by the z launch, upsampled, through an identity block
+          WBlock w; w.eye = 1; w.ncol = u.z_C;
+          ok = ok && add(SRC_Z, 0, u.z_C, PW_UP2, w);
+        }
+      }
+    if (!ok || ps.nsrc == 0) FAIL(CSN_E_INVALID, "output branch without inputs / too many inputs");
+    L.passes.push_back(ps);
+  }
+  add_launch(u, L);
+  for (PwLaunchPlan& l : u.pwl) {
+    const int st = finish_launch(bl, l);
+    if (st != CSN_OK) return st;
   }
   return CSN_OK;
 }
@@ -306,18 +325,20 @@ int plan_ms(Builder& bl, UnitPlan& u) {
   csn_plan& P = bl.P;
   const csn_unit_desc& d = u.d;
   u.kname = "msblock_kernel";
-  if (d.in_act[0] < 0 || d.out_act[0] < 0) FAIL(CSN_E_INVALID, "csn_plan.hip:328");
+  if (d.in_act[0] < 0 || d.out_act[0] < 0) FAIL(CSN_E_INVALID, "ms acts");
   const Act& ai = P.acts[d.in_act[0]];
   const Act& ao = P.acts[d.out_act[0]];
   int tot = 0;
   for (int k = 0; k < CSN_NDIL; ++k) tot += d.dil_ch[k];
-  if (ai.channels != d.cin[0] || ao.channels != d.cout[0] || tot != d.cout[0] || ai.lvl != ao.lvl) FAIL(CSN_E_INVALID, "csn_plan.hip:333");
-  if (!bn_ok(d.bn[0])) FAIL(CSN_E_INVALID, "csn_plan.hip:334");
-  for (int k = 0; k < CSN_NDIL; ++k) {
+  if (ai.channels != d.cin[0] || ao.channels != d.cout[0] || tot != d.cout[0] || ai.lvl != ao.lvl) FAIL(CSN_E_INVALID, "ms shapes");
+  if (!bn_ok(d.bn[0])) FAIL(CSN_E_INVALID, "ms BN");
+  u.base_lvl = ai.lvl;
+  const int cinp = (d.cin[0] + 1) & ~1;
+  for (int k = 0; k < CSN_NDIL; ++k) {     // dilation 2^k, padding 2^k (csnet.py:127-135), weight x100 (conv2d.py:104)
     if (d.dil_ch[k] == 0) continue;
-    if (d.w_off[k] < 0) FAIL(CSN_E_INVALID, "csn_plan.hip:337");
-    u.ms_w[k] = bl.alloc_packed((int64_t)((d.dil_ch[k] + 7) / 8) * d.cin[0] * 72);
-    bl.job(CSN_PREP_C3, d.dil_ch[k], u.ms_w[k], d.w_off[k], -1, -1, -1, 100.0f, d.cin[0], d.cin[0], d.cin[0], 0);
+    if (d.w_off[k] < 0) FAIL(CSN_E_INVALID, "ms weight");
+    u.ms_w[k] = bl.alloc_packed((int64_t)((d.dil_ch[k] + 7) / 8) * cinp * 72);
+    bl.job(CSN_PREP_C3, d.dil_ch[k], u.ms_w[k], d.w_off[k], -1, -1, -1, 100.0f, d.cin[0], d.cin[0], cinp, 0);
   }
   u.ms_epi = bl.bn_epi(d.bn[0], d.cout[0]);
   return CSN_OK;
@@ -332,13 +353,20 @@ int plan_cls(Builder& bl, UnitPlan& u) {
   if (ai.channels != d.cin[0] || ai.lvl != 1) FAIL(CSN_E_INVALID, "cls: input must be at H/2");  // csnet.py:380-385
   u.base_lvl = 1;
   u.logits_off = bl.alloc_ws(bl.act_bytes(1, 1));
-  Epi epi[3];
-  epi[0].scale = bl.alloc_packed(1); epi[0].shift = bl.alloc_packed(1); epi[0].alpha = bl.alloc_packed(1);
-  bl.job(CSN_PREP_FILL, 1, epi[0].scale, -1, -1, -1, -1, 1.f);
-  bl.job(CSN_PREP_COPY, 1, epi[0].shift, d.bias_off);
-  bl.job(CSN_PREP_FILL, 1, epi[0].alpha, -1, -1, -1, -1, 1.f);
-  const int32_t cin[3] = {d.cin[0], 0, 0}, cout[3] = {1, 0, 0};
-  return build_pw_passes(bl, u, 1, 1, cin, cout, d.w_off[0], d.cin[0], epi);
+  PwLaunchPlan L;
+  L.lvl = 1;
+  PwPassPlan ps;
+  ps.r = 0; ps.nsrc = 1; ps.src_kind[0] = SRC_IN; ps.src_branch[0] = 0; ps.src_C[0] = d.cin[0]; ps.src_mode[0] = PW_OWN;
+  ps.K = d.cin[0]; ps.nrows = 1; ps.out_kind = OUT_LOGITS; ps.out_ctot = 1;
+  ps.epi.scale = bl.alloc_packed(1); ps.epi.shift = bl.alloc_packed(1); ps.epi.alpha = bl.alloc_packed(1);
+  bl.job(CSN_PREP_FILL, 1, ps.epi.scale, -1, -1, -1, -1, 1.f);
+  bl.job(CSN_PREP_COPY, 1, ps.epi.shift, d.bias_off);
+  bl.job(CSN_PREP_FILL, 1, ps.epi.alpha, -1, -1, -1, -1, 1.f);
+  WBlock w; w.src = d.w_off[0]; w.ld = d.cin[0]; w.ncol = d.cin[0]; w.col = 0;
+  ps.wb.push_back(w);
+  L.passes.push_back(ps);
+  u.pwl.push_back(L);
+  return finish_launch(bl, u.pwl.back());
 }
 
 // ------------------------------------------------------------------------------------ execution
@@ -369,48 +397,35 @@ int choose_dw_rows(int H, int NY) {
   return best;
 }
 
-int launch_pw(const Ctx& c, const UnitPlan& u, const float* const xin[3], float* const outp[3], int H0, int W0) {
+// xin[i]: unit input branch i (pooled copy for stride 2); outp[j]: output act of branch j
+int launch_pw(const Ctx& c, const UnitPlan& u, const PwLaunchPlan& L, const float* const xin[3], float* const outp[3]) {
+  const csn_plan& P = c.P;
   PwArgs a;
-  a.npass = (int)u.pw.size();
-  a.H0 = H0; a.W0 = W0; a.B = c.P.S;
-  a.tiles_x = (W0 + PW_TX0 - 1) / PW_TX0; a.tiles_y = (H0 + PW_TY0 - 1) / PW_TY0;
-  a.wimg = c.pk(u.wimg); a.wimg_floats = u.wimg_floats;
+  a.npass = (int)L.passes.size();
+  a.H0 = P.H >> L.lvl; a.W0 = P.W >> L.lvl; a.B = P.S;
+  a.tiles_x = (a.W0 + PW_TX0 - 1) / PW_TX0; a.tiles_y = (a.H0 + PW_TY0 - 1) / PW_TY0;
+  a.wimg = c.pk(L.wimg); a.wimg_floats = L.wimg_floats;
   for (int q = 0; q < a.npass; ++q) {
-    const PwPassPlan& pp = u.pw[q];
+    const PwPassPlan& pp = L.passes[q];
     PwPass& ps = a.pass[q];
     ps.r = pp.r; ps.nsrc = pp.nsrc;
     for (int s = 0; s < 3; ++s) {
-      ps.src[s].ptr = nullptr; ps.src[s].C = 0; ps.src[s].Ctot = 0; ps.src[s].mode = PW_OWN; ps.src[s].pad = 0;
+      ps.src[s].ptr = nullptr; ps.src[s].C = 0; ps.src[s].Ctot = 0; ps.src[s].mode = PW_OWN; ps.src[s].K = 0;
+      ps.src[s].dil = 1; ps.src[s].pad = 0;
       if (s < pp.nsrc) {
-        const int br = pp.src_branch[s];
-        ps.src[s].ptr = xin[br]; ps.src[s].C = pp.src_C[s]; ps.src[s].Ctot = pp.src_C[s]; ps.src[s].mode = pp.src_mode[s];
+        ps.src[s].ptr = pp.src_kind[s] == SRC_Z ? reinterpret_cast<const float*>(c.ws + u.z_off) : xin[pp.src_branch[s]];
+        ps.src[s].C = pp.src_C[s]; ps.src[s].Ctot = pp.src_C[s]; ps.src[s].mode = pp.src_mode[s];
+        ps.src[s].K = (pp.src_mode[s] == PW_TAPS || pp.src_mode[s] == PW_POOL2_TAPS) ? 9 * pp.src_C[s] : pp.src_C[s];
+        ps.src[s].dil = pp.src_dil[s];
       }
     }
-    ps.cin = pp.cin; ps.cin4 = pp.cin4; ps.nrows = pp.nrows; ps.w_off = pp.w_off; ps.w_stride = pp.w_stride;
-    ps.out = outp[pp.out_branch];
+    ps.cin = pp.K; ps.cin4 = pp.K4; ps.nrows = pp.nrows; ps.w_off = pp.w_off; ps.w_stride = pp.w_stride;
+    float* ob = pp.out_kind == OUT_Z ? reinterpret_cast<float*>(c.ws + u.z_off)
+                : pp.out_kind == OUT_LOGITS ? reinterpret_cast<float*>(c.ws + u.logits_off) : outp[pp.out_branch];
+    const int64_t hw = (int64_t)(a.H0 >> pp.r) * (a.W0 >> pp.r);
+    ps.out = ob + (int64_t)pp.out_c0 * hw;
+    ps.out_ctot = pp.out_ctot; ps.pad2 = 0;
     ps.scale = c.pk(pp.epi.scale); ps.shift = c.pk(pp.epi.shift); ps.alpha = c.pk(pp.epi.alpha);
-  }
-  int maxrows = 0;
-  for (const PwPassPlan& pp : u.pw) maxrows = std::max(maxrows, pp.nrows);
-  (void)maxrows;
-  if (a.npass > 1 && (int64_t)u.wimg_floats * 4 > 24 * 1024) {
-    // a large weight image would cap the occupancy through LDS: one launch per output branch instead
-    // (the shared high-resolution input is then re-read through L2 / Infinity Cache)
-    for (int q = 0; q < (int)u.pw.size(); ++q) {
-      PwArgs one = a;
-      one.npass = 1;
-      one.pass[0] = a.pass[q];
-      const int rows16 = (one.pass[0].nrows + 15) & ~15;
-      one.wimg = a.wimg + one.pass[0].w_off;
-      one.wimg_floats = (rows16 * one.pass[0].w_stride + 3) & ~3;
-      one.pass[0].w_off = 0;
-      // re-base the launch on this pass's own resolution so that its tiles are full 16x32 tiles
-      one.H0 = H0 >> one.pass[0].r; one.W0 = W0 >> one.pass[0].r;
-      one.pass[0].r = 0;
-      one.tiles_x = (one.W0 + PW_TX0 - 1) / PW_TX0; one.tiles_y = (one.H0 + PW_TY0 - 1) / PW_TY0;
-      LAUNCH_TRY(csn_launch_pw(one, 2, c.stream));
-    }
-    return CSN_OK;
   }
   LAUNCH_TRY(csn_launch_pw(a, 2, c.stream));
   return CSN_OK;
@@ -469,32 +484,12 @@ int run_unit(const Ctx& c, const UnitPlan& u) {
         for (int i = 0; i < d.n_in; ++i)
           if (d.cin[i] > 0) xin[i] = c.act_in(d.in_act[i]);
       }
-      if (d.ksize == 1) {
-        float* outp[3] = {nullptr, nullptr, nullptr};
-        for (int j = 0; j < d.n_out; ++j)
-          if (d.cout[j] > 0) outp[j] = c.act_out(d.out_act[j]);
-        const int st = launch_pw(c, u, xin, outp, P.H >> u.base_lvl, P.W >> u.base_lvl);
+      float* outp[3] = {nullptr, nullptr, nullptr};
+      for (int j = 0; j < d.n_out; ++j)
+        if (d.cout[j] > 0) outp[j] = c.act_out(d.out_act[j]);
+      for (const PwLaunchPlan& L : u.pwl) {
+        const int st = launch_pw(c, u, L, xin, outp);
         if (st != CSN_OK) return st;
-      } else {
-        for (const C3Plan& cp : u.c3) {
-          C3Args a;
-          a.nsrc = cp.nsrc; a.cin = cp.cin; a.cout = cp.cout; a.w = c.pk(cp.w);
-          for (int s = 0; s < 2; ++s) {
-            a.src[s].ptr = s < cp.nsrc ? xin[cp.src_branch[s]] : nullptr;
-            a.src[s].C = s < cp.nsrc ? cp.src_C[s] : 0;
-            a.src[s].shift = cp.src_shift[s];
-          }
-          a.H = P.H >> (u.base_lvl + cp.res_branch); a.W = P.W >> (u.base_lvl + cp.res_branch); a.B = S;
-          if (cp.to_z) {
-            a.out = reinterpret_cast<float*>(c.ws + u.z_off);
-            a.scale = a.shift = a.alpha = nullptr; a.zadd = nullptr;
-          } else {
-            a.out = c.act_out(d.out_act[cp.out_branch]);
-            a.scale = c.pk(cp.epi.scale); a.shift = c.pk(cp.epi.shift); a.alpha = c.pk(cp.epi.alpha);
-            a.zadd = cp.add_z ? reinterpret_cast<const float*>(c.ws + u.z_off) : nullptr;
-          }
-          LAUNCH_TRY(csn_launch_c3(a, c.stream));
-        }
       }
     } break;
     case CSN_UNIT_MS: {
@@ -512,12 +507,13 @@ int run_unit(const Ctx& c, const UnitPlan& u) {
     } break;
     case CSN_UNIT_CLS: {
       const float* xin[3] = {c.act_in(d.in_act[0]), nullptr, nullptr};
-      float* logits = reinterpret_cast<float*>(c.ws + u.logits_off);
-      float* outp[3] = {logits, nullptr, nullptr};
-      const int st = launch_pw(c, u, xin, outp, P.H >> 1, P.W >> 1);
-      if (st != CSN_OK) return st;
+      float* outp[3] = {nullptr, nullptr, nullptr};
+      for (const PwLaunchPlan& L : u.pwl) {
+        const int st = launch_pw(c, u, L, xin, outp);
+        if (st != CSN_OK) return st;
+      }
       Up2Args ua;
-      ua.in = logits; ua.out = c.y; ua.planes = S; ua.H = P.H; ua.W = P.W;
+      ua.in = reinterpret_cast<const float*>(c.ws + u.logits_off); ua.out = c.y; ua.planes = S; ua.H = P.H; ua.W = P.W;
       LAUNCH_TRY(csn_launch_up2(ua, c.stream));
     } break;
     default:

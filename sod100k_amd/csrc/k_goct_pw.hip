@@ -133,6 +133,58 @@ __device__ __forceinline__ void pw_batch_up(csn_buf rb, unsigned o00, unsigned o
     if (k0 + j < rmax) xrow[(k0 + j) * 64] = w00 * t0[j] + w01 * t1[j] + w10 * t2[j] + w11 * t3[j];
 }
 
+// 3x3 taps of an own-resolution slice: gathered entry kk = 9*ch + t, t = 3*(dy+1) + (dx+1).  `vm` has
+// bit t set when tap t of this lane's pixel lies inside the image (zero padding otherwise).
+template <int NB>
+__device__ __forceinline__ void pw_batch_taps(csn_buf rb, unsigned lo, unsigned cs4, int Wr, int dil, unsigned vm,
+                                              int k_lo, int k0, int n, int rmax, float* xrow) {
+  float v[NB];
+  unsigned m[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int kk = k_lo + min(k0 + j, n - 1);
+    const int ch = kk / 9, t = kk - 9 * ch;
+    const int dy = t / 3 - 1, dx = t - 3 * (t / 3) - 1;
+    v[j] = csn_ld1(rb, lo + (unsigned)((dy * Wr + dx) * dil * 4), (unsigned)ch * cs4);
+    m[j] = (vm >> t) & 1u;
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+    if (k0 + j < rmax) xrow[(k0 + j) * 64] = m[j] ? v[j] : 0.f;
+}
+
+// 3x3 taps of a 2x2-max-pooled slice (source at twice the resolution).
+template <int NB>
+__device__ __forceinline__ void pw_batch_pool2_taps(csn_buf rb, unsigned lo, unsigned cs4, unsigned ws4, unsigned vm,
+                                                    int k_lo, int k0, int n, int rmax, float* xrow) {
+  float2 a0[NB], a1[NB];
+  unsigned m[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int kk = k_lo + min(k0 + j, n - 1);
+    const int ch = kk / 9, t = kk - 9 * ch;
+    const int dy = t / 3 - 1, dx = t - 3 * (t / 3) - 1;
+    const unsigned vo = lo + (unsigned)(2 * dy) * ws4 + (unsigned)(8 * dx);
+    a0[j] = csn_ld2(rb, vo, (unsigned)ch * cs4);
+    a1[j] = csn_ld2(rb, vo + ws4, (unsigned)ch * cs4);
+    m[j] = (vm >> t) & 1u;
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+    if (k0 + j < rmax)
+      xrow[(k0 + j) * 64] = m[j] ? fmaxf(fmaxf(a0[j].x, a0[j].y), fmaxf(a1[j].x, a1[j].y)) : 0.f;
+}
+
+__device__ __forceinline__ unsigned pw_tap_mask(int y, int x, int Hr, int Wr, int dil) {
+  unsigned vm = 0;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + (t / 3 - 1) * dil, xx = x + (t % 3 - 1) * dil;
+    vm |= (yy >= 0 && yy < Hr && xx >= 0 && xx < Wr) ? (1u << t) : 0u;
+  }
+  return vm;
+}
+
 __device__ __forceinline__ void pw_gather_slice(PwPassP ps, int s, int c_lo, int c_hi, float* xrow, int rmax, int b,
                                                 int y, int x, int Hr, int Wr) {
   const int mode = ps->src[s].mode;
@@ -155,6 +207,22 @@ __device__ __forceinline__ void pw_gather_slice(PwPassP ps, int s, int c_lo, int
     const csn_buf rb = csn_make_buf(ps->src[s].ptr + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
     const unsigned lo = ((unsigned)(4 * y) * Ws + 4u * x) * 4u;
     for (int k0 = 0; k0 < n; k0 += 2) pw_batch_pool4<2>(rb, lo, cs * 4u, Ws * 4u, k0, n, rmax, xrow);
+  } else if (mode == PW_TAPS) {
+    const unsigned cs = (unsigned)(Hr * Wr);
+    const int dil = ps->src[s].dil;
+    const csn_buf rb = csn_make_buf_n(ps->src[s].ptr + (int64_t)b * ps->src[s].Ctot * cs,
+                                      (unsigned)ps->src[s].Ctot * cs * 4u);
+    const unsigned lo = (unsigned)(y * Wr + x) * 4u;
+    const unsigned vm = pw_tap_mask(y, x, Hr, Wr, dil);
+    pw_batch_taps<16>(rb, lo, cs * 4u, Wr, dil, vm, c_lo, 0, n, rmax, xrow);
+  } else if (mode == PW_POOL2_TAPS) {
+    const unsigned Ws = (unsigned)Wr * 2u;
+    const unsigned cs = (unsigned)(Hr * 2) * Ws;
+    const csn_buf rb = csn_make_buf_n(ps->src[s].ptr + (int64_t)b * ps->src[s].Ctot * cs,
+                                      (unsigned)ps->src[s].Ctot * cs * 4u);
+    const unsigned lo = ((unsigned)(2 * y) * Ws + 2u * x) * 4u;
+    const unsigned vm = pw_tap_mask(y, x, Hr, Wr, 1);
+    for (int k0 = 0; k0 < n; k0 += 8) pw_batch_pool2_taps<8>(rb, lo, cs * 4u, Ws * 4u, vm, c_lo, k0, n, rmax, xrow);
   } else {  // bilinear from a 2x / 4x coarser branch, align_corners=False
     const int sh = mode == PW_UP2 ? 1 : 2;
     const int Hs = Hr >> sh, Ws = Wr >> sh;
@@ -218,7 +286,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
       const int ng = (npx + 63) >> 6;
       const int cin = ps->cin, cin4 = ps->cin4, nrows = ps->nrows, stride = ps->w_stride;
       const float* wl0 = lds + ps->w_off;
-      const int c1 = ps->src[0].C, c2 = c1 + ps->src[1].C;
+      const int c1 = ps->src[0].K, c2 = c1 + ps->src[1].K;
       for (int c = 0; c < ng; ++c) {
         if (((gbase + c) & 3) != wave) continue;
         // pixel this lane gathers
@@ -227,7 +295,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
         const int py_ = (ty0 >> r) + (p >> txl), px_ = (tx0 >> r) + (p & ((1 << txl) - 1));
         const bool valid = p < npx && py_ < Hr && px_ < Wr;
         const int64_t cs = (int64_t)Hr * Wr;
-        float* __restrict__ ob = ps->out + (int64_t)b * nrows * cs + (int64_t)gy * Wr + gx;
+        float* __restrict__ ob = ps->out + (int64_t)b * ps->out_ctot * cs + (int64_t)gy * Wr + gx;
         for (int row0 = 0; row0 < nrows; row0 += 16 * MAXNT) {
           csn_f4 acc[MAXNT][4];
 #pragma unroll

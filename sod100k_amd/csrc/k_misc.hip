@@ -51,6 +51,9 @@ __global__ __launch_bounds__(CSN_BLOCK) void csn_prep_kernel(const CsnPrepJob* _
             j.p0f * arena[j.src0 + ((int64_t)co * j.p0 + ci) * 9 + t];
       }
     } break;
+    case CSN_PREP_EYE:
+      for (int i = tid; i < j.n; i += CSN_BLOCK) dst[(int64_t)i * j.p2 + j.p3 + i] = j.p0f;
+      break;
     default:
       break;
   }
@@ -248,3 +251,5 @@ int csn_launch_up2(const Up2Args& a, void* stream) {
   CSN_LAUNCH(bilinear_up2_kernel, dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
 }
+
+int csn_kernels_init(void) { return 0; }
