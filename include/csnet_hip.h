@@ -99,6 +99,12 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
                     int32_t B, int32_t H, int32_t W, int32_t sub_batch, csn_plan** out_plan);
 void csn_plan_destroy(csn_plan* plan);
 
+/* Options (default in brackets).  CSN_OPT_FUSE_DW [1]: run the two depthwise units of an ILBlock
+ * (conv3x3_1 -> conv3x3_2, csnet.py:74-75) as one kernel that keeps the intermediate in LDS; with 0 every
+ * unit's output is materialised in the workspace (per-unit parity probes). */
+enum csn_option { CSN_OPT_FUSE_DW = 1 };
+int csn_plan_set_option(csn_plan* plan, int32_t option, int32_t value);
+
 size_t csn_plan_workspace_bytes(const csn_plan* plan);
 int csn_plan_act_info(const csn_plan* plan, int32_t act_id, csn_act_info* out);
 int32_t csn_plan_num_units(const csn_plan* plan);

@@ -19,6 +19,7 @@ SOURCES = ("csn_plan.hip", "k_misc.hip", "k_goct_pw.hip", "k_ms.hip")
 MAX_BRANCH = 3
 NDIL = 5
 UNIT_GOCT, UNIT_DW, UNIT_MS, UNIT_CLS = 1, 2, 3, 4
+OPT_FUSE_DW = 1
 
 
 class ActDesc(C.Structure):
@@ -95,6 +96,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     lib.csn_plan_destroy.restype = None
     lib.csn_plan_destroy.argtypes = [C.c_void_p]
+    lib.csn_plan_set_option.restype = C.c_int
+    lib.csn_plan_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.csn_plan_workspace_bytes.restype = C.c_size_t
     lib.csn_plan_workspace_bytes.argtypes = [C.c_void_p]
     lib.csn_plan_num_units.restype = C.c_int32
@@ -117,7 +120,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
 
 EXPORTS: Sequence[str] = (
     "csn_abi_version", "csn_strerror", "csn_last_hip_error", "csn_plan_create", "csn_plan_destroy",
-    "csn_plan_workspace_bytes", "csn_plan_act_info", "csn_plan_num_units", "csn_plan_refresh_params",
+    "csn_plan_set_option", "csn_plan_workspace_bytes", "csn_plan_act_info", "csn_plan_num_units", "csn_plan_refresh_params",
     "csn_forward", "csn_forward_profile", "csn_unit_kernel_name", "csn_unit_algorithmic_bytes")
 
 _lib: Optional[C.CDLL] = None

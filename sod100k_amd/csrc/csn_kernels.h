@@ -35,6 +35,10 @@ struct DwBranch {
   const float* scale;
   const float* shift;
   const float* alpha;
+  const float* w9b;      // second unit of a fused pair (dw3x3x2 kernel) -- null otherwise
+  const float* scale_b;
+  const float* shift_b;
+  const float* alpha_b;
   int32_t C, H, W;
   int32_t LX, NY, R;          // lanes per row (4 px each), lane rows per block, rows per lane
   int32_t tiles_x, tiles_y;   // tiles per plane
@@ -125,6 +129,8 @@ struct Up2Args {
 // launchers (implemented next to the kernels)
 int csn_launch_prep(const CsnPrepJob* jobs_dev, int njobs, const float* arena, float* packed, void* stream);
 int csn_launch_dw(const DwArgs& a, void* stream);
+int csn_launch_dw2(const DwArgs& a, void* stream);
+size_t csn_dw2_lds_bytes(const DwArgs& a);
 int csn_launch_pw(const PwArgs& a, int maxnt, void* stream);
 int csn_launch_ms(const MsArgs& a, void* stream);
 int csn_launch_pool(const PoolArgs& a, void* stream);

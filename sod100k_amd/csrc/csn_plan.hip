@@ -87,6 +87,7 @@ struct UnitPlan {
   // DW
   int64_t dw_w[3] = {-1, -1, -1};
   Epi dw_epi[3];
+  int fuse_next = 0;   // DW: the next unit is the second depthwise unit of the same ILBlock
   // MS
   int64_t ms_w[5] = {-1, -1, -1, -1, -1};
   Epi ms_epi;
@@ -106,6 +107,7 @@ struct csn_plan {
   std::vector<CsnPrepJob> jobs;
   CsnPrepJob* jobs_dev = nullptr;
   bool params_ready = false;
+  bool fuse_dw = true;
   std::vector<hipEvent_t> ev;
 };
 
@@ -160,7 +162,7 @@ int finish_launch(Builder& bl, PwLaunchPlan& L) {
     img = (img + 3) & ~3;
   }
   if ((int)L.passes.size() > PW_MAX_PASS) FAIL(CSN_E_UNSUPPORTED, "too many passes in one launch");
-  if (((int64_t)img + 4 * 16 * 64) * 4 > 160 * 1024) FAIL(CSN_E_UNSUPPORTED, "weight image exceeds the LDS of a CU");
+  if (((int64_t)img + 4 * 16 * 80) * 4 > 160 * 1024) FAIL(CSN_E_UNSUPPORTED, "weight image exceeds the LDS of a CU");
   L.wimg_floats = img;
   L.wimg = bl.alloc_packed(img);
   for (const PwPassPlan& ps : L.passes)
@@ -384,6 +386,22 @@ struct Ctx {
   const float* pk(int64_t off) const { return P.packed + off; }
 };
 
+// rows per lane of the fused depthwise pair: the intermediate tile (NY*R + 2 rows) must stay small in LDS
+int choose_dw2_rows(int H, int NY, int LX) {
+  int best = 1;
+  double best_s = -1;
+  for (int R = 1; R <= 16; ++R) {
+    const int rows = NY * R;
+    const size_t lds = (size_t)(rows + 2) * (LX * 4 + 8) * 4;
+    if (lds > 36 * 1024 && R > 1) break;
+    const int tiles = (H + rows - 1) / rows;
+    const double eff = (double)H / ((double)tiles * rows);
+    const double s = eff * rows / (rows + 4.0);   // halo rows are fetched and computed twice
+    if (s > best_s + 1e-9) { best_s = s; best = R; }
+  }
+  return best;
+}
+
 int choose_dw_rows(int H, int NY) {
   int best = 4;
   double best_s = -1;
@@ -431,34 +449,45 @@ int launch_pw(const Ctx& c, const UnitPlan& u, const PwLaunchPlan& L, const floa
   return CSN_OK;
 }
 
-int run_unit(const Ctx& c, const UnitPlan& u) {
+int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
   const csn_plan& P = c.P;
   const csn_unit_desc& d = u.d;
   const int S = P.S;
   switch (d.kind) {
     case CSN_UNIT_DW: {
       DwArgs a;
+      const bool fused = next != nullptr;
       a.nbr = 0; a.B = S;
       int blk = 0;
       for (int k = 0; k < d.n_in; ++k) {
         if (d.cout[k] == 0) continue;
         DwBranch& br = a.br[a.nbr++];
         const Act& act = P.acts[d.in_act[k]];
-        br.in = c.act_in(d.in_act[k]); br.out = c.act_out(d.out_act[k]);
+        br.in = c.act_in(d.in_act[k]);
+        br.out = c.act_out(fused ? next->d.out_act[k] : d.out_act[k]);
         br.w9 = c.pk(u.dw_w[k]);
         br.scale = c.pk(u.dw_epi[k].scale); br.shift = c.pk(u.dw_epi[k].shift); br.alpha = c.pk(u.dw_epi[k].alpha);
+        br.w9b = br.scale_b = br.shift_b = br.alpha_b = nullptr;
         br.C = d.cout[k]; br.H = P.H >> act.lvl; br.W = P.W >> act.lvl;
         const int cols = (br.W + 3) / 4;
         br.LX = cols < 64 ? cols : 64;
         br.NY = CSN_BLOCK / br.LX;
         br.tiles_x = (cols + br.LX - 1) / br.LX;
-        br.R = choose_dw_rows(br.H, br.NY);
+        if (fused) {
+          br.w9b = c.pk(next->dw_w[k]);
+          br.scale_b = c.pk(next->dw_epi[k].scale); br.shift_b = c.pk(next->dw_epi[k].shift);
+          br.alpha_b = c.pk(next->dw_epi[k].alpha);
+          br.R = choose_dw2_rows(br.H, br.NY, br.LX);
+        } else {
+          br.R = choose_dw_rows(br.H, br.NY);
+        }
         br.tiles_y = (br.H + br.NY * br.R - 1) / (br.NY * br.R);
         blk += br.tiles_x * br.tiles_y * br.C * S;
         br.blk_end = blk;
       }
       if (a.nbr == 0) return CSN_OK;
-      LAUNCH_TRY(csn_launch_dw(a, c.stream));
+      if (fused) LAUNCH_TRY(csn_launch_dw2(a, c.stream));
+      else LAUNCH_TRY(csn_launch_dw(a, c.stream));
     } break;
     case CSN_UNIT_GOCT: {
       // optional 2x2 avg-pool prologue of every input branch (csnet.py:679-680)
@@ -597,6 +626,24 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
     }
     u.alg_bytes = bytes;
   }
+  // fusable depthwise pairs: unit k+1 consumes exactly unit k's outputs, nobody else does, one tile in x
+  for (int k = 0; k + 1 < n_units; ++k) {
+    const csn_unit_desc& a = P->units[k].d;
+    const csn_unit_desc& b = P->units[k + 1].d;
+    if (a.kind != CSN_UNIT_DW || b.kind != CSN_UNIT_DW || a.n_in != b.n_in) continue;
+    bool ok = true;
+    for (int i = 0; i < a.n_in && ok; ++i) {
+      if (a.cout[i] != b.cin[i]) ok = false;
+      if (a.cout[i] == 0) continue;
+      if (a.out_act[i] != b.in_act[i] || (W >> P->acts[a.out_act[i]].lvl) > 256) ok = false;
+      for (int q = 0; q < n_units && ok; ++q) {
+        if (q == k + 1) continue;
+        for (int s = 0; s < CSN_MAX_BRANCH; ++s)
+          if (P->units[q].d.in_act[s] == a.out_act[i] && s < P->units[q].d.n_in && P->units[q].d.cin[s] > 0) ok = false;
+      }
+    }
+    if (ok) { P->units[k].fuse_next = 1; ++k; }
+  }
   if (csn_kernels_init() != 0) { delete P; return CSN_E_HIP; }
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&P->packed), (size_t)(P->packed_floats + 4) * sizeof(float));
   if (e != hipSuccess) { delete P; hip_fail(e, "hipMalloc(packed)"); return CSN_E_NOMEM; }
@@ -615,6 +662,14 @@ void csn_plan_destroy(csn_plan* P) {
   if (P->packed) (void)hipFree(P->packed);
   if (P->jobs_dev) (void)hipFree(P->jobs_dev);
   delete P;
+}
+
+int csn_plan_set_option(csn_plan* P, int32_t option, int32_t value) {
+  if (!P) return CSN_E_INVALID;
+  switch (option) {
+    case CSN_OPT_FUSE_DW: P->fuse_dw = value != 0; return CSN_OK;
+    default: return CSN_E_INVALID;
+  }
 }
 
 size_t csn_plan_workspace_bytes(const csn_plan* P) { return P ? (size_t)P->ws_bytes : 0; }
@@ -666,9 +721,14 @@ static int forward_impl(csn_plan* P, const float* x, float* y, void* workspace, 
       Ctx c{*P, x + start * in_stride, y + start * out_stride, static_cast<char*>(workspace), stream};
       if (prof) HIP_TRY(hipEventRecord(P->ev[0], (hipStream_t)stream));
       for (int u = 0; u < nu; ++u) {
-        const int st = run_unit(c, P->units[u]);
+        const bool fuse = P->fuse_dw && P->units[u].fuse_next && u + 1 < nu;
+        const int st = run_unit(c, P->units[u], fuse ? &P->units[u + 1] : nullptr);
         if (st != CSN_OK) return st;
         if (prof) HIP_TRY(hipEventRecord(P->ev[u + 1], (hipStream_t)stream));
+        if (fuse) {   // the pair ran as one kernel: the second unit takes no time of its own
+          ++u;
+          if (prof) HIP_TRY(hipEventRecord(P->ev[u + 1], (hipStream_t)stream));
+        }
       }
       if (prof) {
         HIP_TRY(hipEventSynchronize(P->ev[nu]));

@@ -42,7 +42,9 @@ typedef float csn_f4 __attribute__((ext_vector_type(4)));
 #define CSN_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #endif
 
-#define PW_KC 16  // channels per LDS panel
+#define PW_KC 16   // channels per LDS panel
+#define PW_XP 80   // panel row pitch (floats): == 16 (mod 32), so the two k rows a 32-lane half reads hit disjoint banks
+#define PW_EP 68   // pitch of the epilogue transpose: rows 4 apart land on the other half of the banks
 
 // acc[i] += sum_{u<4} W[row0 + (lane>>4)*4 + i][k0 + u] * x[k0 + u][16 s + (lane&15)]
 // wt = &W[row0][k0] in the LDS weight image (row pitch `stride`), xs = &x[k0][16 s] in the wave's panel.
@@ -52,12 +54,12 @@ __device__ __forceinline__ void pw_mfma16(const float* wt, int stride, const flo
   for (int i = 0; i < 4; ++i) {
     const int row = (lane >> 4) * 4 + i;
     float a = acc[i];
-    for (int u = 0; u < 4; ++u) a = fmaf(wt[row * stride + u], xs[u * 64 + col], a);
+    for (int u = 0; u < 4; ++u) a = fmaf(wt[row * stride + u], xs[u * PW_XP + col], a);
     acc[i] = a;
   }
 #else
   const float av = wt[(lane & 15) * stride + (lane >> 4)];
-  const float bv = xs[(lane >> 4) * 64 + (lane & 15)];
+  const float bv = xs[(lane >> 4) * PW_XP + (lane & 15)];
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
 #endif
 }
@@ -78,7 +80,7 @@ __device__ __forceinline__ void pw_batch_own(csn_buf rb, unsigned lo, unsigned c
   for (int j = 0; j < NB; ++j) v[j] = csn_ld1(rb, lo, (unsigned)min(k0 + j, n - 1) * cs4);
 #pragma unroll
   for (int j = 0; j < NB; ++j)
-    if (k0 + j < rmax) xrow[(k0 + j) * 64] = v[j];
+    if (k0 + j < rmax) xrow[(k0 + j) * PW_XP] = v[j];
 }
 
 template <int NB>
@@ -93,7 +95,7 @@ __device__ __forceinline__ void pw_batch_pool2(csn_buf rb, unsigned lo, unsigned
   }
 #pragma unroll
   for (int j = 0; j < NB; ++j)
-    if (k0 + j < rmax) xrow[(k0 + j) * 64] = fmaxf(fmaxf(a0[j].x, a0[j].y), fmaxf(a1[j].x, a1[j].y));
+    if (k0 + j < rmax) xrow[(k0 + j) * PW_XP] = fmaxf(fmaxf(a0[j].x, a0[j].y), fmaxf(a1[j].x, a1[j].y));
 }
 
 template <int NB>
@@ -111,7 +113,7 @@ __device__ __forceinline__ void pw_batch_pool4(csn_buf rb, unsigned lo, unsigned
     float m = -3.402823466e+38f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) m = fmaxf(m, fmaxf(fmaxf(q[j][r].x, q[j][r].y), fmaxf(q[j][r].z, q[j][r].w)));
-    if (k0 + j < rmax) xrow[(k0 + j) * 64] = m;
+    if (k0 + j < rmax) xrow[(k0 + j) * PW_XP] = m;
   }
 }
 
@@ -130,7 +132,7 @@ __device__ __forceinline__ void pw_batch_up(csn_buf rb, unsigned o00, unsigned o
   }
 #pragma unroll
   for (int j = 0; j < NB; ++j)
-    if (k0 + j < rmax) xrow[(k0 + j) * 64] = w00 * t0[j] + w01 * t1[j] + w10 * t2[j] + w11 * t3[j];
+    if (k0 + j < rmax) xrow[(k0 + j) * PW_XP] = w00 * t0[j] + w01 * t1[j] + w10 * t2[j] + w11 * t3[j];
 }
 
 // 3x3 taps of an own-resolution slice: gathered entry kk = 9*ch + t, t = 3*(dy+1) + (dx+1).  `vm` has
@@ -150,7 +152,7 @@ __device__ __forceinline__ void pw_batch_taps(csn_buf rb, unsigned lo, unsigned 
   }
 #pragma unroll
   for (int j = 0; j < NB; ++j)
-    if (k0 + j < rmax) xrow[(k0 + j) * 64] = m[j] ? v[j] : 0.f;
+    if (k0 + j < rmax) xrow[(k0 + j) * PW_XP] = m[j] ? v[j] : 0.f;
 }
 
 // 3x3 taps of a 2x2-max-pooled slice (source at twice the resolution).
@@ -172,7 +174,7 @@ __device__ __forceinline__ void pw_batch_pool2_taps(csn_buf rb, unsigned lo, uns
 #pragma unroll
   for (int j = 0; j < NB; ++j)
     if (k0 + j < rmax)
-      xrow[(k0 + j) * 64] = m[j] ? fmaxf(fmaxf(a0[j].x, a0[j].y), fmaxf(a1[j].x, a1[j].y)) : 0.f;
+      xrow[(k0 + j) * PW_XP] = m[j] ? fmaxf(fmaxf(a0[j].x, a0[j].y), fmaxf(a1[j].x, a1[j].y)) : 0.f;
 }
 
 __device__ __forceinline__ unsigned pw_tap_mask(int y, int x, int Hr, int Wr, int dil) {
@@ -248,7 +250,7 @@ __device__ __forceinline__ void pw_contract(const float* wl, int stride, const f
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) pw_mfma16(wl + (16 * t) * stride + k0, stride, xb + k0 * 64 + 16 * s, lane, acc[t][s]);
+      for (int s = 0; s < 4; ++s) pw_mfma16(wl + (16 * t) * stride + k0, stride, xb + k0 * PW_XP + 16 * s, lane, acc[t][s]);
     }
   }
 }
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
   __syncthreads();
 
   const int wave = tid >> 6, lane = tid & 63;
-  float* xb = lds + a->wimg_floats + wave * (PW_KC * 64);   // this wave's x[k][64] panel
+  float* xb = lds + a->wimg_floats + wave * (PW_KC * PW_XP);   // this wave's x[k][64 px] panel
   const int H0 = a->H0, W0 = a->W0, npass = a->npass;
   const int tiles_xy = a->tiles_x * a->tiles_y;
   const int ntiles = tiles_xy * a->B;
@@ -312,15 +314,15 @@ __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
             if (kc < c1) pw_gather_slice(ps, 0, kc, min(kend, c1), xb + lane, PW_KC, b, gy, gx, Hr, Wr);
             if (max(kc, c1) < min(kend, c2)) {
               const int r0 = max(kc, c1) - kc;
-              pw_gather_slice(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xb + r0 * 64 + lane, PW_KC - r0, b, gy, gx,
+              pw_gather_slice(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xb + r0 * PW_XP + lane, PW_KC - r0, b, gy, gx,
                               Hr, Wr);
             }
             if (max(kc, c2) < min(kend, cin)) {
               const int r0 = max(kc, c2) - kc;
-              pw_gather_slice(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xb + r0 * 64 + lane, PW_KC - r0, b, gy, gx,
+              pw_gather_slice(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xb + r0 * PW_XP + lane, PW_KC - r0, b, gy, gx,
                               Hr, Wr);
             }
-            for (int k = max(cin, kc); k < kend; ++k) xb[(k - kc) * 64 + lane] = 0.f;  // pad to a multiple of 4
+            for (int k = max(cin, kc); k < kend; ++k) xb[(k - kc) * PW_XP + lane] = 0.f;  // pad to a multiple of 4
             CSN_WAVE_SYNC();  // panel complete
             const float* wl = wl0 + row0 * stride + kc;
             if (nt == 1) pw_contract<1, MAXNT>(wl, stride, xb, kend - kc, lane, acc);
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
 #pragma unroll
               for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) xb[((lane >> 4) * 4 + i) * 64 + 16 * s + (lane & 15)] = acc[t][s][i];
+                for (int i = 0; i < 4; ++i) xb[((lane >> 4) * 4 + i) * PW_EP + 16 * s + (lane & 15)] = acc[t][s][i];
               CSN_WAVE_SYNC();
               const int rbase = row0 + 16 * t;
               const int rn = min(16, nrows - rbase);
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
               float* __restrict__ orow = ob + (int64_t)rbase * cs;
 #pragma unroll 4
               for (int rr = 0; rr < rn; ++rr) {
-                const float val = csn_epi(xb[rr * 64 + lane], scale[rr], shift[rr], alpha[rr]);
+                const float val = csn_epi(xb[rr * PW_EP + lane], scale[rr], shift[rr], alpha[rr]);
                 if (valid) orow[rr * cs] = val;
               }
             }
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
 int csn_launch_pw(const PwArgs& a, int maxnt, void* stream) {
   const int ntiles = a.tiles_x * a.tiles_y * a.B;
   const dim3 grid(ntiles < PW_MAX_GRID ? ntiles : PW_MAX_GRID);
-  const size_t lds = ((size_t)a.wimg_floats + 4 * PW_KC * 64) * sizeof(float);
+  const size_t lds = ((size_t)a.wimg_floats + 4 * PW_KC * PW_XP) * sizeof(float);
 #ifndef CSN_CPU_EMU
   static bool attr_done = false;
   if (!attr_done) {

@@ -172,6 +172,162 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- two depthwise units back to back
+// conv3x3_1 -> conv3x3_2 of an ILBlock (csnet.py:74-75) in one pass over HBM: the block computes the first
+// unit's output for its rows plus one halo row above and below into LDS (never written to HBM), then the
+// second unit reads its 3x3 windows from LDS.  Rows of the intermediate that lie outside the image are
+// ZERO (the second conv pads its input, it does not see the first conv's response to padding).
+// Used when the plane is at most 256 pixels wide (one tile in x), i.e. for every CSNet resolution.
+template <bool VEC>
+__global__ __launch_bounds__(CSN_BLOCK) void dw3x3x2_bn_prelu_kernel(DwArgs a) {
+  CSN_DYN_SMEM(float, lds);
+  int bid = blockIdx.x;
+  int k = 0;
+  if (a.nbr > 1 && bid >= a.br[0].blk_end) k = 1;
+  if (a.nbr > 2 && bid >= a.br[1].blk_end) k = 2;
+  const DwBranch br = a.br[k];
+  if (k > 0) bid -= a.br[k - 1].blk_end;
+  const int ty = bid % br.tiles_y;
+  const int pc = bid / br.tiles_y;  // b*C + c
+  const int c = pc % br.C;
+  const int tid = threadIdx.x;
+  const int lx = tid % br.LX, ly = tid / br.LX;
+  const int H = br.H, W = br.W, R = br.R, NY = br.NY;
+  const int pitch = br.LX * 4 + 8;           // [4 pad | LX*4 pixels | 4 pad], rows 16-byte aligned
+  const int x0 = lx * 4;
+  const int yb = ty * NY * R;                // first output row of the block
+  const bool active = ly < NY && x0 < W;
+  const csn_buf rb = csn_make_buf_n(br.in + (int64_t)pc * H * W, (unsigned)(H * W) * 4u);
+  float* __restrict__ op = br.out + (int64_t)pc * H * W;
+  csn_cfp w9a = csn_const(br.w9), w9b = csn_const(br.w9b);
+  const bool has_l = x0 > 0, has_r = x0 + 4 < W;
+  // ---- phase 1: intermediate rows [yb - 1, yb + NY*R] -> LDS row index (y - yb + 1) ----
+  if (active) {
+    float w[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) w[i] = w9a[c * 9 + i];
+    const float sc = csn_const(br.scale)[c], sh = csn_const(br.shift)[c], al = csn_const(br.alpha)[c];
+    const int r_first = ly * R - (ly == 0 ? 1 : 0);
+    const int r_last = ly * R + R + (ly == NY - 1 ? 1 : 0);   // exclusive
+    if (x0 == 0 || !has_r) {                                   // zero the pad columns once per row
+      for (int r = r_first; r < r_last; ++r) {
+        float* row = lds + (r + 1) * pitch;
+        if (x0 == 0) { row[0] = row[1] = row[2] = row[3] = 0.f; }
+        if (!has_r) {
+          const int xe = x0 + 4 + 4;  // first pad column after this lane's strip
+#pragma unroll
+          for (int j = 0; j < 4; ++j) row[xe + j] = 0.f;
+        }
+      }
+    }
+    DwRow r0 = dw_load_row<VEC>(rb, yb + r_first - 1, x0, W, has_l, has_r);
+    DwRow r1 = dw_load_row<VEC>(rb, yb + r_first, x0, W, has_l, has_r);
+    for (int r = r_first; r < r_last; r += 4) {
+      const DwRow n0 = dw_load_row<VEC>(rb, yb + r + 1, x0, W, has_l, has_r);
+      const DwRow n1 = dw_load_row<VEC>(rb, yb + r + 2, x0, W, has_l, has_r);
+      const DwRow n2 = dw_load_row<VEC>(rb, yb + r + 3, x0, W, has_l, has_r);
+      const DwRow n3 = dw_load_row<VEC>(rb, yb + r + 4, x0, W, has_l, has_r);
+      const DwRow tp[6] = {r0, r1, n0, n1, n2, n3};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int rr = r + q;
+        if (rr < r_last) {
+          const int yy = yb + rr;
+          const bool inside = yy >= 0 && yy < H;
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float acc = w[0] * tp[q].v[j];
+            acc = fmaf(w[1], tp[q].v[j + 1], acc);
+            acc = fmaf(w[2], tp[q].v[j + 2], acc);
+            acc = fmaf(w[3], tp[q + 1].v[j], acc);
+            acc = fmaf(w[4], tp[q + 1].v[j + 1], acc);
+            acc = fmaf(w[5], tp[q + 1].v[j + 2], acc);
+            acc = fmaf(w[6], tp[q + 2].v[j], acc);
+            acc = fmaf(w[7], tp[q + 2].v[j + 1], acc);
+            acc = fmaf(w[8], tp[q + 2].v[j + 2], acc);
+            const float t = csn_epi(acc, sc, sh, al);
+            o[j] = (inside && x0 + j < W) ? t : 0.f;
+          }
+          *reinterpret_cast<float4*>(lds + (rr + 1) * pitch + 4 + x0) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+      }
+      r0 = n2;
+      r1 = n3;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: second depthwise unit from LDS ----
+  if (active) {
+    float w[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) w[i] = w9b[c * 9 + i];
+    const float sc = csn_const(br.scale_b)[c], sh = csn_const(br.shift_b)[c], al = csn_const(br.alpha_b)[c];
+    const float* base = lds + 4 + x0;   // column x0 of LDS row 0 (= image row yb - 1)
+    auto ld_row = [&](int lr) {
+      DwRow r;
+      const float* p = base + lr * pitch;
+      const float4 cv = *reinterpret_cast<const float4*>(p);
+      r.v[0] = p[-1]; r.v[1] = cv.x; r.v[2] = cv.y; r.v[3] = cv.z; r.v[4] = cv.w; r.v[5] = p[4];
+      return r;
+    };
+    const int rs = ly * R;
+    DwRow top = ld_row(rs), mid = ld_row(rs + 1);
+    for (int q = 0; q < R; ++q) {
+      const int y = yb + rs + q;
+      if (y >= H) break;
+      const DwRow bot = ld_row(rs + q + 2);
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float acc = w[0] * top.v[j];
+        acc = fmaf(w[1], top.v[j + 1], acc);
+        acc = fmaf(w[2], top.v[j + 2], acc);
+        acc = fmaf(w[3], mid.v[j], acc);
+        acc = fmaf(w[4], mid.v[j + 1], acc);
+        acc = fmaf(w[5], mid.v[j + 2], acc);
+        acc = fmaf(w[6], bot.v[j], acc);
+        acc = fmaf(w[7], bot.v[j + 1], acc);
+        acc = fmaf(w[8], bot.v[j + 2], acc);
+        o[j] = csn_epi(acc, sc, sh, al);
+      }
+      float* q4 = op + (int64_t)y * W + x0;
+      if (VEC) {
+        *reinterpret_cast<float4*>(q4) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (x0 + j < W) q4[j] = o[j];
+      }
+      top = mid;
+      mid = bot;
+    }
+  }
+}
+
+size_t csn_dw2_lds_bytes(const DwArgs& a) {
+  size_t m = 0;
+  for (int k = 0; k < a.nbr; ++k) {
+    const size_t n = (size_t)(a.br[k].NY * a.br[k].R + 2) * (a.br[k].LX * 4 + 8) * sizeof(float);
+    if (n > m) m = n;
+  }
+  return m;
+}
+
+int csn_launch_dw2(const DwArgs& a, void* stream) {
+  const int nblk = a.br[a.nbr - 1].blk_end;
+  if (nblk <= 0) return 0;
+  bool vec = true;
+  for (int k = 0; k < a.nbr; ++k) vec = vec && (a.br[k].W % 4 == 0);
+  const size_t lds = csn_dw2_lds_bytes(a);
+  if (vec) {
+    CSN_LAUNCH((dw3x3x2_bn_prelu_kernel<true>), dim3(nblk), dim3(CSN_BLOCK), lds, stream, a);
+  } else {
+    CSN_LAUNCH((dw3x3x2_bn_prelu_kernel<false>), dim3(nblk), dim3(CSN_BLOCK), lds, stream, a);
+  }
+  return (int)hipGetLastError();
+}
+
 int csn_launch_dw(const DwArgs& a, void* stream) {
   const int nblk = a.br[a.nbr - 1].blk_end;
   if (nblk <= 0) return 0;

@@ -112,6 +112,9 @@ class Engine:
             self.lib.csn_plan_destroy(plan)
             self.plan = None
 
+    def set_option(self, option: int, value: int) -> None:
+        N.check(self.lib, self.lib.csn_plan_set_option(self.plan, option, value), "csn_plan_set_option")
+
     def _stream(self) -> int:
         if self.device.type == "cuda":
             return torch.cuda.current_stream(self.device).cuda_stream

@@ -52,8 +52,9 @@ def check_unit_probes(lib, device, manifest):
     """G3: every unit's output against the reference's probes (localises a mismatch to a kernel)."""
     m, _ = make_model(lib, manifest, device)
     x = torch.from_numpy(I.randn_batch(0, 2)).to(device)
-    m(x)
     eng = m.engine_for(x)
+    eng.set_option(N.OPT_FUSE_DW, 0)      # materialise every unit's output for the probes
+    m(x)
     units, acts, names = m.describe(m._arena.offsets)
     probes = json.load(open(os.path.join(GOLD, "g3_unit_probes_x2.json")))
     worst = 0.0
