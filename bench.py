@@ -71,12 +71,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", device_id=dev)
-        dist = dist_mod
+    from sod100k_amd import dist as D
+    world = D.init(device=dev)
 
     from sod100k_amd.model import csnet as M
     from sod100k_amd.checkpoint import load_manifest_state_dict
@@ -99,22 +95,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = D.timed_region(step, args.steps, sync=lambda: torch.cuda.synchronize(dev), device=dev)
 
     # ---- per-kernel roofline (HIP events around every unit, same stream) ----
     ms, names, nbytes = eng.profile(x, iters=args.profile_iters)
@@ -165,8 +146,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(man)
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    D.finalize()
 
 
 def eng_sub(eng, B):

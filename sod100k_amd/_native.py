@@ -20,6 +20,7 @@ MAX_BRANCH = 3
 NDIL = 5
 UNIT_GOCT, UNIT_DW, UNIT_MS, UNIT_CLS = 1, 2, 3, 4
 OPT_FUSE_DW = 1
+OPT_GRAPH = 2
 
 
 class ActDesc(C.Structure):

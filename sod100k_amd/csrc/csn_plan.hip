@@ -108,6 +108,13 @@ struct csn_plan {
   CsnPrepJob* jobs_dev = nullptr;
   bool params_ready = false;
   bool fuse_dw = true;
+  bool use_graph = true;
+  // hipGraph of one whole csn_forward (all batch slices), captured on a plan-owned stream on the second
+  // call with the same (x, y, workspace) and replayed on the caller's stream afterwards
+  hipStream_t cap_stream = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  const void* g_x = nullptr; const void* g_y = nullptr; const void* g_ws = nullptr;
+  int eager_calls = 0;
   std::vector<hipEvent_t> ev;
 };
 
@@ -659,15 +666,22 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
 void csn_plan_destroy(csn_plan* P) {
   if (!P) return;
   for (hipEvent_t ev : P->ev) (void)hipEventDestroy(ev);
+#ifndef CSN_CPU_EMU
+  if (P->graph_exec) (void)hipGraphExecDestroy(P->graph_exec);
+  if (P->cap_stream) (void)hipStreamDestroy(P->cap_stream);
+#endif
   if (P->packed) (void)hipFree(P->packed);
   if (P->jobs_dev) (void)hipFree(P->jobs_dev);
   delete P;
 }
 
+static void drop_graph(csn_plan* P);
+
 int csn_plan_set_option(csn_plan* P, int32_t option, int32_t value) {
   if (!P) return CSN_E_INVALID;
   switch (option) {
-    case CSN_OPT_FUSE_DW: P->fuse_dw = value != 0; return CSN_OK;
+    case CSN_OPT_FUSE_DW: P->fuse_dw = value != 0; drop_graph(P); return CSN_OK;
+    case CSN_OPT_GRAPH: P->use_graph = value != 0; drop_graph(P); return CSN_OK;
     default: return CSN_E_INVALID;
   }
 }
@@ -698,7 +712,7 @@ int csn_plan_refresh_params(csn_plan* P, const float* arena, int64_t arena_float
   return CSN_OK;
 }
 
-static int forward_impl(csn_plan* P, const float* x, float* y, void* workspace, void* stream, int32_t iters,
+static int forward_body(csn_plan* P, const float* x, float* y, void* workspace, void* stream, int32_t iters,
                         float* unit_ms) {
   if (!P || !x || !y || !workspace) return CSN_E_INVALID;
   if (!P->params_ready) return CSN_E_STATE;
@@ -745,14 +759,50 @@ static int forward_impl(csn_plan* P, const float* x, float* y, void* workspace, 
   return CSN_OK;
 }
 
+static void drop_graph(csn_plan* P) {
+#ifndef CSN_CPU_EMU
+  if (P->graph_exec) { (void)hipGraphExecDestroy(P->graph_exec); P->graph_exec = nullptr; }
+#endif
+  P->g_x = P->g_y = P->g_ws = nullptr;
+  P->eager_calls = 0;
+}
+
 int csn_forward(csn_plan* P, const float* x, float* y, void* workspace, void* stream) {
-  return forward_impl(P, x, y, workspace, stream, 1, nullptr);
+#ifdef CSN_CPU_EMU
+  return forward_body(P, x, y, workspace, stream, 1, nullptr);
+#else
+  if (!P || !P->use_graph) return forward_body(P, x, y, workspace, stream, 1, nullptr);
+  if (x != P->g_x || y != P->g_y || workspace != P->g_ws) {
+    drop_graph(P);
+    P->g_x = x; P->g_y = y; P->g_ws = workspace;
+  }
+  if (P->graph_exec) {
+    HIP_TRY(hipGraphLaunch(P->graph_exec, (hipStream_t)stream));
+    return CSN_OK;
+  }
+  if (P->eager_calls++ < 1) return forward_body(P, x, y, workspace, stream, 1, nullptr);  // warm-up: lazy init done
+  if (!P->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&P->cap_stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamBeginCapture(P->cap_stream, hipStreamCaptureModeThreadLocal));
+  const int st = forward_body(P, x, y, workspace, P->cap_stream, 1, nullptr);
+  hipGraph_t g = nullptr;
+  const hipError_t e = hipStreamEndCapture(P->cap_stream, &g);
+  if (st != CSN_OK || e != hipSuccess || !g) {     // capture failed: stay eager
+    if (g) (void)hipGraphDestroy(g);
+    P->use_graph = false;
+    return forward_body(P, x, y, workspace, stream, 1, nullptr);
+  }
+  const hipError_t e2 = hipGraphInstantiate(&P->graph_exec, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e2 != hipSuccess) { P->graph_exec = nullptr; P->use_graph = false; return forward_body(P, x, y, workspace, stream, 1, nullptr); }
+  HIP_TRY(hipGraphLaunch(P->graph_exec, (hipStream_t)stream));
+  return CSN_OK;
+#endif
 }
 
 int csn_forward_profile(csn_plan* P, const float* x, float* y, void* workspace, void* stream, int32_t iters,
                         float* unit_ms) {
   if (!unit_ms) return CSN_E_INVALID;
-  return forward_impl(P, x, y, workspace, stream, iters, unit_ms);
+  return forward_body(P, x, y, workspace, stream, iters, unit_ms);
 }
 
 const char* csn_unit_kernel_name(const csn_plan* P, int32_t u) {
