@@ -119,10 +119,16 @@ int csn_plan_refresh_params(csn_plan* plan, const float* arena, int64_t arena_fl
 /* Eval-mode forward: x [B][3][H][W] -> y [B][1][H][W] logits (no sigmoid), csnet.py:365-387. */
 int csn_forward(csn_plan* plan, const float* x, float* y, void* workspace, void* stream);
 
-/* Same as csn_forward but brackets every unit with HIP events on `stream` and returns the mean
- * duration per unit over `iters` passes (unit_ms[n_units], milliseconds).  Synchronises. */
+/* Same as csn_forward (eager launches) but records a HIP event on `stream` after every kernel launch and
+ * returns the mean duration per unit over `iters` passes (unit_ms[n_units], milliseconds).  Synchronises. */
 int csn_forward_profile(csn_plan* plan, const float* x, float* y, void* workspace, void* stream,
                         int32_t iters, float* unit_ms);
+
+/* Per-kernel aggregation of the last csn_forward_profile call: every launch was bracketed by HIP events on
+ * the launch stream; entry i gives the kernel name, its total milliseconds per forward and its launch count
+ * per forward (so ms / launches is the mean launch duration rocprofv3 --stats reports for that name). */
+int32_t csn_profile_num_kernels(const csn_plan* plan);
+int csn_profile_kernel(const csn_plan* plan, int32_t i, const char** name, double* ms_per_forward, int32_t* launches);
 
 /* Name of the dominant kernel of unit `u` (static string) and the algorithmic bytes it moves per
  * csn_forward (sum of unit input + output activation bytes). */

@@ -112,6 +112,11 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.csn_forward_profile.restype = C.c_int
     lib.csn_forward_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_int32, C.POINTER(C.c_float)]
+    lib.csn_profile_num_kernels.restype = C.c_int32
+    lib.csn_profile_num_kernels.argtypes = [C.c_void_p]
+    lib.csn_profile_kernel.restype = C.c_int
+    lib.csn_profile_kernel.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_int32)]
     lib.csn_unit_kernel_name.restype = C.c_char_p
     lib.csn_unit_kernel_name.argtypes = [C.c_void_p, C.c_int32]
     lib.csn_unit_algorithmic_bytes.restype = C.c_int64
@@ -122,7 +127,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
 EXPORTS: Sequence[str] = (
     "csn_abi_version", "csn_strerror", "csn_last_hip_error", "csn_plan_create", "csn_plan_destroy",
     "csn_plan_set_option", "csn_plan_workspace_bytes", "csn_plan_act_info", "csn_plan_num_units", "csn_plan_refresh_params",
-    "csn_forward", "csn_forward_profile", "csn_unit_kernel_name", "csn_unit_algorithmic_bytes")
+    "csn_forward", "csn_forward_profile", "csn_profile_num_kernels", "csn_profile_kernel", "csn_unit_kernel_name", "csn_unit_algorithmic_bytes")
 
 _lib: Optional[C.CDLL] = None
 

@@ -116,6 +116,12 @@ struct csn_plan {
   const void* g_x = nullptr; const void* g_y = nullptr; const void* g_ws = nullptr;
   int eager_calls = 0;
   std::vector<hipEvent_t> ev;
+  // per-launch profiling (csn_forward_profile): one event after every kernel launch, tagged with its name
+  struct KStat { const char* name; double ms; int launches; };
+  std::vector<const char*> tags;     // tag of the launch that ended at event i+1 (filled while profiling)
+  std::vector<KStat> kstats;         // aggregated over the last csn_forward_profile call
+  bool profiling = false;
+  size_t ev_used = 0;
 };
 
 namespace {
@@ -380,7 +386,7 @@ int plan_cls(Builder& bl, UnitPlan& u) {
 
 // ------------------------------------------------------------------------------------ execution
 struct Ctx {
-  const csn_plan& P;
+  csn_plan& P;
   const float* x;  // slice pointers
   float* y;
   char* ws;
@@ -391,6 +397,18 @@ struct Ctx {
   }
   float* act_out(int id) const { return reinterpret_cast<float*>(ws + P.acts[id].ws_off); }
   const float* pk(int64_t off) const { return P.packed + off; }
+  // profiling: close the interval of the launch that was just enqueued
+  int mark(const char* kernel) const {
+    if (!P.profiling) return CSN_OK;
+    if (P.ev_used >= P.ev.size()) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreate(&e));
+      P.ev.push_back(e);
+    }
+    HIP_TRY(hipEventRecord(P.ev[P.ev_used++], (hipStream_t)stream));
+    P.tags.push_back(kernel);
+    return CSN_OK;
+  }
 };
 
 // rows per lane of the fused depthwise pair: the intermediate tile (NY*R + 2 rows) must stay small in LDS
@@ -453,7 +471,7 @@ int launch_pw(const Ctx& c, const UnitPlan& u, const PwLaunchPlan& L, const floa
     ps.scale = c.pk(pp.epi.scale); ps.shift = c.pk(pp.epi.shift); ps.alpha = c.pk(pp.epi.alpha);
   }
   LAUNCH_TRY(csn_launch_pw(a, 2, c.stream));
-  return CSN_OK;
+  return c.mark("goct_pw_kernel");
 }
 
 int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
@@ -495,6 +513,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
       if (a.nbr == 0) return CSN_OK;
       if (fused) LAUNCH_TRY(csn_launch_dw2(a, c.stream));
       else LAUNCH_TRY(csn_launch_dw(a, c.stream));
+      { const int ms_ = c.mark(fused ? "dw3x3x2_bn_prelu_kernel" : "dw3x3_bn_prelu_kernel"); if (ms_ != CSN_OK) return ms_; }
     } break;
     case CSN_UNIT_GOCT: {
       // optional 2x2 avg-pool prologue of every input branch (csnet.py:679-680)
@@ -516,6 +535,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
           pa.blk_end[k] = blk;
         }
         LAUNCH_TRY(csn_launch_pool(pa, c.stream));
+        { const int ms_ = c.mark("avgpool2_kernel"); if (ms_ != CSN_OK) return ms_; }
       } else {
         for (int i = 0; i < d.n_in; ++i)
           if (d.cin[i] > 0) xin[i] = c.act_in(d.in_act[i]);
@@ -540,6 +560,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
       a.cin = d.cin[0]; a.cout = d.cout[0]; a.H = P.H >> act.lvl; a.W = P.W >> act.lvl; a.B = S;
       a.scale = c.pk(u.ms_epi.scale); a.shift = c.pk(u.ms_epi.shift); a.alpha = c.pk(u.ms_epi.alpha);
       LAUNCH_TRY(csn_launch_ms(a, c.stream));
+      { const int ms_ = c.mark("msblock_kernel"); if (ms_ != CSN_OK) return ms_; }
     } break;
     case CSN_UNIT_CLS: {
       const float* xin[3] = {c.act_in(d.in_act[0]), nullptr, nullptr};
@@ -551,6 +572,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
       Up2Args ua;
       ua.in = reinterpret_cast<const float*>(c.ws + u.logits_off); ua.out = c.y; ua.planes = S; ua.H = P.H; ua.W = P.W;
       LAUNCH_TRY(csn_launch_up2(ua, c.stream));
+      { const int ms_ = c.mark("bilinear_up2_kernel"); if (ms_ != CSN_OK) return ms_; }
     } break;
     default:
       return CSN_E_INVALID;
@@ -719,12 +741,8 @@ static int forward_body(csn_plan* P, const float* x, float* y, void* workspace, 
   const int nu = (int)P->units.size();
   const bool prof = unit_ms != nullptr;
   if (prof) {
-    while ((int)P->ev.size() < nu + 1) {
-      hipEvent_t e;
-      HIP_TRY(hipEventCreate(&e));
-      P->ev.push_back(e);
-    }
     for (int u = 0; u < nu; ++u) unit_ms[u] = 0.f;
+    P->kstats.clear();
   }
   const int64_t in_stride = (int64_t)P->acts[0].channels * P->H * P->W, out_stride = (int64_t)P->H * P->W;
   const int reps = prof ? (iters > 0 ? iters : 1) : 1;
@@ -733,29 +751,39 @@ static int forward_body(csn_plan* P, const float* x, float* y, void* workspace, 
       // the last slice may overlap the previous one when S does not divide B (same results, written twice)
       const int start = (b0 + P->S <= P->B) ? b0 : P->B - P->S;
       Ctx c{*P, x + start * in_stride, y + start * out_stride, static_cast<char*>(workspace), stream};
-      if (prof) HIP_TRY(hipEventRecord(P->ev[0], (hipStream_t)stream));
+      std::vector<int> unit_of_tag;
+      if (prof) {
+        P->profiling = true; P->ev_used = 0; P->tags.clear();
+        const int st0 = c.mark("start");
+        if (st0 != CSN_OK) { P->profiling = false; return st0; }
+      }
       for (int u = 0; u < nu; ++u) {
         const bool fuse = P->fuse_dw && P->units[u].fuse_next && u + 1 < nu;
+        const size_t t0 = P->tags.size();
         const int st = run_unit(c, P->units[u], fuse ? &P->units[u + 1] : nullptr);
-        if (st != CSN_OK) return st;
-        if (prof) HIP_TRY(hipEventRecord(P->ev[u + 1], (hipStream_t)stream));
-        if (fuse) {   // the pair ran as one kernel: the second unit takes no time of its own
-          ++u;
-          if (prof) HIP_TRY(hipEventRecord(P->ev[u + 1], (hipStream_t)stream));
-        }
+        if (st != CSN_OK) { P->profiling = false; return st; }
+        if (prof) unit_of_tag.resize(P->tags.size(), u), (void)t0;
+        if (fuse) ++u;   // the pair ran as one kernel: the second unit takes no time of its own
       }
       if (prof) {
-        HIP_TRY(hipEventSynchronize(P->ev[nu]));
-        for (int u = 0; u < nu; ++u) {
+        P->profiling = false;
+        HIP_TRY(hipEventSynchronize(P->ev[P->ev_used - 1]));
+        for (size_t i = 1; i < P->ev_used; ++i) {
           float ms = 0.f;
-          HIP_TRY(hipEventElapsedTime(&ms, P->ev[u], P->ev[u + 1]));
-          unit_ms[u] += ms;
+          HIP_TRY(hipEventElapsedTime(&ms, P->ev[i - 1], P->ev[i]));
+          unit_ms[unit_of_tag[i]] += ms;
+          bool found = false;
+          for (auto& k : P->kstats)
+            if (k.name == P->tags[i]) { k.ms += ms; k.launches += 1; found = true; break; }
+          if (!found) P->kstats.push_back(csn_plan::KStat{P->tags[i], ms, 1});
         }
       }
     }
   }
-  if (prof)
+  if (prof) {
     for (int u = 0; u < nu; ++u) unit_ms[u] /= (float)reps;
+    for (auto& k : P->kstats) { k.ms /= reps; k.launches /= reps; }
+  }
   return CSN_OK;
 }
 
@@ -807,7 +835,18 @@ int csn_forward_profile(csn_plan* P, const float* x, float* y, void* workspace, 
 
 const char* csn_unit_kernel_name(const csn_plan* P, int32_t u) {
   if (!P || u < 0 || u >= (int)P->units.size()) return "";
+  if (P->fuse_dw && P->units[u].d.kind == CSN_UNIT_DW) {
+    if (P->units[u].fuse_next || (u > 0 && P->units[u - 1].fuse_next)) return "dw3x3x2_bn_prelu_kernel";
+  }
   return P->units[u].kname;
+}
+
+int32_t csn_profile_num_kernels(const csn_plan* P) { return P ? (int32_t)P->kstats.size() : 0; }
+
+int csn_profile_kernel(const csn_plan* P, int32_t i, const char** name, double* ms_per_forward, int32_t* launches) {
+  if (!P || i < 0 || i >= (int)P->kstats.size() || !name || !ms_per_forward || !launches) return CSN_E_INVALID;
+  *name = P->kstats[i].name; *ms_per_forward = P->kstats[i].ms; *launches = P->kstats[i].launches;
+  return CSN_OK;
 }
 
 int64_t csn_unit_algorithmic_bytes(const csn_plan* P, int32_t u) {

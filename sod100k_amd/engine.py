@@ -145,6 +145,16 @@ class Engine:
         nbytes = [int(self.lib.csn_unit_algorithmic_bytes(self.plan, u)) for u in range(self.n_units)]
         return list(ms), names, nbytes
 
+    def kernel_stats(self):
+        """{kernel name: (ms per forward, launches per forward)} of the last ``profile`` call."""
+        out = {}
+        for i in range(self.lib.csn_profile_num_kernels(self.plan)):
+            name, ms, n = C.c_char_p(), C.c_double(), C.c_int32()
+            N.check(self.lib, self.lib.csn_profile_kernel(self.plan, i, C.byref(name), C.byref(ms), C.byref(n)),
+                    "csn_profile_kernel")
+            out[name.value.decode()] = (ms.value, n.value)
+        return out
+
     def activation(self, act_id: int) -> torch.Tensor:
         """View of an internal activation of the LAST processed batch slice (debug / parity probes)."""
         info = N.ActInfo()
