@@ -60,6 +60,10 @@ static inline float2 csn_ld2(csn_buf b, unsigned voff, unsigned soff) {
   if (!(o + 8u <= b.n && o + 8u > o)) return make_float2(0.f, 0.f);
   return *reinterpret_cast<const float2*>(b.p + o);
 }
+// store through a bounded resource: dropped when the lane's own offset (voff) is out of range
+static inline void csn_st1(csn_buf b, unsigned voff, unsigned soff, float v) {
+  if (voff + 4u <= b.n && voff + 4u > voff) *reinterpret_cast<float*>(const_cast<char*>(b.p) + voff + soff) = v;
+}
 static inline float4 csn_ld4(csn_buf b, unsigned voff, unsigned soff) {
   const unsigned o = voff + soff;
   if (!(o + 16u <= b.n && o + 16u > o)) return make_float4(0.f, 0.f, 0.f, 0.f);
@@ -78,6 +82,11 @@ __device__ __forceinline__ csn_buf csn_make_buf_n(const float* p, unsigned nbyte
 }
 __device__ __forceinline__ float csn_ld1(csn_buf b, unsigned voff, unsigned soff) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b, voff, soff, 0));
+}
+// NOTE (measured on gfx950): the range check of a raw buffer access is applied to voffset + soffset, so a
+// bounded resource must span everything the soffset can reach
+__device__ __forceinline__ void csn_st1(csn_buf b, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), b, voff, soff, 0);
 }
 __device__ __forceinline__ float2 csn_ld2(csn_buf b, unsigned voff, unsigned soff) {
   const csn_u2 v = __builtin_amdgcn_raw_buffer_load_b64(b, voff, soff, 0);

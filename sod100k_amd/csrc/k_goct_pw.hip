@@ -243,9 +243,9 @@ __device__ __forceinline__ void pw_gather_slice(PwPassP ps, int s, int c_lo, int
 }
 
 // NT row tiles (16 rows each) x 4 pixel sub-groups against the `kn` (multiple of 4) channels of the panel.
-template <int NT, int MAXNT>
+template <int NT>
 __device__ __forceinline__ void pw_contract(const float* wl, int stride, const float* xb, int kn, int lane,
-                                            csn_f4 (&acc)[MAXNT][4]) {
+                                            csn_f4 (&acc)[NT][4]) {
   for (int k0 = 0; k0 < kn; k0 += 4) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -255,7 +255,59 @@ __device__ __forceinline__ void pw_contract(const float* wl, int stride, const f
   }
 }
 
-template <int MAXNT>
+// One sweep of NT row tiles (16 output channels each) for the wave's current 64-pixel group: channel chunks
+// are gathered into the panel and contracted, then every tile is transposed through the panel so that each
+// lane gets ITS pixel back and the wave stores 256 contiguous bytes per output channel (buffer stores: one
+// VGPR offset per lane, the channel offset rides in an SGPR; lanes outside the image are exec-masked).
+template <int NT>
+__device__ __forceinline__ void pw_sweep(PwPassP ps, const float* wl0, float* xb, int row0, int b, int gy, int gx,
+                                         int Hr, int Wr, unsigned ovoff, bool valid, int lane) {
+  const int cin = ps->cin, cin4 = ps->cin4, nrows = ps->nrows, stride = ps->w_stride;
+  const int c1 = ps->src[0].K, c2 = c1 + ps->src[1].K;
+  csn_f4 acc[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[t][s][i] = 0.f;
+  for (int kc = 0; kc < cin4; kc += PW_KC) {
+    const int kend = min(kc + PW_KC, cin4);
+    CSN_WAVE_SYNC();  // previous panel fully consumed
+    if (kc < c1) pw_gather_slice(ps, 0, kc, min(kend, c1), xb + lane, PW_KC, b, gy, gx, Hr, Wr);
+    if (max(kc, c1) < min(kend, c2)) {
+      const int r0 = max(kc, c1) - kc;
+      pw_gather_slice(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xb + r0 * PW_XP + lane, PW_KC - r0, b, gy, gx, Hr, Wr);
+    }
+    if (max(kc, c2) < min(kend, cin)) {
+      const int r0 = max(kc, c2) - kc;
+      pw_gather_slice(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xb + r0 * PW_XP + lane, PW_KC - r0, b, gy, gx, Hr, Wr);
+    }
+    for (int k = max(cin, kc); k < kend; ++k) xb[(k - kc) * PW_XP + lane] = 0.f;  // pad to a multiple of 4
+    CSN_WAVE_SYNC();  // panel complete
+    pw_contract<NT>(wl0 + row0 * stride + kc, stride, xb, kend - kc, lane, acc);
+  }
+  const unsigned cs4 = (unsigned)(Hr * Wr) * 4u;
+  const csn_buf ob = csn_make_buf(ps->out + (int64_t)b * ps->out_ctot * (Hr * Wr));
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    CSN_WAVE_SYNC();
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xb[((lane >> 4) * 4 + i) * PW_EP + 16 * s + (lane & 15)] = acc[t][s][i];
+    CSN_WAVE_SYNC();
+    const int rbase = row0 + 16 * t;
+    const int rn = min(16, nrows - rbase);
+    csn_cfp scale = csn_const(ps->scale) + rbase, shift = csn_const(ps->shift) + rbase, alpha = csn_const(ps->alpha) + rbase;
+#pragma unroll 4
+    for (int rr = 0; rr < rn; ++rr) {
+      const float val = csn_epi(xb[rr * PW_EP + lane], scale[rr], shift[rr], alpha[rr]);
+      if (valid) csn_st1(ob, ovoff, (unsigned)(rbase + rr) * cs4, val);
+    }
+  }
+}
+
 __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
   CSN_DYN_SMEM(float, lds);
   const CSN_CONST_AS PwArgs* a = CSN_KERNARG(PwArgs, a_byval);
@@ -286,75 +338,18 @@ __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
       const int txl = 5 - r;  // log2(PW_TX0 >> r)
       const int npx = (PW_TY0 >> r) << txl;
       const int ng = (npx + 63) >> 6;
-      const int cin = ps->cin, cin4 = ps->cin4, nrows = ps->nrows, stride = ps->w_stride;
+      const int nrows = ps->nrows;
       const float* wl0 = lds + ps->w_off;
-      const int c1 = ps->src[0].K, c2 = c1 + ps->src[1].K;
       for (int c = 0; c < ng; ++c) {
         if (((gbase + c) & 3) != wave) continue;
-        // pixel this lane gathers
         const int p = (c << 6) + lane;
-        const int gy = min((ty0 >> r) + (p >> txl), Hr - 1), gx = min((tx0 >> r) + (p & ((1 << txl) - 1)), Wr - 1);
         const int py_ = (ty0 >> r) + (p >> txl), px_ = (tx0 >> r) + (p & ((1 << txl) - 1));
         const bool valid = p < npx && py_ < Hr && px_ < Wr;
-        const int64_t cs = (int64_t)Hr * Wr;
-        float* __restrict__ ob = ps->out + (int64_t)b * ps->out_ctot * cs + (int64_t)gy * Wr + gx;
-        for (int row0 = 0; row0 < nrows; row0 += 16 * MAXNT) {
-          csn_f4 acc[MAXNT][4];
-#pragma unroll
-          for (int t = 0; t < MAXNT; ++t)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) acc[t][s][i] = 0.f;
-          const int nt = min(MAXNT, (nrows - row0 + 15) >> 4);
-          for (int kc = 0; kc < cin4; kc += PW_KC) {
-            const int kend = min(kc + PW_KC, cin4);
-            CSN_WAVE_SYNC();  // previous panel fully consumed
-            // channels [kc, kend) of the gathered vector -> panel rows 0..
-            if (kc < c1) pw_gather_slice(ps, 0, kc, min(kend, c1), xb + lane, PW_KC, b, gy, gx, Hr, Wr);
-            if (max(kc, c1) < min(kend, c2)) {
-              const int r0 = max(kc, c1) - kc;
-              pw_gather_slice(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xb + r0 * PW_XP + lane, PW_KC - r0, b, gy, gx,
-                              Hr, Wr);
-            }
-            if (max(kc, c2) < min(kend, cin)) {
-              const int r0 = max(kc, c2) - kc;
-              pw_gather_slice(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xb + r0 * PW_XP + lane, PW_KC - r0, b, gy, gx,
-                              Hr, Wr);
-            }
-            for (int k = max(cin, kc); k < kend; ++k) xb[(k - kc) * PW_XP + lane] = 0.f;  // pad to a multiple of 4
-            CSN_WAVE_SYNC();  // panel complete
-            const float* wl = wl0 + row0 * stride + kc;
-            if (nt == 1) pw_contract<1, MAXNT>(wl, stride, xb, kend - kc, lane, acc);
-            else if (nt == 2) pw_contract<2, MAXNT>(wl, stride, xb, kend - kc, lane, acc);
-            else if constexpr (MAXNT > 2) {
-              if (nt == 3) pw_contract<3, MAXNT>(wl, stride, xb, kend - kc, lane, acc);
-              else pw_contract<4, MAXNT>(wl, stride, xb, kend - kc, lane, acc);
-            }
-          }
-          // epilogue: transpose each 16-row tile through the (now free) panel so that every lane gets ITS
-          // pixel back and a wave stores 256 contiguous bytes per output channel
-#pragma unroll
-          for (int t = 0; t < MAXNT; ++t) {
-            if (t < nt) {
-              CSN_WAVE_SYNC();
-#pragma unroll
-              for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) xb[((lane >> 4) * 4 + i) * PW_EP + 16 * s + (lane & 15)] = acc[t][s][i];
-              CSN_WAVE_SYNC();
-              const int rbase = row0 + 16 * t;
-              const int rn = min(16, nrows - rbase);
-              csn_cfp scale = csn_const(ps->scale) + rbase, shift = csn_const(ps->shift) + rbase,
-                      alpha = csn_const(ps->alpha) + rbase;
-              float* __restrict__ orow = ob + (int64_t)rbase * cs;
-#pragma unroll 4
-              for (int rr = 0; rr < rn; ++rr) {
-                const float val = csn_epi(xb[rr * PW_EP + lane], scale[rr], shift[rr], alpha[rr]);
-                if (valid) orow[rr * cs] = val;
-              }
-            }
-          }
+        const int gy = min(py_, Hr - 1), gx = min(px_, Wr - 1);     // lanes off the image gather a valid pixel
+        const unsigned ovoff = (unsigned)(gy * Wr + gx) * 4u;        // ... and store nothing (exec-masked)
+        for (int row0 = 0; row0 < nrows; row0 += 32) {
+          if (nrows - row0 <= 16) pw_sweep<1>(ps, wl0, xb, row0, b, gy, gx, Hr, Wr, ovoff, valid, lane);
+          else pw_sweep<2>(ps, wl0, xb, row0, b, gy, gx, Hr, Wr, ovoff, valid, lane);
         }
       }
       gbase += ng;
@@ -362,8 +357,8 @@ __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
   }
 }
 
-// maxnt: 2 (every pass has <= 32 output channels: 32 accumulator VGPRs) or 4 (<= 64 per sweep)
 int csn_launch_pw(const PwArgs& a, int maxnt, void* stream) {
+  (void)maxnt;
   const int ntiles = a.tiles_x * a.tiles_y * a.B;
   const dim3 grid(ntiles < PW_MAX_GRID ? ntiles : PW_MAX_GRID);
   const size_t lds = ((size_t)a.wimg_floats + 4 * PW_KC * PW_XP) * sizeof(float);
@@ -371,19 +366,12 @@ int csn_launch_pw(const PwArgs& a, int maxnt, void* stream) {
   static bool attr_done = false;
   if (!attr_done) {
     // units with a large weight image may use the full 160 KiB of LDS of a CDNA4 CU
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&goct_pw_kernel<2>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&goct_pw_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&goct_pw_kernel<4>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
 #endif
-  if (maxnt <= 2) {
-    CSN_LAUNCH((goct_pw_kernel<2>), grid, dim3(CSN_BLOCK), lds, stream, a);
-  } else {
-    CSN_LAUNCH((goct_pw_kernel<4>), grid, dim3(CSN_BLOCK), lds, stream, a);
-  }
+  CSN_LAUNCH(goct_pw_kernel, grid, dim3(CSN_BLOCK), lds, stream, a);
   return (int)hipGetLastError();
 }
