@@ -90,6 +90,7 @@ struct PwArgs {
   int32_t H0, W0;      // resolution of branch 0
   int32_t B;
   int32_t tiles_x, tiles_y;
+  int32_t ty_log2;     // tile of branch 0 is (1 << ty_log2) rows x 32 columns; 4, 3 or 2
   int32_t wimg_floats; // multiple of 4
   const float* wimg;   // weight image of all passes: rows padded to 16, pitch w_stride, zero filled
 };

@@ -446,7 +446,14 @@ int launch_pw(const Ctx& c, const UnitPlan& u, const PwLaunchPlan& L, const floa
   PwArgs a;
   a.npass = (int)L.passes.size();
   a.H0 = P.H >> L.lvl; a.W0 = P.W >> L.lvl; a.B = P.S;
-  a.tiles_x = (a.W0 + PW_TX0 - 1) / PW_TX0; a.tiles_y = (a.H0 + PW_TY0 - 1) / PW_TY0;
+  // tile height: 16 rows, or 8 / 4 for small maps so that the launch still fills the 256 CUs several times over
+  int rmax = 0;
+  for (const PwPassPlan& pp : L.passes) rmax = std::max(rmax, pp.r);
+  a.ty_log2 = 4;
+  a.tiles_x = (a.W0 + PW_TX0 - 1) / PW_TX0;
+  while (a.ty_log2 > 2 && a.ty_log2 > rmax &&
+         (int64_t)a.tiles_x * ((a.H0 + (1 << a.ty_log2) - 1) >> a.ty_log2) * a.B < 512) --a.ty_log2;
+  a.tiles_y = (a.H0 + (1 << a.ty_log2) - 1) >> a.ty_log2;
   a.wimg = c.pk(L.wimg); a.wimg_floats = L.wimg_floats;
   for (int q = 0; q < a.npass; ++q) {
     const PwPassPlan& pp = L.passes[q];

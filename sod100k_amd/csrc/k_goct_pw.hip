@@ -329,14 +329,15 @@ __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int b = tile / tiles_xy;
     const int txy = tile - b * tiles_xy;
-    const int ty0 = (txy / a->tiles_x) * PW_TY0, tx0 = (txy % a->tiles_x) * PW_TX0;
+    const int tyl = a->ty_log2;   // tile height 16 / 8 / 4 rows of branch 0 (small maps get more, smaller tiles)
+    const int ty0 = (txy / a->tiles_x) << tyl, tx0 = (txy % a->tiles_x) * PW_TX0;
     int gbase = 0;  // running group index over the outputs of the unit -> wave assignment
     for (int pi = 0; pi < npass; ++pi) {
       PwPassP ps = &a->pass[pi];
       const int r = ps->r;
       const int Hr = H0 >> r, Wr = W0 >> r;
       const int txl = 5 - r;  // log2(PW_TX0 >> r)
-      const int npx = (PW_TY0 >> r) << txl;
+      const int npx = ((1 << tyl) >> r) << txl;
       const int ng = (npx + 63) >> 6;
       const int nrows = ps->nrows;
       const float* wl0 = lds + ps->w_off;
