@@ -119,6 +119,16 @@ int csn_plan_refresh_params(csn_plan* plan, const float* arena, int64_t arena_fl
 /* Eval-mode forward: x [B][3][H][W] -> y [B][1][H][W] logits (no sigmoid), csnet.py:365-387. */
 int csn_forward(csn_plan* plan, const float* x, float* y, void* workspace, void* stream);
 
+/* Train-mode forward (nn.BatchNorm2d batch statistics, csnet.py:764,825,138; Oct_bn_hook csnet.py:391-410):
+ * every BatchNorm normalises with the biased variance of the current batch, its running_mean/running_var
+ * inside `arena` are updated in place (momentum 0.1, unbiased variance) and `*penalty` (device, fp64, NOT
+ * cleared) accumulates  sum 0.5 * flop_w[u][j] * sum_{n,c} |mean_hw y[n,c]| * gamma_c^2  over the output branches
+ * j of the units u (flop_w is a HOST array [n_units][CSN_MAX_BRANCH]; 0 = not hooked).  The caller increments
+ * num_batches_tracked and divides the penalty by its batch size (csnet.py:324-330).  Requires sub_batch == 0.
+ * Backward is not part of this build yet. */
+int csn_forward_train(csn_plan* plan, const float* x, float* y, void* workspace, float* arena, int64_t arena_floats,
+                      const float* flop_w, double* penalty, void* stream);
+
 /* Same as csn_forward (eager launches) but records a HIP event on `stream` after every kernel launch and
  * returns the mean duration per unit over `iters` passes (unit_ms[n_units], milliseconds).  Synchronises. */
 int csn_forward_profile(csn_plan* plan, const float* x, float* y, void* workspace, void* stream,

@@ -127,6 +127,41 @@ struct Up2Args {
   int32_t planes, H, W;
 };
 
+// ---------------------------------------------------------------------------------------------
+// train-mode BatchNorm + PReLU + GAP penalty (see k_train.hip)
+// ---------------------------------------------------------------------------------------------
+#define CSN_BN_NSLAB 32
+struct BnStatsArgs {
+  const float* z;     // [S][C][HW] raw conv output
+  double* partial;    // [C][CSN_BN_NSLAB][2]
+  int32_t S, C;
+  int64_t HW;
+};
+struct BnFinalizeArgs {
+  const double* partial;
+  float* arena;       // parameter arena: gamma/beta read, running stats updated in place
+  float* scale;       // folded table of this BN for the apply pass (plan-owned)
+  float* shift;
+  int64_t off_weight, off_bias, off_rmean, off_rvar;
+  int64_t count;      // S * HW
+  int32_t C;
+};
+struct BnApplyArgs {
+  float* z;           // in: raw conv output, out: PReLU(BN(z))
+  const float* scale;
+  const float* shift;
+  const float* alpha;
+  const float* arena;
+  double* penalty;    // accumulates 0.5 * flop_w * |mean_hw y| * gamma^2 over (n, c)
+  int64_t off_weight;
+  int64_t HW;
+  int32_t S, C;
+  float flop_w;       // 0: not a hooked ILBlock sub-module
+};
+int csn_launch_bn_stats(const BnStatsArgs& a, void* stream);
+int csn_launch_bn_finalize(const BnFinalizeArgs& a, void* stream);
+int csn_launch_bn_apply(const BnApplyArgs& a, void* stream);
+
 // launchers (implemented next to the kernels)
 int csn_launch_prep(const CsnPrepJob* jobs_dev, int njobs, const float* arena, float* packed, void* stream);
 int csn_launch_dw(const DwArgs& a, void* stream);

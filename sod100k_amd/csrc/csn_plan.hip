@@ -88,6 +88,8 @@ struct UnitPlan {
   int64_t dw_w[3] = {-1, -1, -1};
   Epi dw_epi[3];
   int fuse_next = 0;   // DW: the next unit is the second depthwise unit of the same ILBlock
+  Epi out_epi[3];                        // folded BN/PReLU tables of every output branch (train mode rewrites them)
+  int64_t stats_off[3] = {-1, -1, -1};   // workspace byte offsets of the BN statistics partials
   // MS
   int64_t ms_w[5] = {-1, -1, -1, -1, -1};
   Epi ms_epi;
@@ -107,7 +109,9 @@ struct csn_plan {
   std::vector<CsnPrepJob> jobs;
   CsnPrepJob* jobs_dev = nullptr;
   bool params_ready = false;
+  bool bn_tables_train = false;   // csn_forward_train overwrote the folded BN tables: refresh before eval
   bool fuse_dw = true;
+  Epi ident;   // identity epilogue (scale 1, shift 0, alpha 1): train mode runs the conv kernels raw
   bool use_graph = true;
   // hipGraph of one whole csn_forward (all batch slices), captured on a plan-owned stream on the second
   // call with the same (x, y, workspace) and replayed on the caller's stream afterwards
@@ -241,7 +245,7 @@ int plan_goct(Builder& bl, UnitPlan& u) {
     FAIL(CSN_E_INVALID, "H/W not divisible for the lowest branch");
   Epi epi[3];
   for (int j = 0; j < d.n_out; ++j)
-    if (d.cout[j] > 0) epi[j] = bl.bn_epi(d.bn[j], d.cout[j]);
+    if (d.cout[j] > 0) { epi[j] = bl.bn_epi(d.bn[j], d.cout[j]); u.out_epi[j] = epi[j]; }
   const int kk = d.ksize * d.ksize;
   const int ld = cin_tot * kk;
   u.kname = "goct_pw_kernel";
@@ -332,6 +336,7 @@ int plan_dw(Builder& bl, UnitPlan& u) {
     u.dw_w[k] = bl.alloc_packed((int64_t)d.cout[k] * 9);
     bl.job(CSN_PREP_COPY, d.cout[k] * 9, u.dw_w[k], d.w_off[k], -1, -1, -1, 100.0f);  // conv2d.py:104
     u.dw_epi[k] = bl.bn_epi(d.bn[k], d.cout[k]);
+    u.out_epi[k] = u.dw_epi[k];
   }
   return CSN_OK;
 }
@@ -356,6 +361,7 @@ int plan_ms(Builder& bl, UnitPlan& u) {
     bl.job(CSN_PREP_C3, d.dil_ch[k], u.ms_w[k], d.w_off[k], -1, -1, -1, 100.0f, d.cin[0], d.cin[0], cinp, 0);
   }
   u.ms_epi = bl.bn_epi(d.bn[0], d.cout[0]);
+  u.out_epi[0] = u.ms_epi;
   return CSN_OK;
 }
 
@@ -397,6 +403,10 @@ struct Ctx {
   }
   float* act_out(int id) const { return reinterpret_cast<float*>(ws + P.acts[id].ws_off); }
   const float* pk(int64_t off) const { return P.packed + off; }
+  bool raw = false;   // train mode: convolutions write the un-normalised z (identity epilogue)
+  const float* sc(const Epi& e) const { return P.packed + (raw ? P.ident.scale : e.scale); }
+  const float* sh(const Epi& e) const { return P.packed + (raw ? P.ident.shift : e.shift); }
+  const float* al(const Epi& e) const { return P.packed + (raw ? P.ident.alpha : e.alpha); }
   // profiling: close the interval of the launch that was just enqueued
   int mark(const char* kernel) const {
     if (!P.profiling) return CSN_OK;
@@ -475,7 +485,10 @@ int launch_pw(const Ctx& c, const UnitPlan& u, const PwLaunchPlan& L, const floa
     const int64_t hw = (int64_t)(a.H0 >> pp.r) * (a.W0 >> pp.r);
     ps.out = ob + (int64_t)pp.out_c0 * hw;
     ps.out_ctot = pp.out_ctot; ps.pad2 = 0;
-    ps.scale = c.pk(pp.epi.scale); ps.shift = c.pk(pp.epi.shift); ps.alpha = c.pk(pp.epi.alpha);
+    const bool bn_out = pp.out_kind == OUT_ACT;   // z scratch and cls logits have no BN
+    ps.scale = bn_out ? c.sc(pp.epi) : c.pk(pp.epi.scale);
+    ps.shift = bn_out ? c.sh(pp.epi) : c.pk(pp.epi.shift);
+    ps.alpha = bn_out ? c.al(pp.epi) : c.pk(pp.epi.alpha);
   }
   LAUNCH_TRY(csn_launch_pw(a, 2, c.stream));
   return c.mark("goct_pw_kernel");
@@ -498,7 +511,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
         br.in = c.act_in(d.in_act[k]);
         br.out = c.act_out(fused ? next->d.out_act[k] : d.out_act[k]);
         br.w9 = c.pk(u.dw_w[k]);
-        br.scale = c.pk(u.dw_epi[k].scale); br.shift = c.pk(u.dw_epi[k].shift); br.alpha = c.pk(u.dw_epi[k].alpha);
+        br.scale = c.sc(u.dw_epi[k]); br.shift = c.sh(u.dw_epi[k]); br.alpha = c.al(u.dw_epi[k]);
         br.w9b = br.scale_b = br.shift_b = br.alpha_b = nullptr;
         br.C = d.cout[k]; br.H = P.H >> act.lvl; br.W = P.W >> act.lvl;
         const int cols = (br.W + 3) / 4;
@@ -565,7 +578,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
         a.w[k] = d.dil_ch[k] ? c.pk(u.ms_w[k]) : nullptr;
       }
       a.cin = d.cin[0]; a.cout = d.cout[0]; a.H = P.H >> act.lvl; a.W = P.W >> act.lvl; a.B = S;
-      a.scale = c.pk(u.ms_epi.scale); a.shift = c.pk(u.ms_epi.shift); a.alpha = c.pk(u.ms_epi.alpha);
+      a.scale = c.sc(u.ms_epi); a.shift = c.sh(u.ms_epi); a.alpha = c.al(u.ms_epi);
       LAUNCH_TRY(csn_launch_ms(a, c.stream));
       { const int ms_ = c.mark("msblock_kernel"); if (ms_ != CSN_OK) return ms_; }
     } break;
@@ -680,6 +693,18 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
     }
     if (ok) { P->units[k].fuse_next = 1; ++k; }
   }
+  {  // identity epilogue + per-BN statistics partials for the train-mode forward
+    int maxc = 1;
+    for (int i = 0; i < n_acts; ++i) maxc = std::max(maxc, (int)acts[i].channels);
+    P->ident.scale = bl.alloc_packed(maxc); P->ident.shift = bl.alloc_packed(maxc); P->ident.alpha = bl.alloc_packed(maxc);
+    bl.job(CSN_PREP_FILL, maxc, P->ident.scale, -1, -1, -1, -1, 1.f);
+    bl.job(CSN_PREP_FILL, maxc, P->ident.shift, -1, -1, -1, -1, 0.f);
+    bl.job(CSN_PREP_FILL, maxc, P->ident.alpha, -1, -1, -1, -1, 1.f);
+    for (auto& u : P->units)
+      if (u.d.kind != CSN_UNIT_CLS)
+        for (int j = 0; j < u.d.n_out; ++j)
+          if (u.d.cout[j] > 0) u.stats_off[j] = bl.alloc_ws((int64_t)u.d.cout[j] * CSN_BN_NSLAB * 2 * sizeof(double));
+  }
   if (csn_kernels_init() != 0) { delete P; return CSN_E_HIP; }
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&P->packed), (size_t)(P->packed_floats + 4) * sizeof(float));
   if (e != hipSuccess) { delete P; hip_fail(e, "hipMalloc(packed)"); return CSN_E_NOMEM; }
@@ -738,13 +763,14 @@ int csn_plan_refresh_params(csn_plan* P, const float* arena, int64_t arena_float
   }
   LAUNCH_TRY(csn_launch_prep(P->jobs_dev, (int)P->jobs.size(), arena, P->packed, stream));
   P->params_ready = true;
+  P->bn_tables_train = false;
   return CSN_OK;
 }
 
 static int forward_body(csn_plan* P, const float* x, float* y, void* workspace, void* stream, int32_t iters,
                         float* unit_ms) {
   if (!P || !x || !y || !workspace) return CSN_E_INVALID;
-  if (!P->params_ready) return CSN_E_STATE;
+  if (!P->params_ready || P->bn_tables_train) return CSN_E_STATE;   // train forward rewrote the BN tables
   const int nu = (int)P->units.size();
   const bool prof = unit_ms != nullptr;
   if (prof) {
@@ -838,6 +864,44 @@ int csn_forward_profile(csn_plan* P, const float* x, float* y, void* workspace, 
                         float* unit_ms) {
   if (!unit_ms) return CSN_E_INVALID;
   return forward_body(P, x, y, workspace, stream, iters, unit_ms);
+}
+
+int csn_forward_train(csn_plan* P, const float* x, float* y, void* workspace, float* arena, int64_t arena_floats,
+                      const float* flop_w, double* penalty, void* stream) {
+  if (!P || !x || !y || !workspace || !arena || !flop_w || !penalty) return CSN_E_INVALID;
+  if (!P->params_ready) return CSN_E_STATE;
+  P->bn_tables_train = true;
+  if (P->S != P->B) { g_hip_err = "train mode needs the whole batch in one slice (sub_batch = 0)"; return CSN_E_UNSUPPORTED; }
+  (void)arena_floats;
+  const int nu = (int)P->units.size();
+  Ctx c{*P, x, y, static_cast<char*>(workspace), stream};
+  for (int u = 0; u < nu; ++u) {
+    const UnitPlan& up = P->units[u];
+    const csn_unit_desc& d = up.d;
+    c.raw = d.kind != CSN_UNIT_CLS;
+    const int st = run_unit(c, up, nullptr);           // raw z of every output branch (no depthwise fusion)
+    if (st != CSN_OK) return st;
+    if (d.kind == CSN_UNIT_CLS) continue;
+    for (int j = 0; j < d.n_out; ++j) {
+      if (d.cout[j] == 0) continue;
+      const Act& act = P->acts[d.out_act[j]];
+      const int64_t hw = (int64_t)(P->H >> act.lvl) * (P->W >> act.lvl);
+      float* z = c.act_out(d.out_act[j]);
+      double* part = reinterpret_cast<double*>(c.ws + up.stats_off[j]);
+      BnStatsArgs sa; sa.z = z; sa.partial = part; sa.S = P->S; sa.C = d.cout[j]; sa.HW = hw;
+      LAUNCH_TRY(csn_launch_bn_stats(sa, stream));
+      BnFinalizeArgs fa; fa.partial = part; fa.arena = arena;
+      fa.scale = P->packed + up.out_epi[j].scale; fa.shift = P->packed + up.out_epi[j].shift;
+      fa.off_weight = d.bn[j].weight; fa.off_bias = d.bn[j].bias; fa.off_rmean = d.bn[j].running_mean;
+      fa.off_rvar = d.bn[j].running_var; fa.count = (int64_t)P->S * hw; fa.C = d.cout[j];
+      LAUNCH_TRY(csn_launch_bn_finalize(fa, stream));
+      BnApplyArgs aa; aa.z = z; aa.scale = fa.scale; aa.shift = fa.shift; aa.alpha = P->packed + up.out_epi[j].alpha;
+      aa.arena = arena; aa.penalty = penalty; aa.off_weight = d.bn[j].weight; aa.HW = hw; aa.S = P->S; aa.C = d.cout[j];
+      aa.flop_w = flop_w[u * CSN_MAX_BRANCH + j];
+      LAUNCH_TRY(csn_launch_bn_apply(aa, stream));
+    }
+  }
+  return CSN_OK;
 }
 
 const char* csn_unit_kernel_name(const csn_plan* P, int32_t u) {

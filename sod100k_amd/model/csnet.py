@@ -286,8 +286,8 @@ class CSNet(nn.Module):
     def flops_hook(self, expandflop=2):
         """Assign the per-stage penalty weights of the reference hook (csnet.py:332-355).
 
-        The penalty itself (Oct_bn_hook, csnet.py:391-410) needs train-mode activations; the train-mode
-        kernels are not part of this build yet, so only the weights are recorded here."""
+        The penalty itself (Oct_bn_hook, csnet.py:391-410) is fused into the train-mode BN/PReLU pass
+        (k_train.hip: bn_apply_gap_kernel); this only records the weights."""
         baseflop = expandflop ** (len(self.stages) - 1)
         real_stages = list(self.stages)
         real_stages[0] += 1
@@ -475,11 +475,59 @@ class CSNet(nn.Module):
         if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32:
             raise ValueError("expected a float32 tensor of shape B x 3 x H x W")
         if self.training:
-            raise NotImplementedError("train-mode forward/backward (batch-stat BN, dynamic weight decay) is not "
-                                      "part of this build yet; call model.eval()")
+            return self._forward_train(x)
         eng = self.engine_for(x)
         eng.refresh(self._arena.flat)
         return eng.forward(x)
+
+
+    def _flop_weight_table(self, names, units):
+        """Host table [n_units][3] of the Oct_bn_hook branch weights (csnet.py:393-398); zeros when
+        flops_hook() was not called (no hooks registered -> no penalty)."""
+        tab = [0.0] * (len(units) * N.MAX_BRANCH)
+        if self._penalty_cfg is None:
+            return tab
+        mods = dict(self.named_modules())
+        for ui, (name, u) in enumerate(zip(names, units)):
+            sub = mods.get(name)
+            if sub is None or getattr(sub, "baseflop", None) is None:   # only ILBlock sub-modules are hooked
+                continue
+            branches = int(u.n_out)
+            w = sub.baseflop * (sub.expandflop ** (branches - 1))
+            for k in range(branches):
+                tab[ui * N.MAX_BRANCH + k] = w
+                w /= sub.expandflop
+        return tab
+
+    def _forward_train(self, x):
+        """Train-mode forward on the device: batch-statistics BN with running-stat update (csnet.py:764,825,138)
+        and, once flops_hook() has been called, the dynamic-weight-decay penalty (csnet.py:391-410) read back
+        through get_flops().  The result carries no autograd graph: backward kernels are a later round."""
+        eng = self.engine_for(x)
+        if eng.sub_batch not in (0, eng.B):
+            raise RuntimeError("train mode needs sub_batch == 0 (batch statistics span the whole batch)")
+        arena = self._arena
+        eng.refresh(arena.flat)                       # weight blocks + PReLU tables; BN tables are rewritten per batch
+        units, _, names = self._desc_cache(arena)
+        penalty = torch.zeros(1, dtype=torch.float64, device=x.device)
+        y = eng.forward_train(x, arena.flat, self._flop_weight_table(names, units), penalty)
+        with torch.no_grad():
+            nbt = [m.num_batches_tracked for m in self.modules()
+                   if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
+            if nbt:
+                torch._foreach_add_(nbt, 1)
+        if self._penalty_cfg is not None:
+            # the reference spreads the sum over the ILBlock sub-modules' all_flops; get_flops() only ever reads
+            # the total, which is kept on the first hooked module
+            first = self.stage0[0].conv1x1
+            first.all_flops = first.all_flops + penalty.to(torch.float32)[0]
+        return y
+
+    def _desc_cache(self, arena):
+        key = id(arena)
+        if getattr(self, "_desc", None) is None or self._desc[0] != key:
+            self._desc = (key, self.describe(arena.offsets))
+        return self._desc[1]
 
 
 # ---- dynamic weight decay hook (csnet.py:391-410) -----------------------------------------------------------

@@ -216,3 +216,67 @@ def check_g4(lib, device):
             worst = max(worst, err)
         report[tag] = worst
     return report
+
+
+# ---------------------------------------------------------------------------------------------------
+# train-mode forward (batch-stat BN, running-stat update, dynamic-weight-decay penalty)
+# ---------------------------------------------------------------------------------------------------
+def check_train_forward(lib, device, manifest, B=4, size=64, expandflop=2, seed=10):
+    """Train-mode forward vs the oracle on the same seeded batch: logits, every BN's running stats after the
+    step, num_batches_tracked and get_flops()."""
+    m, sd = make_model(lib, manifest, device)
+    m.train()
+    x = torch.from_numpy(I.randn_batch(seed, B, size, size))
+    m.set_batchsize(B)
+    m.clear_flops()
+    m.flops_hook(expandflop)
+    y = m(x.to(device)).cpu()
+    pen = float(m.get_flops())
+
+    cfg = O.load_layer_config_json(manifest)
+    sd_ref = {k: v.clone() for k, v in sd.items()}
+    taps = {}
+    with torch.no_grad():
+        ref = O.csnet_forward(cfg, sd_ref, x, training=True, taps=taps)
+    pen_ref = float(O.gap_penalty(sd_ref, taps, O.flop_weights(cfg, expandflop), B))
+    err = (y - ref).abs().max().item()
+    assert err <= TOL, f"train-mode logits: max-abs {err:.3e}"
+    assert abs(pen - pen_ref) <= 1e-5 * max(1.0, abs(pen_ref)) + 1e-7, (pen, pen_ref)
+    got = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    worst = 0.0
+    for k, v in sd_ref.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(got[k]) == int(v), k
+        elif k.endswith("running_mean") or k.endswith("running_var"):
+            e = ((got[k] - v).abs() / (1.0 + v.abs())).max().item()
+            assert e <= 1e-5, f"{k}: {e:.3e}"
+            worst = max(worst, e)
+        else:
+            assert torch.equal(got[k], v), k      # forward must not touch learnable parameters
+    # eval after train must pick the updated running statistics up again
+    m.eval()
+    y2 = m(x.to(device)).cpu()
+    with torch.no_grad():
+        ref2 = O.csnet_forward(cfg, sd_ref, x)
+    assert (y2 - ref2).abs().max().item() <= TOL
+    return err, pen, pen_ref, worst
+
+
+def check_train_golden(lib, device, manifest, idx):
+    """G5: penalty and BN running statistics after ONE train-mode forward of the reference itself
+    (tests/golden/g5_g7_train_step.json; x = randn_batch(10, 4), 224x224)."""
+    rec = json.load(open(os.path.join(GOLD, "g5_g7_train_step.json")))[idx]
+    ef = 2 if rec["expandflop"] is None else rec["expandflop"]
+    m, _ = make_model(lib, manifest, device)
+    m.train()
+    m.set_batchsize(4)
+    m.clear_flops()
+    m.flops_hook(ef)
+    m(torch.from_numpy(I.randn_batch(10, 4)).to(device))
+    pen = float(m.get_flops())
+    assert abs(pen - rec["penalty"][0]) <= 1e-5 * max(1.0, abs(rec["penalty"][0])) + 1e-7, (pen, rec["penalty"][0])
+    got = m.state_dict()
+    for n, v in rec["bn_after_rank0"].items():
+        s = float(got[n].double().sum())
+        assert abs(s - v["sum"]) <= 1e-5 * max(abs(v["sum"]), 1.0), (n, s, v["sum"])
+    return pen

@@ -49,3 +49,12 @@ def test_emu_sub_batch_slicing(emu_lib, x2_manifest):
     y_full, _ = P.check_vs_oracle(emu_lib, CPU, x2_manifest, x, sub_batch=0)
     y_sl, _ = P.check_vs_oracle(emu_lib, CPU, x2_manifest, x, sub_batch=2)   # 2+2+(overlapping last) slices
     assert torch.equal(y_full, y_sl)
+
+
+def test_emu_train_forward_vs_oracle(emu_lib, x2_manifest):
+    err, pen, pen_ref, worst = P.check_train_forward(emu_lib, CPU, x2_manifest, B=3, size=48)
+    assert pen_ref > 0
+
+
+def test_emu_train_forward_expandflop1_x1(emu_lib, x1_manifest):
+    P.check_train_forward(emu_lib, CPU, x1_manifest, B=2, size=32, expandflop=1.0, seed=3)
