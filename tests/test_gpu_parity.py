@@ -97,11 +97,13 @@ def test_gpu_requires_device_tensor(hip, x2_manifest):
 
 def test_gpu_train_forward_vs_oracle(hip, x2_manifest):
     """Train-mode forward (batch-stat BN + running-stat update + dynamic-weight-decay penalty) vs the oracle."""
-    err, pen, pen_ref, worst = P.check_train_forward(hip, DEV, x2_manifest, B=4, size=96)
+    lib, dev = hip
+    err, pen, pen_ref, worst = P.check_train_forward(lib, dev, x2_manifest, B=4, size=96)
     print(f"train-mode logits max-abs {err:.2e}; penalty {pen:.7f} vs {pen_ref:.7f}; running stats rel {worst:.1e}")
 
 
 @pytest.mark.parametrize("idx", [0, 1])
 def test_gpu_train_forward_golden(hip, x2_manifest, idx):
     """G5: penalty + BN buffers after the reference's own train-mode forward (expandflop 1 and default 2)."""
-    P.check_train_golden(hip, DEV, x2_manifest, idx)
+    lib, dev = hip
+    P.check_train_golden(lib, dev, x2_manifest, idx)
