@@ -125,9 +125,32 @@ int csn_forward(csn_plan* plan, const float* x, float* y, void* workspace, void*
  * cleared) accumulates  sum 0.5 * flop_w[u][j] * sum_{n,c} |mean_hw y[n,c]| * gamma_c^2  over the output branches
  * j of the units u (flop_w is a HOST array [n_units][CSN_MAX_BRANCH]; 0 = not hooked).  The caller increments
  * num_batches_tracked and divides the penalty by its batch size (csnet.py:324-330).  Requires sub_batch == 0.
- * Backward is not part of this build yet. */
+ * With csn_plan_enable_training the raw outputs are kept for csn_backward. */
 int csn_forward_train(csn_plan* plan, const float* x, float* y, void* workspace, float* arena, int64_t arena_floats,
                       const float* flop_w, double* penalty, void* stream);
+
+/* Training buffers.  Call once after csn_plan_create and BEFORE csn_plan_workspace_bytes / csn_plan_refresh_params:
+ * adds, per activation, a buffer for the raw convolution output z (saved for backward, later overwritten by dz) and
+ * one gradient buffer per consumer, the backward scratch, and the transposed / tap-flipped weight images of the
+ * input-gradient launches (re-packed by every csn_plan_refresh_params).  Requires sub_batch == 0. */
+int csn_plan_enable_training(csn_plan* plan);
+
+/* Backward of the last csn_forward_train call (autograd through csnet.py:365-387 as train.py:211-214 drives it).
+ * dy [B][1][H][W] is d loss / d logits; `grad` is an arena with the parameter arena's offsets: the gradient of every
+ * convolution weight, BN weight/bias, PReLU weight and the cls bias is WRITTEN (not accumulated) there, other
+ * positions are left untouched.  `pen_scale` = d loss / d (penalty sum) = FLOPS.WEIGHT / batchsize (train.py:91,210)
+ * adds the dynamic-weight-decay term's gradient w.r.t. the BN weights of the hooked units (same flop_w table as the
+ * forward call; y.detach() in Oct_bn_hook: no gradient through the activations).  No input gradient is produced. */
+int csn_backward(csn_plan* plan, const float* x, const float* dy, void* workspace, const float* arena, float* grad,
+                 int64_t arena_floats, const float* flop_w, float pen_scale, void* stream);
+
+/* Caller-side training maths on flat device buffers.
+ * csn_bce_with_logits: *loss (device, fp64, NOT cleared) += mean BCE-with-logits (train.py:209), dy = d mean / d y.
+ * csn_adam_step: torch.optim.Adam with L2 weight decay folded into the gradient (train.py:108-123); wd[i] is the
+ * per-element weight decay of the parameter group element i belongs to; `step` counts from 1. */
+int csn_bce_with_logits(const float* y, const float* t, float* dy, int64_t n, double* loss, void* stream);
+int csn_adam_step(float* p, const float* g, float* m, float* v, const float* wd, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int32_t step, void* stream);
 
 /* Same as csn_forward (eager launches) but records a HIP event on `stream` after every kernel launch and
  * returns the mean duration per unit over `iters` passes (unit_ms[n_units], milliseconds).  Synchronises. */

@@ -14,7 +14,7 @@ from typing import Optional, Sequence
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libcsnet_hip.so")
-SOURCES = ("csn_plan.hip", "k_misc.hip", "k_goct_pw.hip", "k_ms.hip", "k_train.hip")
+SOURCES = ("csn_plan.hip", "k_misc.hip", "k_goct_pw.hip", "k_ms.hip", "k_train.hip", "k_wgrad.hip")
 
 MAX_BRANCH = 3
 NDIL = 5
@@ -112,6 +112,16 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.csn_forward_train.restype = C.c_int
     lib.csn_forward_train.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                       C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+    lib.csn_plan_enable_training.restype = C.c_int
+    lib.csn_plan_enable_training.argtypes = [C.c_void_p]
+    lib.csn_backward.restype = C.c_int
+    lib.csn_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                 C.POINTER(C.c_float), C.c_float, C.c_void_p]
+    lib.csn_bce_with_logits.restype = C.c_int
+    lib.csn_bce_with_logits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.csn_adam_step.restype = C.c_int
+    lib.csn_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
+                                  C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]
     lib.csn_forward_profile.restype = C.c_int
     lib.csn_forward_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_int32, C.POINTER(C.c_float)]
@@ -130,7 +140,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
 EXPORTS: Sequence[str] = (
     "csn_abi_version", "csn_strerror", "csn_last_hip_error", "csn_plan_create", "csn_plan_destroy",
     "csn_plan_set_option", "csn_plan_workspace_bytes", "csn_plan_act_info", "csn_plan_num_units", "csn_plan_refresh_params",
-    "csn_forward", "csn_forward_train", "csn_forward_profile", "csn_profile_num_kernels", "csn_profile_kernel", "csn_unit_kernel_name", "csn_unit_algorithmic_bytes")
+    "csn_forward", "csn_forward_train", "csn_plan_enable_training", "csn_backward", "csn_bce_with_logits",
+           "csn_adam_step", "csn_forward_profile", "csn_profile_num_kernels", "csn_profile_kernel", "csn_unit_kernel_name", "csn_unit_algorithmic_bytes")
 
 _lib: Optional[C.CDLL] = None
 

@@ -1,0 +1,581 @@
+// csn_backward.inl -- backward planning + sequencing of the train step (included by csn_plan.hip).
+//
+// Reference: autograd through CSNet.forward (csnet.py:365-387) as driven by train.py:203-216
+//   loss = BCEWithLogits(model(x), t) + FLOPS.WEIGHT * model.get_flops();  loss.backward()
+// For every unit, in reverse order:
+//   1. BN(train) + PReLU backward per output branch (k_train.hip): dy (from up to two consumers) and the saved
+//      raw conv output z -> dz (written over z), d gamma / d beta / d alpha (+ the penalty's d/d gamma);
+//   2. weight gradient: one k_wgrad.hip launch per forward contraction pass (same gathered vector as the forward);
+//   3. input gradient.  gOctConv (csnet.py:664-726) for input branch i:
+//        dx_i = sum_{j == i} W_ij^T dz_j                              own resolution
+//             + sum_{j <  i} W_ij^T adjoint_up(dz_j)                  x_i was bilinearly upsampled into y_j; the
+//                                                                    1x1 (3x3: tap-flipped) transpose commutes
+//                                                                    with the linear resampling
+//             + sum_{j >  i} maxpool_backward(W_ij^T dz_j)            x_i was max-pooled into y_j
+//      The first two are ONE forward-kernel launch (goct_pw_kernel with transposed, tap-flipped weight blocks
+//      and an identity epilogue), the third a launch at the low resolution into a temporary followed by the
+//      arg-max routing kernel.  stride 2: the gradient of the pooled copy goes through the avg-pool adjoint.
+//      Depthwise: the forward depthwise kernel with flipped taps.  MSBlock: dilated taps, flipped, per dilation.
+
+namespace {
+
+struct AdjPlan {      // adjoint-upsampled dz of output branch j at the resolution of input branch i
+  int j = 0, i = 0, f = 2, C = 0, lvl = 0;
+  int64_t off = 0;    // bytes inside the unit scratch
+};
+
+struct DataLaunch {
+  PwLaunchPlan L;
+  int i = 0;          // input branch the gradient belongs to
+  bool to_tmp = false;
+  int pool_f = 0;     // to_tmp: max-pool factor of the routing kernel that follows
+  int lvl_lo = 0;     // to_tmp: level of the temporary
+};
+
+struct WgPlan {
+  PwLaunchPlan L;     // one pass, r = 0, L.lvl = absolute level (weight image unused)
+  int a_kind = SRC_DZ, a_idx = 0, a_c0 = 0, a_ctot = 0;
+  std::vector<WgBlock> blocks;
+};
+
+struct UnitBwd {
+  std::vector<AdjPlan> adj;
+  std::vector<DataLaunch> data;
+  std::vector<WgPlan> wg;
+  bool need_dx[3] = {false, false, false};
+  bool zero_dx[3] = {false, false, false};   // no own-resolution term: clear before the pooled terms are added
+  int64_t dxp_off[3] = {-1, -1, -1};         // stride 2: gradient of the pooled copies (unit scratch)
+  int64_t tmp_off = -1;
+  int64_t dwf_w[3] = {-1, -1, -1};           // depthwise: tap-flipped x100 weights (packed)
+  int64_t scratch = 0;                       // bytes of unit scratch used
+};
+
+int64_t bw_alloc(UnitBwd& ub, int64_t bytes) {
+  const int64_t off = ub.scratch;
+  ub.scratch += align_up(bytes, 256);
+  return off;
+}
+
+void ident_epi(const csn_plan& P, PwPassPlan& ps) { ps.epi = P.ident; }
+
+WgPlan make_wg(const PwLaunchPlan& L, const PwPassPlan& pp) {
+  WgPlan w;
+  w.L.lvl = L.lvl + pp.r;
+  PwPassPlan q = pp;
+  q.r = 0;
+  w.L.passes.push_back(q);
+  for (const WBlock& b : pp.wb) {
+    if (b.eye) continue;
+    WgBlock g;
+    g.dst = b.src; g.ld = b.ld; g.ncol = b.ncol; g.col = b.col; g.scale = b.scale;
+    w.blocks.push_back(g);
+  }
+  return w;
+}
+
+int plan_goct_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
+  csn_plan& P = bl.P;
+  const csn_unit_desc& d = u.d;
+  const int kk = d.ksize * d.ksize;
+  const int base = u.base_lvl;
+  int cin_tot = 0, cout_tot = 0, ci_off[4] = {0}, co_off[4] = {0};
+  for (int i = 0; i < d.n_in; ++i) { ci_off[i] = cin_tot; cin_tot += d.cin[i]; }
+  for (int j = 0; j < d.n_out; ++j) { co_off[j] = cout_tot; cout_tot += d.cout[j]; }
+  const int ld = cin_tot * kk;
+  for (int i = 0; i < d.n_in; ++i) ub.need_dx[i] = d.cin[i] > 0 && d.in_act[i] > 0;
+  auto adj_index = [&](int j, int i) {
+    for (size_t k = 0; k < ub.adj.size(); ++k)
+      if (ub.adj[k].j == j && ub.adj[k].i == i) return (int)k;
+    AdjPlan a;
+    a.j = j; a.i = i; a.f = 1 << (i - j); a.C = d.cout[j]; a.lvl = base + i;
+    a.off = bw_alloc(ub, bl.act_bytes(a.C, a.lvl));
+    ub.adj.push_back(a);
+    return (int)ub.adj.size() - 1;
+  };
+  // ---- weight gradients: one launch per forward pass (the z launch pairs with the adjoint-upsampled dz_0)
+  for (const PwLaunchPlan& L : u.pwl)
+    for (const PwPassPlan& pp : L.passes) {
+      PwPassPlan q = pp;
+      if (q.nsrc > 0 && q.src_kind[q.nsrc - 1] == SRC_Z) {   // identity columns carry no parameter
+        q.nsrc -= 1;
+        q.K -= u.z_C;
+      }
+      if (q.nsrc == 0 || q.K == 0) continue;
+      WgPlan w = make_wg(L, q);
+      if (pp.out_kind == OUT_Z) {
+        w.a_kind = SRC_ADJ; w.a_idx = adj_index(0, 1); w.a_c0 = 0; w.a_ctot = u.z_C;
+      } else {
+        w.a_kind = SRC_DZ; w.a_idx = pp.out_branch; w.a_c0 = 0; w.a_ctot = d.cout[pp.out_branch];
+      }
+      if (((w.L.passes[0].nrows + 15) & ~15) > 80) FAIL(CSN_E_UNSUPPORTED, "weight gradient: more than 80 output channels");
+      ub.wg.push_back(w);
+    }
+  // ---- input gradients
+  const int mode = d.ksize == 3 ? PW_TAPS : PW_OWN;
+  int64_t tmp_bytes = 0;
+  for (int i = 0; i < d.n_in; ++i) {
+    if (!ub.need_dx[i]) continue;
+    if (d.stride == 2) ub.dxp_off[i] = bw_alloc(ub, bl.act_bytes(d.cin[i], base + i));
+    auto wblk = [&](int j) {
+      WBlock w;
+      w.src = d.w_off[0] + ((int64_t)co_off[j] * cin_tot + ci_off[i]) * kk;
+      w.ld = ld; w.ncol = d.cout[j] * kk; w.tk = kk;
+      return w;
+    };
+    PwLaunchPlan L;
+    L.lvl = base + i;
+    PwPassPlan ps;
+    ps.r = 0; ps.nrows = d.cin[i]; ps.out_kind = OUT_DX; ps.out_branch = i; ps.out_ctot = d.cin[i];
+    ident_epi(P, ps);
+    auto add = [&](PwPassPlan& q, int kind, int idx, int C) {
+      const int s = q.nsrc++;
+      q.src_kind[s] = kind; q.src_branch[s] = idx; q.src_C[s] = C; q.src_mode[s] = mode;
+      return s;
+    };
+    for (int j = 0; j <= i && j < d.n_out; ++j) {
+      if (d.cout[j] == 0) continue;
+      if (ps.nsrc >= 3) FAIL(CSN_E_UNSUPPORTED, "backward: too many sources");
+      WBlock w = wblk(j);
+      w.col = ps.K;
+      if (j == i) add(ps, SRC_DZ, j, d.cout[j]);
+      else add(ps, SRC_ADJ, adj_index(j, i), d.cout[j]);
+      ps.wb.push_back(w);
+      ps.K += d.cout[j] * kk;
+    }
+    if (ps.nsrc > 0) {
+      L.passes.push_back(ps);
+      DataLaunch dl;
+      dl.L = L; dl.i = i;
+      ub.data.push_back(dl);
+    } else {
+      ub.zero_dx[i] = true;
+    }
+    for (int j = i + 1; j < d.n_out; ++j) {   // x_i was max-pooled into y_j
+      if (d.cout[j] == 0) continue;
+      PwLaunchPlan Lp;
+      Lp.lvl = base + j;
+      PwPassPlan pq;
+      pq.r = 0; pq.nrows = d.cin[i]; pq.out_kind = OUT_TMP; pq.out_ctot = d.cin[i];
+      ident_epi(P, pq);
+      add(pq, SRC_DZ, j, d.cout[j]);
+      WBlock w = wblk(j);
+      w.col = 0;
+      pq.wb.push_back(w);
+      pq.K = d.cout[j] * kk;
+      Lp.passes.push_back(pq);
+      DataLaunch dl;
+      dl.L = Lp; dl.i = i; dl.to_tmp = true; dl.pool_f = 1 << (j - i); dl.lvl_lo = base + j;
+      ub.data.push_back(dl);
+      tmp_bytes = std::max(tmp_bytes, bl.act_bytes(d.cin[i], base + j));
+    }
+  }
+  if (tmp_bytes > 0) ub.tmp_off = bw_alloc(ub, tmp_bytes);
+  for (DataLaunch& dl : ub.data) {
+    const int st = finish_launch(bl, dl.L);
+    if (st != CSN_OK) return st;
+  }
+  return CSN_OK;
+}
+
+int plan_dw_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
+  const csn_unit_desc& d = u.d;
+  for (int k = 0; k < d.n_in; ++k) {
+    if (d.cout[k] == 0) continue;
+    ub.need_dx[k] = d.in_act[k] > 0;
+    ub.dwf_w[k] = bl.alloc_packed((int64_t)d.cout[k] * 9);
+    bl.job(CSN_PREP_FLIP9, d.cout[k] * 9, ub.dwf_w[k], d.w_off[k], -1, -1, -1, 100.0f);
+  }
+  return CSN_OK;
+}
+
+int plan_ms_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
+  csn_plan& P = bl.P;
+  const csn_unit_desc& d = u.d;
+  const int cin = d.cin[0], cout = d.cout[0];
+  ub.need_dx[0] = d.in_act[0] > 0;
+  int cobase[CSN_NDIL], base = 0;
+  for (int k = 0; k < CSN_NDIL; ++k) { cobase[k] = base; base += d.dil_ch[k]; }
+  for (int k = 0; k < CSN_NDIL; ++k) {
+    if (d.dil_ch[k] == 0) continue;
+    PwLaunchPlan L;
+    L.lvl = u.base_lvl;
+    PwPassPlan ps;
+    ps.r = 0; ps.nsrc = 1; ps.src_kind[0] = SRC_IN; ps.src_branch[0] = 0; ps.src_C[0] = cin; ps.src_mode[0] = PW_TAPS;
+    ps.src_dil[0] = 1 << k; ps.K = cin * 9; ps.nrows = d.dil_ch[k];
+    WBlock w; w.src = d.w_off[k]; w.ld = cin * 9; w.ncol = cin * 9; w.col = 0; w.scale = 100.f;
+    ps.wb.push_back(w);
+    WgPlan wg = make_wg(L, ps);
+    wg.a_kind = SRC_DZ; wg.a_idx = 0; wg.a_c0 = cobase[k]; wg.a_ctot = cout;
+    ub.wg.push_back(wg);
+  }
+  if (!ub.need_dx[0]) return CSN_OK;
+  int k = 0;
+  bool first = true;
+  while (k < CSN_NDIL) {
+    PwLaunchPlan L;
+    L.lvl = u.base_lvl;
+    PwPassPlan ps;
+    ps.r = 0; ps.nrows = cin; ps.out_kind = OUT_DX; ps.out_branch = 0; ps.out_ctot = cin;
+    ident_epi(P, ps);
+    const int room = first ? 3 : 2;
+    for (; k < CSN_NDIL && ps.nsrc < room; ++k) {
+      if (d.dil_ch[k] == 0) continue;
+      const int s = ps.nsrc++;
+      ps.src_kind[s] = SRC_DZ; ps.src_branch[s] = 0; ps.src_C[s] = d.dil_ch[k]; ps.src_mode[s] = PW_TAPS;
+      ps.src_dil[s] = 1 << k; ps.src_c0[s] = cobase[k]; ps.src_ctot[s] = cout;
+      WBlock w; w.src = d.w_off[k]; w.ld = cin * 9; w.ncol = d.dil_ch[k] * 9; w.col = ps.K; w.scale = 100.f; w.tk = 9;
+      ps.wb.push_back(w);
+      ps.K += d.dil_ch[k] * 9;
+    }
+    if (ps.nsrc == 0) break;
+    if (!first) {   // accumulate onto the dilations of the previous launch through an identity block
+      const int s = ps.nsrc++;
+      ps.src_kind[s] = SRC_DX; ps.src_branch[s] = 0; ps.src_C[s] = cin; ps.src_mode[s] = PW_OWN;
+      WBlock w; w.eye = 1; w.ncol = cin; w.col = ps.K;
+      ps.wb.push_back(w);
+      ps.K += cin;
+    }
+    L.passes.push_back(ps);
+    DataLaunch dl;
+    dl.L = L; dl.i = 0;
+    ub.data.push_back(dl);
+    first = false;
+    bool more = false;
+    for (int q = k; q < CSN_NDIL; ++q) more = more || d.dil_ch[q] > 0;
+    if (!more) break;
+  }
+  for (DataLaunch& dl : ub.data) {
+    const int st = finish_launch(bl, dl.L);
+    if (st != CSN_OK) return st;
+  }
+  return CSN_OK;
+}
+
+int plan_cls_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
+  csn_plan& P = bl.P;
+  const csn_unit_desc& d = u.d;
+  ub.need_dx[0] = d.in_act[0] > 0;
+  {
+    WgPlan wg = make_wg(u.pwl[0], u.pwl[0].passes[0]);
+    wg.a_kind = SRC_DZ; wg.a_idx = 0; wg.a_c0 = 0; wg.a_ctot = 1;
+    ub.wg.push_back(wg);
+  }
+  if (!ub.need_dx[0]) return CSN_OK;
+  PwLaunchPlan L;
+  L.lvl = 1;
+  PwPassPlan ps;
+  ps.r = 0; ps.nsrc = 1; ps.src_kind[0] = SRC_DZ; ps.src_branch[0] = 0; ps.src_C[0] = 1; ps.src_mode[0] = PW_OWN;
+  ps.K = 1; ps.nrows = d.cin[0]; ps.out_kind = OUT_DX; ps.out_branch = 0; ps.out_ctot = d.cin[0];
+  ident_epi(P, ps);
+  WBlock w; w.src = d.w_off[0]; w.ld = d.cin[0]; w.ncol = 1; w.col = 0; w.tk = 1;
+  ps.wb.push_back(w);
+  L.passes.push_back(ps);
+  DataLaunch dl;
+  dl.L = L; dl.i = 0;
+  ub.data.push_back(dl);
+  return finish_launch(bl, ub.data.back().L);
+}
+
+// ---------------------------------------------------------------------------------------------- execution
+struct BwdCtx {
+  const Ctx& c;
+  const float* arena;
+  float* grad;
+  const float* flop_w;
+  float pen_scale;
+};
+
+float* grad_buf(const Ctx& c, int act, int slot) {
+  return reinterpret_cast<float*>(c.ws + c.P.tg_off[act][slot]);
+}
+
+int run_wgrad(const BwdCtx& b, const WgPlan& w, const PwBind& bd) {
+  const csn_plan& P = b.c.P;
+  const PwPassPlan& pp = w.L.passes[0];
+  WgArgs a;
+  fill_pass(b.c, w.L, pp, bd, a.ps);
+  a.Hr = P.H >> w.L.lvl; a.Wr = P.W >> w.L.lvl; a.B = P.S;
+  const int64_t hw = (int64_t)a.Hr * a.Wr;
+  const float* ab = w.a_kind == SRC_ADJ ? bd.adj[w.a_idx] : bd.dz[w.a_idx];
+  a.a = ab + (int64_t)w.a_c0 * hw;
+  a.a_ctot = w.a_ctot;
+  a.gpp = (int)((hw + 63) / 64);
+  a.ngroups = a.gpp * P.S;
+  a.nblk = a.ngroups < WG_MAX_BLOCKS ? a.ngroups : WG_MAX_BLOCKS;
+  a.rows16 = (pp.nrows + 15) & ~15;
+  a.k16 = (pp.K + 15) & ~15;
+  a.partial = reinterpret_cast<float*>(b.c.ws + P.wg_off);
+  LAUNCH_TRY(csn_launch_wgrad(a, b.c.stream));
+  WgReduceArgs r;
+  r.partial = a.partial; r.grad = b.grad;
+  r.nblocks = (int)w.blocks.size();
+  for (int q = 0; q < 3; ++q)
+    if (q < r.nblocks) r.blk[q] = w.blocks[q];
+    else { r.blk[q].dst = 0; r.blk[q].ld = 0; r.blk[q].ncol = 0; r.blk[q].col = 0; r.blk[q].scale = 0.f; }
+  r.nblk = a.nblk; r.nrows = pp.nrows; r.K = pp.K; r.rows16 = a.rows16; r.k16 = a.k16;
+  LAUNCH_TRY(csn_launch_wgrad_reduce(r, b.c.stream));
+  return CSN_OK;
+}
+
+int run_bn_bwd(const BwdCtx& b, int ui, const UnitPlan& u, int j) {
+  const csn_plan& P = b.c.P;
+  const csn_unit_desc& d = u.d;
+  const int act = d.out_act[j];
+  const Act& A = P.acts[act];
+  BnBwdArgs a;
+  a.dyA = grad_buf(b.c, act, 0);
+  a.dyB = P.n_cons[act] > 1 ? grad_buf(b.c, act, 1) : nullptr;
+  a.z = reinterpret_cast<float*>(b.c.ws + P.tz_off[act]);
+  a.scale = P.packed + u.out_epi[j].scale; a.shift = P.packed + u.out_epi[j].shift; a.alpha = P.packed + u.out_epi[j].alpha;
+  a.mean = P.packed + u.tr_mean[j]; a.invstd = P.packed + u.tr_invstd[j];
+  a.partial = reinterpret_cast<double*>(b.c.ws + P.red_off);
+  a.m1m2 = P.packed + u.tr_m1m2[j];
+  a.arena = b.arena; a.grad = b.grad;
+  a.gapabs = u.gap_off[j] >= 0 ? reinterpret_cast<const float*>(b.c.ws + u.gap_off[j]) : nullptr;
+  a.off_weight = d.bn[j].weight; a.off_bias = d.bn[j].bias; a.off_prelu = d.bn[j].prelu;
+  a.HW = (int64_t)(P.H >> A.lvl) * (P.W >> A.lvl);
+  a.S = P.S; a.C = d.cout[j];
+  a.flop_w = b.flop_w[ui * CSN_MAX_BRANCH + j];
+  a.pen_scale = b.pen_scale;
+  LAUNCH_TRY(csn_launch_bn_bwd(a, b.c.stream));
+  return CSN_OK;
+}
+
+int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
+  const Ctx& c = b.c;
+  csn_plan& P = c.P;
+  const UnitPlan& u = P.units[ui];
+  const UnitBwd& ub = P.bwd[ui];
+  const csn_unit_desc& d = u.d;
+  const int S = P.S;
+  char* scratch = c.ws + P.scratch_off;
+  PwBind bd;
+  if (d.kind == CSN_UNIT_CLS) {
+    float* dlh = reinterpret_cast<float*>(c.ws + u.logits_off);   // gradient of the half-resolution logits
+    AdjUpArgs ua;
+    ua.in = dy; ua.out = dlh; ua.planes = S; ua.Hl = P.H >> 1; ua.Wl = P.W >> 1; ua.f = 2;
+    LAUNCH_TRY(csn_launch_adjup(ua, c.stream));
+    LAUNCH_TRY(csn_launch_sum_to_grad(dlh, (int64_t)S * ua.Hl * ua.Wl, b.grad + d.bias_off, c.stream));
+    bd.in[0] = c.act_in(d.in_act[0]);
+    bd.dz[0] = dlh;
+  } else {
+    for (int j = 0; j < d.n_out; ++j) {
+      if (d.cout[j] == 0) continue;
+      const int st = run_bn_bwd(b, ui, u, j);
+      if (st != CSN_OK) return st;
+      bd.dz[j] = reinterpret_cast<const float*>(c.ws + P.tz_off[d.out_act[j]]);
+    }
+    for (int i = 0; i < d.n_in; ++i) {
+      if (d.cin[i] == 0) continue;
+      bd.in[i] = (d.kind == CSN_UNIT_GOCT && d.stride == 2) ? reinterpret_cast<const float*>(c.ws + u.pooled_off[i])
+                                                             : c.act_in(d.in_act[i]);
+    }
+  }
+  for (int i = 0; i < d.n_in; ++i) {
+    if (!ub.need_dx[i]) continue;
+    float* g = grad_buf(c, d.in_act[i], u.in_slot[i]);
+    bd.dx[i] = ub.dxp_off[i] >= 0 ? reinterpret_cast<float*>(scratch + ub.dxp_off[i]) : g;
+    bd.dxsrc[i] = bd.dx[i];
+  }
+  if (ub.tmp_off >= 0) bd.tmp = reinterpret_cast<float*>(scratch + ub.tmp_off);
+
+  if (d.kind == CSN_UNIT_DW) {
+    DwArgs a;
+    a.nbr = 0; a.B = S;
+    int blk = 0;
+    for (int k = 0; k < d.n_in; ++k) {
+      if (d.cout[k] == 0) continue;
+      const Act& act = P.acts[d.in_act[k]];
+      const int H = P.H >> act.lvl, W = P.W >> act.lvl;
+      DwWgradArgs w;
+      w.dz = bd.dz[k]; w.x = bd.in[k]; w.partial = reinterpret_cast<double*>(c.ws + P.red_off); w.grad = b.grad;
+      w.off_w = d.w_off[k]; w.C = d.cout[k]; w.S = S; w.H = H; w.W = W;
+      LAUNCH_TRY(csn_launch_dw_wgrad(w, c.stream));
+      if (!ub.need_dx[k]) continue;
+      DwBranch& br = a.br[a.nbr++];
+      br.in = bd.dz[k]; br.out = bd.dx[k];
+      br.w9 = c.pk(ub.dwf_w[k]);
+      br.scale = c.pk(P.ident.scale); br.shift = c.pk(P.ident.shift); br.alpha = c.pk(P.ident.alpha);
+      br.w9b = br.scale_b = br.shift_b = br.alpha_b = nullptr;
+      br.C = d.cout[k]; br.H = H; br.W = W;
+      const int cols = (br.W + 3) / 4;
+      br.LX = cols < 64 ? cols : 64;
+      br.NY = CSN_BLOCK / br.LX;
+      br.tiles_x = (cols + br.LX - 1) / br.LX;
+      br.R = choose_dw_rows(br.H, br.NY);
+      br.tiles_y = (br.H + br.NY * br.R - 1) / (br.NY * br.R);
+      blk += br.tiles_x * br.tiles_y * br.C * S;
+      br.blk_end = blk;
+    }
+    if (a.nbr > 0) LAUNCH_TRY(csn_launch_dw(a, c.stream));
+    return CSN_OK;
+  }
+
+  // adjoint-upsampled dz (gOctConv low->high terms)
+  for (size_t k = 0; k < ub.adj.size(); ++k) {
+    const AdjPlan& ap = ub.adj[k];
+    AdjUpArgs ua;
+    ua.in = bd.dz[ap.j]; ua.out = reinterpret_cast<float*>(scratch + ap.off);
+    ua.planes = S * ap.C; ua.Hl = P.H >> ap.lvl; ua.Wl = P.W >> ap.lvl; ua.f = ap.f;
+    LAUNCH_TRY(csn_launch_adjup(ua, c.stream));
+    bd.adj[k] = ua.out;
+  }
+  for (const WgPlan& w : ub.wg) {
+    const int st = run_wgrad(b, w, bd);
+    if (st != CSN_OK) return st;
+  }
+  for (int i = 0; i < d.n_in; ++i)
+    if (ub.need_dx[i] && ub.zero_dx[i]) {
+      const Act& A = P.acts[d.in_act[i]];
+      const int lvl = ub.dxp_off[i] >= 0 ? u.base_lvl + i : A.lvl;
+      HIP_TRY(hipMemsetAsync(bd.dx[i], 0, (size_t)S * d.cin[i] * (P.H >> lvl) * (P.W >> lvl) * sizeof(float),
+                             (hipStream_t)c.stream));
+    }
+  for (const DataLaunch& dl : ub.data) {
+    const int st = launch_pw(c, dl.L, bd);
+    if (st != CSN_OK) return st;
+    if (dl.to_tmp) {
+      PoolBwdArgs pa;
+      pa.x = bd.in[dl.i]; pa.t = bd.tmp; pa.dx = bd.dx[dl.i];
+      pa.planes = S * d.cin[dl.i]; pa.Hl = P.H >> dl.lvl_lo; pa.Wl = P.W >> dl.lvl_lo; pa.f = dl.pool_f;
+      LAUNCH_TRY(csn_launch_maxpool_bwd_add(pa, c.stream));
+    }
+  }
+  if (d.kind == CSN_UNIT_GOCT && d.stride == 2)
+    for (int i = 0; i < d.n_in; ++i) {
+      if (!ub.need_dx[i]) continue;
+      PoolBwdArgs pa;
+      pa.x = nullptr; pa.t = bd.dx[i]; pa.dx = grad_buf(c, d.in_act[i], u.in_slot[i]);
+      pa.planes = S * d.cin[i]; pa.Hl = P.H >> (u.base_lvl + i); pa.Wl = P.W >> (u.base_lvl + i); pa.f = 2;
+      LAUNCH_TRY(csn_launch_avgpool2_bwd(pa, c.stream));
+    }
+  return CSN_OK;
+}
+
+}  // namespace
+
+csn_plan::~csn_plan() = default;
+
+extern "C" {
+
+int csn_plan_enable_training(csn_plan* P) {
+  if (!P) return CSN_E_INVALID;
+  if (P->train) return CSN_OK;
+  if (P->S != P->B) { g_hip_err = "training needs the whole batch in one slice (sub_batch = 0)"; return CSN_E_UNSUPPORTED; }
+  Builder bl(*P);
+  const int na = (int)P->acts.size(), nu = (int)P->units.size();
+  P->tz_off.assign(na, -1);
+  P->tg_off.assign(na, std::array<int64_t, 2>{-1, -1});
+  P->n_cons.assign(na, 0);
+  int maxc = 1;
+  for (int i = 1; i < na; ++i) {
+    P->tz_off[i] = bl.alloc_ws(bl.act_bytes(P->acts[i].channels, P->acts[i].lvl));
+    maxc = std::max(maxc, P->acts[i].channels);
+  }
+  for (int k = 0; k < nu; ++k) {
+    UnitPlan& u = P->units[k];
+    for (int i = 0; i < u.d.n_in; ++i) {
+      const int a = u.d.in_act[i];
+      if (u.d.cin[i] == 0 || a <= 0) continue;
+      if (P->n_cons[a] >= 2) { g_hip_err = "an activation with more than two consumers"; return CSN_E_UNSUPPORTED; }
+      u.in_slot[i] = P->n_cons[a]++;
+      P->tg_off[a][u.in_slot[i]] = bl.alloc_ws(bl.act_bytes(P->acts[a].channels, P->acts[a].lvl));
+    }
+    if (u.d.kind == CSN_UNIT_CLS) continue;
+    for (int j = 0; j < u.d.n_out; ++j) {
+      if (u.d.cout[j] == 0) continue;
+      u.tr_mean[j] = bl.alloc_packed(u.d.cout[j]);
+      u.tr_invstd[j] = bl.alloc_packed(u.d.cout[j]);
+      u.tr_m1m2[j] = bl.alloc_packed(2 * u.d.cout[j]);
+      u.gap_off[j] = bl.alloc_ws((int64_t)u.d.cout[j] * P->S * sizeof(float));
+    }
+  }
+  for (int k = 0; k < nu; ++k) {
+    const UnitPlan& u = P->units[k];
+    if (u.d.kind == CSN_UNIT_CLS) continue;
+    for (int j = 0; j < u.d.n_out; ++j)
+      if (u.d.cout[j] > 0 && P->n_cons[u.d.out_act[j]] == 0) {
+        g_hip_err = "unit " + std::to_string(k) + ": an output branch without consumer has no gradient";
+        return CSN_E_UNSUPPORTED;
+      }
+  }
+  P->red_off = bl.alloc_ws((int64_t)maxc * CSN_BN_NSLAB * 9 * sizeof(double));
+  P->bwd.clear();
+  P->bwd.resize(nu);
+  int64_t scratch = 0, wg_floats = 0;
+  for (int k = 0; k < nu; ++k) {
+    UnitPlan& u = P->units[k];
+    UnitBwd& ub = P->bwd[k];
+    int st = CSN_OK;
+    switch (u.d.kind) {
+      case CSN_UNIT_GOCT: st = plan_goct_bwd(bl, u, ub); break;
+      case CSN_UNIT_DW: st = plan_dw_bwd(bl, u, ub); break;
+      case CSN_UNIT_MS: st = plan_ms_bwd(bl, u, ub); break;
+      case CSN_UNIT_CLS: st = plan_cls_bwd(bl, u, ub); break;
+      default: st = CSN_E_INVALID;
+    }
+    if (st != CSN_OK) {
+      g_hip_err = "backward plan of unit " + std::to_string(k) + ": " + g_why;
+      return st;
+    }
+    scratch = std::max(scratch, ub.scratch);
+    for (const WgPlan& w : ub.wg) {
+      const PwPassPlan& pp = w.L.passes[0];
+      wg_floats = std::max(wg_floats, (int64_t)WG_MAX_BLOCKS * ((pp.nrows + 15) & ~15) * ((pp.K + 15) & ~15));
+    }
+  }
+  P->scratch_bytes = scratch;
+  P->scratch_off = bl.alloc_ws(scratch > 0 ? scratch : 256);
+  P->wg_off = bl.alloc_ws(wg_floats * (int64_t)sizeof(float));
+  // the packed buffer and the job list grew: re-allocate / re-upload
+  if (P->packed) (void)hipFree(P->packed);
+  if (P->jobs_dev) (void)hipFree(P->jobs_dev);
+  P->packed = nullptr; P->jobs_dev = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&P->packed), (size_t)(P->packed_floats + 4) * sizeof(float));
+  if (e != hipSuccess) { hip_fail(e, "hipMalloc(packed)"); return CSN_E_NOMEM; }
+  e = hipMemsetAsync(P->packed, 0, (size_t)(P->packed_floats + 4) * sizeof(float), nullptr);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&P->jobs_dev), P->jobs.size() * sizeof(CsnPrepJob));
+  if (e == hipSuccess)
+    e = hipMemcpy(P->jobs_dev, P->jobs.data(), P->jobs.size() * sizeof(CsnPrepJob), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return hip_fail(e, "plan upload");
+  P->params_ready = false;
+  P->train = true;
+  drop_graph(P);
+  return CSN_OK;
+}
+
+int csn_backward(csn_plan* P, const float* x, const float* dy, void* workspace, const float* arena, float* grad,
+                 int64_t arena_floats, const float* flop_w, float pen_scale, void* stream) {
+  if (!P || !x || !dy || !workspace || !arena || !grad || !flop_w) return CSN_E_INVALID;
+  if (!P->train || !P->params_ready || !P->bn_tables_train) return CSN_E_STATE;   // needs csn_forward_train first
+  (void)arena_floats;
+  Ctx c{*P, x, nullptr, static_cast<char*>(workspace), stream};
+  c.raw = true;
+  const BwdCtx b{c, arena, grad, flop_w, pen_scale};
+  for (int u = (int)P->units.size() - 1; u >= 0; --u) {
+    const int st = run_unit_bwd(b, u, dy);
+    if (st != CSN_OK) return st;
+  }
+  return CSN_OK;
+}
+
+int csn_bce_with_logits(const float* y, const float* t, float* dy, int64_t n, double* loss, void* stream) {
+  if (!y || !t || !dy || !loss || n <= 0) return CSN_E_INVALID;
+  LAUNCH_TRY(csn_launch_bce(y, t, dy, n, loss, stream));
+  return CSN_OK;
+}
+
+int csn_adam_step(float* p, const float* g, float* m, float* v, const float* wd, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int32_t step, void* stream) {
+  if (!p || !g || !m || !v || !wd || n <= 0 || step <= 0) return CSN_E_INVALID;
+  AdamArgs a;
+  a.p = p; a.g = g; a.m = m; a.v = v; a.wd = wd; a.n = n;
+  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  const double bc1 = 1.0 - std::pow((double)beta1, (double)step), bc2 = 1.0 - std::pow((double)beta2, (double)step);
+  a.step_size = (float)((double)lr / bc1);
+  a.sqrt_bc2 = (float)std::sqrt(bc2);
+  LAUNCH_TRY(csn_launch_adam(a, stream));
+  return CSN_OK;
+}
+
+}  // extern "C"

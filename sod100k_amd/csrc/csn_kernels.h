@@ -17,6 +17,11 @@ enum CsnPrepKind {
   // (n = nrow, p1 = ncol(ci), p0 = ld (total cin of the source weight), p3 = ci offset inside dst, p2 = dst cin total)
   CSN_PREP_C3 = 5,
   CSN_PREP_EYE = 6,       // dst[r*p2 + p3 + r] = p0f  for r < n (identity block inside packed rows)
+  // backward-data weights: transposed block with flipped taps
+  //   dst[ci*p2 + (p3 & 0xffffff) + co*kk + t] = p0f * src0[co*p0 + ci*kk + (kk-1-t)],  kk = p3 >> 24,
+  //   ci < n (rows), co*kk + t < p1 (columns)
+  CSN_PREP_ROWS_T = 7,
+  CSN_PREP_FLIP9 = 8,     // dst[c*9 + t] = p0f * src0[c*9 + 8 - t]   (n = 9*C)
 };
 struct CsnPrepJob {
   int32_t kind, n, p0, p1, p2, p3;
@@ -128,6 +133,35 @@ struct Up2Args {
 };
 
 // ---------------------------------------------------------------------------------------------
+// weight gradient of one contraction pass (see k_wgrad.hip)
+// ---------------------------------------------------------------------------------------------
+#define WG_MAX_BLOCKS 512
+struct WgArgs {
+  PwPass ps;            // gather descriptor of the forward pass (src, cin, nrows); out/epilogue fields unused
+  const float* a;       // dz: first of ps.nrows channels inside [B][a_ctot][Hr][Wr]
+  int32_t a_ctot;
+  int32_t Hr, Wr, B;
+  int32_t gpp;          // 64-pixel groups per image plane
+  int32_t ngroups;      // B * gpp
+  int32_t nblk;         // blocks (= partial slices)
+  int32_t rows16, k16;  // nrows / cin rounded up to 16
+  float* partial;       // [nblk][rows16][k16]
+};
+struct WgBlock {        // one rectangular block of weight columns inside the reference's weight tensor
+  int64_t dst;          // float offset into the gradient arena
+  int32_t ld, ncol, col;
+  float scale;          // 100 for Conv2dX100 weights (conv2d.py:104), else 1
+};
+struct WgReduceArgs {
+  const float* partial;
+  float* grad;
+  WgBlock blk[3];
+  int32_t nblocks, nblk, nrows, K, rows16, k16;
+};
+int csn_launch_wgrad(const WgArgs& a, void* stream);
+int csn_launch_wgrad_reduce(const WgReduceArgs& a, void* stream);
+
+// ---------------------------------------------------------------------------------------------
 // train-mode BatchNorm + PReLU + GAP penalty (see k_train.hip)
 // ---------------------------------------------------------------------------------------------
 #define CSN_BN_NSLAB 32
@@ -142,12 +176,16 @@ struct BnFinalizeArgs {
   float* arena;       // parameter arena: gamma/beta read, running stats updated in place
   float* scale;       // folded table of this BN for the apply pass (plan-owned)
   float* shift;
+  float* mean;        // batch mean / 1/sqrt(var+eps), kept for the backward pass
+  float* invstd;
   int64_t off_weight, off_bias, off_rmean, off_rvar;
   int64_t count;      // S * HW
   int32_t C;
 };
 struct BnApplyArgs {
-  float* z;           // in: raw conv output, out: PReLU(BN(z))
+  const float* z;     // raw conv output (kept for the backward pass)
+  float* y;           // PReLU(BN(z))
+  float* gapabs;      // [C][S] |mean_hw y| per image (null: not needed)
   const float* scale;
   const float* shift;
   const float* alpha;
@@ -161,6 +199,67 @@ struct BnApplyArgs {
 int csn_launch_bn_stats(const BnStatsArgs& a, void* stream);
 int csn_launch_bn_finalize(const BnFinalizeArgs& a, void* stream);
 int csn_launch_bn_apply(const BnApplyArgs& a, void* stream);
+
+struct BnBwdArgs {
+  const float* dyA;    // gradient w.r.t. the branch output y, from its first consumer
+  const float* dyB;    // ... second consumer (null if none)
+  float* z;            // in: saved raw conv output, out: dz
+  const float* scale;  // train-mode folded tables of the forward pass
+  const float* shift;
+  const float* alpha;
+  const float* mean;
+  const float* invstd;
+  double* partial;     // [C][CSN_BN_NSLAB][3]
+  float* m1m2;         // [C][2] mean(dbn), mean(dbn*xhat)
+  const float* arena;  // gamma
+  float* grad;         // gradient arena (same offsets as the parameter arena)
+  const float* gapabs; // [C][S] from the forward pass (null: no penalty)
+  int64_t off_weight, off_bias, off_prelu;
+  int64_t HW;
+  int32_t S, C;
+  float flop_w;        // Oct_bn_hook branch weight (0: not hooked)
+  float pen_scale;     // d loss / d (penalty sum) = FLOPS.WEIGHT / batchsize  (train.py:91,210)
+};
+int csn_launch_bn_bwd(const BnBwdArgs& a, void* stream);
+
+struct DwWgradArgs {
+  const float* dz;
+  const float* x;
+  double* partial;     // [C][CSN_BN_NSLAB][9]
+  float* grad;
+  int64_t off_w;
+  int32_t C, S, H, W;
+};
+int csn_launch_dw_wgrad(const DwWgradArgs& a, void* stream);
+
+struct AdjUpArgs {
+  const float* in;     // [planes][Hl*f][Wl*f]
+  float* out;          // [planes][Hl][Wl]
+  int32_t planes, Hl, Wl, f;
+};
+int csn_launch_adjup(const AdjUpArgs& a, void* stream);
+
+struct PoolBwdArgs {
+  const float* x;      // max-pool: the pooled INPUT [planes][Hl*f][Wl*f]; avg-pool: unused
+  const float* t;      // gradient at the low resolution [planes][Hl][Wl]
+  float* dx;           // [planes][Hl*f][Wl*f]  (max-pool: accumulated, avg-pool: written)
+  int32_t planes, Hl, Wl, f;
+};
+int csn_launch_avgpool2_bwd(const PoolBwdArgs& a, void* stream);
+int csn_launch_maxpool_bwd_add(const PoolBwdArgs& a, void* stream);
+int csn_launch_sum_to_grad(const float* in, int64_t n, float* dst, void* stream);
+int csn_launch_bce(const float* y, const float* t, float* dy, int64_t n, double* loss, void* stream);
+
+struct AdamArgs {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  const float* wd;     // per-element weight decay
+  int64_t n;
+  float beta1, beta2, eps, step_size, sqrt_bc2;
+};
+int csn_launch_adam(const AdamArgs& a, void* stream);
 
 // launchers (implemented next to the kernels)
 int csn_launch_prep(const CsnPrepJob* jobs_dev, int njobs, const float* arena, float* packed, void* stream);

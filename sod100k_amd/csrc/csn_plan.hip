@@ -1,6 +1,8 @@
 // csn_plan.hip -- host side of libcsnet_hip.so: plan construction, parameter packing jobs, workspace
 // layout and the launch sequence of CSNet.forward (CSNet/model/csnet.py:365-387) behind the C ABI of
 // include/csnet_hip.h.  No torch types; the caller owns every tensor.
+#include <array>
+#include <cmath>
 #include <algorithm>
 #include <new>
 #include <string>
@@ -41,17 +43,21 @@ struct Act {
 
 struct Epi {  // float offsets into the packed buffer
   int64_t scale = -1, shift = -1, alpha = -1;
+  int64_t dummy = -1;   // identity tables only: a scratch row for outputs nobody reads
 };
 
 // ---- plan of the panel + MFMA contraction kernel (k_goct_pw.hip) --------------------------------------
-enum SrcKind { SRC_IN = 0, SRC_Z = 1 };     // unit input branch (pooled copy when stride 2) / unit-private scratch
-enum OutKind { OUT_ACT = 0, OUT_Z = 1, OUT_LOGITS = 2 };
+// sources: unit input branch (pooled copy when stride 2) / unit-private scratch / backward: dz of an output branch,
+// adjoint-upsampled dz (unit scratch), the gradient buffer being accumulated
+enum SrcKind { SRC_IN = 0, SRC_Z = 1, SRC_DZ = 2, SRC_ADJ = 3, SRC_DX = 4 };
+enum OutKind { OUT_ACT = 0, OUT_Z = 1, OUT_LOGITS = 2, OUT_DX = 3, OUT_TMP = 4 };
 
 struct WBlock {           // one rectangular block of a pass's weight rows
   int eye = 0;            // 1: identity block (adds an already convolved tensor through the contraction)
   int64_t src = -1;       // arena offset of W[row 0][col 0] of the block
   int ld = 0, ncol = 0, col = 0;
   float scale = 1.f;
+  int tk = 0;             // > 0: transposed block with flipped taps (backward data), tk = k*k of the forward weight
 };
 
 struct PwPassPlan {
@@ -62,6 +68,8 @@ struct PwPassPlan {
   int src_C[3] = {0, 0, 0};
   int src_mode[3] = {0, 0, 0};         // PwMode
   int src_dil[3] = {1, 1, 1};
+  int src_c0[3] = {0, 0, 0};           // first channel of the slice inside its tensor
+  int src_ctot[3] = {0, 0, 0};         // channels of the whole tensor (0: == src_C)
   int K = 0, K4 = 0, nrows = 0;
   int w_off = 0, w_stride = 0;         // inside the launch's weight image
   int out_kind = OUT_ACT, out_branch = 0, out_c0 = 0, out_ctot = 0;
@@ -90,12 +98,19 @@ struct UnitPlan {
   int fuse_next = 0;   // DW: the next unit is the second depthwise unit of the same ILBlock
   Epi out_epi[3];                        // folded BN/PReLU tables of every output branch (train mode rewrites them)
   int64_t stats_off[3] = {-1, -1, -1};   // workspace byte offsets of the BN statistics partials
+  // training (csn_plan_enable_training): per output branch batch mean / invstd / backward means (packed offsets),
+  // per-image |GAP| table (workspace bytes), consumer slot of every input branch in its activation's gradient list
+  int64_t tr_mean[3] = {-1, -1, -1}, tr_invstd[3] = {-1, -1, -1}, tr_m1m2[3] = {-1, -1, -1};
+  int64_t gap_off[3] = {-1, -1, -1};
+  int in_slot[3] = {-1, -1, -1};
   // MS
   int64_t ms_w[5] = {-1, -1, -1, -1, -1};
   Epi ms_epi;
   const char* kname = "";
   int64_t alg_bytes = 0;
 };
+
+struct UnitBwd;
 
 }  // namespace
 
@@ -126,6 +141,16 @@ struct csn_plan {
   std::vector<KStat> kstats;         // aggregated over the last csn_forward_profile call
   bool profiling = false;
   size_t ev_used = 0;
+  // ---- training (csn_plan_enable_training) ----
+  bool train = false;
+  std::vector<int64_t> tz_off;                  // per act: raw conv output z, later dz (workspace bytes)
+  std::vector<std::array<int64_t, 2>> tg_off;   // per act: gradient buffer per consumer
+  std::vector<int> n_cons;
+  int64_t scratch_off = 0, scratch_bytes = 0;   // per-unit backward temporaries (shared by all units)
+  int64_t red_off = 0;                          // fp64 partials of the BN / depthwise reductions
+  int64_t wg_off = 0;                           // partial dW slices (k_wgrad.hip)
+  std::vector<UnitBwd> bwd;
+  ~csn_plan();
 };
 
 namespace {
@@ -186,6 +211,9 @@ int finish_launch(Builder& bl, PwLaunchPlan& L) {
     for (const WBlock& w : ps.wb) {
       if (w.eye)
         bl.job(CSN_PREP_EYE, w.ncol, L.wimg + ps.w_off, -1, -1, -1, -1, 1.f, 0, 0, ps.w_stride, w.col);
+      else if (w.tk > 0)
+        bl.job(CSN_PREP_ROWS_T, ps.nrows, L.wimg + ps.w_off, w.src, -1, -1, -1, w.scale, w.ld, w.ncol, ps.w_stride,
+               w.col | (w.tk << 24));
       else
         bl.job(CSN_PREP_ROWS, ps.nrows, L.wimg + ps.w_off, w.src, -1, -1, -1, w.scale, w.ld, w.ncol, ps.w_stride, w.col);
     }
@@ -401,7 +429,11 @@ struct Ctx {
     const Act& a = P.acts[id];
     return a.ws_off < 0 ? x : reinterpret_cast<const float*>(ws + a.ws_off);
   }
-  float* act_out(int id) const { return reinterpret_cast<float*>(ws + P.acts[id].ws_off); }
+  // train mode with backward buffers: the convolutions write z next to (not over) the activation y
+  float* act_out(int id) const {
+    return reinterpret_cast<float*>(ws + ((raw && P.train) ? P.tz_off[id] : P.acts[id].ws_off));
+  }
+  float* act_y(int id) const { return reinterpret_cast<float*>(ws + P.acts[id].ws_off); }
   const float* pk(int64_t off) const { return P.packed + off; }
   bool raw = false;   // train mode: convolutions write the un-normalised z (identity epilogue)
   const float* sc(const Epi& e) const { return P.packed + (raw ? P.ident.scale : e.scale); }
@@ -450,8 +482,71 @@ int choose_dw_rows(int H, int NY) {
   return best;
 }
 
-// xin[i]: unit input branch i (pooled copy for stride 2); outp[j]: output act of branch j
-int launch_pw(const Ctx& c, const UnitPlan& u, const PwLaunchPlan& L, const float* const xin[3], float* const outp[3]) {
+// pointers a launch's sources / outputs resolve to, by SrcKind / OutKind and branch
+struct PwBind {
+  const float* in[3] = {nullptr, nullptr, nullptr};    // SRC_IN: unit input branch i (pooled copy for stride 2)
+  const float* z = nullptr;                            // SRC_Z
+  const float* dz[3] = {nullptr, nullptr, nullptr};    // SRC_DZ
+  const float* adj[4] = {nullptr, nullptr, nullptr, nullptr};   // SRC_ADJ
+  const float* dxsrc[3] = {nullptr, nullptr, nullptr}; // SRC_DX
+  float* act[3] = {nullptr, nullptr, nullptr};         // OUT_ACT: output act of branch j
+  float* zout = nullptr;                               // OUT_Z
+  float* logits = nullptr;                             // OUT_LOGITS
+  float* dx[3] = {nullptr, nullptr, nullptr};          // OUT_DX
+  float* tmp = nullptr;                                // OUT_TMP
+};
+
+// kernel-side descriptor of one pass: source slices (resolved pointers), weight rows, output, epilogue
+void fill_pass(const Ctx& c, const PwLaunchPlan& L, const PwPassPlan& pp, const PwBind& bd, PwPass& ps) {
+  const csn_plan& P = c.P;
+  ps.r = pp.r; ps.nsrc = pp.nsrc;
+  const int Hr = P.H >> (L.lvl + pp.r), Wr = P.W >> (L.lvl + pp.r);
+  for (int s = 0; s < 3; ++s) {
+    ps.src[s].ptr = nullptr; ps.src[s].C = 0; ps.src[s].Ctot = 0; ps.src[s].mode = PW_OWN; ps.src[s].K = 0;
+    ps.src[s].dil = 1; ps.src[s].pad = 0;
+    if (s < pp.nsrc) {
+      const int br = pp.src_branch[s], mode = pp.src_mode[s];
+      const float* base = nullptr;
+      switch (pp.src_kind[s]) {
+        case SRC_Z: base = bd.z; break;
+        case SRC_DZ: base = bd.dz[br]; break;
+        case SRC_ADJ: base = bd.adj[br]; break;
+        case SRC_DX: base = bd.dxsrc[br]; break;
+        default: base = bd.in[br]; break;
+      }
+      // resolution of the source tensor relative to the pass (channel offset -> plane offset)
+      int sh = 0;
+      if (mode == PW_POOL2 || mode == PW_POOL2_TAPS) sh = -1;
+      else if (mode == PW_POOL4) sh = -2;
+      else if (mode == PW_UP2) sh = 1;
+      else if (mode == PW_UP4) sh = 2;
+      const int64_t hs = sh >= 0 ? (int64_t)(Hr >> sh) * (Wr >> sh) : (int64_t)(Hr << -sh) * (Wr << -sh);
+      ps.src[s].ptr = base + (int64_t)pp.src_c0[s] * hs;
+      ps.src[s].C = pp.src_C[s];
+      ps.src[s].Ctot = pp.src_ctot[s] > 0 ? pp.src_ctot[s] : pp.src_C[s];
+      ps.src[s].mode = mode;
+      ps.src[s].K = (mode == PW_TAPS || mode == PW_POOL2_TAPS) ? 9 * pp.src_C[s] : pp.src_C[s];
+      ps.src[s].dil = pp.src_dil[s];
+    }
+  }
+  ps.cin = pp.K; ps.cin4 = pp.K4; ps.nrows = pp.nrows; ps.w_off = pp.w_off; ps.w_stride = pp.w_stride;
+  float* ob = nullptr;
+  switch (pp.out_kind) {
+    case OUT_Z: ob = bd.zout; break;
+    case OUT_LOGITS: ob = bd.logits; break;
+    case OUT_DX: ob = bd.dx[pp.out_branch]; break;
+    case OUT_TMP: ob = bd.tmp; break;
+    default: ob = bd.act[pp.out_branch]; break;
+  }
+  ps.out = ob ? ob + (int64_t)pp.out_c0 * Hr * Wr : nullptr;
+  ps.out_ctot = pp.out_ctot; ps.pad2 = 0;
+  const bool bn_out = pp.out_kind == OUT_ACT;   // scratch, logits and gradients have no BN
+  ps.scale = bn_out ? c.sc(pp.epi) : c.pk(pp.epi.scale);
+  ps.shift = bn_out ? c.sh(pp.epi) : c.pk(pp.epi.shift);
+  ps.alpha = bn_out ? c.al(pp.epi) : c.pk(pp.epi.alpha);
+}
+
+int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
   const csn_plan& P = c.P;
   PwArgs a;
   a.npass = (int)L.passes.size();
@@ -468,27 +563,7 @@ int launch_pw(const Ctx& c, const UnitPlan& u, const PwLaunchPlan& L, const floa
   for (int q = 0; q < a.npass; ++q) {
     const PwPassPlan& pp = L.passes[q];
     PwPass& ps = a.pass[q];
-    ps.r = pp.r; ps.nsrc = pp.nsrc;
-    for (int s = 0; s < 3; ++s) {
-      ps.src[s].ptr = nullptr; ps.src[s].C = 0; ps.src[s].Ctot = 0; ps.src[s].mode = PW_OWN; ps.src[s].K = 0;
-      ps.src[s].dil = 1; ps.src[s].pad = 0;
-      if (s < pp.nsrc) {
-        ps.src[s].ptr = pp.src_kind[s] == SRC_Z ? reinterpret_cast<const float*>(c.ws + u.z_off) : xin[pp.src_branch[s]];
-        ps.src[s].C = pp.src_C[s]; ps.src[s].Ctot = pp.src_C[s]; ps.src[s].mode = pp.src_mode[s];
-        ps.src[s].K = (pp.src_mode[s] == PW_TAPS || pp.src_mode[s] == PW_POOL2_TAPS) ? 9 * pp.src_C[s] : pp.src_C[s];
-        ps.src[s].dil = pp.src_dil[s];
-      }
-    }
-    ps.cin = pp.K; ps.cin4 = pp.K4; ps.nrows = pp.nrows; ps.w_off = pp.w_off; ps.w_stride = pp.w_stride;
-    float* ob = pp.out_kind == OUT_Z ? reinterpret_cast<float*>(c.ws + u.z_off)
-                : pp.out_kind == OUT_LOGITS ? reinterpret_cast<float*>(c.ws + u.logits_off) : outp[pp.out_branch];
-    const int64_t hw = (int64_t)(a.H0 >> pp.r) * (a.W0 >> pp.r);
-    ps.out = ob + (int64_t)pp.out_c0 * hw;
-    ps.out_ctot = pp.out_ctot; ps.pad2 = 0;
-    const bool bn_out = pp.out_kind == OUT_ACT;   // z scratch and cls logits have no BN
-    ps.scale = bn_out ? c.sc(pp.epi) : c.pk(pp.epi.scale);
-    ps.shift = bn_out ? c.sh(pp.epi) : c.pk(pp.epi.shift);
-    ps.alpha = bn_out ? c.al(pp.epi) : c.pk(pp.epi.alpha);
+    fill_pass(c, L, pp, bd, ps);
   }
   LAUNCH_TRY(csn_launch_pw(a, 2, c.stream));
   return c.mark("goct_pw_kernel");
@@ -560,11 +635,13 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
         for (int i = 0; i < d.n_in; ++i)
           if (d.cin[i] > 0) xin[i] = c.act_in(d.in_act[i]);
       }
-      float* outp[3] = {nullptr, nullptr, nullptr};
+      PwBind bd;
+      for (int i = 0; i < 3; ++i) bd.in[i] = xin[i];
       for (int j = 0; j < d.n_out; ++j)
-        if (d.cout[j] > 0) outp[j] = c.act_out(d.out_act[j]);
+        if (d.cout[j] > 0) bd.act[j] = c.act_out(d.out_act[j]);
+      if (u.z_off >= 0) bd.z = bd.zout = reinterpret_cast<float*>(c.ws + u.z_off);
       for (const PwLaunchPlan& L : u.pwl) {
-        const int st = launch_pw(c, u, L, xin, outp);
+        const int st = launch_pw(c, L, bd);
         if (st != CSN_OK) return st;
       }
     } break;
@@ -583,10 +660,11 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
       { const int ms_ = c.mark("msblock_kernel"); if (ms_ != CSN_OK) return ms_; }
     } break;
     case CSN_UNIT_CLS: {
-      const float* xin[3] = {c.act_in(d.in_act[0]), nullptr, nullptr};
-      float* outp[3] = {nullptr, nullptr, nullptr};
+      PwBind bd;
+      bd.in[0] = c.act_in(d.in_act[0]);
+      bd.logits = reinterpret_cast<float*>(c.ws + u.logits_off);
       for (const PwLaunchPlan& L : u.pwl) {
-        const int st = launch_pw(c, u, L, xin, outp);
+        const int st = launch_pw(c, L, bd);
         if (st != CSN_OK) return st;
       }
       Up2Args ua;
@@ -601,6 +679,16 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
 }
 
 }  // namespace
+
+static void drop_graph(csn_plan* P) {
+#ifndef CSN_CPU_EMU
+  if (P->graph_exec) { (void)hipGraphExecDestroy(P->graph_exec); P->graph_exec = nullptr; }
+#endif
+  P->g_x = P->g_y = P->g_ws = nullptr;
+  P->eager_calls = 0;
+}
+
+#include "csn_backward.inl"   // backward planning + sequencing (shares the plan's private types)
 
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" {
@@ -697,6 +785,7 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
     int maxc = 1;
     for (int i = 0; i < n_acts; ++i) maxc = std::max(maxc, (int)acts[i].channels);
     P->ident.scale = bl.alloc_packed(maxc); P->ident.shift = bl.alloc_packed(maxc); P->ident.alpha = bl.alloc_packed(maxc);
+    P->ident.dummy = bl.alloc_packed(maxc);
     bl.job(CSN_PREP_FILL, maxc, P->ident.scale, -1, -1, -1, -1, 1.f);
     bl.job(CSN_PREP_FILL, maxc, P->ident.shift, -1, -1, -1, -1, 0.f);
     bl.job(CSN_PREP_FILL, maxc, P->ident.alpha, -1, -1, -1, -1, 1.f);
@@ -728,8 +817,6 @@ void csn_plan_destroy(csn_plan* P) {
   if (P->jobs_dev) (void)hipFree(P->jobs_dev);
   delete P;
 }
-
-static void drop_graph(csn_plan* P);
 
 int csn_plan_set_option(csn_plan* P, int32_t option, int32_t value) {
   if (!P) return CSN_E_INVALID;
@@ -820,14 +907,6 @@ static int forward_body(csn_plan* P, const float* x, float* y, void* workspace, 
   return CSN_OK;
 }
 
-static void drop_graph(csn_plan* P) {
-#ifndef CSN_CPU_EMU
-  if (P->graph_exec) { (void)hipGraphExecDestroy(P->graph_exec); P->graph_exec = nullptr; }
-#endif
-  P->g_x = P->g_y = P->g_ws = nullptr;
-  P->eager_calls = 0;
-}
-
 int csn_forward(csn_plan* P, const float* x, float* y, void* workspace, void* stream) {
 #ifdef CSN_CPU_EMU
   return forward_body(P, x, y, workspace, stream, 1, nullptr);
@@ -886,7 +965,7 @@ int csn_forward_train(csn_plan* P, const float* x, float* y, void* workspace, fl
       if (d.cout[j] == 0) continue;
       const Act& act = P->acts[d.out_act[j]];
       const int64_t hw = (int64_t)(P->H >> act.lvl) * (P->W >> act.lvl);
-      float* z = c.act_out(d.out_act[j]);
+      float* z = c.act_out(d.out_act[j]);      // raw conv output (its own buffer when training is enabled)
       double* part = reinterpret_cast<double*>(c.ws + up.stats_off[j]);
       BnStatsArgs sa; sa.z = z; sa.partial = part; sa.S = P->S; sa.C = d.cout[j]; sa.HW = hw;
       LAUNCH_TRY(csn_launch_bn_stats(sa, stream));
@@ -894,8 +973,13 @@ int csn_forward_train(csn_plan* P, const float* x, float* y, void* workspace, fl
       fa.scale = P->packed + up.out_epi[j].scale; fa.shift = P->packed + up.out_epi[j].shift;
       fa.off_weight = d.bn[j].weight; fa.off_bias = d.bn[j].bias; fa.off_rmean = d.bn[j].running_mean;
       fa.off_rvar = d.bn[j].running_var; fa.count = (int64_t)P->S * hw; fa.C = d.cout[j];
+      // backward needs the batch mean / invstd; without training buffers they land in a dummy slot of the tables
+      fa.mean = P->packed + (P->train ? up.tr_mean[j] : P->ident.dummy);
+      fa.invstd = P->packed + (P->train ? up.tr_invstd[j] : P->ident.dummy);
       LAUNCH_TRY(csn_launch_bn_finalize(fa, stream));
-      BnApplyArgs aa; aa.z = z; aa.scale = fa.scale; aa.shift = fa.shift; aa.alpha = P->packed + up.out_epi[j].alpha;
+      BnApplyArgs aa; aa.z = z; aa.y = c.act_y(d.out_act[j]);
+      aa.gapabs = (P->train && up.gap_off[j] >= 0) ? reinterpret_cast<float*>(c.ws + up.gap_off[j]) : nullptr;
+      aa.scale = fa.scale; aa.shift = fa.shift; aa.alpha = P->packed + up.out_epi[j].alpha;
       aa.arena = arena; aa.penalty = penalty; aa.off_weight = d.bn[j].weight; aa.HW = hw; aa.S = P->S; aa.C = d.cout[j];
       aa.flop_w = flop_w[u * CSN_MAX_BRANCH + j];
       LAUNCH_TRY(csn_launch_bn_apply(aa, stream));

@@ -54,6 +54,18 @@ __global__ __launch_bounds__(CSN_BLOCK) void csn_prep_kernel(const CsnPrepJob* _
     case CSN_PREP_EYE:
       for (int i = tid; i < j.n; i += CSN_BLOCK) dst[(int64_t)i * j.p2 + j.p3 + i] = j.p0f;
       break;
+    case CSN_PREP_ROWS_T: {
+      const int kk = j.p3 >> 24, col = j.p3 & 0xffffff, ncol = j.p1;
+      const int tot = j.n * ncol;
+      for (int i = tid; i < tot; i += CSN_BLOCK) {
+        const int ci = i / ncol, c = i - ci * ncol;
+        const int co = c / kk, t = c - co * kk;
+        dst[(int64_t)ci * j.p2 + col + c] = j.p0f * arena[j.src0 + (int64_t)co * j.p0 + ci * kk + (kk - 1 - t)];
+      }
+    } break;
+    case CSN_PREP_FLIP9:
+      for (int i = tid; i < j.n; i += CSN_BLOCK) dst[i] = j.p0f * arena[j.src0 + (i / 9) * 9 + 8 - (i % 9)];
+      break;
     default:
       break;
   }

@@ -71,33 +71,37 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_finalize_kernel(BnFinalizeArgs a
   const float sc = gamma * invstd;
   a.scale[c] = sc;
   a.shift[c] = beta - (float)mean * sc;
+  a.mean[c] = (float)mean;       // kept for the backward pass
+  a.invstd[c] = invstd;
   const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
   a.arena[a.off_rmean + c] = 0.9f * a.arena[a.off_rmean + c] + 0.1f * (float)mean;
   a.arena[a.off_rvar + c] = 0.9f * a.arena[a.off_rvar + c] + 0.1f * (float)unbiased;
 }
 
-// grid (C, S): block (c, n) streams one plane: y = PReLU(z*scale + shift) in place, and the plane sum
-// feeds the penalty 0.5 * w * |mean_hw y| * gamma^2 (fp64 atomic; w == 0: unit is not hooked).
+// grid (C, S): block (c, n) streams one plane: y = PReLU(z*scale + shift) (z is kept for the backward pass), and
+// the plane sum feeds the penalty 0.5 * w * |mean_hw y| * gamma^2 (fp64 atomic; w == 0: unit is not hooked).
 __global__ __launch_bounds__(CSN_BLOCK) void bn_apply_gap_kernel(BnApplyArgs a) {
   CSN_DYN_SMEM(double, sm);
   const int c = blockIdx.x, n = blockIdx.y;
   const int64_t hw = a.HW;
-  float* __restrict__ p = a.z + ((int64_t)n * a.C + c) * hw;
+  const float* __restrict__ p = a.z + ((int64_t)n * a.C + c) * hw;
+  float* __restrict__ q = a.y + ((int64_t)n * a.C + c) * hw;
   const float sc = a.scale[c], sh = a.shift[c], al = a.alpha[c];
   double s = 0.0;
   if ((hw & 3) == 0) {
-    float4* p4 = reinterpret_cast<float4*>(p);
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    float4* q4 = reinterpret_cast<float4*>(q);
     for (int64_t i = threadIdx.x; i < (hw >> 2); i += CSN_BLOCK) {
       float4 v = p4[i];
       v.x = csn_epi(v.x, sc, sh, al); v.y = csn_epi(v.y, sc, sh, al);
       v.z = csn_epi(v.z, sc, sh, al); v.w = csn_epi(v.w, sc, sh, al);
-      p4[i] = v;
+      q4[i] = v;
       s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
     }
   } else {
     for (int64_t i = threadIdx.x; i < hw; i += CSN_BLOCK) {
       const float v = csn_epi(p[i], sc, sh, al);
-      p[i] = v;
+      q[i] = v;
       s += (double)v;
     }
   }
@@ -105,7 +109,9 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_apply_gap_kernel(BnApplyArgs a) 
     s = bn_block_sum(s, sm);
     if (threadIdx.x == 0) {
       const double g = (double)a.arena[a.off_weight + c];
-      const double term = 0.5 * (double)a.flop_w * fabs(s / (double)hw) * g * g;
+      const double gap = fabs(s / (double)hw);
+      if (a.gapabs) a.gapabs[(int64_t)c * a.S + n] = (float)gap;   // d penalty / d gamma needs sum_n |gap|
+      const double term = 0.5 * (double)a.flop_w * gap * g * g;
 #ifdef CSN_CPU_EMU
 #pragma omp atomic
       *a.penalty += term;
@@ -113,6 +119,240 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_apply_gap_kernel(BnApplyArgs a) 
       atomicAdd(a.penalty, term);
 #endif
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// BN(train) + PReLU backward of one output branch.  With bn = z*scale + shift, xhat = (z - mean)*invstd:
+//   y = bn > 0 ? bn : alpha*bn      dbn = dy * (bn > 0 ? 1 : alpha)      dalpha = sum dy*bn over bn <= 0
+//   dbeta = sum dbn    dgamma = sum dbn*xhat    dz = gamma*invstd * (dbn - mean(dbn) - xhat*mean(dbn*xhat))
+// (ATen batch_norm_backward / prelu_backward semantics).  dy may arrive from two consumers (the stage outputs feed
+// both the next stage and the CSF head); the sums are fp64, one partial per (channel, slab) -> deterministic.
+__device__ __forceinline__ float bnb_dy(const BnBwdArgs& a, int64_t i) {
+  float v = a.dyA[i];
+  if (a.dyB) v += a.dyB[i];
+  return v;
+}
+
+__global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_reduce_kernel(BnBwdArgs a) {
+  CSN_DYN_SMEM(double, sm);
+  const int c = blockIdx.y, slab = blockIdx.x;
+  const int64_t hw = a.HW;
+  const int64_t per = ((int64_t)a.S * hw + BN_NSLAB - 1) / BN_NSLAB;
+  const int64_t beg = (int64_t)slab * per;
+  const int64_t end = min(beg + per, (int64_t)a.S * hw);
+  const float sc = a.scale[c], sh = a.shift[c], al = a.alpha[c], mu = a.mean[c], is = a.invstd[c];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int64_t i = beg + threadIdx.x; i < end; i += CSN_BLOCK) {
+    const int64_t n = i / hw, p = i - n * hw;
+    const int64_t idx = (n * a.C + c) * hw + p;
+    const float z = a.z[idx], dy = bnb_dy(a, idx);
+    const float bn = z * sc + sh;
+    const float dbn = bn > 0.f ? dy : al * dy;
+    s0 += (double)dbn;
+    s1 += (double)dbn * (double)((z - mu) * is);
+    if (!(bn > 0.f)) s2 += (double)dy * (double)bn;
+  }
+  s0 = bn_block_sum(s0, sm);
+  s1 = bn_block_sum(s1, sm);
+  s2 = bn_block_sum(s2, sm);
+  if (threadIdx.x == 0) {
+    double* o = a.partial + ((int64_t)c * BN_NSLAB + slab) * 3;
+    o[0] = s0; o[1] = s1; o[2] = s2;
+  }
+}
+
+__global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_finalize_kernel(BnBwdArgs a) {
+  const int c = blockIdx.x * CSN_BLOCK + threadIdx.x;
+  if (c >= a.C) return;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < BN_NSLAB; ++k) {
+    const double* o = a.partial + ((int64_t)c * BN_NSLAB + k) * 3;
+    s0 += o[0]; s1 += o[1]; s2 += o[2];
+  }
+  const double n = (double)a.S * (double)a.HW;
+  a.m1m2[2 * c + 0] = (float)(s0 / n);
+  a.m1m2[2 * c + 1] = (float)(s1 / n);
+  const double gamma = (double)a.arena[a.off_weight + c];
+  double dgamma = s1;
+  if (a.flop_w != 0.f && a.gapabs) {   // d/dgamma of pen_scale * 0.5 * w * sum_n |gap[n,c]| * gamma^2
+    double sg = 0.0;
+    for (int k = 0; k < a.S; ++k) sg += (double)a.gapabs[(int64_t)c * a.S + k];
+    dgamma += (double)a.pen_scale * (double)a.flop_w * sg * gamma;
+  }
+  a.grad[a.off_weight + c] = (float)dgamma;
+  a.grad[a.off_bias + c] = (float)s0;
+  a.grad[a.off_prelu + c] = (float)s2;
+}
+
+// grid (C, S): dz written over z (same index, same thread)
+__global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_apply_kernel(BnBwdArgs a) {
+  const int c = blockIdx.x, n = blockIdx.y;
+  const int64_t hw = a.HW;
+  const int64_t base = ((int64_t)n * a.C + c) * hw;
+  const float sc = a.scale[c], sh = a.shift[c], al = a.alpha[c], mu = a.mean[c], is = a.invstd[c];
+  const float m1 = a.m1m2[2 * c], m2 = a.m1m2[2 * c + 1];
+  const float gi = a.arena[a.off_weight + c] * is;
+  for (int64_t i = threadIdx.x; i < hw; i += CSN_BLOCK) {
+    const float z = a.z[base + i], dy = bnb_dy(a, base + i);
+    const float bn = z * sc + sh;
+    const float dbn = bn > 0.f ? dy : al * dy;
+    a.z[base + i] = gi * (dbn - m1 - (z - mu) * is * m2);
+  }
+}
+
+// depthwise 3x3 weight gradient: dW[c][t] = 100 * sum_{n,p} dz[n,c,p] * x[n,c,p + off(t)]   (conv2d.py:104)
+__global__ __launch_bounds__(CSN_BLOCK) void dw_wgrad_kernel(DwWgradArgs a) {
+  CSN_DYN_SMEM(double, sm);
+  const int c = blockIdx.y, slab = blockIdx.x;
+  const int H = a.H, W = a.W;
+  const int64_t hw = (int64_t)H * W;
+  const int64_t per = ((int64_t)a.S * hw + BN_NSLAB - 1) / BN_NSLAB;
+  const int64_t beg = (int64_t)slab * per;
+  const int64_t end = min(beg + per, (int64_t)a.S * hw);
+  double s[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) s[t] = 0.0;
+  for (int64_t i = beg + threadIdx.x; i < end; i += CSN_BLOCK) {
+    const int64_t n = i / hw;
+    const int p = (int)(i - n * hw);
+    const int y = p / W, x = p - y * W;
+    const int64_t base = (n * a.C + c) * hw;
+    const float g = a.dz[base + p];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+      const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const float v = a.x[base + (in ? yy * W + xx : p)];
+      s[t] += in ? (double)g * (double)v : 0.0;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const double r = bn_block_sum(s[t], sm);
+    if (threadIdx.x == 0) a.partial[((int64_t)c * BN_NSLAB + slab) * 9 + t] = r;
+  }
+}
+
+__global__ __launch_bounds__(CSN_BLOCK) void dw_wgrad_finalize_kernel(DwWgradArgs a) {
+  const int e = blockIdx.x * CSN_BLOCK + threadIdx.x;
+  if (e >= a.C * 9) return;
+  const int c = e / 9, t = e - 9 * c;
+  double s = 0.0;
+  for (int k = 0; k < BN_NSLAB; ++k) s += a.partial[((int64_t)c * BN_NSLAB + k) * 9 + t];
+  a.grad[a.off_w + e] = (float)(100.0 * s);
+}
+
+// adjoint of F.interpolate(scale_factor=f, mode='bilinear', align_corners=False): out[lo] = sum_hi w(hi->lo) in[hi]
+__global__ __launch_bounds__(CSN_BLOCK) void adjup_kernel(AdjUpArgs a) {
+  const int Hl = a.Hl, Wl = a.Wl, f = a.f;
+  const int Hh = Hl * f, Wh = Wl * f;
+  const int64_t tot = (int64_t)a.planes * Hl * Wl;
+  const float inv = 1.f / (float)f;
+  for (int64_t e = (int64_t)blockIdx.x * CSN_BLOCK + threadIdx.x; e < tot; e += (int64_t)gridDim.x * CSN_BLOCK) {
+    const int64_t pl = e / (Hl * Wl);
+    const int r = (int)(e - pl * Hl * Wl);
+    const int ys = r / Wl, xs = r - ys * Wl;
+    const float* ip = a.in + pl * (int64_t)Hh * Wh;
+    float acc = 0.f;
+    for (int oy = max(ys * f - f, 0); oy < min(ys * f + 2 * f, Hh); ++oy) {
+      int y0, y1; float ly;
+      csn_bilin(oy, inv, Hl, y0, y1, ly);
+      const float wy = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = max(xs * f - f, 0); ox < min(xs * f + 2 * f, Wh); ++ox) {
+        int x0, x1; float lx;
+        csn_bilin(ox, inv, Wl, x0, x1, lx);
+        const float wx = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
+        acc += wy * wx * ip[(int64_t)oy * Wh + ox];
+      }
+    }
+    a.out[e] = acc;
+  }
+}
+
+// adjoint of avg_pool2d(2, 2): dx[p] = 0.25 * dxp[p >> 1]
+__global__ __launch_bounds__(CSN_BLOCK) void avgpool2_bwd_kernel(PoolBwdArgs a) {
+  const int Hh = a.Hl * 2, Wh = a.Wl * 2;
+  const int64_t tot = (int64_t)a.planes * Hh * Wh;
+  for (int64_t e = (int64_t)blockIdx.x * CSN_BLOCK + threadIdx.x; e < tot; e += (int64_t)gridDim.x * CSN_BLOCK) {
+    const int64_t pl = e / ((int64_t)Hh * Wh);
+    const int r = (int)(e - pl * Hh * Wh);
+    const int y = r / Wh, x = r - y * Wh;
+    a.dx[e] = 0.25f * a.t[pl * (int64_t)a.Hl * a.Wl + (y >> 1) * a.Wl + (x >> 1)];
+  }
+}
+
+// backward of max_pool2d(f, f): the window's gradient goes to its FIRST maximum in row-major order (ATen's
+// `val > maxval` scan), added to dx (the own-resolution term was written before).  One thread per window.
+__global__ __launch_bounds__(CSN_BLOCK) void maxpool_bwd_add_kernel(PoolBwdArgs a) {
+  const int f = a.f, Hl = a.Hl, Wl = a.Wl;
+  const int Wh = Wl * f;
+  const int64_t hwh = (int64_t)Hl * f * Wh;
+  const int64_t tot = (int64_t)a.planes * Hl * Wl;
+  for (int64_t e = (int64_t)blockIdx.x * CSN_BLOCK + threadIdx.x; e < tot; e += (int64_t)gridDim.x * CSN_BLOCK) {
+    const int64_t pl = e / (Hl * Wl);
+    const int r = (int)(e - pl * Hl * Wl);
+    const int yl = r / Wl, xl = r - yl * Wl;
+    const float* xp = a.x + pl * hwh + (int64_t)(yl * f) * Wh + xl * f;
+    float best = xp[0];
+    int bi = 0;
+    for (int dy = 0; dy < f; ++dy)
+      for (int dx = 0; dx < f; ++dx) {
+        const float v = xp[dy * Wh + dx];
+        if (v > best || v != v) { best = v; bi = dy * Wh + dx; }
+      }
+    a.dx[pl * hwh + (int64_t)(yl * f) * Wh + xl * f + bi] += a.t[e];
+  }
+}
+
+// dst[0] = sum in[0..n)   (cls bias gradient; single block, fixed order)
+__global__ __launch_bounds__(CSN_BLOCK) void sum_to_grad_kernel(const float* in, int64_t n, float* dst) {
+  CSN_DYN_SMEM(double, sm);
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += CSN_BLOCK) s += (double)in[i];
+  s = bn_block_sum(s, sm);
+  if (threadIdx.x == 0) dst[0] = (float)s;
+}
+
+// mean BCE-with-logits (train.py:209) and its gradient: loss = mean(max(y,0) - y*t + log1p(exp(-|y|))),
+// dy = (sigmoid(y) - t) / n.  Partial sums per block -> fp64 atomic (the loss value is a log line, the gradient exact).
+__global__ __launch_bounds__(CSN_BLOCK) void bce_logits_kernel(const float* y, const float* t, float* dy, int64_t n,
+                                                                double* loss) {
+  CSN_DYN_SMEM(double, sm);
+  double s = 0.0;
+  const float inv = 1.f / (float)n;
+  for (int64_t i = (int64_t)blockIdx.x * CSN_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CSN_BLOCK) {
+    const float v = y[i], tg = t[i];
+    const float e = expf(-fabsf(v));
+    s += (double)(fmaxf(v, 0.f) - v * tg + log1pf(e));
+    const float sig = v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    dy[i] = (sig - tg) * inv;
+  }
+  s = bn_block_sum(s, sm);
+  if (threadIdx.x == 0) {
+    const double term = s / (double)n;
+#ifdef CSN_CPU_EMU
+#pragma omp atomic
+    *loss += term;
+#else
+    atomicAdd(loss, term);
+#endif
+  }
+}
+
+// torch.optim.Adam step (L2 weight decay folded into the gradient, train.py:108-123) over the flat parameter arena;
+// wd[i] carries the per-parameter-group weight decay.
+__global__ __launch_bounds__(CSN_BLOCK) void adam_kernel(AdamArgs a) {
+  for (int64_t i = (int64_t)blockIdx.x * CSN_BLOCK + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * CSN_BLOCK) {
+    const float w = a.p[i];
+    const float g = a.g[i] + a.wd[i] * w;
+    const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
+    const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+    a.m[i] = m;
+    a.v[i] = v;
+    const float denom = sqrtf(v) / a.sqrt_bc2 + a.eps;
+    a.p[i] = w - a.step_size * (m / denom);
   }
 }
 
@@ -126,5 +366,44 @@ int csn_launch_bn_finalize(const BnFinalizeArgs& a, void* stream) {
 }
 int csn_launch_bn_apply(const BnApplyArgs& a, void* stream) {
   CSN_LAUNCH(bn_apply_gap_kernel, dim3(a.C, a.S), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
+  return (int)hipGetLastError();
+}
+
+static inline int grid_for(int64_t n) { return (int)((n + CSN_BLOCK - 1) / CSN_BLOCK < 4096 ? (n + CSN_BLOCK - 1) / CSN_BLOCK : 4096); }
+
+int csn_launch_bn_bwd(const BnBwdArgs& a, void* stream) {
+  CSN_LAUNCH(bn_bwd_reduce_kernel, dim3(BN_NSLAB, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
+  CSN_LAUNCH(bn_bwd_finalize_kernel, dim3((a.C + CSN_BLOCK - 1) / CSN_BLOCK), dim3(CSN_BLOCK), 0, stream, a);
+  CSN_LAUNCH(bn_bwd_apply_kernel, dim3(a.C, a.S), dim3(CSN_BLOCK), 0, stream, a);
+  return (int)hipGetLastError();
+}
+int csn_launch_dw_wgrad(const DwWgradArgs& a, void* stream) {
+  CSN_LAUNCH(dw_wgrad_kernel, dim3(BN_NSLAB, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
+  CSN_LAUNCH(dw_wgrad_finalize_kernel, dim3((a.C * 9 + CSN_BLOCK - 1) / CSN_BLOCK), dim3(CSN_BLOCK), 0, stream, a);
+  return (int)hipGetLastError();
+}
+int csn_launch_adjup(const AdjUpArgs& a, void* stream) {
+  CSN_LAUNCH(adjup_kernel, dim3(grid_for((int64_t)a.planes * a.Hl * a.Wl)), dim3(CSN_BLOCK), 0, stream, a);
+  return (int)hipGetLastError();
+}
+int csn_launch_avgpool2_bwd(const PoolBwdArgs& a, void* stream) {
+  CSN_LAUNCH(avgpool2_bwd_kernel, dim3(grid_for((int64_t)a.planes * a.Hl * a.Wl * 4)), dim3(CSN_BLOCK), 0, stream, a);
+  return (int)hipGetLastError();
+}
+int csn_launch_maxpool_bwd_add(const PoolBwdArgs& a, void* stream) {
+  CSN_LAUNCH(maxpool_bwd_add_kernel, dim3(grid_for((int64_t)a.planes * a.Hl * a.Wl)), dim3(CSN_BLOCK), 0, stream, a);
+  return (int)hipGetLastError();
+}
+int csn_launch_sum_to_grad(const float* in, int64_t n, float* dst, void* stream) {
+  CSN_LAUNCH(sum_to_grad_kernel, dim3(1), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, in, n, dst);
+  return (int)hipGetLastError();
+}
+int csn_launch_bce(const float* y, const float* t, float* dy, int64_t n, double* loss, void* stream) {
+  CSN_LAUNCH(bce_logits_kernel, dim3(grid_for(n) < 1024 ? grid_for(n) : 1024), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream,
+             y, t, dy, n, loss);
+  return (int)hipGetLastError();
+}
+int csn_launch_adam(const AdamArgs& a, void* stream) {
+  CSN_LAUNCH(adam_kernel, dim3(grid_for(a.n)), dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
 }

@@ -1,0 +1,203 @@
+// pw_gather.h -- per-lane gather of a channel slice into a wave's LDS panel x[k][64 px] (shared by the
+// forward contraction k_goct_pw.hip and the weight-gradient kernel k_wgrad.hip).  XP = panel row pitch.
+#pragma once
+#include "csn_kernels.h"
+
+#ifdef CSN_CPU_EMU
+struct csn_f4 {
+  float v[4];
+  float& operator[](int i) { return v[i]; }
+  float operator[](int i) const { return v[i]; }
+};
+// lanes of a wave run as sequential fibers: make LDS hand-offs inside a wave visible
+#define CSN_WAVE_SYNC() __syncthreads()
+#else
+typedef float csn_f4 __attribute__((ext_vector_type(4)));
+// a wave executes in lockstep and its LDS operations retire in order: only stop the compiler from
+// moving LDS accesses across the hand-off
+#define CSN_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+
+#define PW_KC 16   // channels per LDS panel
+#define PW_XP 80   // panel row pitch (floats): == 16 (mod 32), so the two k rows a 32-lane half reads hit disjoint banks
+#define PW_EP 68   // pitch of the epilogue transpose: rows 4 apart land on the other half of the banks
+
+typedef const CSN_CONST_AS PwPass* PwPassP;
+
+// Gather channels [c_lo, c_hi) of one slice for this lane's pixel into the panel rows starting at xrow
+// (`rmax` rows are left in the panel).  Loads go through a buffer resource whose base is channel c_lo of
+// image b (wave-uniform, SGPRs); the lane contributes one 32-bit byte offset, the channel a uniform SGPR
+// offset.  Every batch issues ALL its loads before the first use (fixed trip count, channel index clamped
+// instead of predicated: a predicated load would be waited for at the join), so a lane has 16-32 loads
+// in flight; rows written past the slice are overwritten by the next slice / the zero padding.
+template <int NB, int XP>
+__device__ __forceinline__ void pw_batch_own(csn_buf rb, unsigned lo, unsigned cs4, int k0, int n, int rmax,
+                                             float* xrow) {
+  float v[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) v[j] = csn_ld1(rb, lo, (unsigned)min(k0 + j, n - 1) * cs4);
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+    if (k0 + j < rmax) xrow[(k0 + j) * XP] = v[j];
+}
+
+template <int NB, int XP>
+__device__ __forceinline__ void pw_batch_pool2(csn_buf rb, unsigned lo, unsigned cs4, unsigned ws4, int k0, int n,
+                                               int rmax, float* xrow) {
+  float2 a0[NB], a1[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const unsigned so = (unsigned)min(k0 + j, n - 1) * cs4;
+    a0[j] = csn_ld2(rb, lo, so);
+    a1[j] = csn_ld2(rb, lo, so + ws4);
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+    if (k0 + j < rmax) xrow[(k0 + j) * XP] = fmaxf(fmaxf(a0[j].x, a0[j].y), fmaxf(a1[j].x, a1[j].y));
+}
+
+template <int NB, int XP>
+__device__ __forceinline__ void pw_batch_pool4(csn_buf rb, unsigned lo, unsigned cs4, unsigned ws4, int k0, int n,
+                                               int rmax, float* xrow) {
+  float4 q[NB][4];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const unsigned so = (unsigned)min(k0 + j, n - 1) * cs4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) q[j][r] = csn_ld4(rb, lo, so + r * ws4);
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    float m = -3.402823466e+38f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m = fmaxf(m, fmaxf(fmaxf(q[j][r].x, q[j][r].y), fmaxf(q[j][r].z, q[j][r].w)));
+    if (k0 + j < rmax) xrow[(k0 + j) * XP] = m;
+  }
+}
+
+template <int NB, int XP>
+__device__ __forceinline__ void pw_batch_up(csn_buf rb, unsigned o00, unsigned o01, unsigned o10, unsigned o11,
+                                            float w00, float w01, float w10, float w11, unsigned cs4, int k0, int n,
+                                            int rmax, float* xrow) {
+  float t0[NB], t1[NB], t2[NB], t3[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const unsigned so = (unsigned)min(k0 + j, n - 1) * cs4;
+    t0[j] = csn_ld1(rb, o00, so);
+    t1[j] = csn_ld1(rb, o01, so);
+    t2[j] = csn_ld1(rb, o10, so);
+    t3[j] = csn_ld1(rb, o11, so);
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+    if (k0 + j < rmax) xrow[(k0 + j) * XP] = w00 * t0[j] + w01 * t1[j] + w10 * t2[j] + w11 * t3[j];
+}
+
+// 3x3 taps of an own-resolution slice: gathered entry kk = 9*ch + t, t = 3*(dy+1) + (dx+1).  `vm` has
+// bit t set when tap t of this lane's pixel lies inside the image (zero padding otherwise).
+template <int NB, int XP>
+__device__ __forceinline__ void pw_batch_taps(csn_buf rb, unsigned lo, unsigned cs4, int Wr, int dil, unsigned vm,
+                                              int k_lo, int k0, int n, int rmax, float* xrow) {
+  float v[NB];
+  unsigned m[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int kk = k_lo + min(k0 + j, n - 1);
+    const int ch = kk / 9, t = kk - 9 * ch;
+    const int dy = t / 3 - 1, dx = t - 3 * (t / 3) - 1;
+    v[j] = csn_ld1(rb, lo + (unsigned)((dy * Wr + dx) * dil * 4), (unsigned)ch * cs4);
+    m[j] = (vm >> t) & 1u;
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+    if (k0 + j < rmax) xrow[(k0 + j) * XP] = m[j] ? v[j] : 0.f;
+}
+
+// 3x3 taps of a 2x2-max-pooled slice (source at twice the resolution).
+template <int NB, int XP>
+__device__ __forceinline__ void pw_batch_pool2_taps(csn_buf rb, unsigned lo, unsigned cs4, unsigned ws4, unsigned vm,
+                                                    int k_lo, int k0, int n, int rmax, float* xrow) {
+  float2 a0[NB], a1[NB];
+  unsigned m[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int kk = k_lo + min(k0 + j, n - 1);
+    const int ch = kk / 9, t = kk - 9 * ch;
+    const int dy = t / 3 - 1, dx = t - 3 * (t / 3) - 1;
+    const unsigned vo = lo + (unsigned)(2 * dy) * ws4 + (unsigned)(8 * dx);
+    a0[j] = csn_ld2(rb, vo, (unsigned)ch * cs4);
+    a1[j] = csn_ld2(rb, vo + ws4, (unsigned)ch * cs4);
+    m[j] = (vm >> t) & 1u;
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+    if (k0 + j < rmax)
+      xrow[(k0 + j) * XP] = m[j] ? fmaxf(fmaxf(a0[j].x, a0[j].y), fmaxf(a1[j].x, a1[j].y)) : 0.f;
+}
+
+__device__ __forceinline__ unsigned pw_tap_mask(int y, int x, int Hr, int Wr, int dil) {
+  unsigned vm = 0;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + (t / 3 - 1) * dil, xx = x + (t % 3 - 1) * dil;
+    vm |= (yy >= 0 && yy < Hr && xx >= 0 && xx < Wr) ? (1u << t) : 0u;
+  }
+  return vm;
+}
+
+template <int XP>
+__device__ __forceinline__ void pw_gather_slice(PwPassP ps, int s, int c_lo, int c_hi, float* xrow, int rmax, int b,
+                                                int y, int x, int Hr, int Wr) {
+  const int mode = ps->src[s].mode;
+  const int n = c_hi - c_lo;   // 1..16
+  if (mode == PW_OWN) {
+    const unsigned cs = (unsigned)(Hr * Wr);
+    const csn_buf rb = csn_make_buf(ps->src[s].ptr + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
+    const unsigned lo = (unsigned)(y * Wr + x) * 4u;
+    if (n <= 8) pw_batch_own<8, XP>(rb, lo, cs * 4u, 0, n, rmax, xrow);
+    else pw_batch_own<16, XP>(rb, lo, cs * 4u, 0, n, rmax, xrow);
+  } else if (mode == PW_POOL2) {
+    const unsigned Ws = (unsigned)Wr * 2u;
+    const unsigned cs = (unsigned)(Hr * 2) * Ws;
+    const csn_buf rb = csn_make_buf(ps->src[s].ptr + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
+    const unsigned lo = ((unsigned)(2 * y) * Ws + 2u * x) * 4u;
+    for (int k0 = 0; k0 < n; k0 += 8) pw_batch_pool2<8, XP>(rb, lo, cs * 4u, Ws * 4u, k0, n, rmax, xrow);
+  } else if (mode == PW_POOL4) {
+    const unsigned Ws = (unsigned)Wr * 4u;
+    const unsigned cs = (unsigned)(Hr * 4) * Ws;
+    const csn_buf rb = csn_make_buf(ps->src[s].ptr + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
+    const unsigned lo = ((unsigned)(4 * y) * Ws + 4u * x) * 4u;
+    for (int k0 = 0; k0 < n; k0 += 2) pw_batch_pool4<2, XP>(rb, lo, cs * 4u, Ws * 4u, k0, n, rmax, xrow);
+  } else if (mode == PW_TAPS) {
+    const unsigned cs = (unsigned)(Hr * Wr);
+    const int dil = ps->src[s].dil;
+    const csn_buf rb = csn_make_buf_n(ps->src[s].ptr + (int64_t)b * ps->src[s].Ctot * cs,
+                                      (unsigned)ps->src[s].Ctot * cs * 4u);
+    const unsigned lo = (unsigned)(y * Wr + x) * 4u;
+    const unsigned vm = pw_tap_mask(y, x, Hr, Wr, dil);
+    pw_batch_taps<16, XP>(rb, lo, cs * 4u, Wr, dil, vm, c_lo, 0, n, rmax, xrow);
+  } else if (mode == PW_POOL2_TAPS) {
+    const unsigned Ws = (unsigned)Wr * 2u;
+    const unsigned cs = (unsigned)(Hr * 2) * Ws;
+    const csn_buf rb = csn_make_buf_n(ps->src[s].ptr + (int64_t)b * ps->src[s].Ctot * cs,
+                                      (unsigned)ps->src[s].Ctot * cs * 4u);
+    const unsigned lo = ((unsigned)(2 * y) * Ws + 2u * x) * 4u;
+    const unsigned vm = pw_tap_mask(y, x, Hr, Wr, 1);
+    for (int k0 = 0; k0 < n; k0 += 8) pw_batch_pool2_taps<8, XP>(rb, lo, cs * 4u, Ws * 4u, vm, c_lo, k0, n, rmax, xrow);
+  } else {  // bilinear from a 2x / 4x coarser branch, align_corners=False
+    const int sh = mode == PW_UP2 ? 1 : 2;
+    const int Hs = Hr >> sh, Ws = Wr >> sh;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    csn_bilin(y, mode == PW_UP2 ? 0.5f : 0.25f, Hs, y0, y1, ly);
+    csn_bilin(x, mode == PW_UP2 ? 0.5f : 0.25f, Ws, x0, x1, lx);
+    const unsigned cs = (unsigned)(Hs * Ws);
+    const csn_buf rb = csn_make_buf(ps->src[s].ptr + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
+    const unsigned o00 = (unsigned)(y0 * Ws + x0) * 4u, o01 = (unsigned)(y0 * Ws + x1) * 4u,
+                   o10 = (unsigned)(y1 * Ws + x0) * 4u, o11 = (unsigned)(y1 * Ws + x1) * 4u;
+    const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+    for (int k0 = 0; k0 < n; k0 += 8)
+      pw_batch_up<8, XP>(rb, o00, o01, o10, o11, w00, w01, w10, w11, cs * 4u, k0, n, rmax, xrow);
+  }
+}
+

@@ -90,7 +90,7 @@ class Engine:
 
     def __init__(self, lib: C.CDLL, units: Sequence[N.UnitDesc], acts: Sequence[Tuple[int, int]],
                  B: int, H: int, W: int, device: torch.device, sub_batch: int = 0,
-                 unit_names: Optional[Sequence[str]] = None):
+                 unit_names: Optional[Sequence[str]] = None, train: bool = False):
         self.lib = lib
         self.B, self.H, self.W = B, H, W
         self.sub_batch = sub_batch
@@ -102,6 +102,9 @@ class Engine:
         N.check(lib, lib.csn_plan_create(ua, len(units), aa, len(acts), B, H, W, sub_batch, C.byref(plan)),
                 "csn_plan_create")
         self.plan = plan
+        self.train = bool(train)
+        if self.train:      # z / gradient / scratch buffers + backward weight images (before the workspace query)
+            N.check(lib, lib.csn_plan_enable_training(plan), "csn_plan_enable_training")
         self.n_units = len(units)
         self.n_acts = len(acts)
         nbytes = int(lib.csn_plan_workspace_bytes(plan))
@@ -146,6 +149,17 @@ class Engine:
                                                      arena.data_ptr(), arena.numel(), fw, penalty.data_ptr(),
                                                      self._stream()), "csn_forward_train")
         return y
+
+    def backward(self, x: torch.Tensor, dy: torch.Tensor, arena: torch.Tensor, grad: torch.Tensor, flop_w,
+                 pen_scale: float) -> None:
+        """Backward of the last ``forward_train``: writes every parameter gradient into ``grad`` (arena offsets)."""
+        assert self.train, "engine was created without training buffers"
+        assert dy.dtype == torch.float32 and dy.is_contiguous() and dy.numel() == self.B * self.H * self.W
+        assert grad.dtype == torch.float32 and grad.is_contiguous() and grad.device == arena.device
+        fw = (C.c_float * (self.n_units * N.MAX_BRANCH))(*[float(v) for v in flop_w])
+        N.check(self.lib, self.lib.csn_backward(self.plan, x.data_ptr(), dy.data_ptr(), self.workspace.data_ptr(),
+                                                arena.data_ptr(), grad.data_ptr(), grad.numel(), fw,
+                                                float(pen_scale), self._stream()), "csn_backward")
 
     def profile(self, x: torch.Tensor, iters: int = 10):
         """Mean milliseconds per unit (HIP events on the launch stream), kernel names, algorithmic bytes."""

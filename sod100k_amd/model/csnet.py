@@ -450,7 +450,7 @@ class CSNet(nn.Module):
             self._engines = {}
         return self._arena
 
-    def engine_for(self, x: torch.Tensor) -> Engine:
+    def engine_for(self, x: torch.Tensor, train: bool = False) -> Engine:
         arena = self._ensure_arena()
         if x.device != arena.flat.device:
             raise RuntimeError(f"input on {x.device} but model parameters on {arena.flat.device}")
@@ -460,14 +460,15 @@ class CSNet(nn.Module):
                 raise RuntimeError("sod100k_amd.CSNet runs on ROCm devices only (hand-written HIP kernels); "
                                    "move the model and the input to the GPU (`model.cuda()`, `x.cuda()`).")
             lib = N.load()
-        key = (tuple(x.shape), x.device)
+        key = (tuple(x.shape), x.device, bool(train))
         eng = self._engines.get(key)
         if eng is None:
             B, _, H, W = x.shape
             if H % 16 or W % 16:
                 raise ValueError("CSNet needs H and W to be multiples of 16 (cf. test.py:80-85)")
             units, acts, names = self.describe(arena.offsets)
-            eng = Engine(lib, units, acts, B, H, W, x.device, sub_batch=self._sub_batch, unit_names=names)
+            eng = Engine(lib, units, acts, B, H, W, x.device, sub_batch=0 if train else self._sub_batch,
+                         unit_names=names, train=train)
             self._engines[key] = eng
         return eng
 
@@ -500,34 +501,78 @@ class CSNet(nn.Module):
         return tab
 
     def _forward_train(self, x):
-        """Train-mode forward on the device: batch-statistics BN with running-stat update (csnet.py:764,825,138)
-        and, once flops_hook() has been called, the dynamic-weight-decay penalty (csnet.py:391-410) read back
-        through get_flops().  The result carries no autograd graph: backward kernels are a later round."""
-        eng = self.engine_for(x)
-        if eng.sub_batch not in (0, eng.B):
-            raise RuntimeError("train mode needs sub_batch == 0 (batch statistics span the whole batch)")
+        """Train-mode forward/backward on the device: batch-statistics BN with running-stat update
+        (csnet.py:764,825,138), the dynamic-weight-decay penalty (csnet.py:391-410, read back through
+        get_flops()) and, under autograd, the hand-written backward kernels (csn_backward)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            params = [p for p in self.parameters()]
+            y, pen = _CSNetTrainFn.apply(self, x, *params)
+        else:
+            y, pen = self._train_forward_raw(x, with_backward=False)
+            pen = pen.to(torch.float32)[0]
+        if self._penalty_cfg is not None:
+            # the reference spreads the sum over the ILBlock sub-modules' all_flops; get_flops() only ever reads
+            # the total, which is kept on the first hooked module
+            first = self.stage0[0].conv1x1
+            first.all_flops = first.all_flops + pen
+        return y
+
+    def _train_forward_raw(self, x, with_backward=True):
+        """(logits, fp64 device scalar penalty SUM) of one train-mode forward; keeps what csn_backward needs."""
+        eng = self.engine_for(x, train=with_backward)
         arena = self._arena
         eng.refresh(arena.flat)                       # weight blocks + PReLU tables; BN tables are rewritten per batch
         units, _, names = self._desc_cache(arena)
+        self._flop_tab = self._flop_weight_table(names, units)
         penalty = torch.zeros(1, dtype=torch.float64, device=x.device)
-        y = eng.forward_train(x, arena.flat, self._flop_weight_table(names, units), penalty)
+        y = eng.forward_train(x, arena.flat, self._flop_tab, penalty)
         with torch.no_grad():
             nbt = [m.num_batches_tracked for m in self.modules()
                    if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
             if nbt:
                 torch._foreach_add_(nbt, 1)
-        if self._penalty_cfg is not None:
-            # the reference spreads the sum over the ILBlock sub-modules' all_flops; get_flops() only ever reads
-            # the total, which is kept on the first hooked module
-            first = self.stage0[0].conv1x1
-            first.all_flops = first.all_flops + penalty.to(torch.float32)[0]
-        return y
+        return y, penalty
+
+    def _train_backward_raw(self, x, dy, pen_scale, grad=None):
+        """Parameter gradients of the last _train_forward_raw call into a flat tensor (arena offsets)."""
+        arena = self._arena
+        eng = self.engine_for(x, train=True)
+        if grad is None:
+            grad = torch.zeros(arena.n_param_floats, dtype=torch.float32, device=x.device)
+        eng.backward(x.contiguous(), dy.contiguous(), arena.flat, grad, self._flop_tab, pen_scale)
+        return grad
 
     def _desc_cache(self, arena):
         key = id(arena)
         if getattr(self, "_desc", None) is None or self._desc[0] != key:
             self._desc = (key, self.describe(arena.offsets))
         return self._desc[1]
+
+
+class _CSNetTrainFn(torch.autograd.Function):
+    """autograd seam of the train-mode forward: outputs (logits, penalty sum); backward runs csn_backward and hands
+    every parameter its slice of the flat gradient (callers keep `loss.backward(); optimizer.step()`, train.py:211-214)."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        y, pen = model._train_forward_raw(x, with_backward=True)
+        ctx.model, ctx.x = model, x
+        ctx.mark_non_differentiable()
+        return y, pen.to(torch.float32)[0]
+
+    @staticmethod
+    def backward(ctx, dy, dpen):
+        model = ctx.model
+        pen_scale = float(dpen) if dpen is not None else 0.0
+        if dy is None:
+            dy = torch.zeros((ctx.x.shape[0], 1) + tuple(ctx.x.shape[2:]), dtype=torch.float32, device=ctx.x.device)
+        flat = model._train_backward_raw(ctx.x, dy, pen_scale)
+        offs = model._arena.offsets
+        grads = []
+        for name, p in model.named_parameters():
+            o = offs[name]
+            grads.append(flat[o:o + p.numel()].view(p.shape) if p.requires_grad else None)
+        return (None, None) + tuple(grads)
 
 
 # ---- dynamic weight decay hook (csnet.py:391-410) -----------------------------------------------------------

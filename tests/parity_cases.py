@@ -284,3 +284,53 @@ def check_train_golden(lib, device, manifest, idx):
         s = float(got[n].double().sum())
         assert abs(s - v["sum"]) <= 1e-5 * max(abs(v["sum"]), 1.0), (n, s, v["sum"])
     return pen
+
+
+# ---------------------------------------------------------------------------------------------------
+# train step: hand-written backward kernels vs autograd through the oracle
+# ---------------------------------------------------------------------------------------------------
+def bce_and_grad(lib, y, t):
+    """csn_bce_with_logits through the C ABI: (fp64 device scalar mean loss, dy)."""
+    dy = torch.empty_like(y)
+    loss = torch.zeros(1, dtype=torch.float64, device=y.device)
+    stream = torch.cuda.current_stream(y.device).cuda_stream if y.is_cuda else 0
+    N.check(lib, lib.csn_bce_with_logits(y.data_ptr(), t.data_ptr(), dy.data_ptr(), y.numel(), loss.data_ptr(), stream),
+            "csn_bce_with_logits")
+    return loss, dy
+
+
+def grad_errors(model, flat, ref_grads):
+    """Per-parameter relative L2 error of the flat gradient arena against a dict of reference gradients."""
+    offs = model._arena.offsets
+    out = {}
+    for name, p in model.named_parameters():
+        g = flat[offs[name]:offs[name] + p.numel()].view(p.shape).detach().cpu().double()
+        r = ref_grads[name].double()
+        out[name] = (float((g - r).norm()), float(r.norm()))
+    return out
+
+
+def check_train_step(lib, device, manifest, B=2, size=32, expandflop=1.0, flops_weight=3.0, seed=10, rel=2e-3):
+    m, sd = make_model(lib, manifest, device)
+    m.train()
+    m.set_batchsize(B)
+    m.clear_flops()
+    m.flops_hook(expandflop)
+    x = torch.from_numpy(I.randn_batch(seed, B, size, size))
+    t = torch.from_numpy(I.binary_target(seed + 1, B, size, size))
+    xd, td = x.to(device), t.to(device)
+    y, pen = m._train_forward_raw(xd)
+    loss, dy = bce_and_grad(m._lib or N.load(), y, td)
+    flat = m._train_backward_raw(xd, dy, flops_weight / B)
+
+    cfg = O.load_layer_config_json(manifest)
+    sd_ref = {k: v.clone() for k, v in sd.items()}
+    r = O.train_step(cfg, sd_ref, x, t, expandflop=expandflop, flops_weight=flops_weight, batchsize=B, lr=0.0, wd=0.0)
+    assert abs(float(loss) - r["loss_bce"]) <= 1e-5 * max(1.0, abs(r["loss_bce"])), (float(loss), r["loss_bce"])
+    assert abs(float(pen) / B - r["penalty"]) <= 1e-5 * max(1.0, abs(r["penalty"])), (float(pen) / B, r["penalty"])
+    errs = grad_errors(m, flat, r["grads"])
+    gmax = max(n for _, n in errs.values())
+    bad = {k: (e, n) for k, (e, n) in errs.items() if e > rel * n + 1e-6 * gmax}
+    assert not bad, f"{len(bad)} of {len(errs)} gradients off, e.g. {list(bad.items())[:6]}"
+    worst = max(e / (n + 1e-6 * gmax) for e, n in errs.values())
+    return worst, float(loss), float(pen) / B

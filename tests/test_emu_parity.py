@@ -58,3 +58,9 @@ def test_emu_train_forward_vs_oracle(emu_lib, x2_manifest):
 
 def test_emu_train_forward_expandflop1_x1(emu_lib, x1_manifest):
     P.check_train_forward(emu_lib, CPU, x1_manifest, B=2, size=32, expandflop=1.0, seed=3)
+
+
+def test_emu_train_step_gradients(emu_lib, x2_manifest):
+    """Every parameter gradient of one train step (BCE + dynamic weight decay) vs autograd through the oracle."""
+    worst, loss, pen = P.check_train_step(emu_lib, CPU, x2_manifest, B=2, size=32)
+    print("worst relative gradient error", worst)
