@@ -5,9 +5,20 @@ the training copy adds PRUNE / AUTO / FINETUNE, CSNet_training/configs/defaults.
 file over it with ``cfg.merge_from_file`` (test.py:23-25).  yacs is not a dependency here: ``CfgNode`` below
 keeps the same surface (attribute access, ``merge_from_file``, unknown keys raise ``KeyError`` like yacs).
 """
+import ast
 import copy
 
 import yaml
+
+
+def _decode(v):
+    """yacs' _decode_cfg_value: strings that are Python literals become the literal (PyYAML reads `1e-4` as str)."""
+    if not isinstance(v, str):
+        return v
+    try:
+        return ast.literal_eval(v)
+    except (ValueError, SyntaxError):
+        return v
 
 
 class CfgNode(dict):
@@ -37,7 +48,7 @@ class CfgNode(dict):
                     raise ValueError(f"{path + k} must be a mapping")
                 self[k]._merge(v, path + k + ".")
             else:
-                self[k] = v
+                self[k] = _decode(v)
 
     def merge_from_file(self, filename):
         with open(filename) as f:
@@ -51,7 +62,7 @@ class CfgNode(dict):
                 node = node[p]
             if parts[-1] not in node:
                 raise KeyError(f"Non-existent config key: {key}")
-            node[parts[-1]] = val
+            node[parts[-1]] = _decode(val)
 
 
 def defaults() -> CfgNode:

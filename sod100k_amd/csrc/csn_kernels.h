@@ -181,6 +181,7 @@ struct BnFinalizeArgs {
   int64_t off_weight, off_bias, off_rmean, off_rvar;
   int64_t count;      // S * HW
   int32_t C;
+  int32_t nslab;      // set by the launcher
 };
 struct BnApplyArgs {
   const float* z;     // raw conv output (kept for the backward pass)
@@ -219,6 +220,7 @@ struct BnBwdArgs {
   int32_t S, C;
   float flop_w;        // Oct_bn_hook branch weight (0: not hooked)
   float pen_scale;     // d loss / d (penalty sum) = FLOPS.WEIGHT / batchsize  (train.py:91,210)
+  int32_t nslab;       // set by the launcher
 };
 int csn_launch_bn_bwd(const BnBwdArgs& a, void* stream);
 
@@ -229,6 +231,7 @@ struct DwWgradArgs {
   float* grad;
   int64_t off_w;
   int32_t C, S, H, W;
+  int32_t nslab;       // set by the launcher
 };
 int csn_launch_dw_wgrad(const DwWgradArgs& a, void* stream);
 

@@ -15,7 +15,13 @@
 //   bn_apply_gap_kernel y = PReLU(z*scale + shift) in place (float4 stream), per-(n,c) plane sum -> penalty.
 #include "csn_kernels.h"
 
-#define BN_NSLAB 32   // slabs per channel for the statistics partials
+#define BN_NSLAB CSN_BN_NSLAB   // max slabs per channel; a launch uses gridDim.x <= BN_NSLAB of them
+
+// slabs for n elements per channel: about 8K elements each, at most BN_NSLAB
+static inline int bn_nslab(int64_t n) {
+  const int64_t k = (n + 8191) / 8192;
+  return (int)(k < 1 ? 1 : (k > BN_NSLAB ? BN_NSLAB : k));
+}
 
 __device__ __forceinline__ double bn_block_sum(double v, double* sm) {
   const int tid = threadIdx.x;
@@ -35,7 +41,8 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_stats_kernel(BnStatsArgs a) {
   CSN_DYN_SMEM(double, sm);
   const int c = blockIdx.y, slab = blockIdx.x;
   const int64_t hw = a.HW;
-  const int64_t per = ((int64_t)a.S * hw + BN_NSLAB - 1) / BN_NSLAB;
+  const int nslab = gridDim.x;
+  const int64_t per = ((int64_t)a.S * hw + nslab - 1) / nslab;
   const int64_t beg = (int64_t)slab * per;
   const int64_t end = min(beg + per, (int64_t)a.S * hw);
   double s1 = 0.0, s2 = 0.0;
@@ -58,7 +65,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_finalize_kernel(BnFinalizeArgs a
   const int c = blockIdx.x * CSN_BLOCK + threadIdx.x;
   if (c >= a.C) return;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < BN_NSLAB; ++k) {
+  for (int k = 0; k < a.nslab; ++k) {
     s1 += a.partial[((int64_t)c * BN_NSLAB + k) * 2 + 0];
     s2 += a.partial[((int64_t)c * BN_NSLAB + k) * 2 + 1];
   }
@@ -138,7 +145,8 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_reduce_kernel(BnBwdArgs a) {
   CSN_DYN_SMEM(double, sm);
   const int c = blockIdx.y, slab = blockIdx.x;
   const int64_t hw = a.HW;
-  const int64_t per = ((int64_t)a.S * hw + BN_NSLAB - 1) / BN_NSLAB;
+  const int nslab = gridDim.x;
+  const int64_t per = ((int64_t)a.S * hw + nslab - 1) / nslab;
   const int64_t beg = (int64_t)slab * per;
   const int64_t end = min(beg + per, (int64_t)a.S * hw);
   const float sc = a.scale[c], sh = a.shift[c], al = a.alpha[c], mu = a.mean[c], is = a.invstd[c];
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_finalize_kernel(BnBwdArgs a)
   const int c = blockIdx.x * CSN_BLOCK + threadIdx.x;
   if (c >= a.C) return;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < BN_NSLAB; ++k) {
+  for (int k = 0; k < a.nslab; ++k) {
     const double* o = a.partial + ((int64_t)c * BN_NSLAB + k) * 3;
     s0 += o[0]; s1 += o[1]; s2 += o[2];
   }
@@ -207,7 +215,8 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw_wgrad_kernel(DwWgradArgs a) {
   const int c = blockIdx.y, slab = blockIdx.x;
   const int H = a.H, W = a.W;
   const int64_t hw = (int64_t)H * W;
-  const int64_t per = ((int64_t)a.S * hw + BN_NSLAB - 1) / BN_NSLAB;
+  const int nslab = gridDim.x;
+  const int64_t per = ((int64_t)a.S * hw + nslab - 1) / nslab;
   const int64_t beg = (int64_t)slab * per;
   const int64_t end = min(beg + per, (int64_t)a.S * hw);
   double s[9];
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw_wgrad_finalize_kernel(DwWgradArg
   if (e >= a.C * 9) return;
   const int c = e / 9, t = e - 9 * c;
   double s = 0.0;
-  for (int k = 0; k < BN_NSLAB; ++k) s += a.partial[((int64_t)c * BN_NSLAB + k) * 9 + t];
+  for (int k = 0; k < a.nslab; ++k) s += a.partial[((int64_t)c * BN_NSLAB + k) * 9 + t];
   a.grad[a.off_w + e] = (float)(100.0 * s);
 }
 
@@ -357,10 +366,12 @@ __global__ __launch_bounds__(CSN_BLOCK) void adam_kernel(AdamArgs a) {
 }
 
 int csn_launch_bn_stats(const BnStatsArgs& a, void* stream) {
-  CSN_LAUNCH(bn_stats_kernel, dim3(BN_NSLAB, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
+  CSN_LAUNCH(bn_stats_kernel, dim3(bn_nslab((int64_t)a.S * a.HW), a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   return (int)hipGetLastError();
 }
-int csn_launch_bn_finalize(const BnFinalizeArgs& a, void* stream) {
+int csn_launch_bn_finalize(const BnFinalizeArgs& a0, void* stream) {
+  BnFinalizeArgs a = a0;
+  a.nslab = bn_nslab(a.count);
   CSN_LAUNCH(bn_finalize_kernel, dim3((a.C + CSN_BLOCK - 1) / CSN_BLOCK), dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
 }
@@ -371,14 +382,18 @@ int csn_launch_bn_apply(const BnApplyArgs& a, void* stream) {
 
 static inline int grid_for(int64_t n) { return (int)((n + CSN_BLOCK - 1) / CSN_BLOCK < 4096 ? (n + CSN_BLOCK - 1) / CSN_BLOCK : 4096); }
 
-int csn_launch_bn_bwd(const BnBwdArgs& a, void* stream) {
-  CSN_LAUNCH(bn_bwd_reduce_kernel, dim3(BN_NSLAB, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
+int csn_launch_bn_bwd(const BnBwdArgs& a0, void* stream) {
+  BnBwdArgs a = a0;
+  a.nslab = bn_nslab((int64_t)a.S * a.HW);
+  CSN_LAUNCH(bn_bwd_reduce_kernel, dim3(a.nslab, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   CSN_LAUNCH(bn_bwd_finalize_kernel, dim3((a.C + CSN_BLOCK - 1) / CSN_BLOCK), dim3(CSN_BLOCK), 0, stream, a);
   CSN_LAUNCH(bn_bwd_apply_kernel, dim3(a.C, a.S), dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
 }
-int csn_launch_dw_wgrad(const DwWgradArgs& a, void* stream) {
-  CSN_LAUNCH(dw_wgrad_kernel, dim3(BN_NSLAB, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
+int csn_launch_dw_wgrad(const DwWgradArgs& a0, void* stream) {
+  DwWgradArgs a = a0;
+  a.nslab = bn_nslab((int64_t)a.S * a.H * a.W);
+  CSN_LAUNCH(dw_wgrad_kernel, dim3(a.nslab, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   CSN_LAUNCH(dw_wgrad_finalize_kernel, dim3((a.C * 9 + CSN_BLOCK - 1) / CSN_BLOCK), dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
 }

@@ -64,3 +64,7 @@ def test_emu_train_step_gradients(emu_lib, x2_manifest):
     """Every parameter gradient of one train step (BCE + dynamic weight decay) vs autograd through the oracle."""
     worst, loss, pen = P.check_train_step(emu_lib, CPU, x2_manifest, B=2, size=32)
     print("worst relative gradient error", worst)
+
+
+def test_emu_autograd_seam(emu_lib, x2_manifest):
+    P.check_autograd_seam(emu_lib, CPU, x2_manifest, B=2, size=16)

@@ -107,3 +107,22 @@ def test_gpu_train_forward_golden(hip, x2_manifest, idx):
     """G5: penalty + BN buffers after the reference's own train-mode forward (expandflop 1 and default 2)."""
     lib, dev = hip
     P.check_train_golden(lib, dev, x2_manifest, idx)
+
+
+def test_gpu_train_step_gradients(hip, x2_manifest):
+    """All 419 parameter gradients of one train step vs autograd through the oracle."""
+    lib, dev = hip
+    worst, loss, pen = P.check_train_step(lib, dev, x2_manifest, B=4, size=96)
+    print(f"worst relative gradient error {worst:.2e}; bce {loss:.6f}; penalty {pen:.6f}")
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_gpu_train_step_golden(hip, x2_manifest, idx):
+    """G5: the reference's own train step (grad norms, parameters after Adam, BN buffers)."""
+    lib, dev = hip
+    print("worst grad-norm deviation", P.check_train_golden_step(lib, dev, x2_manifest, idx))
+
+
+def test_gpu_autograd_seam(hip, x2_manifest):
+    lib, dev = hip
+    P.check_autograd_seam(lib, dev, x2_manifest, B=2, size=64)
