@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--sub-batch", type=int, default=int(os.environ.get("CSN_SUB_BATCH", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=5)
+    ap.add_argument("--train-steps", type=int, default=10,
+                    help="also time this many full train steps (0 = skip); reported under \"train_step\"")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -131,6 +133,33 @@ def main():
                                         alg_GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None)
                                 for k, v in agg.items() if "ms" in v})
 
+    sub_b = eng_sub(eng, B)
+    # ---- second data point: the full train step (fwd train-mode + BCE + backward + gradient all-reduce + Adam) ----
+    train = None
+    if args.train_steps > 0:
+        from sod100k_amd.tools.train import FusedTrainer
+        del eng, y
+        model._engines = {}
+        torch.cuda.empty_cache()
+        model.train()
+        model.flops_hook(1.0)                       # csnet-L-x2_train.yml: FLOPS.EXPAND 1.0, WEIGHT 3.0
+        model.set_batchsize(B)
+        tr = FusedTrainer(model, lr=1e-4, weight_decay=5e-3, flops_weight=3.0, batchsize=B)
+        tgt = (torch.rand(B, 1, 224, 224, generator=g) > 0.5).float().to(dev)
+
+        def tstep():
+            tr.step(x, tgt, world_size=world)
+
+        for _ in range(3):
+            tstep()
+        tdt = D.timed_region(tstep, args.train_steps, sync=lambda: torch.cuda.synchronize(dev), device=dev)
+        train = {"value": round(world * B * args.train_steps / tdt, 1), "unit": "images/sec",
+                 "ms_per_step": round(tdt / args.train_steps * 1e3, 3), "steps": args.train_steps,
+                 "batch_per_gpu": B, "dtype": "f32",
+                 "what": "train-mode forward (batch-stat BN + penalty) + BCE + backward + "
+                         + ("RCCL all-reduce of the flat gradient + " if world > 1 else "") + "Adam, csnet-L-x2 weights"}
+        model.eval()
+
     if rank == 0:
         value = world * B * args.steps / dt
         out = {
@@ -140,11 +169,13 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "CSNet-100K (csnet-L-x2 shipped checkpoint) fp32 eval forward, "
                                    f"batch {B} x 3x224x224 per GPU, inputs resident in HBM",
-                       "batch_per_gpu": B, "global_batch": B * world, "sub_batch": eng_sub(eng, B),
+                       "batch_per_gpu": B, "global_batch": B * world, "sub_batch": sub_b,
                        "parallelism": f"image shards x{world}, no data-path collective",
                        "algorithmic_bytes_per_image": int(total_alg // B)},
             "roofline": roofline,
         }
+        if train is not None:
+            out["train_step"] = train
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(man)
         print(json.dumps(out))

@@ -301,9 +301,9 @@ int run_wgrad(const BwdCtx& b, const WgPlan& w, const PwBind& bd) {
   a.a_ctot = w.a_ctot;
   a.gpp = (int)((hw + 63) / 64);
   a.ngroups = a.gpp * P.S;
-  a.nblk = a.ngroups < WG_MAX_BLOCKS ? a.ngroups : WG_MAX_BLOCKS;
   a.rows16 = (pp.nrows + 15) & ~15;
   a.k16 = (pp.K + 15) & ~15;
+  a.nblk = csn_wgrad_blocks(a.rows16, a.k16, a.ngroups);
   a.partial = reinterpret_cast<float*>(b.c.ws + P.wg_off);
   LAUNCH_TRY(csn_launch_wgrad(a, b.c.stream));
   WgReduceArgs r;

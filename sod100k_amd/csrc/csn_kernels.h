@@ -159,17 +159,19 @@ struct WgReduceArgs {
   int32_t nblocks, nblk, nrows, K, rows16, k16;
 };
 int csn_launch_wgrad(const WgArgs& a, void* stream);
+int csn_wgrad_blocks(int rows16, int k16, int ngroups);   // partial slices (= blocks) the launch will use
 int csn_launch_wgrad_reduce(const WgReduceArgs& a, void* stream);
 
 // ---------------------------------------------------------------------------------------------
 // train-mode BatchNorm + PReLU + GAP penalty (see k_train.hip)
 // ---------------------------------------------------------------------------------------------
-#define CSN_BN_NSLAB 32
+#define CSN_BN_NSLAB 1024
 struct BnStatsArgs {
   const float* z;     // [S][C][HW] raw conv output
   double* partial;    // [C][CSN_BN_NSLAB][2]
   int32_t S, C;
   int64_t HW;
+  int32_t cpp;        // chunks per plane, set by the launcher
 };
 struct BnFinalizeArgs {
   const double* partial;
@@ -181,6 +183,7 @@ struct BnFinalizeArgs {
   int64_t off_weight, off_bias, off_rmean, off_rvar;
   int64_t count;      // S * HW
   int32_t C;
+  int32_t S;
   int32_t nslab;      // set by the launcher
 };
 struct BnApplyArgs {
@@ -220,7 +223,7 @@ struct BnBwdArgs {
   int32_t S, C;
   float flop_w;        // Oct_bn_hook branch weight (0: not hooked)
   float pen_scale;     // d loss / d (penalty sum) = FLOPS.WEIGHT / batchsize  (train.py:91,210)
-  int32_t nslab;       // set by the launcher
+  int32_t nslab, cpp;  // set by the launcher
 };
 int csn_launch_bn_bwd(const BnBwdArgs& a, void* stream);
 
@@ -231,7 +234,7 @@ struct DwWgradArgs {
   float* grad;
   int64_t off_w;
   int32_t C, S, H, W;
-  int32_t nslab;       // set by the launcher
+  int32_t nslab, cpp;  // set by the launcher
 };
 int csn_launch_dw_wgrad(const DwWgradArgs& a, void* stream);
 

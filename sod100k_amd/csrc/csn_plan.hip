@@ -972,7 +972,7 @@ int csn_forward_train(csn_plan* P, const float* x, float* y, void* workspace, fl
       BnFinalizeArgs fa; fa.partial = part; fa.arena = arena;
       fa.scale = P->packed + up.out_epi[j].scale; fa.shift = P->packed + up.out_epi[j].shift;
       fa.off_weight = d.bn[j].weight; fa.off_bias = d.bn[j].bias; fa.off_rmean = d.bn[j].running_mean;
-      fa.off_rvar = d.bn[j].running_var; fa.count = (int64_t)P->S * hw; fa.C = d.cout[j];
+      fa.off_rvar = d.bn[j].running_var; fa.count = (int64_t)P->S * hw; fa.C = d.cout[j]; fa.S = P->S;
       // backward needs the batch mean / invstd; without training buffers they land in a dummy slot of the tables
       fa.mean = P->packed + (P->train ? up.tr_mean[j] : P->ident.dummy);
       fa.invstd = P->packed + (P->train ? up.tr_invstd[j] : P->ident.dummy);

@@ -17,14 +17,31 @@
 
 #define BN_NSLAB CSN_BN_NSLAB   // max slabs per channel; a launch uses gridDim.x <= BN_NSLAB of them
 
-// slabs for n elements per channel: about 8K elements each, at most BN_NSLAB
-static inline int bn_nslab(int64_t n) {
-  const int64_t k = (n + 8191) / 8192;
-  return (int)(k < 1 ? 1 : (k > BN_NSLAB ? BN_NSLAB : k));
+// A channel's S*HW elements are S contiguous planes; a slab is one chunk of one plane (cpp chunks per plane), so a
+// block streams contiguous memory and never divides: slab = n*cpp + chunk.  About 8K elements per slab.
+static inline int bn_cpp(int S, int64_t hw) {
+  int64_t cpp = (hw + 8191) / 8192;
+  if (cpp < 1) cpp = 1;
+  while (cpp > 1 && cpp * S > BN_NSLAB) --cpp;
+  return (int)cpp;
+}
+
+struct BnRange { int64_t base; int beg, end; };   // element range [beg, end) of the plane at `base`
+
+__device__ __forceinline__ BnRange bn_range(int slab, int cpp, int C, int c, int64_t hw) {
+  const int n = slab / cpp, ch = slab - n * cpp;
+  int per = (int)((hw + cpp - 1) / cpp);
+  per = (per + 3) & ~3;   // chunks start on a float4 boundary
+  BnRange r;
+  r.base = ((int64_t)n * C + c) * hw;
+  r.beg = min(ch * per, (int)hw);
+  r.end = min(r.beg + per, (int)hw);
+  return r;
 }
 
 __device__ __forceinline__ double bn_block_sum(double v, double* sm) {
   const int tid = threadIdx.x;
+#ifdef CSN_CPU_EMU
   sm[tid] = v;
   __syncthreads();
   for (int s = CSN_BLOCK / 2; s > 0; s >>= 1) {
@@ -34,23 +51,37 @@ __device__ __forceinline__ double bn_block_sum(double v, double* sm) {
   const double r = sm[0];
   __syncthreads();
   return r;
+#else
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);   // butterfly inside the wave, fixed order
+  if ((tid & 63) == 0) sm[tid >> 6] = v;
+  __syncthreads();
+  const double r = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+  __syncthreads();
+  return r;
+#endif
 }
 
-// grid (BN_NSLAB, C): block (slab, c) reduces its share of the S*HW elements of channel c.
+// grid (nslab, C): block (slab, c) reduces one chunk of one plane of channel c.
 __global__ __launch_bounds__(CSN_BLOCK) void bn_stats_kernel(BnStatsArgs a) {
   CSN_DYN_SMEM(double, sm);
   const int c = blockIdx.y, slab = blockIdx.x;
-  const int64_t hw = a.HW;
-  const int nslab = gridDim.x;
-  const int64_t per = ((int64_t)a.S * hw + nslab - 1) / nslab;
-  const int64_t beg = (int64_t)slab * per;
-  const int64_t end = min(beg + per, (int64_t)a.S * hw);
+  const BnRange r = bn_range(slab, a.cpp, a.C, c, a.HW);
+  const float* __restrict__ p = a.z + r.base;
   double s1 = 0.0, s2 = 0.0;
-  for (int64_t i = beg + threadIdx.x; i < end; i += CSN_BLOCK) {
-    const int64_t n = i / hw, p = i - n * hw;
-    const double v = (double)a.z[(n * a.C + c) * hw + p];
-    s1 += v;
-    s2 += v * v;
+  if ((a.HW & 3) == 0) {
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    for (int i = (r.beg >> 2) + threadIdx.x; i < (r.end >> 2); i += CSN_BLOCK) {
+      const float4 v = p4[i];
+      s1 += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+      s2 += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+    }
+  } else {
+    for (int i = r.beg + threadIdx.x; i < r.end; i += CSN_BLOCK) {
+      const double v = (double)p[i];
+      s1 += v;
+      s2 += v * v;
+    }
   }
   s1 = bn_block_sum(s1, sm);
   s2 = bn_block_sum(s2, sm);
@@ -60,15 +91,18 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_stats_kernel(BnStatsArgs a) {
   }
 }
 
-// one thread per channel
+// one block per channel: the slab partials are summed by the block (fixed order), thread 0 finishes
 __global__ __launch_bounds__(CSN_BLOCK) void bn_finalize_kernel(BnFinalizeArgs a) {
-  const int c = blockIdx.x * CSN_BLOCK + threadIdx.x;
-  if (c >= a.C) return;
+  CSN_DYN_SMEM(double, sm);
+  const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < a.nslab; ++k) {
+  for (int k = threadIdx.x; k < a.nslab; k += CSN_BLOCK) {
     s1 += a.partial[((int64_t)c * BN_NSLAB + k) * 2 + 0];
     s2 += a.partial[((int64_t)c * BN_NSLAB + k) * 2 + 1];
   }
+  s1 = bn_block_sum(s1, sm);
+  s2 = bn_block_sum(s2, sm);
+  if (threadIdx.x != 0) return;
   const double n = (double)a.count;
   const double mean = s1 / n;
   double var = s2 / n - mean * mean;
@@ -144,16 +178,11 @@ __device__ __forceinline__ float bnb_dy(const BnBwdArgs& a, int64_t i) {
 __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_reduce_kernel(BnBwdArgs a) {
   CSN_DYN_SMEM(double, sm);
   const int c = blockIdx.y, slab = blockIdx.x;
-  const int64_t hw = a.HW;
-  const int nslab = gridDim.x;
-  const int64_t per = ((int64_t)a.S * hw + nslab - 1) / nslab;
-  const int64_t beg = (int64_t)slab * per;
-  const int64_t end = min(beg + per, (int64_t)a.S * hw);
+  const BnRange r = bn_range(slab, a.cpp, a.C, c, a.HW);
   const float sc = a.scale[c], sh = a.shift[c], al = a.alpha[c], mu = a.mean[c], is = a.invstd[c];
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  for (int64_t i = beg + threadIdx.x; i < end; i += CSN_BLOCK) {
-    const int64_t n = i / hw, p = i - n * hw;
-    const int64_t idx = (n * a.C + c) * hw + p;
+  for (int i = r.beg + threadIdx.x; i < r.end; i += CSN_BLOCK) {
+    const int64_t idx = r.base + i;
     const float z = a.z[idx], dy = bnb_dy(a, idx);
     const float bn = z * sc + sh;
     const float dbn = bn > 0.f ? dy : al * dy;
@@ -171,23 +200,29 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_reduce_kernel(BnBwdArgs a) {
 }
 
 __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_finalize_kernel(BnBwdArgs a) {
-  const int c = blockIdx.x * CSN_BLOCK + threadIdx.x;
-  if (c >= a.C) return;
+  CSN_DYN_SMEM(double, sm);
+  const int c = blockIdx.x;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < a.nslab; ++k) {
+  for (int k = threadIdx.x; k < a.nslab; k += CSN_BLOCK) {
     const double* o = a.partial + ((int64_t)c * BN_NSLAB + k) * 3;
     s0 += o[0]; s1 += o[1]; s2 += o[2];
   }
+  s0 = bn_block_sum(s0, sm);
+  s1 = bn_block_sum(s1, sm);
+  s2 = bn_block_sum(s2, sm);
+  double sg = 0.0;
+  const bool pen = a.flop_w != 0.f && a.gapabs;
+  if (pen) {
+    for (int k = threadIdx.x; k < a.S; k += CSN_BLOCK) sg += (double)a.gapabs[(int64_t)c * a.S + k];
+    sg = bn_block_sum(sg, sm);
+  }
+  if (threadIdx.x != 0) return;
   const double n = (double)a.S * (double)a.HW;
   a.m1m2[2 * c + 0] = (float)(s0 / n);
   a.m1m2[2 * c + 1] = (float)(s1 / n);
   const double gamma = (double)a.arena[a.off_weight + c];
   double dgamma = s1;
-  if (a.flop_w != 0.f && a.gapabs) {   // d/dgamma of pen_scale * 0.5 * w * sum_n |gap[n,c]| * gamma^2
-    double sg = 0.0;
-    for (int k = 0; k < a.S; ++k) sg += (double)a.gapabs[(int64_t)c * a.S + k];
-    dgamma += (double)a.pen_scale * (double)a.flop_w * sg * gamma;
-  }
+  if (pen) dgamma += (double)a.pen_scale * (double)a.flop_w * sg * gamma;   // d/dgamma of 0.5 w sum_n|gap| gamma^2
   a.grad[a.off_weight + c] = (float)dgamma;
   a.grad[a.off_bias + c] = (float)s0;
   a.grad[a.off_prelu + c] = (float)s2;
@@ -201,11 +236,23 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_apply_kernel(BnBwdArgs a) {
   const float sc = a.scale[c], sh = a.shift[c], al = a.alpha[c], mu = a.mean[c], is = a.invstd[c];
   const float m1 = a.m1m2[2 * c], m2 = a.m1m2[2 * c + 1];
   const float gi = a.arena[a.off_weight + c] * is;
-  for (int64_t i = threadIdx.x; i < hw; i += CSN_BLOCK) {
-    const float z = a.z[base + i], dy = bnb_dy(a, base + i);
+  auto f = [&](float z, float dy) {
     const float bn = z * sc + sh;
     const float dbn = bn > 0.f ? dy : al * dy;
-    a.z[base + i] = gi * (dbn - m1 - (z - mu) * is * m2);
+    return gi * (dbn - m1 - (z - mu) * is * m2);
+  };
+  if ((hw & 3) == 0) {
+    float4* z4 = reinterpret_cast<float4*>(a.z + base);
+    const float4* a4 = reinterpret_cast<const float4*>(a.dyA + base);
+    const float4* b4 = a.dyB ? reinterpret_cast<const float4*>(a.dyB + base) : nullptr;
+    for (int64_t i = threadIdx.x; i < (hw >> 2); i += CSN_BLOCK) {
+      float4 z = z4[i], d = a4[i];
+      if (b4) { const float4 e = b4[i]; d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
+      z.x = f(z.x, d.x); z.y = f(z.y, d.y); z.z = f(z.z, d.z); z.w = f(z.w, d.w);
+      z4[i] = z;
+    }
+  } else {
+    for (int64_t i = threadIdx.x; i < hw; i += CSN_BLOCK) a.z[base + i] = f(a.z[base + i], bnb_dy(a, base + i));
   }
 }
 
@@ -214,45 +261,51 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw_wgrad_kernel(DwWgradArgs a) {
   CSN_DYN_SMEM(double, sm);
   const int c = blockIdx.y, slab = blockIdx.x;
   const int H = a.H, W = a.W;
-  const int64_t hw = (int64_t)H * W;
-  const int nslab = gridDim.x;
-  const int64_t per = ((int64_t)a.S * hw + nslab - 1) / nslab;
-  const int64_t beg = (int64_t)slab * per;
-  const int64_t end = min(beg + per, (int64_t)a.S * hw);
-  double s[9];
+  const BnRange r = bn_range(slab, a.cpp, a.C, c, (int64_t)H * W);
+  const float* __restrict__ gp = a.dz + r.base;
+  const float* __restrict__ xp = a.x + r.base;
+  float s[9];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) s[t] = 0.0;
-  for (int64_t i = beg + threadIdx.x; i < end; i += CSN_BLOCK) {
-    const int64_t n = i / hw;
-    const int p = (int)(i - n * hw);
+  for (int t = 0; t < 9; ++t) s[t] = 0.f;
+  for (int p = r.beg + threadIdx.x; p < r.end; p += CSN_BLOCK) {   // <= 32 terms per lane: fp32 partials
     const int y = p / W, x = p - y * W;
-    const int64_t base = (n * a.C + c) * hw;
-    const float g = a.dz[base + p];
+    const float g = gp[p];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
       const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
-      const float v = a.x[base + (in ? yy * W + xx : p)];
-      s[t] += in ? (double)g * (double)v : 0.0;
+      const float v = xp[in ? yy * W + xx : p];
+      s[t] = fmaf(g, in ? v : 0.f, s[t]);
     }
   }
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
-    const double r = bn_block_sum(s[t], sm);
-    if (threadIdx.x == 0) a.partial[((int64_t)c * BN_NSLAB + slab) * 9 + t] = r;
+    const double rs = bn_block_sum((double)s[t], sm);
+    if (threadIdx.x == 0) a.partial[((int64_t)c * BN_NSLAB + slab) * 9 + t] = rs;
   }
 }
 
+// one block per channel
 __global__ __launch_bounds__(CSN_BLOCK) void dw_wgrad_finalize_kernel(DwWgradArgs a) {
-  const int e = blockIdx.x * CSN_BLOCK + threadIdx.x;
-  if (e >= a.C * 9) return;
-  const int c = e / 9, t = e - 9 * c;
-  double s = 0.0;
-  for (int k = 0; k < a.nslab; ++k) s += a.partial[((int64_t)c * BN_NSLAB + k) * 9 + t];
-  a.grad[a.off_w + e] = (float)(100.0 * s);
+  CSN_DYN_SMEM(double, sm);
+  const int c = blockIdx.x;
+  double s[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) s[t] = 0.0;
+  for (int k = threadIdx.x; k < a.nslab; k += CSN_BLOCK)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) s[t] += a.partial[((int64_t)c * BN_NSLAB + k) * 9 + t];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const double r = bn_block_sum(s[t], sm);
+    if (threadIdx.x == 0) a.grad[a.off_w + c * 9 + t] = (float)(100.0 * r);
+  }
 }
 
-// adjoint of F.interpolate(scale_factor=f, mode='bilinear', align_corners=False): out[lo] = sum_hi w(hi->lo) in[hi]
+// adjoint of F.interpolate(scale_factor=f, mode='bilinear', align_corners=False): out[lo] = sum_hi w(hi->lo) in[hi].
+// Source pixel s receives from the outputs o in [f*s - f/2, f*s + f + f/2 - 1] (2f candidates per axis, f = 2 or 4);
+// the weight of each candidate is read off the forward's own index computation (csn_bilin), so the border clamping
+// is the adjoint of exactly what the forward did.
 __global__ __launch_bounds__(CSN_BLOCK) void adjup_kernel(AdjUpArgs a) {
   const int Hl = a.Hl, Wl = a.Wl, f = a.f;
   const int Hh = Hl * f, Wh = Wl * f;
@@ -263,18 +316,29 @@ __global__ __launch_bounds__(CSN_BLOCK) void adjup_kernel(AdjUpArgs a) {
     const int r = (int)(e - pl * Hl * Wl);
     const int ys = r / Wl, xs = r - ys * Wl;
     const float* ip = a.in + pl * (int64_t)Hh * Wh;
+    float wx[8];
+    const int ox0 = xs * f - (f >> 1), oy0 = ys * f - (f >> 1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ox = ox0 + j;
+      int x0, x1; float lx;
+      csn_bilin(min(max(ox, 0), Wh - 1), inv, Wl, x0, x1, lx);
+      const float w = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
+      wx[j] = (j < 2 * f && ox >= 0 && ox < Wh) ? w : 0.f;
+    }
     float acc = 0.f;
-    for (int oy = max(ys * f - f, 0); oy < min(ys * f + 2 * f, Hh); ++oy) {
+    for (int i = 0; i < 2 * f; ++i) {
+      const int oy = oy0 + i;
+      if (oy < 0 || oy >= Hh) continue;
       int y0, y1; float ly;
       csn_bilin(oy, inv, Hl, y0, y1, ly);
       const float wy = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
-      if (wy == 0.f) continue;
-      for (int ox = max(xs * f - f, 0); ox < min(xs * f + 2 * f, Wh); ++ox) {
-        int x0, x1; float lx;
-        csn_bilin(ox, inv, Wl, x0, x1, lx);
-        const float wx = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
-        acc += wy * wx * ip[(int64_t)oy * Wh + ox];
-      }
+      const float* row = ip + (int64_t)oy * Wh;
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < 2 * f) t = fmaf(wx[j], row[min(max(ox0 + j, 0), Wh - 1)], t);
+      acc = fmaf(wy, t, acc);
     }
     a.out[e] = acc;
   }
@@ -365,14 +429,16 @@ __global__ __launch_bounds__(CSN_BLOCK) void adam_kernel(AdamArgs a) {
   }
 }
 
-int csn_launch_bn_stats(const BnStatsArgs& a, void* stream) {
-  CSN_LAUNCH(bn_stats_kernel, dim3(bn_nslab((int64_t)a.S * a.HW), a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
+int csn_launch_bn_stats(const BnStatsArgs& a0, void* stream) {
+  BnStatsArgs a = a0;
+  a.cpp = bn_cpp(a.S, a.HW);
+  CSN_LAUNCH(bn_stats_kernel, dim3(a.S * a.cpp, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   return (int)hipGetLastError();
 }
 int csn_launch_bn_finalize(const BnFinalizeArgs& a0, void* stream) {
   BnFinalizeArgs a = a0;
-  a.nslab = bn_nslab(a.count);
-  CSN_LAUNCH(bn_finalize_kernel, dim3((a.C + CSN_BLOCK - 1) / CSN_BLOCK), dim3(CSN_BLOCK), 0, stream, a);
+  a.nslab = a.S * bn_cpp(a.S, a.count / a.S);
+  CSN_LAUNCH(bn_finalize_kernel, dim3(a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   return (int)hipGetLastError();
 }
 int csn_launch_bn_apply(const BnApplyArgs& a, void* stream) {
@@ -384,17 +450,19 @@ static inline int grid_for(int64_t n) { return (int)((n + CSN_BLOCK - 1) / CSN_B
 
 int csn_launch_bn_bwd(const BnBwdArgs& a0, void* stream) {
   BnBwdArgs a = a0;
-  a.nslab = bn_nslab((int64_t)a.S * a.HW);
+  a.cpp = bn_cpp(a.S, a.HW);
+  a.nslab = a.S * a.cpp;
   CSN_LAUNCH(bn_bwd_reduce_kernel, dim3(a.nslab, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
-  CSN_LAUNCH(bn_bwd_finalize_kernel, dim3((a.C + CSN_BLOCK - 1) / CSN_BLOCK), dim3(CSN_BLOCK), 0, stream, a);
+  CSN_LAUNCH(bn_bwd_finalize_kernel, dim3(a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   CSN_LAUNCH(bn_bwd_apply_kernel, dim3(a.C, a.S), dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
 }
 int csn_launch_dw_wgrad(const DwWgradArgs& a0, void* stream) {
   DwWgradArgs a = a0;
-  a.nslab = bn_nslab((int64_t)a.S * a.H * a.W);
+  a.cpp = bn_cpp(a.S, (int64_t)a.H * a.W);
+  a.nslab = a.S * a.cpp;
   CSN_LAUNCH(dw_wgrad_kernel, dim3(a.nslab, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
-  CSN_LAUNCH(dw_wgrad_finalize_kernel, dim3((a.C * 9 + CSN_BLOCK - 1) / CSN_BLOCK), dim3(CSN_BLOCK), 0, stream, a);
+  CSN_LAUNCH(dw_wgrad_finalize_kernel, dim3(a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   return (int)hipGetLastError();
 }
 int csn_launch_adjup(const AdjUpArgs& a, void* stream) {

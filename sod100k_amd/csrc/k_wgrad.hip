@@ -24,7 +24,7 @@
 typedef const CSN_CONST_AS WgArgs* WgArgsP;
 
 template <int NT>
-__device__ __forceinline__ void wg_mma(const float* dzp, const float* xp, int lane, csn_f4 (&acc)[WG_MAX_NT]) {
+__device__ __forceinline__ void wg_mma(const float* dzp, const float* xp, int lane, csn_f4 (&acc)[NT]) {
 #ifdef CSN_CPU_EMU
   const int j = lane & 15;
   for (int s = 0; s < 16; ++s)
@@ -49,7 +49,15 @@ __device__ __forceinline__ void wg_mma(const float* dzp, const float* xp, int la
 #endif
 }
 
-__global__ __launch_bounds__(CSN_BLOCK) void goct_wgrad_kernel(WgArgs a_byval) {
+// Not inlined on purpose: hipcc otherwise keeps the address arithmetic of every gather mode of all three call
+// sites live at once (390 VGPRs, one wave per SIMD); as a call the kernel needs 125.
+__device__ __attribute__((noinline)) void wg_gather(PwPassP ps, int s, int c_lo, int c_hi, float* xrow, int rmax, int b,
+                                                   int y, int x, int Hr, int Wr) {
+  pw_gather_slice<WG_P>(ps, s, c_lo, c_hi, xrow, rmax, b, y, x, Hr, Wr);
+}
+
+template <int NT>
+__global__ __launch_bounds__(CSN_BLOCK, 3) void goct_wgrad_kernel(WgArgs a_byval) {
   CSN_DYN_SMEM(float, lds);
   WgArgsP a = CSN_KERNARG(WgArgs, a_byval);
   PwPassP ps = &a->ps;
@@ -61,14 +69,13 @@ __global__ __launch_bounds__(CSN_BLOCK) void goct_wgrad_kernel(WgArgs a_byval) {
   for (int i = tid; i < rows16 * WG_P; i += CSN_BLOCK) dzp[i] = 0.f;   // rows nrows..rows16 stay zero
   const int cin = ps->cin;
   const int c1 = ps->src[0].K, c2 = c1 + ps->src[1].K;
-  const int nt = rows16 >> 4;
   const int nsweep = (k16 / 16 + 3) >> 2;
   for (int sw = 0; sw < nsweep; ++sw) {
     const int kc = (4 * sw + wave) * 16;
     const bool active = kc < k16;
-    csn_f4 acc[WG_MAX_NT];
+    csn_f4 acc[NT];
 #pragma unroll
-    for (int t = 0; t < WG_MAX_NT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[t][i] = 0.f;
     for (int g = blockIdx.x; g < a->ngroups; g += a->nblk) {
@@ -89,63 +96,175 @@ __global__ __launch_bounds__(CSN_BLOCK) void goct_wgrad_kernel(WgArgs a_byval) {
       if (active) {
         const int kend = min(kc + 16, cin);
         CSN_WAVE_SYNC();
-        if (kc < c1) pw_gather_slice<WG_P>(ps, 0, kc, min(kend, c1), xp + lane, 16, b, y, x, Hr, Wr);
+        if (kc < c1) wg_gather(ps, 0, kc, min(kend, c1), xp + lane, 16, b, y, x, Hr, Wr);
         if (max(kc, c1) < min(kend, c2)) {
           const int r0 = max(kc, c1) - kc;
-          pw_gather_slice<WG_P>(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
+          wg_gather(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
         }
         if (max(kc, c2) < min(kend, cin)) {
           const int r0 = max(kc, c2) - kc;
-          pw_gather_slice<WG_P>(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
+          wg_gather(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
         }
         for (int k = max(cin, kc); k < kc + 16; ++k) xp[(k - kc) * WG_P + lane] = 0.f;
         CSN_WAVE_SYNC();
-        switch (nt) {
-          case 1: wg_mma<1>(dzp, xp, lane, acc); break;
-          case 2: wg_mma<2>(dzp, xp, lane, acc); break;
-          case 3: wg_mma<3>(dzp, xp, lane, acc); break;
-          case 4: wg_mma<4>(dzp, xp, lane, acc); break;
-          default: wg_mma<5>(dzp, xp, lane, acc); break;
-        }
+        wg_mma<NT>(dzp, xp, lane, acc);
       }
     }
     if (active) {
       float* out = a->partial + (int64_t)blockIdx.x * rows16 * k16 + kc + (lane & 15);
 #pragma unroll
-      for (int t = 0; t < WG_MAX_NT; ++t)
-        if (t < nt)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) out[(int64_t)(16 * t + (lane >> 4) * 4 + i) * k16] = acc[t][i];
+        for (int i = 0; i < 4; ++i) out[(int64_t)(16 * t + (lane >> 4) * 4 + i) * k16] = acc[t][i];
+    }
+  }
+}
+
+// Variant for few, small passes (K <= 64 gathered channels, <= 48 rows: every 1x1 unit of stages 0-3): each wave
+// owns its pixel groups AND all k chunks, with a private dz panel -- no block barrier in the loop, no idle wave
+// when K < 64.  The four waves' accumulators are added through LDS once, at the end.
+template <int NT, int NCH>
+__global__ __launch_bounds__(CSN_BLOCK, 3) void goct_wgrad_wave_kernel(WgArgs a_byval) {
+  CSN_DYN_SMEM(float, lds);
+  WgArgsP a = CSN_KERNARG(WgArgs, a_byval);
+  PwPassP ps = &a->ps;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int rows16 = a->rows16, k16 = a->k16, nrows = ps->nrows;
+  const int Hr = a->Hr, Wr = a->Wr, HW = Hr * Wr;
+  const int wfloats = (rows16 + 16) * WG_P;
+  float* dzp = lds + wave * wfloats;          // this wave's dz[rows16][64 px]
+  float* xp = dzp + rows16 * WG_P;            // ... and x[16 k][64 px]
+  for (int i = lane; i < rows16 * WG_P; i += 64) dzp[i] = 0.f;   // rows nrows..rows16 stay zero
+  const int cin = ps->cin;
+  const int c1 = ps->src[0].K, c2 = c1 + ps->src[1].K;
+  csn_f4 acc[NCH][NT];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[c][t][i] = 0.f;
+  const unsigned cs4 = (unsigned)HW * 4u;
+  // block-uniform trip count (the CPU emulation maps the wave hand-offs to block barriers): a wave without a group
+  // left walks the last group with an all-zero dz panel
+  for (int g0 = blockIdx.x * 4; g0 < a->ngroups; g0 += a->nblk * 4) {
+    const int g = min(g0 + wave, a->ngroups - 1);
+    const int b = g / a->gpp;
+    const int p = (g - b * a->gpp) * 64 + lane;
+    const bool valid = p < HW && g0 + wave < a->ngroups;
+    const int pc = valid ? p : HW - 1;
+    const int y = pc / Wr, x = pc - y * Wr;
+    CSN_WAVE_SYNC();   // previous group's panels fully consumed
+    for (int r0 = 0; r0 < nrows; r0 += 16) {
+      const csn_buf rb = csn_make_buf(a->a + ((int64_t)b * a->a_ctot + r0) * HW);
+      pw_batch_own<16, WG_P>(rb, (unsigned)pc * 4u, cs4, 0, min(16, nrows - r0), 16, dzp + r0 * WG_P + lane);
+    }
+    if (!valid)   // pixels past the plane contribute nothing
+      for (int r = 0; r < nrows; ++r) dzp[r * WG_P + lane] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int kc = 16 * c;
+      if (kc < k16) {
+        const int kend = min(kc + 16, cin);
+        CSN_WAVE_SYNC();
+        if (kc < c1) wg_gather(ps, 0, kc, min(kend, c1), xp + lane, 16, b, y, x, Hr, Wr);
+        if (max(kc, c1) < min(kend, c2)) {
+          const int r0 = max(kc, c1) - kc;
+          wg_gather(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
+        }
+        if (max(kc, c2) < min(kend, cin)) {
+          const int r0 = max(kc, c2) - kc;
+          wg_gather(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
+        }
+        for (int k = max(cin, kc); k < kc + 16; ++k) xp[(k - kc) * WG_P + lane] = 0.f;
+        CSN_WAVE_SYNC();
+        wg_mma<NT>(dzp, xp, lane, acc[c]);
+      }
+    }
+  }
+  // ---- add the four waves' tiles and write the block's partial
+  __syncthreads();
+  float* comb = lds + wave * wfloats;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) comb[(c * NT + t) * 256 + ((lane >> 4) * 4 + i) * 16 + (lane & 15)] = acc[c][t][i];
+  __syncthreads();
+  float* out = a->partial + (int64_t)blockIdx.x * rows16 * k16;
+  const int row = tid >> 4, col = tid & 15;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (16 * c >= k16) continue;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int o = (c * NT + t) * 256 + tid;
+      const float v = (lds[o] + lds[wfloats + o]) + (lds[2 * wfloats + o] + lds[3 * wfloats + o]);
+      out[(int64_t)(16 * t + row) * k16 + 16 * c + col] = v;
     }
   }
 }
 
 // grad[dst + r*ld + c] = scale * sum_blk partial[blk][r][col + c]  for every block of weight columns.
+// Block = 64 consecutive k (coalesced) x 4 interleaved slices of the partial index; grid (ceil(K/64), nrows).
 __global__ __launch_bounds__(CSN_BLOCK) void wgrad_reduce_kernel(WgReduceArgs a) {
-  const int e = blockIdx.x * CSN_BLOCK + threadIdx.x;
-  if (e >= a.nrows * a.K) return;
-  const int r = e / a.K, k = e - r * a.K;
+  CSN_DYN_SMEM(double, sm);
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane, r = blockIdx.y;
+  double s = 0.0;
+  if (k < a.K) {
+    const float* p = a.partial + (int64_t)r * a.k16 + k;
+    const int64_t stride = (int64_t)a.rows16 * a.k16;
+    for (int b = grp; b < a.nblk; b += 4) s += (double)p[b * stride];
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (grp != 0 || k >= a.K) return;
+  s = (sm[lane] + sm[64 + lane]) + (sm[128 + lane] + sm[192 + lane]);
   int bi = -1;
 #pragma unroll
   for (int q = 0; q < 3; ++q)
     if (q < a.nblocks && k >= a.blk[q].col && k < a.blk[q].col + a.blk[q].ncol) bi = q;
   if (bi < 0) return;   // identity columns (already convolved partial sums) carry no parameter
-  double s = 0.0;
-  const float* p = a.partial + (int64_t)r * a.k16 + k;
-  const int64_t stride = (int64_t)a.rows16 * a.k16;
-  for (int b = 0; b < a.nblk; ++b) s += (double)p[b * stride];
   a.grad[a.blk[bi].dst + (int64_t)r * a.blk[bi].ld + (k - a.blk[bi].col)] = (float)((double)a.blk[bi].scale * s);
+}
+
+// wave-private variant: 4 groups per block step; returns false when the pass does not fit it
+static bool wgrad_wave_fits(const WgArgs& a) { return a.k16 <= 64 && a.rows16 <= 48; }
+
+int csn_wgrad_blocks(int rows16, int k16, int ngroups) {
+  WgArgs t;
+  t.rows16 = rows16; t.k16 = k16;
+  const int units = wgrad_wave_fits(t) ? (ngroups + 3) / 4 : ngroups;
+  return units < WG_MAX_BLOCKS ? units : WG_MAX_BLOCKS;
 }
 
 int csn_launch_wgrad(const WgArgs& a, void* stream) {
   if (a.rows16 > 16 * WG_MAX_NT) return -1;
+  if (wgrad_wave_fits(a)) {
+    const int nt = a.rows16 >> 4, nch = a.k16 <= 32 ? 2 : 4;
+    const size_t wl = (size_t)4 * (a.rows16 + 16) * WG_P * sizeof(float);
+    const dim3 grid(a.nblk), block(CSN_BLOCK);
+    if (nt == 1 && nch == 2) CSN_LAUNCH((goct_wgrad_wave_kernel<1, 2>), grid, block, wl, stream, a);
+    else if (nt == 1) CSN_LAUNCH((goct_wgrad_wave_kernel<1, 4>), grid, block, wl, stream, a);
+    else if (nt == 2 && nch == 2) CSN_LAUNCH((goct_wgrad_wave_kernel<2, 2>), grid, block, wl, stream, a);
+    else if (nt == 2) CSN_LAUNCH((goct_wgrad_wave_kernel<2, 4>), grid, block, wl, stream, a);
+    else CSN_LAUNCH((goct_wgrad_wave_kernel<3, 4>), grid, block, wl, stream, a);
+    return (int)hipGetLastError();
+  }
   const size_t lds = ((size_t)a.rows16 * WG_P + 4 * 16 * WG_P) * sizeof(float);
-  CSN_LAUNCH(goct_wgrad_kernel, dim3(a.nblk), dim3(CSN_BLOCK), lds, stream, a);
+  switch (a.rows16 >> 4) {
+    case 1: CSN_LAUNCH(goct_wgrad_kernel<1>, dim3(a.nblk), dim3(CSN_BLOCK), lds, stream, a); break;
+    case 2: CSN_LAUNCH(goct_wgrad_kernel<2>, dim3(a.nblk), dim3(CSN_BLOCK), lds, stream, a); break;
+    case 3: CSN_LAUNCH(goct_wgrad_kernel<3>, dim3(a.nblk), dim3(CSN_BLOCK), lds, stream, a); break;
+    case 4: CSN_LAUNCH(goct_wgrad_kernel<4>, dim3(a.nblk), dim3(CSN_BLOCK), lds, stream, a); break;
+    default: CSN_LAUNCH(goct_wgrad_kernel<5>, dim3(a.nblk), dim3(CSN_BLOCK), lds, stream, a); break;
+  }
   return (int)hipGetLastError();
 }
 
 int csn_launch_wgrad_reduce(const WgReduceArgs& a, void* stream) {
-  const int n = a.nrows * a.K;
-  CSN_LAUNCH(wgrad_reduce_kernel, dim3((n + CSN_BLOCK - 1) / CSN_BLOCK), dim3(CSN_BLOCK), 0, stream, a);
+  CSN_LAUNCH(wgrad_reduce_kernel, dim3((a.K + 63) / 64, a.nrows), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   return (int)hipGetLastError();
 }
