@@ -107,7 +107,6 @@ int plan_goct_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
       } else {
         w.a_kind = SRC_DZ; w.a_idx = pp.out_branch; w.a_c0 = 0; w.a_ctot = d.cout[pp.out_branch];
       }
-      if (((w.L.passes[0].nrows + 15) & ~15) > 80) FAIL(CSN_E_UNSUPPORTED, "weight gradient: more than 80 output channels");
       ub.wg.push_back(w);
     }
   // ---- input gradients
@@ -297,23 +296,28 @@ int run_wgrad(const BwdCtx& b, const WgPlan& w, const PwBind& bd) {
   a.Hr = P.H >> w.L.lvl; a.Wr = P.W >> w.L.lvl; a.B = P.S;
   const int64_t hw = (int64_t)a.Hr * a.Wr;
   const float* ab = w.a_kind == SRC_ADJ ? bd.adj[w.a_idx] : bd.dz[w.a_idx];
-  a.a = ab + (int64_t)w.a_c0 * hw;
   a.a_ctot = w.a_ctot;
   a.gpp = (int)((hw + 63) / 64);
   a.ngroups = a.gpp * P.S;
-  a.rows16 = (pp.nrows + 15) & ~15;
   a.k16 = (pp.K + 15) & ~15;
-  a.nblk = csn_wgrad_blocks(a.rows16, a.k16, a.ngroups);
   a.partial = reinterpret_cast<float*>(b.c.ws + P.wg_off);
-  LAUNCH_TRY(csn_launch_wgrad(a, b.c.stream));
-  WgReduceArgs r;
-  r.partial = a.partial; r.grad = b.grad;
-  r.nblocks = (int)w.blocks.size();
-  for (int q = 0; q < 3; ++q)
-    if (q < r.nblocks) r.blk[q] = w.blocks[q];
-    else { r.blk[q].dst = 0; r.blk[q].ld = 0; r.blk[q].ncol = 0; r.blk[q].col = 0; r.blk[q].scale = 0.f; }
-  r.nblk = a.nblk; r.nrows = pp.nrows; r.K = pp.K; r.rows16 = a.rows16; r.k16 = a.k16;
-  LAUNCH_TRY(csn_launch_wgrad_reduce(r, b.c.stream));
+  // the kernel holds at most 80 output channels (5 MFMA row tiles) per launch: wider passes go in row chunks
+  for (int r0 = 0; r0 < pp.nrows; r0 += WG_MAX_ROWS) {
+    const int nr = std::min(WG_MAX_ROWS, pp.nrows - r0);
+    a.ps.nrows = nr;
+    a.a = ab + (int64_t)(w.a_c0 + r0) * hw;
+    a.rows16 = (nr + 15) & ~15;
+    a.nblk = csn_wgrad_blocks(a.rows16, a.k16, a.ngroups);
+    LAUNCH_TRY(csn_launch_wgrad(a, b.c.stream));
+    WgReduceArgs r;
+    r.partial = a.partial; r.grad = b.grad;
+    r.nblocks = (int)w.blocks.size();
+    for (int q = 0; q < 3; ++q)
+      if (q < r.nblocks) { r.blk[q] = w.blocks[q]; r.blk[q].dst += (int64_t)r0 * r.blk[q].ld; }
+      else { r.blk[q].dst = 0; r.blk[q].ld = 0; r.blk[q].ncol = 0; r.blk[q].col = 0; r.blk[q].scale = 0.f; }
+    r.nblk = a.nblk; r.nrows = nr; r.K = pp.K; r.rows16 = a.rows16; r.k16 = a.k16;
+    LAUNCH_TRY(csn_launch_wgrad_reduce(r, b.c.stream));
+  }
   return CSN_OK;
 }
 
@@ -521,7 +525,8 @@ int csn_plan_enable_training(csn_plan* P) {
     scratch = std::max(scratch, ub.scratch);
     for (const WgPlan& w : ub.wg) {
       const PwPassPlan& pp = w.L.passes[0];
-      wg_floats = std::max(wg_floats, (int64_t)WG_MAX_BLOCKS * ((pp.nrows + 15) & ~15) * ((pp.K + 15) & ~15));
+      const int rows = std::min(pp.nrows, WG_MAX_ROWS);
+      wg_floats = std::max(wg_floats, (int64_t)WG_MAX_BLOCKS * ((rows + 15) & ~15) * ((pp.K + 15) & ~15));
     }
   }
   P->scratch_bytes = scratch;

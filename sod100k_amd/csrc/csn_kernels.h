@@ -136,6 +136,7 @@ struct Up2Args {
 // weight gradient of one contraction pass (see k_wgrad.hip)
 // ---------------------------------------------------------------------------------------------
 #define WG_MAX_BLOCKS 512
+#define WG_MAX_ROWS 80     // output channels per launch (5 MFMA row tiles)
 struct WgArgs {
   PwPass ps;            // gather descriptor of the forward pass (src, cin, nrows); out/epilogue fields unused
   const float* a;       // dz: first of ps.nrows channels inside [B][a_ctot][Hr][Wr]

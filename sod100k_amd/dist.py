@@ -2,7 +2,7 @@
 
 The eval-mode hot path shards by image and needs NO data-path collective; what remains is
 the synchronisation around a timed region and the MAX-reduction of its duration (bench.py contract).  The
-gradient all-reduce of the training path will live here as well (one flat bucket = the ParamArena).
+gradient all-reduce of the training path lives here as well (one flat bucket with the ParamArena's layout).
 """
 import os
 import time
@@ -52,6 +52,15 @@ def timed_region(step: Callable[[], None], steps: int, sync: Callable[[], None],
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
+
+
+def allreduce_mean_(flat: torch.Tensor, world: int) -> torch.Tensor:
+    """The training path's ONLY collective: all-reduce(sum) of the flat gradient arena, then 1/world.
+    563 KB for CSNet-100K -- latency regime, one call per step, nothing to overlap with."""
+    if world > 1:
+        dist.all_reduce(flat)
+        flat.mul_(1.0 / world)
+    return flat
 
 
 def finalize() -> None:

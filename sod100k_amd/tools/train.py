@@ -83,9 +83,8 @@ class FusedTrainer:
         bs = self.batchsize or B
         model._train_backward_raw(x, dy, self.flops_weight / bs, grad=self.grad)
         if world_size > 1:          # the step's only collective: average the flat gradient over the data-parallel ranks
-            import torch.distributed as dist
-            dist.all_reduce(self.grad)
-            self.grad.mul_(1.0 / world_size)
+            from sod100k_amd.dist import allreduce_mean_
+            allreduce_mean_(self.grad, world_size)
         self.steps += 1
         flat = model._arena.flat
         N.check(self.lib, self.lib.csn_adam_step(flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(),

@@ -57,3 +57,65 @@ def test_config_loader_accepts_reference_keys(tmp_path):
     bad.write_text("MODEL:\n  NOT_A_KEY: 1\n")
     with pytest.raises(KeyError):
         cfg.merge_from_file(str(bad))
+
+
+def _train_worker(rank, world, port, out):
+    """Data-parallel train step on two ranks (CPU emulation of the kernels + gloo all-reduce of the flat gradient)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import ctypes
+    torch.set_num_threads(2)
+    from sod100k_amd import dist as D, _native as N
+    from sod100k_amd.tools.train import FusedTrainer
+    from oracle import inputs as I
+    import parity_cases as P
+    assert D.init(backend="gloo") == world
+    lib = N.bind(ctypes.CDLL(os.path.join(ROOT, "tests", "emu", "libcsnet_emu.so")))
+    man = os.path.join(ROOT, "sod100k_amd", "data", "csnet-L-x2.json")
+    m, _ = P.make_model(lib, man, torch.device("cpu"))
+    m.train(); m.set_batchsize(2); m.clear_flops(); m.flops_hook(1.0)
+    tr = FusedTrainer(m, lr=0.0, weight_decay=0.0, flops_weight=3.0, batchsize=2, lib=lib)
+    x = torch.from_numpy(I.randn_batch(10, 4, 32, 32))[2 * rank:2 * rank + 2]
+    t = torch.from_numpy(I.binary_target(11, 4, 32, 32))[2 * rank:2 * rank + 2]
+    loss, pen = tr.step(x, t, world_size=world)
+    out.put((rank, float(loss), float(pen), tr.grad.clone().numpy()))
+    D.finalize()
+
+
+def test_two_rank_gradient_allreduce(emu_lib):
+    """G7-style check: per-shard BN statistics, gradients averaged by ONE all-reduce == the oracle's two-shard mean."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import csnet_oracle as O, inputs as I
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
+    [p.join(60) for p in procs]
+    assert np.array_equal(res[0][3], res[1][3])            # both ranks hold the same averaged gradient
+    man = os.path.join(ROOT, "sod100k_amd", "data", "csnet-L-x2.json")
+    cfg = O.load_layer_config_json(man)
+    x = torch.from_numpy(I.randn_batch(10, 4, 32, 32))
+    t = torch.from_numpy(I.binary_target(11, 4, 32, 32))
+    grads = None
+    for s in range(2):
+        sd = O.load_weights(man)
+        r = O.train_step(cfg, sd, x[2 * s:2 * s + 2], t[2 * s:2 * s + 2], expandflop=1.0, flops_weight=3.0, batchsize=2,
+                         lr=0.0, wd=0.0)
+        assert abs(r["loss_bce"] - res[s][1]) <= 1e-5 and abs(r["penalty"] - res[s][2]) <= 1e-5 * max(1.0, r["penalty"])
+        grads = r["grads"] if grads is None else {k: grads[k] + v for k, v in r["grads"].items()}
+    # flat layout = ParamArena: parameters in named_parameters() order, each padded to 4 floats
+    import parity_cases as P
+    m, _ = P.make_model(emu_lib, man, torch.device("cpu"))
+    offs = m._ensure_arena().offsets
+    flat = torch.from_numpy(res[0][3])
+    gmax = max(float(v.norm()) for v in grads.values()) / 2
+    for name, p in m.named_parameters():
+        g = flat[offs[name]:offs[name] + p.numel()].view(p.shape).double()
+        ref = (grads[name] / 2).double()
+        assert float((g - ref).norm()) <= 2e-3 * float(ref.norm()) + 1e-6 * gmax, name
