@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--sub-batch", type=int, default=int(os.environ.get("CSN_SUB_BATCH", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=5)
+    ap.add_argument("--train-batch", type=int, default=0, help="images per GPU per train step (0 = --batch)")
     ap.add_argument("--train-steps", type=int, default=10,
                     help="also time this many full train steps (0 = skip); reported under \"train_step\"")
     args = ap.parse_args()
@@ -144,18 +145,21 @@ def main():
         model.train()
         model.flops_hook(1.0)                       # csnet-L-x2_train.yml: FLOPS.EXPAND 1.0, WEIGHT 3.0
         model.set_batchsize(B)
-        tr = FusedTrainer(model, lr=1e-4, weight_decay=5e-3, flops_weight=3.0, batchsize=B)
-        tgt = (torch.rand(B, 1, 224, 224, generator=g) > 0.5).float().to(dev)
+        TB = args.train_batch or B
+        model.set_batchsize(TB)
+        tr = FusedTrainer(model, lr=1e-4, weight_decay=5e-3, flops_weight=3.0, batchsize=TB)
+        xt = x if TB == B else torch.randn(TB, 3, 224, 224, generator=g).to(dev)
+        tgt = (torch.rand(TB, 1, 224, 224, generator=g) > 0.5).float().to(dev)
 
         def tstep():
-            tr.step(x, tgt, world_size=world)
+            tr.step(xt, tgt, world_size=world)
 
         for _ in range(3):
             tstep()
         tdt = D.timed_region(tstep, args.train_steps, sync=lambda: torch.cuda.synchronize(dev), device=dev)
-        train = {"value": round(world * B * args.train_steps / tdt, 1), "unit": "images/sec",
+        train = {"value": round(world * TB * args.train_steps / tdt, 1), "unit": "images/sec",
                  "ms_per_step": round(tdt / args.train_steps * 1e3, 3), "steps": args.train_steps,
-                 "batch_per_gpu": B, "dtype": "f32",
+                 "batch_per_gpu": TB, "dtype": "f32",
                  "what": "train-mode forward (batch-stat BN + penalty) + BCE + backward + "
                          + ("RCCL all-reduce of the flat gradient + " if world > 1 else "") + "Adam, csnet-L-x2 weights"}
         model.eval()

@@ -50,6 +50,18 @@ struct UnitBwd {
   int64_t scratch = 0;                       // bytes of unit scratch used
 };
 
+// one DataLaunch per row chunk of `L`; the routing kernel (to_tmp) follows the last chunk only
+void push_data(UnitBwd& ub, const PwLaunchPlan& L, const DataLaunch& proto) {
+  std::vector<PwLaunchPlan> parts;
+  add_launch(parts, L);
+  for (size_t k = 0; k < parts.size(); ++k) {
+    DataLaunch dl = proto;
+    dl.L = parts[k];
+    dl.to_tmp = proto.to_tmp && k + 1 == parts.size();
+    ub.data.push_back(dl);
+  }
+}
+
 int64_t bw_alloc(UnitBwd& ub, int64_t bytes) {
   const int64_t off = ub.scratch;
   ub.scratch += align_up(bytes, 256);
@@ -103,9 +115,9 @@ int plan_goct_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
       if (q.nsrc == 0 || q.K == 0) continue;
       WgPlan w = make_wg(L, q);
       if (pp.out_kind == OUT_Z) {
-        w.a_kind = SRC_ADJ; w.a_idx = adj_index(0, 1); w.a_c0 = 0; w.a_ctot = u.z_C;
+        w.a_kind = SRC_ADJ; w.a_idx = adj_index(0, 1); w.a_c0 = pp.out_c0; w.a_ctot = u.z_C;
       } else {
-        w.a_kind = SRC_DZ; w.a_idx = pp.out_branch; w.a_c0 = 0; w.a_ctot = d.cout[pp.out_branch];
+        w.a_kind = SRC_DZ; w.a_idx = pp.out_branch; w.a_c0 = pp.out_c0; w.a_ctot = d.cout[pp.out_branch];
       }
       ub.wg.push_back(w);
     }
@@ -144,8 +156,8 @@ int plan_goct_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
     if (ps.nsrc > 0) {
       L.passes.push_back(ps);
       DataLaunch dl;
-      dl.L = L; dl.i = i;
-      ub.data.push_back(dl);
+      dl.i = i;
+      push_data(ub, L, dl);
     } else {
       ub.zero_dx[i] = true;
     }
@@ -163,8 +175,8 @@ int plan_goct_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
       pq.K = d.cout[j] * kk;
       Lp.passes.push_back(pq);
       DataLaunch dl;
-      dl.L = Lp; dl.i = i; dl.to_tmp = true; dl.pool_f = 1 << (j - i); dl.lvl_lo = base + j;
-      ub.data.push_back(dl);
+      dl.i = i; dl.to_tmp = true; dl.pool_f = 1 << (j - i); dl.lvl_lo = base + j;
+      push_data(ub, Lp, dl);
       tmp_bytes = std::max(tmp_bytes, bl.act_bytes(d.cin[i], base + j));
     }
   }
@@ -236,8 +248,8 @@ int plan_ms_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
     }
     L.passes.push_back(ps);
     DataLaunch dl;
-    dl.L = L; dl.i = 0;
-    ub.data.push_back(dl);
+    dl.i = 0;
+    push_data(ub, L, dl);
     first = false;
     bool more = false;
     for (int q = k; q < CSN_NDIL; ++q) more = more || d.dil_ch[q] > 0;
@@ -270,9 +282,13 @@ int plan_cls_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
   ps.wb.push_back(w);
   L.passes.push_back(ps);
   DataLaunch dl;
-  dl.L = L; dl.i = 0;
-  ub.data.push_back(dl);
-  return finish_launch(bl, ub.data.back().L);
+  dl.i = 0;
+  push_data(ub, L, dl);
+  for (DataLaunch& one : ub.data) {
+    const int st = finish_launch(bl, one.L);
+    if (st != CSN_OK) return st;
+  }
+  return CSN_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- execution

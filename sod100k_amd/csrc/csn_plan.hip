@@ -58,6 +58,7 @@ struct WBlock {           // one rectangular block of a pass's weight rows
   int ld = 0, ncol = 0, col = 0;
   float scale = 1.f;
   int tk = 0;             // > 0: transposed block with flipped taps (backward data), tk = k*k of the forward weight
+  int eye_rows = 0, eye_col0 = 0;   // identity block of a row chunk: rows in the chunk, first row of the chunk
 };
 
 struct PwPassPlan {
@@ -210,7 +211,8 @@ int finish_launch(Builder& bl, PwLaunchPlan& L) {
   for (const PwPassPlan& ps : L.passes)
     for (const WBlock& w : ps.wb) {
       if (w.eye)
-        bl.job(CSN_PREP_EYE, w.ncol, L.wimg + ps.w_off, -1, -1, -1, -1, 1.f, 0, 0, ps.w_stride, w.col);
+        bl.job(CSN_PREP_EYE, w.eye_rows > 0 ? w.eye_rows : w.ncol, L.wimg + ps.w_off, -1, -1, -1, -1, 1.f, 0, 0,
+               ps.w_stride, w.col + w.eye_col0);
       else if (w.tk > 0)
         bl.job(CSN_PREP_ROWS_T, ps.nrows, L.wimg + ps.w_off, w.src, -1, -1, -1, w.scale, w.ld, w.ncol, ps.w_stride,
                w.col | (w.tk << 24));
@@ -220,9 +222,36 @@ int finish_launch(Builder& bl, PwLaunchPlan& L) {
   return CSN_OK;
 }
 
+// A single-pass launch whose weight image would not fit the LDS comfortably is cut into row chunks (each chunk
+// re-gathers the inputs; only the wide un-pruned networks get here).
+void push_row_chunks(std::vector<PwLaunchPlan>& dst, const PwLaunchPlan& L) {
+  const PwPassPlan& ps = L.passes[0];
+  const int64_t stride = round4(ps.K) + 2;
+  const int64_t limit = 96 * 1024;
+  if (L.passes.size() != 1 || (int64_t)((ps.nrows + 15) & ~15) * stride * 4 <= limit) {
+    dst.push_back(L);
+    return;
+  }
+  int rows = (int)((limit / (stride * 4)) & ~15);
+  if (rows < 16) rows = 16;
+  for (int r0 = 0; r0 < ps.nrows; r0 += rows) {
+    PwLaunchPlan one = L;
+    PwPassPlan& q = one.passes[0];
+    q.nrows = std::min(rows, ps.nrows - r0);
+    q.out_c0 = ps.out_c0 + r0;
+    q.epi.scale += r0; q.epi.shift += r0; q.epi.alpha += r0;
+    for (WBlock& w : q.wb) {
+      if (w.eye) { w.eye_rows = q.nrows; w.eye_col0 = r0; }
+      else if (w.tk > 0) w.src += (int64_t)r0 * w.tk;
+      else w.src += (int64_t)r0 * w.ld;
+    }
+    dst.push_back(one);
+  }
+}
+
 // Split a launch whose weight image would cap the occupancy through LDS into one launch per pass, each
 // re-based on its own resolution (the shared inputs are then re-read through L2 / Infinity Cache).
-void add_launch(UnitPlan& u, PwLaunchPlan L) {
+void add_launch(std::vector<PwLaunchPlan>& dst, PwLaunchPlan L) {
   int64_t img = 0;
   for (const PwPassPlan& ps : L.passes) img += (int64_t)((ps.nrows + 15) & ~15) * (round4(ps.K) + 2);
   if (L.passes.size() > 1 && img * 4 > 24 * 1024) {
@@ -231,10 +260,10 @@ void add_launch(UnitPlan& u, PwLaunchPlan L) {
       one.lvl = L.lvl + ps.r;
       one.passes.push_back(ps);
       one.passes[0].r = 0;
-      u.pwl.push_back(one);
+      push_row_chunks(dst, one);
     }
   } else {
-    u.pwl.push_back(L);
+    push_row_chunks(dst, L);
   }
 }
 
@@ -297,7 +326,7 @@ int plan_goct(Builder& bl, UnitPlan& u) {
     WBlock w; w.src = d.w_off[0] + ((int64_t)co_off[0] * cin_tot + ci_off[1]) * 9; w.ld = ld; w.ncol = d.cin[1] * 9; w.col = 0;
     ps.wb.push_back(w);
     L.passes.push_back(ps);
-    u.pwl.push_back(L);
+    add_launch(u.pwl, L);
   }
   PwLaunchPlan L;
   L.lvl = base;
@@ -341,7 +370,7 @@ int plan_goct(Builder& bl, UnitPlan& u) {
     if (!ok || ps.nsrc == 0) FAIL(CSN_E_INVALID, "output branch without inputs / too many inputs");
     L.passes.push_back(ps);
   }
-  add_launch(u, L);
+  add_launch(u.pwl, L);
   for (PwLaunchPlan& l : u.pwl) {
     const int st = finish_launch(bl, l);
     if (st != CSN_OK) return st;

@@ -26,8 +26,8 @@ import torch.nn as nn
 from torch.nn import init
 
 from .conv2d import Conv2dX100
-from .. import _native as N
-from ..engine import Engine, ParamArena
+from sod100k_amd import _native as N
+from sod100k_amd.engine import Engine, ParamArena
 
 DILATIONS = (1, 2, 4, 8, 16)      # csnet.py:121
 

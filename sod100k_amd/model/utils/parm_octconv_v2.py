@@ -47,7 +47,7 @@ def _octconv_flops(conv, in_shapes, k):
 
 def print_model_parm_flops(model, inputsize, device=-1):
     from .. import csnet as M
-    from ... import _native as N
+    from sod100k_amd import _native as N
 
     class _Zero(dict):
         def __missing__(self, key):

@@ -61,3 +61,19 @@ def test_emu_unpruned_expand1_train_step(emu_lib):
     ref = np.array([float((r32["grads"][k].double() - g).norm() / (g.norm() + 1e-12)) for k, g in r64["grads"].items()])
     assert np.median(mine) <= 2 * np.median(ref) and mine.max() <= 3 * ref.max(), (np.median(mine), np.median(ref),
                                                                                   mine.max(), ref.max())
+
+
+def test_emu_unpruned_expand2_forward(emu_lib):
+    """expand 2.0 (width 40, the training recipe's starting point): weight images beyond the LDS budget are cut into
+    row chunks; eval forward and train-mode forward against the oracle."""
+    m = M.build_model(basic_split=[0.5, 0.5], expand=2.0, save_path="/tmp")
+    sd = _random_state(m, 1)
+    m.load_state_dict(sd)
+    m._lib = emu_lib
+    cfg = O.init_layers(40, [0.5, 0.5])
+    x = torch.from_numpy(I.randn_batch(7, 2, 32, 32))
+    m.eval()
+    with torch.no_grad():
+        ref = O.csnet_forward(cfg, {k: v.clone() for k, v in sd.items()}, x)
+    y = m(x)
+    assert (y - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
