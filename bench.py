@@ -62,7 +62,8 @@ def main():
     ap.add_argument("--sub-batch", type=int, default=int(os.environ.get("CSN_SUB_BATCH", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=5)
-    ap.add_argument("--train-batch", type=int, default=0, help="images per GPU per train step (0 = --batch)")
+    ap.add_argument("--train-batch", type=int, default=256,
+                    help="images per GPU per train step (SURVEY 8(d) config 3: 256; 0 = --batch)")
     ap.add_argument("--train-steps", type=int, default=10,
                     help="also time this many full train steps (0 = skip); reported under \"train_step\"")
     args = ap.parse_args()

@@ -594,7 +594,10 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
     PwPass& ps = a.pass[q];
     fill_pass(c, L, pp, bd, ps);
   }
-  LAUNCH_TRY(csn_launch_pw(a, 2, c.stream));
+  // raw: every pass of the launch stores plain sums (train-mode conv outputs, gradients, scratch)
+  bool all_raw = true;
+  for (const PwPassPlan& pp : L.passes) all_raw = all_raw && (pp.out_kind == OUT_DX || pp.out_kind == OUT_TMP || (c.raw && pp.out_kind != OUT_LOGITS));
+  LAUNCH_TRY(csn_launch_pw(a, all_raw ? 1 : 0, c.stream));
   return c.mark("goct_pw_kernel");
 }
 

@@ -62,7 +62,7 @@ __device__ __forceinline__ void pw_contract(const float* wl, int stride, const f
 // are gathered into the panel and contracted, then every tile is transposed through the panel so that each
 // lane gets ITS pixel back and the wave stores 256 contiguous bytes per output channel (buffer stores: one
 // VGPR offset per lane, the channel offset rides in an SGPR; lanes outside the image are exec-masked).
-template <int NT>
+template <int NT, bool RAW>
 __device__ __forceinline__ void pw_sweep(PwPassP ps, const float* wl0, float* xb, int row0, int b, int gy, int gx,
                                          int Hr, int Wr, unsigned ovoff, bool valid, int lane) {
   const int cin = ps->cin, cin4 = ps->cin4, nrows = ps->nrows, stride = ps->w_stride;
@@ -105,12 +105,15 @@ __device__ __forceinline__ void pw_sweep(PwPassP ps, const float* wl0, float* xb
     csn_cfp scale = csn_const(ps->scale) + rbase, shift = csn_const(ps->shift) + rbase, alpha = csn_const(ps->alpha) + rbase;
 #pragma unroll 4
     for (int rr = 0; rr < rn; ++rr) {
-      const float val = csn_epi(xb[rr * PW_EP + lane], scale[rr], shift[rr], alpha[rr]);
+      const float val = RAW ? xb[rr * PW_EP + lane] : csn_epi(xb[rr * PW_EP + lane], scale[rr], shift[rr], alpha[rr]);
       if (valid) csn_st1(ob, ovoff, (unsigned)(rbase + rr) * cs4, val);
     }
   }
 }
 
+// RAW = true: plain store (train-mode raw convolution outputs, every backward-data launch) -- its own symbol, so
+// kernel traces keep the eval-mode launches (BN + PReLU epilogue) apart from the training ones.
+template <bool RAW>
 __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
   CSN_DYN_SMEM(float, lds);
   const CSN_CONST_AS PwArgs* a = CSN_KERNARG(PwArgs, a_byval);
@@ -152,8 +155,8 @@ __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
         const int gy = min(py_, Hr - 1), gx = min(px_, Wr - 1);     // lanes off the image gather a valid pixel
         const unsigned ovoff = (unsigned)(gy * Wr + gx) * 4u;        // ... and store nothing (exec-masked)
         for (int row0 = 0; row0 < nrows; row0 += 32) {
-          if (nrows - row0 <= 16) pw_sweep<1>(ps, wl0, xb, row0, b, gy, gx, Hr, Wr, ovoff, valid, lane);
-          else pw_sweep<2>(ps, wl0, xb, row0, b, gy, gx, Hr, Wr, ovoff, valid, lane);
+          if (nrows - row0 <= 16) pw_sweep<1, RAW>(ps, wl0, xb, row0, b, gy, gx, Hr, Wr, ovoff, valid, lane);
+          else pw_sweep<2, RAW>(ps, wl0, xb, row0, b, gy, gx, Hr, Wr, ovoff, valid, lane);
         }
       }
       gbase += ng;
@@ -161,8 +164,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
   }
 }
 
-int csn_launch_pw(const PwArgs& a, int maxnt, void* stream) {
-  (void)maxnt;
+int csn_launch_pw(const PwArgs& a, int raw, void* stream) {
   const int ntiles = a.tiles_x * a.tiles_y * a.B;
   const dim3 grid(ntiles < PW_MAX_GRID ? ntiles : PW_MAX_GRID);
   const size_t lds = ((size_t)a.wimg_floats + 4 * PW_KC * PW_XP) * sizeof(float);
@@ -170,12 +172,16 @@ int csn_launch_pw(const PwArgs& a, int maxnt, void* stream) {
   static bool attr_done = false;
   if (!attr_done) {
     // units with a large weight image may use the full 160 KiB of LDS of a CDNA4 CU
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&goct_pw_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&goct_pw_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&goct_pw_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
 #endif
-  CSN_LAUNCH(goct_pw_kernel, grid, dim3(CSN_BLOCK), lds, stream, a);
+  if (raw) CSN_LAUNCH(goct_pw_kernel<true>, grid, dim3(CSN_BLOCK), lds, stream, a);
+  else CSN_LAUNCH(goct_pw_kernel<false>, grid, dim3(CSN_BLOCK), lds, stream, a);
   return (int)hipGetLastError();
 }
