@@ -146,6 +146,16 @@ EXPORTS: Sequence[str] = (
 _lib: Optional[C.CDLL] = None
 
 
+def _share_torch_hip_runtime() -> None:
+    """One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (soname libamdhip64.so.7, the name
+    libcsnet_hip.so needs).  It must be mapped BEFORE our library, otherwise the loader would pull a second copy
+    from /opt/rocm and torch's streams / allocations would belong to a different runtime than our launches."""
+    import torch
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load() -> C.CDLL:
     """Load libcsnet_hip.so.  Raises if it has not been built: the HIP path is the only path."""
     global _lib
@@ -154,6 +164,7 @@ def load() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing.  Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  sod100k_amd has no CPU / PyTorch fallback by design.")
+        _share_torch_hip_runtime()
         _lib = bind(C.CDLL(LIB_PATH))
         if _lib.csn_abi_version() != 1:
             raise RuntimeError("libcsnet_hip.so ABI version mismatch")

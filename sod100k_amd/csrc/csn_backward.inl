@@ -375,7 +375,8 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
     AdjUpArgs ua;
     ua.in = dy; ua.out = dlh; ua.planes = S; ua.Hl = P.H >> 1; ua.Wl = P.W >> 1; ua.f = 2;
     LAUNCH_TRY(csn_launch_adjup(ua, c.stream));
-    LAUNCH_TRY(csn_launch_sum_to_grad(dlh, (int64_t)S * ua.Hl * ua.Wl, b.grad + d.bias_off, c.stream));
+    LAUNCH_TRY(csn_launch_sum_to_grad(dlh, (int64_t)S * ua.Hl * ua.Wl, b.grad + d.bias_off,
+                                      reinterpret_cast<double*>(c.ws + P.red_off), c.stream));
     bd.in[0] = c.act_in(d.in_act[0]);
     bd.dz[0] = dlh;
   } else {

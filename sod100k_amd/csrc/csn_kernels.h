@@ -254,7 +254,7 @@ struct PoolBwdArgs {
 };
 int csn_launch_avgpool2_bwd(const PoolBwdArgs& a, void* stream);
 int csn_launch_maxpool_bwd_add(const PoolBwdArgs& a, void* stream);
-int csn_launch_sum_to_grad(const float* in, int64_t n, float* dst, void* stream);
+int csn_launch_sum_to_grad(const float* in, int64_t n, float* dst, double* partial /* >= 512 */, void* stream);
 int csn_launch_bce(const float* y, const float* t, float* dy, int64_t n, double* loss, void* stream);
 
 struct AdamArgs {

@@ -379,11 +379,19 @@ __global__ __launch_bounds__(CSN_BLOCK) void maxpool_bwd_add_kernel(PoolBwdArgs 
   }
 }
 
-// dst[0] = sum in[0..n)   (cls bias gradient; single block, fixed order)
-__global__ __launch_bounds__(CSN_BLOCK) void sum_to_grad_kernel(const float* in, int64_t n, float* dst) {
+// dst[0] = sum in[0..n)   (cls bias gradient): per-block fp64 partials, then one block in a fixed order
+__global__ __launch_bounds__(CSN_BLOCK) void sum_partial_kernel(const float* in, int64_t n, double* partial) {
   CSN_DYN_SMEM(double, sm);
   double s = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += CSN_BLOCK) s += (double)in[i];
+  for (int64_t i = (int64_t)blockIdx.x * CSN_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CSN_BLOCK) s += (double)in[i];
+  s = bn_block_sum(s, sm);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(CSN_BLOCK) void sum_final_kernel(const double* partial, int nblk, float* dst) {
+  CSN_DYN_SMEM(double, sm);
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += CSN_BLOCK) s += partial[i];
   s = bn_block_sum(s, sm);
   if (threadIdx.x == 0) dst[0] = (float)s;
 }
@@ -477,8 +485,10 @@ int csn_launch_maxpool_bwd_add(const PoolBwdArgs& a, void* stream) {
   CSN_LAUNCH(maxpool_bwd_add_kernel, dim3(grid_for((int64_t)a.planes * a.Hl * a.Wl)), dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
 }
-int csn_launch_sum_to_grad(const float* in, int64_t n, float* dst, void* stream) {
-  CSN_LAUNCH(sum_to_grad_kernel, dim3(1), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, in, n, dst);
+int csn_launch_sum_to_grad(const float* in, int64_t n, float* dst, double* partial, void* stream) {
+  const int nblk = grid_for(n) < 512 ? grid_for(n) : 512;
+  CSN_LAUNCH(sum_partial_kernel, dim3(nblk), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, in, n, partial);
+  CSN_LAUNCH(sum_final_kernel, dim3(1), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, partial, nblk, dst);
   return (int)hipGetLastError();
 }
 int csn_launch_bce(const float* y, const float* t, float* dy, int64_t n, double* loss, void* stream) {
