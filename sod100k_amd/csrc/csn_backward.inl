@@ -79,7 +79,7 @@ WgPlan make_wg(const PwLaunchPlan& L, const PwPassPlan& pp) {
   for (const WBlock& b : pp.wb) {
     if (b.eye) continue;
     WgBlock g;
-    g.dst = b.src; g.ld = b.ld; g.ncol = b.ncol; g.col = b.col; g.scale = b.scale;
+    g.dst = b.src; g.ld = b.ld; g.ncol = b.ncol; g.col = b.col; g.scale = b.scale; g.tk = b.tk;
     w.blocks.push_back(g);
   }
   return w;
@@ -206,17 +206,26 @@ int plan_ms_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
   ub.need_dx[0] = d.in_act[0] > 0;
   int cobase[CSN_NDIL], base = 0;
   for (int k = 0; k < CSN_NDIL; ++k) { cobase[k] = base; base += d.dil_ch[k]; }
-  for (int k = 0; k < CSN_NDIL; ++k) {
-    if (d.dil_ch[k] == 0) continue;
+  // weight gradient with the roles swapped: rows = the cin input channels (A = x), gathered = the dilated taps of the
+  // dz slices -- sum_d 9*dch_d gathered entries per pixel instead of 9*cin per dilation (5-10x fewer loads):
+  //   dW_d[co][ci][t] = 100 * sum_p' x[ci][p'] * dz[co][p' + dil*off(8 - t)]
+  for (int k0 = 0; k0 < CSN_NDIL;) {
     PwLaunchPlan L;
     L.lvl = u.base_lvl;
     PwPassPlan ps;
-    ps.r = 0; ps.nsrc = 1; ps.src_kind[0] = SRC_IN; ps.src_branch[0] = 0; ps.src_C[0] = cin; ps.src_mode[0] = PW_TAPS;
-    ps.src_dil[0] = 1 << k; ps.K = cin * 9; ps.nrows = d.dil_ch[k];
-    WBlock w; w.src = d.w_off[k]; w.ld = cin * 9; w.ncol = cin * 9; w.col = 0; w.scale = 100.f;
-    ps.wb.push_back(w);
+    ps.r = 0; ps.nrows = cin;
+    for (; k0 < CSN_NDIL && ps.nsrc < 3; ++k0) {
+      if (d.dil_ch[k0] == 0) continue;
+      const int s = ps.nsrc++;
+      ps.src_kind[s] = SRC_DZ; ps.src_branch[s] = 0; ps.src_C[s] = d.dil_ch[k0]; ps.src_mode[s] = PW_TAPS;
+      ps.src_dil[s] = 1 << k0; ps.src_c0[s] = cobase[k0]; ps.src_ctot[s] = cout;
+      WBlock w; w.src = d.w_off[k0]; w.ld = cin * 9; w.ncol = d.dil_ch[k0] * 9; w.col = ps.K; w.scale = 100.f; w.tk = 9;
+      ps.wb.push_back(w);
+      ps.K += d.dil_ch[k0] * 9;
+    }
+    if (ps.nsrc == 0) break;
     WgPlan wg = make_wg(L, ps);
-    wg.a_kind = SRC_DZ; wg.a_idx = 0; wg.a_c0 = cobase[k]; wg.a_ctot = cout;
+    wg.a_kind = SRC_IN; wg.a_idx = 0; wg.a_c0 = 0; wg.a_ctot = cin;
     ub.wg.push_back(wg);
   }
   if (!ub.need_dx[0]) return CSN_OK;
@@ -311,7 +320,7 @@ int run_wgrad(const BwdCtx& b, const WgPlan& w, const PwBind& bd) {
   fill_pass(b.c, w.L, pp, bd, a.ps);
   a.Hr = P.H >> w.L.lvl; a.Wr = P.W >> w.L.lvl; a.B = P.S;
   const int64_t hw = (int64_t)a.Hr * a.Wr;
-  const float* ab = w.a_kind == SRC_ADJ ? bd.adj[w.a_idx] : bd.dz[w.a_idx];
+  const float* ab = w.a_kind == SRC_ADJ ? bd.adj[w.a_idx] : (w.a_kind == SRC_IN ? bd.in[w.a_idx] : bd.dz[w.a_idx]);
   a.a_ctot = w.a_ctot;
   a.gpp = (int)((hw + 63) / 64);
   a.ngroups = a.gpp * P.S;
@@ -329,8 +338,12 @@ int run_wgrad(const BwdCtx& b, const WgPlan& w, const PwBind& bd) {
     r.partial = a.partial; r.grad = b.grad;
     r.nblocks = (int)w.blocks.size();
     for (int q = 0; q < 3; ++q)
-      if (q < r.nblocks) { r.blk[q] = w.blocks[q]; r.blk[q].dst += (int64_t)r0 * r.blk[q].ld; }
-      else { r.blk[q].dst = 0; r.blk[q].ld = 0; r.blk[q].ncol = 0; r.blk[q].col = 0; r.blk[q].scale = 0.f; }
+      if (q < r.nblocks) {
+        r.blk[q] = w.blocks[q];
+        r.blk[q].dst += (int64_t)r0 * (r.blk[q].tk > 0 ? r.blk[q].tk : r.blk[q].ld);
+      } else {
+        r.blk[q].dst = 0; r.blk[q].ld = 0; r.blk[q].ncol = 0; r.blk[q].col = 0; r.blk[q].scale = 0.f; r.blk[q].tk = 0;
+      }
     r.nblk = a.nblk; r.nrows = nr; r.K = pp.K; r.rows16 = a.rows16; r.k16 = a.k16;
     LAUNCH_TRY(csn_launch_wgrad_reduce(r, b.c.stream));
   }

@@ -152,6 +152,8 @@ struct WgBlock {        // one rectangular block of weight columns inside the re
   int64_t dst;          // float offset into the gradient arena
   int32_t ld, ncol, col;
   float scale;          // 100 for Conv2dX100 weights (conv2d.py:104), else 1
+  int32_t tk;           // > 0: the pass computed dW^T with flipped taps: element (r, col + co*tk + t) belongs to
+                        //      grad[dst + co*ld + r*tk + (tk-1-t)]   (MSBlock: gather dz taps, rows = input channels)
 };
 struct WgReduceArgs {
   const float* partial;

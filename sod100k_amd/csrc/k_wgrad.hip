@@ -227,7 +227,10 @@ __global__ __launch_bounds__(CSN_BLOCK) void wgrad_reduce_kernel(WgReduceArgs a)
   for (int q = 0; q < 3; ++q)
     if (q < a.nblocks && k >= a.blk[q].col && k < a.blk[q].col + a.blk[q].ncol) bi = q;
   if (bi < 0) return;   // identity columns (already convolved partial sums) carry no parameter
-  a.grad[a.blk[bi].dst + (int64_t)r * a.blk[bi].ld + (k - a.blk[bi].col)] = (float)((double)a.blk[bi].scale * s);
+  const int c = k - a.blk[bi].col, tk = a.blk[bi].tk;
+  const int64_t idx = tk > 0 ? (int64_t)(c / tk) * a.blk[bi].ld + (int64_t)r * tk + (tk - 1 - c % tk)
+                             : (int64_t)r * a.blk[bi].ld + c;
+  a.grad[a.blk[bi].dst + idx] = (float)((double)a.blk[bi].scale * s);
 }
 
 // wave-private variant: 4 groups per block step; returns false when the pass does not fit it
