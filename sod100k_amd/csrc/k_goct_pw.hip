@@ -132,7 +132,14 @@ __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
   const int H0 = a->H0, W0 = a->W0, npass = a->npass;
   const int tiles_xy = a->tiles_x * a->tiles_y;
   const int ntiles = tiles_xy * a->B;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (blockIdx.x & 7), each with its own L2.
+  // XCD x walks the contiguous tile range [x*chunk, (x+1)*chunk) -- neighbouring tiles (shared halo rows, the
+  // low-resolution sources of the bilinear / pooled slices) then hit the same L2 instead of 8 different ones.
+  const int nslot = gridDim.x >> 3;                 // gridDim.x is a multiple of 8
+  const int chunk = (ntiles + 7) >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int tend = min((xcd + 1) * chunk, ntiles);
+  for (int tile = xcd * chunk + (blockIdx.x >> 3); tile < tend; tile += nslot) {
     const int b = tile / tiles_xy;
     const int txy = tile - b * tiles_xy;
     const int tyl = a->ty_log2;   // tile height 16 / 8 / 4 rows of branch 0 (small maps get more, smaller tiles)
@@ -166,7 +173,8 @@ __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
 
 int csn_launch_pw(const PwArgs& a, int raw, void* stream) {
   const int ntiles = a.tiles_x * a.tiles_y * a.B;
-  const dim3 grid(ntiles < PW_MAX_GRID ? ntiles : PW_MAX_GRID);
+  const int nblk = ntiles < PW_MAX_GRID ? ntiles : PW_MAX_GRID;
+  const dim3 grid((nblk + 7) & ~7);   // multiple of 8: see the XCD-aware tile order in the kernel
   const size_t lds = ((size_t)a.wimg_floats + 4 * PW_KC * PW_XP) * sizeof(float);
 #ifndef CSN_CPU_EMU
   static bool attr_done = false;
