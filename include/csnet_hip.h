@@ -103,8 +103,10 @@ void csn_plan_destroy(csn_plan* plan);
  * (conv3x3_1 -> conv3x3_2, csnet.py:74-75) as one kernel that keeps the intermediate in LDS; with 0 every
  * unit's output is materialised in the workspace (per-unit parity probes).
  * CSN_OPT_GRAPH [1]: csn_forward captures its launch sequence into a hipGraph on the second call with the same
- * (x, y, workspace) and replays it afterwards (launch-gap removal); 0 = always launch eagerly. */
-enum csn_option { CSN_OPT_FUSE_DW = 1, CSN_OPT_GRAPH = 2 };
+ * (x, y, workspace) and replays it afterwards (launch-gap removal); 0 = always launch eagerly.
+ * CSN_OPT_FUSE_CLS [1]: the cls_layer (1x1 + bias, csnet.py:306-308) is evaluated in the epilogue of the unit that
+ * feeds it (CSFHead.fuse1x1), whose 79-channel output is then never written; 0 = separate launches (probes). */
+enum csn_option { CSN_OPT_FUSE_DW = 1, CSN_OPT_GRAPH = 2, CSN_OPT_FUSE_CLS = 3 };
 int csn_plan_set_option(csn_plan* plan, int32_t option, int32_t value);
 
 size_t csn_plan_workspace_bytes(const csn_plan* plan);

@@ -21,6 +21,7 @@ NDIL = 5
 UNIT_GOCT, UNIT_DW, UNIT_MS, UNIT_CLS = 1, 2, 3, 4
 OPT_FUSE_DW = 1
 OPT_GRAPH = 2
+OPT_FUSE_CLS = 3
 
 
 class ActDesc(C.Structure):

@@ -88,6 +88,10 @@ struct PwPass {
   const float* scale;
   const float* shift;
   const float* alpha;
+  // row reduction (cls_layer fused into the pass that feeds it): instead of storing its nrows channels the pass
+  // stores ONE channel  red_b[0] + sum_r red_w[r] * y_r  (null: normal pass)
+  const float* red_w;
+  const float* red_b;
 };
 struct PwArgs {
   PwPass pass[PW_MAX_PASS];

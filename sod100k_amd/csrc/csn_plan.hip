@@ -97,6 +97,7 @@ struct UnitPlan {
   int64_t dw_w[3] = {-1, -1, -1};
   Epi dw_epi[3];
   int fuse_next = 0;   // DW: the next unit is the second depthwise unit of the same ILBlock
+  int fuse_cls = 0;    // GOCT: the next unit is the cls_layer and nobody else reads this unit's output
   Epi out_epi[3];                        // folded BN/PReLU tables of every output branch (train mode rewrites them)
   int64_t stats_off[3] = {-1, -1, -1};   // workspace byte offsets of the BN statistics partials
   // training (csn_plan_enable_training): per output branch batch mean / invstd / backward means (packed offsets),
@@ -127,6 +128,7 @@ struct csn_plan {
   bool params_ready = false;
   bool bn_tables_train = false;   // csn_forward_train overwrote the folded BN tables: refresh before eval
   bool fuse_dw = true;
+  bool fuse_cls = true;   // CSN_OPT_FUSE_CLS
   Epi ident;   // identity epilogue (scale 1, shift 0, alpha 1): train mode runs the conv kernels raw
   bool use_graph = true;
   // hipGraph of one whole csn_forward (all batch slices), captured on a plan-owned stream on the second
@@ -523,6 +525,8 @@ struct PwBind {
   float* logits = nullptr;                             // OUT_LOGITS
   float* dx[3] = {nullptr, nullptr, nullptr};          // OUT_DX
   float* tmp = nullptr;                                // OUT_TMP
+  const float* red_w = nullptr;                        // fused cls_layer: weights / bias, result -> `logits`
+  const float* red_b = nullptr;
 };
 
 // kernel-side descriptor of one pass: source slices (resolved pointers), weight rows, output, epilogue
@@ -568,6 +572,10 @@ void fill_pass(const Ctx& c, const PwLaunchPlan& L, const PwPassPlan& pp, const 
     default: ob = bd.act[pp.out_branch]; break;
   }
   ps.out = ob ? ob + (int64_t)pp.out_c0 * Hr * Wr : nullptr;
+  ps.red_w = ps.red_b = nullptr;
+  if (bd.red_w && pp.out_kind == OUT_ACT) {   // rows are reduced into the half-resolution logits
+    ps.red_w = bd.red_w + pp.out_c0; ps.red_b = bd.red_b; ps.out = bd.logits;
+  }
   ps.out_ctot = pp.out_ctot; ps.pad2 = 0;
   const bool bn_out = pp.out_kind == OUT_ACT;   // scratch, logits and gradients have no BN
   ps.scale = bn_out ? c.sc(pp.epi) : c.pk(pp.epi.scale);
@@ -672,9 +680,21 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
       for (int j = 0; j < d.n_out; ++j)
         if (d.cout[j] > 0) bd.act[j] = c.act_out(d.out_act[j]);
       if (u.z_off >= 0) bd.z = bd.zout = reinterpret_cast<float*>(c.ws + u.z_off);
+      if (next && next->d.kind == CSN_UNIT_CLS) {   // cls_layer (csnet.py:306-308,381) rides in this unit's epilogue
+        const PwLaunchPlan& CL = next->pwl[0];
+        bd.red_w = c.pk(CL.wimg + CL.passes[0].w_off);
+        bd.red_b = c.pk(CL.passes[0].epi.shift);
+        bd.logits = reinterpret_cast<float*>(c.ws + next->logits_off);
+      }
       for (const PwLaunchPlan& L : u.pwl) {
         const int st = launch_pw(c, L, bd);
         if (st != CSN_OK) return st;
+      }
+      if (next && next->d.kind == CSN_UNIT_CLS) {
+        Up2Args ua;
+        ua.in = bd.logits; ua.out = c.y; ua.planes = S; ua.H = P.H; ua.W = P.W;
+        LAUNCH_TRY(csn_launch_up2(ua, c.stream));
+        { const int ms_ = c.mark("bilinear_up2_kernel"); if (ms_ != CSN_OK) return ms_; }
       }
     } break;
     case CSN_UNIT_MS: {
@@ -813,6 +833,20 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
     }
     if (ok) { P->units[k].fuse_next = 1; ++k; }
   }
+  // cls fusion: a single-output, single-launch 1x1 unit whose only reader is the cls_layer that follows it
+  for (int k = 0; k + 1 < n_units; ++k) {
+    const csn_unit_desc& a = P->units[k].d;
+    const csn_unit_desc& b = P->units[k + 1].d;
+    if (a.kind != CSN_UNIT_GOCT || b.kind != CSN_UNIT_CLS || a.n_out != 1 || a.ksize != 1) continue;
+    if (b.in_act[0] != a.out_act[0] || P->units[k].pwl.size() != 1 || P->units[k].pwl[0].passes.size() != 1) continue;
+    bool ok = true;
+    for (int q = 0; q < n_units && ok; ++q) {
+      if (q == k + 1) continue;
+      for (int s = 0; s < CSN_MAX_BRANCH; ++s)
+        if (s < P->units[q].d.n_in && P->units[q].d.cin[s] > 0 && P->units[q].d.in_act[s] == a.out_act[0]) ok = false;
+    }
+    if (ok) P->units[k].fuse_cls = 1;
+  }
   {  // identity epilogue + per-BN statistics partials for the train-mode forward
     int maxc = 1;
     for (int i = 0; i < n_acts; ++i) maxc = std::max(maxc, (int)acts[i].channels);
@@ -855,6 +889,7 @@ int csn_plan_set_option(csn_plan* P, int32_t option, int32_t value) {
   switch (option) {
     case CSN_OPT_FUSE_DW: P->fuse_dw = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_GRAPH: P->use_graph = value != 0; drop_graph(P); return CSN_OK;
+    case CSN_OPT_FUSE_CLS: P->fuse_cls = value != 0; drop_graph(P); return CSN_OK;
     default: return CSN_E_INVALID;
   }
 }
@@ -910,7 +945,7 @@ static int forward_body(csn_plan* P, const float* x, float* y, void* workspace, 
         if (st0 != CSN_OK) { P->profiling = false; return st0; }
       }
       for (int u = 0; u < nu; ++u) {
-        const bool fuse = P->fuse_dw && P->units[u].fuse_next && u + 1 < nu;
+        const bool fuse = u + 1 < nu && ((P->fuse_dw && P->units[u].fuse_next) || (P->fuse_cls && P->units[u].fuse_cls));
         const size_t t0 = P->tags.size();
         const int st = run_unit(c, P->units[u], fuse ? &P->units[u + 1] : nullptr);
         if (st != CSN_OK) { P->profiling = false; return st; }

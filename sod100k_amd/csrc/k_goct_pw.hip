@@ -64,7 +64,7 @@ __device__ __forceinline__ void pw_contract(const float* wl, int stride, const f
 // VGPR offset per lane, the channel offset rides in an SGPR; lanes outside the image are exec-masked).
 template <int NT, bool RAW>
 __device__ __forceinline__ void pw_sweep(PwPassP ps, const float* wl0, float* xb, int row0, int b, int gy, int gx,
-                                         int Hr, int Wr, unsigned ovoff, bool valid, int lane) {
+                                         int Hr, int Wr, unsigned ovoff, bool valid, int lane, float& red) {
   const int cin = ps->cin, cin4 = ps->cin4, nrows = ps->nrows, stride = ps->w_stride;
   const int c1 = ps->src[0].K, c2 = c1 + ps->src[1].K;
   csn_f4 acc[NT][4];
@@ -103,6 +103,12 @@ __device__ __forceinline__ void pw_sweep(PwPassP ps, const float* wl0, float* xb
     const int rbase = row0 + 16 * t;
     const int rn = min(16, nrows - rbase);
     csn_cfp scale = csn_const(ps->scale) + rbase, shift = csn_const(ps->shift) + rbase, alpha = csn_const(ps->alpha) + rbase;
+    if (!RAW && ps->red_w) {   // fused 1x1 consumer (cls_layer): accumulate w[r] * y_r per pixel, nothing is stored here
+      csn_cfp rw = csn_const(ps->red_w) + rbase;
+#pragma unroll 4
+      for (int rr = 0; rr < rn; ++rr) red = fmaf(rw[rr], csn_epi(xb[rr * PW_EP + lane], scale[rr], shift[rr], alpha[rr]), red);
+      continue;
+    }
 #pragma unroll 4
     for (int rr = 0; rr < rn; ++rr) {
       const float val = RAW ? xb[rr * PW_EP + lane] : csn_epi(xb[rr * PW_EP + lane], scale[rr], shift[rr], alpha[rr]);
@@ -161,9 +167,14 @@ __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
         const bool valid = p < npx && py_ < Hr && px_ < Wr;
         const int gy = min(py_, Hr - 1), gx = min(px_, Wr - 1);     // lanes off the image gather a valid pixel
         const unsigned ovoff = (unsigned)(gy * Wr + gx) * 4u;        // ... and store nothing (exec-masked)
+        float red = 0.f;
         for (int row0 = 0; row0 < nrows; row0 += 32) {
-          if (nrows - row0 <= 16) pw_sweep<1, RAW>(ps, wl0, xb, row0, b, gy, gx, Hr, Wr, ovoff, valid, lane);
-          else pw_sweep<2, RAW>(ps, wl0, xb, row0, b, gy, gx, Hr, Wr, ovoff, valid, lane);
+          if (nrows - row0 <= 16) pw_sweep<1, RAW>(ps, wl0, xb, row0, b, gy, gx, Hr, Wr, ovoff, valid, lane, red);
+          else pw_sweep<2, RAW>(ps, wl0, xb, row0, b, gy, gx, Hr, Wr, ovoff, valid, lane, red);
+        }
+        if (!RAW && ps->red_w && valid) {   // out: [B][1][Hr][Wr]
+          const csn_buf ob = csn_make_buf(ps->out + (int64_t)b * (Hr * Wr));
+          csn_st1(ob, ovoff, 0, red + csn_const(ps->red_b)[0]);
         }
       }
       gbase += ng;

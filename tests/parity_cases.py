@@ -54,6 +54,7 @@ def check_unit_probes(lib, device, manifest):
     x = torch.from_numpy(I.randn_batch(0, 2)).to(device)
     eng = m.engine_for(x)
     eng.set_option(N.OPT_FUSE_DW, 0)      # materialise every unit's output for the probes
+    eng.set_option(N.OPT_FUSE_CLS, 0)
     m(x)
     units, acts, names = m.describe(m._arena.offsets)
     probes = json.load(open(os.path.join(GOLD, "g3_unit_probes_x2.json")))
