@@ -44,6 +44,9 @@ struct DwBranch {
   const float* scale_b;
   const float* shift_b;
   const float* alpha_b;
+  float* pool;           // dw3x3x2 only: 2x2 average of the pair's output [B*C][H/2][W/2] for the stride-2 unit that
+                         // follows (csnet.py:679-680), null = none;  skip_out: that unit is the only reader
+  int32_t skip_out;
   int32_t C, H, W;
   int32_t LX, NY, R;          // lanes per row (4 px each), lane rows per block, rows per lane
   int32_t tiles_x, tiles_y;   // tiles per plane

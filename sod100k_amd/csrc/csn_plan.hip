@@ -98,6 +98,9 @@ struct UnitPlan {
   Epi dw_epi[3];
   int fuse_next = 0;   // DW: the next unit is the second depthwise unit of the same ILBlock
   int fuse_cls = 0;    // GOCT: the next unit is the cls_layer and nobody else reads this unit's output
+  int pool_unit = -1;  // DW (first of a fused pair): index of the stride-2 unit whose pooled inputs the pair writes
+  int pool_skip[3] = {0, 0, 0};   // ... and that unit is the only reader of branch i (full-resolution store skipped)
+  int pooled_by_producer = 0;     // GOCT stride 2: the preceding fused depthwise pair delivers the pooled inputs
   Epi out_epi[3];                        // folded BN/PReLU tables of every output branch (train mode rewrites them)
   int64_t stats_off[3] = {-1, -1, -1};   // workspace byte offsets of the BN statistics partials
   // training (csn_plan_enable_training): per output branch batch mean / invstd / backward means (packed offsets),
@@ -485,13 +488,13 @@ struct Ctx {
 };
 
 // rows per lane of the fused depthwise pair: the intermediate tile (NY*R + 2 rows) must stay small in LDS
-int choose_dw2_rows(int H, int NY, int LX) {
-  int best = 1;
+int choose_dw2_rows(int H, int NY, int LX, bool even = false) {
+  int best = even ? 2 : 1;
   double best_s = -1;
-  for (int R = 1; R <= 16; ++R) {
+  for (int R = even ? 2 : 1; R <= 16; R += even ? 2 : 1) {
     const int rows = NY * R;
     const size_t lds = (size_t)(rows + 2) * (LX * 4 + 8) * 4;
-    if (lds > 36 * 1024 && R > 1) break;
+    if (lds > 36 * 1024 && R > (even ? 2 : 1)) break;
     const int tiles = (H + rows - 1) / rows;
     const double eff = (double)H / ((double)tiles * rows);
     const double s = eff * rows / (rows + 4.0);   // halo rows are fetched and computed twice
@@ -628,6 +631,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
         br.w9 = c.pk(u.dw_w[k]);
         br.scale = c.sc(u.dw_epi[k]); br.shift = c.sh(u.dw_epi[k]); br.alpha = c.al(u.dw_epi[k]);
         br.w9b = br.scale_b = br.shift_b = br.alpha_b = nullptr;
+        br.pool = nullptr; br.skip_out = 0;
         br.C = d.cout[k]; br.H = P.H >> act.lvl; br.W = P.W >> act.lvl;
         const int cols = (br.W + 3) / 4;
         br.LX = cols < 64 ? cols : 64;
@@ -637,7 +641,12 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
           br.w9b = c.pk(next->dw_w[k]);
           br.scale_b = c.pk(next->dw_epi[k].scale); br.shift_b = c.pk(next->dw_epi[k].shift);
           br.alpha_b = c.pk(next->dw_epi[k].alpha);
-          br.R = choose_dw2_rows(br.H, br.NY, br.LX);
+          const bool pool = u.pool_unit >= 0 && (br.W % 4) == 0;
+          if (pool) {   // the stride-2 unit that follows reads only the 2x2 averages
+            br.pool = reinterpret_cast<float*>(c.ws + P.units[u.pool_unit].pooled_off[k]);
+            br.skip_out = u.pool_skip[k];
+          }
+          br.R = choose_dw2_rows(br.H, br.NY, br.LX, pool);
         } else {
           br.R = choose_dw_rows(br.H, br.NY);
         }
@@ -653,7 +662,10 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
     case CSN_UNIT_GOCT: {
       // optional 2x2 avg-pool prologue of every input branch (csnet.py:679-680)
       const float* xin[3] = {nullptr, nullptr, nullptr};
-      if (d.stride == 2) {
+      if (d.stride == 2 && u.pooled_by_producer && P.fuse_dw && !c.raw) {
+        for (int i = 0; i < d.n_in; ++i)
+          if (d.cin[i] > 0) xin[i] = reinterpret_cast<const float*>(c.ws + u.pooled_off[i]);
+      } else if (d.stride == 2) {
         PoolArgs pa;
         pa.n = 0;
         int blk = 0;
@@ -832,6 +844,31 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
       }
     }
     if (ok) { P->units[k].fuse_next = 1; ++k; }
+  }
+  // pooled outputs: a fused depthwise pair directly followed by the stride-2 unit that consumes all its branches
+  for (int k = 0; k + 2 < n_units; ++k) {
+    if (!P->units[k].fuse_next) continue;
+    const csn_unit_desc& b = P->units[k + 1].d;
+    const csn_unit_desc& g = P->units[k + 2].d;
+    if (g.kind != CSN_UNIT_GOCT || g.stride != 2 || g.n_in != b.n_out) continue;
+    bool ok = true;
+    for (int i = 0; i < g.n_in && ok; ++i) {
+      if (g.cin[i] != b.cout[i] || (g.cin[i] > 0 && g.in_act[i] != b.out_act[i])) ok = false;
+      if (g.cin[i] > 0 && ((W >> P->acts[b.out_act[i]].lvl) % 4) != 0) ok = false;
+    }
+    if (!ok) continue;
+    P->units[k].pool_unit = k + 2;
+    P->units[k + 2].pooled_by_producer = 1;
+    for (int i = 0; i < g.n_in; ++i) {
+      if (g.cin[i] == 0) continue;
+      bool only = true;
+      for (int q = 0; q < n_units && only; ++q) {
+        if (q == k + 2) continue;
+        for (int s = 0; s < CSN_MAX_BRANCH; ++s)
+          if (s < P->units[q].d.n_in && P->units[q].d.cin[s] > 0 && P->units[q].d.in_act[s] == b.out_act[i]) only = false;
+      }
+      P->units[k].pool_skip[i] = only ? 1 : 0;
+    }
   }
   // cls fusion: a single-output, single-launch 1x1 unit whose only reader is the cls_layer that follows it
   for (int k = 0; k + 1 < n_units; ++k) {

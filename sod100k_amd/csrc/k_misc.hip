@@ -285,6 +285,8 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3x2_bn_prelu_kernel(DwArgs a) {
     };
     const int rs = ly * R;
     DwRow top = ld_row(rs), mid = ld_row(rs + 1);
+    float* __restrict__ pp = br.pool ? br.pool + (int64_t)pc * (H >> 1) * (W >> 1) : nullptr;   // R is even then
+    float e0 = 0.f, e1 = 0.f;   // left-to-right sums of the even row's two column pairs
     for (int q = 0; q < R; ++q) {
       const int y = yb + rs + q;
       if (y >= H) break;
@@ -304,8 +306,19 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3x2_bn_prelu_kernel(DwArgs a) {
         o[j] = csn_epi(acc, sc, sh, al);
       }
       float* q4 = op + (int64_t)y * W + x0;
+      if (VEC && pp) {   // avg_pool2d(2, 2) of the output, same summation order as avgpool2_kernel
+        if ((q & 1) == 0) {
+          e0 = o[0] + o[1];
+          e1 = o[2] + o[3];
+        } else {
+          float2 pv;
+          pv.x = (e0 + o[0] + o[1]) * 0.25f;
+          pv.y = (e1 + o[2] + o[3]) * 0.25f;
+          *reinterpret_cast<float2*>(pp + (int64_t)(y >> 1) * (W >> 1) + (x0 >> 1)) = pv;
+        }
+      }
       if (VEC) {
-        *reinterpret_cast<float4*>(q4) = make_float4(o[0], o[1], o[2], o[3]);
+        if (!br.skip_out) *reinterpret_cast<float4*>(q4) = make_float4(o[0], o[1], o[2], o[3]);
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
