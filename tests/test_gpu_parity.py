@@ -126,3 +126,43 @@ def test_gpu_train_step_golden(hip, x2_manifest, idx):
 def test_gpu_autograd_seam(hip, x2_manifest):
     lib, dev = hip
     P.check_autograd_seam(lib, dev, x2_manifest, B=2, size=64)
+
+
+@pytest.mark.parametrize("B,size", [(1, 48), (3, 16), (2, 112)])
+def test_gpu_train_step_shapes(hip, x2_manifest, B, size):
+    """Edge shapes of the train step: single image, the 16-pixel minimum (1x1 maps on the lowest branch), mid size."""
+    lib, dev = hip
+    rel = 2e-3 if size >= 48 else 2e-2      # 16x16: BN over 1..4 samples per channel at the deep layers
+    worst, loss, pen = P.check_train_step(lib, dev, x2_manifest, B=B, size=size, rel=rel)
+    print(f"B={B} {size}x{size}: worst relative gradient error {worst:.2e}")
+
+
+def test_gpu_train_nonsquare_and_repeat(hip, x2_manifest):
+    """Non-square input; two consecutive steps (state carried in the arena: weights, BN buffers, Adam moments)."""
+    from sod100k_amd.tools.train import FusedTrainer
+    lib, dev = hip
+    m, sd = P.make_model(lib, x2_manifest, dev)
+    m.train(); m.set_batchsize(2); m.clear_flops(); m.flops_hook(1.0)
+    # eps 1e-3: with the default 1e-8 Adam's first steps move every element by ~lr * sign(g), so elements whose
+    # gradient is rounding noise walk in implementation-dependent directions (see check_train_golden_step)
+    tr = FusedTrainer(m, lr=1e-4, weight_decay=5e-3, eps=1e-3, flops_weight=3.0, batchsize=2, lib=lib)
+    cfg = O.load_layer_config_json(x2_manifest)
+    sd_ref = {k: v.clone() for k, v in sd.items()}
+    state = None
+    for step in range(2):
+        x = torch.from_numpy(I.randn_batch(20 + step, 2, 64, 96))
+        t = torch.from_numpy(I.binary_target(30 + step, 2, 64, 96))
+        loss, pen = tr.step(x.to(dev), t.to(dev))
+        m.clear_flops()
+        r = O.train_step(cfg, sd_ref, x, t, expandflop=1.0, flops_weight=3.0, batchsize=2, lr=1e-4, wd=5e-3, eps=1e-3,
+                         adam_state=state)
+        state = r["adam_state"]
+        # step 1 starts from parameters that already carry the first step's ~1e-3 relative gradient differences
+        tol = 2e-5 if step == 0 else 1e-3
+        assert abs(float(loss) - r["loss_bce"]) <= tol * max(1.0, abs(r["loss_bce"])), (step, float(loss), r["loss_bce"])
+    got = m.state_dict()
+    for k, v in sd_ref.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(got[k]) == int(v), k       # both advanced by 2
+        elif k.endswith("running_mean") or k.endswith("running_var"):
+            assert ((got[k].cpu() - v).abs() / (1 + v.abs())).max().item() <= 1e-4, k
