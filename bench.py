@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--sub-batch", type=int, default=int(os.environ.get("CSN_SUB_BATCH", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=5)
+    ap.add_argument("--no-fuse-cls", action="store_true",
+                    help="keep cls_layer as its own launch (PMC calibration: it reads exactly 79x112x112x4 B per image)")
     ap.add_argument("--train-batch", type=int, default=256,
                     help="images per GPU per train step (SURVEY 8(d) config 3: 256; 0 = --batch)")
     ap.add_argument("--train-steps", type=int, default=10,
@@ -92,6 +94,9 @@ def main():
     x = torch.randn(B, 3, 224, 224, generator=g).to(dev)        # synthetic, resident in HBM before timing
     eng = model.engine_for(x)
     eng.refresh(model._arena.flat)
+    if args.no_fuse_cls:
+        from sod100k_amd import _native as N
+        eng.set_option(N.OPT_FUSE_CLS, 0)
     y = torch.empty(B, 1, 224, 224, device=dev)
 
     def step():

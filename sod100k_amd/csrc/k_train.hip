@@ -344,6 +344,51 @@ __global__ __launch_bounds__(CSN_BLOCK) void adjup_kernel(AdjUpArgs a) {
   }
 }
 
+// f = 2, even source width: one thread produces TWO neighbouring source pixels (xs even) from the 4 x 6 window of
+// outputs they receive from -- per row one aligned float4 (columns 2 xs .. 2 xs + 3) and the two edge columns.
+__global__ __launch_bounds__(CSN_BLOCK) void adjup2_pair_kernel(AdjUpArgs a) {
+  const int Hl = a.Hl, Wl = a.Wl, Wp = Wl >> 1;
+  const int Hh = Hl * 2, Wh = Wl * 2;
+  const int64_t tot = (int64_t)a.planes * Hl * Wp;
+  for (int64_t e = (int64_t)blockIdx.x * CSN_BLOCK + threadIdx.x; e < tot; e += (int64_t)gridDim.x * CSN_BLOCK) {
+    const int64_t pl = e / (Hl * Wp);
+    const int r = (int)(e - pl * Hl * Wp);
+    const int ys = r / Wp, xs = (r - ys * Wp) * 2;
+    const float* ip = a.in + pl * (int64_t)Hh * Wh;
+    // column weights of the six outputs 2 xs - 1 .. 2 xs + 4 towards source columns xs and xs + 1
+    float w0[6], w1[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int ox = 2 * xs - 1 + j;
+      int x0, x1; float lx;
+      csn_bilin(min(max(ox, 0), Wh - 1), 0.5f, Wl, x0, x1, lx);
+      const bool in = ox >= 0 && ox < Wh;
+      w0[j] = in ? (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f) : 0.f;
+      w1[j] = in ? (x0 == xs + 1 ? 1.f - lx : 0.f) + (x1 == xs + 1 ? lx : 0.f) : 0.f;
+    }
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int oy = 2 * ys - 1 + i;
+      if (oy < 0 || oy >= Hh) continue;
+      int y0, y1; float ly;
+      csn_bilin(oy, 0.5f, Hl, y0, y1, ly);
+      const float wy = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
+      const float* row = ip + (int64_t)oy * Wh + 2 * xs;
+      const float4 c = *reinterpret_cast<const float4*>(row);
+      const float l = row[xs > 0 ? -1 : 0], rr = row[2 * xs + 4 < Wh ? 4 : 3];
+      const float v[6] = {l, c.x, c.y, c.z, c.w, rr};
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) { t0 = fmaf(w0[j], v[j], t0); t1 = fmaf(w1[j], v[j], t1); }
+      a0 = fmaf(wy, t0, a0);
+      a1 = fmaf(wy, t1, a1);
+    }
+    float* op = a.out + pl * (int64_t)Hl * Wl + (int64_t)ys * Wl + xs;
+    *reinterpret_cast<float2*>(op) = make_float2(a0, a1);
+  }
+}
+
 // adjoint of avg_pool2d(2, 2): dx[p] = 0.25 * dxp[p >> 1]
 __global__ __launch_bounds__(CSN_BLOCK) void avgpool2_bwd_kernel(PoolBwdArgs a) {
   const int Hh = a.Hl * 2, Wh = a.Wl * 2;
@@ -474,6 +519,10 @@ int csn_launch_dw_wgrad(const DwWgradArgs& a0, void* stream) {
   return (int)hipGetLastError();
 }
 int csn_launch_adjup(const AdjUpArgs& a, void* stream) {
+  if (a.f == 2 && (a.Wl & 1) == 0) {
+    CSN_LAUNCH(adjup2_pair_kernel, dim3(grid_for((int64_t)a.planes * a.Hl * (a.Wl >> 1))), dim3(CSN_BLOCK), 0, stream, a);
+    return (int)hipGetLastError();
+  }
   CSN_LAUNCH(adjup_kernel, dim3(grid_for((int64_t)a.planes * a.Hl * a.Wl)), dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
 }

@@ -6,10 +6,11 @@ mkdir -p gpurun_out/round
 R=$PWD
 ( timeout 900 python bench.py ) > gpurun_out/round/bench.json 2> gpurun_out/round/bench.err
 cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/round/trace $R/gpurun_out/round/fetch $R/gpurun_out/round/write
+rm -rf $R/gpurun_out/round/trace $R/gpurun_out/round/fetch $R/gpurun_out/round/write $R/gpurun_out/round/fetchcal
 ( timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/round/trace -o trace -- python $R/bench.py --no-cpu-baseline ) > $R/gpurun_out/round/trace.log 2>&1
 ( timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/round/fetch -o fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-iters 1 --train-steps 0 ) > $R/gpurun_out/round/fetch.log 2>&1
 ( timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/round/write -o write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-iters 1 --train-steps 0 ) > $R/gpurun_out/round/write.log 2>&1
+( timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/round/fetchcal -o fetchcal -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-iters 1 --train-steps 0 --no-fuse-cls ) > $R/gpurun_out/round/fetchcal.log 2>&1
 cd $R
 ls gpurun_out/round gpurun_out/round/trace | head -20
 tail -c 400 gpurun_out/round/bench.json

@@ -8,7 +8,8 @@ FETCH_SIZE reports exactly 1/2 of a wide (16 B/lane) coalesced stream, other wid
 known byte count in the kernel's own access pattern.  Calibration used here:
   * depthwise kernels (b128 loads): factor 2.0 (checks against in+halo bytes within 3 %);
   * goct_pw_kernel (dword buffer loads): factor from its cls_layer launch, which reads exactly
-    79 x 112 x 112 x 4 B x 64 images once (no re-reads, no halo);
+    79 x 112 x 112 x 4 B x 64 images once (no re-reads, no halo) -- taken from a third pass with
+    `--no-fuse-cls`, because the default plan evaluates cls_layer inside CSFHead.fuse1x1's epilogue;
   * WRITE_SIZE: factor 1.0 (cls launch writes 112 x 112 x 4 B x 64: matches within 2 %).
 """
 import collections
@@ -48,8 +49,9 @@ def main():
     assert [n for n, _ in fetch] == [n for n, _ in write]
     B = bench["config"]["batch_per_gpu"]
     cls_read = 79 * 112 * 112 * 4 * B
-    pw_idx = [i for i, (n, _) in enumerate(fetch) if n == "goct_pw_kernel"]
-    c_pw = cls_read / (fetch[pw_idx[-1]][1] * 1024)
+    cal = per_dispatch("fetchcal", "FETCH_SIZE")     # same command with --no-fuse-cls: the last pw launch is cls_layer
+    pw_idx = [i for i, (n, _) in enumerate(cal) if n == "goct_pw_kernel"]
+    c_pw = cls_read / (cal[pw_idx[-1]][1] * 1024)
     factor = collections.defaultdict(lambda: 2.0, {"goct_pw_kernel": c_pw, "msblock_kernel": c_pw})
     agg = collections.OrderedDict()
     for (n, f), (_, w) in zip(fetch, write):
