@@ -522,7 +522,6 @@ int csn_plan_enable_training(csn_plan* P) {
       u.tr_mean[j] = bl.alloc_packed(u.d.cout[j]);
       u.tr_invstd[j] = bl.alloc_packed(u.d.cout[j]);
       u.tr_m1m2[j] = bl.alloc_packed(2 * u.d.cout[j]);
-      u.gap_off[j] = bl.alloc_ws((int64_t)u.d.cout[j] * P->S * sizeof(float));
     }
   }
   for (int k = 0; k < nu; ++k) {

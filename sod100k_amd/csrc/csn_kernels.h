@@ -199,7 +199,7 @@ struct BnFinalizeArgs {
 struct BnApplyArgs {
   const float* z;     // raw conv output (kept for the backward pass)
   float* y;           // PReLU(BN(z))
-  float* gapabs;      // [C][S] |mean_hw y| per image (null: not needed)
+  float* gapabs;      // [C][S] |mean_hw y| per image (required when flop_w != 0)
   const float* scale;
   const float* shift;
   const float* alpha;

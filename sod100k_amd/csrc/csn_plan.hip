@@ -895,7 +895,10 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
     for (auto& u : P->units)
       if (u.d.kind != CSN_UNIT_CLS)
         for (int j = 0; j < u.d.n_out; ++j)
-          if (u.d.cout[j] > 0) u.stats_off[j] = bl.alloc_ws((int64_t)u.d.cout[j] * CSN_BN_NSLAB * 2 * sizeof(double));
+          if (u.d.cout[j] > 0) {
+            u.stats_off[j] = bl.alloc_ws((int64_t)u.d.cout[j] * CSN_BN_NSLAB * 2 * sizeof(double));
+            u.gap_off[j] = bl.alloc_ws((int64_t)u.d.cout[j] * P->S * sizeof(float));   // per-image |GAP| (penalty)
+          }
   }
   if (csn_kernels_init() != 0) { delete P; return CSN_E_HIP; }
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&P->packed), (size_t)(P->packed_floats + 4) * sizeof(float));
@@ -1082,7 +1085,7 @@ int csn_forward_train(csn_plan* P, const float* x, float* y, void* workspace, fl
       fa.invstd = P->packed + (P->train ? up.tr_invstd[j] : P->ident.dummy);
       LAUNCH_TRY(csn_launch_bn_finalize(fa, stream));
       BnApplyArgs aa; aa.z = z; aa.y = c.act_y(d.out_act[j]);
-      aa.gapabs = (P->train && up.gap_off[j] >= 0) ? reinterpret_cast<float*>(c.ws + up.gap_off[j]) : nullptr;
+      aa.gapabs = reinterpret_cast<float*>(c.ws + up.gap_off[j]);
       aa.scale = fa.scale; aa.shift = fa.shift; aa.alpha = P->packed + up.out_epi[j].alpha;
       aa.arena = arena; aa.penalty = penalty; aa.off_weight = d.bn[j].weight; aa.HW = hw; aa.S = P->S; aa.C = d.cout[j];
       aa.flop_w = flop_w[u * CSN_MAX_BRANCH + j];

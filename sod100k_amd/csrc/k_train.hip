@@ -146,21 +146,26 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_apply_gap_kernel(BnApplyArgs a) 
       s += (double)v;
     }
   }
-  if (a.flop_w != 0.f) {
+  if (a.flop_w != 0.f) {   // |mean_hw y| per (channel, image); bn_penalty_kernel turns the table into the penalty
     s = bn_block_sum(s, sm);
-    if (threadIdx.x == 0) {
-      const double g = (double)a.arena[a.off_weight + c];
-      const double gap = fabs(s / (double)hw);
-      if (a.gapabs) a.gapabs[(int64_t)c * a.S + n] = (float)gap;   // d penalty / d gamma needs sum_n |gap|
-      const double term = 0.5 * (double)a.flop_w * gap * g * g;
-#ifdef CSN_CPU_EMU
-#pragma omp atomic
-      *a.penalty += term;
-#else
-      atomicAdd(a.penalty, term);
-#endif
-    }
+    if (threadIdx.x == 0) a.gapabs[(int64_t)c * a.S + n] = (float)fabs(s / (double)hw);
   }
+}
+
+// penalty += 0.5 * w * sum_c gamma_c^2 * sum_n |gap[c][n]|   (Oct_bn_hook, csnet.py:391-410).  One block, fixed
+// summation order, plain read-modify-write of the device scalar (launches are stream ordered): deterministic, and no
+// fp64 atomics from thousands of blocks on one address.
+__global__ __launch_bounds__(CSN_BLOCK) void bn_penalty_kernel(BnApplyArgs a) {
+  CSN_DYN_SMEM(double, sm);
+  double t = 0.0;
+  for (int c = threadIdx.x; c < a.C; c += CSN_BLOCK) {
+    double sg = 0.0;
+    for (int n = 0; n < a.S; ++n) sg += (double)a.gapabs[(int64_t)c * a.S + n];
+    const double g = (double)a.arena[a.off_weight + c];
+    t += sg * g * g;
+  }
+  t = bn_block_sum(t, sm);
+  if (threadIdx.x == 0) *a.penalty += 0.5 * (double)a.flop_w * t;
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -496,6 +501,7 @@ int csn_launch_bn_finalize(const BnFinalizeArgs& a0, void* stream) {
 }
 int csn_launch_bn_apply(const BnApplyArgs& a, void* stream) {
   CSN_LAUNCH(bn_apply_gap_kernel, dim3(a.C, a.S), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
+  if (a.flop_w != 0.f) CSN_LAUNCH(bn_penalty_kernel, dim3(1), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   return (int)hipGetLastError();
 }
 
