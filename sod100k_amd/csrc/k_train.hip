@@ -186,14 +186,25 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_reduce_kernel(BnBwdArgs a) {
   const BnRange r = bn_range(slab, a.cpp, a.C, c, a.HW);
   const float sc = a.scale[c], sh = a.shift[c], al = a.alpha[c], mu = a.mean[c], is = a.invstd[c];
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  for (int i = r.beg + threadIdx.x; i < r.end; i += CSN_BLOCK) {
-    const int64_t idx = r.base + i;
-    const float z = a.z[idx], dy = bnb_dy(a, idx);
+  auto acc = [&](float z, float dy) {
     const float bn = z * sc + sh;
     const float dbn = bn > 0.f ? dy : al * dy;
     s0 += (double)dbn;
     s1 += (double)dbn * (double)((z - mu) * is);
     if (!(bn > 0.f)) s2 += (double)dy * (double)bn;
+  };
+  if ((a.HW & 3) == 0) {   // chunks start on float4 boundaries (bn_range)
+    const float4* z4 = reinterpret_cast<const float4*>(a.z + r.base);
+    const float4* a4 = reinterpret_cast<const float4*>(a.dyA + r.base);
+    const float4* b4 = a.dyB ? reinterpret_cast<const float4*>(a.dyB + r.base) : nullptr;
+    for (int i = (r.beg >> 2) + threadIdx.x; i < (r.end >> 2); i += CSN_BLOCK) {
+      const float4 z = z4[i];
+      float4 d = a4[i];
+      if (b4) { const float4 e = b4[i]; d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
+      acc(z.x, d.x); acc(z.y, d.y); acc(z.z, d.z); acc(z.w, d.w);
+    }
+  } else {
+    for (int i = r.beg + threadIdx.x; i < r.end; i += CSN_BLOCK) acc(a.z[r.base + i], bnb_dy(a, r.base + i));
   }
   s0 = bn_block_sum(s0, sm);
   s1 = bn_block_sum(s1, sm);
