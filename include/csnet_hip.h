@@ -154,6 +154,14 @@ int csn_bce_with_logits(const float* y, const float* t, float* dy, int64_t n, do
 int csn_adam_step(float* p, const float* g, float* m, float* v, const float* wd, int64_t n, float lr, float beta1,
                   float beta2, float eps, int32_t step, void* stream);
 
+/* The steps either side of csn_forward in the inference caller (CSNet/test.py), on the device:
+ * csn_normalize_nchw: float H x W x 3 images in [0,1] (already at the network size) -> ImageNet-normalised NCHW
+ *   ((img - mean) / std, test.py:68-69,86);
+ * csn_saliency_u8: logits -> (sigmoid(y) * 255).astype(uint8), truncation as numpy does (test.py:92-96).
+ * Resizing (skimage in the reference) stays host IO. */
+int csn_normalize_nchw(const float* hwc, float* nchw, int64_t B, int64_t H, int64_t W, void* stream);
+int csn_saliency_u8(const float* logits, uint8_t* out, int64_t n, void* stream);
+
 /* Same as csn_forward (eager launches) but records a HIP event on `stream` after every kernel launch and
  * returns the mean duration per unit over `iters` passes (unit_ms[n_units], milliseconds).  Synchronises. */
 int csn_forward_profile(csn_plan* plan, const float* x, float* y, void* workspace, void* stream,

@@ -600,6 +600,18 @@ int csn_bce_with_logits(const float* y, const float* t, float* dy, int64_t n, do
   return CSN_OK;
 }
 
+int csn_saliency_u8(const float* logits, uint8_t* out, int64_t n, void* stream) {
+  if (!logits || !out || n <= 0) return CSN_E_INVALID;
+  LAUNCH_TRY(csn_launch_saliency_u8(logits, out, n, stream));
+  return CSN_OK;
+}
+
+int csn_normalize_nchw(const float* hwc, float* nchw, int64_t B, int64_t H, int64_t W, void* stream) {
+  if (!hwc || !nchw || B <= 0 || H <= 0 || W <= 0) return CSN_E_INVALID;
+  LAUNCH_TRY(csn_launch_normalize_nchw(hwc, nchw, B, H * W, stream));
+  return CSN_OK;
+}
+
 int csn_adam_step(float* p, const float* g, float* m, float* v, const float* wd, int64_t n, float lr, float beta1,
                   float beta2, float eps, int32_t step, void* stream) {
   if (!p || !g || !m || !v || !wd || n <= 0 || step <= 0) return CSN_E_INVALID;

@@ -276,6 +276,8 @@ struct AdamArgs {
   float beta1, beta2, eps, step_size, sqrt_bc2;
 };
 int csn_launch_adam(const AdamArgs& a, void* stream);
+int csn_launch_saliency_u8(const float* y, unsigned char* o, int64_t n, void* stream);
+int csn_launch_normalize_nchw(const float* hwc, float* chw, int64_t B, int64_t HW, void* stream);
 
 // launchers (implemented next to the kernels)
 int csn_launch_prep(const CsnPrepJob* jobs_dev, int njobs, const float* arena, float* packed, void* stream);

@@ -433,4 +433,39 @@ int csn_launch_up2(const Up2Args& a, void* stream) {
   return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------- caller-side pre/post
+// test.py:92-96 from the logits onward (no resize): sigmoid -> x255 -> uint8 (numpy astype truncation).
+__global__ __launch_bounds__(CSN_BLOCK) void saliency_u8_kernel(const float* __restrict__ y, unsigned char* __restrict__ o,
+                                                                 int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * CSN_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CSN_BLOCK) {
+    const float v = y[i];
+    const float e = expf(-fabsf(v));
+    const float p = v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    o[i] = (unsigned char)(p * 255.f);
+  }
+}
+
+// test.py:68-69,86: (img - mean) / std per channel, H x W x 3 (float, [0,1]) -> 3 x H x W, batched
+__global__ __launch_bounds__(CSN_BLOCK) void normalize_nchw_kernel(const float* __restrict__ hwc, float* __restrict__ chw,
+                                                                    int64_t B, int64_t HW) {
+  const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+  for (int64_t i = (int64_t)blockIdx.x * CSN_BLOCK + threadIdx.x; i < B * HW; i += (int64_t)gridDim.x * CSN_BLOCK) {
+    const int64_t b = i / HW, p = i - b * HW;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) chw[(b * 3 + c) * HW + p] = (hwc[i * 3 + c] - mean[c]) / stdv[c];
+  }
+}
+
+int csn_launch_saliency_u8(const float* y, unsigned char* o, int64_t n, void* stream) {
+  const int64_t nb = (n + CSN_BLOCK - 1) / CSN_BLOCK;
+  CSN_LAUNCH(saliency_u8_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(CSN_BLOCK), 0, stream, y, o, n);
+  return (int)hipGetLastError();
+}
+
+int csn_launch_normalize_nchw(const float* hwc, float* chw, int64_t B, int64_t HW, void* stream) {
+  const int64_t nb = (B * HW + CSN_BLOCK - 1) / CSN_BLOCK;
+  CSN_LAUNCH(normalize_nchw_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(CSN_BLOCK), 0, stream, hwc, chw, B, HW);
+  return (int)hipGetLastError();
+}
+
 int csn_kernels_init(void) { return 0; }

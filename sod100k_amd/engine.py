@@ -192,3 +192,27 @@ class Engine:
         off = info.ws_offset_bytes
         return self.workspace[off:off + 4 * n].view(torch.float32).view(info.batch, info.channels, info.height,
                                                                          info.width)
+
+
+def _stream_of(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
+
+
+def normalize_nchw(lib: C.CDLL, hwc: torch.Tensor) -> torch.Tensor:
+    """B x H x W x 3 float images in [0,1] -> ImageNet-normalised B x 3 x H x W (test.py:68-69,86) on the device."""
+    assert hwc.dtype == torch.float32 and hwc.dim() == 4 and hwc.shape[3] == 3
+    hwc = hwc.contiguous()
+    B, H, W, _ = hwc.shape
+    out = torch.empty((B, 3, H, W), dtype=torch.float32, device=hwc.device)
+    N.check(lib, lib.csn_normalize_nchw(hwc.data_ptr(), out.data_ptr(), B, H, W, _stream_of(hwc)), "csn_normalize_nchw")
+    return out
+
+
+def saliency_u8(lib: C.CDLL, logits: torch.Tensor) -> torch.Tensor:
+    """(sigmoid(logits) * 255).astype(uint8) of test.py:92-96 on the device."""
+    assert logits.dtype == torch.float32
+    logits = logits.contiguous()
+    out = torch.empty(logits.shape, dtype=torch.uint8, device=logits.device)
+    N.check(lib, lib.csn_saliency_u8(logits.data_ptr(), out.data_ptr(), logits.numel(), _stream_of(logits)),
+            "csn_saliency_u8")
+    return out

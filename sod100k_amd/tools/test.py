@@ -22,6 +22,7 @@ for p in (ROOT, os.path.join(ROOT, "sod100k_amd")):       # ``model.csnet`` reso
     if p not in sys.path:
         sys.path.insert(0, p)
 
+from sod100k_amd import _native as N, engine as E         # noqa: E402
 from sod100k_amd.checkpoint import load_checkpoint       # noqa: E402
 from sod100k_amd.configs import defaults                  # noqa: E402
 
@@ -35,6 +36,14 @@ def preprocess(img: np.ndarray, h: int, w: int) -> np.ndarray:
     if img.shape[:2] != (h, w):
         img = np.asarray(Image.fromarray((img * 255).astype(np.uint8)).resize((w, h), Image.BILINEAR)) / 255.0
     return np.transpose((img - MEAN) / STD, (2, 0, 1)).astype(np.float32)
+
+
+def resize_hw(img: np.ndarray, h: int, w: int) -> np.ndarray:
+    """H x W x 3 float image in [0,1] at the network size (bilinear, host side)."""
+    from PIL import Image
+    if img.shape[:2] == (h, w):
+        return img
+    return np.asarray(Image.fromarray((img * 255).astype(np.uint8)).resize((w, h), Image.BILINEAR)) / 255.0
 
 
 def postprocess(logits: torch.Tensor, h: int, w: int) -> np.ndarray:
@@ -73,11 +82,15 @@ def run(cfg, batch: int = 16, device: str = "cuda"):
         for i in range(0, len(names), batch):
             chunk = names[i:i + batch]
             imgs = [np.asarray(Image.open(os.path.join(img_dir, n)).convert("RGB")) / 255.0 for n in chunk]
-            x = np.stack([preprocess(im, H, W) for im in imgs] + [np.zeros((3, H, W), np.float32)] * (batch - len(chunk)))
+            # host: resize to the network size (IO side); device: normalise + NCHW pack, forward, sigmoid -> uint8
+            hwc = np.stack([resize_hw(im, H, W) for im in imgs] + [np.zeros((H, W, 3), np.float32)] * (batch - len(chunk)))
             with torch.no_grad():
-                pred = model(torch.from_numpy(x).to(device))
-            for n, im, lg in zip(chunk, imgs, pred):
-                Image.fromarray(postprocess(lg, *im.shape[:2])).save(os.path.join(out_dir, n[:-4] + '.png'))
+                x = E.normalize_nchw(N.load(), torch.from_numpy(hwc.astype(np.float32)).to(device))
+                pred = model(x)
+                maps = E.saliency_u8(N.load(), pred).cpu().numpy()
+            for k, (n, im, lg) in enumerate(zip(chunk, imgs, pred)):
+                u8 = maps[k, 0] if im.shape[:2] == (H, W) else postprocess(lg, *im.shape[:2])
+                Image.fromarray(u8).save(os.path.join(out_dir, n[:-4] + '.png'))
         print('Dataset: {}, {} images'.format(dataset, len(names)))
 
 

@@ -406,3 +406,20 @@ def check_autograd_seam(lib, device, manifest, B=2, size=32):
         ref = flat[offs[name]:offs[name] + p.numel()].view(p.shape)
         # torch's BCE gradient differs from csn_bce_with_logits in the last bit: compare per tensor, not per element
         assert (p.grad - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-7, name
+
+
+def check_pre_post(lib, device, manifest):
+    """a13: device-side normalise/pack and sigmoid->uint8 either side of the forward, against numpy and G9."""
+    from sod100k_amd import engine as E
+    rng = np.random.default_rng(3)
+    img = rng.random((2, 32, 48, 3), dtype=np.float32)
+    got = E.normalize_nchw(lib, torch.from_numpy(img).to(device)).cpu().numpy()
+    mean = np.array([0.485, 0.456, 0.406], np.float32); std = np.array([0.229, 0.224, 0.225], np.float32)
+    ref = np.transpose((img - mean) / std, (0, 3, 1, 2))
+    assert np.abs(got - ref).max() <= 1e-6
+    m, _ = make_model(lib, manifest, device)
+    y = m(torch.from_numpy(I.image_like()).to(device))
+    u8 = E.saliency_u8(lib, y)[0, 0].cpu().numpy()
+    g9 = np.load(os.path.join(GOLD, "g9_uint8_x2_image.npy"))
+    assert u8.shape == g9.shape and u8.dtype == np.uint8
+    assert np.abs(u8.astype(int) - g9.astype(int)).max() <= 1 and (u8 != g9).mean() < 5e-3

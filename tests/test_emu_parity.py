@@ -68,3 +68,7 @@ def test_emu_train_step_gradients(emu_lib, x2_manifest):
 
 def test_emu_autograd_seam(emu_lib, x2_manifest):
     P.check_autograd_seam(emu_lib, CPU, x2_manifest, B=2, size=16)
+
+
+def test_emu_pre_post_processing(emu_lib, x2_manifest):
+    P.check_pre_post(emu_lib, CPU, x2_manifest)

@@ -166,3 +166,8 @@ def test_gpu_train_nonsquare_and_repeat(hip, x2_manifest):
             assert int(got[k]) == int(v), k       # both advanced by 2
         elif k.endswith("running_mean") or k.endswith("running_var"):
             assert ((got[k].cpu() - v).abs() / (1 + v.abs())).max().item() <= 1e-4, k
+
+
+def test_gpu_pre_post_processing(hip, x2_manifest):
+    lib, dev = hip
+    P.check_pre_post(lib, dev, x2_manifest)
