@@ -62,6 +62,8 @@ struct DwArgs {
 // ---------------------------------------------------------------------------------------------
 #define PW_TY0 16
 #define PW_TX0 32
+#define PW_KC 16   // gathered channels per LDS panel (32: one load phase less per group but 3 instead of 4 waves/SIMD -- slower)
+#define PW_XP 80   // panel row pitch (floats): == 16 (mod 32), so the two k rows a 32-lane half reads hit disjoint banks
 #define PW_MAX_PASS 6
 #define PW_MAX_GRID 2048
 // how a channel slice is brought to the pass resolution; the *_TAPS modes contribute 9 gathered

@@ -18,8 +18,6 @@ typedef float csn_f4 __attribute__((ext_vector_type(4)));
 #define CSN_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #endif
 
-#define PW_KC 16   // channels per LDS panel
-#define PW_XP 80   // panel row pitch (floats): == 16 (mod 32), so the two k rows a 32-lane half reads hit disjoint banks
 #define PW_EP 68   // pitch of the epilogue transpose: rows 4 apart land on the other half of the banks
 
 typedef const CSN_CONST_AS PwPass* PwPassP;
@@ -155,7 +153,7 @@ __device__ __forceinline__ void pw_gather_slice(PwPassP ps, int s, int c_lo, int
     const csn_buf rb = csn_make_buf(ps->src[s].ptr + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
     const unsigned lo = (unsigned)(y * Wr + x) * 4u;
     if (n <= 8) pw_batch_own<8, XP>(rb, lo, cs * 4u, 0, n, rmax, xrow);
-    else pw_batch_own<16, XP>(rb, lo, cs * 4u, 0, n, rmax, xrow);
+    else for (int k0 = 0; k0 < n; k0 += 16) pw_batch_own<16, XP>(rb, lo, cs * 4u, k0, n, rmax, xrow);
   } else if (mode == PW_POOL2) {
     const unsigned Ws = (unsigned)Wr * 2u;
     const unsigned cs = (unsigned)(Hr * 2) * Ws;
@@ -175,7 +173,7 @@ __device__ __forceinline__ void pw_gather_slice(PwPassP ps, int s, int c_lo, int
                                       (unsigned)ps->src[s].Ctot * cs * 4u);
     const unsigned lo = (unsigned)(y * Wr + x) * 4u;
     const unsigned vm = pw_tap_mask(y, x, Hr, Wr, dil);
-    pw_batch_taps<16, XP>(rb, lo, cs * 4u, Wr, dil, vm, c_lo, 0, n, rmax, xrow);
+    for (int k0 = 0; k0 < n; k0 += 16) pw_batch_taps<16, XP>(rb, lo, cs * 4u, Wr, dil, vm, c_lo, k0, n, rmax, xrow);
   } else if (mode == PW_POOL2_TAPS) {
     const unsigned Ws = (unsigned)Wr * 2u;
     const unsigned cs = (unsigned)(Hr * 2) * Ws;
