@@ -25,8 +25,15 @@ __device__ __forceinline__ unsigned ms_tap_mask(int y, int x, int H, int W, int 
 __global__ __launch_bounds__(CSN_BLOCK) void msblock_kernel(MsArgs a) {
   const int H = a.H, W = a.W;
   const int hw = H * W;
-  const int p0 = blockIdx.x * CSN_BLOCK + threadIdx.x;
-  const int b = blockIdx.y;
+  // 1-D grid, XCD-aware: workgroups go round-robin to the 8 XCDs (blockIdx.x & 7).  The five dilation blocks of a
+  // pixel tile are dealt to the SAME XCD, back to back, so the tile's input (read by all five) stays in that L2
+  // (with a (tiles, B, 5) grid they ran far apart on different XCDs: 382 MB of HBM reads per launch for 47 MB).
+  const int ntx = (hw + CSN_BLOCK - 1) / CSN_BLOCK;
+  const int slot = blockIdx.x >> 3;
+  const int tile = (slot / 5) * 8 + (blockIdx.x & 7);
+  if (tile >= ntx * a.B) return;
+  const int b = tile / ntx;
+  const int p0 = (tile - b * ntx) * CSN_BLOCK + threadIdx.x;
   const bool valid = p0 < hw;
   const int p = valid ? p0 : hw - 1;
   const int y = p / W, x = p - y * W;
@@ -37,7 +44,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void msblock_kernel(MsArgs a) {
   csn_cfp scale = csn_const(a.scale), shift = csn_const(a.shift), alpha = csn_const(a.alpha);
   const int cinp = (a.cin + 1) & ~1;
   {
-    const int d = blockIdx.z;   // one dilation per block: 5x more blocks for the small low-resolution maps
+    const int d = slot % 5;   // one dilation per block: 5x more blocks for the small low-resolution maps
     const int nco = a.dch[d];
     if (nco == 0) return;
     const int dil = 1 << d;
@@ -84,7 +91,8 @@ __global__ __launch_bounds__(CSN_BLOCK) void msblock_kernel(MsArgs a) {
 
 int csn_launch_ms(const MsArgs& a, void* stream) {
   const int hw = a.H * a.W;
-  const dim3 grid((unsigned)((hw + CSN_BLOCK - 1) / CSN_BLOCK), a.B, 5);
+  const int tiles = ((hw + CSN_BLOCK - 1) / CSN_BLOCK) * a.B;
+  const dim3 grid((unsigned)(((tiles + 7) / 8) * 5 * 8));
   CSN_LAUNCH(msblock_kernel, grid, dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
 }
