@@ -14,7 +14,7 @@ from typing import Optional, Sequence
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libcsnet_hip.so")
-SOURCES = ("csn_plan.hip", "k_misc.hip", "k_goct_pw.hip", "k_ms.hip", "k_train.hip", "k_wgrad.hip")
+SOURCES = ("csn_plan.hip", "k_misc.hip", "k_goct_pw.hip", "k_ms.hip", "k_train.hip", "k_wgrad.hip", "k_goct_c3.hip")
 
 MAX_BRANCH = 3
 NDIL = 5
@@ -22,6 +22,7 @@ UNIT_GOCT, UNIT_DW, UNIT_MS, UNIT_CLS = 1, 2, 3, 4
 OPT_FUSE_DW = 1
 OPT_GRAPH = 2
 OPT_FUSE_CLS = 3
+OPT_TILED3 = 4
 
 
 class ActDesc(C.Structure):

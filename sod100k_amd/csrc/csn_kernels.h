@@ -286,7 +286,9 @@ int csn_launch_prep(const CsnPrepJob* jobs_dev, int njobs, const float* arena, f
 int csn_launch_dw(const DwArgs& a, void* stream);
 int csn_launch_dw2(const DwArgs& a, void* stream);
 size_t csn_dw2_lds_bytes(const DwArgs& a);
-int csn_launch_pw(const PwArgs& a, int raw, void* stream);   // raw: plain-store instantiation (no BN/PReLU epilogue)
+int csn_launch_pw(const PwArgs& a, int raw, void* stream);
+bool csn_c3_eligible(const PwArgs& a);                        // one pass of 3x3 tap slices (k_goct_c3.hip)
+int csn_launch_c3(const PwArgs& a, int raw, void* stream);   // raw: plain-store instantiation (no BN/PReLU epilogue)
 int csn_launch_ms(const MsArgs& a, void* stream);
 int csn_launch_pool(const PoolArgs& a, void* stream);
 int csn_launch_up2(const Up2Args& a, void* stream);

@@ -132,6 +132,7 @@ struct csn_plan {
   bool bn_tables_train = false;   // csn_forward_train overwrote the folded BN tables: refresh before eval
   bool fuse_dw = true;
   bool fuse_cls = true;   // CSN_OPT_FUSE_CLS
+  bool tiled3 = true;     // CSN_OPT_TILED3
   Epi ident;   // identity epilogue (scale 1, shift 0, alpha 1): train mode runs the conv kernels raw
   bool use_graph = true;
   // hipGraph of one whole csn_forward (all batch slices), captured on a plan-owned stream on the second
@@ -259,7 +260,10 @@ void push_row_chunks(std::vector<PwLaunchPlan>& dst, const PwLaunchPlan& L) {
 void add_launch(std::vector<PwLaunchPlan>& dst, PwLaunchPlan L) {
   int64_t img = 0;
   for (const PwPassPlan& ps : L.passes) img += (int64_t)((ps.nrows + 15) & ~15) * (round4(ps.K) + 2);
-  if (L.passes.size() > 1 && img * 4 > 24 * 1024) {
+  bool taps = false;   // 3x3 passes run one per launch (k_goct_c3.hip)
+  for (const PwPassPlan& ps : L.passes)
+    for (int s = 0; s < ps.nsrc; ++s) taps = taps || ps.src_mode[s] == PW_TAPS || ps.src_mode[s] == PW_POOL2_TAPS;
+  if (L.passes.size() > 1 && (img * 4 > 24 * 1024 || taps)) {
     for (const PwPassPlan& ps : L.passes) {
       PwLaunchPlan one;
       one.lvl = L.lvl + ps.r;
@@ -608,6 +612,10 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
   // raw: every pass of the launch stores plain sums (train-mode conv outputs, gradients, scratch)
   bool all_raw = true;
   for (const PwPassPlan& pp : L.passes) all_raw = all_raw && (pp.out_kind == OUT_DX || pp.out_kind == OUT_TMP || (c.raw && pp.out_kind != OUT_LOGITS));
+  if (P.tiled3 && csn_c3_eligible(a)) {   // 3x3 pass: LDS-tiled implicit GEMM
+    LAUNCH_TRY(csn_launch_c3(a, all_raw ? 1 : 0, c.stream));
+    return c.mark("goct_c3_kernel");
+  }
   LAUNCH_TRY(csn_launch_pw(a, all_raw ? 1 : 0, c.stream));
   return c.mark("goct_pw_kernel");
 }
@@ -930,6 +938,7 @@ int csn_plan_set_option(csn_plan* P, int32_t option, int32_t value) {
     case CSN_OPT_FUSE_DW: P->fuse_dw = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_GRAPH: P->use_graph = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_FUSE_CLS: P->fuse_cls = value != 0; drop_graph(P); return CSN_OK;
+    case CSN_OPT_TILED3: P->tiled3 = value != 0; drop_graph(P); return CSN_OK;
     default: return CSN_E_INVALID;
   }
 }
@@ -1100,6 +1109,7 @@ const char* csn_unit_kernel_name(const csn_plan* P, int32_t u) {
   if (P->fuse_dw && P->units[u].d.kind == CSN_UNIT_DW) {
     if (P->units[u].fuse_next || (u > 0 && P->units[u - 1].fuse_next)) return "dw3x3x2_bn_prelu_kernel";
   }
+  if (P->tiled3 && P->units[u].d.kind == CSN_UNIT_GOCT && P->units[u].d.ksize == 3) return "goct_c3_kernel";
   return P->units[u].kname;
 }
 

@@ -6,6 +6,7 @@ PyTorch is used here for device memory and streams only (``tensor.data_ptr()``,
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -105,6 +106,8 @@ class Engine:
         self.train = bool(train)
         if self.train:      # z / gradient / scratch buffers + backward weight images (before the workspace query)
             N.check(lib, lib.csn_plan_enable_training(plan), "csn_plan_enable_training")
+        if os.environ.get("CSN_TILED3") is not None:      # A/B switch for measurements
+            self.set_option(N.OPT_TILED3, int(os.environ["CSN_TILED3"]))
         self.n_units = len(units)
         self.n_acts = len(acts)
         nbytes = int(lib.csn_plan_workspace_bytes(plan))

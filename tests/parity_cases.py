@@ -325,15 +325,25 @@ def check_train_step(lib, device, manifest, B=2, size=32, expandflop=1.0, flops_
     flat = m._train_backward_raw(xd, dy, flops_weight / B)
 
     cfg = O.load_layer_config_json(manifest)
-    sd_ref = {k: v.clone() for k, v in sd.items()}
-    r = O.train_step(cfg, sd_ref, x, t, expandflop=expandflop, flops_weight=flops_weight, batchsize=B, lr=0.0, wd=0.0)
+    kw = dict(expandflop=expandflop, flops_weight=flops_weight, batchsize=B, lr=0.0, wd=0.0)
+    r = O.train_step(cfg, {k: v.clone() for k, v in sd.items()}, x, t, **kw)
     assert abs(float(loss) - r["loss_bce"]) <= 1e-5 * max(1.0, abs(r["loss_bce"])), (float(loss), r["loss_bce"])
     assert abs(float(pen) / B - r["penalty"]) <= 1e-5 * max(1.0, abs(r["penalty"])), (float(pen) / B, r["penalty"])
-    errs = grad_errors(m, flat, r["grads"])
+    # Gradients through 57 batch-normalised layers are ill-conditioned where the batch variance of a channel is ~0
+    # (check_train_forward): the fp32 oracle itself is up to ~2e-2 away from an fp64 run of the same step on single
+    # tensors.  Judge every tensor against the fp64 run, allowing the fp32 oracle's own deviation on that tensor.
+    r64 = O.train_step(cfg, {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()},
+                       x.double(), t.double(), **kw)
+    errs = grad_errors(m, flat, r64["grads"])
     gmax = max(n for _, n in errs.values())
-    bad = {k: (e, n) for k, (e, n) in errs.items() if e > rel * n + 1e-6 * gmax}
+    bad, worst = {}, 0.0
+    for k, (e, n) in errs.items():
+        ref = float((r["grads"][k].double() - r64["grads"][k]).norm())
+        lim = rel * n + 3.0 * ref + 1e-6 * gmax
+        worst = max(worst, e / (n + 1e-6 * gmax))
+        if e > lim:
+            bad[k] = (e, n, ref)
     assert not bad, f"{len(bad)} of {len(errs)} gradients off, e.g. {list(bad.items())[:6]}"
-    worst = max(e / (n + 1e-6 * gmax) for e, n in errs.values())
     return worst, float(loss), float(pen) / B
 
 
