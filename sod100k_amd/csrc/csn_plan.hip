@@ -98,6 +98,7 @@ struct UnitPlan {
   Epi dw_epi[3];
   int fuse_next = 0;   // DW: the next unit is the second depthwise unit of the same ILBlock
   int fuse_cls = 0;    // GOCT: the next unit is the cls_layer and nobody else reads this unit's output
+  int c3 = 0;          // GOCT 3x3: every launch of the unit qualifies for the LDS-tiled kernel (profile attribution)
   int pool_unit = -1;  // DW (first of a fused pair): index of the stride-2 unit whose pooled inputs the pair writes
   int pool_skip[3] = {0, 0, 0};   // ... and that unit is the only reader of branch i (full-resolution store skipped)
   int pooled_by_producer = 0;     // GOCT stride 2: the preceding fused depthwise pair delivers the pooled inputs
@@ -380,9 +381,11 @@ int plan_goct(Builder& bl, UnitPlan& u) {
     L.passes.push_back(ps);
   }
   add_launch(u.pwl, L);
+  u.c3 = d.ksize == 3;
   for (PwLaunchPlan& l : u.pwl) {
     const int st = finish_launch(bl, l);
     if (st != CSN_OK) return st;
+    if (l.passes.size() != 1 || (size_t)l.wimg_floats * sizeof(float) > 48 * 1024) u.c3 = 0;   // csn_c3_eligible
   }
   return CSN_OK;
 }
@@ -1109,7 +1112,7 @@ const char* csn_unit_kernel_name(const csn_plan* P, int32_t u) {
   if (P->fuse_dw && P->units[u].d.kind == CSN_UNIT_DW) {
     if (P->units[u].fuse_next || (u > 0 && P->units[u - 1].fuse_next)) return "dw3x3x2_bn_prelu_kernel";
   }
-  if (P->tiled3 && P->units[u].d.kind == CSN_UNIT_GOCT && P->units[u].d.ksize == 3) return "goct_c3_kernel";
+  if (P->tiled3 && P->units[u].c3) return "goct_c3_kernel";
   return P->units[u].kname;
 }
 
