@@ -385,7 +385,7 @@ int plan_goct(Builder& bl, UnitPlan& u) {
   for (PwLaunchPlan& l : u.pwl) {
     const int st = finish_launch(bl, l);
     if (st != CSN_OK) return st;
-    if (l.passes.size() != 1 || (size_t)l.wimg_floats * sizeof(float) > 48 * 1024) u.c3 = 0;   // csn_c3_eligible
+    if (l.passes.size() != 1) u.c3 = 0;   // csn_c3_eligible
   }
   return CSN_OK;
 }

@@ -7,7 +7,8 @@
 //
 // Here a block owns an 8 x 32 output tile and stages the (8 + 2) x (32 + 2) input tile of 16 channels at a time
 // in LDS (max-pooling on the way in for the high -> low slice, zero padding by the bounds check), so a value is
-// fetched from global memory 1.33 times instead of 9.  The contraction keeps goct_pw_kernel's MFMA layout
+// fetched from global memory 1.33 times instead of 9.  The weight columns of the same 16 channels (<= 32 rows x 144)
+// are staged next to it, so a block needs 41 KB of LDS whatever the size of the unit's weight image.  The contraction keeps goct_pw_kernel's MFMA layout
 // (v_mfma_f32_16x16x4_f32, A = W[row][k] from the LDS weight image, k = 9 * channel + tap) but reads the B operand
 // x[k][pixel] straight from the tile: entry k of lane (k sub-index, pixel) is tile[ch][row + dy][col + dx] -- no
 // gathered panel is materialised.  The optional bilinear z slice (identity weight block) goes through a
@@ -20,6 +21,8 @@
 #define C3_TP 36                       // tile row pitch (34 columns used)
 #define C3_PLANE ((C3_TY + 2) * C3_TP) // floats per channel of the tile
 #define C3_TILE (C3_CC * C3_PLANE)     // 5760 floats = 22.5 KB
+#define C3_WP (9 * C3_CC + 2)           // pitch of the staged weight chunk: 146 = 2 (mod 4), conflict-free A reads
+#define C3_WCH (32 * C3_WP)            // 32 rows x 144 columns = 18.3 KB
 
 __device__ __forceinline__ int c3_entry_off(int kk) {   // kk = 9 * ch + tap inside the chunk -> tile offset
   const int ch = kk / 9, t = kk - 9 * ch;
@@ -27,25 +30,29 @@ __device__ __forceinline__ int c3_entry_off(int kk) {   // kk = 9 * ch + tap ins
   return ch * C3_PLANE + dy * C3_TP + dx;
 }
 
-template <bool RAW>
-__global__ __launch_bounds__(CSN_BLOCK, 2) void goct_c3_kernel(PwArgs a_byval) {
+// WCH = false: the pass's whole weight image is staged once per block (small images: no per-chunk copy);
+// WCH = true: only the current chunk's columns live in LDS (large images: 41 KB per block, 3 blocks per CU).
+template <bool RAW, bool WCH>
+__global__ __launch_bounds__(CSN_BLOCK, 3) void goct_c3_kernel(PwArgs a_byval) {
   CSN_DYN_SMEM(float, lds);
   const CSN_CONST_AS PwArgs* a = CSN_KERNARG(PwArgs, a_byval);
   PwPassP ps = &a->pass[0];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  {
+  if (!WCH) {
     const float4* __restrict__ src = reinterpret_cast<const float4*>(a->wimg);
     float4* dst = reinterpret_cast<float4*>(lds);
     const int n4 = a->wimg_floats >> 2;
     for (int i = tid; i < n4; i += CSN_BLOCK) dst[i] = src[i];
   }
-  float* tile = lds + a->wimg_floats;          // [C3_CC][C3_TY + 2][C3_TP]; also the waves' panels / epilogue scratch
+  float* wch = lds;                            // WCH: [32][C3_WP] weight columns of the current chunk
+  float* tile = lds + (WCH ? C3_WCH : a->wimg_floats);
+  const int wp = WCH ? C3_WP : ps->w_stride;   // row pitch of the A operand's source          // [C3_CC][C3_TY + 2][C3_TP]; also the waves' panels / epilogue scratch
   const int Hr = a->H0, Wr = a->W0;
   const int tiles_x = (Wr + C3_TX - 1) / C3_TX, tiles_y = (Hr + C3_TY - 1) / C3_TY;
   const int tiles_xy = tiles_x * tiles_y;
   const int ntiles = tiles_xy * a->B;
   const int nrows = ps->nrows, stride = ps->w_stride;
-  const float* wl0 = lds + ps->w_off;
+  const float* __restrict__ wg0 = a->wimg + ps->w_off;   // the pass's rows in the (global) weight image
   // tap slices first (TAPS / POOL2_TAPS), an optional non-tap slice (bilinear z) last
   int ntap = 0;
   for (int s = 0; s < ps->nsrc; ++s)
@@ -103,10 +110,18 @@ __global__ __launch_bounds__(CSN_BLOCK, 2) void goct_c3_kernel(PwArgs a_byval) {
             }
             tile[ch * C3_PLANE + ty * C3_TP + tx] = in ? v : 0.f;
           }
+          const int kn = 9 * nc;
+          if (WCH) {   // weight columns [kcol + 9 c_lo, + kn) of rows row0 .. row0 + 31 (rows past nrows are zero in the image)
+            const int nr = two ? 32 : 16;
+            const float* __restrict__ wg = wg0 + (int64_t)row0 * stride + kcol + 9 * c_lo;
+            for (int e = tid; e < nr * kn; e += CSN_BLOCK) {
+              const int r = e / kn, k = e - r * kn;
+              wch[r * C3_WP + k] = wg[(int64_t)r * stride + k];
+            }
+          }
           __syncthreads();
           // ---- contract the chunk's 9 * nc entries straight from the tile
-          const int kn = 9 * nc;
-          const float* wt = wl0 + row0 * stride + kcol + 9 * c_lo;
+          const float* wt = WCH ? wch : lds + ps->w_off + row0 * stride + kcol + 9 * c_lo;
           for (int k0 = 0; k0 < kn; k0 += 4) {
             const int kk = k0 + kq;
             const bool kin = kk < kn;
@@ -120,15 +135,15 @@ __global__ __launch_bounds__(CSN_BLOCK, 2) void goct_c3_kernel(PwArgs a_byval) {
                   const int row = kq * 4 + i;
                   float acc_ = acc[t][sg][i];
                   for (int u = 0; u < 4 && k0 + u < kn; ++u)
-                    acc_ = fmaf(wt[(16 * t + row) * stride + k0 + u], tile[c3_entry_off(k0 + u) + trow * C3_TP + tcol], acc_);
+                    acc_ = fmaf(wt[(16 * t + row) * wp + k0 + u], tile[c3_entry_off(k0 + u) + trow * C3_TP + tcol], acc_);
                   acc[t][sg][i] = acc_;
                 }
               }
             (void)eo;
 #else
             // A = W[16 t + (lane & 15)][k0 + kq] (0 past the chunk: the image columns beyond belong to other slices)
-            const float a0 = kin ? wt[pxi * stride + kk] : 0.f;
-            const float a1 = (two && kin) ? wt[(16 + pxi) * stride + kk] : 0.f;
+            const float a0 = kin ? wt[pxi * wp + kk] : 0.f;
+            const float a1 = (two && kin) ? wt[(16 + pxi) * wp + kk] : 0.f;
 #pragma unroll
             for (int sg = 0; sg < 4; ++sg) {
               const float bv = tile[eo + (2 * wave + (sg >> 1)) * C3_TP + 16 * (sg & 1) + pxi];
@@ -147,12 +162,21 @@ __global__ __launch_bounds__(CSN_BLOCK, 2) void goct_c3_kernel(PwArgs a_byval) {
         const int K = ps->src[s].K;
         for (int kc = 0; kc < K; kc += PW_KC) {
           const int n = min(PW_KC, K - kc), n4 = (n + 3) & ~3;
-          CSN_WAVE_SYNC();
+          __syncthreads();   // previous step (and, WCH, its weight chunk) consumed by every wave
+          if (WCH) {
+            const int nr = two ? 32 : 16;
+            const float* __restrict__ wg = wg0 + (int64_t)row0 * stride + kcol + kc;
+            for (int e = tid; e < nr * n; e += CSN_BLOCK) {
+              const int r = e / n, k = e - r * n;
+              wch[r * C3_WP + k] = wg[(int64_t)r * stride + k];
+            }
+          }
+          __syncthreads();
           pw_gather_slice<PW_XP>(ps, s, kc, kc + n, xb + lane, PW_KC, b, gy, gx, Hr, Wr);
           for (int k = n; k < n4; ++k) xb[k * PW_XP + lane] = 0.f;
           CSN_WAVE_SYNC();
           // lane-as-pixel panel order = the wave's 2 x 32 strip: sub-group sg = pixels 16 sg .. 16 sg + 15
-          const float* wt = wl0 + row0 * stride + kcol + kc;
+          const float* wt = WCH ? wch : lds + ps->w_off + row0 * stride + kcol + kc;
           for (int k0 = 0; k0 < n4; k0 += 4) {
 #ifdef CSN_CPU_EMU
             for (int t = 0; t < (two ? 2 : 1); ++t)
@@ -161,13 +185,13 @@ __global__ __launch_bounds__(CSN_BLOCK, 2) void goct_c3_kernel(PwArgs a_byval) {
                   const int row = kq * 4 + i;
                   float acc_ = acc[t][sg][i];
                   for (int u = 0; u < 4; ++u)
-                    acc_ = fmaf((k0 + u < n) ? wt[(16 * t + row) * stride + k0 + u] : 0.f, xb[(k0 + u) * PW_XP + 16 * sg + pxi], acc_);
+                    acc_ = fmaf((k0 + u < n) ? wt[(16 * t + row) * wp + k0 + u] : 0.f, xb[(k0 + u) * PW_XP + 16 * sg + pxi], acc_);
                   acc[t][sg][i] = acc_;
                 }
 #else
             const bool kin = k0 + kq < n;
-            const float a0 = kin ? wt[pxi * stride + k0 + kq] : 0.f;
-            const float a1 = (two && kin) ? wt[(16 + pxi) * stride + k0 + kq] : 0.f;
+            const float a0 = kin ? wt[pxi * wp + k0 + kq] : 0.f;
+            const float a1 = (two && kin) ? wt[(16 + pxi) * wp + k0 + kq] : 0.f;
 #pragma unroll
             for (int sg = 0; sg < 4; ++sg) {
               const float bv = xb[(k0 + kq) * PW_XP + 16 * sg + pxi];
@@ -207,9 +231,6 @@ __global__ __launch_bounds__(CSN_BLOCK, 2) void goct_c3_kernel(PwArgs a_byval) {
 // true when the launch is one pass made of 3x3 tap slices (dilation 1) plus at most one trailing non-tap slice
 bool csn_c3_eligible(const PwArgs& a) {
   if (a.npass != 1 || a.pass[0].red_w) return false;
-  // the whole weight image sits in LDS next to the 22.5 KB tile: beyond 48 KB only one block fits a CU and the
-  // per-pixel gather of goct_pw_kernel is faster (stage3.0: 51 input channels x 9 taps, measured 269 vs 315 us)
-  if ((size_t)a.wimg_floats * sizeof(float) > 48 * 1024) return false;
   const PwPass& ps = a.pass[0];
   int ntap = 0;
   bool tail = false;
@@ -230,20 +251,26 @@ int csn_launch_c3(const PwArgs& a, int raw, void* stream) {
   const int tiles = ((a.W0 + C3_TX - 1) / C3_TX) * ((a.H0 + C3_TY - 1) / C3_TY) * a.B;
   const int nblk = tiles < PW_MAX_GRID ? tiles : PW_MAX_GRID;
   const dim3 grid((nblk + 7) & ~7);
-  const size_t lds = ((size_t)a.wimg_floats + C3_TILE) * sizeof(float);
+  // small weight images are staged whole (stage0.0 / 2.0 / 4.0: measured faster), large ones chunk by chunk
+  const bool wch = (size_t)a.wimg_floats * sizeof(float) > 48 * 1024;
+  const size_t lds = (size_t)((wch ? C3_WCH : a.wimg_floats) + C3_TILE) * sizeof(float);
 #ifndef CSN_CPU_EMU
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&goct_c3_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&goct_c3_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
+    const void* fns[4] = {reinterpret_cast<const void*>(&goct_c3_kernel<false, false>),
+                          reinterpret_cast<const void*>(&goct_c3_kernel<false, true>),
+                          reinterpret_cast<const void*>(&goct_c3_kernel<true, false>),
+                          reinterpret_cast<const void*>(&goct_c3_kernel<true, true>)};
+    for (const void* f : fns) {
+      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+    }
     attr_done = true;
   }
 #endif
-  if (raw) CSN_LAUNCH(goct_c3_kernel<true>, grid, dim3(CSN_BLOCK), lds, stream, a);
-  else CSN_LAUNCH(goct_c3_kernel<false>, grid, dim3(CSN_BLOCK), lds, stream, a);
+  if (raw && wch) CSN_LAUNCH((goct_c3_kernel<true, true>), grid, dim3(CSN_BLOCK), lds, stream, a);
+  else if (raw) CSN_LAUNCH((goct_c3_kernel<true, false>), grid, dim3(CSN_BLOCK), lds, stream, a);
+  else if (wch) CSN_LAUNCH((goct_c3_kernel<false, true>), grid, dim3(CSN_BLOCK), lds, stream, a);
+  else CSN_LAUNCH((goct_c3_kernel<false, false>), grid, dim3(CSN_BLOCK), lds, stream, a);
   return (int)hipGetLastError();
 }
