@@ -164,6 +164,13 @@ int csn_adam_step(float* p, const float* g, float* m, float* v, const float* wd,
 int csn_normalize_nchw(const float* hwc, float* nchw, int64_t B, int64_t H, int64_t W, void* stream);
 int csn_saliency_u8(const float* logits, uint8_t* out, int64_t n, void* stream);
 
+/* Evaluation metrics (SalMetric/src/sal_metric.cpp:87-120, the reference's only native component): for n_images
+ * equally sized uint8 maps, ACCUMULATES (caller zeroes) per image the joint histogram hist[img][2*v + (gt > 128)]
+ * of the predicted value v and the binarised ground truth, and abs_sum[img] = sum |sal - gt|.  Every threshold's
+ * precision / recall and the MAE follow from these (sod100k_amd/metric.py) -- one pass instead of 256. */
+int csn_sal_hist(const uint8_t* sal, const uint8_t* gt, int64_t npix, int32_t n_images, uint64_t* hist, uint64_t* abs_sum,
+                 void* stream);
+
 /* Same as csn_forward (eager launches) but records a HIP event on `stream` after every kernel launch and
  * returns the mean duration per unit over `iters` passes (unit_ms[n_units], milliseconds).  Synchronises. */
 int csn_forward_profile(csn_plan* plan, const float* x, float* y, void* workspace, void* stream,

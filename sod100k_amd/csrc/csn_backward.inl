@@ -612,6 +612,14 @@ int csn_normalize_nchw(const float* hwc, float* nchw, int64_t B, int64_t H, int6
   return CSN_OK;
 }
 
+int csn_sal_hist(const uint8_t* sal, const uint8_t* gt, int64_t npix, int32_t n_images, uint64_t* hist, uint64_t* abs_sum,
+                 void* stream) {
+  if (!sal || !gt || !hist || !abs_sum || npix <= 0 || n_images <= 0) return CSN_E_INVALID;
+  LAUNCH_TRY(csn_launch_sal_hist(sal, gt, npix, n_images, reinterpret_cast<unsigned long long*>(hist),
+                                 reinterpret_cast<unsigned long long*>(abs_sum), stream));
+  return CSN_OK;
+}
+
 int csn_adam_step(float* p, const float* g, float* m, float* v, const float* wd, int64_t n, float lr, float beta1,
                   float beta2, float eps, int32_t step, void* stream) {
   if (!p || !g || !m || !v || !wd || n <= 0 || step <= 0) return CSN_E_INVALID;

@@ -456,6 +456,43 @@ __global__ __launch_bounds__(CSN_BLOCK) void normalize_nchw_kernel(const float* 
   }
 }
 
+// Saliency metrics (SalMetric/src/sal_metric.cpp:87-120): the reference makes 256 passes over every image (one per
+// threshold).  All of them follow from ONE joint histogram h[v][g], v = predicted value 0..255, g = (gt > 128):
+//     a_sum(th) = sum_{v > th} (h[v][0] + h[v][1]),  ab(th) = sum_{v > th} h[v][1],  b_sum = sum_v h[v][1]
+// plus sum |sal - gt| for the MAE.  grid (blocks per image, images); LDS histogram, integer atomics (deterministic).
+__global__ __launch_bounds__(CSN_BLOCK) void sal_hist_kernel(const unsigned char* __restrict__ sal,
+                                                              const unsigned char* __restrict__ gt, int64_t npix,
+                                                              unsigned long long* __restrict__ hist,
+                                                              unsigned long long* __restrict__ abs_sum) {
+  CSN_DYN_SMEM(unsigned int, lh);   // [512] + [1]
+  const int img = blockIdx.y;
+  for (int i = threadIdx.x; i < 513; i += CSN_BLOCK) lh[i] = 0u;
+  __syncthreads();
+  const unsigned char* sp = sal + (int64_t)img * npix;
+  const unsigned char* gp = gt + (int64_t)img * npix;
+  unsigned int ad = 0u;
+  for (int64_t i = (int64_t)blockIdx.x * CSN_BLOCK + threadIdx.x; i < npix; i += (int64_t)gridDim.x * CSN_BLOCK) {
+    const int v = sp[i], g = gp[i];
+    atomicAdd(&lh[2 * v + (g > 128 ? 1 : 0)], 1u);
+    ad += (unsigned int)(v > g ? v - g : g - v);
+  }
+  atomicAdd(&lh[512], ad);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 512; i += CSN_BLOCK)
+    if (lh[i]) atomicAdd(&hist[(int64_t)img * 512 + i], (unsigned long long)lh[i]);
+  if (threadIdx.x == 0) atomicAdd(&abs_sum[img], (unsigned long long)lh[512]);
+}
+
+int csn_launch_sal_hist(const unsigned char* sal, const unsigned char* gt, int64_t npix, int n_images,
+                        unsigned long long* hist, unsigned long long* abs_sum, void* stream) {
+  int64_t nb = (npix + CSN_BLOCK * 16 - 1) / (CSN_BLOCK * 16);
+  if (nb < 1) nb = 1;
+  if (nb > 64) nb = 64;
+  CSN_LAUNCH(sal_hist_kernel, dim3((unsigned)nb, (unsigned)n_images), dim3(CSN_BLOCK), 513 * sizeof(unsigned int), stream,
+             sal, gt, npix, hist, abs_sum);
+  return (int)hipGetLastError();
+}
+
 int csn_launch_saliency_u8(const float* y, unsigned char* o, int64_t n, void* stream) {
   const int64_t nb = (n + CSN_BLOCK - 1) / CSN_BLOCK;
   CSN_LAUNCH(saliency_u8_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(CSN_BLOCK), 0, stream, y, o, n);

@@ -79,6 +79,14 @@ void yield_barrier();
 #define blockDim (csn_emu::g.bDim)
 #define gridDim (csn_emu::g.gDim)
 static inline void __syncthreads() { csn_emu::yield_barrier(); }
+// atomics: fibers of a block are sequential, blocks run on OpenMP threads
+template <class T>
+static inline T atomicAdd(T* p, T v) {
+  T old;
+#pragma omp atomic capture
+  { old = *p; *p += v; }
+  return old;
+}
 
 #ifdef CSN_EMU_IMPL
 #include <omp.h>
