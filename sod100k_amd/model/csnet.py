@@ -645,17 +645,155 @@ def save_layer_config(layer_config, save_path, epoch, latest=False, finetune=Fal
     print("Saved in:", targets[0])
 
 
+# ---- prune-and-finetune surgery (CSNet_training/model/csnet.py:526-538, 779-879) ---------------------------------
+def get_CSFHead_dliconf(mask, old_split):
+    """Surviving channels per dilation of every MSBlock: ``mask[i]`` covers branch i's concat of dilation groups."""
+    old_split = np.asarray(old_split)
+    new_split = np.zeros(old_split.shape)
+    for i, branch_mask in enumerate(mask):
+        bounds = np.concatenate([[0], np.cumsum(old_split[i]).astype(np.int64)])
+        for j in range(old_split.shape[1]):
+            new_split[i][j] = int(np.count_nonzero(branch_mask[bounds[j]:bounds[j + 1]]))
+    return new_split
+
+
+def finetune_model(model, save_path, base_layer_config, thres, maxpram=None):
+    """Channel masks and the slim ``layer_config`` from a trained model: an output channel of a gOctaveCBR / MSBlock
+    survives when ``|BN gamma| >= thres`` (the dynamic weight decay drives unneeded gammas to zero).  The two
+    depthwise units of an ILBlock follow their block's conv1x1 mask.  Returns (new_layer_config, out_mask)."""
+    thres = float(thres)
+    n_layers = len(base_layer_config)
+    new_cfg = [None] * n_layers
+    out_mask = [None] * n_layers
+    stages = base_layer_config[-1]
+    layer = 0
+    for m in model.modules():
+        if not isinstance(m, (gOctaveCBR, PallMSBlock)):
+            continue
+        this_out = base_layer_config[layer][1]
+        gammas = np.concatenate([n.weight.data.detach().cpu().numpy() for n in m.modules() if isinstance(n, nn.BatchNorm2d)])
+        keep = np.ones(len(gammas))
+        keep[np.abs(gammas) < thres] = 0
+        cuts = np.cumsum([int(c) for c in this_out])[:-1]
+        mask = np.split(keep, cuts)
+        newsplit = np.array([float(np.count_nonzero(b)) for b in mask])
+        out_mask[layer] = mask
+        if layer == 0:
+            new_cfg[layer] = [3, newsplit]
+        elif layer == n_layers - 4:          # CSF fuse: its inputs are the high branches of the last block of stages 2-4
+            side4 = sum(new_cfg[layer - 1][1])
+            side3 = sum(new_cfg[layer - stages[3] - 1][1])
+            side2 = sum(new_cfg[layer - stages[3] - stages[2] - 1][1])
+            new_cfg[layer] = [np.array([side2, side3, side4]), newsplit]
+        elif layer == n_layers - 3:          # PallMSBlock: also the per-dilation split
+            new_cfg[layer] = [new_cfg[layer - 1][1], newsplit,
+                              get_CSFHead_dliconf(mask, np.asarray(base_layer_config[layer][2]).astype(np.int32))]
+        else:
+            new_cfg[layer] = [new_cfg[layer - 1][1], newsplit]
+        layer += 1
+    new_cfg[-1] = stages
+    return new_cfg, out_mask
+
+
+def _keep(mask_list):
+    return np.nonzero(np.concatenate([np.asarray(b) for b in mask_list]))[0]
+
+
+def _copy_bn_prelu(old, new, idx):
+    """BN weight / bias and PReLU slope of the surviving channels (running statistics restart, like the reference)."""
+    if old is None or new is None:
+        return
+    sel = torch.as_tensor(np.nonzero(np.asarray(idx))[0], dtype=torch.long)
+    with torch.no_grad():
+        new.weight.copy_(old.weight.detach().cpu()[sel])
+        if getattr(new, "bias", None) is not None and getattr(old, "bias", None) is not None:
+            new.bias.copy_(old.bias.detach().cpu()[sel])
+
+
+def _copy_goct(old, new, this_mask, last_mask):
+    rows = torch.as_tensor(_keep(this_mask), dtype=torch.long)
+    cols = torch.as_tensor(_keep(last_mask), dtype=torch.long)
+    with torch.no_grad():
+        new.conv.weight.copy_(old.conv.weight.detach().cpu()[rows][:, cols])
+    for j in range(len(this_mask)):
+        if j < len(old.bns) and j < len(new.bns):
+            _copy_bn_prelu(old.bns[j], new.bns[j], this_mask[j])
+            _copy_bn_prelu(old.prelus[j], new.prelus[j], this_mask[j])
+
+
+def _copy_dw(old, new, this_mask):
+    for j in range(len(this_mask)):
+        if j >= len(old.convs) or old.convs[j] is None or new.convs[j] is None:
+            continue
+        sel = torch.as_tensor(np.nonzero(np.asarray(this_mask[j]))[0], dtype=torch.long)
+        with torch.no_grad():
+            new.convs[j].weight.copy_(old.convs[j].weight.detach().cpu()[sel])
+        _copy_bn_prelu(old.bns[j], new.bns[j], this_mask[j])
+        _copy_bn_prelu(old.prelus[j], new.prelus[j], this_mask[j])
+
+
+def _copy_ms(old, new, this_mask, last_mask):
+    for i in range(len(this_mask)):
+        mo, mn = old.convs[i], new.convs[i]
+        if mo is None or mn is None:
+            continue
+        cols = torch.as_tensor(np.nonzero(np.asarray(last_mask[i]))[0], dtype=torch.long)
+        off = 0
+        for d in range(len(mo.msconv)):
+            if mo.msconv[d] is None:
+                continue
+            w = mo.msconv[d].weight.detach().cpu()
+            seg = np.asarray(this_mask[i])[off:off + w.shape[0]]
+            off += w.shape[0]
+            if mn.msconv[d] is None:
+                continue
+            rows = torch.as_tensor(np.nonzero(seg)[0], dtype=torch.long)
+            with torch.no_grad():
+                mn.msconv[d].weight.copy_(w[rows][:, cols])
+        _copy_bn_prelu(mo.bn, mn.bn, this_mask[i])
+        _copy_bn_prelu(mo.prelu, mn.prelu, this_mask[i])
+
+
+def build_model_with_weight(layer_config, old_model, mask, verbose=False):
+    """Slim CSNet for ``layer_config`` carrying the surviving channels of ``old_model`` (``mask`` from finetune_model)."""
+    model = CSNet(layer_config=layer_config)
+    stages = layer_config[-1]
+    blocks_old, blocks_new = old_model._blocks(), model._blocks()
+    for k, (bo, bn_) in enumerate(zip(blocks_old, blocks_new)):
+        last = [np.array([1, 1, 1])] if k == 0 else mask[k - 1]
+        _copy_goct(bo.conv1x1, bn_.conv1x1, mask[k], last)
+        _copy_dw(bo.conv3x3_1, bn_.conv3x3_1, mask[k])
+        _copy_dw(bo.conv3x3_2, bn_.conv3x3_2, mask[k])
+    k = len(blocks_old)                       # CSF head: fuse, ms, fuse1x1
+    sides = [mask[k - stages[3] - stages[2] - 1][0], mask[k - stages[3] - 1][0], mask[k - 1][0]]
+    _copy_goct(old_model.oct_fuse.fuse, model.oct_fuse.fuse, mask[k], sides)
+    _copy_ms(old_model.oct_fuse.ms, model.oct_fuse.ms, mask[k + 1], mask[k])
+    _copy_goct(old_model.oct_fuse.fuse1x1, model.oct_fuse.fuse1x1, mask[k + 2], mask[k + 1])
+    cols = torch.as_tensor(_keep(mask[k + 2]), dtype=torch.long)
+    with torch.no_grad():
+        model.cls_layer.weight.copy_(old_model.cls_layer.weight.detach().cpu()[:, cols])
+        model.cls_layer.bias.copy_(old_model.cls_layer.bias.detach().cpu())
+    return model
+
+
 def build_model(epoch=0, predefine='', basic_split=[1, ], save_path='tmp', expand=1.0, model=None,
                 load_weight="NO", finetune_thres='1e-20', finetune=False):
-    """Inference signature csnet.py:571-597; the extra keyword arguments of the training copy
-    (CSNet_training/model/csnet.py:882-892) are accepted, pruning surgery (finetune=True) is out of scope."""
-    if finetune:
-        raise NotImplementedError("prune-and-finetune model surgery (CSNet_training/model/csnet.py:571-879) "
-                                  "is outside the accelerated hot path")
+    """Inference signature csnet.py:571-597 plus the training copy's keyword arguments
+    (CSNet_training/model/csnet.py:882-945): ``finetune=True`` prunes ``model`` against the layer_config in ``predefine``
+    (channels with |BN gamma| < finetune_thres go), writes ``layer_config_finetune_<epoch>.bin`` and, with
+    ``load_weight='FINETUNE'`` and ``epoch != 0``, returns the slim model carrying the surviving weights.
+    ``redefine_model`` (re-widening during training, csnet.py:940-944) is not provided."""
     basewidth = 20
     real_width = int(round(basewidth * expand)) if expand > 1 else basewidth
-    if os.path.isfile(predefine):
+    out_mask = None
+    if finetune:
+        layer_config, out_mask = finetune_model(model, base_layer_config=load_layer_config(predefine), save_path=save_path,
+                                                thres=finetune_thres)
+        save_layer_config(layer_config, save_path, epoch, finetune=True)
+    elif os.path.isfile(predefine):
         layer_config = load_layer_config(predefine)
     else:
         layer_config = init_layers(real_width, basic_split)
+    if out_mask is not None and load_weight == 'FINETUNE' and epoch != 0:
+        return build_model_with_weight(layer_config=layer_config, old_model=model, mask=out_mask)
     return CSNet(layer_config=layer_config)

@@ -1,0 +1,67 @@
+"""Prune-and-finetune surgery against G10, the reference's own result on the shipped x2 weights."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import csnet_oracle as O
+from sod100k_amd.model import csnet as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _norm(e):
+    if isinstance(e, (list, tuple)):
+        return [_norm(v) for v in e]
+    if isinstance(e, np.ndarray):
+        return _norm(e.tolist())
+    return float(e)
+
+
+def test_prune_matches_reference(tmp_path):
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "g10_prune_x2.json")))
+    man = os.path.join(ROOT, "sod100k_amd", "data", "csnet-L-x2.json")
+    m = M.build_model(predefine=man)
+    m.load_state_dict(O.load_weights(man))
+    new_cfg, mask = M.finetune_model(m, save_path=str(tmp_path), base_layer_config=M.load_layer_config(man), thres=g["thres"])
+    assert _norm(new_cfg) == _norm(g["layer_config"])
+    assert [[int(np.count_nonzero(b)) for b in layer] for layer in mask if layer is not None] == g["mask_counts"]
+    slim = M.build_model_with_weight(new_cfg, m, mask)
+    sd = slim.state_dict()
+    assert list(sd.keys()) == list(g["keys"].keys())
+    assert sum(p.numel() for p in slim.parameters()) == g["n_params"]
+    for k, e in g["keys"].items():
+        v = sd[k]
+        assert list(v.shape) == e["shape"], k
+        assert abs(float(v.double().sum()) - e["sum"]) <= 1e-9 * max(1.0, abs(e["sum"])), k
+        assert np.allclose(v.double().reshape(-1)[:3].numpy(), e["head"], rtol=0, atol=0), k
+
+
+def test_build_model_finetune_path(tmp_path):
+    man = os.path.join(ROOT, "sod100k_amd", "data", "csnet-L-x2.json")
+    m = M.build_model(predefine=man)
+    m.load_state_dict(O.load_weights(man))
+    slim = M.build_model(epoch=3, predefine=man, save_path=str(tmp_path), model=m, load_weight="FINETUNE",
+                         finetune_thres=0.01, finetune=True)
+    assert sum(p.numel() for p in slim.parameters()) == 55740
+    assert os.path.isfile(os.path.join(str(tmp_path), "layer_config_finetune_3.bin"))
+    again = M.CSNet(M.load_layer_config(os.path.join(str(tmp_path), "layer_config_finetune_3.bin")))
+    assert [tuple(v.shape) for v in again.state_dict().values()] == [tuple(v.shape) for v in slim.state_dict().values()]
+
+
+def test_slim_model_runs_through_the_kernels(emu_lib, tmp_path):
+    """The pruned network (it has an output branch with zero channels) through the same kernels, against the oracle."""
+    from oracle import inputs as I
+    man = os.path.join(ROOT, "sod100k_amd", "data", "csnet-L-x2.json")
+    m = M.build_model(predefine=man)
+    m.load_state_dict(O.load_weights(man))
+    new_cfg, mask = M.finetune_model(m, save_path=str(tmp_path), base_layer_config=M.load_layer_config(man), thres=0.01)
+    slim = M.build_model_with_weight(new_cfg, m, mask).eval()
+    slim._lib = emu_lib
+    x = torch.from_numpy(I.randn_batch(2, 2, 32, 48))
+    sd = {k: v.clone() for k, v in slim.state_dict().items()}
+    with torch.no_grad():
+        ref = O.csnet_forward(new_cfg, sd, x)
+    y = slim(x)
+    assert (y - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
