@@ -584,14 +584,21 @@ int csn_backward(csn_plan* P, const float* x, const float* dy, void* workspace, 
   if (!P || !x || !dy || !workspace || !arena || !grad || !flop_w) return CSN_E_INVALID;
   if (!P->train || !P->params_ready || !P->bn_tables_train) return CSN_E_STATE;   // needs csn_forward_train first
   (void)arena_floats;
-  Ctx c{*P, x, nullptr, static_cast<char*>(workspace), stream};
-  c.raw = true;
-  const BwdCtx b{c, arena, grad, flop_w, pen_scale};
-  for (int u = (int)P->units.size() - 1; u >= 0; --u) {
-    const int st = run_unit_bwd(b, u, dy);
-    if (st != CSN_OK) return st;
-  }
-  return CSN_OK;
+  uint32_t ps_bits;
+  std::memcpy(&ps_bits, &pen_scale, 4);
+  const std::vector<uint64_t> key = {(uint64_t)(uintptr_t)x, (uint64_t)(uintptr_t)dy, (uint64_t)(uintptr_t)workspace,
+                                     (uint64_t)(uintptr_t)arena, (uint64_t)(uintptr_t)grad, (uint64_t)ps_bits,
+                                     hash_floats(flop_w, (int)P->units.size() * CSN_MAX_BRANCH)};
+  return run_graphed(P, P->g_bwd, key, stream, [&](void* s) {
+    Ctx c{*P, x, nullptr, static_cast<char*>(workspace), s};
+    c.raw = true;
+    const BwdCtx b{c, arena, grad, flop_w, pen_scale};
+    for (int u = (int)P->units.size() - 1; u >= 0; --u) {
+      const int st = run_unit_bwd(b, u, dy);
+      if (st != CSN_OK) return st;
+    }
+    return (int)CSN_OK;
+  });
 }
 
 int csn_bce_with_logits(const float* y, const float* t, float* dy, int64_t n, double* loss, void* stream) {

@@ -3,6 +3,7 @@
 // include/csnet_hip.h.  No torch types; the caller owns every tensor.
 #include <array>
 #include <cmath>
+#include <cstring>
 #include <algorithm>
 #include <new>
 #include <string>
@@ -142,6 +143,13 @@ struct csn_plan {
   hipGraphExec_t graph_exec = nullptr;
   const void* g_x = nullptr; const void* g_y = nullptr; const void* g_ws = nullptr;
   int eager_calls = 0;
+  // same for the train-mode forward and the backward pass (keyed by every pointer / scalar baked into the launches)
+  struct GraphSlot {
+    hipGraphExec_t exec = nullptr;
+    std::vector<uint64_t> key;
+    int eager_calls = 0;
+  };
+  GraphSlot g_train, g_bwd;
   std::vector<hipEvent_t> ev;
   // per-launch profiling (csn_forward_profile): one event after every kernel launch, tagged with its name
   struct KStat { const char* name; double ms; int launches; };
@@ -755,10 +763,66 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
 
 }  // namespace
 
+static void drop_slot(csn_plan::GraphSlot& s) {
+#ifndef CSN_CPU_EMU
+  if (s.exec) { (void)hipGraphExecDestroy(s.exec); s.exec = nullptr; }
+#endif
+  s.key.clear();
+  s.eager_calls = 0;
+}
+
+// Run `body(stream)` eagerly the first two times it is seen with `key`, capture it on the third and replay afterwards.
+template <class F>
+static int run_graphed(csn_plan* P, csn_plan::GraphSlot& slot, const std::vector<uint64_t>& key, void* stream, F body) {
+#ifdef CSN_CPU_EMU
+  (void)P; (void)slot; (void)key;
+  return body(stream);
+#else
+  if (!P->use_graph) return body(stream);
+  if (key != slot.key) {
+    if (slot.exec) { (void)hipGraphExecDestroy(slot.exec); slot.exec = nullptr; }
+    slot.key = key;
+    slot.eager_calls = 0;
+  }
+  if (slot.exec) {
+    HIP_TRY(hipGraphLaunch(slot.exec, (hipStream_t)stream));
+    return CSN_OK;
+  }
+  if (slot.eager_calls++ < 2) return body(stream);   // warm-up: lazy initialisation (function attributes) done
+  if (!P->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&P->cap_stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamBeginCapture(P->cap_stream, hipStreamCaptureModeThreadLocal));
+  const int st = body(P->cap_stream);
+  hipGraph_t g = nullptr;
+  const hipError_t e = hipStreamEndCapture(P->cap_stream, &g);
+  if (st != CSN_OK || e != hipSuccess || !g) {
+    if (g) (void)hipGraphDestroy(g);
+    slot.eager_calls = -1000000;   // stay eager for this slot
+    return body(stream);
+  }
+  const hipError_t e2 = hipGraphInstantiate(&slot.exec, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e2 != hipSuccess) { slot.exec = nullptr; slot.eager_calls = -1000000; return body(stream); }
+  HIP_TRY(hipGraphLaunch(slot.exec, (hipStream_t)stream));
+  return CSN_OK;
+#endif
+}
+
+static uint64_t hash_floats(const float* p, int n) {
+  uint64_t h = 1469598103934665603ull;
+  for (int i = 0; i < n; ++i) {
+    uint32_t b;
+    std::memcpy(&b, &p[i], 4);
+    h = (h ^ b) * 1099511628211ull;
+  }
+  return h;
+}
+
 static void drop_graph(csn_plan* P) {
 #ifndef CSN_CPU_EMU
   if (P->graph_exec) { (void)hipGraphExecDestroy(P->graph_exec); P->graph_exec = nullptr; }
 #endif
+  drop_slot(P->g_train);
+  drop_slot(P->g_bwd);
   P->g_x = P->g_y = P->g_ws = nullptr;
   P->eager_calls = 0;
 }
@@ -1064,13 +1128,27 @@ int csn_forward_profile(csn_plan* P, const float* x, float* y, void* workspace, 
   return forward_body(P, x, y, workspace, stream, iters, unit_ms);
 }
 
+static int forward_train_body(csn_plan* P, const float* x, float* y, void* workspace, float* arena,
+                              const float* flop_w, double* penalty, void* stream);
+
 int csn_forward_train(csn_plan* P, const float* x, float* y, void* workspace, float* arena, int64_t arena_floats,
                       const float* flop_w, double* penalty, void* stream) {
   if (!P || !x || !y || !workspace || !arena || !flop_w || !penalty) return CSN_E_INVALID;
   if (!P->params_ready) return CSN_E_STATE;
+  (void)arena_floats;
+  P->bn_tables_train = true;   // host-side state: set here, a graph replay does not run the body
+  const std::vector<uint64_t> key = {(uint64_t)(uintptr_t)x, (uint64_t)(uintptr_t)y, (uint64_t)(uintptr_t)workspace,
+                                     (uint64_t)(uintptr_t)arena, (uint64_t)(uintptr_t)penalty,
+                                     hash_floats(flop_w, (int)P->units.size() * CSN_MAX_BRANCH)};
+  return run_graphed(P, P->g_train, key, stream, [&](void* s) {
+    return forward_train_body(P, x, y, workspace, arena, flop_w, penalty, s);
+  });
+}
+
+static int forward_train_body(csn_plan* P, const float* x, float* y, void* workspace, float* arena,
+                              const float* flop_w, double* penalty, void* stream) {
   P->bn_tables_train = true;
   if (P->S != P->B) { g_hip_err = "train mode needs the whole batch in one slice (sub_batch = 0)"; return CSN_E_UNSUPPORTED; }
-  (void)arena_floats;
   const int nu = (int)P->units.size();
   Ctx c{*P, x, y, static_cast<char*>(workspace), stream};
   for (int u = 0; u < nu; ++u) {

@@ -141,12 +141,13 @@ class Engine:
                                                self._stream()), "csn_forward")
         return y
 
-    def forward_train(self, x: torch.Tensor, arena: torch.Tensor, flop_w, penalty: torch.Tensor) -> torch.Tensor:
+    def forward_train(self, x: torch.Tensor, arena: torch.Tensor, flop_w, penalty: torch.Tensor,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Train-mode forward: batch-stat BN (running stats in ``arena`` updated in place), penalty accumulated
         into the fp64 device scalar ``penalty``.  ``flop_w``: n_units x 3 floats (host)."""
         assert penalty.dtype == torch.float64 and penalty.numel() == 1 and penalty.device == x.device
         x = x.contiguous()
-        y = torch.empty((self.B, 1, self.H, self.W), dtype=torch.float32, device=x.device)
+        y = out if out is not None else torch.empty((self.B, 1, self.H, self.W), dtype=torch.float32, device=x.device)
         fw = (C.c_float * (self.n_units * N.MAX_BRANCH))(*[float(v) for v in flop_w])
         N.check(self.lib, self.lib.csn_forward_train(self.plan, x.data_ptr(), y.data_ptr(), self.workspace.data_ptr(),
                                                      arena.data_ptr(), arena.numel(), fw, penalty.data_ptr(),

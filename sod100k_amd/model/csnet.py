@@ -517,15 +517,20 @@ class CSNet(nn.Module):
             first.all_flops = first.all_flops + pen
         return y
 
-    def _train_forward_raw(self, x, with_backward=True):
+    def _train_forward_raw(self, x, with_backward=True, y=None, penalty=None):
         """(logits, fp64 device scalar penalty SUM) of one train-mode forward; keeps what csn_backward needs."""
         eng = self.engine_for(x, train=with_backward)
         arena = self._arena
         eng.refresh(arena.flat)                       # weight blocks + PReLU tables; BN tables are rewritten per batch
         units, _, names = self._desc_cache(arena)
         self._flop_tab = self._flop_weight_table(names, units)
-        penalty = torch.zeros(1, dtype=torch.float64, device=x.device)
-        y = eng.forward_train(x, arena.flat, self._flop_tab, penalty)
+        # persistent output / penalty buffers (FusedTrainer) keep every pointer of the step stable, which lets the
+        # library replay the step's launch sequence as a hipGraph
+        if penalty is None:
+            penalty = torch.zeros(1, dtype=torch.float64, device=x.device)
+        else:
+            penalty.zero_()
+        y = eng.forward_train(x, arena.flat, self._flop_tab, penalty, out=y)
         with torch.no_grad():
             nbt = [m.num_batches_tracked for m in self.modules()
                    if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]

@@ -64,6 +64,8 @@ class FusedTrainer:
         self.wd = wd.to(dev)
         self.steps = 0
         self.loss = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.pen = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.y = self.dy = None        # allocated on the first step, then re-used (stable pointers -> graph replay)
 
     def _stream(self, t):
         return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
@@ -75,9 +77,12 @@ class FusedTrainer:
         if model._arena is None or not model._arena.is_current():
             raise RuntimeError("the parameter arena was re-allocated (model.to()/cuda() after creating the trainer)")
         B = x.shape[0]
-        y, pen = model._train_forward_raw(x)
+        if self.y is None or self.y.shape[0] != B or tuple(self.y.shape[2:]) != tuple(x.shape[2:]):
+            self.y = torch.empty((B, 1) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+            self.dy = torch.empty_like(self.y)
+        y, pen = model._train_forward_raw(x, y=self.y, penalty=self.pen)
         self.loss.zero_()
-        dy = torch.empty_like(y)
+        dy = self.dy
         N.check(self.lib, self.lib.csn_bce_with_logits(y.data_ptr(), target.data_ptr(), dy.data_ptr(), y.numel(),
                                                        self.loss.data_ptr(), self._stream(y)), "csn_bce_with_logits")
         bs = self.batchsize or B
@@ -91,7 +96,7 @@ class FusedTrainer:
                                                  self.v.data_ptr(), self.wd.data_ptr(), self.n, self.lr,
                                                  self.betas[0], self.betas[1], self.eps, self.steps,
                                                  self._stream(y)), "csn_adam_step")
-        return self.loss.clone(), pen / bs
+        return self.loss.clone(), pen.clone() / bs
 
 
 def reference_style_step(model, optimizer, x, target, flops_weight):
