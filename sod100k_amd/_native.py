@@ -14,7 +14,7 @@ from typing import Optional, Sequence
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libcsnet_hip.so")
-SOURCES = ("csn_plan.hip", "k_misc.hip", "k_goct_pw.hip", "k_ms.hip", "k_train.hip", "k_wgrad.hip", "k_goct_c3.hip")
+SOURCES = ("csn_plan.hip", "k_misc.hip", "k_goct_pw.hip", "k_ms.hip", "k_train.hip", "k_wgrad.hip", "k_goct_c3.hip", "k_csf.hip")
 
 MAX_BRANCH = 3
 NDIL = 5
@@ -62,6 +62,23 @@ def new_unit(kind: int) -> UnitDesc:
     return u
 
 
+CSF_MAX_BRANCH = 4
+
+
+class CsfGnOff(C.Structure):
+    _fields_ = [("weight", C.c_int64), ("bias", C.c_int64), ("prelu", C.c_int64)]
+
+
+class CsfHeadDesc(C.Structure):
+    """include/csf_hip.h: csf_head_desc."""
+    _fields_ = [("n_branch", C.c_int32), ("gn_groups", C.c_int32),
+                ("cin", C.c_int32 * CSF_MAX_BRANCH), ("cmid", C.c_int32 * CSF_MAX_BRANCH),
+                ("ms_split", (C.c_int32 * NDIL) * CSF_MAX_BRANCH),
+                ("fuse_w", C.c_int64), ("fuse_gn", CsfGnOff * CSF_MAX_BRANCH),
+                ("ms_w", (C.c_int64 * NDIL) * CSF_MAX_BRANCH), ("ms_gn", CsfGnOff * CSF_MAX_BRANCH),
+                ("fuse1_w", C.c_int64), ("fuse1_gn", CsfGnOff), ("cls_w", C.c_int64), ("cls_b", C.c_int64)]
+
+
 def hipcc_path() -> Optional[str]:
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -72,8 +89,8 @@ def hipcc_path() -> Optional[str]:
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 into ``csrc/libcsnet_hip.so`` (in-tree, not installed)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ("csn_device.h", "csn_kernels.h")] + \
-        [os.path.join(os.path.dirname(HERE), "include", "csnet_hip.h")]
+    deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith((".h", ".inl"))] + \
+        [os.path.join(os.path.dirname(HERE), "include", h) for h in ("csnet_hip.h", "csf_hip.h")]
     if not force and os.path.exists(LIB_PATH) and all(
             os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
@@ -142,6 +159,23 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.csn_unit_kernel_name.argtypes = [C.c_void_p, C.c_int32]
     lib.csn_unit_algorithmic_bytes.restype = C.c_int64
     lib.csn_unit_algorithmic_bytes.argtypes = [C.c_void_p, C.c_int32]
+    # include/csf_hip.h
+    lib.csf_head_create.restype = C.c_int
+    lib.csf_head_create.argtypes = [C.POINTER(CsfHeadDesc), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                    C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.csf_head_destroy.restype = None
+    lib.csf_head_destroy.argtypes = [C.c_void_p]
+    lib.csf_head_workspace_bytes.restype = C.c_size_t
+    lib.csf_head_workspace_bytes.argtypes = [C.c_void_p]
+    lib.csf_head_refresh_params.restype = C.c_int
+    lib.csf_head_refresh_params.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.csf_head_forward.restype = C.c_int
+    lib.csf_head_forward.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.csf_head_stage_info.restype = C.c_int
+    lib.csf_head_stage_info.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.csf_head_macs.restype = C.c_int64
+    lib.csf_head_macs.argtypes = [C.c_void_p]
     return lib
 
 
@@ -149,7 +183,9 @@ EXPORTS: Sequence[str] = (
     "csn_abi_version", "csn_strerror", "csn_last_hip_error", "csn_plan_create", "csn_plan_destroy",
     "csn_plan_set_option", "csn_plan_workspace_bytes", "csn_plan_act_info", "csn_plan_num_units", "csn_plan_refresh_params",
     "csn_forward", "csn_forward_train", "csn_plan_enable_training", "csn_backward", "csn_bce_with_logits",
-           "csn_adam_step", "csn_saliency_u8", "csn_normalize_nchw", "csn_sal_hist", "csn_forward_profile", "csn_profile_num_kernels", "csn_profile_kernel", "csn_unit_kernel_name", "csn_unit_algorithmic_bytes")
+           "csn_adam_step", "csn_saliency_u8", "csn_normalize_nchw", "csn_sal_hist", "csn_forward_profile", "csn_profile_num_kernels", "csn_profile_kernel", "csn_unit_kernel_name", "csn_unit_algorithmic_bytes",
+    "csf_head_create", "csf_head_destroy", "csf_head_workspace_bytes", "csf_head_refresh_params", "csf_head_forward",
+    "csf_head_stage_info", "csf_head_macs")
 
 _lib: Optional[C.CDLL] = None
 

@@ -1,0 +1,111 @@
+// csf_kernels.h -- argument blocks and launchers of the CSF+Res2Net head kernels (k_csf.hip).
+//
+// Everything is planar fp32 [B][C][H*W].  The head is dense contraction work (K = 128 .. 3840), so unlike the
+// CSNet-100K kernels it is priced against the fp32 matrix-core roofline: csf_gemm_kernel is a block-tiled
+// implicit GEMM  out[n][m][p] = sum_k A[m][k] * G(k; n, p)  on v_mfma_f32_16x16x4_f32 whose B operand G is gathered
+// on the fly from up to four source tensors (own resolution, bilinear resample of another level, dilated 3x3 taps).
+#pragma once
+#include "csn_device.h"
+
+#define CSF_KC 16            // K chunk staged per barrier
+#define CSF_BN 256           // pixels per block: 4 waves x 64
+#define CSF_BP (CSF_BN + 16) // LDS pitch of a B row (pitch mod 32 == 16: the 4 k rows of one MFMA read hit distinct banks)
+#define CSF_MAX_SEG 4
+
+enum CsfSegMode { CSF_OWN = 0, CSF_RESIZE = 1 };
+
+struct CsfSeg {
+  const float* src;      // [B][ctot][Hs*Ws], already offset to the first channel of the slice
+  unsigned bytes;        // extent of the tensor from src on (bounded buffer resource)
+  int nstride;           // floats between images
+  int cstride;           // floats between channels (= Hs*Ws)
+  int Hs, Ws;
+  int chunks;            // channels / 16
+  int mode;
+  float ry, rx;          // RESIZE: Hs/Ho, Ws/Wo as F.interpolate computes them (float(in) / out)
+};
+
+struct CsfGemmArgs {
+  const float* A;        // [Mp][Kp] row-major, zero padded (rows to the block tile, K to 16)
+  int M, Kp;
+  int nseg;              // 1x1: concatenated segments; taps: ONE source, 9 pseudo-segments (tap-major K)
+  int taps;              // 0 or 9
+  int dil;
+  CsfSeg seg[CSF_MAX_SEG];
+  float* out;            // [B][out_ctot][HWo], already offset to the first output row
+  long long out_nstride;
+  int Ho, Wo, HWo, Ntot; // Ntot = B * HWo
+  int n_mtiles, n_ntiles;
+};
+
+struct CsfZ {            // a coarser tensor added through bilinear up-sampling (gOctConv.py:96-98)
+  const float* z;        // [B][ctot][Hz*Wz] offset to the first channel
+  long long nstride;
+  int Hz, Wz;
+  float ry, rx;
+};
+
+struct CsfCombArgs {     // s += sum_i up(z_i); partial sums of s and s^2 per (image, group, slab) in fp64
+  float* s;              // [B][C][HW]
+  int B, C, H, W, HW, cpg, groups;
+  int nz;
+  CsfZ z[3];
+  double* part;          // [B*groups][nslab][2]
+  int nslab, slab_len;   // a group's cpg*HW contiguous floats cut into nslab slabs
+};
+
+struct CsfGnFinArgs {    // per (image, group): mean / rstd -> per (image, channel) scale and shift
+  const double* part;
+  int nslab, cpg, groups, C, HW, B;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  float* scale;          // [B][C]
+  float* shift;
+};
+
+struct CsfApplyArgs {    // y = prelu(s * scale[n][c] + shift[n][c]) in place
+  float* s;
+  const float* scale;
+  const float* shift;
+  const float* alpha;
+  int C, HW;
+  long long total;       // B*C*HW
+};
+
+struct CsfClsArgs {      // logits[n][p] = bias + sum_c w[c] * prelu(s[n][c][p] * scale + shift)
+  const float* s;
+  const float* scale;
+  const float* shift;
+  const float* alpha;
+  const float* w;
+  const float* bias;
+  float* out;            // [B][HW]
+  int C, HW, B;
+};
+
+struct CsfResizeArgs {   // F.interpolate(size, bilinear, align_corners=False) of [planes][Hi][Wi]
+  const float* in;
+  float* out;
+  int planes, Hi, Wi, Ho, Wo;
+  float ry, rx;
+};
+
+struct CsfPrepSeg { int k0, C, col0; };
+struct CsfPrepArgs {     // weight image: dst[m][k] (zero padded) from arena rows
+  const float* src;      // arena + offset of W[row 0][0]
+  float* dst;
+  int M, Mp, Kp, ld;     // ld: floats per source row
+  int taps;              // 9: k = tap*Cp + c reads src[m*ld + c*9 + tap] (seg[0] = {Cp, C, 0}); 0: k in segment s reads
+                         // src[m*ld + col0 + (k-k0)], columns past C are zero
+  int nseg;
+  CsfPrepSeg seg[CSF_MAX_SEG];
+};
+
+int csf_launch_gemm(const CsfGemmArgs& a, int mt, void* stream);     // mt: 16-row tiles per block (2 or 4)
+int csf_launch_combine(const CsfCombArgs& a, void* stream);
+int csf_launch_gn_finalize(const CsfGnFinArgs& a, void* stream);
+int csf_launch_apply(const CsfApplyArgs& a, void* stream);
+int csf_launch_cls(const CsfClsArgs& a, void* stream);
+int csf_launch_resize(const CsfResizeArgs& a, void* stream);
+int csf_launch_prep(const CsfPrepArgs& a, void* stream);

@@ -1208,3 +1208,5 @@ int64_t csn_unit_algorithmic_bytes(const csn_plan* P, int32_t u) {
 }
 
 }  // extern "C"
+
+#include "csf_head.inl"      // CSF+Res2Net decoder head (include/csf_hip.h)

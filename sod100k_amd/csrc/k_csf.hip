@@ -1,0 +1,393 @@
+// k_csf.hip -- kernels of the CSF+Res2Net decoder head (CSF+Res2Net/networks/csf_res2net.py:227-256).
+//
+//   csf_gemm_kernel<MT>   out[n][m][p] = sum_k A[m][k] * G(k; n, p): every gOctConv 1x1 block (gOctConv.py:60-114) and
+//                         every dense dilated 3x3 of the MSBlocks (csf_res2net.py:192-214) as an implicit GEMM on
+//                         v_mfma_f32_16x16x4_f32.  Block tile (16 MT) rows x 256 pixels, K in chunks of 16:
+//                           A chunk   one 128-bit load per thread from the zero-padded row-major weight image
+//                                     (k contiguous), stored k-major in LDS;
+//                           B chunk   lane = pixel; 16 channels of its pixel through a bounded buffer resource
+//                                     (per-lane byte offset in ONE VGPR, the channel rides in the scalar offset):
+//                                     own resolution / 3x3 tap (zero padding = out-of-range offset -> 0) one dword,
+//                                     bilinear resample of another level (gOctConv.py:99-101) four dwords + lerp;
+//                           both land in registers while the PREVIOUS chunk is being contracted (register prefetch,
+//                           two LDS buffers, one barrier per chunk);
+//                           contract  every wave owns (16 MT) x 64 outputs: per 4 k, MT A reads + 4 B reads feed
+//                                     4 MT MFMAs; accumulators stay in VGPRs for the whole K loop.
+//                         Blocks that share a pixel tile (different row tiles) are adjacent in the launch order and
+//                         the order is cut into 8 contiguous chunks, one per XCD, so the re-gathered B operand is
+//                         served by that XCD's L2.
+//   csf_combine_kernel    adds the coarser levels' partial outputs through bilinear up-sampling (gOctConv.py:96-98,
+//                         109-110) and takes the GroupNorm statistics (fp64 partials, fixed order) in the same pass
+//   csf_gn_finalize / csf_apply_kernel   nn.GroupNorm(32, C) + nn.PReLU(C) (gOctConv.py:127-130,148-151)
+//   csf_cls_kernel        fuse1x1's GroupNorm + PReLU applied on the fly + cls_layer (1x1 + bias) (csf_res2net.py:253)
+//   csf_resize_kernel     F.interpolate(size, bilinear, align_corners=False) (csf_res2net.py:254)
+//   csf_prep_kernel       weight images
+#include "csf_kernels.h"
+#include "pw_gather.h"   // csn_f4
+
+// ---------------------------------------------------------------------------------------------------- GEMM
+struct CsfGather {       // per-lane addressing of the current (pseudo-)segment
+  unsigned o00, o01, o10, o11;   // byte offsets (RESIZE uses all four)
+  float ly, lx;
+};
+
+__device__ __forceinline__ void csf_seg_setup(const CsfGemmArgs& a, int ps, int n, int oy, int ox, CsfGather& g,
+                                              int& si) {
+  if (a.taps) {   // pseudo-segment = tap of the dilated 3x3, zero padding (csf_res2net.py:203)
+    si = 0;
+    const CsfSeg& s = a.seg[0];
+    const int ty = ps / 3, tx = ps - 3 * ty;
+    const int y = oy + (ty - 1) * a.dil, x = ox + (tx - 1) * a.dil;
+    const bool ok = y >= 0 && y < s.Hs && x >= 0 && x < s.Ws;
+    g.o00 = ok ? (unsigned)(n * s.nstride + y * s.Ws + x) * 4u : 0x80000000u;
+    return;
+  }
+  si = ps;
+  const CsfSeg& s = a.seg[ps];
+  if (s.mode == CSF_OWN) {
+    g.o00 = (unsigned)(n * s.nstride + oy * s.Ws + ox) * 4u;
+  } else {
+    int y0, y1, x0, x1;
+    csn_bilin(oy, s.ry, s.Hs, y0, y1, g.ly);
+    csn_bilin(ox, s.rx, s.Ws, x0, x1, g.lx);
+    const unsigned b = (unsigned)(n * s.nstride);
+    g.o00 = (b + y0 * s.Ws + x0) * 4u;
+    g.o01 = (b + y0 * s.Ws + x1) * 4u;
+    g.o10 = (b + y1 * s.Ws + x0) * 4u;
+    g.o11 = (b + y1 * s.Ws + x1) * 4u;
+  }
+}
+
+template <int MT>
+__global__ __launch_bounds__(256) void csf_gemm_kernel(CsfGemmArgs a) {
+  constexpr int BM = 16 * MT, AP = BM + 16;
+  CSN_DYN_SMEM(float, lds);
+  float* As = lds;                       // [2][16][AP]
+  float* Bs = lds + 2 * CSF_KC * AP;     // [2][16][CSF_BP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  const int per = gridDim.x >> 3;        // grid is a multiple of 8: contiguous chunk of the tile order per XCD
+  const int lb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (lb >= a.n_mtiles * a.n_ntiles) return;
+  const int mt = lb % a.n_mtiles, nt = lb / a.n_mtiles;
+  const int m0 = mt * BM;
+
+  const int p = nt * CSF_BN + tid;
+  const int pc = p < a.Ntot ? p : a.Ntot - 1;
+  const int n = pc / a.HWo, pix = pc - n * a.HWo;
+  const int oy = pix / a.Wo, ox = pix - oy * a.Wo;
+
+  csn_f4 acc[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = csn_f4{0.f, 0.f, 0.f, 0.f};
+
+  const int nps = a.taps ? 9 : a.nseg;
+  const int nchunks = a.Kp / CSF_KC;
+  // A: thread -> (row, 4 consecutive k)
+  const bool a_ld = tid < BM * 4;
+  const float* ap = a.A + (size_t)(m0 + (tid >> 2)) * a.Kp + (tid & 3) * 4;
+
+  int ps = 0, cc = 0, si = 0;
+  CsfGather g;
+  csf_seg_setup(a, 0, n, oy, ox, g, si);
+  csn_buf buf = csn_make_buf_n(a.seg[si].src, a.seg[si].bytes);
+
+  float4 ra = make_float4(0.f, 0.f, 0.f, 0.f);
+  float rb[CSF_KC];
+
+  auto fetch = [&](int kc) {
+    if (a_ld) ra = *reinterpret_cast<const float4*>(ap + (size_t)kc * CSF_KC);
+    const CsfSeg& s = a.seg[si];
+    const unsigned cb = (unsigned)(cc * CSF_KC) * (unsigned)s.cstride * 4u;
+    const unsigned cs = (unsigned)s.cstride * 4u;
+    if (!a.taps && s.mode == CSF_RESIZE) {
+      const float wy0 = 1.f - g.ly, wx0 = 1.f - g.lx;
+#pragma unroll
+      for (int r = 0; r < CSF_KC; ++r) {
+        const unsigned so = cb + r * cs;
+        const float v00 = csn_ld1(buf, g.o00, so), v01 = csn_ld1(buf, g.o01, so);
+        const float v10 = csn_ld1(buf, g.o10, so), v11 = csn_ld1(buf, g.o11, so);
+        rb[r] = wy0 * (wx0 * v00 + g.lx * v01) + g.ly * (wx0 * v10 + g.lx * v11);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < CSF_KC; ++r) rb[r] = csn_ld1(buf, g.o00, cb + r * cs);
+    }
+    // advance to the next chunk's (pseudo-)segment
+    if (++cc == a.seg[si].chunks) {
+      cc = 0;
+      if (++ps < nps) {
+        csf_seg_setup(a, ps, n, oy, ox, g, si);
+        buf = csn_make_buf_n(a.seg[si].src, a.seg[si].bytes);
+      }
+    }
+  };
+
+  fetch(0);
+  for (int kc = 0; kc < nchunks; ++kc) {
+    float* Ab = As + (kc & 1) * CSF_KC * AP;
+    float* Bb = Bs + (kc & 1) * CSF_KC * CSF_BP;
+    if (a_ld) {
+      const int row = tid >> 2, k4 = (tid & 3) * 4;
+      Ab[(k4 + 0) * AP + row] = ra.x;
+      Ab[(k4 + 1) * AP + row] = ra.y;
+      Ab[(k4 + 2) * AP + row] = ra.z;
+      Ab[(k4 + 3) * AP + row] = ra.w;
+    }
+#pragma unroll
+    for (int r = 0; r < CSF_KC; ++r) Bb[r * CSF_BP + tid] = rb[r];
+    __syncthreads();
+    if (kc + 1 < nchunks) fetch(kc + 1);
+    const float* bw = Bb + wave * 64;
+#pragma unroll
+    for (int kk = 0; kk < CSF_KC / 4; ++kk) {
+#ifdef CSN_CPU_EMU
+      const int col = lane & 15;
+      for (int i = 0; i < MT; ++i)
+        for (int j = 0; j < 4; ++j)
+          for (int e = 0; e < 4; ++e) {
+            const int row = (lane >> 4) * 4 + e;
+            float v = acc[i][j][e];
+            for (int u = 0; u < 4; ++u)
+              v = fmaf(Ab[(kk * 4 + u) * AP + i * 16 + row], bw[(kk * 4 + u) * CSF_BP + j * 16 + col], v);
+            acc[i][j][e] = v;
+          }
+#else
+      float av[MT], bv[4];
+      const int kr = kk * 4 + (lane >> 4), c = lane & 15;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) av[i] = Ab[kr * AP + i * 16 + c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = bw[kr * CSF_BP + j * 16 + c];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+#endif
+    }
+  }
+
+  // D layout: register e of a lane = row (lane>>4)*4 + e, column lane&15
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = nt * CSF_BN + wave * 64 + j * 16 + (lane & 15);
+    if (q >= a.Ntot) continue;
+    const int qn = q / a.HWo, qp = q - qn * a.HWo;
+    float* o = a.out + (size_t)qn * a.out_nstride + qp;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + i * 16 + (lane >> 4) * 4 + e;
+        if (m < a.M) o[(size_t)m * a.HWo] = acc[i][j][e];
+      }
+  }
+}
+
+int csf_launch_gemm(const CsfGemmArgs& a, int mt, void* stream) {
+  const int tiles = a.n_mtiles * a.n_ntiles;
+  if (tiles <= 0) return 0;
+  const int grid = (tiles + 7) / 8 * 8;
+  if (mt == 4) {
+    const size_t lds = (size_t)2 * CSF_KC * (64 + 16 + CSF_BP) * sizeof(float);
+    CSN_LAUNCH(csf_gemm_kernel<4>, dim3(grid), dim3(256), lds, stream, a);
+  } else if (mt == 2) {
+    const size_t lds = (size_t)2 * CSF_KC * (32 + 16 + CSF_BP) * sizeof(float);
+    CSN_LAUNCH(csf_gemm_kernel<2>, dim3(grid), dim3(256), lds, stream, a);
+  } else {
+    return -1;
+  }
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------ combine + GroupNorm statistics
+__global__ __launch_bounds__(CSN_BLOCK) void csf_combine_kernel(CsfCombArgs a) {
+  CSN_DYN_SMEM(double, red);   // [2][CSN_BLOCK]
+  const int slab = blockIdx.x, ng = blockIdx.y;
+  const int n = ng / a.groups, gidx = ng - n * a.groups;
+  const long long gbase = ((long long)n * a.C + (long long)gidx * a.cpg) * a.HW;
+  const int glen = a.cpg * a.HW;
+  const int e0 = slab * a.slab_len, e1 = min(glen, e0 + a.slab_len);
+  double s1 = 0.0, s2 = 0.0;
+  for (int e = e0 + (int)threadIdx.x; e < e1; e += CSN_BLOCK) {
+    float v = a.s[gbase + e];
+    if (a.nz) {
+      const int c = e / a.HW, pix = e - c * a.HW;
+      const int y = pix / a.W, x = pix - y * a.W;
+      const int ch = gidx * a.cpg + c;
+      for (int i = 0; i < a.nz; ++i) {
+        const CsfZ& z = a.z[i];
+        int y0, y1, x0, x1;
+        float ly, lx;
+        csn_bilin(y, z.ry, z.Hz, y0, y1, ly);
+        csn_bilin(x, z.rx, z.Wz, x0, x1, lx);
+        const float* q = z.z + (long long)n * z.nstride + (long long)ch * z.Hz * z.Wz;
+        const float t0 = (1.f - lx) * q[y0 * z.Wz + x0] + lx * q[y0 * z.Wz + x1];
+        const float t1 = (1.f - lx) * q[y1 * z.Wz + x0] + lx * q[y1 * z.Wz + x1];
+        v += (1.f - ly) * t0 + ly * t1;
+      }
+      a.s[gbase + e] = v;
+    }
+    s1 += (double)v;
+    s2 += (double)v * (double)v;
+  }
+  red[threadIdx.x] = s1;
+  red[CSN_BLOCK + threadIdx.x] = s2;
+  __syncthreads();
+  for (int st = CSN_BLOCK / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) {
+      red[threadIdx.x] += red[threadIdx.x + st];
+      red[CSN_BLOCK + threadIdx.x] += red[CSN_BLOCK + threadIdx.x + st];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    a.part[((long long)ng * a.nslab + slab) * 2 + 0] = red[0];
+    a.part[((long long)ng * a.nslab + slab) * 2 + 1] = red[CSN_BLOCK];
+  }
+}
+
+int csf_launch_combine(const CsfCombArgs& a, void* stream) {
+  CSN_LAUNCH(csf_combine_kernel, dim3(a.nslab, a.B * a.groups, 1), dim3(CSN_BLOCK), 2 * CSN_BLOCK * sizeof(double),
+             stream, a);
+  return (int)hipGetLastError();
+}
+
+// one thread per (image, channel): group moments (fixed-order sum of the slabs) -> folded scale / shift
+__global__ __launch_bounds__(CSN_BLOCK) void csf_gn_finalize_kernel(CsfGnFinArgs a) {
+  const int i = blockIdx.x * CSN_BLOCK + threadIdx.x;
+  if (i >= a.B * a.C) return;
+  const int n = i / a.C, c = i - n * a.C;
+  const int ng = n * a.groups + c / a.cpg;
+  double s1 = 0.0, s2 = 0.0;
+  for (int s = 0; s < a.nslab; ++s) {
+    s1 += a.part[((long long)ng * a.nslab + s) * 2 + 0];
+    s2 += a.part[((long long)ng * a.nslab + s) * 2 + 1];
+  }
+  const double cnt = (double)a.cpg * (double)a.HW;
+  const double mean = s1 / cnt;
+  double var = s2 / cnt - mean * mean;
+  var = var < 0.0 ? 0.0 : var;
+  const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+  const float sc = rstd * a.gamma[c];
+  a.scale[i] = sc;
+  a.shift[i] = a.beta[c] - sc * (float)mean;
+}
+
+int csf_launch_gn_finalize(const CsfGnFinArgs& a, void* stream) {
+  const int nblk = (a.B * a.C + CSN_BLOCK - 1) / CSN_BLOCK;
+  CSN_LAUNCH(csf_gn_finalize_kernel, dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+__global__ __launch_bounds__(CSN_BLOCK) void csf_apply_kernel(CsfApplyArgs a) {
+  for (long long i = (long long)blockIdx.x * CSN_BLOCK + threadIdx.x; i < a.total; i += (long long)gridDim.x * CSN_BLOCK) {
+    const long long plane = i / a.HW;          // n*C + c
+    const int c = (int)(plane % a.C);
+    const float y = fmaf(a.s[i], a.scale[plane], a.shift[plane]);
+    a.s[i] = y >= 0.f ? y : a.alpha[c] * y;
+  }
+}
+
+int csf_launch_apply(const CsfApplyArgs& a, void* stream) {
+  long long nblk = (a.total + CSN_BLOCK - 1) / CSN_BLOCK;
+  if (nblk > 16384) nblk = 16384;
+  if (nblk <= 0) return 0;
+  CSN_LAUNCH(csf_apply_kernel, dim3((unsigned)nblk), dim3(CSN_BLOCK), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+// lane = pixel (coalesced channel planes), four independent accumulators over the channels
+__global__ __launch_bounds__(CSN_BLOCK) void csf_cls_kernel(CsfClsArgs a) {
+  const long long i = (long long)blockIdx.x * CSN_BLOCK + threadIdx.x;
+  if (i >= (long long)a.B * a.HW) return;
+  const int n = (int)(i / a.HW), pix = (int)(i - (long long)n * a.HW);
+  const float* s = a.s + (long long)n * a.C * a.HW + pix;
+  const float* sc = a.scale + (long long)n * a.C;
+  const float* sh = a.shift + (long long)n * a.C;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int c = 0;
+  for (; c + 4 <= a.C; c += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float y = fmaf(s[(long long)(c + u) * a.HW], sc[c + u], sh[c + u]);
+      y = y >= 0.f ? y : a.alpha[c + u] * y;
+      acc[u] = fmaf(a.w[c + u], y, acc[u]);
+    }
+  }
+  for (; c < a.C; ++c) {
+    float y = fmaf(s[(long long)c * a.HW], sc[c], sh[c]);
+    y = y >= 0.f ? y : a.alpha[c] * y;
+    acc[0] = fmaf(a.w[c], y, acc[0]);
+  }
+  a.out[i] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + a.bias[0];
+}
+
+int csf_launch_cls(const CsfClsArgs& a, void* stream) {
+  const long long total = (long long)a.B * a.HW;
+  const int nblk = (int)((total + CSN_BLOCK - 1) / CSN_BLOCK);
+  if (nblk <= 0) return 0;
+  CSN_LAUNCH(csf_cls_kernel, dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+__global__ __launch_bounds__(CSN_BLOCK) void csf_resize_kernel(CsfResizeArgs a) {
+  const long long total = (long long)a.planes * a.Ho * a.Wo;
+  const long long i = (long long)blockIdx.x * CSN_BLOCK + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % a.Wo);
+  const int y = (int)((i / a.Wo) % a.Ho);
+  const long long plane = i / ((long long)a.Wo * a.Ho);
+  const float* p = a.in + plane * a.Hi * a.Wi;
+  if (a.Hi == a.Ho && a.Wi == a.Wo) {   // F.interpolate copies when the size does not change
+    a.out[i] = p[y * a.Wi + x];
+    return;
+  }
+  int y0, y1, x0, x1;
+  float ly, lx;
+  csn_bilin(y, a.ry, a.Hi, y0, y1, ly);
+  csn_bilin(x, a.rx, a.Wi, x0, x1, lx);
+  const float v0 = (1.f - lx) * p[y0 * a.Wi + x0] + lx * p[y0 * a.Wi + x1];
+  const float v1 = (1.f - lx) * p[y1 * a.Wi + x0] + lx * p[y1 * a.Wi + x1];
+  a.out[i] = (1.f - ly) * v0 + ly * v1;
+}
+
+int csf_launch_resize(const CsfResizeArgs& a, void* stream) {
+  const long long total = (long long)a.planes * a.Ho * a.Wo;
+  const int nblk = (int)((total + CSN_BLOCK - 1) / CSN_BLOCK);
+  if (nblk <= 0) return 0;
+  CSN_LAUNCH(csf_resize_kernel, dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------- weight images
+__global__ __launch_bounds__(CSN_BLOCK) void csf_prep_kernel(CsfPrepArgs a) {
+  const long long total = (long long)a.Mp * a.Kp;
+  for (long long i = (long long)blockIdx.x * CSN_BLOCK + threadIdx.x; i < total; i += (long long)gridDim.x * CSN_BLOCK) {
+    const int m = (int)(i / a.Kp), k = (int)(i - (long long)m * a.Kp);
+    float v = 0.f;
+    if (m < a.M) {
+      if (a.taps) {
+        const int Cp = a.seg[0].k0;            // taps: k = tap * Cp + c (Cp = channels padded to the K chunk)
+        const int tap = k / Cp, c = k - tap * Cp;
+        if (tap < 9 && c < a.seg[0].C) v = a.src[(long long)m * a.ld + (long long)c * 9 + tap];
+      } else {
+        for (int s = 0; s < a.nseg; ++s) {
+          const int kk = k - a.seg[s].k0;
+          if (kk >= 0 && kk < a.seg[s].C) v = a.src[(long long)m * a.ld + a.seg[s].col0 + kk];
+        }
+      }
+    }
+    a.dst[i] = v;
+  }
+}
+
+int csf_launch_prep(const CsfPrepArgs& a, void* stream) {
+  long long nblk = ((long long)a.Mp * a.Kp + CSN_BLOCK - 1) / CSN_BLOCK;
+  if (nblk > 8192) nblk = 8192;
+  if (nblk <= 0) return 0;
+  CSN_LAUNCH(csf_prep_kernel, dim3((unsigned)nblk), dim3(CSN_BLOCK), 0, stream, a);
+  return (int)hipGetLastError();
+}
