@@ -66,6 +66,9 @@ def main():
                     help="keep cls_layer as its own launch (PMC calibration: it reads exactly 79x112x112x4 B per image)")
     ap.add_argument("--train-batch", type=int, default=256,
                     help="images per GPU per train step (SURVEY 8(d) config 3: 256; 0 = --batch)")
+    ap.add_argument("--csf-batch", type=int, default=32,
+                    help="also time the CSF+Res2Net forward (BASELINE config 5: batch x 3x352x352) on 1 GPU; 0 = skip")
+    ap.add_argument("--csf-steps", type=int, default=5)
     ap.add_argument("--train-steps", type=int, default=10,
                     help="also time this many full train steps (0 = skip); reported under \"train_step\"")
     args = ap.parse_args()
@@ -170,6 +173,13 @@ def main():
                          + ("RCCL all-reduce of the flat gradient + " if world > 1 else "") + "Adam, csnet-L-x2 weights"}
         model.eval()
 
+    csf = None
+    if world == 1 and args.csf_batch > 0:
+        try:
+            csf = csf_point(dev, args.csf_batch, args.csf_steps)
+        except Exception as e:          # a secondary data point must never take the headline line down
+            csf = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         value = world * B * args.steps / dt
         out = {
@@ -186,10 +196,47 @@ def main():
         }
         if train is not None:
             out["train_step"] = train
+        if csf is not None:
+            out["csf_res2net"] = csf
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(man)
         print(json.dumps(out))
     D.finalize()
+
+
+def csf_point(dev, batch, steps):
+    """BASELINE config 5: CSF+Res2Net-50 eval forward, batch x 3x352x352 fp32, random-init weights.  The decoder head
+    is the HIP implicit-GEMM path (include/csf_hip.h), the backbone is issued through PyTorch-ROCm / MIOpen."""
+    import torch
+    from sod100k_amd.networks import csf_res2net as R
+    torch.cuda.empty_cache()
+    net = R.build_model().to(dev).eval()
+    x = torch.randn(batch, 3, 352, 352, generator=torch.Generator().manual_seed(5)).to(dev)
+
+    def timed(fn, n):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / n
+
+    with torch.no_grad():
+        feats = [f.contiguous() for f in net.base(x)]
+        ms_head = timed(lambda: net.head_forward(feats, x.shape[2:]), steps)
+        ms_all = timed(lambda: net(x), steps)
+    eng = list(net._engines.values())[-1]
+    tf = 2.0 * eng.macs / (ms_head * 1e-3) / 1e12
+    peak = 157.3                               # fp32 matrix-core peak, MI355X_MICROARCH.md (dense, no sparsity)
+    return {"workload": f"CSF+Res2Net-50 eval forward, batch {batch} x 3x352x352 fp32, random-init weights",
+            "value": round(batch / (ms_all * 1e-3), 1), "unit": "images/sec", "ms_per_step": round(ms_all, 3),
+            "ms_head_hip": round(ms_head, 3), "ms_backbone_miopen": round(ms_all - ms_head, 3),
+            "head_roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                              "frac": round(tf / peak, 4), "kernel": "csf_gemm_kernel (+ combine / GroupNorm passes)",
+                              "flops_per_step": int(2 * eng.macs)}}
 
 
 def eng_sub(eng, B):

@@ -16,6 +16,7 @@ struct csf_head {
   size_t ws_bytes = 0;
   int64_t macs = 0;
   bool refreshed = false;
+  int z_lds_max = 12 * 1024;             // floats; CSF_Z_LDS_MAX overrides (tests force the global-memory tap path)
   std::vector<CsfPrepJob> prep;
   std::vector<CsfCopyJob> copies;
   struct Stage { int64_t off; int C, H, W; } stage[3][CSF_MAX_BRANCH];
@@ -50,16 +51,41 @@ struct CsfSrc {          // one K segment of a GEMM
   int C, ctot, Hs, Ws, mode;
 };
 
-int csf_gemm(CsfWalk& W, int M, int nseg, const CsfSrc* src, int taps, int dil, int64_t w_arena, int ld,
-             const int* col0, float* out, int out_ctot, int Ho, int Wo) {
+struct CsfSubPlan { int M, dil; int64_t w_arena; float* out; };
+
+struct CsfGeom {         // tiling of one launch (known before its output is allocated: split-K needs planes)
+  int mt = 4, BM = 64, n_ntiles = 0, tiles = 0, nchunks = 0, ksplit = 1, cps = 0;
+  int n_mtiles[CSF_MAX_SUB] = {0};
+};
+
+// Under-filled launches (coarse levels: few pixel tiles, K up to 4608) are cut along K until ~3 blocks per CU exist;
+// every slice keeps >= 16 chunks.  The planes are summed in slice order by the combine pass (deterministic).
+CsfGeom csf_geom(int nsub, const int* M, int nseg, const int* segC, int taps, int Ntot, bool allow_split) {
+  CsfGeom g;
+  int maxM = 0;
+  for (int i = 0; i < nsub; ++i) maxM = std::max(maxM, M[i]);
+  g.mt = maxM >= 48 ? 4 : 2;
+  g.BM = 16 * g.mt;
+  g.n_ntiles = (Ntot + CSF_BN - 1) / CSF_BN;
+  for (int i = 0; i < nsub; ++i) {
+    g.n_mtiles[i] = (M[i] + g.BM - 1) / g.BM;
+    g.tiles += g.n_mtiles[i] * g.n_ntiles;
+  }
+  for (int s = 0; s < nseg; ++s) g.nchunks += (segC[s] + CSF_KC - 1) / CSF_KC;
+  if (taps) g.nchunks *= 9;
+  if (allow_split)
+    while (g.tiles * g.ksplit < 768 && g.ksplit < 8 && g.nchunks / (g.ksplit * 2) >= 16) g.ksplit *= 2;
+  g.cps = (g.nchunks + g.ksplit - 1) / g.ksplit;
+  return g;
+}
+
+int csf_gemm(CsfWalk& W, const CsfGeom& G, int nsub, const CsfSubPlan* subs, int nseg, const CsfSrc* src, int taps,
+             int ld, const int* col0, int out_ctot, int Ho, int Wo, int64_t split_stride) {
   csf_head* H = W.H;
-  const int mt = M >= 48 ? 4 : 2, BM = 16 * mt;
-  const int Mp = (M + BM - 1) / BM * BM;
   int Kp = 0;
   CsfPrepJob pj{};
   CsfGemmArgs a{};
   a.taps = taps;
-  a.dil = dil;
   a.nseg = nseg;
   int64_t kreal = 0;
   for (int s = 0; s < nseg; ++s) {
@@ -86,47 +112,55 @@ int csf_gemm(CsfWalk& W, int M, int nseg, const CsfSrc* src, int taps, int dil, 
       kreal += src[s].C;
     }
   }
-  const int64_t img = W.pk_alloc((int64_t)Mp * Kp);
   const int Ntot = H->B * Ho * Wo;
-  W.macs += (int64_t)M * kreal * Ntot;
-  if (W.dry) {
-    pj.a.M = M; pj.a.Mp = Mp; pj.a.Kp = Kp; pj.a.ld = ld; pj.a.taps = taps; pj.a.nseg = nseg;
-    pj.src_off = w_arena;
-    pj.dst_off = img;
-    H->prep.push_back(pj);
-    return CSN_OK;
+  int tile0 = 0;
+  for (int i = 0; i < nsub; ++i) {
+    const int Mp = G.n_mtiles[i] * G.BM;
+    const int64_t img = W.pk_alloc((int64_t)Mp * Kp);
+    W.macs += (int64_t)subs[i].M * kreal * Ntot;
+    if (W.dry) {
+      pj.a.M = subs[i].M; pj.a.Mp = Mp; pj.a.Kp = Kp; pj.a.ld = ld; pj.a.taps = taps; pj.a.nseg = nseg;
+      pj.src_off = subs[i].w_arena;
+      pj.dst_off = img;
+      H->prep.push_back(pj);
+    }
+    a.sub[i] = CsfSub{W.dry ? nullptr : W.pk(img), subs[i].out, subs[i].M, subs[i].dil, G.n_mtiles[i], tile0};
+    tile0 += G.n_mtiles[i] * G.n_ntiles * G.ksplit;
   }
-  a.A = W.pk(img);
-  a.M = M;
+  if (W.dry) return CSN_OK;
+  a.nsub = nsub;
+  a.total_tiles = tile0;
+  a.ksplit = G.ksplit;
+  a.chunks_per_split = G.cps;
+  a.split_stride = split_stride;
   a.Kp = Kp;
-  a.out = out;
   a.out_nstride = (long long)out_ctot * Ho * Wo;
   a.Ho = Ho; a.Wo = Wo; a.HWo = Ho * Wo; a.Ntot = Ntot;
-  a.n_mtiles = Mp / BM;
-  a.n_ntiles = (Ntot + CSF_BN - 1) / CSF_BN;
-  LAUNCH_TRY(csf_launch_gemm(a, mt, W.stream));
+  a.n_ntiles = G.n_ntiles;
+  LAUNCH_TRY(csf_launch_gemm(a, G.mt, W.stream));
   return CSN_OK;
 }
 
-// combine (+ optional up-sampled partials) -> GroupNorm statistics -> scale/shift tables; returns their packed offsets
-int csf_group_norm(CsfWalk& W, float* s, int C, int Hh, int Ww, int nz, const CsfZ* z, const csf_gn_off& gn,
-                   int64_t* scale_off, int64_t* shift_off, int64_t* alpha_off) {
+// combine (split-K planes + optional up-sampled partials) -> GroupNorm statistics -> scale/shift tables
+int csf_group_norm(CsfWalk& W, float* s, int ns, int64_t split_stride, int C, int Hh, int Ww, int nz, const CsfZ* z,
+                   const csf_gn_off& gn, int64_t* scale_off, int64_t* shift_off, int64_t* alpha_off) {
   csf_head* H = W.H;
   const int groups = H->d.gn_groups, cpg = C / groups, HW = Hh * Ww;
-  const int glen = cpg * HW;
-  const int nslab = std::max(1, std::min(64, (glen + 8191) / 8192));
-  const int slab_len = (glen + nslab - 1) / nslab;
-  const int64_t part = W.ws_alloc((int64_t)H->B * groups * nslab * 2 * sizeof(double));
+  const int nslab = cpg;                 // one partial per channel plane
+  const int64_t part = W.ws_alloc((int64_t)H->B * C * 2 * sizeof(double));
   const int64_t sc = W.ws_alloc((int64_t)H->B * C * 4), sh = W.ws_alloc((int64_t)H->B * C * 4);
   const int64_t gamma = W.vec(gn.weight, C), beta = W.vec(gn.bias, C), alpha = W.vec(gn.prelu, C);
   *scale_off = sc; *shift_off = sh; *alpha_off = alpha;
   if (W.dry) return CSN_OK;
+  if (H->B > 65535) FAIL(CSN_E_UNSUPPORTED, "csf: batch exceeds the grid limit");
   CsfCombArgs c{};
-  c.s = s; c.B = H->B; c.C = C; c.H = Hh; c.W = Ww; c.HW = HW; c.cpg = cpg; c.groups = groups;
+  c.s = s; c.ns = ns; c.split_stride = split_stride;
+  c.B = H->B; c.C = C; c.H = Hh; c.W = Ww; c.HW = HW; c.cpg = cpg; c.groups = groups;
   c.nz = nz;
   for (int i = 0; i < nz; ++i) c.z[i] = z[i];
   c.part = reinterpret_cast<double*>(W.ws + part);
-  c.nslab = nslab; c.slab_len = slab_len;
+  for (int i = 0; i < nz; ++i) c.z_floats += z[i].Hz * z[i].Wz;
+  c.z_in_lds = c.z_floats > 0 && c.z_floats <= H->z_lds_max;   // <= 48 KB next to the reduction scratch
   LAUNCH_TRY(csf_launch_combine(c, W.stream));
   CsfGnFinArgs f{};
   f.part = c.part; f.nslab = nslab; f.cpg = cpg; f.groups = groups; f.C = C; f.HW = HW; f.B = H->B;
@@ -165,8 +199,15 @@ int csf_walk(CsfWalk& W) {
   // i' <= i (resized down first, 99-101) in ONE contraction; its contributions to the finer branches j < i are
   // contracted at resolution i (rows 0..bo[i]) and up-sampled afterwards (96-98) by the combine pass.
   int64_t S[CSF_MAX_BRANCH], Z[CSF_MAX_BRANCH] = {0};
-  for (int i = 0; i < nb; ++i) S[i] = W.ws_alloc((int64_t)B * d.cmid[i] * HW[i] * 4);
-  for (int i = 1; i < nb; ++i) Z[i] = W.ws_alloc((int64_t)B * bo[i] * HW[i] * 4);
+  CsfGeom Gs[CSF_MAX_BRANCH], Gz[CSF_MAX_BRANCH];
+  for (int i = 0; i < nb; ++i) {
+    Gs[i] = csf_geom(1, &d.cmid[i], i + 1, d.cin, 0, B * HW[i], true);
+    S[i] = W.ws_alloc((int64_t)Gs[i].ksplit * B * d.cmid[i] * HW[i] * 4);
+  }
+  for (int i = 1; i < nb; ++i) {
+    Gz[i] = csf_geom(1, &bo[i], 1, &d.cin[i], 0, B * HW[i], true);
+    Z[i] = W.ws_alloc((int64_t)Gz[i].ksplit * B * bo[i] * HW[i] * 4);
+  }
   for (int i = 0; i < nb; ++i) {
     CsfSrc src[CSF_MAX_SEG];
     int col0[CSF_MAX_SEG];
@@ -174,12 +215,14 @@ int csf_walk(CsfWalk& W) {
       src[k] = CsfSrc{feat(k), (int64_t)B * d.cin[k] * HW[k], d.cin[k], d.cin[k], H->h[k], H->w[k], k == i ? CSF_OWN : CSF_RESIZE};
       col0[k] = bi[k];
     }
-    CSF_TRY(csf_gemm(W, d.cmid[i], i + 1, src, 0, 1, d.fuse_w + (int64_t)bo[i] * Tin, Tin, col0, wsp(S[i]), d.cmid[i],
-                     H->h[i], H->w[i]));
+    CsfSubPlan own{d.cmid[i], 1, d.fuse_w + (int64_t)bo[i] * Tin, wsp(S[i])};
+    CSF_TRY(csf_gemm(W, Gs[i], 1, &own, i + 1, src, 0, Tin, col0, d.cmid[i], H->h[i], H->w[i],
+                     (int64_t)B * d.cmid[i] * HW[i]));
     if (i >= 1) {
-      CsfSrc own{feat(i), (int64_t)B * d.cin[i] * HW[i], d.cin[i], d.cin[i], H->h[i], H->w[i], CSF_OWN};
+      CsfSrc me{feat(i), (int64_t)B * d.cin[i] * HW[i], d.cin[i], d.cin[i], H->h[i], H->w[i], CSF_OWN};
+      CsfSubPlan zp{bo[i], 1, d.fuse_w, wsp(Z[i])};
       const int c0 = bi[i];
-      CSF_TRY(csf_gemm(W, bo[i], 1, &own, 0, 1, d.fuse_w, Tin, &c0, wsp(Z[i]), bo[i], H->h[i], H->w[i]));
+      CSF_TRY(csf_gemm(W, Gz[i], 1, &zp, 1, &me, 0, Tin, &c0, bo[i], H->h[i], H->w[i], (int64_t)B * bo[i] * HW[i]));
     }
   }
   for (int j = 0; j < nb; ++j) {
@@ -188,46 +231,64 @@ int csf_walk(CsfWalk& W) {
     for (int i = j + 1; i < nb; ++i, ++nz) {
       z[nz].z = W.dry ? nullptr : W.wsf(Z[i]) + (int64_t)bo[j] * HW[i];
       z[nz].nstride = (long long)bo[i] * HW[i];
+      z[nz].ns = Gz[i].ksplit;
+      z[nz].split_stride = (long long)B * bo[i] * HW[i];
       z[nz].Hz = H->h[i]; z[nz].Wz = H->w[i];
       z[nz].ry = (float)H->h[i] / (float)H->h[j];
       z[nz].rx = (float)H->w[i] / (float)H->w[j];
     }
     int64_t sc, sh, al;
-    CSF_TRY(csf_group_norm(W, wsp(S[j]), d.cmid[j], H->h[j], H->w[j], nz, z, d.fuse_gn[j], &sc, &sh, &al));
+    CSF_TRY(csf_group_norm(W, wsp(S[j]), Gs[j].ksplit, (int64_t)B * d.cmid[j] * HW[j], d.cmid[j], H->h[j], H->w[j], nz, z,
+                           d.fuse_gn[j], &sc, &sh, &al));
     CSF_TRY(csf_apply(W, wsp(S[j]), d.cmid[j], HW[j], sc, sh, al));
     H->stage[0][j] = {S[j], d.cmid[j], H->h[j], H->w[j]};
   }
 
   // ---- ms: PallMSBlock (csf_res2net.py:174-223): five dense dilated 3x3 convolutions per branch write channel
-  // slices of one tensor (torch.cat, 212), then GroupNorm + PReLU
+  // slices of one tensor (torch.cat, 212) -- ONE launch with five sub-problems -- then GroupNorm + PReLU
   static const int dil[CSF_NDIL] = {1, 2, 4, 8, 16};
   int64_t Mo[CSF_MAX_BRANCH];
-  for (int j = 0; j < nb; ++j) Mo[j] = W.ws_alloc((int64_t)B * d.cmid[j] * HW[j] * 4);
+  CsfGeom Gm[CSF_MAX_BRANCH];
   for (int j = 0; j < nb; ++j) {
-    int row = 0;
+    int Ms[CSF_NDIL], ns = 0;
+    for (int k = 0; k < CSF_NDIL; ++k)
+      if (d.ms_split[j][k] > 0) Ms[ns++] = d.ms_split[j][k];
+    Gm[j] = csf_geom(ns, Ms, 1, &d.cmid[j], 9, B * HW[j], true);
+    Mo[j] = W.ws_alloc((int64_t)Gm[j].ksplit * B * d.cmid[j] * HW[j] * 4);
+  }
+  for (int j = 0; j < nb; ++j) {
+    CsfSubPlan subs[CSF_NDIL];
+    int ns = 0, row = 0;
     for (int k = 0; k < CSF_NDIL; ++k) {
       const int co = d.ms_split[j][k];
       if (co <= 0) continue;
-      CsfSrc src{wsp(S[j]), (int64_t)B * d.cmid[j] * HW[j], d.cmid[j], d.cmid[j], H->h[j], H->w[j], CSF_OWN};
-      float* out = W.dry ? nullptr : W.wsf(Mo[j]) + (int64_t)row * HW[j];
-      CSF_TRY(csf_gemm(W, co, 1, &src, 9, dil[k], d.ms_w[j][k], d.cmid[j] * 9, nullptr, out, d.cmid[j], H->h[j], H->w[j]));
+      subs[ns++] = CsfSubPlan{co, dil[k], d.ms_w[j][k], W.dry ? nullptr : W.wsf(Mo[j]) + (int64_t)row * HW[j]};
       row += co;
     }
+    CsfSrc src{wsp(S[j]), (int64_t)B * d.cmid[j] * HW[j], d.cmid[j], d.cmid[j], H->h[j], H->w[j], CSF_OWN};
+    CSF_TRY(csf_gemm(W, Gm[j], ns, subs, 1, &src, 9, d.cmid[j] * 9, nullptr, d.cmid[j], H->h[j], H->w[j],
+                     (int64_t)B * d.cmid[j] * HW[j]));
     int64_t sc, sh, al;
-    CSF_TRY(csf_group_norm(W, wsp(Mo[j]), d.cmid[j], H->h[j], H->w[j], 0, nullptr, d.ms_gn[j], &sc, &sh, &al));
+    CSF_TRY(csf_group_norm(W, wsp(Mo[j]), Gm[j].ksplit, (int64_t)B * d.cmid[j] * HW[j], d.cmid[j], H->h[j], H->w[j], 0,
+                           nullptr, d.ms_gn[j], &sc, &sh, &al));
     CSF_TRY(csf_apply(W, wsp(Mo[j]), d.cmid[j], HW[j], sc, sh, al));
     H->stage[1][j] = {Mo[j], d.cmid[j], H->h[j], H->w[j]};
   }
 
   // ---- fuse1x1: gOctaveCBR 4 -> 1 (csf_res2net.py:243-244): branch 0 directly, branches i >= 1 contracted at their
   // own resolution and up-sampled by the combine pass
-  const int64_t F = W.ws_alloc((int64_t)B * Tm * HW[0] * 4);
   int64_t Z1[CSF_MAX_BRANCH] = {0};
-  for (int i = 1; i < nb; ++i) Z1[i] = W.ws_alloc((int64_t)B * Tm * HW[i] * 4);
+  CsfGeom Gf[CSF_MAX_BRANCH];
+  for (int i = 0; i < nb; ++i) {
+    Gf[i] = csf_geom(1, &Tm, 1, &d.cmid[i], 0, B * HW[i], i > 0);
+    Z1[i] = W.ws_alloc((int64_t)Gf[i].ksplit * B * Tm * HW[i] * 4);
+  }
+  const int64_t F = Z1[0];
   for (int i = 0; i < nb; ++i) {
     CsfSrc src{wsp(Mo[i]), (int64_t)B * d.cmid[i] * HW[i], d.cmid[i], d.cmid[i], H->h[i], H->w[i], CSF_OWN};
+    CsfSubPlan sp{Tm, 1, d.fuse1_w, wsp(Z1[i])};
     const int c0 = bo[i];
-    CSF_TRY(csf_gemm(W, Tm, 1, &src, 0, 1, d.fuse1_w, Tm, &c0, wsp(i == 0 ? F : Z1[i]), Tm, H->h[i], H->w[i]));
+    CSF_TRY(csf_gemm(W, Gf[i], 1, &sp, 1, &src, 0, Tm, &c0, Tm, H->h[i], H->w[i], (int64_t)B * Tm * HW[i]));
   }
   {
     CsfZ z[3];
@@ -235,12 +296,14 @@ int csf_walk(CsfWalk& W) {
     for (int i = 1; i < nb; ++i, ++nz) {
       z[nz].z = wsp(Z1[i]);
       z[nz].nstride = (long long)Tm * HW[i];
+      z[nz].ns = Gf[i].ksplit;
+      z[nz].split_stride = (long long)B * Tm * HW[i];
       z[nz].Hz = H->h[i]; z[nz].Wz = H->w[i];
       z[nz].ry = (float)H->h[i] / (float)H->h[0];
       z[nz].rx = (float)H->w[i] / (float)H->w[0];
     }
     int64_t sc, sh, al;
-    CSF_TRY(csf_group_norm(W, wsp(F), Tm, H->h[0], H->w[0], nz, z, d.fuse1_gn, &sc, &sh, &al));
+    CSF_TRY(csf_group_norm(W, wsp(F), 1, 0, Tm, H->h[0], H->w[0], nz, z, d.fuse1_gn, &sc, &sh, &al));
     H->stage[2][0] = {F, Tm, H->h[0], H->w[0]};
     // ---- cls_layer on PReLU(GroupNorm(.)) + resize to the input size (csf_res2net.py:253-254)
     const int64_t lo = W.ws_alloc((int64_t)B * HW[0] * 4);
@@ -293,6 +356,7 @@ int csf_head_create(const csf_head_desc* desc, int32_t batch, const int32_t* h, 
   for (int i = 0; i < d.n_branch; ++i) { H->h[i] = h[i]; H->w[i] = w[i]; }
   H->oh = out_h;
   H->ow = out_w;
+  if (const char* e = getenv("CSF_Z_LDS_MAX")) H->z_lds_max = atoi(e);
   CsfWalk W;
   W.H = H;
   W.dry = true;

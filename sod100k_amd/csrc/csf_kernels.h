@@ -25,33 +25,48 @@ struct CsfSeg {
   float ry, rx;          // RESIZE: Hs/Ho, Ws/Wo as F.interpolate computes them (float(in) / out)
 };
 
-struct CsfGemmArgs {
+#define CSF_MAX_SUB 5
+struct CsfSub {          // one GEMM of a launch: the sub-problems share the B operand's sources and the geometry
   const float* A;        // [Mp][Kp] row-major, zero padded (rows to the block tile, K to 16)
-  int M, Kp;
+  float* out;            // [B][out_ctot][HWo], already offset to the first output row
+  int M, dil;
+  int n_mtiles;
+  int tile0;             // first logical block of the sub-problem
+};
+
+struct CsfGemmArgs {
+  int Kp;
   int nseg;              // 1x1: concatenated segments; taps: ONE source, 9 pseudo-segments (tap-major K)
   int taps;              // 0 or 9
-  int dil;
   CsfSeg seg[CSF_MAX_SEG];
-  float* out;            // [B][out_ctot][HWo], already offset to the first output row
+  int nsub;              // e.g. the five dilations of an MSBlock (csf_res2net.py:207-211) in ONE launch
+  CsfSub sub[CSF_MAX_SUB];
+  int total_tiles;
+  int ksplit, chunks_per_split;   // split-K: slice ks covers chunks [ks*cps, (ks+1)*cps) and writes plane ks
+  long long split_stride;         // floats between the planes (summed by csf_combine_kernel in a fixed order)
   long long out_nstride;
   int Ho, Wo, HWo, Ntot; // Ntot = B * HWo
-  int n_mtiles, n_ntiles;
+  int n_ntiles;
 };
 
 struct CsfZ {            // a coarser tensor added through bilinear up-sampling (gOctConv.py:96-98)
   const float* z;        // [B][ctot][Hz*Wz] offset to the first channel
   long long nstride;
+  int ns;                // split-K planes of z (summed before the interpolation)
+  long long split_stride;
   int Hz, Wz;
   float ry, rx;
 };
 
-struct CsfCombArgs {     // s += sum_i up(z_i); partial sums of s and s^2 per (image, group, slab) in fp64
-  float* s;              // [B][C][HW]
+struct CsfCombArgs {     // s = sum_k s_k + sum_i up(z_i); partial sums of s and s^2 per (image, group, slab) in fp64
+  float* s;              // [ns][B][C][HW]; the result replaces plane 0
+  int ns;
+  long long split_stride;
   int B, C, H, W, HW, cpg, groups;
   int nz;
   CsfZ z[3];
-  double* part;          // [B*groups][nslab][2]
-  int nslab, slab_len;   // a group's cpg*HW contiguous floats cut into nslab slabs
+  double* part;          // [B][C][2]: one block (and one partial) per channel plane
+  int z_in_lds, z_floats;// the nz coarse planes of one channel fit in LDS (z_floats in total)
 };
 
 struct CsfGnFinArgs {    // per (image, group): mean / rstd -> per (image, channel) scale and shift

@@ -3,6 +3,7 @@
 // include/csnet_hip.h.  No torch types; the caller owns every tensor.
 #include <array>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <new>

@@ -31,13 +31,13 @@ struct CsfGather {       // per-lane addressing of the current (pseudo-)segment
   float ly, lx;
 };
 
-__device__ __forceinline__ void csf_seg_setup(const CsfGemmArgs& a, int ps, int n, int oy, int ox, CsfGather& g,
-                                              int& si) {
+__device__ __forceinline__ void csf_seg_setup(const CsfGemmArgs& a, int ps, int dil, int n, int oy, int ox,
+                                              CsfGather& g, int& si) {
   if (a.taps) {   // pseudo-segment = tap of the dilated 3x3, zero padding (csf_res2net.py:203)
     si = 0;
     const CsfSeg& s = a.seg[0];
     const int ty = ps / 3, tx = ps - 3 * ty;
-    const int y = oy + (ty - 1) * a.dil, x = ox + (tx - 1) * a.dil;
+    const int y = oy + (ty - 1) * dil, x = ox + (tx - 1) * dil;
     const bool ok = y >= 0 && y < s.Hs && x >= 0 && x < s.Ws;
     g.o00 = ok ? (unsigned)(n * s.nstride + y * s.Ws + x) * 4u : 0x80000000u;
     return;
@@ -68,8 +68,18 @@ __global__ __launch_bounds__(256) void csf_gemm_kernel(CsfGemmArgs a) {
 
   const int per = gridDim.x >> 3;        // grid is a multiple of 8: contiguous chunk of the tile order per XCD
   const int lb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if (lb >= a.n_mtiles * a.n_ntiles) return;
-  const int mt = lb % a.n_mtiles, nt = lb / a.n_mtiles;
+  if (lb >= a.total_tiles) return;
+  // sub-problem, then (row tile fastest, K slice, pixel tile): blocks that share a B tile are neighbours
+  int sp = 0;
+#pragma unroll
+  for (int q = 1; q < CSF_MAX_SUB; ++q)
+    if (q < a.nsub && lb >= a.sub[q].tile0) sp = q;
+  const float* Aimg = a.sub[sp].A;
+  float* outp = a.sub[sp].out;
+  const int M = a.sub[sp].M, dil = a.sub[sp].dil, nmt = a.sub[sp].n_mtiles;
+  const int local = lb - a.sub[sp].tile0;
+  const int mt = local % nmt, rest = local / nmt;
+  const int ks = rest % a.ksplit, nt = rest / a.ksplit;
   const int m0 = mt * BM;
 
   const int p = nt * CSF_BN + tid;
@@ -85,13 +95,22 @@ __global__ __launch_bounds__(256) void csf_gemm_kernel(CsfGemmArgs a) {
 
   const int nps = a.taps ? 9 : a.nseg;
   const int nchunks = a.Kp / CSF_KC;
+  const int c0 = ks * a.chunks_per_split;
+  const int c1 = min(nchunks, c0 + a.chunks_per_split);
   // A: thread -> (row, 4 consecutive k)
   const bool a_ld = tid < BM * 4;
-  const float* ap = a.A + (size_t)(m0 + (tid >> 2)) * a.Kp + (tid & 3) * 4;
+  const float* ap = Aimg + (size_t)(m0 + (tid >> 2)) * a.Kp + (tid & 3) * 4;
 
-  int ps = 0, cc = 0, si = 0;
+  // (pseudo-)segment and chunk inside it of the slice's first chunk
+  int ps = 0, cc = c0, si = 0;
+  if (a.taps) {
+    ps = c0 / a.seg[0].chunks;
+    cc = c0 - ps * a.seg[0].chunks;
+  } else {
+    while (ps + 1 < nps && cc >= a.seg[ps].chunks) cc -= a.seg[ps++].chunks;
+  }
   CsfGather g;
-  csf_seg_setup(a, 0, n, oy, ox, g, si);
+  csf_seg_setup(a, ps, dil, n, oy, ox, g, si);
   csn_buf buf = csn_make_buf_n(a.seg[si].src, a.seg[si].bytes);
 
   float4 ra = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -119,16 +138,16 @@ __global__ __launch_bounds__(256) void csf_gemm_kernel(CsfGemmArgs a) {
     if (++cc == a.seg[si].chunks) {
       cc = 0;
       if (++ps < nps) {
-        csf_seg_setup(a, ps, n, oy, ox, g, si);
+        csf_seg_setup(a, ps, dil, n, oy, ox, g, si);
         buf = csn_make_buf_n(a.seg[si].src, a.seg[si].bytes);
       }
     }
   };
 
-  fetch(0);
-  for (int kc = 0; kc < nchunks; ++kc) {
-    float* Ab = As + (kc & 1) * CSF_KC * AP;
-    float* Bb = Bs + (kc & 1) * CSF_KC * CSF_BP;
+  if (c0 < c1) fetch(c0);
+  for (int kc = c0; kc < c1; ++kc) {
+    float* Ab = As + ((kc - c0) & 1) * CSF_KC * AP;
+    float* Bb = Bs + ((kc - c0) & 1) * CSF_KC * CSF_BP;
     if (a_ld) {
       const int row = tid >> 2, k4 = (tid & 3) * 4;
       Ab[(k4 + 0) * AP + row] = ra.x;
@@ -139,7 +158,7 @@ __global__ __launch_bounds__(256) void csf_gemm_kernel(CsfGemmArgs a) {
 #pragma unroll
     for (int r = 0; r < CSF_KC; ++r) Bb[r * CSF_BP + tid] = rb[r];
     __syncthreads();
-    if (kc + 1 < nchunks) fetch(kc + 1);
+    if (kc + 1 < c1) fetch(kc + 1);
     const float* bw = Bb + wave * 64;
 #pragma unroll
     for (int kk = 0; kk < CSF_KC / 4; ++kk) {
@@ -170,24 +189,25 @@ __global__ __launch_bounds__(256) void csf_gemm_kernel(CsfGemmArgs a) {
   }
 
   // D layout: register e of a lane = row (lane>>4)*4 + e, column lane&15
+  outp += (size_t)ks * a.split_stride;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int q = nt * CSF_BN + wave * 64 + j * 16 + (lane & 15);
     if (q >= a.Ntot) continue;
     const int qn = q / a.HWo, qp = q - qn * a.HWo;
-    float* o = a.out + (size_t)qn * a.out_nstride + qp;
+    float* o = outp + (size_t)qn * a.out_nstride + qp;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int m = m0 + i * 16 + (lane >> 4) * 4 + e;
-        if (m < a.M) o[(size_t)m * a.HWo] = acc[i][j][e];
+        if (m < M) o[(size_t)m * a.HWo] = acc[i][j][e];
       }
   }
 }
 
 int csf_launch_gemm(const CsfGemmArgs& a, int mt, void* stream) {
-  const int tiles = a.n_mtiles * a.n_ntiles;
+  const int tiles = a.total_tiles;
   if (tiles <= 0) return 0;
   const int grid = (tiles + 7) / 8 * 8;
   if (mt == 4) {
@@ -203,55 +223,87 @@ int csf_launch_gemm(const CsfGemmArgs& a, int mt, void* stream) {
 }
 
 // ------------------------------------------------------------------------------ combine + GroupNorm statistics
+// One block per (image, channel) plane.  The coarser tensors' planes of that channel (a few KB: 44x44 + 22x22 + 11x11
+// floats at 352x352) are staged in LDS once -- split-K slices summed on the way in -- so the 4 taps x nz levels per
+// output pixel are LDS reads; the plane itself streams through once (coalesced read + write).
 __global__ __launch_bounds__(CSN_BLOCK) void csf_combine_kernel(CsfCombArgs a) {
-  CSN_DYN_SMEM(double, red);   // [2][CSN_BLOCK]
-  const int slab = blockIdx.x, ng = blockIdx.y;
-  const int n = ng / a.groups, gidx = ng - n * a.groups;
-  const long long gbase = ((long long)n * a.C + (long long)gidx * a.cpg) * a.HW;
-  const int glen = a.cpg * a.HW;
-  const int e0 = slab * a.slab_len, e1 = min(glen, e0 + a.slab_len);
+  CSN_DYN_SMEM(double, red);   // [2][CSN_BLOCK] doubles, then the staged planes (floats)
+  float* zl = reinterpret_cast<float*>(red + 2 * CSN_BLOCK);
+  const int ch = blockIdx.x, n = blockIdx.y;
+  const int tid = threadIdx.x;
+  int zoff[3] = {0, 0, 0};
+  if (a.z_in_lds) {
+    int off = 0;
+    for (int i = 0; i < a.nz; ++i) {
+      const CsfZ& z = a.z[i];
+      const int len = z.Hz * z.Wz;
+      const float* q = z.z + (long long)n * z.nstride + (long long)ch * len;
+      for (int e = tid; e < len; e += CSN_BLOCK) {
+        float v = q[e];
+        for (int k = 1; k < z.ns; ++k) v += q[(long long)k * z.split_stride + e];
+        zl[off + e] = v;
+      }
+      zoff[i] = off;
+      off += len;
+    }
+    __syncthreads();
+  }
+  float* sp = a.s + ((long long)n * a.C + ch) * a.HW;
   double s1 = 0.0, s2 = 0.0;
-  for (int e = e0 + (int)threadIdx.x; e < e1; e += CSN_BLOCK) {
-    float v = a.s[gbase + e];
+  for (int pix = tid; pix < a.HW; pix += CSN_BLOCK) {
+    float v = sp[pix];
+    for (int k = 1; k < a.ns; ++k) v += sp[(long long)k * a.split_stride + pix];
     if (a.nz) {
-      const int c = e / a.HW, pix = e - c * a.HW;
       const int y = pix / a.W, x = pix - y * a.W;
-      const int ch = gidx * a.cpg + c;
       for (int i = 0; i < a.nz; ++i) {
         const CsfZ& z = a.z[i];
         int y0, y1, x0, x1;
         float ly, lx;
         csn_bilin(y, z.ry, z.Hz, y0, y1, ly);
         csn_bilin(x, z.rx, z.Wz, x0, x1, lx);
-        const float* q = z.z + (long long)n * z.nstride + (long long)ch * z.Hz * z.Wz;
-        const float t0 = (1.f - lx) * q[y0 * z.Wz + x0] + lx * q[y0 * z.Wz + x1];
-        const float t1 = (1.f - lx) * q[y1 * z.Wz + x0] + lx * q[y1 * z.Wz + x1];
+        float v00, v01, v10, v11;
+        if (a.z_in_lds) {
+          const float* q = zl + zoff[i];
+          v00 = q[y0 * z.Wz + x0]; v01 = q[y0 * z.Wz + x1];
+          v10 = q[y1 * z.Wz + x0]; v11 = q[y1 * z.Wz + x1];
+        } else {
+          const float* q = z.z + (long long)n * z.nstride + (long long)ch * z.Hz * z.Wz;
+          v00 = q[y0 * z.Wz + x0]; v01 = q[y0 * z.Wz + x1];
+          v10 = q[y1 * z.Wz + x0]; v11 = q[y1 * z.Wz + x1];
+          for (int k = 1; k < z.ns; ++k) {
+            const float* qk = q + (long long)k * z.split_stride;
+            v00 += qk[y0 * z.Wz + x0]; v01 += qk[y0 * z.Wz + x1];
+            v10 += qk[y1 * z.Wz + x0]; v11 += qk[y1 * z.Wz + x1];
+          }
+        }
+        const float t0 = (1.f - lx) * v00 + lx * v01;
+        const float t1 = (1.f - lx) * v10 + lx * v11;
         v += (1.f - ly) * t0 + ly * t1;
       }
-      a.s[gbase + e] = v;
     }
+    if (a.nz || a.ns > 1) sp[pix] = v;
     s1 += (double)v;
     s2 += (double)v * (double)v;
   }
-  red[threadIdx.x] = s1;
-  red[CSN_BLOCK + threadIdx.x] = s2;
+  red[tid] = s1;
+  red[CSN_BLOCK + tid] = s2;
   __syncthreads();
   for (int st = CSN_BLOCK / 2; st > 0; st >>= 1) {
-    if ((int)threadIdx.x < st) {
-      red[threadIdx.x] += red[threadIdx.x + st];
-      red[CSN_BLOCK + threadIdx.x] += red[CSN_BLOCK + threadIdx.x + st];
+    if (tid < st) {
+      red[tid] += red[tid + st];
+      red[CSN_BLOCK + tid] += red[CSN_BLOCK + tid + st];
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    a.part[((long long)ng * a.nslab + slab) * 2 + 0] = red[0];
-    a.part[((long long)ng * a.nslab + slab) * 2 + 1] = red[CSN_BLOCK];
+  if (tid == 0) {   // [image][channel][2]: csf_gn_finalize sums the cpg channels of a group in order
+    a.part[((long long)n * a.C + ch) * 2 + 0] = red[0];
+    a.part[((long long)n * a.C + ch) * 2 + 1] = red[CSN_BLOCK];
   }
 }
 
 int csf_launch_combine(const CsfCombArgs& a, void* stream) {
-  CSN_LAUNCH(csf_combine_kernel, dim3(a.nslab, a.B * a.groups, 1), dim3(CSN_BLOCK), 2 * CSN_BLOCK * sizeof(double),
-             stream, a);
+  const size_t lds = 2 * CSN_BLOCK * sizeof(double) + (a.z_in_lds ? (size_t)a.z_floats * sizeof(float) : 0);
+  CSN_LAUNCH(csf_combine_kernel, dim3(a.C, a.B, 1), dim3(CSN_BLOCK), lds, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -309,12 +361,15 @@ __global__ __launch_bounds__(CSN_BLOCK) void csf_cls_kernel(CsfClsArgs a) {
   const float* sh = a.shift + (long long)n * a.C;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   int c = 0;
-  for (; c + 4 <= a.C; c += 4) {
+  for (; c + 8 <= a.C; c += 8) {
+    float v[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      float y = fmaf(s[(long long)(c + u) * a.HW], sc[c + u], sh[c + u]);
+    for (int u = 0; u < 8; ++u) v[u] = s[(long long)(c + u) * a.HW];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float y = fmaf(v[u], sc[c + u], sh[c + u]);
       y = y >= 0.f ? y : a.alpha[c + u] * y;
-      acc[u] = fmaf(a.w[c + u], y, acc[u]);
+      acc[u & 3] = fmaf(a.w[c + u], y, acc[u & 3]);
     }
   }
   for (; c < a.C; ++c) {

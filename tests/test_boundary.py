@@ -56,7 +56,8 @@ def test_param_group_name_matching():
 
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "csnet_hip.h")).read()
-    declared = set(re.findall(r"\b(csn_[a-z0-9_]+)\s*\(", hdr))
+    hdr += open(os.path.join(ROOT, "include", "csf_hip.h")).read()
+    declared = set(re.findall(r"\b(cs[nf]_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(N.EXPORTS), declared ^ set(N.EXPORTS)
     if not os.path.exists(N.LIB_PATH):
         pytest.skip("libcsnet_hip.so not built (run __graft_entry__.build())")
@@ -87,3 +88,17 @@ def test_bad_plans_are_rejected(emu_lib):
     assert emu_lib.csn_plan_create(ua, 1, aa, 2, 1, 32, 32, 0, ctypes.byref(plan)) == 1   # missing BN offsets
     assert emu_lib.csn_plan_create(ua, 1, aa, 2, 1, 30, 32, 0, ctypes.byref(plan)) == 1   # H not multiple of 16
     assert emu_lib.csn_strerror(1).decode().startswith("invalid")
+
+
+def test_csfnet_state_dict_matches_reference_manifest():
+    """CSF+Res2Net drop-in: same state_dict names / shapes / dtypes as the reference's CSFNet (G8 manifest)."""
+    from sod100k_amd.networks import csf_res2net as R
+    from oracle import csf_oracle as CO
+    keys = json.load(open(os.path.join(GOLD, "g8_csf_probes.json")))["keys"]
+    net = R.build_model()
+    mine = {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()}
+    assert list(mine) == list(keys) and mine == keys
+    assert net.load_state_dict(CO.synthetic_state(), strict=True).missing_keys == []
+    d = net.describe_head(net._ensure_arena().offsets)
+    assert list(d.cin) == [256, 512, 1024, 2048] and list(d.cmid) == [128, 256, 512, 512]
+    assert [list(r) for r in d.ms_split] == [[25, 25, 25, 25, 28], [51, 51, 51, 51, 52], [102, 102, 102, 102, 104]] * 1 + [[102, 102, 102, 102, 104]]

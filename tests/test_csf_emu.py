@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import csf_oracle as CO
-from tests import csf_cases as K
+import csf_cases as K
 
 
 @pytest.fixture(scope="module")
@@ -28,6 +28,15 @@ def test_head_matches_oracle(net_sd, sizes, out_size, batch):
     # logits: within 1e-4 of the fp32 oracle, and not further from the fp64 truth than a few times the oracle itself
     assert errs["logits"] <= 1e-4, errs
     assert errs["hip_vs_fp64"] <= 3 * errs["oracle_vs_fp64"] + 2e-5, errs
+
+
+def test_head_global_tap_path(emu_lib, monkeypatch):
+    """Coarse planes too large for LDS: the combine pass takes its taps from global memory (forced here)."""
+    monkeypatch.setenv("CSF_Z_LDS_MAX", "0")
+    net, sd = K.build_csfnet("cpu", emu_lib)
+    feats = CO.synthetic_features(4, 1, [(8, 8), (4, 4), (2, 2), (1, 1)])
+    y, ref, errs = K.head_errors(net, sd, feats, (32, 32))
+    assert errs["logits"] <= 1e-4 and max(v for k, v in errs.items() if k.startswith(("fuse.", "ms."))) <= 2e-4, errs
 
 
 def test_head_requires_device_without_library():

@@ -140,3 +140,22 @@ def test_init_layers_matches_reference_manifest():
     lc = O.init_layers(40, [0.5, 0.5])
     assert lc[-1] == [3, 4, 6, 4] and len(lc) == 22
     assert g6["init_e2.0_s2"]["params"] == 788631
+
+
+# ---- G8: CSF+Res2Net (oracle/csf_oracle.py against the reference's CSFNet, oracle/make_golden_csf.py) -------------
+@pytest.mark.parametrize("name", ["96x128", "100x76", "352"])
+def test_g8_csf_logits_and_probes(name):
+    from oracle import csf_oracle as CO
+    meta = json.load(open(os.path.join(GOLD, "g8_csf_probes.json")))["cases"][name]
+    b, _, h, w = meta["shape"]
+    x = torch.from_numpy(I.randn_batch(meta["seed"], b, h, w))
+    probes = {}
+    with torch.no_grad():
+        y = CO.csfnet_forward(CO.synthetic_state(), x, probes=probes)
+    g = np.load(os.path.join(GOLD, f"g8_csf_logits_{name}.npy"))
+    assert np.abs(y.numpy() - g).max() <= TOL
+    for key in ("features", "fuse", "ms", "fuse1x1"):
+        for t, p in zip(probes[key], meta[key]):
+            q = I.probe(t.numpy())
+            assert q["shape"] == p["shape"]
+            assert abs(q["l2"] - p["l2"]) <= 1e-5 * max(1.0, p["l2"]) and np.abs(np.array(q["samples"]) - np.array(p["samples"])).max() <= 1e-5 * max(1.0, p["absmax"])
