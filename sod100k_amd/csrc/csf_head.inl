@@ -64,6 +64,8 @@ CsfGeom csf_geom(int nsub, const int* M, int nseg, const int* segC, int taps, in
   CsfGeom g;
   int maxM = 0;
   for (int i = 0; i < nsub; ++i) maxM = std::max(maxM, M[i]);
+  // 64-row blocks (3 resident blocks per CU); 32 rows for the 25..28-row dilation groups of the 128-channel MSBlock.
+  // 112 / 128-row variants were measured: fewer re-gathers of B, but 2 blocks per CU -- no faster (profiles/r1_notes.md)
   g.mt = maxM >= 48 ? 4 : 2;
   g.BM = 16 * g.mt;
   g.n_ntiles = (Ntot + CSF_BN - 1) / CSF_BN;
@@ -160,7 +162,9 @@ int csf_group_norm(CsfWalk& W, float* s, int ns, int64_t split_stride, int C, in
   for (int i = 0; i < nz; ++i) c.z[i] = z[i];
   c.part = reinterpret_cast<double*>(W.ws + part);
   for (int i = 0; i < nz; ++i) c.z_floats += z[i].Hz * z[i].Wz;
-  c.z_in_lds = c.z_floats > 0 && c.z_floats <= H->z_lds_max;   // <= 48 KB next to the reduction scratch
+  c.z_in_lds = c.z_floats > 0 && 4 * c.z_floats <= H->z_lds_max;   // <= 48 KB next to the reduction scratch
+  c.step_x = CSN_BLOCK % Ww;
+  c.step_y = CSN_BLOCK / Ww;
   LAUNCH_TRY(csf_launch_combine(c, W.stream));
   CsfGnFinArgs f{};
   f.part = c.part; f.nslab = nslab; f.cpg = cpg; f.groups = groups; f.C = C; f.HW = HW; f.B = H->B;

@@ -66,7 +66,8 @@ struct CsfCombArgs {     // s = sum_k s_k + sum_i up(z_i); partial sums of s and
   int nz;
   CsfZ z[3];
   double* part;          // [B][C][2]: one block (and one partial) per channel plane
-  int z_in_lds, z_floats;// the nz coarse planes of one channel fit in LDS (z_floats in total)
+  int z_in_lds, z_floats;// the nz coarse planes of a block's channels fit in LDS (z_floats per channel)
+  int step_x, step_y;    // CSN_BLOCK % W, CSN_BLOCK / W
 };
 
 struct CsfGnFinArgs {    // per (image, group): mean / rstd -> per (image, channel) scale and shift

@@ -223,87 +223,108 @@ int csf_launch_gemm(const CsfGemmArgs& a, int mt, void* stream) {
 }
 
 // ------------------------------------------------------------------------------ combine + GroupNorm statistics
-// One block per (image, channel) plane.  The coarser tensors' planes of that channel (a few KB: 44x44 + 22x22 + 11x11
-// floats at 352x352) are staged in LDS once -- split-K slices summed on the way in -- so the 4 taps x nz levels per
-// output pixel are LDS reads; the plane itself streams through once (coalesced read + write).
+// One block per (image, CSF_CG consecutive channels).  The coarser tensors' planes of those channels (a few KB each:
+// 44x44 + 22x22 + 11x11 floats at 352x352) are staged in LDS once -- split-K slices summed on the way in -- so the
+// 4 taps x nz levels per output value are LDS reads, and a lane computes the interpolation indices / weights of its
+// pixel once for the CSF_CG channels; the planes stream through once (coalesced read + write).
+#define CSF_CG 4
 __global__ __launch_bounds__(CSN_BLOCK) void csf_combine_kernel(CsfCombArgs a) {
   CSN_DYN_SMEM(double, red);   // [2][CSN_BLOCK] doubles, then the staged planes (floats)
   float* zl = reinterpret_cast<float*>(red + 2 * CSN_BLOCK);
-  const int ch = blockIdx.x, n = blockIdx.y;
+  const int ch0 = blockIdx.x * CSF_CG, n = blockIdx.y;
   const int tid = threadIdx.x;
-  int zoff[3] = {0, 0, 0};
+  int zoff[3] = {0, 0, 0}, zlen[3] = {0, 0, 0};
   if (a.z_in_lds) {
     int off = 0;
     for (int i = 0; i < a.nz; ++i) {
       const CsfZ& z = a.z[i];
       const int len = z.Hz * z.Wz;
-      const float* q = z.z + (long long)n * z.nstride + (long long)ch * len;
-      for (int e = tid; e < len; e += CSN_BLOCK) {
+      const float* q = z.z + (long long)n * z.nstride + (long long)ch0 * len;   // CSF_CG planes are contiguous
+      for (int e = tid; e < CSF_CG * len; e += CSN_BLOCK) {
         float v = q[e];
         for (int k = 1; k < z.ns; ++k) v += q[(long long)k * z.split_stride + e];
         zl[off + e] = v;
       }
       zoff[i] = off;
-      off += len;
+      zlen[i] = len;
+      off += CSF_CG * len;
     }
     __syncthreads();
   }
-  float* sp = a.s + ((long long)n * a.C + ch) * a.HW;
-  double s1 = 0.0, s2 = 0.0;
+  float* sp = a.s + ((long long)n * a.C + ch0) * a.HW;
+  double s1[CSF_CG], s2[CSF_CG];
+#pragma unroll
+  for (int c = 0; c < CSF_CG; ++c) s1[c] = s2[c] = 0.0;
+  int y = tid / a.W, x = tid - y * a.W;
   for (int pix = tid; pix < a.HW; pix += CSN_BLOCK) {
-    float v = sp[pix];
-    for (int k = 1; k < a.ns; ++k) v += sp[(long long)k * a.split_stride + pix];
-    if (a.nz) {
-      const int y = pix / a.W, x = pix - y * a.W;
-      for (int i = 0; i < a.nz; ++i) {
-        const CsfZ& z = a.z[i];
-        int y0, y1, x0, x1;
-        float ly, lx;
-        csn_bilin(y, z.ry, z.Hz, y0, y1, ly);
-        csn_bilin(x, z.rx, z.Wz, x0, x1, lx);
-        float v00, v01, v10, v11;
-        if (a.z_in_lds) {
-          const float* q = zl + zoff[i];
-          v00 = q[y0 * z.Wz + x0]; v01 = q[y0 * z.Wz + x1];
-          v10 = q[y1 * z.Wz + x0]; v11 = q[y1 * z.Wz + x1];
-        } else {
-          const float* q = z.z + (long long)n * z.nstride + (long long)ch * z.Hz * z.Wz;
-          v00 = q[y0 * z.Wz + x0]; v01 = q[y0 * z.Wz + x1];
-          v10 = q[y1 * z.Wz + x0]; v11 = q[y1 * z.Wz + x1];
+    float v[CSF_CG];
+#pragma unroll
+    for (int c = 0; c < CSF_CG; ++c) {
+      const float* q = sp + (long long)c * a.HW + pix;
+      v[c] = q[0];
+      for (int k = 1; k < a.ns; ++k) v[c] += q[(long long)k * a.split_stride];
+    }
+    for (int i = 0; i < a.nz; ++i) {
+      const CsfZ& z = a.z[i];
+      int y0, y1, x0, x1;
+      float ly, lx;
+      csn_bilin(y, z.ry, z.Hz, y0, y1, ly);
+      csn_bilin(x, z.rx, z.Wz, x0, x1, lx);
+      const int o00 = y0 * z.Wz + x0, o01 = y0 * z.Wz + x1, o10 = y1 * z.Wz + x0, o11 = y1 * z.Wz + x1;
+      const float wx0 = 1.f - lx, wy0 = 1.f - ly;
+      if (a.z_in_lds) {
+        const float* q = zl + zoff[i];
+#pragma unroll
+        for (int c = 0; c < CSF_CG; ++c, q += zlen[i])
+          v[c] += wy0 * (wx0 * q[o00] + lx * q[o01]) + ly * (wx0 * q[o10] + lx * q[o11]);
+      } else {
+        const long long len = (long long)z.Hz * z.Wz;
+        const float* q = z.z + (long long)n * z.nstride + (long long)ch0 * len;
+#pragma unroll
+        for (int c = 0; c < CSF_CG; ++c, q += len) {
+          float v00 = q[o00], v01 = q[o01], v10 = q[o10], v11 = q[o11];
           for (int k = 1; k < z.ns; ++k) {
             const float* qk = q + (long long)k * z.split_stride;
-            v00 += qk[y0 * z.Wz + x0]; v01 += qk[y0 * z.Wz + x1];
-            v10 += qk[y1 * z.Wz + x0]; v11 += qk[y1 * z.Wz + x1];
+            v00 += qk[o00]; v01 += qk[o01]; v10 += qk[o10]; v11 += qk[o11];
           }
+          v[c] += wy0 * (wx0 * v00 + lx * v01) + ly * (wx0 * v10 + lx * v11);
         }
-        const float t0 = (1.f - lx) * v00 + lx * v01;
-        const float t1 = (1.f - lx) * v10 + lx * v11;
-        v += (1.f - ly) * t0 + ly * t1;
       }
     }
-    if (a.nz || a.ns > 1) sp[pix] = v;
-    s1 += (double)v;
-    s2 += (double)v * (double)v;
+#pragma unroll
+    for (int c = 0; c < CSF_CG; ++c) {
+      if (a.nz || a.ns > 1) sp[(long long)c * a.HW + pix] = v[c];
+      s1[c] += (double)v[c];
+      s2[c] += (double)v[c] * (double)v[c];
+    }
+    x += a.step_x;                       // pix += CSN_BLOCK without a division
+    y += a.step_y;
+    if (x >= a.W) { x -= a.W; ++y; }
   }
-  red[tid] = s1;
-  red[CSN_BLOCK + tid] = s2;
-  __syncthreads();
-  for (int st = CSN_BLOCK / 2; st > 0; st >>= 1) {
-    if (tid < st) {
-      red[tid] += red[tid + st];
-      red[CSN_BLOCK + tid] += red[CSN_BLOCK + tid + st];
+#pragma unroll
+  for (int c = 0; c < CSF_CG; ++c) {
+    red[tid] = s1[c];
+    red[CSN_BLOCK + tid] = s2[c];
+    __syncthreads();
+    for (int st = CSN_BLOCK / 2; st > 0; st >>= 1) {
+      if (tid < st) {
+        red[tid] += red[tid + st];
+        red[CSN_BLOCK + tid] += red[CSN_BLOCK + tid + st];
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {   // [image][channel][2]: csf_gn_finalize sums the cpg channels of a group in order
+      a.part[((long long)n * a.C + ch0 + c) * 2 + 0] = red[0];
+      a.part[((long long)n * a.C + ch0 + c) * 2 + 1] = red[CSN_BLOCK];
     }
     __syncthreads();
-  }
-  if (tid == 0) {   // [image][channel][2]: csf_gn_finalize sums the cpg channels of a group in order
-    a.part[((long long)n * a.C + ch) * 2 + 0] = red[0];
-    a.part[((long long)n * a.C + ch) * 2 + 1] = red[CSN_BLOCK];
   }
 }
 
 int csf_launch_combine(const CsfCombArgs& a, void* stream) {
-  const size_t lds = 2 * CSN_BLOCK * sizeof(double) + (a.z_in_lds ? (size_t)a.z_floats * sizeof(float) : 0);
-  CSN_LAUNCH(csf_combine_kernel, dim3(a.C, a.B, 1), dim3(CSN_BLOCK), lds, stream, a);
+  if (a.C % CSF_CG) return -1;
+  const size_t lds = 2 * CSN_BLOCK * sizeof(double) + (a.z_in_lds ? (size_t)CSF_CG * a.z_floats * sizeof(float) : 0);
+  CSN_LAUNCH(csf_combine_kernel, dim3(a.C / CSF_CG, a.B, 1), dim3(CSN_BLOCK), lds, stream, a);
   return (int)hipGetLastError();
 }
 
