@@ -13,7 +13,8 @@ from typing import Optional, Sequence
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libcsnet_hip.so")
+# SOD100K_HIP_LIB: developer override (A/B builds of the same sources, e.g. the knock-out variants of profiles/r1_notes.md)
+LIB_PATH = os.environ.get("SOD100K_HIP_LIB") or os.path.join(CSRC, "libcsnet_hip.so")
 SOURCES = ("csn_plan.hip", "k_misc.hip", "k_goct_pw.hip", "k_ms.hip", "k_train.hip", "k_wgrad.hip", "k_goct_c3.hip", "k_csf.hip")
 
 MAX_BRANCH = 3

@@ -228,25 +228,50 @@ int csf_launch_gemm(const CsfGemmArgs& a, int mt, void* stream) {
 // 4 taps x nz levels per output value are LDS reads, and a lane computes the interpolation indices / weights of its
 // pixel once for the CSF_CG channels; the planes stream through once (coalesced read + write).
 #define CSF_CG 4
+// fixed-order block sum: butterfly inside the wave, then the four wave results (one barrier pair instead of a
+// log2(256)-step LDS tree: the tree's barriers were a quarter of a block's life)
+__device__ __forceinline__ double csf_block_sum(double v, double* sm) {
+  const int tid = threadIdx.x;
+#ifdef CSN_CPU_EMU
+  sm[tid] = v;
+  __syncthreads();
+  for (int s = CSN_BLOCK / 2; s > 0; s >>= 1) {
+    if (tid < s) sm[tid] += sm[tid + s];
+    __syncthreads();
+  }
+  const double r = sm[0];
+  __syncthreads();
+  return r;
+#else
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((tid & 63) == 0) sm[tid >> 6] = v;
+  __syncthreads();
+  const double r = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+  __syncthreads();
+  return r;
+#endif
+}
+
 __global__ __launch_bounds__(CSN_BLOCK) void csf_combine_kernel(CsfCombArgs a) {
   CSN_DYN_SMEM(double, red);   // [2][CSN_BLOCK] doubles, then the staged planes (floats)
   float* zl = reinterpret_cast<float*>(red + 2 * CSN_BLOCK);
   const int ch0 = blockIdx.x * CSF_CG, n = blockIdx.y;
   const int tid = threadIdx.x;
-  int zoff[3] = {0, 0, 0}, zlen[3] = {0, 0, 0};
+  int zoff[3] = {0, 0, 0};
   if (a.z_in_lds) {
     int off = 0;
     for (int i = 0; i < a.nz; ++i) {
       const CsfZ& z = a.z[i];
       const int len = z.Hz * z.Wz;
       const float* q = z.z + (long long)n * z.nstride + (long long)ch0 * len;   // CSF_CG planes are contiguous
-      for (int e = tid; e < CSF_CG * len; e += CSN_BLOCK) {
+      for (int e = tid; e < CSF_CG * len; e += CSN_BLOCK) {   // [channel][pixel] -> [pixel][channel]
         float v = q[e];
         for (int k = 1; k < z.ns; ++k) v += q[(long long)k * z.split_stride + e];
-        zl[off + e] = v;
+        const int c = e / len;
+        zl[off + (e - c * len) * CSF_CG + c] = v;
       }
       zoff[i] = off;
-      zlen[i] = len;
       off += CSF_CG * len;
     }
     __syncthreads();
@@ -272,11 +297,13 @@ __global__ __launch_bounds__(CSN_BLOCK) void csf_combine_kernel(CsfCombArgs a) {
       csn_bilin(x, z.rx, z.Wz, x0, x1, lx);
       const int o00 = y0 * z.Wz + x0, o01 = y0 * z.Wz + x1, o10 = y1 * z.Wz + x0, o11 = y1 * z.Wz + x1;
       const float wx0 = 1.f - lx, wy0 = 1.f - ly;
-      if (a.z_in_lds) {
-        const float* q = zl + zoff[i];
-#pragma unroll
-        for (int c = 0; c < CSF_CG; ++c, q += zlen[i])
-          v[c] += wy0 * (wx0 * q[o00] + lx * q[o01]) + ly * (wx0 * q[o10] + lx * q[o11]);
+      if (a.z_in_lds) {   // one 128-bit LDS read per tap serves the CSF_CG channels
+        const float4* q = reinterpret_cast<const float4*>(zl + zoff[i]);
+        const float4 t00 = q[o00], t01 = q[o01], t10 = q[o10], t11 = q[o11];
+        v[0] += wy0 * (wx0 * t00.x + lx * t01.x) + ly * (wx0 * t10.x + lx * t11.x);
+        v[1] += wy0 * (wx0 * t00.y + lx * t01.y) + ly * (wx0 * t10.y + lx * t11.y);
+        v[2] += wy0 * (wx0 * t00.z + lx * t01.z) + ly * (wx0 * t10.z + lx * t11.z);
+        v[3] += wy0 * (wx0 * t00.w + lx * t01.w) + ly * (wx0 * t10.w + lx * t11.w);
       } else {
         const long long len = (long long)z.Hz * z.Wz;
         const float* q = z.z + (long long)n * z.nstride + (long long)ch0 * len;
@@ -302,22 +329,12 @@ __global__ __launch_bounds__(CSN_BLOCK) void csf_combine_kernel(CsfCombArgs a) {
     if (x >= a.W) { x -= a.W; ++y; }
   }
 #pragma unroll
-  for (int c = 0; c < CSF_CG; ++c) {
-    red[tid] = s1[c];
-    red[CSN_BLOCK + tid] = s2[c];
-    __syncthreads();
-    for (int st = CSN_BLOCK / 2; st > 0; st >>= 1) {
-      if (tid < st) {
-        red[tid] += red[tid + st];
-        red[CSN_BLOCK + tid] += red[CSN_BLOCK + tid + st];
-      }
-      __syncthreads();
+  for (int c = 0; c < CSF_CG; ++c) {   // [image][channel][2]: csf_gn_finalize sums the cpg channels of a group in order
+    const double r1 = csf_block_sum(s1[c], red), r2 = csf_block_sum(s2[c], red);
+    if (tid == 0) {
+      a.part[((long long)n * a.C + ch0 + c) * 2 + 0] = r1;
+      a.part[((long long)n * a.C + ch0 + c) * 2 + 1] = r2;
     }
-    if (tid == 0) {   // [image][channel][2]: csf_gn_finalize sums the cpg channels of a group in order
-      a.part[((long long)n * a.C + ch0 + c) * 2 + 0] = red[0];
-      a.part[((long long)n * a.C + ch0 + c) * 2 + 1] = red[CSN_BLOCK];
-    }
-    __syncthreads();
   }
 }
 
