@@ -122,19 +122,21 @@ int plan_goct_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
       ub.wg.push_back(w);
     }
   // ---- input gradients
-  const int mode = d.ksize == 3 ? PW_TAPS : PW_OWN;
+  const bool std_s2 = u.std_conv && d.stride == 2;   // real stride: the input gradient is the zero-stuffed adjoint
+  const int mode = d.ksize == 3 ? (std_s2 ? PW_TAPS_UPS2 : PW_TAPS) : PW_OWN;
   int64_t tmp_bytes = 0;
   for (int i = 0; i < d.n_in; ++i) {
     if (!ub.need_dx[i]) continue;
-    if (d.stride == 2) ub.dxp_off[i] = bw_alloc(ub, bl.act_bytes(d.cin[i], base + i));
+    if (d.stride == 2 && !std_s2) ub.dxp_off[i] = bw_alloc(ub, bl.act_bytes(d.cin[i], base + i));
     auto wblk = [&](int j) {
       WBlock w;
       w.src = d.w_off[0] + ((int64_t)co_off[j] * cin_tot + ci_off[i]) * kk;
       w.ld = ld; w.ncol = d.cout[j] * kk; w.tk = kk;
+      if (u.std_conv) w.scale = 100.f;
       return w;
     };
     PwLaunchPlan L;
-    L.lvl = base + i;
+    L.lvl = base + i - (std_s2 ? 1 : 0);
     PwPassPlan ps;
     ps.r = 0; ps.nrows = d.cin[i]; ps.out_kind = OUT_DX; ps.out_branch = i; ps.out_ctot = d.cin[i];
     ident_epi(P, ps);
@@ -401,7 +403,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
     }
     for (int i = 0; i < d.n_in; ++i) {
       if (d.cin[i] == 0) continue;
-      bd.in[i] = (d.kind == CSN_UNIT_GOCT && d.stride == 2) ? reinterpret_cast<const float*>(c.ws + u.pooled_off[i])
+      bd.in[i] = (d.kind == CSN_UNIT_GOCT && d.stride == 2 && !u.std_conv) ? reinterpret_cast<const float*>(c.ws + u.pooled_off[i])
                                                              : c.act_in(d.in_act[i]);
     }
   }
@@ -476,7 +478,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
       LAUNCH_TRY(csn_launch_maxpool_bwd_add(pa, c.stream));
     }
   }
-  if (d.kind == CSN_UNIT_GOCT && d.stride == 2)
+  if (d.kind == CSN_UNIT_GOCT && d.stride == 2 && !u.std_conv)
     for (int i = 0; i < d.n_in; ++i) {
       if (!ub.need_dx[i]) continue;
       PoolBwdArgs pa;

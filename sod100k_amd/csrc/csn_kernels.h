@@ -68,7 +68,10 @@ struct DwArgs {
 #define PW_MAX_GRID 2048
 // how a channel slice is brought to the pass resolution; the *_TAPS modes contribute 9 gathered
 // entries per channel (k = 9*ch + 3*(dy+1) + (dx+1), zero padded) = a 3x3 convolution as a contraction
-enum PwMode { PW_OWN = 0, PW_POOL2 = 1, PW_POOL4 = 2, PW_UP2 = 3, PW_UP4 = 4, PW_TAPS = 5, PW_POOL2_TAPS = 6 };
+enum PwMode { PW_OWN = 0, PW_POOL2 = 1, PW_POOL4 = 2, PW_UP2 = 3, PW_UP4 = 4, PW_TAPS = 5, PW_POOL2_TAPS = 6,
+              PW_TAPS_S2 = 7,     // 3x3 taps with stride 2 of a source at twice the resolution (std_conv, csnet.py:751-754)
+              PW_TAPS_UPS2 = 8 }; // its adjoint: 3x3 taps of a zero-stuffed source at half the resolution
+static inline bool pw_mode_taps(int m) { return m == PW_TAPS || m == PW_POOL2_TAPS || m == PW_TAPS_S2 || m == PW_TAPS_UPS2; }
 struct PwSrc {
   const float* ptr;  // first channel of the slice inside [B][Ctot][H_s][W_s]
   int32_t C;         // channels of the slice

@@ -100,6 +100,7 @@ struct UnitPlan {
   Epi dw_epi[3];
   int fuse_next = 0;   // DW: the next unit is the second depthwise unit of the same ILBlock
   int fuse_cls = 0;    // GOCT: the next unit is the cls_layer and nobody else reads this unit's output
+  int std_conv = 0;    // GOCT 1 -> 1: Conv2dX100 (x100 weights, real stride 2)
   int c3 = 0;          // GOCT 3x3: every launch of the unit qualifies for the LDS-tiled kernel (profile attribution)
   int pool_unit = -1;  // DW (first of a fused pair): index of the stride-2 unit whose pooled inputs the pair writes
   int pool_skip[3] = {0, 0, 0};   // ... and that unit is the only reader of branch i (full-resolution store skipped)
@@ -272,7 +273,7 @@ void add_launch(std::vector<PwLaunchPlan>& dst, PwLaunchPlan L) {
   for (const PwPassPlan& ps : L.passes) img += (int64_t)((ps.nrows + 15) & ~15) * (round4(ps.K) + 2);
   bool taps = false;   // 3x3 passes run one per launch (k_goct_c3.hip)
   for (const PwPassPlan& ps : L.passes)
-    for (int s = 0; s < ps.nsrc; ++s) taps = taps || ps.src_mode[s] == PW_TAPS || ps.src_mode[s] == PW_POOL2_TAPS;
+    for (int s = 0; s < ps.nsrc; ++s) taps = taps || pw_mode_taps(ps.src_mode[s]);
   if (L.passes.size() > 1 && (img * 4 > 24 * 1024 || taps)) {
     for (const PwPassPlan& ps : L.passes) {
       PwLaunchPlan one;
@@ -291,7 +292,10 @@ int plan_goct(Builder& bl, UnitPlan& u) {
   const csn_unit_desc& d = u.d;
   if (d.n_in < 1 || d.n_in > 3 || d.n_out < 1 || d.n_out > 3) FAIL(CSN_E_INVALID, "branch count");
   if (!(d.ksize == 1 || d.ksize == 3) || !(d.stride == 1 || d.stride == 2)) FAIL(CSN_E_INVALID, "ksize/stride");
-  if (d.n_in == 1 && d.n_out == 1) FAIL(CSN_E_UNSUPPORTED, "std_conv (Conv2dX100) unit, csnet.py:751-754");
+  // single branch in, single branch out: the reference builds a Conv2dX100 ("std_conv", csnet.py:751-754): weights x100
+  // (conv2d.py:104) and a REAL stride (no 2x2 avg-pool in front, csnet.py:779-786)
+  u.std_conv = d.n_in == 1 && d.n_out == 1;
+  if (u.std_conv && d.stride == 2 && d.ksize != 3) FAIL(CSN_E_UNSUPPORTED, "std_conv 1x1 with stride 2");
   int cin_tot = 0, cout_tot = 0, ci_off[4] = {0}, co_off[4] = {0};
   for (int i = 0; i < d.n_in; ++i) { ci_off[i] = cin_tot; cin_tot += d.cin[i]; }
   for (int j = 0; j < d.n_out; ++j) { co_off[j] = cout_tot; cout_tot += d.cout[j]; }
@@ -309,12 +313,13 @@ int plan_goct(Builder& bl, UnitPlan& u) {
   if (base < 0) FAIL(CSN_E_INVALID, "no outputs");
   u.base_lvl = base;
   const int ds = d.stride == 2 ? 1 : 0;
+  const bool std_s2 = u.std_conv && ds;
   for (int i = 0; i < d.n_in; ++i)
     if (d.cin[i] > 0) {
       if (d.in_act[i] < 0 || d.in_act[i] >= (int)P.acts.size()) FAIL(CSN_E_INVALID, "in_act");
       const Act& a = P.acts[d.in_act[i]];
       if (a.channels != d.cin[i] || a.lvl + ds != base + i) FAIL(CSN_E_INVALID, "input resolution/channels");
-      if (ds) u.pooled_off[i] = bl.alloc_ws(bl.act_bytes(d.cin[i], base + i));
+      if (ds && !std_s2) u.pooled_off[i] = bl.alloc_ws(bl.act_bytes(d.cin[i], base + i));
     }
   const int nb = d.n_in > d.n_out ? d.n_in : d.n_out;
   if (((P.H >> (base + nb - 1)) << (base + nb - 1)) != P.H || ((P.W >> (base + nb - 1)) << (base + nb - 1)) != P.W)
@@ -360,17 +365,19 @@ int plan_goct(Builder& bl, UnitPlan& u) {
       WBlock w = wproto;
       w.col = ps.K;
       ps.wb.push_back(w);
-      ps.K += (mode == PW_TAPS || mode == PW_POOL2_TAPS) ? 9 * C : C;
+      ps.K += pw_mode_taps(mode) ? 9 * C : C;
       return true;
     };
     auto wblk = [&](int i) {
       WBlock w;
       w.src = d.w_off[0] + ((int64_t)co_off[j] * cin_tot + ci_off[i]) * kk;
       w.ld = ld; w.ncol = d.cin[i] * kk;
+      if (u.std_conv) w.scale = 100.f;
       return w;
     };
     bool ok = true;
-    if (j < d.n_in && d.cin[j] > 0) ok = ok && add(SRC_IN, j, d.cin[j], d.ksize == 3 ? PW_TAPS : PW_OWN, wblk(j));
+    if (j < d.n_in && d.cin[j] > 0)
+      ok = ok && add(SRC_IN, j, d.cin[j], d.ksize == 3 ? (std_s2 ? PW_TAPS_S2 : PW_TAPS) : PW_OWN, wblk(j));
     for (int i = 0; i < j && i < d.n_in; ++i)
       if (d.cin[i] > 0) {
         if (j - i > 2 || (d.ksize == 3 && j - i > 1)) FAIL(CSN_E_UNSUPPORTED, "max-pool factor");
@@ -390,7 +397,7 @@ int plan_goct(Builder& bl, UnitPlan& u) {
     L.passes.push_back(ps);
   }
   add_launch(u.pwl, L);
-  u.c3 = d.ksize == 3;
+  u.c3 = d.ksize == 3 && !std_s2;
   for (PwLaunchPlan& l : u.pwl) {
     const int st = finish_launch(bl, l);
     if (st != CSN_OK) return st;
@@ -568,16 +575,16 @@ void fill_pass(const Ctx& c, const PwLaunchPlan& L, const PwPassPlan& pp, const 
       }
       // resolution of the source tensor relative to the pass (channel offset -> plane offset)
       int sh = 0;
-      if (mode == PW_POOL2 || mode == PW_POOL2_TAPS) sh = -1;
+      if (mode == PW_POOL2 || mode == PW_POOL2_TAPS || mode == PW_TAPS_S2) sh = -1;
       else if (mode == PW_POOL4) sh = -2;
-      else if (mode == PW_UP2) sh = 1;
+      else if (mode == PW_UP2 || mode == PW_TAPS_UPS2) sh = 1;
       else if (mode == PW_UP4) sh = 2;
       const int64_t hs = sh >= 0 ? (int64_t)(Hr >> sh) * (Wr >> sh) : (int64_t)(Hr << -sh) * (Wr << -sh);
       ps.src[s].ptr = base + (int64_t)pp.src_c0[s] * hs;
       ps.src[s].C = pp.src_C[s];
       ps.src[s].Ctot = pp.src_ctot[s] > 0 ? pp.src_ctot[s] : pp.src_C[s];
       ps.src[s].mode = mode;
-      ps.src[s].K = (mode == PW_TAPS || mode == PW_POOL2_TAPS) ? 9 * pp.src_C[s] : pp.src_C[s];
+      ps.src[s].K = pw_mode_taps(mode) ? 9 * pp.src_C[s] : pp.src_C[s];
       ps.src[s].dil = pp.src_dil[s];
     }
   }
@@ -685,7 +692,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
       if (d.stride == 2 && u.pooled_by_producer && P.fuse_dw && !c.raw) {
         for (int i = 0; i < d.n_in; ++i)
           if (d.cin[i] > 0) xin[i] = reinterpret_cast<const float*>(c.ws + u.pooled_off[i]);
-      } else if (d.stride == 2) {
+      } else if (d.stride == 2 && !u.std_conv) {
         PoolArgs pa;
         pa.n = 0;
         int blk = 0;
@@ -926,7 +933,7 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
     if (!P->units[k].fuse_next) continue;
     const csn_unit_desc& b = P->units[k + 1].d;
     const csn_unit_desc& g = P->units[k + 2].d;
-    if (g.kind != CSN_UNIT_GOCT || g.stride != 2 || g.n_in != b.n_out) continue;
+    if (g.kind != CSN_UNIT_GOCT || g.stride != 2 || g.n_in != b.n_out || (g.n_in == 1 && g.n_out == 1)) continue;
     bool ok = true;
     for (int i = 0; i < g.n_in && ok; ++i) {
       if (g.cin[i] != b.cout[i] || (g.cin[i] > 0 && g.in_act[i] != b.out_act[i])) ok = false;

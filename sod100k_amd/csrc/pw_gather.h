@@ -133,6 +133,26 @@ __device__ __forceinline__ void pw_batch_pool2_taps(csn_buf rb, unsigned lo, uns
       xrow[(k0 + j) * XP] = m[j] ? fmaxf(fmaxf(a0[j].x, a0[j].y), fmaxf(a1[j].x, a1[j].y)) : 0.f;
 }
 
+// 3x3 taps of a zero-stuffed slice (source at half the resolution): the adjoint of a stride-2 3x3 convolution.
+// Tap t of output pixel (y, x) reads source ((y + dy) / 2, (x + dx) / 2) when both coordinates are even and inside.
+template <int NB, int XP>
+__device__ __forceinline__ void pw_batch_taps_ups2(csn_buf rb, int y, int x, int Hr, int Wr, int Ws, unsigned cs4,
+                                                   int k_lo, int k0, int n, int rmax, float* xrow) {
+  float v[NB];
+  bool m[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int kk = k_lo + min(k0 + j, n - 1);
+    const int ch = kk / 9, t = kk - 9 * ch;
+    const int h = y + t / 3 - 1, w = x + (t - 3 * (t / 3)) - 1;
+    m[j] = h >= 0 && w >= 0 && h < Hr && w < Wr && ((h | w) & 1) == 0;
+    v[j] = csn_ld1(rb, m[j] ? (unsigned)((h >> 1) * Ws + (w >> 1)) * 4u : 0u, (unsigned)ch * cs4);
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+    if (k0 + j < rmax) xrow[(k0 + j) * XP] = m[j] ? v[j] : 0.f;
+}
+
 __device__ __forceinline__ unsigned pw_tap_mask(int y, int x, int Hr, int Wr, int dil) {
   unsigned vm = 0;
 #pragma unroll
@@ -182,6 +202,22 @@ __device__ __forceinline__ void pw_gather_slice(PwPassP ps, int s, int c_lo, int
     const unsigned lo = ((unsigned)(2 * y) * Ws + 2u * x) * 4u;
     const unsigned vm = pw_tap_mask(y, x, Hr, Wr, 1);
     for (int k0 = 0; k0 < n; k0 += 8) pw_batch_pool2_taps<8, XP>(rb, lo, cs * 4u, Ws * 4u, vm, c_lo, k0, n, rmax, xrow);
+  } else if (mode == PW_TAPS_S2) {   // Conv2dX100 with stride 2 (csnet.py:751-754): taps (2y + dy, 2x + dx), zero padding
+    const unsigned Ws = (unsigned)Wr * 2u;
+    const unsigned cs = (unsigned)(Hr * 2) * Ws;
+    const csn_buf rb = csn_make_buf_n(ps->src[s].ptr + (int64_t)b * ps->src[s].Ctot * cs,
+                                      (unsigned)ps->src[s].Ctot * cs * 4u);
+    const unsigned lo = ((unsigned)(2 * y) * Ws + 2u * x) * 4u;
+    unsigned vm = 0x1ffu;            // only the top row / left column can fall outside
+    if (y == 0) vm &= ~0x007u;
+    if (x == 0) vm &= ~0x049u;
+    for (int k0 = 0; k0 < n; k0 += 16) pw_batch_taps<16, XP>(rb, lo, cs * 4u, (int)Ws, 1, vm, c_lo, k0, n, rmax, xrow);
+  } else if (mode == PW_TAPS_UPS2) {
+    const int Hs = Hr >> 1, Ws = Wr >> 1;
+    const unsigned cs = (unsigned)(Hs * Ws);
+    const csn_buf rb = csn_make_buf_n(ps->src[s].ptr + (int64_t)b * ps->src[s].Ctot * cs,
+                                      (unsigned)ps->src[s].Ctot * cs * 4u);
+    for (int k0 = 0; k0 < n; k0 += 16) pw_batch_taps_ups2<16, XP>(rb, y, x, Hr, Wr, Ws, cs * 4u, c_lo, k0, n, rmax, xrow);
   } else {  // bilinear from a 2x / 4x coarser branch, align_corners=False
     const int sh = mode == PW_UP2 ? 1 : 2;
     const int Hs = Hr >> sh, Ws = Wr >> sh;

@@ -338,17 +338,23 @@ class CSNet(nn.Module):
 
         def add_goct(name, cbr: gOctaveCBR, cur):
             """cur: list of (act_id | None, channels, lvl) per input branch."""
-            if cbr.std_conv:
-                raise NotImplementedError("single-branch gOctaveCBR (Conv2dX100 std_conv, csnet.py:751-754) is "
-                                          "not supported by the HIP plan yet")
             conv = cbr.conv
-            bi, bo = conv.in_bounds(), conv.out_bounds()
             u = N.new_unit(N.UNIT_GOCT)
-            u.n_in, u.n_out = conv.inbranch, conv.outbranch
-            u.ksize, u.stride = cbr.kernel_size[0], conv.stride
+            if cbr.std_conv:      # Conv2dX100 (csnet.py:751-754): the plan infers x100 / real stride from 1 -> 1 branches
+                bi, bo = [0, cbr.in_channels], [0, cbr.out_channels]
+                u.n_in = u.n_out = 1
+                stride = cbr.stride
+                if isinstance(cur, tuple):
+                    cur = [cur]
+            else:
+                bi, bo = conv.in_bounds(), conv.out_bounds()
+                u.n_in, u.n_out = conv.inbranch, conv.outbranch
+                stride = conv.stride
+            nin, nout = int(u.n_in), int(u.n_out)
+            u.ksize, u.stride = cbr.kernel_size[0], stride
             u.w_off[0] = offsets[name + ".conv.weight"]
             lvl0 = None
-            for i in range(conv.inbranch):
+            for i in range(nin):
                 c = bi[i + 1] - bi[i]
                 present = cur[i] is not None and cur[i][0] is not None and c > 0
                 u.cin[i] = c if present else 0
@@ -357,9 +363,9 @@ class CSNet(nn.Module):
                     assert cur[i][1] == c, (name, i, cur[i], c)
                     if lvl0 is None:
                         lvl0 = cur[i][2] - i
-            base = lvl0 + (1 if conv.stride == 2 else 0)
+            base = lvl0 + (1 if stride == 2 else 0)
             outs = []
-            for j in range(conv.outbranch):
+            for j in range(nout):
                 c = bo[j + 1] - bo[j]
                 if c > 0 and cbr.bns[j] is not None:
                     assert cbr.bns[j].num_features == c

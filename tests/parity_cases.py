@@ -206,8 +206,6 @@ def check_g4(lib, device):
     arrs = np.load(os.path.join(GOLD, "g4_ops.npz"))
     report = {}
     for tag, mt in meta.items():
-        if mt["kind"] == "cbr" and len(mt["cin"]) == 1 and len(mt["cout"]) == 1:
-            continue  # Conv2dX100 std_conv branch: not on the shipped configs' path (checked separately)
         worst = 0.0
         for got, exp in run_g4_case(lib, device, tag, mt, arrs):
             assert got.shape == exp.shape, (tag, got.shape, exp.shape)
@@ -433,3 +431,43 @@ def check_pre_post(lib, device, manifest):
     g9 = np.load(os.path.join(GOLD, "g9_uint8_x2_image.npy"))
     assert u8.shape == g9.shape and u8.dtype == np.uint8
     assert np.abs(u8.astype(int) - g9.astype(int)).max() <= 1 and (u8 != g9).mean() < 5e-3
+
+
+def check_std_conv_network(lib, device, random_state):
+    """``build_model()`` with its default ``basic_split=[1]``: every ILBlock's first conv is the Conv2dX100 ``std_conv``
+    of csnet.py:751-754 (x100 weights; the stride-2 blocks are REAL strided 3x3 convolutions, no avg-pool).  Eval forward,
+    train-mode forward and every gradient against the oracle (penalty off: the reference's hook is ill-defined on the
+    tensor output of a std_conv module)."""
+    from sod100k_amd.model import csnet as M
+    m = M.build_model(save_path="/tmp")
+    assert m.stage1[0].conv1x1.std_conv and m.stage2[0].conv1x1.stride == 2
+    sd = random_state(m, 2)
+    for k in sd:                                   # x100 convolutions: keep the activations O(1)
+        if k.endswith("conv1x1.conv.weight"):
+            sd[k] = sd[k] * 0.01
+    m.load_state_dict(sd)
+    m = m.to(device)
+    if device.type == "cpu":
+        m._lib = lib
+    cfg = O.init_layers(20, [1])
+    x = torch.from_numpy(I.randn_batch(8, 2, 64, 64))
+    t = torch.from_numpy(I.binary_target(9, 2, 64, 64))
+    m.eval()
+    with torch.no_grad():
+        ref = O.csnet_forward(cfg, {k: v.clone() for k, v in sd.items()}, x)
+    y = m(x.to(device)).cpu()
+    assert (y - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+    m.train(); m.set_batchsize(2); m.clear_flops()
+    xd = x.to(device)
+    yt, _ = m._train_forward_raw(xd)
+    loss, dy = bce_and_grad(lib, yt, t.to(device))
+    flat = m._train_backward_raw(xd, dy, 0.0)
+    kw = dict(expandflop=1.0, flops_weight=0.0, batchsize=2, lr=0.0, wd=0.0)
+    r32 = O.train_step(cfg, {k: v.clone() for k, v in sd.items()}, x, t, **kw)
+    r64 = O.train_step(cfg, {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()},
+                       x.double(), t.double(), **kw)
+    assert abs(float(loss) - r64["loss_bce"]) <= 1e-5
+    mine = np.array([e / (n + 1e-12) for e, n in grad_errors(m, flat, r64["grads"]).values()])
+    ref = np.array([float((r32["grads"][k].double() - g).norm() / (g.norm() + 1e-12)) for k, g in r64["grads"].items()])
+    assert np.median(mine) <= 2 * np.median(ref) + 1e-6 and mine.max() <= 3 * ref.max() + 1e-5, (
+        np.median(mine), np.median(ref), mine.max(), ref.max())

@@ -171,3 +171,10 @@ def test_gpu_train_nonsquare_and_repeat(hip, x2_manifest):
 def test_gpu_pre_post_processing(hip, x2_manifest):
     lib, dev = hip
     P.check_pre_post(lib, dev, x2_manifest)
+
+
+def test_gpu_std_conv_network(hip):
+    """build_model() defaults (basic_split=[1]): Conv2dX100 std_conv units, real stride-2 3x3 -- forward and all gradients."""
+    from test_unpruned_emu import _random_state
+    lib, dev = hip
+    P.check_std_conv_network(lib, dev, _random_state)

@@ -77,3 +77,7 @@ def test_emu_unpruned_expand2_forward(emu_lib):
         ref = O.csnet_forward(cfg, {k: v.clone() for k, v in sd.items()}, x)
     y = m(x)
     assert (y - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+
+
+def test_emu_single_branch_std_conv_network(emu_lib):
+    P.check_std_conv_network(emu_lib, CPU, _random_state)
