@@ -84,6 +84,63 @@ def main():
                     f"{a['hbm_write_bytes_per_launch']/1e6:.1f} | {alg} |\n")
     json.dump(bench, open(os.path.join(DST, f"{TAG}_bench.json"), "w"), indent=1)
     print(open(os.path.join(DST, f"{TAG}_kernel_stats.md")).read())
+    csf_summary(bench)
+
+
+def csf_summary(bench):
+    """profiles/<tag>_csf_head.md: one CSF+Res2Net head forward launch by launch (kernel trace) with the SQ counters of
+    the same launches (separate PMC pass).  Matrix-pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES (= 32 x MFMAs issued)
+    / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)."""
+    tr = os.path.join(SRC, "csf_trace", "trace_kernel_trace.csv")
+    if not os.path.exists(tr) or "csf_res2net" not in bench:
+        return
+    rows = [r for r in csv.DictReader(open(tr)) if short(r["Kernel_Name"]).startswith("csf_")]
+    seqs, cur = [], []
+    for r in rows:
+        cur.append(r)
+        if short(r["Kernel_Name"]) == "csf_resize_kernel":
+            seqs.append(cur)
+            cur = []
+    last = [r for r in seqs[-1] if short(r["Kernel_Name"]) != "csf_prep_kernel"]
+    pmc_rows = list(csv.DictReader(open(os.path.join(SRC, "csf_pmc", "pmc_counter_collection.csv"))))
+    disp = collections.OrderedDict()
+    for r in pmc_rows:
+        n = short(r["Kernel_Name"])
+        if not n.startswith("csf_") or n == "csf_prep_kernel":
+            continue
+        disp.setdefault(r["Dispatch_Id"], dict(name=n))[r["Counter_Name"]] = float(r["Counter_Value"])
+    pseq, cur = [], []
+    for d in disp.values():
+        cur.append(d)
+        if d["name"] == "csf_resize_kernel":
+            pseq.append(cur)
+            cur = []
+    plast = pseq[-1] if pseq else []
+    c = bench["csf_res2net"]
+    with open(os.path.join(DST, f"{TAG}_csf_head.md"), "w") as f:
+        f.write(f"# CSF+Res2Net decoder head, one forward ({c['workload']})\n\n")
+        f.write(f"bench: {c['value']} img/s whole network, head {c['ms_head_hip']} ms = {c['head_roofline']['achieved']} TFLOP/s "
+                f"= {c['head_roofline']['frac']} of the fp32 matrix peak, backbone (MIOpen) {c['ms_backbone_miopen']} ms\n\n"
+                "| # | kernel | blocks | us | matrix pipe | wait_any | wait_inst | active | LDS conflict |\n|---|---|---|---|---|---|---|---|---|\n")
+        tot = collections.Counter()
+        for i, r in enumerate(last):
+            n = short(r["Kernel_Name"])
+            us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            tot[n] += us
+            d = plast[i] if i < len(plast) and plast[i]["name"] == n else {}
+            wc = d.get("SQ_WAVE_CYCLES", 0) or 1
+            gui = d.get("GRBM_GUI_ACTIVE", 0)
+            mf = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (gui / 8 * 1024) if gui else 0
+            blocks = int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]) * int(r["Grid_Size_Y"])
+            cols = (f"{mf:.2f} | {d.get('SQ_WAIT_ANY', 0) / wc:.2f} | {d.get('SQ_WAIT_INST_ANY', 0) / wc:.2f} | "
+                    f"{d.get('SQ_ACTIVE_INST_ANY', 0) / wc:.2f} | "
+                    f"{d.get('SQ_LDS_BANK_CONFLICT', 0) / max(1.0, d.get('SQ_LDS_IDX_ACTIVE', 0)):.2f}") if d else " | | | | "
+            f.write(f"| {i} | {n} | {blocks} | {us:.1f} | {cols} |\n")
+        f.write("\n| kernel | us per forward |\n|---|---|\n")
+        for n, us in tot.most_common():
+            f.write(f"| {n} | {us:.0f} |\n")
+        f.write(f"| total | {sum(tot.values()):.0f} |\n")
+    print(open(os.path.join(DST, f"{TAG}_csf_head.md")).read()[:1500])
 
 
 if __name__ == "__main__":
