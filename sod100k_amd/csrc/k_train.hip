@@ -158,11 +158,10 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_apply_gap_kernel(BnApplyArgs a) 
 __global__ __launch_bounds__(CSN_BLOCK) void bn_penalty_kernel(BnApplyArgs a) {
   CSN_DYN_SMEM(double, sm);
   double t = 0.0;
-  for (int c = threadIdx.x; c < a.C; c += CSN_BLOCK) {
-    double sg = 0.0;
-    for (int n = 0; n < a.S; ++n) sg += (double)a.gapabs[(int64_t)c * a.S + n];
-    const double g = (double)a.arena[a.off_weight + c];
-    t += sg * g * g;
+  const int total = a.C * a.S;        // lanes walk the [C][S] table linearly (coalesced), fp64 accumulation
+  for (int i = threadIdx.x; i < total; i += CSN_BLOCK) {
+    const double g = (double)a.arena[a.off_weight + i / a.S];
+    t += (double)a.gapabs[i] * (g * g);
   }
   t = bn_block_sum(t, sm);
   if (threadIdx.x == 0) *a.penalty += 0.5 * (double)a.flop_w * t;
