@@ -44,3 +44,44 @@ def test_head_requires_device_without_library():
     net = R.build_model().eval()
     with pytest.raises(RuntimeError):
         net.head_forward(CO.synthetic_features(1, 1, [(4, 4), (2, 2), (1, 1), (1, 1)]), (16, 16))
+
+
+def test_head_abi_error_paths(emu_lib):
+    """Status codes instead of exceptions / crashes across the C ABI (include/csf_hip.h conventions)."""
+    import ctypes as C
+    from sod100k_amd import _native as N
+    from sod100k_amd.networks import csf_res2net as R
+    net = R.build_model().eval()
+    d = net.describe_head(net._ensure_arena().offsets)
+    hs = (C.c_int32 * 4)(8, 4, 2, 1)
+    head = C.c_void_p()
+    bad = N.CsfHeadDesc.from_buffer_copy(d)
+    bad.n_branch = 0
+    assert emu_lib.csf_head_create(C.byref(bad), 1, hs, hs, 32, 32, C.byref(head)) == 1        # CSN_E_INVALID
+    bad = N.CsfHeadDesc.from_buffer_copy(d)
+    bad.ms_split[0][4] += 1                                                                     # does not add up to cmid
+    assert emu_lib.csf_head_create(C.byref(bad), 1, hs, hs, 32, 32, C.byref(head)) == 1
+    bad = N.CsfHeadDesc.from_buffer_copy(d)
+    bad.cmid[1] = 250                                                                           # GroupNorm(32) needs C % 32 == 0
+    assert emu_lib.csf_head_create(C.byref(bad), 1, hs, hs, 32, 32, C.byref(head)) == 1
+    assert emu_lib.csf_head_create(C.byref(d), 1, hs, hs, 32, 32, C.byref(head)) == 0
+    try:
+        ws = torch.empty(int(emu_lib.csf_head_workspace_bytes(head)), dtype=torch.uint8)
+        feats = CO.synthetic_features(1, 1, [(8, 8), (4, 4), (2, 2), (1, 1)])
+        ptrs = (C.c_void_p * 4)(*[f.data_ptr() for f in feats])
+        y = torch.empty(1, 1, 32, 32)
+        # forward before refresh: call order violated
+        assert emu_lib.csf_head_forward(head, ptrs, y.data_ptr(), ws.data_ptr(), None) == 5    # CSN_E_STATE
+        arena = net._arena.flat
+        # an arena that is too short for the descriptor's offsets
+        assert emu_lib.csf_head_refresh_params(head, arena.data_ptr(), 1000, None) == 1
+        assert emu_lib.csf_head_refresh_params(head, arena.data_ptr(), arena.numel(), None) == 0
+        assert emu_lib.csf_head_forward(head, ptrs, y.data_ptr(), ws.data_ptr(), None) == 0
+        assert torch.isfinite(y).all()
+        off, c, h, w = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32()
+        assert emu_lib.csf_head_stage_info(head, 3, 0, C.byref(off), C.byref(c), C.byref(h), C.byref(w)) == 1
+        assert emu_lib.csf_head_stage_info(head, 1, 2, C.byref(off), C.byref(c), C.byref(h), C.byref(w)) == 0
+        assert (c.value, h.value, w.value) == (512, 2, 2)
+        assert emu_lib.csf_head_macs(head) > 0
+    finally:
+        emu_lib.csf_head_destroy(head)
