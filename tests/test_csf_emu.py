@@ -15,6 +15,8 @@ def net_sd(emu_lib):
 @pytest.mark.parametrize("sizes,out_size,batch", [
     ([(12, 16), (6, 8), (3, 4), (2, 2)], (48, 64), 2),        # octave-spaced levels, batch straddling pixel tiles
     ([(13, 10), (7, 5), (4, 3), (2, 2)], (50, 38), 1),        # the sizes a 50 x 38 input produces (non-integer ratios)
+    ([(4, 4), (2, 2), (1, 1), (1, 1)], (16, 16), 1),          # two coarse levels of the same size (identity resize)
+    ([(17, 3), (9, 2), (5, 1), (3, 1)], (68, 12), 3),         # thin maps, batch straddling tiles
 ])
 def test_head_matches_oracle(net_sd, sizes, out_size, batch):
     net, sd = net_sd
