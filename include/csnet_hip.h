@@ -171,6 +171,12 @@ int csn_saliency_u8(const float* logits, uint8_t* out, int64_t n, void* stream);
 int csn_sal_hist(const uint8_t* sal, const uint8_t* gt, int64_t npix, int32_t n_images, uint64_t* hist, uint64_t* abs_sum,
                  void* stream);
 
+/* The validation loop of the training caller (CSNet_training/train.py:262-276) for ONE picture: sigmoid of the
+ * hi x wi logits -> F.interpolate(size=(h, w), bilinear, align_corners=False) -> (x * 255).int() / 255 ->
+ * mean |. - target| over the h x w target (float, the picture's own size).  ADDS the mean to *mae (caller zeroes). */
+int csn_val_mae(const float* logits, int32_t hi, int32_t wi, const float* target, int32_t h, int32_t w, double* mae,
+                void* stream);
+
 /* Same as csn_forward (eager launches) but records a HIP event on `stream` after every kernel launch and
  * returns the mean duration per unit over `iters` passes (unit_ms[n_units], milliseconds).  Synchronises. */
 int csn_forward_profile(csn_plan* plan, const float* x, float* y, void* workspace, void* stream,

@@ -412,3 +412,16 @@ def caller_postprocess(logits: torch.Tensor) -> np.ndarray:
     """test.py:91-96 from the logits onward (no resize): sigmoid -> *255 -> uint8 truncation."""
     p = torch.sigmoid(logits[0].squeeze(0).squeeze(0)).cpu().numpy()
     return (p * 255).astype(np.uint8)
+
+
+def val_mae(logits: torch.Tensor, targets) -> float:
+    """train.py:262-276 for MLOSS == 1: per picture ``(F.interpolate(sigmoid(out[idx])[None], size=(h, w),
+    mode='bilinear') * 255.0).int().float() / 255.0`` against its own-size target, ``F.l1_loss(mean)``, averaged over
+    the pictures (AverageMeter with n = 1)."""
+    sig = torch.sigmoid(logits)
+    maes = []
+    for idx, t in enumerate(targets):
+        h, w = t.shape[-2:]
+        r = (F.interpolate(sig[idx].unsqueeze(0), size=(h, w), mode="bilinear") * 255.0).int().float() / 255.0
+        maes.append(F.l1_loss(r, t.float().reshape(1, 1, h, w), reduction="mean").item())
+    return sum(maes) / len(maes)

@@ -615,6 +615,13 @@ int csn_saliency_u8(const float* logits, uint8_t* out, int64_t n, void* stream) 
   return CSN_OK;
 }
 
+int csn_val_mae(const float* logits, int32_t hi, int32_t wi, const float* target, int32_t h, int32_t w, double* mae,
+                void* stream) {
+  if (!logits || !target || !mae || hi <= 0 || wi <= 0 || h <= 0 || w <= 0) return CSN_E_INVALID;
+  LAUNCH_TRY(csn_launch_val_mae(logits, hi, wi, target, h, w, mae, stream));
+  return CSN_OK;
+}
+
 int csn_normalize_nchw(const float* hwc, float* nchw, int64_t B, int64_t H, int64_t W, void* stream) {
   if (!hwc || !nchw || B <= 0 || H <= 0 || W <= 0) return CSN_E_INVALID;
   LAUNCH_TRY(csn_launch_normalize_nchw(hwc, nchw, B, H * W, stream));

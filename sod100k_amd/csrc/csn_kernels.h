@@ -285,6 +285,7 @@ int csn_launch_saliency_u8(const float* y, unsigned char* o, int64_t n, void* st
 int csn_launch_sal_hist(const unsigned char* sal, const unsigned char* gt, int64_t npix, int n_images,
                         unsigned long long* hist, unsigned long long* abs_sum, void* stream);
 int csn_launch_normalize_nchw(const float* hwc, float* chw, int64_t B, int64_t HW, void* stream);
+int csn_launch_val_mae(const float* logits, int hi, int wi, const float* target, int h, int w, double* mae, void* stream);
 
 // launchers (implemented next to the kernels)
 int csn_launch_prep(const CsnPrepJob* jobs_dev, int njobs, const float* arena, float* packed, void* stream);

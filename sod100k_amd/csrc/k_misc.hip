@@ -493,6 +493,54 @@ int csn_launch_sal_hist(const unsigned char* sal, const unsigned char* gt, int64
   return (int)hipGetLastError();
 }
 
+// val() of the training caller (CSNet_training/train.py:262-276), one picture: sigmoid -> bilinear resize to the
+// picture's own size -> (x * 255).int().float() / 255 -> L1 mean against the target.
+__device__ __forceinline__ float csn_sigmoid(float v) {
+  const float e = expf(-fabsf(v));
+  return v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+}
+
+__global__ __launch_bounds__(CSN_BLOCK) void val_mae_kernel(const float* __restrict__ logits, int Hi, int Wi,
+                                                             const float* __restrict__ target, int H, int W, float ry,
+                                                             float rx, double* mae) {
+  CSN_DYN_SMEM(double, sm);
+  const int64_t n = (int64_t)H * W;
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * CSN_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CSN_BLOCK) {
+    const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+    float v;
+    if (H == Hi && W == Wi) {     // F.interpolate copies when the size does not change
+      v = csn_sigmoid(logits[i]);
+    } else {
+      int y0, y1, x0, x1;
+      float ly, lx;
+      csn_bilin(y, ry, Hi, y0, y1, ly);
+      csn_bilin(x, rx, Wi, x0, x1, lx);
+      const float v0 = (1.f - lx) * csn_sigmoid(logits[y0 * Wi + x0]) + lx * csn_sigmoid(logits[y0 * Wi + x1]);
+      const float v1 = (1.f - lx) * csn_sigmoid(logits[y1 * Wi + x0]) + lx * csn_sigmoid(logits[y1 * Wi + x1]);
+      v = (1.f - ly) * v0 + ly * v1;
+    }
+    const float q = (float)(int)(v * 255.0f) / 255.0f;
+    s += (double)fabsf(q - target[i]);
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = CSN_BLOCK / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) sm[threadIdx.x] += sm[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(mae, sm[0] / (double)n);
+}
+
+int csn_launch_val_mae(const float* logits, int hi, int wi, const float* target, int h, int w, double* mae, void* stream) {
+  const int64_t n = (int64_t)h * w;
+  int nblk = (int)((n + CSN_BLOCK - 1) / CSN_BLOCK);
+  if (nblk > 256) nblk = 256;
+  CSN_LAUNCH(val_mae_kernel, dim3(nblk), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, logits, hi, wi, target, h, w,
+             (float)hi / (float)h, (float)wi / (float)w, mae);
+  return (int)hipGetLastError();
+}
+
 int csn_launch_saliency_u8(const float* y, unsigned char* o, int64_t n, void* stream) {
   const int64_t nb = (n + CSN_BLOCK - 1) / CSN_BLOCK;
   CSN_LAUNCH(saliency_u8_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(CSN_BLOCK), 0, stream, y, o, n);

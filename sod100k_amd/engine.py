@@ -220,3 +220,18 @@ def saliency_u8(lib: C.CDLL, logits: torch.Tensor) -> torch.Tensor:
     N.check(lib, lib.csn_saliency_u8(logits.data_ptr(), out.data_ptr(), logits.numel(), _stream_of(logits)),
             "csn_saliency_u8")
     return out
+
+
+def val_mae(lib: C.CDLL, logits: torch.Tensor, target: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One picture of the training caller's validation loop (train.py:262-276): logits 1 x 1 x hi x wi (or hi x wi),
+    target h x w float at the picture's own size -> fp64 device scalar, ADDED to ``out`` when given."""
+    assert logits.dtype == torch.float32 and target.dtype == torch.float32
+    logits, target = logits.contiguous(), target.contiguous()
+    hi, wi = int(logits.shape[-2]), int(logits.shape[-1])
+    h, w = int(target.shape[-2]), int(target.shape[-1])
+    assert logits.numel() == hi * wi and target.numel() == h * w
+    if out is None:
+        out = torch.zeros(1, dtype=torch.float64, device=logits.device)
+    N.check(lib, lib.csn_val_mae(logits.data_ptr(), hi, wi, target.data_ptr(), h, w, out.data_ptr(), _stream_of(logits)),
+            "csn_val_mae")
+    return out

@@ -117,6 +117,28 @@ def multistep_lr(base_lr, steps, epoch, gamma=0.1):
     return base_lr * gamma ** sum(1 for s in steps if epoch + 1 >= s)
 
 
+def val(model, batches, lib=None):
+    """Validation loop of train.py:250-293: eval-mode forward, then per picture sigmoid -> bilinear resize to the
+    picture's own (h, w) -> (x * 255).int() / 255 -> L1 mean against its target; returns the average over pictures
+    (``maes.avg``).  ``batches`` yields (images B x 3 x H x W, [target_i of shape h_i x w_i]); resize + quantise +
+    L1 run in one kernel per picture (csn_val_mae), one host read at the end."""
+    from sod100k_amd.engine import val_mae
+    was_training = model.training
+    model.eval()
+    lib = lib if lib is not None else (model._lib or N.load())
+    total, count = None, 0
+    with torch.no_grad():
+        for img, targets in batches:
+            out = model(img.float())
+            if total is None:
+                total = torch.zeros(1, dtype=torch.float64, device=out.device)
+            for idx, t in enumerate(targets):
+                val_mae(lib, out[idx], t.to(out.device).float(), out=total)
+                count += 1
+    model.train(was_training)
+    return float(total) / max(count, 1) if total is not None else 0.0
+
+
 def synthetic_batches(n, batch, h, w, device, seed=0):
     g = torch.Generator().manual_seed(seed)
     for _ in range(n):

@@ -81,3 +81,56 @@ def test_emu_sal_metric(emu_lib, salm_oracle):
 def test_gpu_sal_metric(salm_oracle):
     from sod100k_amd import _native as N
     check_metrics(N.load(), torch.device("cuda", 0), salm_oracle)
+
+
+def test_val_mae_matches_training_caller(emu_lib):
+    """csn_val_mae (train.py:262-276: sigmoid -> bilinear to the picture's own size -> .int()/255 -> L1) against the
+    torch restatement, for up-, down- and same-size targets."""
+    import torch
+    from oracle import csnet_oracle as O
+    from sod100k_amd.engine import val_mae
+    g = torch.Generator().manual_seed(4)
+    logits = 3.0 * torch.randn(4, 1, 32, 48, generator=g)
+    targets = [(torch.rand(50, 70, generator=g) > 0.5).float(), (torch.rand(32, 48, generator=g) > 0.5).float(),
+               torch.rand(17, 23, generator=g), (torch.rand(96, 31, generator=g) > 0.3).float()]
+    total = torch.zeros(1, dtype=torch.float64)
+    for i, t in enumerate(targets):
+        val_mae(emu_lib, logits[i], t, out=total)
+    ref = O.val_mae(logits, targets)
+    assert abs(float(total) / 4 - ref) <= 2e-6, (float(total) / 4, ref)
+
+
+@pytest.mark.gpu
+def test_gpu_val_mae():
+    import torch
+    from oracle import csnet_oracle as O
+    from sod100k_amd import _native as N
+    from sod100k_amd.engine import val_mae
+    lib, dev = N.load(), torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    logits = 3.0 * torch.randn(3, 1, 224, 224, generator=g)
+    targets = [(torch.rand(300, 400, generator=g) > 0.5).float(), (torch.rand(224, 224, generator=g) > 0.5).float(),
+               torch.rand(120, 90, generator=g)]
+    total = torch.zeros(1, dtype=torch.float64, device=dev)
+    for i, t in enumerate(targets):
+        val_mae(lib, logits[i].to(dev), t.to(dev), out=total)
+    assert abs(float(total) / 3 - O.val_mae(logits, targets)) <= 2e-6
+
+
+def test_val_loop_of_the_training_caller(emu_lib, x2_manifest):
+    """sod100k_amd/tools/train.py:val (train.py:250-293) on the emulated kernels against the oracle's forward + val_mae."""
+    import torch
+    from oracle import csnet_oracle as O, inputs as I
+    from sod100k_amd.model import csnet as M
+    from sod100k_amd.tools import train as T
+    sd = O.load_weights(x2_manifest)
+    m = M.build_model(predefine=x2_manifest)
+    m.load_state_dict(sd)
+    m._lib = emu_lib
+    x = torch.from_numpy(I.randn_batch(12, 2, 64, 64))
+    g = torch.Generator().manual_seed(6)
+    targets = [(torch.rand(70, 50, generator=g) > 0.5).float(), (torch.rand(64, 64, generator=g) > 0.5).float()]
+    got = T.val(m, [(x, targets)], lib=emu_lib)
+    with torch.no_grad():
+        ref = O.val_mae(O.csnet_forward(O.load_layer_config_json(x2_manifest), sd, x), targets)
+    assert abs(got - ref) <= 1e-5, (got, ref)
