@@ -102,8 +102,6 @@ int csf_gemm(CsfWalk& W, const CsfGeom& G, int nsub, const CsfSubPlan* subs, int
     g.nstride = src[s].ctot * g.cstride;
     g.chunks = chunks;
     g.mode = src[s].mode;
-    g.ry = (float)g.Hs / (float)Ho;
-    g.rx = (float)g.Ws / (float)Wo;
     if (taps) {
       pj.a.seg[0] = CsfPrepSeg{chunks * CSF_KC, src[s].C, 0};
       Kp = 9 * chunks * CSF_KC;
@@ -205,22 +203,41 @@ int csf_walk(CsfWalk& W) {
   int64_t S[CSF_MAX_BRANCH], Z[CSF_MAX_BRANCH] = {0};
   CsfGeom Gs[CSF_MAX_BRANCH], Gz[CSF_MAX_BRANCH];
   for (int i = 0; i < nb; ++i) {
-    Gs[i] = csf_geom(1, &d.cmid[i], i + 1, d.cin, 0, B * HW[i], true);
+    const int segc[2] = {i >= 1 ? bi[i] : d.cin[0], d.cin[i]};
+    Gs[i] = csf_geom(1, &d.cmid[i], i >= 1 ? 2 : 1, segc, 0, B * HW[i], true);
     S[i] = W.ws_alloc((int64_t)Gs[i].ksplit * B * d.cmid[i] * HW[i] * 4);
   }
   for (int i = 1; i < nb; ++i) {
     Gz[i] = csf_geom(1, &bo[i], 1, &d.cin[i], 0, B * HW[i], true);
     Z[i] = W.ws_alloc((int64_t)Gz[i].ksplit * B * bo[i] * HW[i] * 4);
   }
-  for (int i = 0; i < nb; ++i) {
-    CsfSrc src[CSF_MAX_SEG];
-    int col0[CSF_MAX_SEG];
-    for (int k = 0; k <= i; ++k) {
-      src[k] = CsfSrc{feat(k), (int64_t)B * d.cin[k] * HW[k], d.cin[k], d.cin[k], H->h[k], H->w[k], k == i ? CSF_OWN : CSF_RESIZE};
-      col0[k] = bi[k];
+  // the finer branches i' < i enter branch i's contraction resized to its resolution (F.interpolate BEFORE the conv,
+  // gOctConv.py:99-101): done once per level into R[i] = [B][bi[i]][HW[i]] (the GEMM re-gathers its B operand per row
+  // tile and K slice -- 8 x 4 times for the coarsest level -- so resizing inside the gather cost 4 loads + a lerp each time)
+  int64_t R[CSF_MAX_BRANCH] = {0};
+  for (int i = 1; i < nb; ++i) R[i] = W.ws_alloc((int64_t)B * bi[i] * HW[i] * 4);
+  for (int i = 1; i < nb; ++i)
+    for (int k = 0; k < i; ++k) {
+      if (W.dry) continue;
+      CsfResizeArgs r{};
+      r.in = W.feats[k]; r.out = W.wsf(R[i]) + (int64_t)bi[k] * HW[i];
+      r.planes = B * d.cin[k]; r.cpi = d.cin[k]; r.out_nstride = (long long)bi[i] * HW[i];
+      r.Hi = H->h[k]; r.Wi = H->w[k]; r.Ho = H->h[i]; r.Wo = H->w[i];
+      r.ry = (float)r.Hi / (float)r.Ho;
+      r.rx = (float)r.Wi / (float)r.Wo;
+      LAUNCH_TRY(csf_launch_resize(r, W.stream));
     }
+  for (int i = 0; i < nb; ++i) {
+    CsfSrc src[2];
+    int col0[2], ns = 0;
+    if (i >= 1) {
+      src[ns] = CsfSrc{wsp(R[i]), (int64_t)B * bi[i] * HW[i], bi[i], bi[i], H->h[i], H->w[i], CSF_OWN};
+      col0[ns++] = 0;
+    }
+    src[ns] = CsfSrc{feat(i), (int64_t)B * d.cin[i] * HW[i], d.cin[i], d.cin[i], H->h[i], H->w[i], CSF_OWN};
+    col0[ns++] = bi[i];
     CsfSubPlan own{d.cmid[i], 1, d.fuse_w + (int64_t)bo[i] * Tin, wsp(S[i])};
-    CSF_TRY(csf_gemm(W, Gs[i], 1, &own, i + 1, src, 0, Tin, col0, d.cmid[i], H->h[i], H->w[i],
+    CSF_TRY(csf_gemm(W, Gs[i], 1, &own, ns, src, 0, Tin, col0, d.cmid[i], H->h[i], H->w[i],
                      (int64_t)B * d.cmid[i] * HW[i]));
     if (i >= 1) {
       CsfSrc me{feat(i), (int64_t)B * d.cin[i] * HW[i], d.cin[i], d.cin[i], H->h[i], H->w[i], CSF_OWN};
@@ -320,6 +337,7 @@ int csf_walk(CsfWalk& W) {
       LAUNCH_TRY(csf_launch_cls(c, W.stream));
       CsfResizeArgs r{};
       r.in = W.wsf(lo); r.out = W.logits; r.planes = B; r.Hi = H->h[0]; r.Wi = H->w[0]; r.Ho = H->oh; r.Wo = H->ow;
+      r.cpi = 1; r.out_nstride = (long long)r.Ho * r.Wo;
       r.ry = (float)r.Hi / (float)r.Ho;
       r.rx = (float)r.Wi / (float)r.Wo;
       LAUNCH_TRY(csf_launch_resize(r, W.stream));

@@ -12,7 +12,7 @@
 #define CSF_BP (CSF_BN + 16) // LDS pitch of a B row (pitch mod 32 == 16: the 4 k rows of one MFMA read hit distinct banks)
 #define CSF_MAX_SEG 4
 
-enum CsfSegMode { CSF_OWN = 0, CSF_RESIZE = 1 };
+enum CsfSegMode { CSF_OWN = 0 };   // every segment is read at the output resolution (resized inputs are materialised once)
 
 struct CsfSeg {
   const float* src;      // [B][ctot][Hs*Ws], already offset to the first channel of the slice
@@ -22,7 +22,6 @@ struct CsfSeg {
   int Hs, Ws;
   int chunks;            // channels / 16
   int mode;
-  float ry, rx;          // RESIZE: Hs/Ho, Ws/Wo as F.interpolate computes them (float(in) / out)
 };
 
 #define CSF_MAX_SUB 5
@@ -105,6 +104,8 @@ struct CsfResizeArgs {   // F.interpolate(size, bilinear, align_corners=False) o
   float* out;
   int planes, Hi, Wi, Ho, Wo;
   float ry, rx;
+  int cpi;                  // channels per image: plane = n * cpi + c ...
+  long long out_nstride;    // ... lands at out + n * out_nstride + c * Ho * Wo (channel slice of a wider tensor)
 };
 
 struct CsfPrepSeg { int k0, C, col0; };

@@ -7,8 +7,9 @@
 //                                     (k contiguous), stored k-major in LDS;
 //                           B chunk   lane = pixel; 16 channels of its pixel through a bounded buffer resource
 //                                     (per-lane byte offset in ONE VGPR, the channel rides in the scalar offset):
-//                                     own resolution / 3x3 tap (zero padding = out-of-range offset -> 0) one dword,
-//                                     bilinear resample of another level (gOctConv.py:99-101) four dwords + lerp;
+//                                     own resolution / 3x3 tap (zero padding = out-of-range offset -> 0), one dword
+//                                     per channel (inputs of another resolution are resized ONCE by csf_resize_kernel
+//                                     into a channel slice of the level's gather tensor, gOctConv.py:99-101);
 //                           both land in registers while the PREVIOUS chunk is being contracted (register prefetch,
 //                           two LDS buffers, one barrier per chunk);
 //                           contract  every wave owns (16 MT) x 64 outputs: per 4 k, MT A reads + 4 B reads feed
@@ -27,8 +28,7 @@
 
 // ---------------------------------------------------------------------------------------------------- GEMM
 struct CsfGather {       // per-lane addressing of the current (pseudo-)segment
-  unsigned o00, o01, o10, o11;   // byte offsets (RESIZE uses all four)
-  float ly, lx;
+  unsigned o00;          // byte offset of the lane's pixel (or tap) in channel 0 of the segment
 };
 
 __device__ __forceinline__ void csf_seg_setup(const CsfGemmArgs& a, int ps, int dil, int n, int oy, int ox,
@@ -44,18 +44,7 @@ __device__ __forceinline__ void csf_seg_setup(const CsfGemmArgs& a, int ps, int 
   }
   si = ps;
   const CsfSeg& s = a.seg[ps];
-  if (s.mode == CSF_OWN) {
-    g.o00 = (unsigned)(n * s.nstride + oy * s.Ws + ox) * 4u;
-  } else {
-    int y0, y1, x0, x1;
-    csn_bilin(oy, s.ry, s.Hs, y0, y1, g.ly);
-    csn_bilin(ox, s.rx, s.Ws, x0, x1, g.lx);
-    const unsigned b = (unsigned)(n * s.nstride);
-    g.o00 = (b + y0 * s.Ws + x0) * 4u;
-    g.o01 = (b + y0 * s.Ws + x1) * 4u;
-    g.o10 = (b + y1 * s.Ws + x0) * 4u;
-    g.o11 = (b + y1 * s.Ws + x1) * 4u;
-  }
+  g.o00 = (unsigned)(n * s.nstride + oy * s.Ws + ox) * 4u;
 }
 
 template <int MT>
@@ -121,19 +110,8 @@ __global__ __launch_bounds__(256) void csf_gemm_kernel(CsfGemmArgs a) {
     const CsfSeg& s = a.seg[si];
     const unsigned cb = (unsigned)(cc * CSF_KC) * (unsigned)s.cstride * 4u;
     const unsigned cs = (unsigned)s.cstride * 4u;
-    if (!a.taps && s.mode == CSF_RESIZE) {
-      const float wy0 = 1.f - g.ly, wx0 = 1.f - g.lx;
 #pragma unroll
-      for (int r = 0; r < CSF_KC; ++r) {
-        const unsigned so = cb + r * cs;
-        const float v00 = csn_ld1(buf, g.o00, so), v01 = csn_ld1(buf, g.o01, so);
-        const float v10 = csn_ld1(buf, g.o10, so), v11 = csn_ld1(buf, g.o11, so);
-        rb[r] = wy0 * (wx0 * v00 + g.lx * v01) + g.ly * (wx0 * v10 + g.lx * v11);
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < CSF_KC; ++r) rb[r] = csn_ld1(buf, g.o00, cb + r * cs);
-    }
+    for (int r = 0; r < CSF_KC; ++r) rb[r] = csn_ld1(buf, g.o00, cb + r * cs);
     // advance to the next chunk's (pseudo-)segment
     if (++cc == a.seg[si].chunks) {
       cc = 0;
@@ -434,8 +412,10 @@ __global__ __launch_bounds__(CSN_BLOCK) void csf_resize_kernel(CsfResizeArgs a) 
   const int y = (int)((i / a.Wo) % a.Ho);
   const long long plane = i / ((long long)a.Wo * a.Ho);
   const float* p = a.in + plane * a.Hi * a.Wi;
+  const long long n = plane / a.cpi, c = plane - n * a.cpi;
+  float* o = a.out + n * a.out_nstride + (c * a.Ho + y) * a.Wo + x;
   if (a.Hi == a.Ho && a.Wi == a.Wo) {   // F.interpolate copies when the size does not change
-    a.out[i] = p[y * a.Wi + x];
+    *o = p[y * a.Wi + x];
     return;
   }
   int y0, y1, x0, x1;
@@ -444,7 +424,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void csf_resize_kernel(CsfResizeArgs a) 
   csn_bilin(x, a.rx, a.Wi, x0, x1, lx);
   const float v0 = (1.f - lx) * p[y0 * a.Wi + x0] + lx * p[y0 * a.Wi + x1];
   const float v1 = (1.f - lx) * p[y1 * a.Wi + x0] + lx * p[y1 * a.Wi + x1];
-  a.out[i] = (1.f - ly) * v0 + ly * v1;
+  *o = (1.f - ly) * v0 + ly * v1;
 }
 
 int csf_launch_resize(const CsfResizeArgs& a, void* stream) {

@@ -96,9 +96,9 @@ def csf_summary(bench):
         return
     rows = [r for r in csv.DictReader(open(tr)) if short(r["Kernel_Name"]).startswith("csf_")]
     seqs, cur = [], []
-    for r in rows:
+    for r in rows:      # a forward ends with the resize that follows csf_cls_kernel (earlier resizes feed the fuse GEMMs)
         cur.append(r)
-        if short(r["Kernel_Name"]) == "csf_resize_kernel":
+        if short(r["Kernel_Name"]) == "csf_resize_kernel" and len(cur) > 1 and short(cur[-2]["Kernel_Name"]) == "csf_cls_kernel":
             seqs.append(cur)
             cur = []
     last = [r for r in seqs[-1] if short(r["Kernel_Name"]) != "csf_prep_kernel"]
@@ -112,7 +112,7 @@ def csf_summary(bench):
     pseq, cur = [], []
     for d in disp.values():
         cur.append(d)
-        if d["name"] == "csf_resize_kernel":
+        if d["name"] == "csf_resize_kernel" and len(cur) > 1 and cur[-2]["name"] == "csf_cls_kernel":
             pseq.append(cur)
             cur = []
     plast = pseq[-1] if pseq else []
