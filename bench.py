@@ -206,7 +206,8 @@ def main():
 
 def csf_point(dev, batch, steps):
     """BASELINE config 5: CSF+Res2Net-50 eval forward, batch x 3x352x352 fp32, random-init weights.  The decoder head
-    is the HIP implicit-GEMM path (include/csf_hip.h), the backbone is issued through PyTorch-ROCm / MIOpen."""
+    is the HIP implicit-GEMM path (include/csf_hip.h); the backbone's convolutions are issued through PyTorch-ROCm /
+    MIOpen, its BatchNorm + residual + ReLU passes through csf_bn_act."""
     import torch
     from sod100k_amd.networks import csf_res2net as R
     torch.cuda.empty_cache()

@@ -78,6 +78,15 @@ int csf_head_stage_info(const csf_head* head, int32_t stage, int32_t branch, int
 /* Multiply-accumulate work of one forward (2 flops each), for the matrix-core roofline of the GEMM kernel. */
 int64_t csf_head_macs(const csf_head* head);
 
+/* ---- eval BatchNorm (+ residual) (+ ReLU) of the backbone in ONE elementwise pass ------------------------------------
+ * The Res2Net bottlenecks (csf_res2net.py:69-103) follow every convolution with  relu(bn(.))  or
+ * relu(bn3(.) + residual); PyTorch issues BatchNorm, add and ReLU as separate kernels (2 + 3 + 2 trips over the tensor
+ * for the residual sites, 30 % of the backbone's time at batch 32).  In place on x = [batch][channels][hw]:
+ *     x = act((x - mean) / sqrt(var + eps) * gamma + beta (+ residual)),   act = max(., 0) when relu != 0
+ * gamma / beta / mean / var are nn.BatchNorm2d's parameters and running statistics (device pointers, [channels]). */
+int csf_bn_act(float* x, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+               const float* residual, int32_t batch, int32_t channels, int32_t hw, int32_t relu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

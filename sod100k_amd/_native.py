@@ -179,6 +179,9 @@ def bind(lib: C.CDLL) -> C.CDLL:
                                         C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.csf_head_macs.restype = C.c_int64
     lib.csf_head_macs.argtypes = [C.c_void_p]
+    lib.csf_bn_act.restype = C.c_int
+    lib.csf_bn_act.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                               C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     return lib
 
 
@@ -188,7 +191,7 @@ EXPORTS: Sequence[str] = (
     "csn_forward", "csn_forward_train", "csn_plan_enable_training", "csn_backward", "csn_bce_with_logits",
            "csn_adam_step", "csn_val_mae", "csn_saliency_u8", "csn_normalize_nchw", "csn_sal_hist", "csn_forward_profile", "csn_profile_num_kernels", "csn_profile_kernel", "csn_unit_kernel_name", "csn_unit_algorithmic_bytes",
     "csf_head_create", "csf_head_destroy", "csf_head_workspace_bytes", "csf_head_refresh_params", "csf_head_forward",
-    "csf_head_stage_info", "csf_head_macs")
+    "csf_head_stage_info", "csf_head_macs", "csf_bn_act")
 
 _lib: Optional[C.CDLL] = None
 

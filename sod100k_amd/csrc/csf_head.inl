@@ -446,4 +446,14 @@ int csf_head_stage_info(const csf_head* H, int32_t stage, int32_t branch, int64_
   return CSN_OK;
 }
 
+int csf_bn_act(float* x, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+               const float* residual, int32_t batch, int32_t channels, int32_t hw, int32_t relu, void* stream) {
+  if (!x || !gamma || !beta || !mean || !var || batch < 1 || channels < 1 || hw < 1) FAIL(CSN_E_INVALID, "csf_bn_act");
+  CsfBnActArgs a{};
+  a.x = x; a.res = residual; a.gamma = gamma; a.beta = beta; a.mean = mean; a.var = var; a.eps = eps;
+  a.C = channels; a.HW = hw; a.relu = relu;
+  LAUNCH_TRY(csf_launch_bn_act(a, batch * channels, stream));
+  return CSN_OK;
+}
+
 }  // extern "C"

@@ -119,6 +119,15 @@ struct CsfPrepArgs {     // weight image: dst[m][k] (zero padded) from arena row
   CsfPrepSeg seg[CSF_MAX_SEG];
 };
 
+struct CsfBnActArgs {    // x = act(x * scale[c] + shift[c] (+ res)), scale / shift folded from the BatchNorm tensors in the kernel
+  float* x;
+  const float* res;
+  const float* gamma; const float* beta; const float* mean; const float* var;
+  float eps;
+  int C, HW, relu;
+  int chunks;            // blocks per (image, channel) plane
+};
+int csf_launch_bn_act(const CsfBnActArgs& a, int planes, void* stream);
 int csf_launch_gemm(const CsfGemmArgs& a, int mt, void* stream);     // mt: 16-row tiles per block (2 or 4)
 int csf_launch_combine(const CsfCombArgs& a, void* stream);
 int csf_launch_gn_finalize(const CsfGnFinArgs& a, void* stream);

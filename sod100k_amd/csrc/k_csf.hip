@@ -367,6 +367,46 @@ int csf_launch_apply(const CsfApplyArgs& a, void* stream) {
   return (int)hipGetLastError();
 }
 
+// eval BatchNorm (+ residual) (+ ReLU) in place: one block per chunk of an (image, channel) plane, 128-bit accesses when
+// the plane size allows; every lane folds the channel's four BatchNorm scalars itself (cached, wave-uniform addresses)
+__global__ __launch_bounds__(CSN_BLOCK) void csf_bn_act_kernel(CsfBnActArgs a) {
+  const int plane = blockIdx.x / a.chunks, chunk = blockIdx.x - plane * a.chunks;
+  const int c = plane % a.C;
+  const float sc = a.gamma[c] / sqrtf(a.var[c] + a.eps);
+  const float sh = a.beta[c] - a.mean[c] * sc;
+  float* x = a.x + (long long)plane * a.HW;
+  const float* r = a.res ? a.res + (long long)plane * a.HW : nullptr;
+  if ((a.HW & 3) == 0) {
+    const int n4 = a.HW >> 2;
+    float4* x4 = reinterpret_cast<float4*>(x);
+    const float4* r4 = reinterpret_cast<const float4*>(r);
+    for (int i = chunk * CSN_BLOCK + threadIdx.x; i < n4; i += a.chunks * CSN_BLOCK) {
+      float4 v = x4[i];
+      v.x = fmaf(v.x, sc, sh); v.y = fmaf(v.y, sc, sh); v.z = fmaf(v.z, sc, sh); v.w = fmaf(v.w, sc, sh);
+      if (r) { const float4 q = r4[i]; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+      if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      x4[i] = v;
+    }
+  } else {
+    for (int i = chunk * CSN_BLOCK + threadIdx.x; i < a.HW; i += a.chunks * CSN_BLOCK) {
+      float v = fmaf(x[i], sc, sh);
+      if (r) v += r[i];
+      x[i] = a.relu ? fmaxf(v, 0.f) : v;
+    }
+  }
+}
+
+int csf_launch_bn_act(const CsfBnActArgs& a0, int planes, void* stream) {
+  CsfBnActArgs a = a0;
+  const int per = (a.HW & 3) == 0 ? a.HW >> 2 : a.HW;             // work items of a plane
+  a.chunks = (per + 4 * CSN_BLOCK - 1) / (4 * CSN_BLOCK);          // ~4 items per lane
+  if (a.chunks < 1) a.chunks = 1;
+  const long long nblk = (long long)planes * a.chunks;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return -1;
+  CSN_LAUNCH(csf_bn_act_kernel, dim3((unsigned)nblk), dim3(CSN_BLOCK), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
 // lane = pixel (coalesced channel planes), four independent accumulators over the channels
 __global__ __launch_bounds__(CSN_BLOCK) void csf_cls_kernel(CsfClsArgs a) {
   const long long i = (long long)blockIdx.x * CSN_BLOCK + threadIdx.x;

@@ -8,7 +8,8 @@ Split of the work:
     and the final resize (csf_res2net.py:240-255), 16.2 of 38.4 GFLOP per 352 x 352 image -- runs in libcsnet_hip.so
     (include/csf_hip.h: implicit-GEMM MFMA kernel + fused combine/GroupNorm passes);
   * the backbone's plain convolutions (csf_res2net.py:26-169) are issued through PyTorch-ROCm (MIOpen), exactly the
-    "backbone can stay on MIOpen" boundary of SURVEY 8 f-1.  ``Res2Net`` below is an ordinary ``nn.Module``.
+    "backbone can stay on MIOpen" boundary of SURVEY 8 f-1.  ``Res2Net`` below is an ordinary ``nn.Module``; in eval mode
+    on the device every BatchNorm (+ residual) + ReLU that follows a convolution is one in-place launch of ``csf_bn_act``.
 There is no CPU path for the head: without the HIP library ``CSFNet.forward`` raises.
 """
 import ctypes as C
@@ -29,6 +30,31 @@ def _frozen_bn(c):
     for p in bn.parameters():                 # csf_res2net.py:48-49,63-68: backbone BN affine parameters are frozen
         p.requires_grad = False
     return bn
+
+
+def _bn_act(owner, bn, y, residual=None, relu=True):
+    """Eval BatchNorm (+ residual) (+ ReLU) after a backbone convolution.  On a ROCm device (or with the emulated library
+    injected through ``owner._lib`` by a test) this is ONE in-place launch of ``csf_bn_act`` (include/csf_hip.h) instead
+    of PyTorch's separate BatchNorm / add / ReLU kernels; training / autograd / CPU tensors take the plain modules."""
+    lib = getattr(owner, "_lib", None)
+    fused = (y.is_cuda or lib is not None) and not bn.training and not torch.is_grad_enabled() and y.dtype == torch.float32
+    if not fused:
+        y = bn(y)
+        if residual is not None:
+            y = y + residual
+        return torch.relu_(y) if relu else y
+    if lib is None:
+        lib = N.load()
+    y = y.contiguous()
+    if residual is not None:
+        residual = residual.contiguous()
+        assert residual.shape == y.shape
+    b, c, h, w = y.shape
+    stream = torch.cuda.current_stream(y.device).cuda_stream if y.is_cuda else 0
+    N.check(lib, lib.csf_bn_act(y.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                                bn.running_var.data_ptr(), bn.eps, residual.data_ptr() if residual is not None else None,
+                                b, c, h * w, 1 if relu else 0, stream), "csf_bn_act")
+    return y
 
 
 class Bottle2neck(nn.Module):
@@ -53,17 +79,19 @@ class Bottle2neck(nn.Module):
         self.stype, self.scale, self.width = stype, scale, width
 
     def forward(self, x):
-        chunks = torch.split(self.relu(self.bn1(self.conv1(x))), self.width, 1)
+        chunks = torch.split(_bn_act(self, self.bn1, self.conv1(x)), self.width, 1)
         pieces, carry = [], None
         for i in range(self.nums):
             carry = chunks[i] if (i == 0 or self.stype == 'stage') else carry + chunks[i]
-            carry = self.relu(self.bns[i](self.convs[i](carry)))
+            carry = _bn_act(self, self.bns[i], self.convs[i](carry))
             pieces.append(carry)
         if self.scale != 1:
             pieces.append(self.pool(chunks[self.nums]) if self.stype == 'stage' else chunks[self.nums])
-        out = self.bn3(self.conv3(torch.cat(pieces, 1)))
-        shortcut = x if self.downsample is None else self.downsample(x)
-        return self.relu(out + shortcut)
+        if self.downsample is None:
+            shortcut = x
+        else:       # AvgPool2d -> conv1x1 -> BatchNorm (csf_res2net.py:136-144)
+            shortcut = _bn_act(self, self.downsample[2], self.downsample[1](self.downsample[0](x)), relu=False)
+        return _bn_act(self, self.bn3, self.conv3(torch.cat(pieces, 1)), residual=shortcut)
 
 
 class Res2Net(nn.Module):
@@ -112,7 +140,10 @@ class Res2Net(nn.Module):
         return nn.Sequential(*seq)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        stem = self.conv1
+        x = _bn_act(self, stem[1], stem[0](x))
+        x = _bn_act(self, stem[4], stem[3](x))
+        x = self.maxpool(_bn_act(self, self.bn1, stem[6](x)))
         feats = []
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             x = layer(x)

@@ -87,3 +87,20 @@ def test_head_abi_error_paths(emu_lib):
         assert emu_lib.csf_head_macs(head) > 0
     finally:
         emu_lib.csf_head_destroy(head)
+
+
+def test_backbone_bn_act_kernel(emu_lib):
+    """csf_bn_act (eval BatchNorm + residual + ReLU in one in-place pass) inside the Res2Net backbone: the emulated
+    kernel against the plain torch modules, plane sizes with and without the 128-bit path."""
+    from sod100k_amd.networks import csf_res2net as R
+    net, sd = K.build_csfnet("cpu", None)
+    base = net.base
+    x = torch.from_numpy(__import__("oracle.inputs", fromlist=["x"]).randn_batch(83, 2, 40, 36))     # 10x9, 5x5, 3x3, 2x2 maps
+    with torch.no_grad():
+        ref = CO.res2net_forward(sd, x)
+        for m in base.modules():
+            if isinstance(m, (R.Bottle2neck, R.Res2Net)):
+                object.__setattr__(m, "_lib", emu_lib)
+        got = base(x)
+    for a, b in zip(got, ref):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
