@@ -94,7 +94,8 @@ def csf_summary(bench):
     tr = os.path.join(SRC, "csf_trace", "trace_kernel_trace.csv")
     if not os.path.exists(tr) or "csf_res2net" not in bench:
         return
-    rows = [r for r in csv.DictReader(open(tr)) if short(r["Kernel_Name"]).startswith("csf_")]
+    rows = [r for r in csv.DictReader(open(tr)) if short(r["Kernel_Name"]).startswith("csf_")
+            and short(r["Kernel_Name"]) != "csf_bn_act_kernel"]          # the backbone's pass, not part of the head
     seqs, cur = [], []
     for r in rows:      # a forward ends with the resize that follows csf_cls_kernel (earlier resizes feed the fuse GEMMs)
         cur.append(r)
@@ -106,7 +107,7 @@ def csf_summary(bench):
     disp = collections.OrderedDict()
     for r in pmc_rows:
         n = short(r["Kernel_Name"])
-        if not n.startswith("csf_") or n == "csf_prep_kernel":
+        if not n.startswith("csf_") or n in ("csf_prep_kernel", "csf_bn_act_kernel"):
             continue
         disp.setdefault(r["Dispatch_Id"], dict(name=n))[r["Counter_Name"]] = float(r["Counter_Value"])
     pseq, cur = [], []
