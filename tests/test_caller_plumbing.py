@@ -59,3 +59,35 @@ def test_inference_caller_writes_the_oracles_maps(emu_lib, tmp_path, monkeypatch
             ref = O.caller_postprocess(O.csnet_forward(lc, sd, x))
         assert got.shape == ref.shape and got.dtype == np.uint8
         assert np.abs(got.astype(int) - ref.astype(int)).max() <= 1 and (got != ref).mean() < 5e-3
+
+
+def test_csf_res2net_caller_writes_the_oracles_maps(emu_lib, tmp_path):
+    """Solver.test counterpart (sod100k_amd/tools/csf_test.py) end to end on CPU: pictures of their own (non-octave)
+    size, backbone through torch, decoder head through the emulated kernels; the PNGs equal the oracle's maps."""
+    from PIL import Image
+    from oracle import csf_oracle as CO
+    from sod100k_amd.networks import csf_res2net as R
+    from sod100k_amd.tools import csf_test as T
+
+    rng = np.random.default_rng(1)
+    root = tmp_path / "imgs"
+    root.mkdir()
+    sizes = {"p.jpg.png": (44, 60), "q.png": (37, 52)}
+    for name, (h, w) in sizes.items():
+        Image.fromarray((rng.random((h, w, 3)) * 255).astype(np.uint8)).save(root / name)
+    sd = CO.synthetic_state()
+    net = R.build_model()
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    object.__setattr__(net, "_lib", emu_lib)
+    T.test(net, list(sizes), str(root), str(tmp_path / "out"), device="cpu", lib=emu_lib)
+    mean, std = np.array([0.485, 0.456, 0.406], np.float32), np.array([0.229, 0.224, 0.225], np.float32)
+    for name in sizes:
+        im = np.asarray(Image.open(root / name).convert("RGB"), dtype=np.float32) / 255.0
+        x = torch.from_numpy(np.transpose((im - mean) / std, (2, 0, 1))[None])
+        with torch.no_grad():
+            ref = torch.sigmoid(CO.csfnet_forward(sd, x)).squeeze().numpy()
+        got = np.asarray(Image.open(tmp_path / "out" / (name[:-4] + "_sal_fuse.png")))
+        exp = np.clip(np.rint(255.0 * ref), 0, 255).astype(np.uint8)
+        assert got.shape == exp.shape and np.abs(got.astype(int) - exp.astype(int)).max() <= 1
+        assert (got != exp).mean() <= 0.01
