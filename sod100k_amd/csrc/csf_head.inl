@@ -19,6 +19,8 @@ struct csf_head {
   int z_lds_max = 12 * 1024;             // floats; CSF_Z_LDS_MAX overrides (tests force the global-memory tap path)
   std::vector<CsfPrepJob> prep;
   std::vector<CsfCopyJob> copies;
+  CsfPrepJobDev* jobs_dev = nullptr;     // prep + copies as one device-resident table (one launch per refresh)
+  int njobs = 0, job_blocks = 0;
   struct Stage { int64_t off; int C, H, W; } stage[3][CSF_MAX_BRANCH];
 };
 
@@ -389,6 +391,30 @@ int csf_head_create(const csf_head_desc* desc, int32_t batch, const int32_t* h, 
   H->macs = W.macs;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&H->packed), (size_t)H->packed_floats * sizeof(float));
   if (e != hipSuccess) { delete H; return hip_fail(e, "hipMalloc(weight images)"); }
+  // the refresh job table (weight images first, then the small parameter vectors as one-row images)
+  std::vector<CsfPrepJobDev> jobs;
+  auto push = [&](const CsfPrepArgs& a, int64_t src_off, int64_t dst_off) {
+    CsfPrepJobDev j{};
+    j.src_off = src_off; j.dst_off = dst_off;
+    j.M = a.M; j.Mp = a.Mp; j.Kp = a.Kp; j.ld = a.ld; j.taps = a.taps; j.nseg = a.nseg;
+    for (int s = 0; s < CSF_MAX_SEG; ++s) j.seg[s] = a.seg[s];
+    const int64_t n = (int64_t)a.Mp * a.Kp;
+    j.nblk = (int)std::max<int64_t>(1, std::min<int64_t>(64, (n + 8 * CSN_BLOCK - 1) / (8 * CSN_BLOCK)));
+    j.blk0 = H->job_blocks;
+    H->job_blocks += j.nblk;
+    jobs.push_back(j);
+  };
+  for (const CsfPrepJob& j : H->prep) push(j.a, j.src_off, j.dst_off);
+  for (const CsfCopyJob& c : H->copies) {
+    CsfPrepArgs a{};
+    a.M = 1; a.Mp = 1; a.Kp = c.n; a.ld = c.n; a.taps = 0; a.nseg = 1;
+    a.seg[0] = CsfPrepSeg{0, c.n, 0};
+    push(a, c.src, c.dst);
+  }
+  H->njobs = (int)jobs.size();
+  e = hipMalloc(reinterpret_cast<void**>(&H->jobs_dev), jobs.size() * sizeof(CsfPrepJobDev));
+  if (e == hipSuccess) e = hipMemcpy(H->jobs_dev, jobs.data(), jobs.size() * sizeof(CsfPrepJobDev), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { csf_head_destroy(H); return hip_fail(e, "refresh job table"); }
   *out = H;
   return CSN_OK;
 }
@@ -396,6 +422,7 @@ int csf_head_create(const csf_head_desc* desc, int32_t batch, const int32_t* h, 
 void csf_head_destroy(csf_head* H) {
   if (!H) return;
   if (H->packed) (void)hipFree(H->packed);
+  if (H->jobs_dev) (void)hipFree(H->jobs_dev);
   delete H;
 }
 
@@ -404,18 +431,11 @@ int64_t csf_head_macs(const csf_head* H) { return H ? H->macs : 0; }
 
 int csf_head_refresh_params(csf_head* H, const float* arena, int64_t arena_floats, void* stream) {
   if (!H || !arena) FAIL(CSN_E_INVALID, "null argument");
-  for (const CsfPrepJob& j : H->prep) {
+  for (const CsfPrepJob& j : H->prep)
     if (j.src_off < 0 || j.src_off + (int64_t)j.a.M * j.a.ld > arena_floats) FAIL(CSN_E_INVALID, "weight offset outside the arena");
-    CsfPrepArgs a = j.a;
-    a.src = arena + j.src_off;
-    a.dst = H->packed + j.dst_off;
-    LAUNCH_TRY(csf_launch_prep(a, stream));
-  }
-  for (const CsfCopyJob& c : H->copies) {
+  for (const CsfCopyJob& c : H->copies)
     if (c.src < 0 || c.src + c.n > arena_floats) FAIL(CSN_E_INVALID, "parameter offset outside the arena");
-    HIP_TRY(hipMemcpyAsync(H->packed + c.dst, arena + c.src, (size_t)c.n * sizeof(float), hipMemcpyDeviceToDevice,
-                           (hipStream_t)stream));
-  }
+  LAUNCH_TRY(csf_launch_prep_all(H->jobs_dev, H->njobs, H->job_blocks, arena, H->packed, stream));
   H->refreshed = true;
   return CSN_OK;
 }

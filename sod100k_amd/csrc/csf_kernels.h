@@ -134,4 +134,11 @@ int csf_launch_gn_finalize(const CsfGnFinArgs& a, void* stream);
 int csf_launch_apply(const CsfApplyArgs& a, void* stream);
 int csf_launch_cls(const CsfClsArgs& a, void* stream);
 int csf_launch_resize(const CsfResizeArgs& a, void* stream);
-int csf_launch_prep(const CsfPrepArgs& a, void* stream);
+struct CsfPrepJobDev {   // device-resident job table: every weight image and parameter vector of a head in ONE launch
+  long long src_off, dst_off;   // floats into the caller's arena / the library's packed buffer
+  int M, Mp, Kp, ld, taps, nseg;
+  CsfPrepSeg seg[CSF_MAX_SEG];
+  int blk0, nblk;               // blocks [blk0, blk0 + nblk) of the launch belong to this job
+};
+int csf_launch_prep_all(const CsfPrepJobDev* jobs_dev, int njobs, int total_blocks, const float* arena, float* packed,
+                        void* stream);

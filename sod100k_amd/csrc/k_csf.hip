@@ -476,31 +476,36 @@ int csf_launch_resize(const CsfResizeArgs& a, void* stream) {
 }
 
 // ---------------------------------------------------------------------------------------------- weight images
-__global__ __launch_bounds__(CSN_BLOCK) void csf_prep_kernel(CsfPrepArgs a) {
-  const long long total = (long long)a.Mp * a.Kp;
-  for (long long i = (long long)blockIdx.x * CSN_BLOCK + threadIdx.x; i < total; i += (long long)gridDim.x * CSN_BLOCK) {
-    const int m = (int)(i / a.Kp), k = (int)(i - (long long)m * a.Kp);
+__global__ __launch_bounds__(CSN_BLOCK) void csf_prep_kernel(const CsfPrepJobDev* __restrict__ jobs, int njobs,
+                                                              const float* __restrict__ arena, float* __restrict__ packed) {
+  int j = 0;
+  while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].blk0) ++j;
+  const CsfPrepJobDev* __restrict__ a = jobs + j;   // read in place: a by-value copy with dynamic seg[] indexing goes to scratch
+  const float* src = arena + a->src_off;
+  float* dst = packed + a->dst_off;
+  const long long total = (long long)a->Mp * a->Kp;
+  for (long long i = (long long)(blockIdx.x - a->blk0) * CSN_BLOCK + threadIdx.x; i < total; i += (long long)a->nblk * CSN_BLOCK) {
+    const int m = (int)(i / a->Kp), k = (int)(i - (long long)m * a->Kp);
     float v = 0.f;
-    if (m < a.M) {
-      if (a.taps) {
-        const int Cp = a.seg[0].k0;            // taps: k = tap * Cp + c (Cp = channels padded to the K chunk)
+    if (m < a->M) {
+      if (a->taps) {
+        const int Cp = a->seg[0].k0;            // taps: k = tap * Cp + c (Cp = channels padded to the K chunk)
         const int tap = k / Cp, c = k - tap * Cp;
-        if (tap < 9 && c < a.seg[0].C) v = a.src[(long long)m * a.ld + (long long)c * 9 + tap];
+        if (tap < 9 && c < a->seg[0].C) v = src[(long long)m * a->ld + (long long)c * 9 + tap];
       } else {
-        for (int s = 0; s < a.nseg; ++s) {
-          const int kk = k - a.seg[s].k0;
-          if (kk >= 0 && kk < a.seg[s].C) v = a.src[(long long)m * a.ld + a.seg[s].col0 + kk];
+        for (int s = 0; s < a->nseg; ++s) {
+          const int kk = k - a->seg[s].k0;
+          if (kk >= 0 && kk < a->seg[s].C) v = src[(long long)m * a->ld + a->seg[s].col0 + kk];
         }
       }
     }
-    a.dst[i] = v;
+    dst[i] = v;
   }
 }
 
-int csf_launch_prep(const CsfPrepArgs& a, void* stream) {
-  long long nblk = ((long long)a.Mp * a.Kp + CSN_BLOCK - 1) / CSN_BLOCK;
-  if (nblk > 8192) nblk = 8192;
-  if (nblk <= 0) return 0;
-  CSN_LAUNCH(csf_prep_kernel, dim3((unsigned)nblk), dim3(CSN_BLOCK), 0, stream, a);
+int csf_launch_prep_all(const CsfPrepJobDev* jobs_dev, int njobs, int total_blocks, const float* arena, float* packed,
+                        void* stream) {
+  if (njobs <= 0 || total_blocks <= 0) return 0;
+  CSN_LAUNCH(csf_prep_kernel, dim3((unsigned)total_blocks), dim3(CSN_BLOCK), 0, stream, jobs_dev, njobs, arena, packed);
   return (int)hipGetLastError();
 }
