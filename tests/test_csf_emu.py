@@ -104,3 +104,46 @@ def test_backbone_bn_act_kernel(emu_lib):
         got = base(x)
     for a, b in zip(got, ref):
         assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
+
+
+def test_head_with_channel_counts_off_the_tile_sizes(emu_lib):
+    """The C ABI is descriptor driven: a narrower head whose channel counts are NOT multiples of the 16-channel K chunk
+    (24 / 40 / 72 / 136 in) nor of the 32 / 64-row tiles (dilation groups of 6 / 12 / 19 rows), against the oracle."""
+    import ctypes as C
+    from sod100k_amd import _native as N
+    from sod100k_amd.networks.csf_res2net import _HeadEngine
+    cin, cmid = (24, 40, 72, 136), (32, 64, 96, 96)
+    sd = CO.synthetic_state(backbone=False, cin=cin, cmid=cmid)
+    offs, chunks, top = {}, [], 0
+    for k, v in sd.items():
+        offs[k] = top
+        chunks.append(v.reshape(-1).float())
+        top += v.numel()
+        pad = (-top) % 4
+        if pad:
+            chunks.append(torch.zeros(pad)); top += pad
+    flat = torch.cat(chunks)
+    d = N.CsfHeadDesc()
+    d.n_branch, d.gn_groups = 4, 32
+    d.fuse_w, d.fuse1_w = offs["fuse.conv.weights"], offs["fuse1x1.conv.weights"]
+    for j in range(4):
+        d.cin[j], d.cmid[j] = cin[j], cmid[j]
+        d.fuse_gn[j] = N.CsfGnOff(offs[f"fuse.bns.{j}.weight"], offs[f"fuse.bns.{j}.bias"], offs[f"fuse.prelus.{j}.weight"])
+        d.ms_gn[j] = N.CsfGnOff(offs[f"ms.convs.{j}.bn.weight"], offs[f"ms.convs.{j}.bn.bias"], offs[f"ms.convs.{j}.prelu.weight"])
+        for k, co in enumerate(CO.ms_split(cmid[j])):
+            d.ms_split[j][k] = co
+            d.ms_w[j][k] = offs[f"ms.convs.{j}.msconv.{k}.weight"]
+    d.fuse1_gn = N.CsfGnOff(offs["fuse1x1.bns.0.weight"], offs["fuse1x1.bns.0.bias"], offs["fuse1x1.prelus.0.weight"])
+    d.cls_w, d.cls_b = offs["cls_layer.weight"], offs["cls_layer.bias"]
+    sizes, out_size, batch = ((11, 9), (6, 5), (3, 3), (2, 2)), (44, 36), 2
+    eng = _HeadEngine(emu_lib, d, batch, sizes, out_size, torch.device("cpu"))
+    eng.refresh(flat)
+    feats = CO.synthetic_features(11, batch, sizes, cin=cin)
+    y = eng.forward(feats)
+    probes = {}
+    with torch.no_grad():
+        ref = CO.head_forward(sd, feats, out_size, cin=cin, cmid=cmid, probes=probes)
+    for st, name in ((0, "fuse"), (1, "ms")):
+        for j, t in enumerate(probes[name]):
+            assert (eng.stage(st, j) - t).abs().max().item() <= 2e-4, (name, j)
+    assert (y - ref).abs().max().item() <= 1e-4
