@@ -97,3 +97,36 @@ def test_finetune_caller_end_to_end(emu_lib, tmp_path, monkeypatch):
     out = torch.load(os.path.join(str(tmp_path), "toy", "finetune_checkpoint", "checkpoint_epoch1.pth.tar"))
     assert out['epoch'] == 1 and list(out['state_dict'].keys()) == list(slim.state_dict().keys())
     assert os.path.isfile(os.path.join(lc_dir, "layer_config_finetune_7.bin"))
+
+
+import pytest
+
+
+@pytest.mark.parametrize("seed,kill", [(0, 0.35), (21, 0.7), (33, 0.9)])
+def test_randomly_pruned_networks_through_the_kernels(emu_lib, tmp_path, seed, kill):
+    """Planner robustness: prune a random 35 / 70 / 90 % of every BatchNorm's channels of the un-pruned expand-1 network with
+    the real surgery (odd channel counts, single channels, empty branches), then eval forward on the emulated kernels
+    against the oracle."""
+    import contextlib
+    import io
+    from oracle import inputs as I
+    from test_unpruned_emu import _random_state
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = M.build_model(basic_split=[0.5, 0.5], expand=1.0, save_path=str(tmp_path))
+    sd = _random_state(m, seed)
+    g = torch.Generator().manual_seed(1000 + seed)
+    for k in sd:
+        if ('.bns.' in k or '.bn.' in k) and k.endswith('weight'):
+            dead = torch.rand(sd[k].shape, generator=g) < kill
+            sd[k] = torch.where(dead, torch.full_like(sd[k], 1e-6), sd[k])
+    m.load_state_dict(sd)
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfg, mask = M.finetune_model(m, save_path=str(tmp_path), base_layer_config=O.init_layers(20, [0.5, 0.5]), thres=1e-3)
+        slim = M.build_model_with_weight(cfg, m, mask).eval()
+    slim._lib = emu_lib
+    x = torch.from_numpy(I.randn_batch(seed, 2, 32, 32))
+    ssd = {k: v.clone() for k, v in slim.state_dict().items()}
+    with torch.no_grad():
+        ref = O.csnet_forward(cfg, ssd, x)
+    y = slim(x)
+    assert (y - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
