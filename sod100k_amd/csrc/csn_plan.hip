@@ -283,6 +283,12 @@ void add_launch(std::vector<PwLaunchPlan>& dst, PwLaunchPlan L) {
       push_row_chunks(dst, one);
     }
   } else {
+    // a launch left with ONE pass of a lower branch (the finer output branches were pruned to zero channels): re-base it
+    // on its own resolution like the split launches above (goct_c3_kernel walks the launch resolution)
+    if (L.passes.size() == 1 && L.passes[0].r > 0) {
+      L.lvl += L.passes[0].r;
+      L.passes[0].r = 0;
+    }
     push_row_chunks(dst, L);
   }
 }

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_c3_kernel(PwArgs a_byval) {
 
 // true when the launch is one pass made of 3x3 tap slices (dilation 1) plus at most one trailing non-tap slice
 bool csn_c3_eligible(const PwArgs& a) {
-  if (a.npass != 1 || a.pass[0].red_w) return false;
+  if (a.npass != 1 || a.pass[0].red_w || a.pass[0].r != 0) return false;   // the kernel walks the launch resolution
   const PwPass& ps = a.pass[0];
   int ntap = 0;
   bool tail = false;

@@ -122,7 +122,14 @@ static void run_block(dim3 grid, dim3 block, unsigned bx, unsigned by, unsigned 
     pool.fibers.resize(n);
     pool.stacks.resize((size_t)n * kStack);
   }
-  if (pool.smem.size() < smem_bytes + 64) pool.smem.resize(smem_bytes + 64);
+  // CSN_EMU_STRICT_LDS=1: a fresh, exactly sized allocation per block, so that an address sanitizer build
+  // (make ASAN=1) flags any access past the launch's dynamic LDS size instead of reading the pool's stale bytes
+  static const bool strict_lds = std::getenv("CSN_EMU_STRICT_LDS") != nullptr;
+  if (strict_lds) {
+    std::vector<unsigned char>(smem_bytes + 16).swap(pool.smem);
+  } else if (pool.smem.size() < smem_bytes + 64) {
+    pool.smem.resize(smem_bytes + 64);
+  }
   // 16-byte aligned dynamic LDS base; poison so that reads of unwritten LDS show up
   unsigned char* sm = pool.smem.data();
   sm += (16 - ((uintptr_t)sm & 15)) & 15;
@@ -132,9 +139,13 @@ static void run_block(dim3 grid, dim3 block, unsigned bx, unsigned by, unsigned 
   g.bDim = block;
   g.gDim = grid;
   pool.body = &body;
+  // CSN_EMU_POISON_STACK=1: fill the part of every fiber stack a kernel frame lives in with 0xFF so that reads of
+  // uninitialised locals (undefined on the GPU as well) show up as NaNs / huge integers instead of stale finite data
+  static const bool poison_stack = std::getenv("CSN_EMU_POISON_STACK") != nullptr;
   for (unsigned t = 0; t < n; ++t) {
     Fiber& f = pool.fibers[t];
     f.done = false;
+    if (poison_stack) std::memset(pool.stacks.data() + (size_t)(t + 1) * kStack - 48 * 1024, 0xFF, 48 * 1024 - 256);
     getcontext(&f.ctx);
     f.ctx.uc_stack.ss_sp = pool.stacks.data() + (size_t)t * kStack;
     f.ctx.uc_stack.ss_size = kStack;
