@@ -366,7 +366,8 @@ def train_step(layer_config, sd, x, target, *, expandflop=1.0, flops_weight=3.0,
         pen = gap_penalty(sd, taps, flop_weights(layer_config, expandflop), batchsize)
         loss = loss + flops_weight * pen
     loss.backward()
-    grads = {k: sd[k].grad.detach().clone() for k in pnames}
+    # a parameter without a path to the loss (an output branch nobody consumes in a pruned net) has grad None in autograd
+    grads = {k: (sd[k].grad.detach().clone() if sd[k].grad is not None else torch.zeros_like(sd[k])) for k in pnames}
     normal, picked = param_groups(pnames)
     if adam_state is None:
         adam_state = {}

@@ -531,8 +531,12 @@ int csn_plan_enable_training(csn_plan* P) {
     if (u.d.kind == CSN_UNIT_CLS) continue;
     for (int j = 0; j < u.d.n_out; ++j)
       if (u.d.cout[j] > 0 && P->n_cons[u.d.out_act[j]] == 0) {
-        g_hip_err = "unit " + std::to_string(k) + ": an output branch without consumer has no gradient";
-        return CSN_E_UNSUPPORTED;
+        // an output nobody reads (e.g. a CSFHead.fuse branch whose MSBlock was pruned away): its gradient is zero, as
+        // autograd would have it -- one zero-filled gradient buffer, cleared at the start of every backward
+        const int a = u.d.out_act[j];
+        P->n_cons[a] = 1;
+        P->tg_off[a][0] = bl.alloc_ws(bl.act_bytes(P->acts[a].channels, P->acts[a].lvl));
+        P->orphan_acts.push_back(a);
       }
   }
   P->red_off = bl.alloc_ws((int64_t)maxc * CSN_BN_NSLAB * 9 * sizeof(double));
@@ -595,6 +599,9 @@ int csn_backward(csn_plan* P, const float* x, const float* dy, void* workspace, 
     Ctx c{*P, x, nullptr, static_cast<char*>(workspace), s};
     c.raw = true;
     const BwdCtx b{c, arena, grad, flop_w, pen_scale};
+    for (int a : P->orphan_acts)
+      HIP_TRY(hipMemsetAsync(c.ws + P->tg_off[a][0], 0, (size_t)P->S * P->acts[a].channels * (P->H >> P->acts[a].lvl) *
+                                                           (P->W >> P->acts[a].lvl) * sizeof(float), (hipStream_t)s));
     for (int u = (int)P->units.size() - 1; u >= 0; --u) {
       const int st = run_unit_bwd(b, u, dy);
       if (st != CSN_OK) return st;

@@ -164,6 +164,7 @@ struct csn_plan {
   std::vector<int64_t> tz_off;                  // per act: raw conv output z, later dz (workspace bytes)
   std::vector<std::array<int64_t, 2>> tg_off;   // per act: gradient buffer per consumer
   std::vector<int> n_cons;
+  std::vector<int> orphan_acts;          // outputs without consumer: zero gradient (training)
   int64_t scratch_off = 0, scratch_bytes = 0;   // per-unit backward temporaries (shared by all units)
   int64_t red_off = 0;                          // fp64 partials of the BN / depthwise reductions
   int64_t wg_off = 0;                           // partial dW slices (k_wgrad.hip)

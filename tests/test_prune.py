@@ -170,3 +170,48 @@ def test_train_forward_when_the_top_branch_is_pruned_away(emu_lib, tmp_path):
     for k, v in ssd.items():
         if k.endswith("running_mean") or k.endswith("running_var"):
             assert ((got[k] - v).abs() / (1.0 + v.abs())).max().item() <= 1e-5, k
+
+
+def test_train_step_with_an_output_branch_nobody_consumes(emu_lib, tmp_path):
+    """85 % pruning (seed 41) removes a whole MSBlock, so one output branch of CSFHead.fuse has no consumer: autograd gives its
+    parameters no gradient; the plan gives the branch a zero gradient (it used to refuse the configuration).  All
+    gradients against the fp64 oracle, in units of the largest gradient norm."""
+    import contextlib
+    import io
+    import parity_cases as P
+    from oracle import inputs as I
+    from test_unpruned_emu import _random_state
+    seed, kill = 41, 0.85
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = M.build_model(basic_split=[0.5, 0.5], expand=1.0, save_path=str(tmp_path))
+    sd = _random_state(m, seed)
+    g = torch.Generator().manual_seed(1000 + seed)
+    for k in sd:
+        if ('.bns.' in k or '.bn.' in k) and k.endswith('weight'):
+            dead = torch.rand(sd[k].shape, generator=g) < kill
+            sd[k] = torch.where(dead, torch.full_like(sd[k], 1e-6), sd[k])
+    m.load_state_dict(sd)
+    with contextlib.redirect_stdout(io.StringIO()):
+        cfg, mask = M.finetune_model(m, save_path=str(tmp_path), base_layer_config=O.init_layers(20, [0.5, 0.5]), thres=1e-3)
+        slim = M.build_model_with_weight(cfg, m, mask)
+    assert any(c is None for c in slim.oct_fuse.ms.convs)          # a pruned-away MSBlock
+    slim._lib = emu_lib
+    x = torch.from_numpy(I.randn_batch(seed, 2, 32, 32))
+    t = torch.from_numpy(I.binary_target(seed + 1, 2, 32, 32))
+    ssd = {k: v.clone() for k, v in slim.state_dict().items()}
+    slim.train(); slim.set_batchsize(2); slim.clear_flops(); slim.flops_hook(1.0)
+    yt, pen = slim._train_forward_raw(x)
+    loss, dy = P.bce_and_grad(emu_lib, yt, t)
+    flat = slim._train_backward_raw(x, dy, 3.0 / 2)
+    r64 = O.train_step(cfg, {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in ssd.items()}, x.double(),
+                       t.double(), expandflop=1.0, flops_weight=3.0, batchsize=2, lr=0.0, wd=0.0)
+    assert abs(float(loss) - r64["loss_bce"]) <= 1e-5
+    errs = P.grad_errors(slim, flat, r64["grads"])
+    gmax = max(n for _, n in errs.values())
+    # BatchNorms the surgery kept with gamma = 1e-6 put EVERY element of their output within rounding distance of the PReLU
+    # kink (bn = beta + 1e-6 * xhat), where the derivative is discontinuous: their own gamma / alpha gradients are
+    # decided by last-bit differences between any two implementations (ATen CPU vs GPU included) -- not compared
+    dead = {k.rsplit(".", 1)[0] for k, v in ssd.items() if ".bns." in k and k.endswith(".weight") and v.abs().max() <= 1e-5}
+    live = {k: e for k, (e, _) in errs.items() if k.rsplit(".", 1)[0] not in dead and k.replace(".prelus.", ".bns.").rsplit(".", 1)[0] not in dead}
+    assert len(live) > 0.5 * len(errs)
+    assert max(live.values()) <= 1e-4 * gmax, max(live.items(), key=lambda kv: kv[1])
