@@ -81,3 +81,30 @@ def test_emu_unpruned_expand2_forward(emu_lib):
 
 def test_emu_single_branch_std_conv_network(emu_lib):
     P.check_std_conv_network(emu_lib, CPU, _random_state)
+
+
+def test_emu_unpruned_expand2_train_step(emu_lib):
+    """The training recipe's starting point (expand 2.0, 788,631 parameters): weight images beyond the LDS budget are cut
+    into row chunks in the backward launches and the weight-gradient kernels too -- one full step against the oracle
+    (fp64 run as the truth, the fp32 oracle's own deviation as the yardstick; random state, hence ill-conditioned)."""
+    m = M.build_model(basic_split=[0.5, 0.5], expand=2.0, save_path="/tmp")
+    sd = _random_state(m, 4)
+    m.load_state_dict(sd)
+    m._lib = emu_lib
+    cfg = O.init_layers(40, [0.5, 0.5])
+    x = torch.from_numpy(I.randn_batch(5, 2, 32, 32))
+    t = torch.from_numpy(I.binary_target(6, 2, 32, 32))
+    m.train(); m.set_batchsize(2); m.clear_flops(); m.flops_hook(1.0)
+    yt, pen = m._train_forward_raw(x)
+    loss, dy = P.bce_and_grad(emu_lib, yt, t)
+    flat = m._train_backward_raw(x, dy, 3.0 / 2)
+    kw = dict(expandflop=1.0, flops_weight=3.0, batchsize=2, lr=0.0, wd=0.0)
+    r32 = O.train_step(cfg, {k: v.clone() for k, v in sd.items()}, x, t, **kw)
+    r64 = O.train_step(cfg, {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()},
+                       x.double(), t.double(), **kw)
+    assert abs(float(loss) - r64["loss_bce"]) <= 1e-5
+    assert abs(float(pen) / 2 - r64["penalty"]) <= 1e-5 * max(1.0, abs(r64["penalty"]))
+    mine = np.array([e / (n + 1e-12) for e, n in P.grad_errors(m, flat, r64["grads"]).values()])
+    ref = np.array([float((r32["grads"][k].double() - g).norm() / (g.norm() + 1e-12)) for k, g in r64["grads"].items()])
+    assert np.median(mine) <= 3 * np.median(ref) and mine.max() <= 3 * ref.max(), (np.median(mine), np.median(ref),
+                                                                                  mine.max(), ref.max())
