@@ -147,3 +147,14 @@ def test_head_with_channel_counts_off_the_tile_sizes(emu_lib):
         for j, t in enumerate(probes[name]):
             assert (eng.stage(st, j) - t).abs().max().item() <= 2e-4, (name, j)
     assert (y - ref).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("nb,cin,cmid,sizes,out_size,batch,zero_dil", [
+    (2, (40, 72), (32, 64), [(9, 7), (5, 4)], (30, 22), 2, None),
+    (3, (24, 40, 72), (32, 64, 96), [(10, 6), (5, 3), (3, 2)], (20, 12), 1, None),
+    (1, (48,), (64,), [(8, 8)], (16, 16), 2, None),
+    (4, (24, 40, 72, 136), (32, 64, 96, 96), [(11, 9), (6, 5), (3, 3), (2, 2)], (44, 36), 1, (1, 2)),
+])
+def test_head_descriptor_variants(emu_lib, nb, cin, cmid, sizes, out_size, batch, zero_dil):
+    """The head ABI is not tied to CSFNet's 4 x (256..2048 -> 128..512): 1-3 branches, other widths, an empty dilation group."""
+    assert K.custom_head_error(emu_lib, nb, cin, cmid, sizes, out_size, batch, zero_dil) <= 1e-4
