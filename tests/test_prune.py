@@ -132,7 +132,7 @@ def test_randomly_pruned_networks_through_the_kernels(emu_lib, tmp_path, seed, k
     assert (y - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
 
 
-def test_train_forward_when_the_top_branch_is_pruned_away(emu_lib, tmp_path):
+def check_top_branch_pruned(lib, device, tmp_path):
     """Regression (found by fuzzing): 90 % pruning leaves stage0.0 with NO channels in its full-resolution output branch,
     i.e. a launch whose only pass walks the half-resolution branch.  It used to reach the LDS-tiled 3x3 kernel with the
     launch resolution of branch 0 (out-of-bounds reads and writes); such launches are now re-based on their own
@@ -155,21 +155,35 @@ def test_train_forward_when_the_top_branch_is_pruned_away(emu_lib, tmp_path):
         cfg, mask = M.finetune_model(m, save_path=str(tmp_path), base_layer_config=O.init_layers(20, [0.5, 0.5]), thres=1e-3)
         slim = M.build_model_with_weight(cfg, m, mask)
     assert int(np.asarray(cfg[0][1])[0]) == 0            # the full-resolution output branch of stage0.0 is gone
-    slim._lib = emu_lib
+    slim = slim.to(device)
+    if device.type == "cpu":
+        slim._lib = lib
     slim.train(); slim.set_batchsize(2); slim.clear_flops(); slim.flops_hook(1.0)
     x = torch.from_numpy(I.randn_batch(seed, 2, 32, 32))
-    ssd = {k: v.clone() for k, v in slim.state_dict().items()}
-    yt, pen = slim._train_forward_raw(x)
+    ssd = {k: v.detach().cpu().clone() for k, v in slim.state_dict().items()}
+    yt, pen = slim._train_forward_raw(x.to(device))
+    yt, pen = yt.cpu(), pen.cpu()
     taps = {}
     with torch.no_grad():
         ref = O.csnet_forward(cfg, ssd, x, training=True, taps=taps)
     pen_ref = float(O.gap_penalty(ssd, taps, O.flop_weights(cfg, 1.0), 2))
     assert (yt - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
     assert abs(float(pen) / 2 - pen_ref) <= 1e-5 * max(1.0, abs(pen_ref))
-    got = slim.state_dict()
+    got = {k: v.cpu() for k, v in slim.state_dict().items()}
     for k, v in ssd.items():
         if k.endswith("running_mean") or k.endswith("running_var"):
             assert ((got[k] - v).abs() / (1.0 + v.abs())).max().item() <= 1e-5, k
+
+
+
+def test_train_forward_when_the_top_branch_is_pruned_away(emu_lib, tmp_path):
+    check_top_branch_pruned(emu_lib, torch.device("cpu"), tmp_path)
+
+
+@pytest.mark.gpu
+def test_gpu_train_forward_when_the_top_branch_is_pruned_away(tmp_path):
+    from sod100k_amd import _native as N
+    check_top_branch_pruned(N.load(), torch.device("cuda", 0), tmp_path)
 
 
 def test_train_step_with_an_output_branch_nobody_consumes(emu_lib, tmp_path):
