@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- images/sec through CSNet-100K (csnet-L-x2) eval forward on synthetic 3x224x224 batches.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no torchrun environment the script re-executes itself under ``python -m torch.distributed.run`` with N
+ranks on 127.0.0.1 (one process per GPU over RCCL); launched by torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE.
 
 A step = one pass of the hot path (``CSNet.forward``, csnet.py:365-387) over one batch of 64 images per
 GPU that is already resident in HBM (BASELINE.json configs[1]: fp32 forward, batch 64, 1 MI355X).  The path
@@ -13,11 +16,17 @@ Rank 0 prints ONE JSON line with, besides the driver's contract fields:
                 once + outputs written once) / mean launch duration measured with HIP
                 events on the launch stream, against the 8 TB/s HBM3E peak;
   cpu_baseline  the CPU oracle (a port of the reference path onto the same ATen CPU kernels) timed on the
-                host cores of this box on a bounded sample (rank 0, N=1 only).
+                host cores of this box on a bounded sample (rank 0, N=1 only): batch-8 throughput on all threads
+                (``value``), the test.py-style batch-1 latency loop, the 1-thread figure and the CPU model;
+  self_check    max |y - oracle| of the first two images of the batch the timed loop just produced (the timed path is
+                the hipGraph replay; the run FAILS if it exceeds 1e-4).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -31,26 +40,87 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALG_BYTES_PER_IMAGE = 169_704_640   # SURVEY.md 8(d), csnet-L-x2 fp32 224x224 (cross-checked below)
 
 
-def cpu_baseline(man, batch=8, target_s=15.0):
-    """Time the CPU oracle on a bounded sample (about 10-30 s of CPU work)."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(man, batch=8, target_s=12.0):
+    """Time the CPU oracle on a bounded sample (about 10-30 s of CPU work in total): batch-8 throughput on all threads,
+    the reference caller's batch-1 loop (test.py:87-93) on all threads and on ONE thread."""
     from oracle import csnet_oracle as O, inputs as I
     sd = O.load_weights(man)
     lc = O.load_layer_config_json(man)
     x = torch.from_numpy(I.randn_batch(0, batch))
     cores = torch.get_num_threads()
+
+    def loop(xx, budget, nmax):
+        O.csnet_forward(lc, sd, xx)          # warm-up
+        ts = []
+        t_end = time.perf_counter() + budget
+        while len(ts) < nmax and (len(ts) < 3 or time.perf_counter() < t_end):
+            t0 = time.perf_counter()
+            O.csnet_forward(lc, sd, xx)
+            ts.append(time.perf_counter() - t0)
+        return ts
+
     with torch.no_grad():
-        O.csnet_forward(lc, sd, x)          # warm-up
-        t0 = time.perf_counter()
-        n = 0
-        while True:
-            O.csnet_forward(lc, sd, x)
-            n += 1
-            if time.perf_counter() - t0 > target_s or n >= 20:
-                break
-        dt = time.perf_counter() - t0
-    return dict(value=round(batch * n / dt, 3), unit="images/sec", cores=cores, kind="port",
-                sample=f"{n} eval forwards of batch {batch} (3x224x224, seed 0) through oracle/csnet_oracle.py "
-                       f"(torch {torch.__version__} CPU ops, {cores} threads), {dt:.1f} s")
+        t8 = loop(x, target_s, 20)
+        t1 = loop(x[:1], 4.0, 20)
+        torch.set_num_threads(1)
+        t1s = loop(x[:1], 4.0, 5)
+        torch.set_num_threads(cores)
+    dt = sum(t8)
+    return dict(value=round(batch * len(t8) / dt, 3), unit="images/sec", cores=cores, kind="port",
+                cpu_model=_cpu_model(),
+                b1_latency_ms=round(statistics.median(t1) * 1e3, 2),
+                b1_images_per_sec=round(1.0 / statistics.median(t1), 3),
+                one_thread_images_per_sec=round(1.0 / statistics.median(t1s), 3),
+                sample=f"{len(t8)} eval forwards of batch {batch} (3x224x224, seed 0) through oracle/csnet_oracle.py "
+                       f"(torch {torch.__version__} CPU ops, {cores} threads), {dt:.1f} s; + {len(t1)} batch-1 forwards "
+                       f"on {cores} threads (median) and {len(t1s)} on 1 thread")
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def respawn(n):
+    """``python bench.py --gpus N`` from a bare shell: run N ranks of this script under torch.distributed.run."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes on this driver)
+    env["SOD100K_BENCH_SPAWNED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def train_algorithmic_bytes(model):
+    """(3 * in + 7 * out) activation elements per unit (two-pass BN forward, backward reads dy and z twice,
+    reads x and writes dx) x 4 bytes, per image at 224 x 224."""
+    arena = model._ensure_arena()
+    units, acts, _ = model.describe(arena.offsets)
+    tin = tout = 0
+    for u in units:
+        for i in range(int(u.n_in)):
+            if u.cin[i] > 0 and u.in_act[i] >= 0:
+                c, lvl = acts[u.in_act[i]]
+                tin += c * (224 >> lvl) * (224 >> lvl)
+        if u.kind == 4:                      # cls_layer: its output is the full-resolution logit map
+            tout += 224 * 224
+            continue
+        for j in range(int(u.n_out)):
+            if u.cout[j] > 0 and u.out_act[j] >= 0:
+                c, lvl = acts[u.out_act[j]]
+                tout += c * (224 >> lvl) * (224 >> lvl)
+    return 4 * (3 * tin + 7 * tout)
 
 
 def main():
@@ -71,17 +141,40 @@ def main():
     ap.add_argument("--csf-steps", type=int, default=5)
     ap.add_argument("--train-steps", type=int, default=10,
                     help="also time this many full train steps (0 = skip); reported under \"train_step\"")
+    ap.add_argument("--event-steps", type=int, default=50,
+                    help="extra steps timed one by one with HIP events after the contract's timed region (median reported)")
+    ap.add_argument("--emu-plumbing", action="store_true",
+                    help="CPU-only test of the launch / rendezvous / reporting plumbing (tests/test_dist_cpu.py): kernels "
+                         "emulated by tests/emu on gloo, tiny shapes; the line is marked invalid and is never a measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(respawn(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+    emu = args.emu_plumbing
+    if emu:
+        dev = torch.device("cpu")
+        args.batch, args.train_batch, args.csf_batch, args.profile_iters = 2, 2, 0, 1
+        args.no_cpu_baseline = True
+    else:
+        if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"rank {rank}: no ROCm device {local_rank} (visible: {torch.cuda.device_count()})")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     from sod100k_amd import dist as D
     world = D.init(device=dev)
+    nranks = world
+    if world > 1:
+        import torch.distributed as tdist
+        nranks = tdist.get_world_size()
+        probe = torch.ones(1, device=dev)
+        tdist.all_reduce(probe)               # the communicator (RCCL on GPUs) really spans `nranks` processes
+        assert int(probe.item()) == nranks, (float(probe.item()), nranks)
+    S = 32 if emu else 224
 
     from sod100k_amd.model import csnet as M
     from sod100k_amd.checkpoint import load_manifest_state_dict
@@ -91,57 +184,88 @@ def main():
     model.load_state_dict(sd)
     model = model.to(dev).eval()
     model._sub_batch = args.sub_batch
+    if emu:
+        import ctypes
+        from sod100k_amd import _native as N_
+        model._lib = N_.bind(ctypes.CDLL(os.path.join(ROOT, "tests", "emu", "libcsnet_emu.so")))
+    sync = (lambda: None) if emu else (lambda: torch.cuda.synchronize(dev))
 
     B = args.batch
     g = torch.Generator(device="cpu").manual_seed(rank)
-    x = torch.randn(B, 3, 224, 224, generator=g).to(dev)        # synthetic, resident in HBM before timing
+    x_host = torch.randn(B, 3, S, S, generator=g)
+    x = x_host.to(dev)                                          # synthetic, resident in HBM before timing
     eng = model.engine_for(x)
     eng.refresh(model._arena.flat)
     if args.no_fuse_cls:
         from sod100k_amd import _native as N
         eng.set_option(N.OPT_FUSE_CLS, 0)
-    y = torch.empty(B, 1, 224, 224, device=dev)
+    y = torch.empty(B, 1, S, S, device=dev)
 
     def step():
         eng.forward(x, out=y)
 
     for _ in range(args.warmup):
         step()
-    dt = D.timed_region(step, args.steps, sync=lambda: torch.cuda.synchronize(dev), device=dev)
+    dt = D.timed_region(step, args.steps, sync=sync, device=dev)
 
-    # ---- per-kernel roofline: a HIP event after EVERY kernel launch, on the launch stream ----
-    ms, names, nbytes = eng.profile(x, iters=args.profile_iters)
-    kstats = eng.kernel_stats()                        # kernel name -> (ms per forward, launches per forward)
-    agg = {}
-    for n, nb in zip(names, nbytes):                   # algorithmic bytes of the units each kernel implements
-        agg.setdefault(n, dict(bytes=0))["bytes"] += nb
-    for n, (kms, kl) in kstats.items():
-        agg.setdefault(n, dict(bytes=0)).update(ms=kms, launches=kl)
-    dom = max((k for k in agg if agg[k]["bytes"] > 0 and "ms" in agg[k]), key=lambda k: agg[k]["ms"])
-    d = agg[dom]
-    bytes_per_launch = d["bytes"] / d["launches"]
-    us_per_launch = d["ms"] * 1e3 / d["launches"]
-    achieved = bytes_per_launch / (us_per_launch * 1e-6) / 1e9
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    total_alg = sum(nbytes)
-    total_ms = sum(v["ms"] for v in agg.values() if "ms" in v)
-    roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                    bytes_per_launch=int(bytes_per_launch), us_per_launch=round(us_per_launch, 2),
-                    launches_per_step=d["launches"],
-                    whole_step=dict(algorithmic_bytes=int(total_alg), events_ms=round(total_ms, 3),
-                                    achieved=round(total_alg / (total_ms * 1e-3) / 1e9, 1),
-                                    frac=round(total_alg / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
-                    per_kernel={k: dict(ms=round(v["ms"], 3), launches=v["launches"],
-                                        us_per_launch=round(v["ms"] * 1e3 / v["launches"], 2),
-                                        alg_GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None)
-                                for k, v in agg.items() if "ms" in v})
+    # ---- the bench checks its own output: the timed path is the hipGraph replay, y is what it just wrote ----
+    self_check = None
+    if rank == 0:
+        from oracle import csnet_oracle as O
+        with torch.no_grad():
+            ref = O.csnet_forward(O.load_layer_config_json(man), O.load_weights(man), x_host[:2])
+        err = float((y[:2].cpu() - ref).abs().max())
+        self_check = {"max_abs_vs_oracle": err, "images": 2, "tol": 1e-4, "path": "output of the last timed step"}
+        if not (err <= 1e-4):
+            raise SystemExit(f"bench self-check FAILED: max|y - oracle| = {err:.3e} > 1e-4")
+
+    # ---- per-step HIP events on the launch stream (median of >= 50 single steps) ----
+    ev_stats = None
+    if not emu and args.event_steps > 0:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.event_steps)]
+        for a_, b_ in evs:                     # eng.forward launches on torch's current stream (engine._stream)
+            a_.record(); step(); b_.record()
+        torch.cuda.synchronize(dev)
+        ts = sorted(a_.elapsed_time(b_) for a_, b_ in evs)
+        ev_stats = {"steps": len(ts), "median_ms": round(statistics.median(ts), 4), "min_ms": round(ts[0], 4),
+                    "p90_ms": round(ts[int(0.9 * (len(ts) - 1))], 4),
+                    "images_per_sec_at_median": round(B / (statistics.median(ts) * 1e-3), 1)}
+
+    roofline, total_alg = None, ALG_BYTES_PER_IMAGE * B
+    if not emu:
+        # ---- per-kernel roofline: a HIP event after EVERY kernel launch, on the launch stream ----
+        ms, names, nbytes = eng.profile(x, iters=args.profile_iters)
+        kstats = eng.kernel_stats()                        # kernel name -> (ms per forward, launches per forward)
+        agg = {}
+        for n, nb in zip(names, nbytes):                   # algorithmic bytes of the units each kernel implements
+            agg.setdefault(n, dict(bytes=0))["bytes"] += nb
+        for n, (kms, kl) in kstats.items():
+            agg.setdefault(n, dict(bytes=0)).update(ms=kms, launches=kl)
+        dom = max((k for k in agg if agg[k]["bytes"] > 0 and "ms" in agg[k]), key=lambda k: agg[k]["ms"])
+        d = agg[dom]
+        bytes_per_launch = d["bytes"] / d["launches"]
+        us_per_launch = d["ms"] * 1e3 / d["launches"]
+        achieved = bytes_per_launch / (us_per_launch * 1e-6) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        total_alg = sum(nbytes)
+        total_ms = sum(v["ms"] for v in agg.values() if "ms" in v)
+        roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                        bytes_per_launch=int(bytes_per_launch), us_per_launch=round(us_per_launch, 2),
+                        launches_per_step=d["launches"],
+                        whole_step=dict(algorithmic_bytes=int(total_alg), events_ms=round(total_ms, 3),
+                                        achieved=round(total_alg / (total_ms * 1e-3) / 1e9, 1),
+                                        frac=round(total_alg / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
+                        per_kernel={k: dict(ms=round(v["ms"], 3), launches=v["launches"],
+                                            us_per_launch=round(v["ms"] * 1e3 / v["launches"], 2),
+                                            alg_GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None)
+                                    for k, v in agg.items() if "ms" in v})
 
     sub_b = eng_sub(eng, B)
     # ---- second data point: the full train step (fwd train-mode + BCE + backward + gradient all-reduce + Adam) ----
@@ -157,18 +281,23 @@ def main():
         TB = args.train_batch or B
         model.set_batchsize(TB)
         tr = FusedTrainer(model, lr=1e-4, weight_decay=5e-3, flops_weight=3.0, batchsize=TB)
-        xt = x if TB == B else torch.randn(TB, 3, 224, 224, generator=g).to(dev)
-        tgt = (torch.rand(TB, 1, 224, 224, generator=g) > 0.5).float().to(dev)
+        xt = x if TB == B else torch.randn(TB, 3, S, S, generator=g).to(dev)
+        tgt = (torch.rand(TB, 1, S, S, generator=g) > 0.5).float().to(dev)
 
         def tstep():
             tr.step(xt, tgt, world_size=world)
 
         for _ in range(3):
             tstep()
-        tdt = D.timed_region(tstep, args.train_steps, sync=lambda: torch.cuda.synchronize(dev), device=dev)
+        tdt = D.timed_region(tstep, args.train_steps, sync=sync, device=dev)
+        t_alg = train_algorithmic_bytes(model) * TB if not emu else 0
+        t_bw = t_alg / (tdt / args.train_steps) / 1e9
         train = {"value": round(world * TB * args.train_steps / tdt, 1), "unit": "images/sec",
                  "ms_per_step": round(tdt / args.train_steps * 1e3, 3), "steps": args.train_steps,
-                 "batch_per_gpu": TB, "dtype": "f32",
+                 "batch_per_gpu": TB, "dtype": "f32", "loss": round(float(tr.loss), 6),
+                 "roofline": {"bound": "hbm", "achieved": round(t_bw, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(t_bw / HBM_PEAK_GBS, 4), "bytes_per_step": int(t_alg),
+                              "what": "algorithmic (3*in + 7*out) x 4 B per unit (SURVEY 8(d)) / whole-step time"},
                  "what": "train-mode forward (batch-stat BN + penalty) + BCE + backward + "
                          + ("RCCL all-reduce of the flat gradient + " if world > 1 else "") + "Adam, csnet-L-x2 weights"}
         model.eval()
@@ -186,14 +315,19 @@ def main():
             "metric": "images/sec CSNet-100K 3x224x224 fwd (and fwd+bwd) at 1/2/4/8 GPU",
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if not emu else "INVALID: CPU plumbing run with emulated kernels (tests only)",
+            "nranks": nranks, "backend": ("gloo" if emu else "nccl (RCCL)") if world > 1 else "none",
             "config": {"workload": "CSNet-100K (csnet-L-x2 shipped checkpoint) fp32 eval forward, "
-                                   f"batch {B} x 3x224x224 per GPU, inputs resident in HBM",
+                                   f"batch {B} x 3x{S}x{S} per GPU, inputs resident in HBM",
                        "batch_per_gpu": B, "global_batch": B * world, "sub_batch": sub_b,
                        "parallelism": f"image shards x{world}, no data-path collective",
                        "algorithmic_bytes_per_image": int(total_alg // B)},
             "roofline": roofline,
+            "self_check": self_check,
         }
+        if ev_stats is not None:
+            out["hip_events"] = ev_stats
         if train is not None:
             out["train_step"] = train
         if csf is not None:

@@ -8,7 +8,7 @@
 #ifdef CSN_CPU_EMU
 #include "hip_cpu_shim.h"
 #define CSN_LAUNCH(kern, grid, block, smem, stream, ...) \
-  csn_emu::launch((grid), (block), (smem), [&]() { kern(__VA_ARGS__); })
+  csn_emu::launch_named(#kern, (grid), (block), (smem), [&]() { kern(__VA_ARGS__); })
 #define CSN_DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(csn_emu::g.smem)
 #else
 #include <hip/hip_runtime.h>

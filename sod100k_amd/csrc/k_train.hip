@@ -42,12 +42,22 @@ __device__ __forceinline__ BnRange bn_range(int slab, int cpp, int C, int c, int
 __device__ __forceinline__ double bn_block_sum(double v, double* sm) {
   const int tid = threadIdx.x;
 #ifdef CSN_CPU_EMU
+  // same summation tree as the device version (butterfly per 64 lanes, then the four wave sums), but evaluated by
+  // ONE fiber between two barriers: a barrier costs the emulator 256 context switches
   sm[tid] = v;
   __syncthreads();
-  for (int s = CSN_BLOCK / 2; s > 0; s >>= 1) {
-    if (tid < s) sm[tid] += sm[tid + s];
-    __syncthreads();
+  if (tid == 0) {
+    double w[4];
+    for (int q = 0; q < 4; ++q) {
+      double t[64];
+      for (int l = 0; l < 64; ++l) t[l] = sm[64 * q + l];
+      for (int o = 32; o > 0; o >>= 1)
+        for (int l = 0; l < o; ++l) t[l] = t[l] + t[l + o];   // lane l of the butterfly ends with the same pairing tree
+      w[q] = t[0];
+    }
+    sm[0] = (w[0] + w[1]) + (w[2] + w[3]);
   }
+  __syncthreads();
   const double r = sm[0];
   __syncthreads();
   return r;
@@ -457,9 +467,11 @@ __global__ __launch_bounds__(CSN_BLOCK) void sum_final_kernel(const double* part
 }
 
 // mean BCE-with-logits (train.py:209) and its gradient: loss = mean(max(y,0) - y*t + log1p(exp(-|y|))),
-// dy = (sigmoid(y) - t) / n.  Partial sums per block -> fp64 atomic (the loss value is a log line, the gradient exact).
-__global__ __launch_bounds__(CSN_BLOCK) void bce_logits_kernel(const float* y, const float* t, float* dy, int64_t n,
-                                                                double* loss) {
+// dy = (sigmoid(y) - t) / n.  One fp64 partial per block into a library-owned table, summed in block order by
+// bce_final_kernel: the loss is bit-reproducible run to run (no floating-point atomics anywhere in the step).
+#define BCE_MAX_BLOCKS 1024
+__device__ double g_bce_partial[BCE_MAX_BLOCKS];
+__global__ __launch_bounds__(CSN_BLOCK) void bce_logits_kernel(const float* y, const float* t, float* dy, int64_t n) {
   CSN_DYN_SMEM(double, sm);
   double s = 0.0;
   const float inv = 1.f / (float)n;
@@ -471,15 +483,14 @@ __global__ __launch_bounds__(CSN_BLOCK) void bce_logits_kernel(const float* y, c
     dy[i] = (sig - tg) * inv;
   }
   s = bn_block_sum(s, sm);
-  if (threadIdx.x == 0) {
-    const double term = s / (double)n;
-#ifdef CSN_CPU_EMU
-#pragma omp atomic
-    *loss += term;
-#else
-    atomicAdd(loss, term);
-#endif
-  }
+  if (threadIdx.x == 0) g_bce_partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(CSN_BLOCK) void bce_final_kernel(int nblk, int64_t n, double* loss) {
+  CSN_DYN_SMEM(double, sm);
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += CSN_BLOCK) s += g_bce_partial[i];
+  s = bn_block_sum(s, sm);
+  if (threadIdx.x == 0) *loss += s / (double)n;
 }
 
 // torch.optim.Adam step (L2 weight decay folded into the gradient, train.py:108-123) over the flat parameter arena;
@@ -557,8 +568,9 @@ int csn_launch_sum_to_grad(const float* in, int64_t n, float* dst, double* parti
   return (int)hipGetLastError();
 }
 int csn_launch_bce(const float* y, const float* t, float* dy, int64_t n, double* loss, void* stream) {
-  CSN_LAUNCH(bce_logits_kernel, dim3(grid_for(n) < 1024 ? grid_for(n) : 1024), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream,
-             y, t, dy, n, loss);
+  const int nblk = grid_for(n) < BCE_MAX_BLOCKS ? grid_for(n) : BCE_MAX_BLOCKS;
+  CSN_LAUNCH(bce_logits_kernel, dim3(nblk), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, y, t, dy, n);
+  CSN_LAUNCH(bce_final_kernel, dim3(1), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, nblk, n, loss);
   return (int)hipGetLastError();
 }
 int csn_launch_adam(const AdamArgs& a, void* stream) {

@@ -262,6 +262,7 @@ class CSNet(nn.Module):
         self._arena: Optional[ParamArena] = None
         self._engines = {}
         self._lib = None            # tests may inject another build of the same C ABI; None -> libcsnet_hip.so
+        self._train_generation = 0  # counts train-mode forwards (autograd seam: backward must belong to the last one)
         self._sub_batch = int(os.environ.get("CSN_SUB_BATCH", "0"))
         self._penalty_cfg = None    # set by flops_hook()
 
@@ -537,6 +538,7 @@ class CSNet(nn.Module):
         else:
             penalty.zero_()
         y = eng.forward_train(x, arena.flat, self._flop_tab, penalty, out=y)
+        self._train_generation = getattr(self, "_train_generation", 0) + 1
         with torch.no_grad():
             nbt = [m.num_batches_tracked for m in self.modules()
                    if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
@@ -568,12 +570,18 @@ class _CSNetTrainFn(torch.autograd.Function):
     def forward(ctx, model, x, *params):
         y, pen = model._train_forward_raw(x, with_backward=True)
         ctx.model, ctx.x = model, x
-        ctx.mark_non_differentiable()
+        # backward reads z / activations / BN statistics of THIS forward from the plan's workspace: remember which
+        # train-mode forward filled it, so that a second forward before this graph's backward is caught
+        ctx.generation = model._train_generation
         return y, pen.to(torch.float32)[0]
 
     @staticmethod
     def backward(ctx, dy, dpen):
         model = ctx.model
+        if ctx.generation != model._train_generation:
+            raise RuntimeError("CSNet backward after a newer train-mode forward: the plan keeps the activations of the LAST "
+                               "forward only (no gradient accumulation over several forwards / combined losses of two "
+                               "forwards); call backward() before the next model(x)")
         pen_scale = float(dpen) if dpen is not None else 0.0
         if dy is None:
             dy = torch.zeros((ctx.x.shape[0], 1) + tuple(ctx.x.shape[2:]), dtype=torch.float32, device=ctx.x.device)
@@ -804,7 +812,22 @@ def build_model(epoch=0, predefine='', basic_split=[1, ], save_path='tmp', expan
     elif os.path.isfile(predefine):
         layer_config = load_layer_config(predefine)
     else:
+        if epoch != 0:
+            raise NotImplementedError("redefine_model (re-widening at epoch > 0) is undefined in the reference as well "
+                                      "(CSNet_training/model/csnet.py:918)")
         layer_config = init_layers(real_width, basic_split)
+        save_layer_config(layer_config, save_path, epoch, latest=True)     # layer_config_0.bin + layer_config_latest.bin
     if out_mask is not None and load_weight == 'FINETUNE' and epoch != 0:
-        return build_model_with_weight(layer_config=layer_config, old_model=model, mask=out_mask)
-    return CSNet(layer_config=layer_config)
+        newmodel = build_model_with_weight(layer_config=layer_config, old_model=model, mask=out_mask)
+    else:
+        newmodel = CSNet(layer_config=layer_config)
+    # CSNet_training/model/csnet.py:933-945 saves the freshly built network at epoch 0.  The inference copy of build_model
+    # (CSNet/model/csnet.py:571-597) has no such side effect; its callers never pass save_path, so the file is written
+    # whenever a save_path was given or a new layer_config was initialised.
+    if epoch == 0 and not finetune and (save_path != 'tmp' or not os.path.isfile(predefine)):
+        ckdir = os.path.join(save_path, 'checkpoint')
+        os.makedirs(ckdir, exist_ok=True)
+        init_save_file = os.path.join(ckdir, 'checkpoint_init.pth.tar')
+        torch.save({'epoch': -1, 'arch': "CSNet", 'state_dict': newmodel.state_dict()}, init_save_file)
+        print("Save init model:", init_save_file)
+    return newmodel

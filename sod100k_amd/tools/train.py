@@ -77,6 +77,14 @@ class FusedTrainer:
         if model._arena is None or not model._arena.is_current():
             raise RuntimeError("the parameter arena was re-allocated (model.to()/cuda() after creating the trainer)")
         B = x.shape[0]
+        dev = model._arena.flat.device
+        # the kernels read raw fp32 memory: the reference calls .float() on both tensors (train.py:199-202)
+        if x.dtype != torch.float32 or x.device != dev or not x.is_contiguous():
+            x = x.to(dev, torch.float32).contiguous()
+        if target.dtype != torch.float32 or target.device != dev or not target.is_contiguous():
+            target = target.to(dev, torch.float32).contiguous()
+        if target.numel() != B * x.shape[2] * x.shape[3]:
+            raise ValueError(f"target of {tuple(target.shape)} does not match logits of {(B, 1) + tuple(x.shape[2:])}")
         if self.y is None or self.y.shape[0] != B or tuple(self.y.shape[2:]) != tuple(x.shape[2:]):
             self.y = torch.empty((B, 1) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
             self.dy = torch.empty_like(self.y)
@@ -97,6 +105,68 @@ class FusedTrainer:
                                                  self.betas[0], self.betas[1], self.eps, self.steps,
                                                  self._stream(y)), "csn_adam_step")
         return self.loss.clone(), pen.clone() / bs
+
+    # ---- checkpointing in torch.optim.Adam's own format (train.py:172-181 saves optimizer.state_dict()) ----
+    def _param_order(self):
+        named = list(self.model.named_parameters())
+        normal = [(n, p) for n, p in named if not is_picked(n)]
+        picked = [(n, p) for n, p in named if is_picked(n)]
+        return normal, picked                     # group 0, group 1 of train.py:97-123
+
+    def state_dict(self):
+        """``torch.optim.Adam(...).state_dict()`` of the reference's two-group optimizer, filled from the flat buffers, so a
+        checkpoint written here resumes under the reference's train.py:130-141 and vice versa."""
+        normal, picked = self._param_order()
+        offs = self.model._arena.offsets
+        state = {}
+        idx = 0
+        for grp in (normal, picked):
+            for name, p in grp:
+                if self.steps > 0:
+                    o = offs[name]
+                    state[idx] = {"step": torch.tensor(float(self.steps)),
+                                  "exp_avg": self.m[o:o + p.numel()].view(p.shape).detach().cpu().clone(),
+                                  "exp_avg_sq": self.v[o:o + p.numel()].view(p.shape).detach().cpu().clone()}
+                idx += 1
+        wd0 = float(self.wd[offs[normal[0][0]]]) if normal else 0.0
+
+        def group(lo, n, wd):
+            return {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": wd, "amsgrad": False,
+                    "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                    "params": list(range(lo, lo + n))}
+        return {"state": state, "param_groups": [group(0, len(normal), wd0), group(len(normal), len(picked), 0.0)]}
+
+    def load_state_dict(self, sd):
+        normal, picked = self._param_order()
+        order = normal + picked
+        offs = self.model._arena.offsets
+        self.m.zero_(); self.v.zero_()
+        steps = 0
+        for idx, (name, p) in enumerate(order):
+            st = sd.get("state", {}).get(idx)
+            if st is None:
+                continue
+            o = offs[name]
+            self.m[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
+            self.v[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+            steps = max(steps, int(float(st["step"])))
+        self.steps = steps                         # one step counter for all parameters, as one optimizer.step() gives
+        groups = sd.get("param_groups") or []
+        if groups:
+            self.lr = float(groups[0].get("lr", self.lr))
+
+
+def load_pretrained(model, pretrained_path):
+    """utils/utils.py:6-24: copy every tensor of a raw state_dict file whose key exists in the model (train.py:124-125)."""
+    if os.path.isfile(pretrained_path):
+        print("=> loading checkpoint '{}'".format(pretrained_path))
+        pretrain = torch.load(pretrained_path, map_location="cpu")
+        state = model.state_dict()
+        state.update({k: v for k, v in pretrain.items() if k in state})
+        model.load_state_dict(state)
+        return model
+    print("=> no checkpoint found at '{}'".format(pretrained_path))
+    return model
 
 
 def reference_style_step(model, optimizer, x, target, flops_weight):
@@ -146,13 +216,27 @@ def synthetic_batches(n, batch, h, w, device, seed=0):
                (torch.rand(batch, 1, h, w, generator=g) > 0.5).float().to(device))
 
 
-def run(cfg, device="cuda", synthetic=0, max_steps=0):
+def run(cfg, device="cuda", synthetic=0, max_steps=0, val_batches=None, lib=None):
+    """train.py:67-181.  One process per GPU when launched by ``torch.distributed.run`` (RANK / WORLD_SIZE in the
+    environment): every rank trains on its own image shard with per-GPU BN statistics and the step's single collective
+    (gradient all-reduce) inside ``FusedTrainer.step``; rank 0 validates and writes the checkpoints."""
+    from sod100k_amd import dist as D
+    rank = int(os.environ.get("RANK", "0"))
+    if str(device).startswith("cuda") and "LOCAL_RANK" in os.environ:
+        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+        device = f"cuda:{int(os.environ['LOCAL_RANK'])}"
+    world = D.init(device=torch.device(device))
     model_lib = importlib.import_module("model." + cfg.MODEL.ARCH)                     # train.py:70
     if not cfg.AUTO.ENABLE:
         print("Enable AUTO to train CSNet!")
         return None
-    layer_config_dir = os.path.join(cfg.DATA.SAVEDIR, cfg.TASK, 'layer_configs')
+    task_dir = os.path.join(cfg.DATA.SAVEDIR, cfg.TASK)
+    layer_config_dir = os.path.join(task_dir, 'layer_configs')
+    check_point_dir = os.path.join(task_dir, 'checkpoint')
     os.makedirs(layer_config_dir, exist_ok=True)
+    os.makedirs(check_point_dir, exist_ok=True)
+    # epoch-0 build: writes layer_config_0.bin / layer_config_latest.bin (init path) and checkpoint/checkpoint_init.pth.tar,
+    # which finetune.py:96-99 reads back (CSNet_training/model/csnet.py:903-945)
     model = model_lib.build_model(basic_split=cfg.MODEL.BASIC_SPLIT, predefine=cfg.AUTO.PREDEFINE,
                                   save_path=layer_config_dir, expand=cfg.AUTO.EXPAND)
     if cfg.AUTO.FLOPS.ENABLE:
@@ -161,30 +245,65 @@ def run(cfg, device="cuda", synthetic=0, max_steps=0):
         else:
             model.flops_hook()
         model.set_batchsize(cfg.DATA.BATCH_SIZE)
+    if lib is not None:
+        model._lib = lib
     model = model.to(device).train()
     if cfg.SOLVER.METHOD != 'Adam_dynamic_weight_decay':
         print("WARNING: Method not implmented.")
         return None
     trainer = FusedTrainer(model, lr=cfg.SOLVER.LR, weight_decay=cfg.SOLVER.WEIGHT_DECAY,
-                           flops_weight=cfg.AUTO.FLOPS.WEIGHT if cfg.AUTO.FLOPS.ENABLE else 0.0,
-                           batchsize=cfg.DATA.BATCH_SIZE)
-    done = 0
-    for epoch in range(cfg.SOLVER.MAX_EPOCHS):
-        if cfg.SOLVER.ADJUST_STEP:
-            trainer.lr = multistep_lr(cfg.SOLVER.LR, cfg.SOLVER.STEPS, epoch)
+                           flops_weight=0.0, batchsize=cfg.DATA.BATCH_SIZE, lib=lib)
+    if cfg.DATA.PRETRAIN != '':
+        load_pretrained(model, cfg.DATA.PRETRAIN)                                      # train.py:124-125
+    start_epoch = 0
+    if cfg.DATA.RESUME != '':                                                          # train.py:127-141
+        if os.path.isfile(cfg.DATA.RESUME):
+            print("=> loading checkpoint '{}'".format(cfg.DATA.RESUME))
+            checkpoint = torch.load(cfg.DATA.RESUME, map_location="cpu", weights_only=False)
+            start_epoch = checkpoint['epoch']
+            model.load_state_dict(checkpoint['state_dict'])
+            if checkpoint.get('optimizer'):
+                trainer.load_state_dict(checkpoint['optimizer'])
+            print("=> loaded checkpoint '{}' (epoch {})".format(cfg.DATA.RESUME, checkpoint['epoch']))
+        else:
+            print("=> no checkpoint found at '{}'".format(cfg.DATA.RESUME))
+    if cfg.SOLVER.ADJUST_STEP and cfg.SOLVER.LR_SCHEDULER != 'step':
+        raise ValueError("Unsupported scheduler.")
+    best_mae, best_epoch, done = 1000000, -1, 0
+    sched_steps = 0                  # the reference's scheduler restarts its own count on resume (train.py:143-157)
+    for epoch in range(start_epoch, cfg.SOLVER.MAX_EPOCHS):
+        if (cfg.SOLVER.FINETUNE.ADJUST_STEP and epoch > cfg.AUTO.FINETUNE) or cfg.SOLVER.ADJUST_STEP:   # train.py:152-156
+            sched_steps += 1
+            trainer.lr = cfg.SOLVER.LR * 0.1 ** sum(1 for s_ in cfg.SOLVER.STEPS if sched_steps >= s_)
+        # the FLOPs penalty is applied only while epoch < AUTO.FINETUNE (train.py:212-213)
+        penal = cfg.AUTO.FLOPS.ENABLE and epoch < cfg.AUTO.FINETUNE
+        trainer.flops_weight = float(cfg.AUTO.FLOPS.WEIGHT) if penal else 0.0
         if synthetic <= 0:
             print("dataset loading (prepare_data.py) is host IO outside this build; use --synthetic N")
             return trainer
+        model.train()
         for i, (x, t) in enumerate(synthetic_batches(synthetic, cfg.DATA.BATCH_SIZE, cfg.DATA.IMAGE_H, cfg.DATA.IMAGE_W,
-                                                     device, seed=epoch)):
-            loss, pen = trainer.step(x, t)
+                                                     device, seed=epoch * world + rank)):
+            loss, pen = trainer.step(x, t, world_size=world)
             model.clear_flops()
-            if i % cfg.PRINT_FREQ == 0:
-                print(f"Epoch: [{epoch}][{i}/{synthetic}] Loss {float(loss):.4f} flops-penalty {float(pen):.6f} "
+            if i % cfg.PRINT_FREQ == 0 and rank == 0:
+                print(f"Epoch: [{epoch + 1}][{i}/{synthetic}] Loss {float(loss):.4f} FakeFLOPs {float(pen):.3f} "
                       f"lr {trainer.lr:g}")
             done += 1
             if max_steps and done >= max_steps:
-                return trainer
+                break
+        if rank == 0:
+            mae = val(model, val_batches, lib=lib) if val_batches is not None else float("nan")       # train.py:160
+            if mae < best_mae:
+                best_mae, best_epoch = mae, epoch + 1
+            print(" epoch: " + str(epoch + 1) + " mae: " + str(mae) + " best_epoch: " + str(best_epoch) + " best_mae: "
+                  + str(best_mae))
+            from sod100k_amd.checkpoint import save_checkpoint
+            save_checkpoint({'epoch': epoch + 1, 'arch': cfg.MODEL.ARCH, 'state_dict': model.state_dict(),
+                             'optimizer': trainer.state_dict()},
+                            os.path.join(check_point_dir, 'checkpoint_epoch{}.pth.tar'.format(epoch + 1)))   # train.py:172-181
+        if max_steps and done >= max_steps:
+            break
     return trainer
 
 

@@ -66,11 +66,14 @@ struct Ctx {
   uint3 tIdx, bIdx;
   dim3 bDim, gDim;
   unsigned char* smem = nullptr;
-  ucontext_t sched;
-  ucontext_t* cur = nullptr;
+  void* sched_sp = nullptr;   // saved stack pointer of the block scheduler (x86-64 fast path)
+  ucontext_t sched;           // portable path
 };
 extern thread_local Ctx g;
 void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body);
+// CSN_EMU_PROFILE=1: wall time and block count per kernel name, printed at exit (finds launches whose grid does not
+// shrink with the problem -- they dominate the emulated tests and the small-batch GPU steps alike)
+void launch_named(const char* name, dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body);
 void yield_barrier();
 }  // namespace csn_emu
 
@@ -90,11 +93,48 @@ static inline T atomicAdd(T* p, T v) {
 
 #ifdef CSN_EMU_IMPL
 #include <omp.h>
+#include <chrono>
+#include <map>
+#include <string>
 namespace csn_emu {
 thread_local Ctx g;
 
+// Fiber switch.  glibc's swapcontext saves and restores the signal mask with a system call per switch; a barrier of a
+// 256-thread block is 256 switches, so the emulated suites spent most of their time there.  On x86-64 the switch is the
+// classic callee-saved-register swap (no signal mask, no FP environment: kernels change neither).
+#if defined(__x86_64__) && !defined(CSN_EMU_UCONTEXT)
+#define CSN_EMU_FAST_SWITCH 1
+extern "C" void csn_emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl csn_emu_switch
+.type csn_emu_switch,@function
+csn_emu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size csn_emu_switch,.-csn_emu_switch
+)");
+#endif
+
 struct Fiber {
+#ifdef CSN_EMU_FAST_SWITCH
+  void* sp = nullptr;
+#else
   ucontext_t ctx;
+#endif
   bool done = false;
 };
 struct Pool {
@@ -107,13 +147,22 @@ struct Pool {
 static thread_local Pool pool;
 static const size_t kStack = 96 * 1024;
 
+#ifdef CSN_EMU_FAST_SWITCH
+static void to_sched() { csn_emu_switch(&pool.running->sp, g.sched_sp); }
+static void to_fiber(Fiber& f) { csn_emu_switch(&g.sched_sp, f.sp); }
+#else
+static void to_sched() { swapcontext(&pool.running->ctx, &g.sched); }
+static void to_fiber(Fiber& f) { swapcontext(&g.sched, &f.ctx); }
+#endif
+
 static void trampoline() {
   (*pool.body)();
   pool.running->done = true;
-  swapcontext(&pool.running->ctx, &g.sched);
+  to_sched();
+  std::abort();   // a finished fiber is never resumed
 }
 
-void yield_barrier() { swapcontext(&pool.running->ctx, &g.sched); }
+void yield_barrier() { to_sched(); }
 
 static void run_block(dim3 grid, dim3 block, unsigned bx, unsigned by, unsigned bz, size_t smem_bytes,
                       const std::function<void()>& body) {
@@ -146,11 +195,23 @@ static void run_block(dim3 grid, dim3 block, unsigned bx, unsigned by, unsigned 
     Fiber& f = pool.fibers[t];
     f.done = false;
     if (poison_stack) std::memset(pool.stacks.data() + (size_t)(t + 1) * kStack - 48 * 1024, 0xFF, 48 * 1024 - 256);
+#ifdef CSN_EMU_FAST_SWITCH
+    // initial frame: six callee-saved registers, the entry point as return address, and a slot that keeps the stack
+    // pointer at 8 (mod 16) on entry as the ABI requires after a call
+    uintptr_t top = (uintptr_t)(pool.stacks.data() + (size_t)(t + 1) * kStack);
+    top &= ~(uintptr_t)15;
+    void** sp = reinterpret_cast<void**>(top);
+    *--sp = nullptr;
+    *--sp = reinterpret_cast<void*>(&trampoline);
+    for (int r = 0; r < 6; ++r) *--sp = nullptr;
+    f.sp = sp;
+#else
     getcontext(&f.ctx);
     f.ctx.uc_stack.ss_sp = pool.stacks.data() + (size_t)t * kStack;
     f.ctx.uc_stack.ss_size = kStack;
     f.ctx.uc_link = nullptr;
     makecontext(&f.ctx, (void (*)())trampoline, 0);
+#endif
   }
   unsigned alive = n;
   while (alive) {
@@ -159,7 +220,7 @@ static void run_block(dim3 grid, dim3 block, unsigned bx, unsigned by, unsigned 
       if (f.done) continue;
       g.tIdx = uint3{t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
       pool.running = &f;
-      swapcontext(&g.sched, &f.ctx);
+      to_fiber(f);
       if (f.done) --alive;
     }
   }
@@ -172,6 +233,28 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
     unsigned bx = (unsigned)(b % grid.x), by = (unsigned)((b / grid.x) % grid.y), bz = (unsigned)(b / ((long)grid.x * grid.y));
     run_block(grid, block, bx, by, bz, smem_bytes, body);
   }
+}
+
+struct ProfEntry { double s = 0; long blocks = 0, launches = 0; };
+static std::map<std::string, ProfEntry>* g_prof = nullptr;
+static void prof_dump() {
+  if (!g_prof) return;
+  std::vector<std::pair<std::string, ProfEntry>> v(g_prof->begin(), g_prof->end());
+  std::sort(v.begin(), v.end(), [](const auto& a, const auto& b) { return a.second.s > b.second.s; });
+  for (const auto& e : v)
+    std::fprintf(stderr, "[emu-profile] %-48s %9.3f s %8ld launches %10ld blocks\n", e.first.c_str(), e.second.s,
+                 e.second.launches, e.second.blocks);
+}
+void launch_named(const char* name, dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body) {
+  static const bool on = std::getenv("CSN_EMU_PROFILE") != nullptr;
+  if (!on) { launch(grid, block, smem_bytes, body); return; }
+  if (!g_prof) { g_prof = new std::map<std::string, ProfEntry>(); std::atexit(prof_dump); }
+  const auto t0 = std::chrono::steady_clock::now();
+  launch(grid, block, smem_bytes, body);
+  ProfEntry& e = (*g_prof)[name];
+  e.s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  e.blocks += (long)grid.x * grid.y * grid.z;
+  e.launches += 1;
 }
 }  // namespace csn_emu
 #endif  // CSN_EMU_IMPL

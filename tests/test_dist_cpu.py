@@ -119,3 +119,25 @@ def test_two_rank_gradient_allreduce(emu_lib):
         g = flat[offs[name]:offs[name] + p.numel()].view(p.shape).double()
         ref = (grads[name] / 2).double()
         assert float((g - ref).norm()) <= 2e-3 * float(ref.norm()) + 1e-6 * gmax, name
+
+
+def test_bench_self_spawns_two_ranks(emu_lib):
+    """``python bench.py --gpus 2`` from a bare shell (no torchrun environment) must start its own two ranks, rendezvous on
+    127.0.0.1, time the eval step and the train step WITH the gradient all-reduce, and print one JSON line whose ``nranks``
+    is the size of the communicator.  Here: gloo + the emulated kernels (``--emu-plumbing``; the line is marked invalid)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--train-steps", "1", "--emu-plumbing"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout                      # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["nranks"] == 2 and out["backend"] == "gloo"
+    assert out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 2 * out["config"]["batch_per_gpu"]
+    assert out["data"].startswith("INVALID")              # never mistaken for a measurement
+    assert out["self_check"]["max_abs_vs_oracle"] <= 1e-4
+    assert "all-reduce" in out["train_step"]["what"] and out["train_step"]["steps"] == 1

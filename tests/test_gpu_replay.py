@@ -1,0 +1,228 @@
+"""The code path bench.py TIMES, under parity: hipGraph replay of the eval forward (fixed x / y / workspace pointers,
+csn_plan.hip csn_forward) and of the train step (run_graphed: two eager calls, capture on the third, replay from the
+fourth), plus size-independent properties of the train step at BASELINE config 3's batch of 256.
+
+The other GPU tests call ``model(x)``, which allocates a fresh output per call and therefore always runs eagerly."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import csnet_oracle as O, inputs as I
+
+import parity_cases as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from sod100k_amd import _native as N
+    assert torch.cuda.is_available(), "no ROCm device"
+    return N.load(), torch.device("cuda", 0)
+
+
+def test_gpu_eval_replay_golden_and_refresh(hip, x2_manifest):
+    """>= 4 calls with the same buffers (eager, capture, replay, replay ...) against the reference golden after EVERY
+    call; then a parameter change + refresh must be visible through the replayed graph (csnet.py:365-387)."""
+    lib, dev = hip
+    m, sd = P.make_model(lib, x2_manifest, dev)
+    x_cpu = torch.from_numpy(I.randn_batch(0, 2))
+    x = x_cpu.to(dev)
+    gold = torch.from_numpy(np.load(os.path.join(P.GOLD, "g2_logits_x2_randn_b2.npy")))
+    eng = m.engine_for(x)
+    eng.refresh(m._arena.flat)
+    y = torch.empty(2, 1, 224, 224, device=dev)
+    first = None
+    for call in range(6):
+        y.fill_(float("nan"))                      # a replay that silently does nothing must not pass
+        eng.forward(x, out=y)
+        got = y.cpu()
+        err = (got - gold).abs().max().item()
+        assert err <= P.TOL, f"call {call}: max-abs {err:.3e}"
+        if first is None:
+            first = got.clone()
+        assert torch.equal(got, first), f"call {call}: replay differs from the eager call"
+    # new input values in the SAME buffer: the replay must read them
+    x2_cpu = torch.from_numpy(I.randn_batch(5, 2))
+    x.copy_(x2_cpu)
+    eng.forward(x, out=y)
+    ref2 = P.oracle_forward(x2_manifest, sd, x2_cpu)
+    assert (y.cpu() - ref2).abs().max().item() <= P.TOL
+    # parameter change + refresh: conv weights of one block, a BN table, the classifier bias
+    g = torch.Generator().manual_seed(3)
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    for k in ("stage1.1.conv1x1.conv.weight", "stage2.2.conv3x3_1.convs.0.weight", "oct_fuse.fuse1x1.conv.weight"):
+        sd2[k] = sd2[k] * (1.0 + 0.05 * torch.randn(sd2[k].shape, generator=g))
+    sd2["stage1.0.conv1x1.bns.0.bias"] = sd2["stage1.0.conv1x1.bns.0.bias"] + 0.01
+    sd2["cls_layer.bias"] = sd2["cls_layer.bias"] + 0.25
+    with torch.no_grad():
+        own = m.state_dict()
+        for k in sd2:
+            own[k].copy_(sd2[k])                   # writes through the arena views: pointers stay the same
+    assert m._arena.is_current()
+    eng.refresh(m._arena.flat)
+    eng.forward(x, out=y)                          # still the replayed graph (same x, y, workspace)
+    ref3 = P.oracle_forward(x2_manifest, sd2, x2_cpu)
+    assert (ref3 - ref2).abs().max().item() > 0.1  # the change is visible at all
+    err = (y.cpu() - ref3).abs().max().item()
+    assert err <= P.TOL, f"after refresh: max-abs {err:.3e}"
+
+
+def test_gpu_eval_replay_batch64_sample(hip, x2_manifest):
+    """bench.py's exact loop (batch 64, out=y, repeated) and its self-check: y[:2] against the oracle."""
+    lib, dev = hip
+    m, sd = P.make_model(lib, x2_manifest, dev)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x_cpu = torch.randn(64, 3, 224, 224, generator=g)
+    x = x_cpu.to(dev)
+    eng = m.engine_for(x)
+    eng.refresh(m._arena.flat)
+    y = torch.empty(64, 1, 224, 224, device=dev)
+    for _ in range(8):
+        eng.forward(x, out=y)
+    ref = P.oracle_forward(x2_manifest, sd, x_cpu[[0, 1, 31, 63]])
+    assert (y[[0, 1, 31, 63]].cpu() - ref).abs().max().item() <= P.TOL
+
+
+def _rel_l2(flat, offs, grads):
+    num = den = 0.0
+    for k, g in grads.items():
+        d = flat[offs[k]:offs[k] + g.numel()].view(g.shape).double() - g.double()
+        num += float((d * d).sum())
+        den += float((g.double() ** 2).sum())
+    return (num / max(den, 1e-300)) ** 0.5
+
+
+def test_gpu_train_replay_steps(hip, x2_manifest):
+    """FusedTrainer with FIXED device buffers for 6 steps (2 eager, capture, 3 replays) against the oracle's step with
+    carried state: loss and penalty every step, BN buffers at the end, the whole gradient on the replayed step 5."""
+    from sod100k_amd.tools.train import FusedTrainer
+    lib, dev = hip
+    B, H, W = 2, 64, 96
+    m, sd = P.make_model(lib, x2_manifest, dev)
+    m.train(); m.set_batchsize(B); m.clear_flops(); m.flops_hook(1.0)
+    tr = FusedTrainer(m, lr=1e-4, weight_decay=5e-3, eps=1e-3, flops_weight=3.0, batchsize=B, lib=lib)
+    cfg = O.load_layer_config_json(x2_manifest)
+    sd_ref = {k: v.clone() for k, v in sd.items()}
+    xd = torch.empty(B, 3, H, W, device=dev)
+    td = torch.empty(B, 1, H, W, device=dev)
+    state = None
+    offs = m._arena.offsets
+    for step in range(6):
+        x = torch.from_numpy(I.randn_batch(40 + step, B, H, W))
+        t = torch.from_numpy(I.binary_target(50 + step, B, H, W))
+        xd.copy_(x); td.copy_(t)
+        loss, pen = tr.step(xd, td)
+        m.clear_flops()
+        r = O.train_step(cfg, sd_ref, x, t, expandflop=1.0, flops_weight=3.0, batchsize=B, lr=1e-4, wd=5e-3, eps=1e-3,
+                         adam_state=state)
+        state = r["adam_state"]
+        tol = 2e-5 if step == 0 else 1e-3          # later steps start from parameters ~1e-3 (relative) apart
+        assert abs(float(loss) - r["loss_bce"]) <= tol * max(1.0, abs(r["loss_bce"])), (step, float(loss), r["loss_bce"])
+        assert abs(float(pen) - r["penalty"]) <= max(tol, 2e-4) * max(1.0, abs(r["penalty"])), (step, float(pen), r["penalty"])
+        rel = _rel_l2(tr.grad.cpu(), offs, r["grads"])
+        print(f"step {step}: bce {float(loss):.6f} / {r['loss_bce']:.6f}  gradient rel-L2 {rel:.2e}")
+        assert rel <= (2e-3 if step == 0 else 2e-2), (step, rel)
+    assert tr.steps == 6
+    got = m.state_dict()
+    for k, v in sd_ref.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(got[k]) == int(v), k
+        elif k.endswith("running_mean") or k.endswith("running_var"):
+            assert ((got[k].cpu() - v).abs() / (1 + v.abs())).max().item() <= 2e-4, k
+
+
+def test_gpu_train_replay_equals_eager(hip, x2_manifest):
+    """With lr = 0 the state is frozen: the replayed step (4th call on) must reproduce the eager step's loss, penalty and
+    gradient arena BIT for bit (fixed-order reductions, same launches)."""
+    from sod100k_amd.tools.train import FusedTrainer
+    lib, dev = hip
+    B, S = 3, 80
+    m, _ = P.make_model(lib, x2_manifest, dev)
+    m.train(); m.set_batchsize(B); m.clear_flops(); m.flops_hook(1.0)
+    tr = FusedTrainer(m, lr=0.0, weight_decay=0.0, flops_weight=3.0, batchsize=B, lib=lib)
+    xd = torch.from_numpy(I.randn_batch(60, B, S, S)).to(dev)
+    td = torch.from_numpy(I.binary_target(61, B, S, S)).to(dev)
+    ref = None
+    for step in range(6):
+        loss, pen = tr.step(xd, td)
+        m.clear_flops()
+        cur = (float(loss), float(pen), tr.grad.clone())
+        if ref is None:
+            ref = cur
+        assert cur[0] == ref[0] and cur[1] == ref[1], (step, cur[:2], ref[:2])
+        assert torch.equal(cur[2], ref[2]), f"step {step}: gradient arena differs from the eager step"
+
+
+def test_gpu_train_batch256_properties(hip, x2_manifest):
+    """BASELINE config 3 size (batch 256, 3x224x224, fp32): the slab counts of the BN / weight-gradient reductions and the
+    row-chunked launches depend on the batch, so the step is checked at its own size through properties:
+      * replication: a batch of 64 copies of 4 images has the batch statistics, loss, penalty / batchsize and mean
+        gradient of those 4 images -> equals the batch-4 step (which the oracle tests pin) up to summation order;
+      * determinism of the replayed step; permutation of the samples changes loss / gradient only by rounding;
+      * loss, penalty and BN running statistics equal the CPU oracle's train-mode forward of the same 256 images."""
+    from sod100k_amd.tools.train import FusedTrainer
+    lib, dev = hip
+    B, R = 256, 4
+    base = torch.from_numpy(I.randn_batch(70, R))
+    tb = torch.from_numpy(I.binary_target(71, R))
+
+    def run(x, t, steps=1):
+        m, sd = P.make_model(lib, x2_manifest, dev)
+        m.train(); m.set_batchsize(x.shape[0]); m.clear_flops(); m.flops_hook(1.0)
+        tr = FusedTrainer(m, lr=0.0, weight_decay=0.0, flops_weight=3.0, batchsize=x.shape[0], lib=lib)
+        xd, td = x.to(dev), t.to(dev)
+        outs = []
+        for _ in range(steps):
+            loss, pen = tr.step(xd, td)
+            m.clear_flops()
+            outs.append((float(loss), float(pen), tr.grad.clone()))
+        stats = {k: v.cpu().clone() for k, v in m.state_dict().items() if "running_" in k}
+        del tr, m                                  # a batch-256 training workspace is 61 GiB: one at a time
+        torch.cuda.empty_cache()
+        return stats, outs
+
+    _, o4 = run(base, tb)
+    x256, t256 = base.repeat(B // R, 1, 1, 1), tb.repeat(B // R, 1, 1, 1)
+    _, o256 = run(x256, t256, steps=5)
+    l4, p4, g4 = o4[0]
+    for step, (l, p, g) in enumerate(o256):
+        assert l == o256[0][0] and p == o256[0][1] and torch.equal(g, o256[0][2]), f"step {step} not deterministic"
+    l, p, g = o256[0]
+    assert abs(l - l4) <= 1e-6 * max(1.0, abs(l4)), (l, l4)
+    assert abs(p - p4) <= 1e-5 * max(1.0, abs(p4)), (p, p4)
+    num = float(((g - g4).double() ** 2).sum()) ** 0.5
+    den = float((g4.double() ** 2).sum()) ** 0.5
+    print(f"batch 256 (64 x 4 images) vs batch 4: loss {l:.7f} / {l4:.7f}, gradient rel-L2 {num / den:.2e}")
+    assert num / den <= 1e-3, num / den
+    # permutation of a batch of 256 distinct images
+    gen = torch.Generator().manual_seed(72)
+    xr = torch.randn(B, 3, 224, 224, generator=gen)
+    trg = (torch.rand(B, 1, 224, 224, generator=gen) > 0.5).float()
+    got, orr = run(xr, trg)
+    perm = torch.randperm(B, generator=gen)
+    _, op = run(xr[perm], trg[perm])
+    assert abs(orr[0][0] - op[0][0]) <= 1e-6 * max(1.0, abs(orr[0][0]))
+    num = float(((orr[0][2] - op[0][2]).double() ** 2).sum()) ** 0.5
+    den = float((orr[0][2].double() ** 2).sum()) ** 0.5
+    assert num / den <= 1e-3, num / den
+    # oracle: train-mode forward of the same 256 images on the host (no autograd: 215 GB of activations otherwise)
+    sd = O.load_weights(x2_manifest)
+    cfg = O.load_layer_config_json(x2_manifest)
+    class GapTaps(dict):                           # keep only the per-image channel means (all gap_penalty reads)
+        def __setitem__(self, k, v):
+            super().__setitem__(k, [None if t is None else torch.nn.functional.adaptive_avg_pool2d(t, 1) for t in v])
+
+    taps = GapTaps()
+    with torch.no_grad():
+        out = O.csnet_forward(cfg, sd, xr, training=True, taps=taps)
+        bce = float(torch.nn.functional.binary_cross_entropy_with_logits(out, trg))
+        pen = float(O.gap_penalty(sd, taps, O.flop_weights(cfg, 1.0), B))
+    print(f"batch 256 vs oracle: bce {orr[0][0]:.7f} / {bce:.7f}, penalty {orr[0][1]:.7f} / {pen:.7f}")
+    assert abs(orr[0][0] - bce) <= 2e-5 * max(1.0, abs(bce))
+    assert abs(orr[0][1] - pen) <= 2e-4 * max(1.0, abs(pen))
+    for k, v in sd.items():                        # the oracle's forward updated sd's running statistics in place
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert ((got[k] - v).abs() / (1 + v.abs())).max().item() <= 1e-4, k
