@@ -50,40 +50,45 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(man, batch=8, target_s=12.0):
-    """Time the CPU oracle on a bounded sample (about 10-30 s of CPU work in total): batch-8 throughput on all threads,
-    the reference caller's batch-1 loop (test.py:87-93) on all threads and on ONE thread."""
+def cpu_baseline(man, batch=8, target_s=20.0):
+    """Time the CPU oracle on a bounded sample (about 20-30 s of CPU work in total): batch-8 throughput and
+    the reference caller's batch-1 loop (test.py:87-93) at several thread counts.  ``value`` is the BEST throughput found
+    (on a 128-core box the oneDNN kernels of this small network are fastest far below all threads), ``cores`` the threads
+    it used; every measured point is listed."""
     from oracle import csnet_oracle as O, inputs as I
     sd = O.load_weights(man)
     lc = O.load_layer_config_json(man)
     x = torch.from_numpy(I.randn_batch(0, batch))
-    cores = torch.get_num_threads()
+    all_threads = torch.get_num_threads()
+    counts = sorted({1, min(8, all_threads), min(32, all_threads), all_threads})
 
     def loop(xx, budget, nmax):
         O.csnet_forward(lc, sd, xx)          # warm-up
         ts = []
         t_end = time.perf_counter() + budget
-        while len(ts) < nmax and (len(ts) < 3 or time.perf_counter() < t_end):
+        while len(ts) < nmax and (len(ts) < 2 or time.perf_counter() < t_end):
             t0 = time.perf_counter()
             O.csnet_forward(lc, sd, xx)
             ts.append(time.perf_counter() - t0)
         return ts
 
+    points = []
+    t_begin = time.perf_counter()
     with torch.no_grad():
-        t8 = loop(x, target_s, 20)
-        t1 = loop(x[:1], 4.0, 20)
-        torch.set_num_threads(1)
-        t1s = loop(x[:1], 4.0, 5)
-        torch.set_num_threads(cores)
-    dt = sum(t8)
-    return dict(value=round(batch * len(t8) / dt, 3), unit="images/sec", cores=cores, kind="port",
-                cpu_model=_cpu_model(),
-                b1_latency_ms=round(statistics.median(t1) * 1e3, 2),
-                b1_images_per_sec=round(1.0 / statistics.median(t1), 3),
-                one_thread_images_per_sec=round(1.0 / statistics.median(t1s), 3),
-                sample=f"{len(t8)} eval forwards of batch {batch} (3x224x224, seed 0) through oracle/csnet_oracle.py "
-                       f"(torch {torch.__version__} CPU ops, {cores} threads), {dt:.1f} s; + {len(t1)} batch-1 forwards "
-                       f"on {cores} threads (median) and {len(t1s)} on 1 thread")
+        for nthr in counts:
+            torch.set_num_threads(nthr)
+            t8 = loop(x, target_s / (2 * len(counts)), 10)
+            t1 = loop(x[:1], target_s / (2 * len(counts)), 10)
+            points.append({"threads": nthr, "batch8_images_per_sec": round(batch / statistics.median(t8), 3),
+                           "batch1_latency_ms": round(statistics.median(t1) * 1e3, 2), "forwards": len(t8) + len(t1)})
+        torch.set_num_threads(all_threads)
+    best = max(points, key=lambda p: max(p["batch8_images_per_sec"], 1e3 / p["batch1_latency_ms"]))
+    best_v = max(best["batch8_images_per_sec"], 1e3 / best["batch1_latency_ms"])
+    return dict(value=round(best_v, 3), unit="images/sec", cores=best["threads"], kind="port",
+                cpu_model=_cpu_model(), host_threads=all_threads, points=points,
+                sample=f"{sum(p['forwards'] for p in points)} eval forwards (batch {batch} and batch 1, 3x224x224, seed 0) "
+                       f"through oracle/csnet_oracle.py (torch {torch.__version__} CPU ops) at {counts} threads, "
+                       f"{time.perf_counter() - t_begin:.1f} s; value = best point")
 
 
 def _free_port():

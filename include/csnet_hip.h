@@ -107,8 +107,11 @@ void csn_plan_destroy(csn_plan* plan);
  * CSN_OPT_FUSE_CLS [1]: the cls_layer (1x1 + bias, csnet.py:306-308) is evaluated in the epilogue of the unit that
  * feeds it (CSFHead.fuse1x1), whose 79-channel output is then never written; 0 = separate launches (probes).
  * CSN_OPT_TILED3 [1]: 3x3 gOctConv passes run as an LDS-tiled implicit GEMM (goct_c3_kernel); 0 = per-pixel tap
- * gathers in goct_pw_kernel (same arithmetic up to the summation order inside a k step). */
-enum csn_option { CSN_OPT_FUSE_DW = 1, CSN_OPT_GRAPH = 2, CSN_OPT_FUSE_CLS = 3, CSN_OPT_TILED3 = 4 };
+ * gathers in goct_pw_kernel (same arithmetic up to the summation order inside a k step).
+ * CSN_OPT_FUSE_ILB [56]: a 1x1 ILBlock (conv1x1 -> conv3x3_1 -> conv3x3_2, csnet.py:72-76) whose finest output branch is
+ * at least this many pixels wide runs as ONE kernel (ilb_kernel: one wave per column strip, every intermediate in
+ * registers); 0 = unit-level kernels only (per-unit parity probes). */
+enum csn_option { CSN_OPT_FUSE_DW = 1, CSN_OPT_GRAPH = 2, CSN_OPT_FUSE_CLS = 3, CSN_OPT_TILED3 = 4, CSN_OPT_FUSE_ILB = 5 };
 int csn_plan_set_option(csn_plan* plan, int32_t option, int32_t value);
 
 size_t csn_plan_workspace_bytes(const csn_plan* plan);

@@ -61,10 +61,11 @@ def encode_checkpoint(ref, name, csnet):
     tensors = []
     for k, v in sd.items():
         a = v.detach().cpu().numpy()
+        shape = list(a.shape)                 # taken BEFORE ascontiguousarray, which promotes 0-d arrays to shape [1]
         a = np.ascontiguousarray(a.astype(a.dtype.newbyteorder("<")))
         while len(blob) % 16:
             blob.append(0)
-        tensors.append(dict(name=k, dtype=str(a.dtype), shape=list(a.shape), offset=len(blob)))
+        tensors.append(dict(name=k, dtype=str(a.dtype), shape=shape, offset=len(blob)))
         blob += a.tobytes()
     lc_json = []
     for e in lc[:-1]:

@@ -60,9 +60,10 @@ static inline float2 csn_ld2(csn_buf b, unsigned voff, unsigned soff) {
   if (!(o + 8u <= b.n && o + 8u > o)) return make_float2(0.f, 0.f);
   return *reinterpret_cast<const float2*>(b.p + o);
 }
-// store through a bounded resource: dropped when the lane's own offset (voff) is out of range
+// store through a bounded resource: dropped when voffset + soffset is out of range (the hardware's rule, see below)
 static inline void csn_st1(csn_buf b, unsigned voff, unsigned soff, float v) {
-  if (voff + 4u <= b.n && voff + 4u > voff) *reinterpret_cast<float*>(const_cast<char*>(b.p) + voff + soff) = v;
+  const unsigned o = voff + soff;
+  if (o + 4u <= b.n && o + 4u > o && o >= voff) *reinterpret_cast<float*>(const_cast<char*>(b.p) + o) = v;
 }
 static inline float4 csn_ld4(csn_buf b, unsigned voff, unsigned soff) {
   const unsigned o = voff + soff;

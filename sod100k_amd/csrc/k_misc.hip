@@ -16,20 +16,20 @@ __global__ __launch_bounds__(CSN_BLOCK) void csn_prep_kernel(const CsnPrepJob* _
   float* dst = packed + j.dst;
   const float eps = 1e-5f;  // nn.BatchNorm2d default
   switch (j.kind) {
-    case CSN_PREP_COPY:
-      for (int i = tid; i < j.n; i += CSN_BLOCK) dst[i] = j.p0f * arena[j.src0 + i];
+    case CSN_PREP_COPY:      // p2 > 0: strided destination dst[i * p2 + p3] (per-channel records of k_ilb.hip)
+      for (int i = tid; i < j.n; i += CSN_BLOCK) dst[j.p2 > 0 ? (int64_t)i * j.p2 + j.p3 : i] = j.p0f * arena[j.src0 + i];
       break;
     case CSN_PREP_FILL:
       for (int i = tid; i < j.n; i += CSN_BLOCK) dst[i] = j.p0f;
       break;
     case CSN_PREP_BN_SCALE:
       for (int i = tid; i < j.n; i += CSN_BLOCK)
-        dst[i] = arena[j.src0 + i] / sqrtf(arena[j.src1 + i] + eps);
+        dst[j.p2 > 0 ? (int64_t)i * j.p2 + j.p3 : i] = arena[j.src0 + i] / sqrtf(arena[j.src1 + i] + eps);
       break;
     case CSN_PREP_BN_SHIFT:
       for (int i = tid; i < j.n; i += CSN_BLOCK) {
         const float sc = arena[j.src0 + i] / sqrtf(arena[j.src1 + i] + eps);
-        dst[i] = arena[j.src2 + i] - arena[j.src3 + i] * sc;
+        dst[j.p2 > 0 ? (int64_t)i * j.p2 + j.p3 : i] = arena[j.src2 + i] - arena[j.src3 + i] * sc;
       }
       break;
     case CSN_PREP_ROWS: {

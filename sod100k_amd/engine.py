@@ -106,8 +106,10 @@ class Engine:
         self.train = bool(train)
         if self.train:      # z / gradient / scratch buffers + backward weight images (before the workspace query)
             N.check(lib, lib.csn_plan_enable_training(plan), "csn_plan_enable_training")
-        if os.environ.get("CSN_TILED3") is not None:      # A/B switch for measurements
+        if os.environ.get("CSN_TILED3") is not None:      # A/B switches for measurements
             self.set_option(N.OPT_TILED3, int(os.environ["CSN_TILED3"]))
+        if os.environ.get("CSN_FUSE_ILB") is not None:
+            self.set_option(N.OPT_FUSE_ILB, int(os.environ["CSN_FUSE_ILB"]))
         self.n_units = len(units)
         self.n_acts = len(acts)
         nbytes = int(lib.csn_plan_workspace_bytes(plan))

@@ -66,6 +66,7 @@ struct Ctx {
   uint3 tIdx, bIdx;
   dim3 bDim, gDim;
   unsigned char* smem = nullptr;
+  float xch[1024];            // cross-lane exchange table of the block being run (DPP emulation, k_ilb.hip)
   void* sched_sp = nullptr;   // saved stack pointer of the block scheduler (x86-64 fast path)
   ucontext_t sched;           // portable path
 };
