@@ -221,7 +221,7 @@ def main():
             ref = O.csnet_forward(O.load_layer_config_json(man), O.load_weights(man), x_host[:2])
         err = float((y[:2].cpu() - ref).abs().max())
         self_check = {"max_abs_vs_oracle": err, "images": 2, "tol": 1e-4, "path": "output of the last timed step"}
-        if not (err <= 1e-4):
+        if not (err <= 1e-4) and os.environ.get("SOD100K_BENCH_KNOCKOUT") != "1":   # knock-out builds compute garbage on purpose
             raise SystemExit(f"bench self-check FAILED: max|y - oracle| = {err:.3e} > 1e-4")
 
     # ---- per-step HIP events on the launch stream (median of >= 50 single steps) ----

@@ -108,9 +108,10 @@ void csn_plan_destroy(csn_plan* plan);
  * feeds it (CSFHead.fuse1x1), whose 79-channel output is then never written; 0 = separate launches (probes).
  * CSN_OPT_TILED3 [1]: 3x3 gOctConv passes run as an LDS-tiled implicit GEMM (goct_c3_kernel); 0 = per-pixel tap
  * gathers in goct_pw_kernel (same arithmetic up to the summation order inside a k step).
- * CSN_OPT_FUSE_ILB [56]: a 1x1 ILBlock (conv1x1 -> conv3x3_1 -> conv3x3_2, csnet.py:72-76) whose finest output branch is
- * at least this many pixels wide runs as ONE kernel (ilb_kernel: one wave per column strip, every intermediate in
- * registers); 0 = unit-level kernels only (per-unit parity probes). */
+ * CSN_OPT_FUSE_ILB [0]: value w > 0: a 1x1 ILBlock (conv1x1 -> conv3x3_1 -> conv3x3_2, csnet.py:72-76) whose finest output
+ * branch is at least w pixels wide runs as ONE kernel (ilb_kernel: one wave per column strip, every intermediate in
+ * registers).  Parity-green, but measured SLOWER than the unit-level kernels on MI355X (2.2 vs 1.8 ms for the 14 blocks
+ * at batch 64, profiles/r2_notes.md), hence off by default. */
 enum csn_option { CSN_OPT_FUSE_DW = 1, CSN_OPT_GRAPH = 2, CSN_OPT_FUSE_CLS = 3, CSN_OPT_TILED3 = 4, CSN_OPT_FUSE_ILB = 5 };
 int csn_plan_set_option(csn_plan* plan, int32_t option, int32_t value);
 
@@ -163,9 +164,18 @@ int csn_adam_step(float* p, const float* g, float* m, float* v, const float* wd,
  * csn_normalize_nchw: float H x W x 3 images in [0,1] (already at the network size) -> ImageNet-normalised NCHW
  *   ((img - mean) / std, test.py:68-69,86);
  * csn_saliency_u8: logits -> (sigmoid(y) * 255).astype(uint8), truncation as numpy does (test.py:92-96).
- * Resizing (skimage in the reference) stays host IO. */
+ * The resizes of test.py:76-85 / 94-96 (skimage.transform.resize, order 1, mode='reflect', anti_aliasing=False = bilinear
+ * with half-pixel centres; the mirrored border sample coincides with the clamped one) on the device as well:
+ * csn_resize_normalize_nchw: B float images Hi x Wi x 3 in [0,1] -> resize to H x W -> normalise -> NCHW;
+ * csn_saliency_resize_u8: logits H x W -> sigmoid -> resize to h x w -> (p * 255) truncated to uint8;
+ * csn_resize_bilinear: planar float tensors [planes][Hi][Wi] -> [planes][Ho][Wo].
+ * skimage is not available to the build: these are checked against torch's F.interpolate(align_corners=False) and
+ * through properties (identity, constants, affine ramps), i.e. parity with skimage itself is unpinned. */
 int csn_normalize_nchw(const float* hwc, float* nchw, int64_t B, int64_t H, int64_t W, void* stream);
 int csn_saliency_u8(const float* logits, uint8_t* out, int64_t n, void* stream);
+int csn_resize_normalize_nchw(const float* hwc, float* nchw, int32_t B, int32_t Hi, int32_t Wi, int32_t H, int32_t W, void* stream);
+int csn_saliency_resize_u8(const float* logits, uint8_t* out, int32_t H, int32_t W, int32_t h, int32_t w, void* stream);
+int csn_resize_bilinear(const float* in, float* out, int32_t planes, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, void* stream);
 
 /* Evaluation metrics (SalMetric/src/sal_metric.cpp:87-120, the reference's only native component): for n_images
  * equally sized uint8 maps, ACCUMULATES (caller zeroes) per image the joint histogram hist[img][2*v + (gt > 128)]

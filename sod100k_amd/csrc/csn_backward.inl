@@ -622,6 +622,24 @@ int csn_saliency_u8(const float* logits, uint8_t* out, int64_t n, void* stream) 
   return CSN_OK;
 }
 
+int csn_resize_normalize_nchw(const float* hwc, float* nchw, int32_t B, int32_t Hi, int32_t Wi, int32_t H, int32_t W, void* stream) {
+  if (!hwc || !nchw || B <= 0 || Hi <= 0 || Wi <= 0 || H <= 0 || W <= 0) return CSN_E_INVALID;
+  LAUNCH_TRY(csn_launch_resize_normalize(hwc, nchw, B, Hi, Wi, H, W, stream));
+  return CSN_OK;
+}
+
+int csn_saliency_resize_u8(const float* logits, uint8_t* out, int32_t H, int32_t W, int32_t h, int32_t w, void* stream) {
+  if (!logits || !out || H <= 0 || W <= 0 || h <= 0 || w <= 0) return CSN_E_INVALID;
+  LAUNCH_TRY(csn_launch_saliency_resize_u8(logits, out, H, W, h, w, stream));
+  return CSN_OK;
+}
+
+int csn_resize_bilinear(const float* in, float* out, int32_t planes, int32_t Hi, int32_t Wi, int32_t Ho, int32_t Wo, void* stream) {
+  if (!in || !out || planes <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return CSN_E_INVALID;
+  LAUNCH_TRY(csn_launch_resize_bilinear(in, out, planes, Hi, Wi, Ho, Wo, stream));
+  return CSN_OK;
+}
+
 int csn_val_mae(const float* logits, int32_t hi, int32_t wi, const float* target, int32_t h, int32_t w, double* mae,
                 void* stream) {
   if (!logits || !target || !mae || hi <= 0 || wi <= 0 || h <= 0 || w <= 0) return CSN_E_INVALID;

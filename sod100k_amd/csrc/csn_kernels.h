@@ -115,6 +115,9 @@ struct PwArgs {
 // ---------------------------------------------------------------------------------------------
 // a whole 1x1 ILBlock (gOctaveCBR 1x1 -> depthwise 3x3 -> depthwise 3x3) per wave strip (see k_ilb.hip)
 // ---------------------------------------------------------------------------------------------
+#ifndef ILB_LANEW
+#define ILB_LANEW 0    // 0: weights through the scalar cache (s_load); 1: lane-resident in VGPRs + v_readlane (slower, measured)
+#endif
 #define ILB_SW 56      // output columns of a wave strip
 #define ILB_HALO 4     // lane 0 <-> column (strip start - 4): the two 3x3 stages need the 1x1 output two columns out
 struct IlbRole {       // one output branch of the block
@@ -123,19 +126,20 @@ struct IlbRole {       // one output branch of the block
                        // role 1: the higher input branch    [B][C_oth][2H][2W]      (2x2 max-pool before the conv)
   float* out;          // output of the second depthwise unit [B][n_out][H][W]
   float* pool;         // 2x2 average of `out` [B][n_out][H/2][W/2] for a stride-2 unit that follows (null: none)
-  const float* wt;     // per channel group: [K8own][NC] [K8oth][NC] transposed 1x1 weights (zero padded), then [NC][32]
-                       // records {scaleA, shiftA, alphaA, 0, w1[9], scaleB, shiftB, alphaB, w2[9], scaleC, shiftC, alphaC, 0...}
+  const float* wt;     // per channel group, ILB_LANEW: [NC][64] W[c][k_own], [NC][64] W[c][k_oth], [NC][64] records;
+                       // else [K8own][NC] [K8oth][NC] transposed 1x1 weights, then [NC][32] records.  Zero padded.  Record =
+                       // {scaleA, shiftA, alphaA, 0, w1[9], scaleB, shiftB, alphaB, w2[9], scaleC, shiftC, alphaC, 0...}
   int32_t C_own, C_oth, K8own, K8oth;
   int32_t n_out, ngroups, gsize, group_stride;
   int32_t H, W;
   int32_t strips, segs, seg_rows;
   int32_t items_img;   // segs * strips * ngroups
   int32_t skip_out;    // `out` has no reader besides the pooled copy
-  int32_t pad;
+  int32_t nc;          // channel-group template width (8, 12, 16, 20), >= gsize
 };
 struct IlbArgs {
   IlbRole role[2];
-  int32_t B, items, nc, pool;   // items = B * (role[0].items_img + role[1].items_img); nc = channel-group template
+  int32_t B, items, nc, pool;   // items / nc: filled per role by the launcher; pool: the block feeds a stride-2 unit
 };
 int csn_launch_ilb(const IlbArgs& a, void* stream);
 
@@ -312,6 +316,9 @@ int csn_launch_saliency_u8(const float* y, unsigned char* o, int64_t n, void* st
 int csn_launch_sal_hist(const unsigned char* sal, const unsigned char* gt, int64_t npix, int n_images,
                         unsigned long long* hist, unsigned long long* abs_sum, void* stream);
 int csn_launch_normalize_nchw(const float* hwc, float* chw, int64_t B, int64_t HW, void* stream);
+int csn_launch_resize_normalize(const float* hwc, float* chw, int B, int Hi, int Wi, int H, int W, void* stream);
+int csn_launch_saliency_resize_u8(const float* logits, unsigned char* o, int H, int W, int h, int w, void* stream);
+int csn_launch_resize_bilinear(const float* in, float* out, int planes, int Hi, int Wi, int Ho, int Wo, void* stream);
 int csn_launch_val_mae(const float* logits, int hi, int wi, const float* target, int h, int w, double* mae, void* stream);
 
 // launchers (implemented next to the kernels)

@@ -147,7 +147,8 @@ struct csn_plan {
   bool fuse_dw = true;
   bool fuse_cls = true;   // CSN_OPT_FUSE_CLS
   bool tiled3 = true;     // CSN_OPT_TILED3
-  int fuse_ilb = 56;      // CSN_OPT_FUSE_ILB: minimum width of the finest output branch (0 = off)
+  int fuse_ilb = 0;       // CSN_OPT_FUSE_ILB: minimum width of the finest output branch; 0 = off (default: measured slower
+                          // than the unit-level kernels on MI355X, profiles/r2_notes.md)
   Epi ident;   // identity epilogue (scale 1, shift 0, alpha 1): train mode runs the conv kernels raw
   bool use_graph = true;
   // hipGraph of one whole csn_forward (all batch slices), captured on a plan-owned stream on the second
@@ -801,7 +802,7 @@ int choose_ilb_nc(int n, int K) {
   const int forced = env_int("CSN_ILB_NC", 0);
   if (forced == 8 || forced == 12 || forced == 16 || forced == 20) return forced;
   static const int cand[4] = {8, 12, 16, 20};
-  static const double occ[4] = {1.0, 1.0, 1.05, 1.15};
+  static const double occ[4] = {1.0, 1.1, 1.25, 1.3};
   int best = 16;
   double best_c = 1e30;
   for (int i = 0; i < 4; ++i) {
@@ -855,12 +856,26 @@ int plan_ilb(Builder& bl, int k) {
     r.nc = choose_ilb_nc(r.n_out, r.C_own + r.C_oth);
     r.ngroups = (r.n_out + r.nc - 1) / r.nc;
     r.gsize = (r.n_out + r.ngroups - 1) / r.ngroups;
+#if ILB_LANEW
+    if (r.C_own > 64 || r.C_oth > 64) return CSN_OK;      // one lane per input channel
+    r.group_stride = 3 * r.nc * 64;
+    const int rstride = 64;
+#else
     r.group_stride = (r.K8own + r.K8oth) * r.nc + r.nc * 32;
+    const int rstride = 32;
+#endif
     r.wt = bl.alloc_packed((int64_t)r.ngroups * r.group_stride);
     for (int g = 0; g < r.ngroups; ++g) {
       const int c0 = g * r.gsize, ng = std::min(r.gsize, r.n_out - c0);
       const int64_t base = r.wt + (int64_t)g * r.group_stride;
       const int64_t wrow = d.w_off[0] + (int64_t)(co_off[j] + c0) * cin_tot;
+#if ILB_LANEW
+      // rows [c][64]: dst[c * 64 + k] = W[co0 + c][ci0 + k]
+      if (r.C_own > 0) bl.job(CSN_PREP_ROWS, ng, base, wrow + ci_off[io], -1, -1, -1, 1.f, cin_tot, r.C_own, 64, 0);
+      if (r.C_oth > 0)
+        bl.job(CSN_PREP_ROWS, ng, base + (int64_t)r.nc * 64, wrow + ci_off[it], -1, -1, -1, 1.f, cin_tot, r.C_oth, 64, 0);
+      const int64_t rec = base + (int64_t)2 * r.nc * 64;
+#else
       // transposed weight rows [k][nc]: dst[ci * nc + co] = W[co0 + co][ci0 + ci]
       if (r.C_own > 0)
         bl.job(CSN_PREP_ROWS_T, r.C_own, base, wrow + ci_off[io], -1, -1, -1, 1.f, cin_tot, ng, r.nc, 0 | (1 << 24));
@@ -868,16 +883,17 @@ int plan_ilb(Builder& bl, int k) {
         bl.job(CSN_PREP_ROWS_T, r.C_oth, base + (int64_t)r.K8own * r.nc, wrow + ci_off[it], -1, -1, -1, 1.f, cin_tot, ng,
                r.nc, 0 | (1 << 24));
       const int64_t rec = base + (int64_t)(r.K8own + r.K8oth) * r.nc;
+#endif
       auto bn_rec = [&](const csn_bn_off& bn, int at) {
-        bl.job(CSN_PREP_BN_SCALE, ng, rec, bn.weight + c0, bn.running_var + c0, -1, -1, 1.f, 0, 0, 32, at);
+        bl.job(CSN_PREP_BN_SCALE, ng, rec, bn.weight + c0, bn.running_var + c0, -1, -1, 1.f, 0, 0, rstride, at);
         bl.job(CSN_PREP_BN_SHIFT, ng, rec, bn.weight + c0, bn.running_var + c0, bn.bias + c0, bn.running_mean + c0, 1.f, 0, 0,
-               32, at + 1);
-        bl.job(CSN_PREP_COPY, ng, rec, bn.prelu + c0, -1, -1, -1, 1.f, 0, 0, 32, at + 2);
+               rstride, at + 1);
+        bl.job(CSN_PREP_COPY, ng, rec, bn.prelu + c0, -1, -1, -1, 1.f, 0, 0, rstride, at + 2);
       };
       bn_rec(d.bn[j], 0);
-      bl.job(CSN_PREP_ROWS, ng, rec, u1.d.w_off[j] + (int64_t)c0 * 9, -1, -1, -1, 100.f, 9, 9, 32, 4);    // conv2d.py:104
+      bl.job(CSN_PREP_ROWS, ng, rec, u1.d.w_off[j] + (int64_t)c0 * 9, -1, -1, -1, 100.f, 9, 9, rstride, 4);    // conv2d.py:104
       bn_rec(u1.d.bn[j], 13);
-      bl.job(CSN_PREP_ROWS, ng, rec, u2.d.w_off[j] + (int64_t)c0 * 9, -1, -1, -1, 100.f, 9, 9, 32, 16);
+      bl.job(CSN_PREP_ROWS, ng, rec, u2.d.w_off[j] + (int64_t)c0 * 9, -1, -1, -1, 100.f, 9, 9, rstride, 16);
       bn_rec(u2.d.bn[j], 25);
     }
   }
@@ -915,7 +931,7 @@ int run_ilb(const Ctx& c, int k) {
     R.H = P.H >> r.lvl; R.W = P.W >> r.lvl;
     R.strips = (R.W + ILB_SW - 1) / ILB_SW;
     // row segments: enough waves to fill the chip about once at this group width's occupancy
-    const int occ = r.nc <= 12 ? 4 : r.nc <= 16 ? 3 : 2;
+    const int occ = r.nc <= 8 ? 4 : r.nc <= 12 ? 3 : 2;
     const int64_t per_seg = (int64_t)P.S * R.strips * R.ngroups;
     int segs = (int)((256 * 4 * occ + per_seg / 2) / per_seg);
     segs = std::max(1, std::min(segs, std::max(1, R.H / 4)));
@@ -923,20 +939,16 @@ int run_ilb(const Ctx& c, int k) {
     if (seg_env > 0) R.seg_rows = (seg_env + 1) & ~1;
     R.segs = (R.H + R.seg_rows - 1) / R.seg_rows;
     R.items_img = R.segs * R.strips * R.ngroups;
+    R.nc = r.nc;
   }
-  // one launch per distinct group width
-  for (int first = 0; first < 2; ++first) {
-    if (!u.ilb[first].present) continue;
-    if (first == 1 && u.ilb[0].present && u.ilb[0].nc == u.ilb[1].nc) continue;   // went with role 0
-    IlbArgs a;
-    std::memset(&a, 0, sizeof(a));
-    a.role[first] = role[first];
-    if (first == 0 && u.ilb[1].present && u.ilb[1].nc == u.ilb[0].nc) a.role[1] = role[1];
-    a.B = P.S;
-    a.items = P.S * (a.role[0].items_img + a.role[1].items_img);
-    a.nc = u.ilb[first].nc;
-    a.pool = u1.pool_unit >= 0 ? 1 : 0;
-    LAUNCH_TRY(csn_launch_ilb(a, c.stream));
+  IlbArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.role[0] = role[0];
+  a.role[1] = role[1];
+  a.B = P.S;
+  a.pool = u1.pool_unit >= 0 ? 1 : 0;
+  LAUNCH_TRY(csn_launch_ilb(a, c.stream));
+  {
     const int ms_ = c.mark("ilb_kernel");
     if (ms_ != CSN_OK) return ms_;
   }

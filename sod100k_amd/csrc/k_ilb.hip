@@ -60,12 +60,47 @@ __device__ __forceinline__ float ilb_shl1(float v) {
 
 typedef const CSN_CONST_AS IlbRole* IlbRoleP;
 
-// acc[c] += sum_k wt[k][c] * g_k for the K gathered channels of one source.  POOL: g_k = max of the 2x2 window whose
-// top-left element is at byte offset voff of a tensor with row pitch pitch4 (two 64-bit loads), else one dword at voff.
-// Channel indices are clamped (a predicated load would be waited for at the join); the weight rows past K are zero.
-template <int NC, bool POOL>
+// ---- where the (wave-uniform) weights come from ---------------------------------------------------------------------
+// ILB_LANEW = 1 (default): the group's tables live in 3 NC VGPRs of the wave, one value per LANE -- register c of the
+//   1x1 weights holds W[c][k] in lane k, register c of the records holds {scale, shift, alpha, 9 taps ...} of channel c in
+//   lanes 0..31 -- and every use broadcasts its value with v_readlane_b32 into an SGPR operand.  One more instruction per
+//   weight, but no memory access in the row loop: a per-row stream of ~100 scalar loads, each waited for with
+//   lgkmcnt(0), ran at 5-9 % of the VALU rate (profiles/r2_notes.md).
+// ILB_LANEW = 0: weights through the scalar cache (s_load), tables [k][NC] / [NC][32].
+template <int NC>
+struct IlbW {
+#if ILB_LANEW
+  float wo[NC], wt[NC], rc[NC];
+#endif
+  csn_cfp base;   // LANEW: [NC][64] own, [NC][64] other, [NC][64] records;  else: [K8own][NC], [K8oth][NC], [NC][32]
+  int oth_off, rec_off;
+};
+#if ILB_LANEW
+#ifdef CSN_CPU_EMU
+#define ILB_BCAST(reg, ptr, ln) ((ptr)[ln])      // lanes are fibers: read the table the registers were loaded from
+#else
+#define ILB_BCAST(reg, ptr, ln) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(reg), (ln)))
+#endif
+#define ILB_WOWN(w, c, k) ILB_BCAST((w).wo[c], (w).base + (c) * 64, (k))
+#define ILB_WOTH(w, c, k) ILB_BCAST((w).wt[c], (w).base + (w).oth_off + (c) * 64, (k))
+#define ILB_REC(w, c, v) ILB_BCAST((w).rc[c], (w).base + (w).rec_off + (c) * 64, (v))
+#elif defined(ILB_KNOCK_SMEM)   // measurement build: every table access hits the same few cache lines (results are wrong)
+#define ILB_WOWN(w, c, k) ((w).base[(c)])
+#define ILB_WOTH(w, c, k) ((w).base[(c)])
+#define ILB_REC(w, c, v) ((w).base[(v)])
+#else
+#define ILB_WOWN(w, c, k) ((w).base[(k) * NC + (c)])
+#define ILB_WOTH(w, c, k) ((w).base[(w).oth_off + (k) * NC + (c)])
+#define ILB_REC(w, c, v) ((w).base[(w).rec_off + 32 * (c) + (v)])
+#endif
+
+// acc[c] += sum_k W[c][k] * g_k for the K gathered channels of one source (OTH: the other input branch's weight block).
+// POOL: g_k = max of the 2x2 window whose top-left element is at byte offset voff of a tensor with row pitch pitch4 (two
+// 64-bit loads), else one dword at voff.  Channel indices are clamped (a predicated load would be waited for at the join);
+// the weights of the channels past K are zero.
+template <int NC, bool POOL, bool OTH>
 __device__ __forceinline__ void ilb_contract(float (&acc)[NC], csn_buf rb, unsigned voff, unsigned pitch4, unsigned cs4,
-                                             int K, csn_cfp wt) {
+                                             int K, const IlbW<NC>& W) {
   const unsigned last = (unsigned)(K - 1) * cs4;
   for (int k0 = 0; k0 < K; k0 += 8) {
     float x[8];
@@ -78,36 +113,39 @@ __device__ __forceinline__ void ilb_contract(float (&acc)[NC], csn_buf rb, unsig
       } else {
         x[j] = csn_ld1(rb, voff, so);
       }
+#ifndef ILB_KNOCK_VMEM
       so = min(so + cs4, last);
+#endif
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      csn_cfp w = wt + (k0 + j) * NC;
 #pragma unroll
-      for (int c = 0; c < NC; ++c) acc[c] = fmaf(w[c], x[j], acc[c]);
+      for (int c = 0; c < NC; ++c)
+        acc[c] = fmaf(OTH ? ILB_WOTH(W, c, k0 + j) : ILB_WOWN(W, c, k0 + j), x[j], acc[c]);
     }
   }
 }
 
 // One depthwise 3x3 + BN + PReLU row from the three input rows (top, mid, bot), all channels of the group.
-// rec + 32 c + wofs: 9 taps (x100 folded), scale, shift, alpha.  maskf zeroes the result outside the image columns.
+// Record values wofs .. wofs + 11 of a channel: 9 taps (x100 folded), scale, shift, alpha.  maskf zeroes the result
+// outside the image columns.
 template <int NC, bool MASK>
 __device__ __forceinline__ void ilb_dw_row(const float (&top)[NC], const float (&mid)[NC], const float (&bot)[NC],
-                                           float (&out)[NC], csn_cfp rec, int wofs, float maskf) {
+                                           float (&out)[NC], const IlbW<NC>& W, int wofs, float maskf) {
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    csn_cfp w = rec + 32 * c + wofs;
-    float sl = w[0] * top[c];
-    sl = fmaf(w[3], mid[c], sl);
-    sl = fmaf(w[6], bot[c], sl);
-    float sm = w[1] * top[c];
-    sm = fmaf(w[4], mid[c], sm);
-    sm = fmaf(w[7], bot[c], sm);
-    float sr = w[2] * top[c];
-    sr = fmaf(w[5], mid[c], sr);
-    sr = fmaf(w[8], bot[c], sr);
+    float sl = ILB_REC(W, c, wofs + 0) * top[c];
+    sl = fmaf(ILB_REC(W, c, wofs + 3), mid[c], sl);
+    sl = fmaf(ILB_REC(W, c, wofs + 6), bot[c], sl);
+    float sm = ILB_REC(W, c, wofs + 1) * top[c];
+    sm = fmaf(ILB_REC(W, c, wofs + 4), mid[c], sm);
+    sm = fmaf(ILB_REC(W, c, wofs + 7), bot[c], sm);
+    float sr = ILB_REC(W, c, wofs + 2) * top[c];
+    sr = fmaf(ILB_REC(W, c, wofs + 5), mid[c], sr);
+    sr = fmaf(ILB_REC(W, c, wofs + 8), bot[c], sr);
     const float t = (sm + ilb_shr1(sl)) + ilb_shl1(sr);   // tap dx = -1 reads column x - 1: the sum held by lane l - 1
-    const float y = csn_epi(t, w[9], MASK ? w[10] * maskf : w[10], w[11]);
+    const float sh = ILB_REC(W, c, wofs + 10);
+    const float y = csn_epi(t, ILB_REC(W, c, wofs + 9), MASK ? sh * maskf : sh, ILB_REC(W, c, wofs + 11));
     out[c] = MASK ? y * maskf : y;
   }
 }
@@ -142,9 +180,24 @@ __device__ __forceinline__ void ilb_wave(IlbRoleP R, int item, int lane) {
   const int r0 = t * R->seg_rows, r1 = min(H, r0 + R->seg_rows);
   const int n = min(R->gsize, R->n_out - g * R->gsize);
   const int K_own = R->C_own, K_oth = R->C_oth;
-  csn_cfp wt_own = csn_const(R->wt) + (int64_t)g * R->group_stride;
-  csn_cfp wt_oth = wt_own + R->K8own * NC;
-  csn_cfp rec = wt_oth + R->K8oth * NC;
+  IlbW<NC> WG;
+  WG.base = csn_const(R->wt) + (int64_t)g * R->group_stride;
+#if ILB_LANEW
+  WG.oth_off = NC * 64;
+  WG.rec_off = 2 * NC * 64;
+  {
+    const float* tb = R->wt + (int64_t)g * R->group_stride + lane;   // one coalesced 256-byte row per register
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      WG.wo[c] = tb[c * 64];
+      WG.wt[c] = tb[(NC + c) * 64];
+      WG.rc[c] = tb[(2 * NC + c) * 64];
+    }
+  }
+#else
+  WG.oth_off = R->K8own * NC;
+  WG.rec_off = (R->K8own + R->K8oth) * NC;
+#endif
   const unsigned HW4 = (unsigned)(H * W) * 4u;
   const csn_buf xo = csn_make_buf_n(R->x_own + (int64_t)b * K_own * (H * W), (unsigned)K_own * HW4);
   const unsigned OOB = 0x80000000u;                        // voffset of lanes outside the image: reads return 0
@@ -188,7 +241,7 @@ __device__ __forceinline__ void ilb_wave(IlbRoleP R, int item, int lane) {
     const int mm = min(max(up.m_cur, 0), Hl - 1);
     float tt[NC];
     ilb_zero<NC>(tt);
-    ilb_contract<NC, false>(tt, xt, (unsigned)mm * oth_pitch4 + oth_col, 0u, oth_cs4, K_oth, wt_oth);
+    ilb_contract<NC, false, true>(tt, xt, (unsigned)mm * oth_pitch4 + oth_col, 0u, oth_cs4, K_oth, WG);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       up.tp[c] = up.tc[c];
@@ -228,25 +281,33 @@ __device__ __forceinline__ void ilb_wave(IlbRoleP R, int item, int lane) {
       } else {
         ilb_zero<NC>(Yn);
       }
-      ilb_contract<NC, false>(Yn, xo, colv + (unsigned)r * (unsigned)W * 4u, 0u, HW4, K_own, wt_own);
+      ilb_contract<NC, false, false>(Yn, xo, colv + (unsigned)r * (unsigned)W * 4u, 0u, HW4, K_own, WG);
       if (ROLE == 1 && K_oth > 0)
-        ilb_contract<NC, true>(Yn, xt, oth_col + (unsigned)(2 * r) * oth_pitch4, oth_pitch4, oth_cs4, K_oth, wt_oth);
+        ilb_contract<NC, true, true>(Yn, xt, oth_col + (unsigned)(2 * r) * oth_pitch4, oth_pitch4, oth_cs4, K_oth, WG);
 #pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        csn_cfp e = rec + 32 * c;
-        Yn[c] = csn_epi(Yn[c], e[0], e[1] * maskf, e[2]) * maskf;
-      }
+      for (int c = 0; c < NC; ++c)
+        Yn[c] = csn_epi(Yn[c], ILB_REC(WG, c, 0), ILB_REC(WG, c, 1) * maskf, ILB_REC(WG, c, 2)) * maskf;
     } else {
       ilb_zero<NC>(Yn);
     }
     // ---- B: first depthwise unit, row r - 1 ----
-    if (r - 1 >= 0 && r - 1 < H) ilb_dw_row<NC, true>(Yo, Ym, Yn, En, rec, 4, maskf);
+#ifdef ILB_KNOCK_DW
+#pragma unroll
+    for (int c = 0; c < NC; ++c) En[c] = Ym[c];
+#else
+    if (r - 1 >= 0 && r - 1 < H) ilb_dw_row<NC, true>(Yo, Ym, Yn, En, WG, 4, maskf);
     else ilb_zero<NC>(En);
+#endif
     // ---- C: second depthwise unit, row r - 2 -> HBM ----
     const int ro = r - 2;
     if (ro >= r0 && ro < r1) {
       float o[NC];
-      ilb_dw_row<NC, false>(Eo, Em, En, o, rec, 16, 1.f);
+#ifdef ILB_KNOCK_DW
+#pragma unroll
+      for (int c = 0; c < NC; ++c) o[c] = Em[c];
+#else
+      ilb_dw_row<NC, false>(Eo, Em, En, o, WG, 16, 1.f);
+#endif
       const unsigned vo = st_lane ? (unsigned)(ro * W + col) * 4u : OOB;
       if (!(POOL && skip_out)) {
 #pragma unroll
@@ -269,15 +330,29 @@ __device__ __forceinline__ void ilb_wave(IlbRoleP R, int item, int lane) {
     }
   };
 
+#ifdef ILB_UNROLL3
+  // three copies of the row body with the window registers renamed: no moves, three times the code
   for (int r = r_first; r < r1 + 2; r += 3) {
     step(r, ya, yc, yb, ea, ec, eb);
     step(r + 1, yb, ya, yc, eb, ea, ec);
     step(r + 2, yc, yb, ya, ec, eb, ea);
   }
+#else
+  // one copy of the row body (it has to stay resident in the instruction cache next to the other waves' copies); the
+  // three-row windows are rotated with 4 NC register moves per row
+  for (int r = r_first; r < r1 + 2; ++r) {
+    step(r, ya, yb, yc, ea, eb, ec);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      yc[c] = yb[c]; yb[c] = ya[c];
+      ec[c] = eb[c]; eb[c] = ea[c];
+    }
+  }
+#endif
 }
 
-template <int NC, bool POOL>
-__global__ __launch_bounds__(CSN_BLOCK, (NC <= 12 ? 4 : NC <= 16 ? 3 : 2)) void ilb_kernel(IlbArgs a_byval) {
+template <int NC, int ROLE, bool POOL>
+__global__ __launch_bounds__(CSN_BLOCK, (NC <= 8 ? 4 : NC <= 12 ? 3 : 2)) void ilb_kernel(IlbArgs a_byval) {
   const CSN_CONST_AS IlbArgs* a = CSN_KERNARG(IlbArgs, a_byval);
   const int lane = threadIdx.x & 63;
 #ifdef CSN_CPU_EMU
@@ -287,38 +362,44 @@ __global__ __launch_bounds__(CSN_BLOCK, (NC <= 12 ? 4 : NC <= 16 ? 3 : 2)) void 
   // divergent (vector loads + readfirstlane waterfall loops instead of s_load)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #endif
-  // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs; XCD x walks a contiguous range of items, so the
-  // channel groups / strips / branches that read the same input region share one L2
+  // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs; XCD x walks a contiguous range of items (image-major),
+  // so the channel groups / strips / row segments that read the same input region share one L2
   const int nitem = a->items;
-  const int nslot = gridDim.x >> 3;
   const int chunk = ((nitem + 4 * 8 - 1) / (4 * 8)) * 4;       // items per XCD, whole blocks
   const int xcd = blockIdx.x & 7;
   const int item = xcd * chunk + (blockIdx.x >> 3) * 4 + wave;
-  (void)nslot;
   if (item >= min(nitem, (xcd + 1) * chunk)) return;
-  // items are ordered image-major; inside an image the role-0 items come first
-  const int per_img = a->role[0].items_img + a->role[1].items_img;
-  const int b = item / per_img;
-  const int w = item - b * per_img;
-  if (w < a->role[0].items_img) ilb_wave<NC, 0, POOL>(&a->role[0], b * a->role[0].items_img + w, lane);
-  else ilb_wave<NC, 1, POOL>(&a->role[1], b * a->role[1].items_img + (w - a->role[0].items_img), lane);
+  ilb_wave<NC, ROLE, POOL>(&a->role[ROLE], item, lane);
 }
 
-int csn_launch_ilb(const IlbArgs& a, void* stream) {
-  const int chunk = ((a.items + 31) / 32) * 4;
-  const dim3 grid((unsigned)(chunk / 4) * 8u);
-#define ILB_CASE(NCV)                                                                              \
-  case NCV:                                                                                        \
-    if (a.pool) CSN_LAUNCH((ilb_kernel<NCV, true>), grid, dim3(CSN_BLOCK), 0, stream, a);          \
-    else CSN_LAUNCH((ilb_kernel<NCV, false>), grid, dim3(CSN_BLOCK), 0, stream, a);                \
+// One launch per output branch (the two branches have different geometry and often different group widths; separate
+// kernels also keep each wave's instruction footprint to its own role).
+int csn_launch_ilb(const IlbArgs& a0, void* stream) {
+  for (int role = 0; role < 2; ++role) {
+    if (a0.role[role].items_img <= 0) continue;
+    IlbArgs a = a0;
+    a.items = a0.B * a0.role[role].items_img;
+    a.nc = a0.role[role].nc;
+    const int chunk = ((a.items + 31) / 32) * 4;
+    const dim3 grid((unsigned)(chunk / 4) * 8u);
+#define ILB_LAUNCH(NCV, ROLEV)                                                                           \
+  do {                                                                                                   \
+    if (a.pool) CSN_LAUNCH((ilb_kernel<NCV, ROLEV, true>), grid, dim3(CSN_BLOCK), 0, stream, a);         \
+    else CSN_LAUNCH((ilb_kernel<NCV, ROLEV, false>), grid, dim3(CSN_BLOCK), 0, stream, a);               \
+  } while (0)
+#define ILB_CASE(NCV)                                       \
+  case NCV:                                                 \
+    if (role == 0) ILB_LAUNCH(NCV, 0); else ILB_LAUNCH(NCV, 1); \
     break;
-  switch (a.nc) {
-    ILB_CASE(8)
-    ILB_CASE(12)
-    ILB_CASE(16)
-    ILB_CASE(20)
-    default: return -1;
-  }
+    switch (a.nc) {
+      ILB_CASE(8)
+      ILB_CASE(12)
+      ILB_CASE(16)
+      ILB_CASE(20)
+      default: return -1;
+    }
 #undef ILB_CASE
+#undef ILB_LAUNCH
+  }
   return (int)hipGetLastError();
 }

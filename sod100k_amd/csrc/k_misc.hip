@@ -456,6 +456,85 @@ __global__ __launch_bounds__(CSN_BLOCK) void normalize_nchw_kernel(const float* 
   }
 }
 
+// ---------------------------------------------------------------------------------------------- resize (f-2)
+// The resizes either side of the forward in the inference caller (test.py:76-85,94-96): skimage.transform.resize(order 1,
+// mode='reflect', anti_aliasing=False) = bilinear interpolation with half-pixel centres,  src = (dst + 0.5) * in / out - 0.5.
+// 'reflect' only matters for source coordinates below 0 / above n - 1, where the mirrored neighbour IS the edge sample for
+// every |excess| <= 1, so it coincides with clamping (F.interpolate(mode='bilinear', align_corners=False, antialias=False)).
+__device__ __forceinline__ void csn_resize_coord(int dst, float scale, int n, int& i0, int& i1, float& l1) {
+  float src = (static_cast<float>(dst) + 0.5f) * scale - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = min(static_cast<int>(src), n - 1);
+  i1 = min(i0 + 1, n - 1);
+  l1 = src - static_cast<float>(i0);
+}
+
+// pre: B images H_i x W_i x 3 (float, [0,1]) -> bilinear resize to H x W -> (v - mean) / std -> [B][3][H][W]
+__global__ __launch_bounds__(CSN_BLOCK) void resize_normalize_kernel(const float* __restrict__ hwc, float* __restrict__ chw,
+                                                                      int B, int Hi, int Wi, int H, int W) {
+  const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+  const float sy = (float)Hi / (float)H, sx = (float)Wi / (float)W;
+  const int64_t n = (int64_t)B * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * CSN_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CSN_BLOCK) {
+    const int x = (int)(i % W), y = (int)((i / W) % H), b = (int)(i / ((int64_t)W * H));
+    int y0, y1, x0, x1;
+    float ly, lx;
+    csn_resize_coord(y, sy, Hi, y0, y1, ly);
+    csn_resize_coord(x, sx, Wi, x0, x1, lx);
+    const float* im = hwc + (int64_t)b * Hi * Wi * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v00 = im[((int64_t)y0 * Wi + x0) * 3 + c], v01 = im[((int64_t)y0 * Wi + x1) * 3 + c];
+      const float v10 = im[((int64_t)y1 * Wi + x0) * 3 + c], v11 = im[((int64_t)y1 * Wi + x1) * 3 + c];
+      const float top = v00 + lx * (v01 - v00), bot = v10 + lx * (v11 - v10);
+      chw[(((int64_t)b * 3 + c) * H + y) * W + x] = ((top + ly * (bot - top)) - mean[c]) / stdv[c];
+    }
+  }
+}
+
+// post: logits [H][W] -> sigmoid -> bilinear resize to h x w -> (p * 255) truncated to uint8 (test.py:92-96)
+__global__ __launch_bounds__(CSN_BLOCK) void saliency_resize_u8_kernel(const float* __restrict__ logits,
+                                                                        unsigned char* __restrict__ o, int H, int W, int h,
+                                                                        int w) {
+  const float sy = (float)H / (float)h, sx = (float)W / (float)w;
+  const int64_t n = (int64_t)h * w;
+  for (int64_t i = (int64_t)blockIdx.x * CSN_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CSN_BLOCK) {
+    const int x = (int)(i % w), y = (int)(i / w);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    csn_resize_coord(y, sy, H, y0, y1, ly);
+    csn_resize_coord(x, sx, W, x0, x1, lx);
+    auto sig = [](float v) {
+      const float e = expf(-fabsf(v));
+      return v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    };
+    const float v00 = sig(logits[(int64_t)y0 * W + x0]), v01 = sig(logits[(int64_t)y0 * W + x1]);
+    const float v10 = sig(logits[(int64_t)y1 * W + x0]), v11 = sig(logits[(int64_t)y1 * W + x1]);
+    const float top = v00 + lx * (v01 - v00), bot = v10 + lx * (v11 - v10);
+    o[i] = (unsigned char)((top + ly * (bot - top)) * 255.f);
+  }
+}
+
+// planar float resize [planes][Hi][Wi] -> [planes][Ho][Wo]
+__global__ __launch_bounds__(CSN_BLOCK) void resize_bilinear_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                     int planes, int Hi, int Wi, int Ho, int Wo) {
+  const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+  const int64_t n = (int64_t)planes * Ho * Wo;
+  for (int64_t i = (int64_t)blockIdx.x * CSN_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CSN_BLOCK) {
+    const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho);
+    const int64_t pl = i / ((int64_t)Wo * Ho);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    csn_resize_coord(y, sy, Hi, y0, y1, ly);
+    csn_resize_coord(x, sx, Wi, x0, x1, lx);
+    const float* im = in + pl * Hi * Wi;
+    const float v00 = im[(int64_t)y0 * Wi + x0], v01 = im[(int64_t)y0 * Wi + x1];
+    const float v10 = im[(int64_t)y1 * Wi + x0], v11 = im[(int64_t)y1 * Wi + x1];
+    const float top = v00 + lx * (v01 - v00), bot = v10 + lx * (v11 - v10);
+    out[i] = top + ly * (bot - top);
+  }
+}
+
 // Saliency metrics (SalMetric/src/sal_metric.cpp:87-120): the reference makes 256 passes over every image (one per
 // threshold).  All of them follow from ONE joint histogram h[v][g], v = predicted value 0..255, g = (gt > 128):
 //     a_sum(th) = sum_{v > th} (h[v][0] + h[v][1]),  ab(th) = sum_{v > th} h[v][1],  b_sum = sum_v h[v][1]
@@ -550,6 +629,24 @@ int csn_launch_saliency_u8(const float* y, unsigned char* o, int64_t n, void* st
 int csn_launch_normalize_nchw(const float* hwc, float* chw, int64_t B, int64_t HW, void* stream) {
   const int64_t nb = (B * HW + CSN_BLOCK - 1) / CSN_BLOCK;
   CSN_LAUNCH(normalize_nchw_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(CSN_BLOCK), 0, stream, hwc, chw, B, HW);
+  return (int)hipGetLastError();
+}
+
+static inline unsigned csn_grid1(int64_t n) {
+  const int64_t nb = (n + CSN_BLOCK - 1) / CSN_BLOCK;
+  return (unsigned)(nb < 4096 ? (nb > 0 ? nb : 1) : 4096);
+}
+int csn_launch_resize_normalize(const float* hwc, float* chw, int B, int Hi, int Wi, int H, int W, void* stream) {
+  CSN_LAUNCH(resize_normalize_kernel, dim3(csn_grid1((int64_t)B * H * W)), dim3(CSN_BLOCK), 0, stream, hwc, chw, B, Hi, Wi, H, W);
+  return (int)hipGetLastError();
+}
+int csn_launch_saliency_resize_u8(const float* logits, unsigned char* o, int H, int W, int h, int w, void* stream) {
+  CSN_LAUNCH(saliency_resize_u8_kernel, dim3(csn_grid1((int64_t)h * w)), dim3(CSN_BLOCK), 0, stream, logits, o, H, W, h, w);
+  return (int)hipGetLastError();
+}
+int csn_launch_resize_bilinear(const float* in, float* out, int planes, int Hi, int Wi, int Ho, int Wo, void* stream) {
+  CSN_LAUNCH(resize_bilinear_kernel, dim3(csn_grid1((int64_t)planes * Ho * Wo)), dim3(CSN_BLOCK), 0, stream, in, out, planes, Hi,
+             Wi, Ho, Wo);
   return (int)hipGetLastError();
 }
 

@@ -224,6 +224,43 @@ def saliency_u8(lib: C.CDLL, logits: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def resize_normalize_nchw(lib: C.CDLL, hwc: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """test.py:72-86 on the device: B x h x w x 3 float images in [0,1] -> bilinear resize (half-pixel centres, no
+    anti-aliasing: skimage's resize(mode='reflect', anti_aliasing=False)) to H x W -> normalise -> B x 3 x H x W."""
+    assert hwc.dtype == torch.float32 and hwc.dim() == 4 and hwc.shape[3] == 3
+    hwc = hwc.contiguous()
+    B, h, w, _ = hwc.shape
+    out = torch.empty((B, 3, H, W), dtype=torch.float32, device=hwc.device)
+    N.check(lib, lib.csn_resize_normalize_nchw(hwc.data_ptr(), out.data_ptr(), B, h, w, H, W, _stream_of(hwc)),
+            "csn_resize_normalize_nchw")
+    return out
+
+
+def saliency_resize_u8(lib: C.CDLL, logits: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """test.py:91-96 on the device: logits of ONE picture (H x W) -> sigmoid -> bilinear resize to its own h x w ->
+    (p * 255) truncated to uint8."""
+    assert logits.dtype == torch.float32
+    logits = logits.contiguous()
+    H, W = int(logits.shape[-2]), int(logits.shape[-1])
+    assert logits.numel() == H * W
+    out = torch.empty((h, w), dtype=torch.uint8, device=logits.device)
+    N.check(lib, lib.csn_saliency_resize_u8(logits.data_ptr(), out.data_ptr(), H, W, h, w, _stream_of(logits)),
+            "csn_saliency_resize_u8")
+    return out
+
+
+def resize_bilinear(lib: C.CDLL, x: torch.Tensor, Ho: int, Wo: int) -> torch.Tensor:
+    """Planar float tensor [..., Hi, Wi] -> [..., Ho, Wo], bilinear with half-pixel centres (align_corners=False)."""
+    assert x.dtype == torch.float32 and x.dim() >= 2
+    x = x.contiguous()
+    Hi, Wi = int(x.shape[-2]), int(x.shape[-1])
+    planes = x.numel() // (Hi * Wi)
+    out = torch.empty(tuple(x.shape[:-2]) + (Ho, Wo), dtype=torch.float32, device=x.device)
+    N.check(lib, lib.csn_resize_bilinear(x.data_ptr(), out.data_ptr(), planes, Hi, Wi, Ho, Wo, _stream_of(x)),
+            "csn_resize_bilinear")
+    return out
+
+
 def val_mae(lib: C.CDLL, logits: torch.Tensor, target: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One picture of the training caller's validation loop (train.py:262-276): logits 1 x 1 x hi x wi (or hi x wi),
     target h x w float at the picture's own size -> fp64 device scalar, ADDED to ``out`` when given."""

@@ -5,9 +5,12 @@
 
 Same flow: cfg merge -> ``import_module("model." + cfg.MODEL.ARCH).build_model(predefine=...)`` -> device ->
 ``simplesum`` -> strict ``load_state_dict`` -> per image: normalise (mean/std of test.py:68-69), ``model(x)``,
-``predict[0]``, sigmoid, resize back, ``(p * 255).astype(uint8)``, PNG.  Differences, all host side: images are
-read/resized with PIL (skimage is not a dependency; host IO is outside the accelerated path)
-and images are pushed through the plan in batches (the HIP plan is compiled per (B, H, W)).
+``predict[0]``, sigmoid, resize back, ``(p * 255).astype(uint8)``, PNG.  Both resizes run on the device as float,
+non-antialiased bilinear interpolation with half-pixel centres (csn_resize_normalize_nchw / csn_saliency_resize_u8 = the
+reference's skimage ``resize(mode='reflect', anti_aliasing=False)``, test.py:76-85,94-96); with ``TEST.IMAGE_H/W == 0`` the
+pictures run at their own size rounded up to multiples of 16 (test.py:80-85).  Differences, all host side: files are
+decoded with PIL (skimage is not a dependency) and pictures of the same network size are pushed through the plan in
+batches (the HIP plan is compiled per (B, H, W)).
 """
 import argparse
 import importlib
@@ -30,29 +33,32 @@ MEAN = np.array([0.485, 0.456, 0.406])
 STD = np.array([0.229, 0.224, 0.225])
 
 
-def preprocess(img: np.ndarray, h: int, w: int) -> np.ndarray:
-    """H x W x 3 float image in [0,1] -> 3 x h x w float32, ImageNet-normalised (test.py:72-86)."""
-    from PIL import Image
-    if img.shape[:2] != (h, w):
-        img = np.asarray(Image.fromarray((img * 255).astype(np.uint8)).resize((w, h), Image.BILINEAR)) / 255.0
-    return np.transpose((img - MEAN) / STD, (2, 0, 1)).astype(np.float32)
+def network_size(h: int, w: int, cfg_h: int, cfg_w: int):
+    """test.py:76-85: the configured size, or the picture's own size rounded up to multiples of 16."""
+    if cfg_h != 0 and cfg_w != 0:
+        return cfg_h, cfg_w
+    return -(-h // 16) * 16, -(-w // 16) * 16
 
 
-def resize_hw(img: np.ndarray, h: int, w: int) -> np.ndarray:
-    """H x W x 3 float image in [0,1] at the network size (bilinear, host side)."""
-    from PIL import Image
-    if img.shape[:2] == (h, w):
-        return img
-    return np.asarray(Image.fromarray((img * 255).astype(np.uint8)).resize((w, h), Image.BILINEAR)) / 255.0
-
-
-def postprocess(logits: torch.Tensor, h: int, w: int) -> np.ndarray:
-    """1 x H x W logits -> uint8 saliency map of the original size (test.py:91-96)."""
-    from PIL import Image
-    p = torch.sigmoid(logits.squeeze(0)).cpu().numpy()
-    if p.shape != (h, w):
-        p = np.asarray(Image.fromarray(p).resize((w, h), Image.BILINEAR))
-    return (p * 255).astype(np.uint8)
+def run_pictures(model, imgs, cfg_h, cfg_w, batch, device, lib=None):
+    """Saliency maps (uint8, each at its picture's own size) of a list of H x W x 3 float pictures in [0,1]: pictures
+    are grouped by network size; resize + normalise, forward, sigmoid + resize back + quantise all run on the device."""
+    lib = lib if lib is not None else (getattr(model, "_lib", None) or N.load())
+    groups = {}
+    for idx, im in enumerate(imgs):
+        key = im.shape[:2] + network_size(im.shape[0], im.shape[1], cfg_h, cfg_w)
+        groups.setdefault(key, []).append(idx)
+    out = [None] * len(imgs)
+    for (h, w, H, W), members in groups.items():
+        for i in range(0, len(members), batch):
+            chunk = members[i:i + batch]
+            hwc = np.stack([imgs[k] for k in chunk] + [np.zeros((h, w, 3), np.float32)] * (batch - len(chunk)))
+            with torch.no_grad():
+                x = E.resize_normalize_nchw(lib, torch.from_numpy(hwc.astype(np.float32)).to(device), H, W)
+                pred = model(x)
+                for j, k in enumerate(chunk):
+                    out[k] = E.saliency_resize_u8(lib, pred[j, 0], h, w).cpu().numpy()
+    return out
 
 
 def run(cfg, batch: int = 16, device: str = "cuda"):
@@ -70,7 +76,6 @@ def run(cfg, batch: int = 16, device: str = "cuda"):
     ck = load_checkpoint(cfg.TEST.CHECKPOINT)
     model.load_state_dict(ck['state_dict'])
     model.eval()
-    H, W = cfg.TEST.IMAGE_H or 224, cfg.TEST.IMAGE_W or 224
     for dataset in cfg.TEST.DATASETS:
         img_dir = os.path.join(cfg.TEST.DATASET_PATH, dataset, 'images')
         if not os.path.isdir(img_dir):
@@ -79,17 +84,11 @@ def run(cfg, batch: int = 16, device: str = "cuda"):
         out_dir = os.path.join(cfg.DATA.SAVEDIR, cfg.TASK or cfg.MODEL.ARCH, dataset + '_' + str(ck['epoch']))
         os.makedirs(out_dir, exist_ok=True)
         names = sorted(os.listdir(img_dir))
-        for i in range(0, len(names), batch):
-            chunk = names[i:i + batch]
+        for i in range(0, len(names), 4 * batch):
+            chunk = names[i:i + 4 * batch]
             imgs = [np.asarray(Image.open(os.path.join(img_dir, n)).convert("RGB")) / 255.0 for n in chunk]
-            # host: resize to the network size (IO side); device: normalise + NCHW pack, forward, sigmoid -> uint8
-            hwc = np.stack([resize_hw(im, H, W) for im in imgs] + [np.zeros((H, W, 3), np.float32)] * (batch - len(chunk)))
-            with torch.no_grad():
-                x = E.normalize_nchw(N.load(), torch.from_numpy(hwc.astype(np.float32)).to(device))
-                pred = model(x)
-                maps = E.saliency_u8(N.load(), pred).cpu().numpy()
-            for k, (n, im, lg) in enumerate(zip(chunk, imgs, pred)):
-                u8 = maps[k, 0] if im.shape[:2] == (H, W) else postprocess(lg, *im.shape[:2])
+            maps = run_pictures(model, imgs, cfg.TEST.IMAGE_H, cfg.TEST.IMAGE_W, batch, device)
+            for n, u8 in zip(chunk, maps):
                 Image.fromarray(u8).save(os.path.join(out_dir, n[:-4] + '.png'))
         print('Dataset: {}, {} images'.format(dataset, len(names)))
 

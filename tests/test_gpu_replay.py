@@ -96,42 +96,66 @@ def _rel_l2(flat, offs, grads):
 
 
 def test_gpu_train_replay_steps(hip, x2_manifest):
-    """FusedTrainer with FIXED device buffers for 6 steps (2 eager, capture, 3 replays) against the oracle's step with
-    carried state: loss and penalty every step, BN buffers at the end, the whole gradient on the replayed step 5."""
-    from sod100k_amd.tools.train import FusedTrainer
+    """FusedTrainer with FIXED device buffers for 6 steps (2 eager, capture, 3 replays) with new data in the buffers every
+    step.  Every step -- the replayed ones included -- is checked against the oracle evaluated on the parameters the
+    device held BEFORE that step (loss, penalty, the whole gradient); the Adam update itself against torch's formula on
+    the device's own gradient; BN buffers and num_batches_tracked at the end.  (Comparing two free-running trajectories
+    instead would measure the chaos of the ~1e-6-gamma channels, not the kernels: their gradients differ by O(1) once
+    the parameters are 1e-3 apart.)"""
+    from sod100k_amd.tools.train import FusedTrainer, is_picked
     lib, dev = hip
     B, H, W = 2, 64, 96
+    lr, wd, eps, b1, b2 = 1e-4, 5e-3, 1e-3, 0.9, 0.99
     m, sd = P.make_model(lib, x2_manifest, dev)
     m.train(); m.set_batchsize(B); m.clear_flops(); m.flops_hook(1.0)
-    tr = FusedTrainer(m, lr=1e-4, weight_decay=5e-3, eps=1e-3, flops_weight=3.0, batchsize=B, lib=lib)
+    tr = FusedTrainer(m, lr=lr, weight_decay=wd, eps=eps, flops_weight=3.0, batchsize=B, lib=lib)
     cfg = O.load_layer_config_json(x2_manifest)
-    sd_ref = {k: v.clone() for k, v in sd.items()}
     xd = torch.empty(B, 3, H, W, device=dev)
     td = torch.empty(B, 1, H, W, device=dev)
-    state = None
     offs = m._arena.offsets
+    n = tr.n
     for step in range(6):
         x = torch.from_numpy(I.randn_batch(40 + step, B, H, W))
         t = torch.from_numpy(I.binary_target(50 + step, B, H, W))
         xd.copy_(x); td.copy_(t)
+        before = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        p0 = m._arena.flat[:n].cpu().clone()
+        m0, v0 = tr.m.cpu().clone(), tr.v.cpu().clone()
         loss, pen = tr.step(xd, td)
         m.clear_flops()
-        r = O.train_step(cfg, sd_ref, x, t, expandflop=1.0, flops_weight=3.0, batchsize=B, lr=1e-4, wd=5e-3, eps=1e-3,
-                         adam_state=state)
-        state = r["adam_state"]
-        tol = 2e-5 if step == 0 else 1e-3          # later steps start from parameters ~1e-3 (relative) apart
-        assert abs(float(loss) - r["loss_bce"]) <= tol * max(1.0, abs(r["loss_bce"])), (step, float(loss), r["loss_bce"])
-        assert abs(float(pen) - r["penalty"]) <= max(tol, 2e-4) * max(1.0, abs(r["penalty"])), (step, float(pen), r["penalty"])
-        rel = _rel_l2(tr.grad.cpu(), offs, r["grads"])
-        print(f"step {step}: bce {float(loss):.6f} / {r['loss_bce']:.6f}  gradient rel-L2 {rel:.2e}")
-        assert rel <= (2e-3 if step == 0 else 2e-2), (step, rel)
+        r = O.train_step(cfg, before, x, t, expandflop=1.0, flops_weight=3.0, batchsize=B, lr=0.0, wd=0.0)
+        assert abs(float(loss) - r["loss_bce"]) <= 2e-5 * max(1.0, abs(r["loss_bce"])), (step, float(loss), r["loss_bce"])
+        assert abs(float(pen) - r["penalty"]) <= 2e-4 * max(1.0, abs(r["penalty"])), (step, float(pen), r["penalty"])
+        g = tr.grad.cpu()
+        rel = _rel_l2(g, offs, r["grads"])
+        errs = P.grad_errors(m, g, r["grads"])
+        gmax = max(nrm for _, nrm in errs.values())
+        good = sum(1 for e, _ in errs.values() if e <= 1e-3 * gmax) / len(errs)
+        print(f"step {step}: bce {float(loss):.6f} / {r['loss_bce']:.6f}  gradient rel-L2 {rel:.2e}, "
+              f"{100 * good:.1f} % of the tensors within 1e-3 of the largest gradient norm")
+        # single elements of the shipped checkpoint's gamma ~ 1e-6 channels sit on the PReLU kink, where the derivative
+        # jumps between 1 and alpha on the last bit of the BN output (profiles/r1_notes.md): a handful of tensors may be
+        # 1e-2 off in ANY two implementations; everything else must agree tightly -- on the replayed steps as well
+        assert rel <= 2e-2 and good >= 0.97, (step, rel, good)
+        # torch.optim.Adam (L2 folded into the gradient, two groups) on the device's own gradient
+        wdv = tr.wd.cpu()
+        gg = g + wdv * p0
+        m1 = b1 * m0 + (1 - b1) * gg
+        v1 = b2 * v0 + (1 - b2) * gg * gg
+        k = step + 1
+        p1 = p0 - (lr / (1 - b1 ** k)) * m1 / ((v1.sqrt() / (1 - b2 ** k) ** 0.5) + eps)
+        got = m._arena.flat[:n].cpu()
+        assert (got - p1).abs().max().item() <= 1e-6 + 1e-5 * p1.abs().max().item(), step
+        # BN running statistics of this step: the oracle updated `before` in place
+        now = m.state_dict()
+        for key, v in before.items():
+            if key.endswith("running_mean") or key.endswith("running_var"):
+                assert ((now[key].cpu() - v).abs() / (1 + v.abs())).max().item() <= 1e-4, (step, key)
     assert tr.steps == 6
-    got = m.state_dict()
-    for k, v in sd_ref.items():
-        if k.endswith("num_batches_tracked"):
-            assert int(got[k]) == int(v), k
-        elif k.endswith("running_mean") or k.endswith("running_var"):
-            assert ((got[k].cpu() - v).abs() / (1 + v.abs())).max().item() <= 2e-4, k
+    for key, v in m.state_dict().items():
+        if key.endswith("num_batches_tracked"):
+            assert int(v) == int(sd[key]) + 6, key
+    assert any(is_picked(name) for name in offs)
 
 
 def test_gpu_train_replay_equals_eager(hip, x2_manifest):
