@@ -22,6 +22,11 @@ enum CsnPrepKind {
   //   ci < n (rows), co*kk + t < p1 (columns)
   CSN_PREP_ROWS_T = 7,
   CSN_PREP_FLIP9 = 8,     // dst[c*9 + t] = p0f * src0[c*9 + 8 - t]   (n = 9*C)
+  // 3x3 block -> tap-major chunks of 16 channels (k_goct_c3.hip): n = rows, p1 = channels C, p2 = dst row pitch, p3 = dst column
+  //   dst[r*p2 + p3 + (c/16)*144 + t*16 + c%16] = p0f * src0[r*p0 + c*9 + t]                     (p0 = source row pitch)
+  CSN_PREP_C3T = 9,
+  // ... of a transposed block with flipped taps (backward data): element (r, c, t) = src0[c*p0 + r*9 + (8 - t)]
+  CSN_PREP_C3T_T = 10,
 };
 struct CsnPrepJob {
   int32_t kind, n, p0, p1, p2, p3;
@@ -110,6 +115,10 @@ struct PwArgs {
   int32_t ty_log2;     // tile of branch 0 is (1 << ty_log2) rows x 32 columns; 4, 3 or 2
   int32_t wimg_floats; // multiple of 4
   const float* wimg;   // weight image of all passes: rows padded to 16, pitch w_stride, zero filled
+  // goct_c3_kernel (single 3x3 pass): the tap-major weight image [rows16][chunk][tap][16 channels] (null: not eligible),
+  // its row pitch / size in floats, and the z channel that belongs to output row 0 of the launch (row-chunked launches)
+  const float* wimg3;
+  int32_t w3_stride, w3_floats, z_c0, pad3;
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -85,6 +85,9 @@ struct PwLaunchPlan {
   int lvl = 0;                         // activation level (H >> lvl) of r = 0
   int64_t wimg = -1;                   // packed-buffer offset of the weight image
   int wimg_floats = 0;
+  // goct_c3_kernel's tap-major image of a single 3x3 pass (k_goct_c3.hip); -1: the launch does not qualify
+  int64_t wimg3 = -1;
+  int w3_stride = 0, w3_floats = 0, z_c0 = 0;
 };
 
 struct UnitPlan {
@@ -249,6 +252,42 @@ int finish_launch(Builder& bl, PwLaunchPlan& L) {
       else
         bl.job(CSN_PREP_ROWS, ps.nrows, L.wimg + ps.w_off, w.src, -1, -1, -1, w.scale, w.ld, w.ncol, ps.w_stride, w.col);
     }
+  // ---- tap-major image for goct_c3_kernel: one pass at the launch resolution, 3x3 tap slices (dilation 1) first, at
+  // most one bilinear slice (identity block) last
+  if (L.passes.size() == 1 && L.passes[0].r == 0) {
+    const PwPassPlan& ps = L.passes[0];
+    int ntap = 0;
+    bool ok = ps.nsrc > 0, tail = false;
+    for (int s = 0; s < ps.nsrc && ok; ++s) {
+      const int m = ps.src_mode[s];
+      if (m == PW_TAPS || m == PW_POOL2_TAPS) {
+        if (tail || ps.src_dil[s] != 1 || ps.wb[s].eye) ok = false;
+        ++ntap;
+      } else if (m == PW_UP2 && !tail && ps.wb[s].eye) {
+        tail = true;
+      } else {
+        ok = false;
+      }
+    }
+    if (ok && ntap > 0 && ntap <= 3) {
+      int cols = 0;
+      for (int s = 0; s < ntap; ++s) cols += ((ps.src_C[s] + 15) / 16) * 144;
+      L.w3_stride = cols + 2;                                  // == 2 (mod 4): conflict-free A-operand reads
+      L.w3_floats = ((ps.nrows + 15) & ~15) * L.w3_stride;
+      L.wimg3 = bl.alloc_packed(L.w3_floats);
+      int col = 0;
+      for (int s = 0; s < ntap; ++s) {
+        const WBlock& w = ps.wb[s];
+        const int C = ps.src_C[s];
+        if (w.tk > 0)      // backward data: element (row ci, channel co, tap t) = W[co][ci][8 - t]
+          bl.job(CSN_PREP_C3T_T, ps.nrows, L.wimg3, w.src, -1, -1, -1, w.scale, w.ld, C, L.w3_stride, col);
+        else
+          bl.job(CSN_PREP_C3T, ps.nrows, L.wimg3, w.src, -1, -1, -1, w.scale, w.ld, C, L.w3_stride, col);
+        col += ((C + 15) / 16) * 144;
+      }
+      if (tail) L.z_c0 = ps.wb[ntap].eye_col0;
+    }
+  }
   return CSN_OK;
 }
 
@@ -642,6 +681,7 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
          (int64_t)a.tiles_x * ((a.H0 + (1 << a.ty_log2) - 1) >> a.ty_log2) * a.B < 512) --a.ty_log2;
   a.tiles_y = (a.H0 + (1 << a.ty_log2) - 1) >> a.ty_log2;
   a.wimg = c.pk(L.wimg); a.wimg_floats = L.wimg_floats;
+  a.wimg3 = L.wimg3 >= 0 ? c.pk(L.wimg3) : nullptr; a.w3_stride = L.w3_stride; a.w3_floats = L.w3_floats; a.z_c0 = L.z_c0; a.pad3 = 0;
   for (int q = 0; q < a.npass; ++q) {
     const PwPassPlan& pp = L.passes[q];
     PwPass& ps = a.pass[q];

@@ -63,6 +63,19 @@ __global__ __launch_bounds__(CSN_BLOCK) void csn_prep_kernel(const CsnPrepJob* _
         dst[(int64_t)ci * j.p2 + col + c] = j.p0f * arena[j.src0 + (int64_t)co * j.p0 + ci * kk + (kk - 1 - t)];
       }
     } break;
+    case CSN_PREP_C3T:
+    case CSN_PREP_C3T_T: {
+      const int C = j.p1;
+      const int tot = j.n * C * 9;
+      for (int i = tid; i < tot; i += CSN_BLOCK) {
+        const int t = i % 9;
+        const int rc = i / 9;
+        const int c = rc % C, r = rc / C;
+        const float v = j.kind == CSN_PREP_C3T ? arena[j.src0 + (int64_t)r * j.p0 + c * 9 + t]
+                                               : arena[j.src0 + (int64_t)c * j.p0 + r * 9 + (8 - t)];
+        dst[(int64_t)r * j.p2 + j.p3 + (c >> 4) * 144 + t * 16 + (c & 15)] = j.p0f * v;
+      }
+    } break;
     case CSN_PREP_FLIP9:
       for (int i = tid; i < j.n; i += CSN_BLOCK) dst[i] = j.p0f * arena[j.src0 + (i / 9) * 9 + 8 - (i % 9)];
       break;
