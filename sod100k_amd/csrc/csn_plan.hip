@@ -238,7 +238,7 @@ int finish_launch(Builder& bl, PwLaunchPlan& L) {
     img = (img + 3) & ~3;
   }
   if ((int)L.passes.size() > PW_MAX_PASS) FAIL(CSN_E_UNSUPPORTED, "too many passes in one launch");
-  if (((int64_t)img + 4 * PW_KC * PW_XP) * 4 > 160 * 1024) FAIL(CSN_E_UNSUPPORTED, "weight image exceeds the LDS of a CU");
+  if (((int64_t)img + 4 * PW_PR * PW_XP) * 4 > 160 * 1024) FAIL(CSN_E_UNSUPPORTED, "weight image exceeds the LDS of a CU");
   L.wimg_floats = img;
   L.wimg = bl.alloc_packed(img);
   for (const PwPassPlan& ps : L.passes)

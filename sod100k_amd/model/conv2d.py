@@ -3,7 +3,7 @@
 The reference layer is an ``nn.Conv2d`` clone whose forward convolves with ``100.0 * weight``
 ("for faster convergence", conv2d.py:102-104).  Here the module only owns the parameters (same
 names, shapes and default initialisation, so checkpoints load key-for-key); the arithmetic -- including
-the x100 -- is done by the HIP kernels of the enclosing unit (csrc/k_misc.hip, csrc/k_conv3.hip).
+the x100 -- is done by the HIP kernels of the enclosing unit (csrc/k_misc.hip depthwise units, csrc/k_ms.hip MSBlock, csrc/k_goct_pw.hip / k_goct_c3.hip std_conv).
 """
 import math
 

@@ -178,3 +178,17 @@ def test_gpu_std_conv_network(hip):
     from test_unpruned_emu import _random_state
     lib, dev = hip
     P.check_std_conv_network(lib, dev, _random_state)
+
+
+def test_gpu_train_step_well_conditioned(hip, x2_manifest):
+    """well-conditioned state (gamma in [0.5, 1.5]); judged against fp64 with the fp32 oracle's own
+    distance as the yardstick (its noise floor is 3e-3, so an absolute 1e-4 is unreachable for any fp32 implementation)."""
+    lib, dev = hip
+    print("rel-L2 vs fp64: kernels %.2e, fp32 oracle %.2e" % P.check_train_step_well_conditioned(lib, dev, x2_manifest, B=3, size=96))
+
+
+def test_gpu_resizes(hip):
+    import resize_cases as RC
+    lib, dev = hip
+    RC.check_resize_bilinear(lib, dev)
+    RC.check_pre_post(lib, dev)
