@@ -66,10 +66,11 @@ struct DwArgs {
 // gOctConv 1x1 (+BN+PReLU), all output branches of a unit in one block (see k_goct_pw.hip)
 // ---------------------------------------------------------------------------------------------
 #define PW_TY0 16
-#define PW_TX0 32
+#ifndef PW_TXL
+#define PW_TXL 5   // log2 of the tile width of branch 0 in goct_pw_kernel (A/B builds: 6, 7)
+#endif
+#define PW_TX0 (1 << PW_TXL)
 #define PW_KC 16   // gathered channels per LDS panel (32: one load phase less per group but 3 instead of 4 waves/SIMD -- slower)
-#define PW_PR 20   // panel rows of goct_pw_kernel: the lean batches write up to 3 rows past a slice (pw_gather.h); 24 rows
-                   // cost a resident block per CU (LDS) and made the kernel slower than the round-1 gather
 #define PW_XP 80   // panel row pitch (floats): == 16 (mod 32), so the two k rows a 32-lane half reads hit disjoint banks
 #define PW_MAX_PASS 6
 #define PW_MAX_GRID 2048

@@ -238,7 +238,7 @@ int finish_launch(Builder& bl, PwLaunchPlan& L) {
     img = (img + 3) & ~3;
   }
   if ((int)L.passes.size() > PW_MAX_PASS) FAIL(CSN_E_UNSUPPORTED, "too many passes in one launch");
-  if (((int64_t)img + 4 * PW_PR * PW_XP) * 4 > 160 * 1024) FAIL(CSN_E_UNSUPPORTED, "weight image exceeds the LDS of a CU");
+  if (((int64_t)img + 4 * PW_KC * PW_XP) * 4 > 160 * 1024) FAIL(CSN_E_UNSUPPORTED, "weight image exceeds the LDS of a CU");
   L.wimg_floats = img;
   L.wimg = bl.alloc_packed(img);
   for (const PwPassPlan& ps : L.passes)
@@ -675,7 +675,7 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
   // tile height: 16 rows, or 8 / 4 for small maps so that the launch still fills the 256 CUs several times over
   int rmax = 0;
   for (const PwPassPlan& pp : L.passes) rmax = std::max(rmax, pp.r);
-  a.ty_log2 = 4;
+  a.ty_log2 = std::max(4 - (PW_TXL - 5), rmax);   // 512 pixels of branch 0 per tile whatever its width
   a.tiles_x = (a.W0 + PW_TX0 - 1) / PW_TX0;
   while (a.ty_log2 > 2 && a.ty_log2 > rmax &&
          (int64_t)a.tiles_x * ((a.H0 + (1 << a.ty_log2) - 1) >> a.ty_log2) * a.B < 512) --a.ty_log2;

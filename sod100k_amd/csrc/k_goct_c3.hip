@@ -83,11 +83,8 @@ static inline void c3_contract_emu(csn_f4 (&acc)[2][4], const float* w0, int wp,
 
 // WCH = false: the pass's whole weight image is staged once per block (small images);
 // WCH = true: only the current chunk's columns live in LDS (large images: 42 KB per block, 3 blocks per CU).
-#ifndef C3_WAVES
-#define C3_WAVES 2   // waves per SIMD the register budget is sized for: 3 (168 VGPRs) spills the prefetch registers
-#endif
 template <bool RAW, bool WCH>
-__global__ __launch_bounds__(CSN_BLOCK, C3_WAVES) void goct_c3_kernel(PwArgs a_byval) {
+__global__ __launch_bounds__(CSN_BLOCK, 3) void goct_c3_kernel(PwArgs a_byval) {
   CSN_DYN_SMEM(float, lds);
   const CSN_CONST_AS PwArgs* a = CSN_KERNARG(PwArgs, a_byval);
   PwPassP ps = &a->pass[0];
@@ -135,67 +132,6 @@ __global__ __launch_bounds__(CSN_BLOCK, C3_WAVES) void goct_c3_kernel(PwArgs a_b
   const int r8 = tid >> 5, lx = tid & 31;
   const int hch = tid / (C3_TY + 2), hrow = tid - hch * (C3_TY + 2);
   const unsigned OOB = 0x80000000u;
-  float pf[22];          // prefetched tile elements of the next chunk (plain slices)
-  bool pf_valid = false;
-  // issue the loads of a plain (not pooled) chunk of tile (b, y0, x0): out-of-image / past-the-slice elements get an
-  // out-of-range offset -> 0.  A wave whose four channels (4 wave .. 4 wave + 3) lie past the chunk issues nothing.
-  auto prefetch = [&](const C3Chunk& c, int b, int y0, int x0) {
-    const int C = ps->src[c.s].C;
-    const csn_buf rb = csn_make_buf_n(ps->src[c.s].ptr + (int64_t)b * ps->src[c.s].Ctot * (Hr * Wr),
-                                      (unsigned)(ps->src[c.s].Ctot * Hr * Wr) * 4u);
-    const unsigned HW4 = (unsigned)(Hr * Wr) * 4u;
-    const int xx = x0 + lx;
-    const unsigned colo = xx < Wr ? (unsigned)xx * 4u : OOB;
-    if (c.c_lo + 4 * wave < C) {
-#pragma unroll
-      for (int i = 0; i < 20; ++i) {
-        const int ch = c.c_lo + 2 * r8 + i / 10, yy = y0 - 1 + (i % 10);
-        const bool ok = ch < C && yy >= 0 && yy < Hr;
-        pf[i] = csn_ld1(rb, ok ? (unsigned)ch * HW4 + (unsigned)(yy * Wr) * 4u + colo : OOB, 0u);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 20; ++i) pf[i] = 0.f;
-    }
-    {
-      const int ch = c.c_lo + hch, yy = y0 - 1 + hrow;
-      const bool ok = tid < C3_CC * (C3_TY + 2) && ch < C && yy >= 0 && yy < Hr;
-      const unsigned ro = (unsigned)ch * HW4 + (unsigned)(yy * Wr) * 4u;
-      pf[20] = csn_ld1(rb, ok && x0 > 0 ? ro + (unsigned)(x0 - 1) * 4u : OOB, 0u);
-      pf[21] = csn_ld1(rb, ok && x0 + C3_TX < Wr ? ro + (unsigned)(x0 + C3_TX) * 4u : OOB, 0u);
-    }
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int i = 0; i < 20; ++i) tile[(2 * r8 + i / 10) * C3_PLANE + (i % 10) * C3_TP + 1 + lx] = pf[i];
-    if (tid < C3_CC * (C3_TY + 2)) {
-      tile[hch * C3_PLANE + hrow * C3_TP] = pf[20];
-      tile[hch * C3_PLANE + hrow * C3_TP + C3_TX + 1] = pf[21];
-    }
-  };
-  // pooled chunk: 2x2 max of the source at twice the resolution, staged synchronously
-  auto stage_pooled = [&](const C3Chunk& c, int b, int y0, int x0) {
-    const int C = ps->src[c.s].C;
-    const int Hs = 2 * Hr, Ws = 2 * Wr;
-    const csn_buf rb = csn_make_buf_n(ps->src[c.s].ptr + (int64_t)b * ps->src[c.s].Ctot * (Hs * Ws),
-                                      (unsigned)(ps->src[c.s].Ctot * Hs * Ws) * 4u);
-    const unsigned HW4 = (unsigned)(Hs * Ws) * 4u, P4 = (unsigned)Ws * 4u;
-    auto pooled = [&](int ch, int yy, int xx) {
-      const bool ok = ch < C && yy >= 0 && yy < Hr && xx >= 0 && xx < Wr;
-      const unsigned o = ok ? (unsigned)ch * HW4 + (unsigned)(2 * yy) * P4 + (unsigned)xx * 8u : OOB;
-      const float2 t0 = csn_ld2(rb, o, 0u), t1 = csn_ld2(rb, ok ? o + P4 : OOB, 0u);
-      return fmaxf(fmaxf(t0.x, t0.y), fmaxf(t1.x, t1.y));
-    };
-#pragma unroll 5
-    for (int i = 0; i < 20; ++i)
-      tile[(2 * r8 + i / 10) * C3_PLANE + (i % 10) * C3_TP + 1 + lx] = pooled(c.c_lo + 2 * r8 + i / 10, y0 - 1 + (i % 10), x0 + lx);
-    if (tid < C3_CC * (C3_TY + 2)) {
-      tile[hch * C3_PLANE + hrow * C3_TP] = pooled(c.c_lo + hch, y0 - 1 + hrow, x0 - 1);
-      tile[hch * C3_PLANE + hrow * C3_TP + C3_TX + 1] = pooled(c.c_lo + hch, y0 - 1 + hrow, x0 + C3_TX);
-    }
-  };
-  const C3Chunk c_first = chunk_of(0);
-  const bool first_plain = ps->src[c_first.s].mode == PW_TAPS;
   for (int tl = xcd * chunkx + (blockIdx.x >> 3); tl < tend; tl += nslot) {
     const int b = tl / tiles_xy;
     const int txy = tl - b * tiles_xy;
@@ -214,13 +150,69 @@ __global__ __launch_bounds__(CSN_BLOCK, C3_WAVES) void goct_c3_kernel(PwArgs a_b
         for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int i = 0; i < 4; ++i) acc[t][s][i] = 0.f;
-      if (!pf_valid && first_plain) { prefetch(c_first, b, y0, x0); pf_valid = true; }   // first sweep of the block only
+      float pf[22];          // prefetched tile elements of the next chunk (plain slices)
+      bool pf_valid = false;
+      // issue the loads of a plain (not pooled) chunk: out-of-image / past-the-slice elements get an out-of-range offset -> 0
+      auto prefetch = [&](const C3Chunk& c) {
+        const int C = ps->src[c.s].C;
+        const csn_buf rb = csn_make_buf_n(ps->src[c.s].ptr + (int64_t)b * ps->src[c.s].Ctot * (Hr * Wr),
+                                          (unsigned)(ps->src[c.s].Ctot * Hr * Wr) * 4u);
+        const unsigned HW4 = (unsigned)(Hr * Wr) * 4u;
+        const int xx = x0 + lx;
+        const unsigned colo = xx < Wr ? (unsigned)xx * 4u : OOB;
+#pragma unroll
+        for (int i = 0; i < 20; ++i) {
+          const int ch = c.c_lo + 2 * r8 + i / 10, yy = y0 - 1 + (i % 10);
+          const bool ok = ch < C && yy >= 0 && yy < Hr;
+          pf[i] = csn_ld1(rb, ok ? (unsigned)ch * HW4 + (unsigned)(yy * Wr) * 4u + colo : OOB, 0u);
+        }
+        {
+          const int ch = c.c_lo + hch, yy = y0 - 1 + hrow;
+          const bool ok = tid < C3_CC * (C3_TY + 2) && ch < C && yy >= 0 && yy < Hr;
+          const unsigned ro = (unsigned)ch * HW4 + (unsigned)(yy * Wr) * 4u;
+          pf[20] = csn_ld1(rb, ok && x0 > 0 ? ro + (unsigned)(x0 - 1) * 4u : OOB, 0u);
+          pf[21] = csn_ld1(rb, ok && x0 + C3_TX < Wr ? ro + (unsigned)(x0 + C3_TX) * 4u : OOB, 0u);
+        }
+      };
+      auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < 20; ++i) tile[(2 * r8 + i / 10) * C3_PLANE + (i % 10) * C3_TP + 1 + lx] = pf[i];
+        if (tid < C3_CC * (C3_TY + 2)) {
+          tile[hch * C3_PLANE + hrow * C3_TP] = pf[20];
+          tile[hch * C3_PLANE + hrow * C3_TP + C3_TX + 1] = pf[21];
+        }
+      };
+      // pooled chunk: 2x2 max of the source at twice the resolution, staged synchronously
+      auto stage_pooled = [&](const C3Chunk& c) {
+        const int C = ps->src[c.s].C;
+        const int Hs = 2 * Hr, Ws = 2 * Wr;
+        const csn_buf rb = csn_make_buf_n(ps->src[c.s].ptr + (int64_t)b * ps->src[c.s].Ctot * (Hs * Ws),
+                                          (unsigned)(ps->src[c.s].Ctot * Hs * Ws) * 4u);
+        const unsigned HW4 = (unsigned)(Hs * Ws) * 4u, P4 = (unsigned)Ws * 4u;
+        auto pooled = [&](int ch, int yy, int xx) {
+          const bool ok = ch < C && yy >= 0 && yy < Hr && xx >= 0 && xx < Wr;
+          const unsigned o = ok ? (unsigned)ch * HW4 + (unsigned)(2 * yy) * P4 + (unsigned)xx * 8u : OOB;
+          const float2 t0 = csn_ld2(rb, o, 0u), t1 = csn_ld2(rb, ok ? o + P4 : OOB, 0u);
+          return fmaxf(fmaxf(t0.x, t0.y), fmaxf(t1.x, t1.y));
+        };
+#pragma unroll 5
+        for (int i = 0; i < 20; ++i)
+          tile[(2 * r8 + i / 10) * C3_PLANE + (i % 10) * C3_TP + 1 + lx] = pooled(c.c_lo + 2 * r8 + i / 10, y0 - 1 + (i % 10), x0 + lx);
+        if (tid < C3_CC * (C3_TY + 2)) {
+          tile[hch * C3_PLANE + hrow * C3_TP] = pooled(c.c_lo + hch, y0 - 1 + hrow, x0 - 1);
+          tile[hch * C3_PLANE + hrow * C3_TP + C3_TX + 1] = pooled(c.c_lo + hch, y0 - 1 + hrow, x0 + C3_TX);
+        }
+      };
+      {
+        const C3Chunk c0 = chunk_of(0);
+        if (ps->src[c0.s].mode == PW_TAPS) { prefetch(c0); pf_valid = true; }
+      }
       for (int ci = 0; ci < nchunk; ++ci) {
         const C3Chunk c = chunk_of(ci);
         const int nc = min(C3_CC, ps->src[c.s].C - c.c_lo);
         __syncthreads();   // the previous chunk (tile, weight chunk) / the previous sweep's epilogue scratch is consumed
         if (pf_valid) commit();
-        else stage_pooled(c, b, y0, x0);
+        else stage_pooled(c);
         if (WCH) {         // weight columns of this chunk, rows row0 .. row0 + 31: thread (r = tid >> 3) x 9 float2
           if (two || wave < 2) {
             const float* __restrict__ wg = a->wimg3 + (int64_t)(row0 + (tid >> 3)) * w3s + ci * C3_KC;
@@ -233,19 +225,9 @@ __global__ __launch_bounds__(CSN_BLOCK, C3_WAVES) void goct_c3_kernel(PwArgs a_b
         }
         __syncthreads();
         pf_valid = false;
-        // the next chunk's loads fly while this one is contracted; after the last chunk: the first chunk of the next
-        // sweep (same tile, next 32 output rows) or of the block's next tile -- they land during the epilogue
-        if (ci + 1 < nchunk) {
+        if (ci + 1 < nchunk) {   // next chunk's loads fly while this one is contracted
           const C3Chunk cn = chunk_of(ci + 1);
-          if (ps->src[cn.s].mode == PW_TAPS) { prefetch(cn, b, y0, x0); pf_valid = true; }
-        } else if (first_plain) {
-          if (row0 + 32 < nrows) { prefetch(c_first, b, y0, x0); pf_valid = true; }
-          else if (tl + nslot < tend) {
-            const int tn = tl + nslot;
-            const int bn = tn / tiles_xy, tn_xy = tn - bn * tiles_xy;
-            prefetch(c_first, bn, (tn_xy / tiles_x) * C3_TY, (tn_xy % tiles_x) * C3_TX);
-            pf_valid = true;
-          }
+          if (ps->src[cn.s].mode == PW_TAPS) { prefetch(cn); pf_valid = true; }
         }
         const int ng = (nc + 3) >> 2;
         const float* w0 = WCH ? wch : lds + (int64_t)row0 * w3s + ci * C3_KC;
@@ -291,29 +273,16 @@ __global__ __launch_bounds__(CSN_BLOCK, C3_WAVES) void goct_c3_kernel(PwArgs a_b
         const int rbase = row0 + 16 * t;
         const int rn = min(16, nrows - rbase);
         csn_cfp scale = csn_const(ps->scale) + rbase, shift = csn_const(ps->shift) + rbase, alpha = csn_const(ps->alpha) + rbase;
-        for (int r8b = 0; r8b < rn; r8b += 4) {
-          // the four bilinear taps of four z channels are issued together (16 loads in flight), not row by row
-          float zv[4];
+#pragma unroll 4
+        for (int rr = 0; rr < rn; ++rr) {
+          float v = xb[rr * PW_EP + lane];
           if (has_z) {
-            float t0[4], t1[4], t2[4], t3[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const unsigned so = (unsigned)(a->z_c0 + rbase + min(r8b + j, rn - 1)) * zcs4;
-              t0[j] = csn_ld1(zb, zo00, so); t1[j] = csn_ld1(zb, zo01, so); t2[j] = csn_ld1(zb, zo10, so); t3[j] = csn_ld1(zb, zo11, so);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) zv[j] = zw00 * t0[j] + zw01 * t1[j] + zw10 * t2[j] + zw11 * t3[j];
+            const unsigned so = (unsigned)(a->z_c0 + rbase + rr) * zcs4;
+            v += zw00 * csn_ld1(zb, zo00, so) + zw01 * csn_ld1(zb, zo01, so) + zw10 * csn_ld1(zb, zo10, so) +
+                 zw11 * csn_ld1(zb, zo11, so);
           }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int rr = r8b + j;
-            if (rr < rn) {
-              float v = xb[rr * PW_EP + lane];
-              if (has_z) v += zv[j];
-              const float val = RAW ? v : csn_epi(v, scale[rr], shift[rr], alpha[rr]);
-              if (valid) csn_st1(ob, ovoff, (unsigned)(rbase + rr) * cs4, val);
-            }
-          }
+          const float val = RAW ? v : csn_epi(v, scale[rr], shift[rr], alpha[rr]);
+          if (valid) csn_st1(ob, ovoff, (unsigned)(rbase + rr) * cs4, val);
         }
       }
     }

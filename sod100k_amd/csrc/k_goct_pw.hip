@@ -27,10 +27,6 @@
 // All loops are run-time: one kernel for every channel plan.  HBM traffic = unit inputs once + outputs once.
 #include "pw_gather.h"
 
-#ifndef PW_LEAN
-#define PW_LEAN 1   // lean gather batches for OWN / POOL2 / UP slices (pw_gather.h); 0 = the general batches (A/B builds)
-#endif
-
 // acc[i] += sum_{u<4} W[row0 + (lane>>4)*4 + i][k0 + u] * x[k0 + u][16 s + (lane&15)]
 // wt = &W[row0][k0] in the LDS weight image (row pitch `stride`), xs = &x[k0][16 s] in the wave's panel.
 __device__ __forceinline__ void pw_mfma16(const float* wt, int stride, const float* xs, int lane, csn_f4& acc) {
@@ -81,14 +77,14 @@ __device__ __forceinline__ void pw_sweep(PwPassP ps, const float* wl0, float* xb
   for (int kc = 0; kc < cin4; kc += PW_KC) {
     const int kend = min(kc + PW_KC, cin4);
     CSN_WAVE_SYNC();  // previous panel fully consumed
-    if (kc < c1) pw_gather_slice<PW_XP, PW_LEAN != 0>(ps, 0, kc, min(kend, c1), xb + lane, PW_KC, b, gy, gx, Hr, Wr);
+    if (kc < c1) pw_gather_slice<PW_XP>(ps, 0, kc, min(kend, c1), xb + lane, PW_KC, b, gy, gx, Hr, Wr);
     if (max(kc, c1) < min(kend, c2)) {
       const int r0 = max(kc, c1) - kc;
-      pw_gather_slice<PW_XP, PW_LEAN != 0>(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xb + r0 * PW_XP + lane, PW_KC - r0, b, gy, gx, Hr, Wr);
+      pw_gather_slice<PW_XP>(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xb + r0 * PW_XP + lane, PW_KC - r0, b, gy, gx, Hr, Wr);
     }
     if (max(kc, c2) < min(kend, cin)) {
       const int r0 = max(kc, c2) - kc;
-      pw_gather_slice<PW_XP, PW_LEAN != 0>(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xb + r0 * PW_XP + lane, PW_KC - r0, b, gy, gx, Hr, Wr);
+      pw_gather_slice<PW_XP>(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xb + r0 * PW_XP + lane, PW_KC - r0, b, gy, gx, Hr, Wr);
     }
     for (int k = max(cin, kc); k < kend; ++k) xb[(k - kc) * PW_XP + lane] = 0.f;  // pad to a multiple of 4
     CSN_WAVE_SYNC();  // panel complete
@@ -138,7 +134,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
   __syncthreads();
 
   const int wave = tid >> 6, lane = tid & 63;
-  float* xb = lds + a->wimg_floats + wave * (PW_PR * PW_XP);   // this wave's x[k][64 px] panel (+ overshoot rows)
+  float* xb = lds + a->wimg_floats + wave * (PW_KC * PW_XP);   // this wave's x[k][64 px] panel
   const int H0 = a->H0, W0 = a->W0, npass = a->npass;
   const int tiles_xy = a->tiles_x * a->tiles_y;
   const int ntiles = tiles_xy * a->B;
@@ -159,7 +155,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
       PwPassP ps = &a->pass[pi];
       const int r = ps->r;
       const int Hr = H0 >> r, Wr = W0 >> r;
-      const int txl = 5 - r;  // log2(PW_TX0 >> r)
+      const int txl = PW_TXL - r;  // log2(PW_TX0 >> r)
       const int npx = ((1 << tyl) >> r) << txl;
       const int ng = (npx + 63) >> 6;
       const int nrows = ps->nrows;
@@ -190,7 +186,7 @@ int csn_launch_pw(const PwArgs& a, int raw, void* stream) {
   const int ntiles = a.tiles_x * a.tiles_y * a.B;
   const int nblk = ntiles < PW_MAX_GRID ? ntiles : PW_MAX_GRID;
   const dim3 grid((nblk + 7) & ~7);   // multiple of 8: see the XCD-aware tile order in the kernel
-  const size_t lds = ((size_t)a.wimg_floats + 4 * PW_PR * PW_XP) * sizeof(float);
+  const size_t lds = ((size_t)a.wimg_floats + 4 * PW_KC * PW_XP) * sizeof(float);
 #ifndef CSN_CPU_EMU
   static bool attr_done = false;
   if (!attr_done) {

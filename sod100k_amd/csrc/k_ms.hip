@@ -239,7 +239,9 @@ int csn_launch_ms(const MsArgs& a, void* stream) {
     attr_done = true;
   }
 #endif
-  static const bool force_old = std::getenv("CSN_MS_TILED") && std::getenv("CSN_MS_TILED")[0] == '0';
+  // the LDS-tiled version measured 2.6x SLOWER than the per-pixel kernel on MI355X (0.69 vs 0.26 ms for the three MSBlocks at
+  // batch 64, profiles/r2_notes.md): opt-in only (CSN_MS_TILED=1, tests)
+  static const bool force_old = !(std::getenv("CSN_MS_TILED") && std::getenv("CSN_MS_TILED")[0] == '1');
   int RB0, CC0, RB1, CC1;
   size_t l0, l1;
   if (!force_old && ms2_geometry(a, 4, RB0, CC0, l0) && ms2_geometry(a, 16, RB1, CC1, l1)) {

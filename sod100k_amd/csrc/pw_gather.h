@@ -91,40 +91,6 @@ __device__ __forceinline__ void pw_batch_up(csn_buf rb, unsigned o00, unsigned o
     if (k0 + j < rmax) xrow[(k0 + j) * XP] = w00 * t0[j] + w01 * t1[j] + w10 * t2[j] + w11 * t3[j];
 }
 
-// ---- lean batches (goct_pw_kernel's hot modes) ------------------------------------------------------------------------
-// Eight (then four) channels per batch, no clamp and no row guard: the buffer resource is bounded to the slice, so channels
-// past its end read 0, and the panel has PW_PR = 20 rows, so the (up to 3) rows written past the slice are either overwritten by the
-// next slice's batch (LDS operations of a wave retire in order) or never contracted.  One s_add per load instead of the
-// clamp + multiply + guarded store of the general batches (7-8 SALU per channel in the round-1 build).
-template <int NB, int XP>
-__device__ __forceinline__ void pw2_own(csn_buf rb, unsigned lo, unsigned cs4, unsigned so, float* xrow) {
-  float v[NB];
-#pragma unroll
-  for (int j = 0; j < NB; ++j) { v[j] = csn_ld1(rb, lo, so); so += cs4; }
-#pragma unroll
-  for (int j = 0; j < NB; ++j) xrow[j * XP] = v[j];
-}
-template <int NB, int XP>
-__device__ __forceinline__ void pw2_pool(csn_buf rb, unsigned lo, unsigned cs4, unsigned ws4, unsigned so, float* xrow) {
-  float2 a0[NB], a1[NB];
-#pragma unroll
-  for (int j = 0; j < NB; ++j) { a0[j] = csn_ld2(rb, lo, so); a1[j] = csn_ld2(rb, lo + ws4, so); so += cs4; }
-#pragma unroll
-  for (int j = 0; j < NB; ++j) xrow[j * XP] = fmaxf(fmaxf(a0[j].x, a0[j].y), fmaxf(a1[j].x, a1[j].y));
-}
-template <int NB, int XP>
-__device__ __forceinline__ void pw2_up(csn_buf rb, unsigned o00, unsigned o01, unsigned o10, unsigned o11, float w00,
-                                       float w01, float w10, float w11, unsigned cs4, unsigned so, float* xrow) {
-  float t0[NB], t1[NB], t2[NB], t3[NB];
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    t0[j] = csn_ld1(rb, o00, so); t1[j] = csn_ld1(rb, o01, so); t2[j] = csn_ld1(rb, o10, so); t3[j] = csn_ld1(rb, o11, so);
-    so += cs4;
-  }
-#pragma unroll
-  for (int j = 0; j < NB; ++j) xrow[j * XP] = w00 * t0[j] + w01 * t1[j] + w10 * t2[j] + w11 * t3[j];
-}
-
 // 3x3 taps of an own-resolution slice: gathered entry kk = 9*ch + t, t = 3*(dy+1) + (dx+1).  `vm` has
 // bit t set when tap t of this lane's pixel lies inside the image (zero padding otherwise).
 template <int NB, int XP>
@@ -197,48 +163,11 @@ __device__ __forceinline__ unsigned pw_tap_mask(int y, int x, int Hr, int Wr, in
   return vm;
 }
 
-template <int XP, bool LEAN = false>
+template <int XP>
 __device__ __forceinline__ void pw_gather_slice(PwPassP ps, int s, int c_lo, int c_hi, float* xrow, int rmax, int b,
                                                 int y, int x, int Hr, int Wr) {
   const int mode = ps->src[s].mode;
   const int n = c_hi - c_lo;   // 1..16
-  if (LEAN && (mode == PW_OWN || mode == PW_POOL2 || mode == PW_UP2 || mode == PW_UP4)) {
-    const int crem = ps->src[s].C - c_lo;                      // channels from the batch start to the end of the slice
-    if (mode == PW_OWN) {
-      const unsigned cs = (unsigned)(Hr * Wr);
-      const csn_buf rb = csn_make_buf_n(ps->src[s].ptr + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs, (unsigned)crem * cs * 4u);
-      const unsigned lo = (unsigned)(y * Wr + x) * 4u;
-      int k0 = 0;
-      for (; k0 + 8 <= n; k0 += 8) pw2_own<8, XP>(rb, lo, cs * 4u, (unsigned)k0 * cs * 4u, xrow + k0 * XP);
-      for (; k0 < n; k0 += 4) pw2_own<4, XP>(rb, lo, cs * 4u, (unsigned)k0 * cs * 4u, xrow + k0 * XP);
-    } else if (mode == PW_POOL2) {
-      const unsigned Ws = (unsigned)Wr * 2u;
-      const unsigned cs = (unsigned)(Hr * 2) * Ws;
-      const csn_buf rb = csn_make_buf_n(ps->src[s].ptr + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs, (unsigned)crem * cs * 4u);
-      const unsigned lo = ((unsigned)(2 * y) * Ws + 2u * x) * 4u;
-      int k0 = 0;
-      for (; k0 + 8 <= n; k0 += 8) pw2_pool<8, XP>(rb, lo, cs * 4u, Ws * 4u, (unsigned)k0 * cs * 4u, xrow + k0 * XP);
-      for (; k0 < n; k0 += 4) pw2_pool<4, XP>(rb, lo, cs * 4u, Ws * 4u, (unsigned)k0 * cs * 4u, xrow + k0 * XP);
-    } else {
-      const int sh = mode == PW_UP2 ? 1 : 2;
-      const int Hs = Hr >> sh, Ws = Wr >> sh;
-      int y0, y1, x0, x1;
-      float ly, lx;
-      csn_bilin(y, mode == PW_UP2 ? 0.5f : 0.25f, Hs, y0, y1, ly);
-      csn_bilin(x, mode == PW_UP2 ? 0.5f : 0.25f, Ws, x0, x1, lx);
-      const unsigned cs = (unsigned)(Hs * Ws);
-      const csn_buf rb = csn_make_buf_n(ps->src[s].ptr + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs, (unsigned)crem * cs * 4u);
-      const unsigned o00 = (unsigned)(y0 * Ws + x0) * 4u, o01 = (unsigned)(y0 * Ws + x1) * 4u,
-                     o10 = (unsigned)(y1 * Ws + x0) * 4u, o11 = (unsigned)(y1 * Ws + x1) * 4u;
-      const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
-      int k0 = 0;
-      for (; k0 + 8 <= n; k0 += 8)
-        pw2_up<8, XP>(rb, o00, o01, o10, o11, w00, w01, w10, w11, cs * 4u, (unsigned)k0 * cs * 4u, xrow + k0 * XP);
-      for (; k0 < n; k0 += 4)
-        pw2_up<4, XP>(rb, o00, o01, o10, o11, w00, w01, w10, w11, cs * 4u, (unsigned)k0 * cs * 4u, xrow + k0 * XP);
-    }
-    return;
-  }
   if (mode == PW_OWN) {
     const unsigned cs = (unsigned)(Hr * Wr);
     const csn_buf rb = csn_make_buf(ps->src[s].ptr + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
