@@ -111,8 +111,12 @@ void csn_plan_destroy(csn_plan* plan);
  * CSN_OPT_FUSE_ILB [0]: value w > 0: a 1x1 ILBlock (conv1x1 -> conv3x3_1 -> conv3x3_2, csnet.py:72-76) whose finest output
  * branch is at least w pixels wide runs as ONE kernel (ilb_kernel: one wave per column strip, every intermediate in
  * registers).  Parity-green, but measured SLOWER than the unit-level kernels on MI355X (2.2 vs 1.8 ms for the 14 blocks
- * at batch 64, profiles/r2_notes.md), hence off by default. */
-enum csn_option { CSN_OPT_FUSE_DW = 1, CSN_OPT_GRAPH = 2, CSN_OPT_FUSE_CLS = 3, CSN_OPT_TILED3 = 4, CSN_OPT_FUSE_ILB = 5 };
+ * at batch 64, profiles/r2_notes.md), hence off by default.
+ * CSN_OPT_OVERLAP [1]: launches that do not depend on each other -- {z -> high pass} || {low pass} of a 3x3 unit, the
+ * per-branch launches of CSFHead.fuse, the three MSBlocks -- are enqueued on parallel stream lanes (fork / join by events on
+ * the caller's stream; parallel branches of the hipGraph); 0 = one stream, strictly in order. */
+enum csn_option { CSN_OPT_FUSE_DW = 1, CSN_OPT_GRAPH = 2, CSN_OPT_FUSE_CLS = 3, CSN_OPT_TILED3 = 4, CSN_OPT_FUSE_ILB = 5,
+                  CSN_OPT_OVERLAP = 6 };
 int csn_plan_set_option(csn_plan* plan, int32_t option, int32_t value);
 
 size_t csn_plan_workspace_bytes(const csn_plan* plan);

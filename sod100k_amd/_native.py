@@ -25,6 +25,7 @@ OPT_GRAPH = 2
 OPT_FUSE_CLS = 3
 OPT_TILED3 = 4
 OPT_FUSE_ILB = 5
+OPT_OVERLAP = 6
 
 
 class ActDesc(C.Structure):

@@ -150,6 +150,9 @@ struct csn_plan {
   bool fuse_dw = true;
   bool fuse_cls = true;   // CSN_OPT_FUSE_CLS
   bool tiled3 = true;     // CSN_OPT_TILED3
+  bool overlap = true;    // CSN_OPT_OVERLAP: independent launches of a unit (and the MSBlocks) on parallel stream lanes
+  hipStream_t lane[2] = {nullptr, nullptr};      // auxiliary lanes (lane 0 = the caller's stream)
+  hipEvent_t lane_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int fuse_ilb = 0;       // CSN_OPT_FUSE_ILB: minimum width of the finest output branch; 0 = off (default: measured slower
                           // than the unit-level kernels on MI355X, profiles/r2_notes.md)
   Epi ident;   // identity epilogue (scale 1, shift 0, alpha 1): train mode runs the conv kernels raw
@@ -551,6 +554,7 @@ struct Ctx {
   float* act_y(int id) const { return reinterpret_cast<float*>(ws + P.acts[id].ws_off); }
   const float* pk(int64_t off) const { return P.packed + off; }
   bool raw = false;   // train mode: convolutions write the un-normalised z (identity epilogue)
+  bool lanes = false; // eval forward outside profiling: independent launches may go to the plan's auxiliary streams
   const float* sc(const Epi& e) const { return P.packed + (raw ? P.ident.scale : e.scale); }
   const float* sh(const Epi& e) const { return P.packed + (raw ? P.ident.shift : e.shift); }
   const float* al(const Epi& e) const { return P.packed + (raw ? P.ident.alpha : e.alpha); }
@@ -698,6 +702,31 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
   return c.mark("goct_pw_kernel");
 }
 
+// ---- stream lanes: fork n auxiliary lanes off the caller's stream / join them back (events; under stream capture these
+// become parallel branches of the hipGraph) ----
+int lanes_fork(const Ctx& c, int n) {
+#ifndef CSN_CPU_EMU
+  csn_plan& P = c.P;
+  HIP_TRY(hipEventRecord(P.lane_ev[0], (hipStream_t)c.stream));
+  for (int k = 0; k < n; ++k) HIP_TRY(hipStreamWaitEvent(P.lane[k], P.lane_ev[0], 0));
+#else
+  (void)c; (void)n;
+#endif
+  return CSN_OK;
+}
+int lanes_join(const Ctx& c, int n) {
+#ifndef CSN_CPU_EMU
+  csn_plan& P = c.P;
+  for (int k = 0; k < n; ++k) {
+    HIP_TRY(hipEventRecord(P.lane_ev[1 + k], P.lane[k]));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)c.stream, P.lane_ev[1 + k], 0));
+  }
+#else
+  (void)c; (void)n;
+#endif
+  return CSN_OK;
+}
+
 int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
   const csn_plan& P = c.P;
   const csn_unit_desc& d = u.d;
@@ -784,9 +813,46 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
         bd.red_b = c.pk(CL.passes[0].epi.shift);
         bd.logits = reinterpret_cast<float*>(c.ws + next->logits_off);
       }
-      for (const PwLaunchPlan& L : u.pwl) {
-        const int st = launch_pw(c, L, bd);
-        if (st != CSN_OK) return st;
+      // Launches of one unit that do not depend on each other run on parallel stream lanes (fork after everything
+      // enqueued so far, join before the next unit): a 3x3 unit is {z -> high pass} || {low pass}, a unit split per output
+      // branch (CSFHead.fuse) is one launch per lane.  Each of them alone leaves CUs idle in its ramp-up / tail.
+      const int nl = (int)u.pwl.size();
+      if (c.lanes && nl >= 2 && nl <= 3) {
+        int lane_of[3] = {0, 0, 0};
+        int next_lane = 1;
+        for (int i = 0; i < nl; ++i) {
+          const PwPassPlan& pp = u.pwl[i].passes[0];
+          bool needs_z = false;
+          for (int s2 = 0; s2 < pp.nsrc; ++s2) needs_z = needs_z || pp.src_kind[s2] == SRC_Z;
+          if (pp.out_kind == OUT_Z || needs_z || u.pwl[i].passes.size() != 1) lane_of[i] = 0;   // the z chain stays in order
+          else lane_of[i] = next_lane++;
+        }
+        // the last independent launch may as well use lane 0 when nothing else is there
+        bool lane0_used = false;
+        for (int i = 0; i < nl; ++i) lane0_used = lane0_used || lane_of[i] == 0;
+        if (!lane0_used) { for (int i = 0; i < nl; ++i) --lane_of[i]; --next_lane; }
+        if (next_lane > 1) {
+          const int st0 = lanes_fork(c, next_lane - 1);
+          if (st0 != CSN_OK) return st0;
+          for (int i = 0; i < nl; ++i) {
+            Ctx cl = c;
+            if (lane_of[i] > 0) cl.stream = c.P.lane[lane_of[i] - 1];
+            const int st = launch_pw(cl, u.pwl[i], bd);
+            if (st != CSN_OK) return st;
+          }
+          const int st1 = lanes_join(c, next_lane - 1);
+          if (st1 != CSN_OK) return st1;
+        } else {
+          for (const PwLaunchPlan& L : u.pwl) {
+            const int st = launch_pw(c, L, bd);
+            if (st != CSN_OK) return st;
+          }
+        }
+      } else {
+        for (const PwLaunchPlan& L : u.pwl) {
+          const int st = launch_pw(c, L, bd);
+          if (st != CSN_OK) return st;
+        }
       }
       if (next && next->d.kind == CSN_UNIT_CLS) {
         Up2Args ua;
@@ -1232,6 +1298,8 @@ void csn_plan_destroy(csn_plan* P) {
 #ifndef CSN_CPU_EMU
   if (P->graph_exec) (void)hipGraphExecDestroy(P->graph_exec);
   if (P->cap_stream) (void)hipStreamDestroy(P->cap_stream);
+  for (int k = 0; k < 2; ++k) if (P->lane[k]) (void)hipStreamDestroy(P->lane[k]);
+  for (int k = 0; k < 6; ++k) if (P->lane_ev[k]) (void)hipEventDestroy(P->lane_ev[k]);
 #endif
   if (P->packed) (void)hipFree(P->packed);
   if (P->jobs_dev) (void)hipFree(P->jobs_dev);
@@ -1246,6 +1314,7 @@ int csn_plan_set_option(csn_plan* P, int32_t option, int32_t value) {
     case CSN_OPT_FUSE_CLS: P->fuse_cls = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_TILED3: P->tiled3 = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_FUSE_ILB: P->fuse_ilb = value < 0 ? 0 : value; drop_graph(P); return CSN_OK;
+    case CSN_OPT_OVERLAP: P->overlap = value != 0; drop_graph(P); return CSN_OK;
     default: return CSN_E_INVALID;
   }
 }
@@ -1277,6 +1346,23 @@ int csn_plan_refresh_params(csn_plan* P, const float* arena, int64_t arena_float
   return CSN_OK;
 }
 
+// auxiliary lanes exist (created lazily; never under the CPU emulation)
+static bool lanes_ready(csn_plan* P) {
+#ifdef CSN_CPU_EMU
+  (void)P;
+  return false;
+#else
+  if (!P->overlap) return false;
+  if (!P->lane[0]) {
+    for (int k = 0; k < 2; ++k)
+      if (hipStreamCreateWithFlags(&P->lane[k], hipStreamNonBlocking) != hipSuccess) { P->overlap = false; return false; }
+    for (int k = 0; k < 6; ++k)
+      if (hipEventCreateWithFlags(&P->lane_ev[k], hipEventDisableTiming) != hipSuccess) { P->overlap = false; return false; }
+  }
+  return true;
+#endif
+}
+
 static bool ilb_active(const csn_plan* P, int u) {
   return P->fuse_ilb > 0 && P->fuse_dw && P->units[u].ilb_ok && P->units[u].ilb_width >= P->fuse_ilb;
 }
@@ -1304,7 +1390,25 @@ static int forward_body(csn_plan* P, const float* x, float* y, void* workspace, 
         const int st0 = c.mark("start");
         if (st0 != CSN_OK) { P->profiling = false; return st0; }
       }
+      c.lanes = lanes_ready(P) && !prof;
       for (int u = 0; u < nu; ++u) {
+        // consecutive MSBlocks (one per CSFHead branch, csnet.py:92-113) read different tensors: one lane each
+        if (c.lanes && P->units[u].d.kind == CSN_UNIT_MS) {
+          int m = 1;
+          while (u + m < nu && m < 3 && P->units[u + m].d.kind == CSN_UNIT_MS) ++m;
+          if (m > 1) {
+            int st = lanes_fork(c, m - 1);
+            for (int k = 0; k < m && st == CSN_OK; ++k) {
+              Ctx cl = c;
+              if (k > 0) cl.stream = P->lane[k - 1];
+              st = run_unit(cl, P->units[u + k], nullptr);
+            }
+            if (st == CSN_OK) st = lanes_join(c, m - 1);
+            if (st != CSN_OK) return st;
+            u += m - 1;
+            continue;
+          }
+        }
         if (ilb_active(P, u)) {      // conv1x1 + conv3x3_1 + conv3x3_2 of an ILBlock in one kernel
           const int st = run_ilb(c, u);
           if (st != CSN_OK) { P->profiling = false; return st; }
