@@ -114,7 +114,8 @@ void csn_plan_destroy(csn_plan* plan);
  * at batch 64, profiles/r2_notes.md), hence off by default.
  * CSN_OPT_OVERLAP [1]: launches that do not depend on each other -- {z -> high pass} || {low pass} of a 3x3 unit, the
  * per-branch launches of CSFHead.fuse, the three MSBlocks -- are enqueued on parallel stream lanes (fork / join by events on
- * the caller's stream; parallel branches of the hipGraph); 0 = one stream, strictly in order. */
+ * the caller's stream; parallel branches of the hipGraph); 0 = one stream, strictly in order; 2 = additionally all
+ * weight-gradient launches of csn_backward on a side lane (own partial buffers; measured: no gain, hence not the default). */
 enum csn_option { CSN_OPT_FUSE_DW = 1, CSN_OPT_GRAPH = 2, CSN_OPT_FUSE_CLS = 3, CSN_OPT_TILED3 = 4, CSN_OPT_FUSE_ILB = 5,
                   CSN_OPT_OVERLAP = 6 };
 int csn_plan_set_option(csn_plan* plan, int32_t option, int32_t value);

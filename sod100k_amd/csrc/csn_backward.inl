@@ -327,7 +327,7 @@ int run_wgrad(const BwdCtx& b, const WgPlan& w, const PwBind& bd) {
   a.gpp = (int)((hw + 63) / 64);
   a.ngroups = a.gpp * P.S;
   a.k16 = (pp.K + 15) & ~15;
-  a.partial = reinterpret_cast<float*>(b.c.ws + P.wg_off);
+  a.partial = reinterpret_cast<float*>(b.c.ws + (b.c.side ? P.wg2_off : P.wg_off));
   // the kernel holds at most 80 output channels (5 MFMA row tiles) per launch: wider passes go in row chunks
   for (int r0 = 0; r0 < pp.nrows; r0 += WG_MAX_ROWS) {
     const int nr = std::min(WG_MAX_ROWS, pp.nrows - r0);
@@ -415,6 +415,17 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
   }
   if (ub.tmp_off >= 0) bd.tmp = reinterpret_cast<float*>(scratch + ub.tmp_off);
 
+  // Weight gradients leave the critical path: they only read dz (final once the BN backward above has run) and saved
+  // activations and nothing reads them before the optimizer, so they go to a side lane (own partial buffers) while the
+  // caller's stream carries on with the input gradients and the next unit's BN backward.  Joined at the end of csn_backward.
+  Ctx cs = c;
+  if (c.lanes) {
+    const int stf = lanes_fork(c, 1);
+    if (stf != CSN_OK) return stf;
+    cs.stream = P.lane[0];
+    cs.side = true;
+  }
+  const BwdCtx bs{cs, b.arena, b.grad, b.flop_w, b.pen_scale};
   if (d.kind == CSN_UNIT_DW) {
     DwArgs a;
     a.nbr = 0; a.B = S;
@@ -424,9 +435,9 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
       const Act& act = P.acts[d.in_act[k]];
       const int H = P.H >> act.lvl, W = P.W >> act.lvl;
       DwWgradArgs w;
-      w.dz = bd.dz[k]; w.x = bd.in[k]; w.partial = reinterpret_cast<double*>(c.ws + P.red_off); w.grad = b.grad;
+      w.dz = bd.dz[k]; w.x = bd.in[k]; w.partial = reinterpret_cast<double*>(c.ws + (cs.side ? P.red2_off : P.red_off)); w.grad = b.grad;
       w.off_w = d.w_off[k]; w.C = d.cout[k]; w.S = S; w.H = H; w.W = W;
-      LAUNCH_TRY(csn_launch_dw_wgrad(w, c.stream));
+      LAUNCH_TRY(csn_launch_dw_wgrad(w, cs.stream));
       if (!ub.need_dx[k]) continue;
       DwBranch& br = a.br[a.nbr++];
       br.in = bd.dz[k]; br.out = bd.dx[k];
@@ -458,7 +469,11 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
     bd.adj[k] = ua.out;
   }
   for (const WgPlan& w : ub.wg) {
-    const int st = run_wgrad(b, w, bd);
+    // a pass that reads the adjoint-upsampled dz lives in the shared scratch, which the next unit overwrites: main lane
+    bool scratch_free = w.a_kind != SRC_ADJ;
+    for (int s2 = 0; s2 < w.L.passes[0].nsrc; ++s2)
+      scratch_free = scratch_free && (w.L.passes[0].src_kind[s2] == SRC_IN || w.L.passes[0].src_kind[s2] == SRC_DZ);
+    const int st = run_wgrad(scratch_free ? bs : b, w, bd);
     if (st != CSN_OK) return st;
   }
   for (int i = 0; i < d.n_in; ++i)
@@ -540,6 +555,7 @@ int csn_plan_enable_training(csn_plan* P) {
       }
   }
   P->red_off = bl.alloc_ws((int64_t)maxc * CSN_BN_NSLAB * 9 * sizeof(double));
+  P->red2_off = bl.alloc_ws((int64_t)maxc * CSN_BN_NSLAB * 9 * sizeof(double));   // ... of the weight-gradient side lane
   P->bwd.clear();
   P->bwd.resize(nu);
   int64_t scratch = 0, wg_floats = 0;
@@ -568,6 +584,7 @@ int csn_plan_enable_training(csn_plan* P) {
   P->scratch_bytes = scratch;
   P->scratch_off = bl.alloc_ws(scratch > 0 ? scratch : 256);
   P->wg_off = bl.alloc_ws(wg_floats * (int64_t)sizeof(float));
+  P->wg2_off = bl.alloc_ws(wg_floats * (int64_t)sizeof(float));
   // the packed buffer and the job list grew: re-allocate / re-upload
   if (P->packed) (void)hipFree(P->packed);
   if (P->jobs_dev) (void)hipFree(P->jobs_dev);
@@ -598,12 +615,17 @@ int csn_backward(csn_plan* P, const float* x, const float* dy, void* workspace, 
   return run_graphed(P, P->g_bwd, key, stream, [&](void* s) {
     Ctx c{*P, x, nullptr, static_cast<char*>(workspace), s};
     c.raw = true;
+    c.lanes = P->overlap_bwd && lanes_ready(P);   // measured: no gain for the train step (106.3 vs 105.5 ms), off by default
     const BwdCtx b{c, arena, grad, flop_w, pen_scale};
     for (int a : P->orphan_acts)
       HIP_TRY(hipMemsetAsync(c.ws + P->tg_off[a][0], 0, (size_t)P->S * P->acts[a].channels * (P->H >> P->acts[a].lvl) *
                                                            (P->W >> P->acts[a].lvl) * sizeof(float), (hipStream_t)s));
     for (int u = (int)P->units.size() - 1; u >= 0; --u) {
       const int st = run_unit_bwd(b, u, dy);
+      if (st != CSN_OK) return st;
+    }
+    if (c.lanes) {       // the weight-gradient lane rejoins the caller's stream
+      const int st = lanes_join(c, 1);
       if (st != CSN_OK) return st;
     }
     return (int)CSN_OK;

@@ -150,6 +150,7 @@ struct csn_plan {
   bool fuse_dw = true;
   bool fuse_cls = true;   // CSN_OPT_FUSE_CLS
   bool tiled3 = true;     // CSN_OPT_TILED3
+  bool overlap_bwd = false;   // CSN_OPT_OVERLAP value 2: also the weight-gradient side lane of csn_backward
   bool overlap = true;    // CSN_OPT_OVERLAP: independent launches of a unit (and the MSBlocks) on parallel stream lanes
   hipStream_t lane[2] = {nullptr, nullptr};      // auxiliary lanes (lane 0 = the caller's stream)
   hipEvent_t lane_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -186,6 +187,7 @@ struct csn_plan {
   int64_t scratch_off = 0, scratch_bytes = 0;   // per-unit backward temporaries (shared by all units)
   int64_t red_off = 0;                          // fp64 partials of the BN / depthwise reductions
   int64_t wg_off = 0;                           // partial dW slices (k_wgrad.hip)
+  int64_t red2_off = 0, wg2_off = 0;            // ... of the weight-gradient side lane (csn_backward)
   std::vector<UnitBwd> bwd;
   ~csn_plan();
 };
@@ -555,6 +557,7 @@ struct Ctx {
   const float* pk(int64_t off) const { return P.packed + off; }
   bool raw = false;   // train mode: convolutions write the un-normalised z (identity epilogue)
   bool lanes = false; // eval forward outside profiling: independent launches may go to the plan's auxiliary streams
+  bool side = false;  // backward: this context enqueues on the weight-gradient side lane (own partial buffers)
   const float* sc(const Epi& e) const { return P.packed + (raw ? P.ident.scale : e.scale); }
   const float* sh(const Epi& e) const { return P.packed + (raw ? P.ident.shift : e.shift); }
   const float* al(const Epi& e) const { return P.packed + (raw ? P.ident.alpha : e.alpha); }
@@ -1127,6 +1130,23 @@ static void drop_graph(csn_plan* P) {
   P->eager_calls = 0;
 }
 
+// auxiliary lanes exist (created lazily; never under the CPU emulation)
+static bool lanes_ready(csn_plan* P) {
+#ifdef CSN_CPU_EMU
+  (void)P;
+  return false;
+#else
+  if (!P->overlap) return false;
+  if (!P->lane[0]) {
+    for (int k = 0; k < 2; ++k)
+      if (hipStreamCreateWithFlags(&P->lane[k], hipStreamNonBlocking) != hipSuccess) { P->overlap = false; return false; }
+    for (int k = 0; k < 6; ++k)
+      if (hipEventCreateWithFlags(&P->lane_ev[k], hipEventDisableTiming) != hipSuccess) { P->overlap = false; return false; }
+  }
+  return true;
+#endif
+}
+
 #include "csn_backward.inl"   // backward planning + sequencing (shares the plan's private types)
 
 // ------------------------------------------------------------------------------------------ C ABI
@@ -1314,7 +1334,7 @@ int csn_plan_set_option(csn_plan* P, int32_t option, int32_t value) {
     case CSN_OPT_FUSE_CLS: P->fuse_cls = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_TILED3: P->tiled3 = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_FUSE_ILB: P->fuse_ilb = value < 0 ? 0 : value; drop_graph(P); return CSN_OK;
-    case CSN_OPT_OVERLAP: P->overlap = value != 0; drop_graph(P); return CSN_OK;
+    case CSN_OPT_OVERLAP: P->overlap = value != 0; P->overlap_bwd = value == 2; drop_graph(P); return CSN_OK;
     default: return CSN_E_INVALID;
   }
 }
@@ -1344,23 +1364,6 @@ int csn_plan_refresh_params(csn_plan* P, const float* arena, int64_t arena_float
   P->params_ready = true;
   P->bn_tables_train = false;
   return CSN_OK;
-}
-
-// auxiliary lanes exist (created lazily; never under the CPU emulation)
-static bool lanes_ready(csn_plan* P) {
-#ifdef CSN_CPU_EMU
-  (void)P;
-  return false;
-#else
-  if (!P->overlap) return false;
-  if (!P->lane[0]) {
-    for (int k = 0; k < 2; ++k)
-      if (hipStreamCreateWithFlags(&P->lane[k], hipStreamNonBlocking) != hipSuccess) { P->overlap = false; return false; }
-    for (int k = 0; k < 6; ++k)
-      if (hipEventCreateWithFlags(&P->lane_ev[k], hipEventDisableTiming) != hipSuccess) { P->overlap = false; return false; }
-  }
-  return true;
-#endif
 }
 
 static bool ilb_active(const csn_plan* P, int u) {
