@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--csf-steps", type=int, default=5)
     ap.add_argument("--train-steps", type=int, default=10,
                     help="also time this many full train steps (0 = skip); reported under \"train_step\"")
+    ap.add_argument("--no-train-bf16", action="store_true", help="skip the bf16-activation train step (\"train_step_bf16\")")
     ap.add_argument("--event-steps", type=int, default=50,
                     help="extra steps timed one by one with HIP events after the contract's timed region (median reported)")
     ap.add_argument("--emu-plumbing", action="store_true",
@@ -269,12 +270,16 @@ def main():
                                         frac=round(total_alg / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
                         per_kernel={k: dict(ms=round(v["ms"], 3), launches=v["launches"],
                                             us_per_launch=round(v["ms"] * 1e3 / v["launches"], 2),
-                                            alg_GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None)
+                                            alg_GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None,
+                                            # the fused depthwise pair implements TWO units per launch: its algorithmic
+                                            # bytes count both units' (in + out), the kernel physically moves half of that
+                                            **({"moved_GBps": round(0.5 * v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
+                                               if k == "dw3x3x2_bn_prelu_kernel" and v["bytes"] else {}))
                                     for k, v in agg.items() if "ms" in v})
 
     sub_b = eng_sub(eng, B)
     # ---- second data point: the full train step (fwd train-mode + BCE + backward + gradient all-reduce + Adam) ----
-    train = None
+    train = train16 = None
     if args.train_steps > 0:
         from sod100k_amd.tools.train import FusedTrainer
         del eng, y
@@ -282,29 +287,42 @@ def main():
         torch.cuda.empty_cache()
         model.train()
         model.flops_hook(1.0)                       # csnet-L-x2_train.yml: FLOPS.EXPAND 1.0, WEIGHT 3.0
-        model.set_batchsize(B)
         TB = args.train_batch or B
         model.set_batchsize(TB)
-        tr = FusedTrainer(model, lr=1e-4, weight_decay=5e-3, flops_weight=3.0, batchsize=TB)
         xt = x if TB == B else torch.randn(TB, 3, S, S, generator=g).to(dev)
         tgt = (torch.rand(TB, 1, S, S, generator=g) > 0.5).float().to(dev)
 
-        def tstep():
-            tr.step(xt, tgt, world_size=world)
+        def time_train(act_dtype):
+            """act_dtype "fp32": the reference's arithmetic; "bf16": BASELINE config 3 (bfloat16 activation storage)."""
+            esz = 2 if act_dtype == "bf16" else 4
+            tr = FusedTrainer(model, lr=1e-4, weight_decay=5e-3, flops_weight=3.0, batchsize=TB, act_dtype=act_dtype)
 
-        for _ in range(3):
-            tstep()
-        tdt = D.timed_region(tstep, args.train_steps, sync=sync, device=dev)
-        t_alg = train_algorithmic_bytes(model) * TB if not emu else 0
-        t_bw = t_alg / (tdt / args.train_steps) / 1e9
-        train = {"value": round(world * TB * args.train_steps / tdt, 1), "unit": "images/sec",
-                 "ms_per_step": round(tdt / args.train_steps * 1e3, 3), "steps": args.train_steps,
-                 "batch_per_gpu": TB, "dtype": "f32", "loss": round(float(tr.loss), 6),
-                 "roofline": {"bound": "hbm", "achieved": round(t_bw, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(t_bw / HBM_PEAK_GBS, 4), "bytes_per_step": int(t_alg),
-                              "what": "algorithmic (3*in + 7*out) x 4 B per unit (SURVEY 8(d)) / whole-step time"},
-                 "what": "train-mode forward (batch-stat BN + penalty) + BCE + backward + "
-                         + ("RCCL all-reduce of the flat gradient + " if world > 1 else "") + "Adam, csnet-L-x2 weights"}
+            def tstep():
+                tr.step(xt, tgt, world_size=world)
+
+            for _ in range(3):
+                tstep()
+            tdt = D.timed_region(tstep, args.train_steps, sync=sync, device=dev)
+            t_alg = train_algorithmic_bytes(model) // 4 * esz * TB if not emu else 0
+            t_bw = t_alg / (tdt / args.train_steps) / 1e9
+            rec = {"value": round(world * TB * args.train_steps / tdt, 1), "unit": "images/sec",
+                   "ms_per_step": round(tdt / args.train_steps * 1e3, 3), "steps": args.train_steps,
+                   "batch_per_gpu": TB, "dtype": "f32" if esz == 4 else "bf16 activations, f32 arithmetic / parameters / optimizer",
+                   "loss": round(float(tr.loss), 6),
+                   "roofline": {"bound": "hbm", "achieved": round(t_bw, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(t_bw / HBM_PEAK_GBS, 4), "bytes_per_step": int(t_alg),
+                                "what": f"algorithmic (3*in + 7*out) x {esz} B per unit (SURVEY 8(d)) / whole-step time"},
+                   "what": "train-mode forward (batch-stat BN + penalty) + BCE + backward + "
+                           + ("RCCL all-reduce of the flat gradient + " if world > 1 else "") + "Adam, csnet-L-x2 weights"}
+            del tr
+            model._engines = {}
+            torch.cuda.empty_cache()
+            return rec
+
+        train = time_train("fp32")
+        if not args.no_train_bf16:
+            train16 = time_train("bf16")
+        model.set_train_act_dtype("fp32")
         model.eval()
 
     csf = None
@@ -335,6 +353,8 @@ def main():
             out["hip_events"] = ev_stats
         if train is not None:
             out["train_step"] = train
+        if train16 is not None:
+            out["train_step_bf16"] = train16
         if csf is not None:
             out["csf_res2net"] = csf
         if world == 1 and not args.no_cpu_baseline:

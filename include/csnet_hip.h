@@ -115,14 +115,34 @@ void csn_plan_destroy(csn_plan* plan);
  * CSN_OPT_OVERLAP [1]: launches that do not depend on each other -- {z -> high pass} || {low pass} of a 3x3 unit, the
  * per-branch launches of CSFHead.fuse, the three MSBlocks -- are enqueued on parallel stream lanes (fork / join by events on
  * the caller's stream; parallel branches of the hipGraph); 0 = one stream, strictly in order; 2 = additionally all
- * weight-gradient launches of csn_backward on a side lane (own partial buffers; measured: no gain, hence not the default). */
+ * weight-gradient launches of csn_backward on a side lane (own partial buffers; measured: no gain, hence not the default).
+ * CSN_OPT_TRAIN_BF16 [0]: BASELINE config 3's dtype -- csn_forward_train / csn_backward keep every activation and activation
+ * gradient in the workspace as bfloat16 (round-to-nearest-even on store; all arithmetic, the BN statistics, the weight
+ * gradients, parameters and optimizer state stay fp32 / fp64).  x, y, dy at the boundary stay float.  Needs
+ * csn_plan_enable_training; csn_forward (eval) is unaffected and stays fp32 (the 1e-4 parity configuration). */
 enum csn_option { CSN_OPT_FUSE_DW = 1, CSN_OPT_GRAPH = 2, CSN_OPT_FUSE_CLS = 3, CSN_OPT_TILED3 = 4, CSN_OPT_FUSE_ILB = 5,
-                  CSN_OPT_OVERLAP = 6 };
+                  CSN_OPT_OVERLAP = 6, CSN_OPT_TRAIN_BF16 = 7 };
 int csn_plan_set_option(csn_plan* plan, int32_t option, int32_t value);
 
 size_t csn_plan_workspace_bytes(const csn_plan* plan);
 int csn_plan_act_info(const csn_plan* plan, int32_t act_id, csn_act_info* out);
 int32_t csn_plan_num_units(const csn_plan* plan);
+
+/* Debug / parity probes of the train step (valid after csn_plan_enable_training): where an activation's companions live
+ * in the workspace.  z: the raw convolution output of the producing unit after csn_forward_train, OVERWRITTEN by the
+ * gradient w.r.t. z (dz) in csn_backward; grad[s]: the gradient w.r.t. the activation contributed by its s-th consumer
+ * (-1: none).  Elements are bfloat16 when CSN_OPT_TRAIN_BF16 is set (`bf16` = 1), else float. */
+typedef struct csn_train_act_info {
+  int64_t act_offset_bytes;     /* the activation itself (-1: the external input; bf16 mode keeps a copy at x16)  */
+  int64_t z_offset_bytes;       /* -1 for the external input                                                       */
+  int64_t grad_offset_bytes[2];
+  int64_t x16_offset_bytes;     /* bf16 copy of the external input (act 0), -1 otherwise / in fp32 mode            */
+  int32_t n_consumers;
+  int32_t bf16;
+} csn_train_act_info;
+int csn_plan_train_act_info(const csn_plan* plan, int32_t act_id, csn_train_act_info* out);
+/* Which of the two gradient buffers of its input activation `branch` unit `unit` writes (0 / 1; < 0: none). */
+int32_t csn_plan_unit_in_slot(const csn_plan* plan, int32_t unit, int32_t branch);
 
 /* (Re)pack parameters: folds BN running stats + affine into per-channel scale/shift, applies the x100
  * of Conv2dX100 (CSNet/model/conv2d.py:104) and re-lays the gOctConv weight blocks for scalar loads.

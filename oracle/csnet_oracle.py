@@ -105,6 +105,44 @@ def _bounds(total: int, alphas: Sequence[float]) -> List[int]:
 
 
 # --------------------------------------------------------------------------
+# bf16 activation storage (BASELINE config 3) -- emulation of what the HIP train path keeps in HBM
+# --------------------------------------------------------------------------
+class _RoundBF16(torch.autograd.Function):
+    """A tensor that lives in memory as bfloat16: the forward value and the gradient that flows back through it are both
+    rounded to nearest-even bf16 (torch's float -> bfloat16 cast), everything else stays float32."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+_ACT_BF16 = False
+Z_CAPTURE = None     # tests: set to a list to collect every BatchNorm input (the raw conv outputs z) in call order
+
+
+class bf16_activations:
+    """``with bf16_activations():`` every tensor the HIP bf16 train mode stores (input copy, pooled copies, raw conv
+    outputs z, activations, half-resolution logits) is rounded through bf16 at that point, forward and backward."""
+
+    def __enter__(self):
+        global _ACT_BF16
+        self._old = _ACT_BF16
+        _ACT_BF16 = True
+
+    def __exit__(self, *exc):
+        global _ACT_BF16
+        _ACT_BF16 = self._old
+
+
+def _st(x):
+    return _RoundBF16.apply(x) if (_ACT_BF16 and x is not None) else x
+
+
+# --------------------------------------------------------------------------
 # primitives
 # --------------------------------------------------------------------------
 def goct_conv(xs, weight, alpha_in, alpha_out, stride, padding):
@@ -116,7 +154,7 @@ def goct_conv(xs, weight, alpha_in, alpha_out, stride, padding):
     for i in range(len(alpha_in)):
         if xs[i] is None:
             continue
-        x = F.avg_pool2d(xs[i], (2, 2), stride=2) if stride == 2 else xs[i]   # :679-682
+        x = _st(F.avg_pool2d(xs[i], (2, 2), stride=2)) if stride == 2 else xs[i]   # :679-682
         if bi[i] == bi[i + 1]:
             continue
         for j in range(len(alpha_out)):
@@ -125,6 +163,8 @@ def goct_conv(xs, weight, alpha_in, alpha_out, stride, padding):
             w = weight[bo[j]:bo[j + 1], bi[i]:bi[i + 1]]
             if i > j:        # low -> high: conv, then bilinear up  (:702-707)
                 y = F.conv2d(x, w, None, 1, padding)
+                if padding:      # 3x3: the HIP path materialises this partial sum (1x1 units interpolate x instead)
+                    y = _st(y)
                 y = F.interpolate(y, scale_factor=2 ** (i - j), mode="bilinear")
             elif i < j:      # high -> low: max-pool, then conv     (:708-714)
                 k = 2 ** (j - i)
@@ -137,12 +177,15 @@ def goct_conv(xs, weight, alpha_in, alpha_out, stride, padding):
 
 def bn_prelu(x, sd, bn_prefix, prelu_key, training):
     """nn.BatchNorm2d (eps 1e-5, momentum 0.1) followed by per-channel nn.PReLU."""
+    x = _st(x)       # the raw conv output z is a stored tensor (statistics are taken from what was stored)
+    if Z_CAPTURE is not None:
+        Z_CAPTURE.append(x)
     y = F.batch_norm(x, sd[bn_prefix + ".running_mean"], sd[bn_prefix + ".running_var"],
                      sd[bn_prefix + ".weight"], sd[bn_prefix + ".bias"],
                      training, BN_MOMENTUM, BN_EPS)
     if training:
         sd[bn_prefix + ".num_batches_tracked"] += 1
-    return F.prelu(y, sd[prelu_key])
+    return _st(F.prelu(y, sd[prelu_key]))
 
 
 def goct_cbr(xs, sd, prefix, alpha_in, alpha_out, k, stride, training):
@@ -264,7 +307,7 @@ def csnet_forward(layer_config, sd: Dict[str, torch.Tensor], x: torch.Tensor,
     """
     stages = layer_config[-1]
     blocks = block_table(layer_config)
-    cur = [x]
+    cur = [_st(x)]
     heads = []
     bi = 0
     cur = il_block(cur, sd, blocks[bi], training, taps); bi += 1
@@ -274,7 +317,7 @@ def csnet_forward(layer_config, sd: Dict[str, torch.Tensor], x: torch.Tensor,
         if s >= 1:
             heads.append(cur[0])                                     # x2[0], x3[0], x4[0]  (:380)
     fuse = csf_head(heads, sd, layer_config[bi:bi + 3], training, taps)
-    out = F.conv2d(fuse[0], sd["cls_layer.weight"], sd["cls_layer.bias"])        # :381
+    out = _st(F.conv2d(fuse[0], sd["cls_layer.weight"], sd["cls_layer.bias"]))        # :381
     if taps is not None:
         taps["cls_layer"] = [out]
     return F.interpolate(out, x.shape[2:], mode="bilinear", align_corners=False)  # :382-385
@@ -346,8 +389,9 @@ def is_param(key: str) -> bool:
 
 
 def train_step(layer_config, sd, x, target, *, expandflop=1.0, flops_weight=3.0, batchsize=None,
-               lr=1e-4, wd=5e-3, betas=(0.9, 0.99), eps=1e-8, adam_state=None, use_penalty=True):
-    """One iteration of train.py:203-216 on a flat state_dict (updated in place).
+               lr=1e-4, wd=5e-3, betas=(0.9, 0.99), eps=1e-8, adam_state=None, use_penalty=True, act_dtype=None):
+    """One iteration of train.py:203-216 on a flat state_dict (updated in place).  ``act_dtype="bf16"`` emulates the bf16
+    activation storage of BASELINE config 3 (see bf16_activations).
 
     Returns dict(loss_bce, penalty, grads).  Adam is torch.optim.Adam semantics with L2-in-gradient
     weight decay, two groups (train.py:108-123).
@@ -358,14 +402,16 @@ def train_step(layer_config, sd, x, target, *, expandflop=1.0, flops_weight=3.0,
         sd[k].requires_grad_(True)
         sd[k].grad = None
     taps = {}
-    out = csnet_forward(layer_config, sd, x, training=True, taps=taps)
-    bce = F.binary_cross_entropy_with_logits(out, target)
-    loss = bce
-    pen = None
-    if use_penalty:
-        pen = gap_penalty(sd, taps, flop_weights(layer_config, expandflop), batchsize)
-        loss = loss + flops_weight * pen
-    loss.backward()
+    import contextlib
+    with (bf16_activations() if act_dtype == "bf16" else contextlib.nullcontext()):
+        out = csnet_forward(layer_config, sd, x, training=True, taps=taps)
+        bce = F.binary_cross_entropy_with_logits(out, target)
+        loss = bce
+        pen = None
+        if use_penalty:
+            pen = gap_penalty(sd, taps, flop_weights(layer_config, expandflop), batchsize)
+            loss = loss + flops_weight * pen
+        loss.backward()
     # a parameter without a path to the loss (an output branch nobody consumes in a pruned net) has grad None in autograd
     grads = {k: (sd[k].grad.detach().clone() if sd[k].grad is not None else torch.zeros_like(sd[k])) for k in pnames}
     normal, picked = param_groups(pnames)
@@ -389,7 +435,7 @@ def train_step(layer_config, sd, x, target, *, expandflop=1.0, flops_weight=3.0,
     for k in pnames:
         sd[k].requires_grad_(False)
         sd[k].grad = None
-    return dict(loss_bce=float(bce), penalty=None if pen is None else float(pen), grads=grads,
+    return dict(loss_bce=float(bce.detach()), penalty=None if pen is None else float(pen.detach()), grads=grads,
                 out=out.detach(), adam_state=adam_state)
 
 

@@ -26,6 +26,7 @@ OPT_FUSE_CLS = 3
 OPT_TILED3 = 4
 OPT_FUSE_ILB = 5
 OPT_OVERLAP = 6
+OPT_TRAIN_BF16 = 7
 
 
 class ActDesc(C.Structure):
@@ -66,6 +67,11 @@ def new_unit(kind: int) -> UnitDesc:
 
 
 CSF_MAX_BRANCH = 4
+
+
+class TrainActInfo(C.Structure):
+    _fields_ = [("act_offset_bytes", C.c_int64), ("z_offset_bytes", C.c_int64), ("grad_offset_bytes", C.c_int64 * 2),
+                ("x16_offset_bytes", C.c_int64), ("n_consumers", C.c_int32), ("bf16", C.c_int32)]
 
 
 class CsfGnOff(C.Structure):
@@ -125,6 +131,10 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.csn_plan_workspace_bytes.argtypes = [C.c_void_p]
     lib.csn_plan_num_units.restype = C.c_int32
     lib.csn_plan_num_units.argtypes = [C.c_void_p]
+    lib.csn_plan_train_act_info.restype = C.c_int
+    lib.csn_plan_train_act_info.argtypes = [C.c_void_p, C.c_int32, C.POINTER(TrainActInfo)]
+    lib.csn_plan_unit_in_slot.restype = C.c_int32
+    lib.csn_plan_unit_in_slot.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.csn_plan_act_info.restype = C.c_int
     lib.csn_plan_act_info.argtypes = [C.c_void_p, C.c_int32, C.POINTER(ActInfo)]
     lib.csn_plan_refresh_params.restype = C.c_int
@@ -195,7 +205,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
 
 EXPORTS: Sequence[str] = (
     "csn_abi_version", "csn_strerror", "csn_last_hip_error", "csn_plan_create", "csn_plan_destroy",
-    "csn_plan_set_option", "csn_plan_workspace_bytes", "csn_plan_act_info", "csn_plan_num_units", "csn_plan_refresh_params",
+    "csn_plan_set_option", "csn_plan_workspace_bytes", "csn_plan_act_info", "csn_plan_train_act_info", "csn_plan_unit_in_slot", "csn_plan_num_units", "csn_plan_refresh_params",
     "csn_forward", "csn_forward_train", "csn_plan_enable_training", "csn_backward", "csn_bce_with_logits",
            "csn_adam_step", "csn_val_mae", "csn_saliency_u8", "csn_normalize_nchw", "csn_resize_normalize_nchw", "csn_saliency_resize_u8", "csn_resize_bilinear", "csn_sal_hist", "csn_forward_profile", "csn_profile_num_kernels", "csn_profile_kernel", "csn_unit_kernel_name", "csn_unit_algorithmic_bytes",
     "csf_head_create", "csf_head_destroy", "csf_head_workspace_bytes", "csf_head_refresh_params", "csf_head_forward",

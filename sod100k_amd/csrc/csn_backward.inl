@@ -328,11 +328,12 @@ int run_wgrad(const BwdCtx& b, const WgPlan& w, const PwBind& bd) {
   a.ngroups = a.gpp * P.S;
   a.k16 = (pp.K + 15) & ~15;
   a.partial = reinterpret_cast<float*>(b.c.ws + (b.c.side ? P.wg2_off : P.wg_off));
+  a.a16 = b.c.a16 ? 1 : 0; a.pad = 0;
   // the kernel holds at most 80 output channels (5 MFMA row tiles) per launch: wider passes go in row chunks
   for (int r0 = 0; r0 < pp.nrows; r0 += WG_MAX_ROWS) {
     const int nr = std::min(WG_MAX_ROWS, pp.nrows - r0);
     a.ps.nrows = nr;
-    a.a = ab + (int64_t)(w.a_c0 + r0) * hw;
+    a.a = b.c.eo(ab, (int64_t)(w.a_c0 + r0) * hw);
     a.rows16 = (nr + 15) & ~15;
     a.nblk = csn_wgrad_blocks(a.rows16, a.k16, a.ngroups);
     LAUNCH_TRY(csn_launch_wgrad(a, b.c.stream));
@@ -372,6 +373,7 @@ int run_bn_bwd(const BwdCtx& b, int ui, const UnitPlan& u, int j) {
   a.S = P.S; a.C = d.cout[j];
   a.flop_w = b.flop_w[ui * CSN_MAX_BRANCH + j];
   a.pen_scale = b.pen_scale;
+  a.a16 = b.c.a16 ? 1 : 0;
   LAUNCH_TRY(csn_launch_bn_bwd(a, b.c.stream));
   return CSN_OK;
 }
@@ -389,9 +391,10 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
     float* dlh = reinterpret_cast<float*>(c.ws + u.logits_off);   // gradient of the half-resolution logits
     AdjUpArgs ua;
     ua.in = dy; ua.out = dlh; ua.planes = S; ua.Hl = P.H >> 1; ua.Wl = P.W >> 1; ua.f = 2;
+    ua.in16 = 0; ua.out16 = c.a16 ? 1 : 0;   // dy is the caller's float gradient of the logits
     LAUNCH_TRY(csn_launch_adjup(ua, c.stream));
     LAUNCH_TRY(csn_launch_sum_to_grad(dlh, (int64_t)S * ua.Hl * ua.Wl, b.grad + d.bias_off,
-                                      reinterpret_cast<double*>(c.ws + P.red_off), c.stream));
+                                      reinterpret_cast<double*>(c.ws + P.red_off), c.a16 ? 1 : 0, c.stream));
     bd.in[0] = c.act_in(d.in_act[0]);
     bd.dz[0] = dlh;
   } else {
@@ -428,13 +431,14 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
   const BwdCtx bs{cs, b.arena, b.grad, b.flop_w, b.pen_scale};
   if (d.kind == CSN_UNIT_DW) {
     DwArgs a;
-    a.nbr = 0; a.B = S;
+    a.nbr = 0; a.B = S; a.a16 = c.a16 ? 1 : 0; a.pad = 0;
     int blk = 0;
     for (int k = 0; k < d.n_in; ++k) {
       if (d.cout[k] == 0) continue;
       const Act& act = P.acts[d.in_act[k]];
       const int H = P.H >> act.lvl, W = P.W >> act.lvl;
       DwWgradArgs w;
+      w.a16 = c.a16 ? 1 : 0;
       w.dz = bd.dz[k]; w.x = bd.in[k]; w.partial = reinterpret_cast<double*>(c.ws + (cs.side ? P.red2_off : P.red_off)); w.grad = b.grad;
       w.off_w = d.w_off[k]; w.C = d.cout[k]; w.S = S; w.H = H; w.W = W;
       LAUNCH_TRY(csn_launch_dw_wgrad(w, cs.stream));
@@ -465,6 +469,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
     AdjUpArgs ua;
     ua.in = bd.dz[ap.j]; ua.out = reinterpret_cast<float*>(scratch + ap.off);
     ua.planes = S * ap.C; ua.Hl = P.H >> ap.lvl; ua.Wl = P.W >> ap.lvl; ua.f = ap.f;
+    ua.in16 = ua.out16 = c.a16 ? 1 : 0;
     LAUNCH_TRY(csn_launch_adjup(ua, c.stream));
     bd.adj[k] = ua.out;
   }
@@ -489,7 +494,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
     if (dl.to_tmp) {
       PoolBwdArgs pa;
       pa.x = bd.in[dl.i]; pa.t = bd.tmp; pa.dx = bd.dx[dl.i];
-      pa.planes = S * d.cin[dl.i]; pa.Hl = P.H >> dl.lvl_lo; pa.Wl = P.W >> dl.lvl_lo; pa.f = dl.pool_f;
+      pa.planes = S * d.cin[dl.i]; pa.Hl = P.H >> dl.lvl_lo; pa.Wl = P.W >> dl.lvl_lo; pa.f = dl.pool_f; pa.a16 = c.a16 ? 1 : 0;
       LAUNCH_TRY(csn_launch_maxpool_bwd_add(pa, c.stream));
     }
   }
@@ -498,7 +503,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
       if (!ub.need_dx[i]) continue;
       PoolBwdArgs pa;
       pa.x = nullptr; pa.t = bd.dx[i]; pa.dx = grad_buf(c, d.in_act[i], u.in_slot[i]);
-      pa.planes = S * d.cin[i]; pa.Hl = P.H >> (u.base_lvl + i); pa.Wl = P.W >> (u.base_lvl + i); pa.f = 2;
+      pa.planes = S * d.cin[i]; pa.Hl = P.H >> (u.base_lvl + i); pa.Wl = P.W >> (u.base_lvl + i); pa.f = 2; pa.a16 = c.a16 ? 1 : 0;
       LAUNCH_TRY(csn_launch_avgpool2_bwd(pa, c.stream));
     }
   return CSN_OK;
@@ -554,6 +559,7 @@ int csn_plan_enable_training(csn_plan* P) {
         P->orphan_acts.push_back(a);
       }
   }
+  P->x16_off = bl.alloc_ws(bl.act_bytes(P->acts[0].channels, 0) / 2);   // bf16 copy of the input batch (CSN_OPT_TRAIN_BF16)
   P->red_off = bl.alloc_ws((int64_t)maxc * CSN_BN_NSLAB * 9 * sizeof(double));
   P->red2_off = bl.alloc_ws((int64_t)maxc * CSN_BN_NSLAB * 9 * sizeof(double));   // ... of the weight-gradient side lane
   P->bwd.clear();
@@ -602,6 +608,26 @@ int csn_plan_enable_training(csn_plan* P) {
   return CSN_OK;
 }
 
+int csn_plan_train_act_info(const csn_plan* P, int32_t id, csn_train_act_info* out) {
+  if (!P || !out || id < 0 || id >= (int)P->acts.size()) return CSN_E_INVALID;
+  if (!P->train) return CSN_E_STATE;
+  out->act_offset_bytes = P->acts[id].ws_off;
+  out->z_offset_bytes = P->tz_off[id];
+  out->grad_offset_bytes[0] = P->tg_off[id][0];
+  out->grad_offset_bytes[1] = P->tg_off[id][1];
+  out->x16_offset_bytes = (id == 0 && P->act16) ? P->x16_off : -1;
+  out->n_consumers = P->n_cons[id];
+  out->bf16 = P->act16 ? 1 : 0;
+  return CSN_OK;
+}
+
+int32_t csn_plan_unit_in_slot(const csn_plan* P, int32_t unit, int32_t branch) {
+  if (!P || !P->train || unit < 0 || unit >= (int)P->units.size() || branch < 0 || branch >= CSN_MAX_BRANCH) return -1;
+  const UnitPlan& u = P->units[unit];
+  if (branch >= u.d.n_in || u.d.cin[branch] == 0 || u.d.in_act[branch] <= 0) return -1;
+  return u.in_slot[branch];
+}
+
 int csn_backward(csn_plan* P, const float* x, const float* dy, void* workspace, const float* arena, float* grad,
                  int64_t arena_floats, const float* flop_w, float pen_scale, void* stream) {
   if (!P || !x || !dy || !workspace || !arena || !grad || !flop_w) return CSN_E_INVALID;
@@ -615,6 +641,7 @@ int csn_backward(csn_plan* P, const float* x, const float* dy, void* workspace, 
   return run_graphed(P, P->g_bwd, key, stream, [&](void* s) {
     Ctx c{*P, x, nullptr, static_cast<char*>(workspace), s};
     c.raw = true;
+    c.a16 = P->act16;
     c.lanes = P->overlap_bwd && lanes_ready(P);   // measured: no gain for the train step (106.3 vs 105.5 ms), off by default
     const BwdCtx b{c, arena, grad, flop_w, pen_scale};
     for (int a : P->orphan_acts)

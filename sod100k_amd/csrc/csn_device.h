@@ -48,9 +48,9 @@ __device__ __forceinline__ csn_cfp csn_const(const float* p) {
 // needs a single address register for all channels of a gather.
 #ifdef CSN_CPU_EMU
 struct csn_buf { const char* p; unsigned n; };
-static inline csn_buf csn_make_buf(const float* p) { return csn_buf{reinterpret_cast<const char*>(p), 0xffffffffu}; }
+static inline csn_buf csn_make_buf(const void* p) { return csn_buf{reinterpret_cast<const char*>(p), 0xffffffffu}; }
 // bounded resource: loads whose byte offset is >= nbytes return 0 (the hardware's out-of-range rule)
-static inline csn_buf csn_make_buf_n(const float* p, unsigned nbytes) { return csn_buf{reinterpret_cast<const char*>(p), nbytes}; }
+static inline csn_buf csn_make_buf_n(const void* p, unsigned nbytes) { return csn_buf{reinterpret_cast<const char*>(p), nbytes}; }
 static inline float csn_ld1(csn_buf b, unsigned voff, unsigned soff) {
   const unsigned o = voff + soff;
   return o + 4u <= b.n && o + 4u > o ? *reinterpret_cast<const float*>(b.p + o) : 0.f;
@@ -71,15 +71,33 @@ static inline float4 csn_ld4(csn_buf b, unsigned voff, unsigned soff) {
   const float* q = reinterpret_cast<const float*>(b.p + o);
   return make_float4(q[0], q[1], q[2], q[3]);
 }
+static inline unsigned short csn_ld_u16(csn_buf b, unsigned voff, unsigned soff) {
+  const unsigned o = voff + soff;
+  return o + 2u <= b.n && o + 2u > o ? *reinterpret_cast<const unsigned short*>(b.p + o) : (unsigned short)0;
+}
+static inline unsigned csn_ld_u32(csn_buf b, unsigned voff, unsigned soff) {
+  const unsigned o = voff + soff;
+  return o + 4u <= b.n && o + 4u > o ? *reinterpret_cast<const unsigned*>(b.p + o) : 0u;
+}
+static inline uint2 csn_ld_u64(csn_buf b, unsigned voff, unsigned soff) {
+  const unsigned o = voff + soff;
+  if (!(o + 8u <= b.n && o + 8u > o)) return make_uint2(0u, 0u);
+  const unsigned* q = reinterpret_cast<const unsigned*>(b.p + o);
+  return make_uint2(q[0], q[1]);
+}
+static inline void csn_st_u16(csn_buf b, unsigned voff, unsigned soff, unsigned short v) {
+  const unsigned o = voff + soff;
+  if (o + 2u <= b.n && o + 2u > o && o >= voff) *reinterpret_cast<unsigned short*>(const_cast<char*>(b.p) + o) = v;
+}
 #else
 typedef __amdgpu_buffer_rsrc_t csn_buf;
 typedef unsigned csn_u2 __attribute__((ext_vector_type(2)));
 typedef unsigned csn_u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ csn_buf csn_make_buf(const float* p) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0xffffffff, 0x00020000);
+__device__ __forceinline__ csn_buf csn_make_buf(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xffffffff, 0x00020000);
 }
-__device__ __forceinline__ csn_buf csn_make_buf_n(const float* p, unsigned nbytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, nbytes, 0x00020000);
+__device__ __forceinline__ csn_buf csn_make_buf_n(const void* p, unsigned nbytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, nbytes, 0x00020000);
 }
 __device__ __forceinline__ float csn_ld1(csn_buf b, unsigned voff, unsigned soff) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b, voff, soff, 0));
@@ -97,7 +115,96 @@ __device__ __forceinline__ float4 csn_ld4(csn_buf b, unsigned voff, unsigned sof
   const csn_u4 v = __builtin_amdgcn_raw_buffer_load_b128(b, voff, soff, 0);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+__device__ __forceinline__ unsigned short csn_ld_u16(csn_buf b, unsigned voff, unsigned soff) {
+  return (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(b, voff, soff, 0);
+}
+__device__ __forceinline__ unsigned csn_ld_u32(csn_buf b, unsigned voff, unsigned soff) {
+  return __builtin_amdgcn_raw_buffer_load_b32(b, voff, soff, 0);
+}
+__device__ __forceinline__ uint2 csn_ld_u64(csn_buf b, unsigned voff, unsigned soff) {
+  const csn_u2 v = __builtin_amdgcn_raw_buffer_load_b64(b, voff, soff, 0);
+  return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ void csn_st_u16(csn_buf b, unsigned voff, unsigned soff, unsigned short v) {
+  __builtin_amdgcn_raw_buffer_store_b16(v, b, voff, soff, 0);
+}
 #endif
+
+// ---------------------------------------------------------------------------------------------------------------
+// Activation element types.  Eval mode and the fp32 train mode keep activations as float; the bf16 train mode
+// (CSN_OPT_TRAIN_BF16, BASELINE config 3) stores every activation / activation gradient in HBM as bfloat16 and does
+// all arithmetic in fp32 registers: kernels are templates over the element type AT and touch memory only through
+// the accessors below (round-to-nearest-even on store, exact widening on load).
+// ---------------------------------------------------------------------------------------------------------------
+struct csn_bf16 { unsigned short u; };
+
+__device__ __forceinline__ float csn_bits_f(unsigned u) {
+#ifdef CSN_CPU_EMU
+  float f; __builtin_memcpy(&f, &u, 4); return f;
+#else
+  return __uint_as_float(u);
+#endif
+}
+__device__ __forceinline__ unsigned short csn_f2bf(float f) {
+#ifdef CSN_CPU_EMU
+  unsigned u; __builtin_memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                                  // round to nearest even
+  return (unsigned short)(u >> 16);
+#else
+  return __builtin_bit_cast(unsigned short, (__bf16)f);                              // v_cvt_pk_bf16_f32
+#endif
+}
+__device__ __forceinline__ float csn_bf2f(unsigned short h) { return csn_bits_f((unsigned)h << 16); }
+// two consecutive elements packed in a dword (element 0 in the low half)
+__device__ __forceinline__ unsigned csn_pack_bf2(float a, float b) { return (unsigned)csn_f2bf(a) | ((unsigned)csn_f2bf(b) << 16); }
+
+// plain-pointer accessors (p is aligned to the access: 1, 2 or 4 elements)
+__device__ __forceinline__ float act_ld(const float* p) { return *p; }
+__device__ __forceinline__ float act_ld(const csn_bf16* p) { return csn_bf2f(p->u); }
+__device__ __forceinline__ void act_st(float* p, float v) { *p = v; }
+__device__ __forceinline__ void act_st(csn_bf16* p, float v) { p->u = csn_f2bf(v); }
+__device__ __forceinline__ float2 act_ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ float2 act_ld2(const csn_bf16* p) {
+  const unsigned u = *reinterpret_cast<const unsigned*>(p);
+  return make_float2(csn_bits_f(u << 16), csn_bits_f(u & 0xffff0000u));
+}
+__device__ __forceinline__ void act_st2(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+__device__ __forceinline__ void act_st2(csn_bf16* p, float2 v) { *reinterpret_cast<unsigned*>(p) = csn_pack_bf2(v.x, v.y); }
+__device__ __forceinline__ float4 act_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 act_ld4(const csn_bf16* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(csn_bits_f(u.x << 16), csn_bits_f(u.x & 0xffff0000u), csn_bits_f(u.y << 16), csn_bits_f(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void act_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void act_st4(csn_bf16* p, float4 v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(csn_pack_bf2(v.x, v.y), csn_pack_bf2(v.z, v.w));
+}
+// typed view of an argument-block pointer (the blocks carry `float*` whatever the element type)
+template <typename AT> __device__ __forceinline__ const AT* act_cast(const float* p) { return reinterpret_cast<const AT*>(p); }
+template <typename AT> __device__ __forceinline__ AT* act_cast(float* p) { return reinterpret_cast<AT*>(p); }
+
+// buffer-resource accessors over the element type: offsets are BYTES (callers scale by sizeof(AT)); a 2- / 4-element
+// access starts on an even / multiple-of-4 element
+template <typename AT> struct csn_bufacc;
+template <> struct csn_bufacc<float> {
+  static __device__ __forceinline__ float ld1(csn_buf b, unsigned voff, unsigned soff) { return csn_ld1(b, voff, soff); }
+  static __device__ __forceinline__ float2 ld2(csn_buf b, unsigned voff, unsigned soff) { return csn_ld2(b, voff, soff); }
+  static __device__ __forceinline__ float4 ld4(csn_buf b, unsigned voff, unsigned soff) { return csn_ld4(b, voff, soff); }
+  static __device__ __forceinline__ void st1(csn_buf b, unsigned voff, unsigned soff, float v) { csn_st1(b, voff, soff, v); }
+};
+template <> struct csn_bufacc<csn_bf16> {
+  static __device__ __forceinline__ float ld1(csn_buf b, unsigned voff, unsigned soff) { return csn_bf2f(csn_ld_u16(b, voff, soff)); }
+  static __device__ __forceinline__ float2 ld2(csn_buf b, unsigned voff, unsigned soff) {
+    const unsigned u = csn_ld_u32(b, voff, soff);
+    return make_float2(csn_bits_f(u << 16), csn_bits_f(u & 0xffff0000u));
+  }
+  static __device__ __forceinline__ float4 ld4(csn_buf b, unsigned voff, unsigned soff) {
+    const uint2 u = csn_ld_u64(b, voff, soff);
+    return make_float4(csn_bits_f(u.x << 16), csn_bits_f(u.x & 0xffff0000u), csn_bits_f(u.y << 16), csn_bits_f(u.y & 0xffff0000u));
+  }
+  static __device__ __forceinline__ void st1(csn_buf b, unsigned voff, unsigned soff, float v) { csn_st_u16(b, voff, soff, csn_f2bf(v)); }
+};
 
 // Folded epilogue of one output channel: y = z*scale + shift; y = y >= 0 ? y : alpha*y
 // (nn.BatchNorm2d in eval mode followed by nn.PReLU; for cls_layer scale=1, shift=bias, alpha=1).

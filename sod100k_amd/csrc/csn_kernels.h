@@ -60,6 +60,7 @@ struct DwBranch {
 struct DwArgs {
   DwBranch br[3];
   int32_t nbr, B;
+  int32_t a16, pad;   // bfloat16 activations (single-unit kernel only; the fused pair is an eval-mode kernel)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -121,7 +122,8 @@ struct PwArgs {
   // goct_c3_kernel (single 3x3 pass): the tap-major weight image [rows16][chunk][tap][16 channels] (null: not eligible),
   // its row pitch / size in floats, and the z channel that belongs to output row 0 of the launch (row-chunked launches)
   const float* wimg3;
-  int32_t w3_stride, w3_floats, z_c0, pad3;
+  int32_t w3_stride, w3_floats, z_c0;
+  int32_t a16;         // activations are bfloat16 (bf16 train mode), else float
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -168,6 +170,7 @@ struct MsArgs {
   const float* scale;
   const float* shift;
   const float* alpha;
+  int32_t a16, pad;    // bfloat16 activations (per-pixel kernel only)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -180,11 +183,13 @@ struct PoolArgs {
   int32_t Ho[3], Wo[3]; // output size
   int32_t blk_end[3];
   int32_t n;
+  int32_t a16, pad;
 };
 struct Up2Args {
   const float* in;  // [planes][H/2][W/2]
-  float* out;       // [planes][H][W]
+  float* out;       // [planes][H][W]  (always float: the caller's logits)
   int32_t planes, H, W;
+  int32_t in16;     // `in` is bfloat16
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -202,6 +207,7 @@ struct WgArgs {
   int32_t nblk;         // blocks (= partial slices)
   int32_t rows16, k16;  // nrows / cin rounded up to 16
   float* partial;       // [nblk][rows16][k16]
+  int32_t a16, pad;     // activations (x and dz) are bfloat16
 };
 struct WgBlock {        // one rectangular block of weight columns inside the reference's weight tensor
   int64_t dst;          // float offset into the gradient arena
@@ -230,6 +236,7 @@ struct BnStatsArgs {
   int32_t S, C;
   int64_t HW;
   int32_t cpp;        // chunks per plane, set by the launcher
+  int32_t a16;        // z is bfloat16
 };
 struct BnFinalizeArgs {
   const double* partial;
@@ -257,6 +264,7 @@ struct BnApplyArgs {
   int64_t HW;
   int32_t S, C;
   float flop_w;       // 0: not a hooked ILBlock sub-module
+  int32_t a16;        // z / y are bfloat16
 };
 int csn_launch_bn_stats(const BnStatsArgs& a, void* stream);
 int csn_launch_bn_finalize(const BnFinalizeArgs& a, void* stream);
@@ -282,6 +290,7 @@ struct BnBwdArgs {
   float flop_w;        // Oct_bn_hook branch weight (0: not hooked)
   float pen_scale;     // d loss / d (penalty sum) = FLOPS.WEIGHT / batchsize  (train.py:91,210)
   int32_t nslab, cpp;  // set by the launcher
+  int32_t a16;         // dy / z are bfloat16
 };
 int csn_launch_bn_bwd(const BnBwdArgs& a, void* stream);
 
@@ -293,6 +302,7 @@ struct DwWgradArgs {
   int64_t off_w;
   int32_t C, S, H, W;
   int32_t nslab, cpp;  // set by the launcher
+  int32_t a16;         // dz / x are bfloat16
 };
 int csn_launch_dw_wgrad(const DwWgradArgs& a, void* stream);
 
@@ -300,6 +310,7 @@ struct AdjUpArgs {
   const float* in;     // [planes][Hl*f][Wl*f]
   float* out;          // [planes][Hl][Wl]
   int32_t planes, Hl, Wl, f;
+  int32_t in16, out16;  // element type of in / out: bfloat16 (1) or float (0)
 };
 int csn_launch_adjup(const AdjUpArgs& a, void* stream);
 
@@ -308,10 +319,12 @@ struct PoolBwdArgs {
   const float* t;      // gradient at the low resolution [planes][Hl][Wl]
   float* dx;           // [planes][Hl*f][Wl*f]  (max-pool: accumulated, avg-pool: written)
   int32_t planes, Hl, Wl, f;
+  int32_t a16;         // bfloat16 tensors
 };
 int csn_launch_avgpool2_bwd(const PoolBwdArgs& a, void* stream);
 int csn_launch_maxpool_bwd_add(const PoolBwdArgs& a, void* stream);
-int csn_launch_sum_to_grad(const float* in, int64_t n, float* dst, double* partial /* >= 512 */, void* stream);
+int csn_launch_sum_to_grad(const float* in, int64_t n, float* dst, double* partial /* >= 512 */, int a16, void* stream);
+int csn_launch_to_bf16(const float* in, void* out, int64_t n, void* stream);   // float -> bfloat16 copy, n multiple of 4
 int csn_launch_bce(const float* y, const float* t, float* dy, int64_t n, double* loss, void* stream);
 
 struct AdamArgs {

@@ -180,6 +180,8 @@ struct csn_plan {
   size_t ev_used = 0;
   // ---- training (csn_plan_enable_training) ----
   bool train = false;
+  bool act16 = false;                           // CSN_OPT_TRAIN_BF16: train-mode activations / gradients are bfloat16
+  int64_t x16_off = -1;                         // bf16 copy of the input batch (workspace bytes)
   std::vector<int64_t> tz_off;                  // per act: raw conv output z, later dz (workspace bytes)
   std::vector<std::array<int64_t, 2>> tg_off;   // per act: gradient buffer per consumer
   std::vector<int> n_cons;
@@ -547,7 +549,15 @@ struct Ctx {
   void* stream;
   const float* act_in(int id) const {
     const Act& a = P.acts[id];
-    return a.ws_off < 0 ? x : reinterpret_cast<const float*>(ws + a.ws_off);
+    if (a.ws_off < 0) return a16 ? reinterpret_cast<const float*>(ws + P.x16_off) : x;
+    return reinterpret_cast<const float*>(ws + a.ws_off);
+  }
+  // pointer `elems` activation elements past p (argument blocks carry float* whatever the element type)
+  const float* eo(const float* p, int64_t elems) const {
+    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + elems * (a16 ? 2 : 4));
+  }
+  float* eo(float* p, int64_t elems) const {
+    return reinterpret_cast<float*>(reinterpret_cast<char*>(p) + elems * (a16 ? 2 : 4));
   }
   // train mode with backward buffers: the convolutions write z next to (not over) the activation y
   float* act_out(int id) const {
@@ -558,6 +568,7 @@ struct Ctx {
   bool raw = false;   // train mode: convolutions write the un-normalised z (identity epilogue)
   bool lanes = false; // eval forward outside profiling: independent launches may go to the plan's auxiliary streams
   bool side = false;  // backward: this context enqueues on the weight-gradient side lane (own partial buffers)
+  bool a16 = false;   // bf16 train mode: every activation tensor in the workspace is bfloat16
   const float* sc(const Epi& e) const { return P.packed + (raw ? P.ident.scale : e.scale); }
   const float* sh(const Epi& e) const { return P.packed + (raw ? P.ident.shift : e.shift); }
   const float* al(const Epi& e) const { return P.packed + (raw ? P.ident.alpha : e.alpha); }
@@ -645,7 +656,7 @@ void fill_pass(const Ctx& c, const PwLaunchPlan& L, const PwPassPlan& pp, const 
       else if (mode == PW_UP2 || mode == PW_TAPS_UPS2) sh = 1;
       else if (mode == PW_UP4) sh = 2;
       const int64_t hs = sh >= 0 ? (int64_t)(Hr >> sh) * (Wr >> sh) : (int64_t)(Hr << -sh) * (Wr << -sh);
-      ps.src[s].ptr = base + (int64_t)pp.src_c0[s] * hs;
+      ps.src[s].ptr = c.eo(base, (int64_t)pp.src_c0[s] * hs);
       ps.src[s].C = pp.src_C[s];
       ps.src[s].Ctot = pp.src_ctot[s] > 0 ? pp.src_ctot[s] : pp.src_C[s];
       ps.src[s].mode = mode;
@@ -662,7 +673,7 @@ void fill_pass(const Ctx& c, const PwLaunchPlan& L, const PwPassPlan& pp, const 
     case OUT_TMP: ob = bd.tmp; break;
     default: ob = bd.act[pp.out_branch]; break;
   }
-  ps.out = ob ? ob + (int64_t)pp.out_c0 * Hr * Wr : nullptr;
+  ps.out = ob ? c.eo(ob, (int64_t)pp.out_c0 * Hr * Wr) : nullptr;
   ps.red_w = ps.red_b = nullptr;
   if (bd.red_w && pp.out_kind == OUT_ACT) {   // rows are reduced into the half-resolution logits
     ps.red_w = bd.red_w + pp.out_c0; ps.red_b = bd.red_b; ps.out = bd.logits;
@@ -688,7 +699,7 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
          (int64_t)a.tiles_x * ((a.H0 + (1 << a.ty_log2) - 1) >> a.ty_log2) * a.B < 512) --a.ty_log2;
   a.tiles_y = (a.H0 + (1 << a.ty_log2) - 1) >> a.ty_log2;
   a.wimg = c.pk(L.wimg); a.wimg_floats = L.wimg_floats;
-  a.wimg3 = L.wimg3 >= 0 ? c.pk(L.wimg3) : nullptr; a.w3_stride = L.w3_stride; a.w3_floats = L.w3_floats; a.z_c0 = L.z_c0; a.pad3 = 0;
+  a.wimg3 = L.wimg3 >= 0 ? c.pk(L.wimg3) : nullptr; a.w3_stride = L.w3_stride; a.w3_floats = L.w3_floats; a.z_c0 = L.z_c0; a.a16 = c.a16 ? 1 : 0;
   for (int q = 0; q < a.npass; ++q) {
     const PwPassPlan& pp = L.passes[q];
     PwPass& ps = a.pass[q];
@@ -697,7 +708,7 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
   // raw: every pass of the launch stores plain sums (train-mode conv outputs, gradients, scratch)
   bool all_raw = true;
   for (const PwPassPlan& pp : L.passes) all_raw = all_raw && (pp.out_kind == OUT_DX || pp.out_kind == OUT_TMP || (c.raw && pp.out_kind != OUT_LOGITS));
-  if (P.tiled3 && csn_c3_eligible(a)) {   // 3x3 pass: LDS-tiled implicit GEMM
+  if (P.tiled3 && csn_c3_eligible(a) && (!c.a16 || all_raw)) {   // 3x3 pass: LDS-tiled implicit GEMM
     LAUNCH_TRY(csn_launch_c3(a, all_raw ? 1 : 0, c.stream));
     return c.mark("goct_c3_kernel");
   }
@@ -738,7 +749,8 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
     case CSN_UNIT_DW: {
       DwArgs a;
       const bool fused = next != nullptr;
-      a.nbr = 0; a.B = S;
+      a.nbr = 0; a.B = S; a.a16 = c.a16 ? 1 : 0; a.pad = 0;
+      if (fused && c.a16) return CSN_E_UNSUPPORTED;   // the fused pair is an eval-mode (float) kernel
       int blk = 0;
       for (int k = 0; k < d.n_in; ++k) {
         if (d.cout[k] == 0) continue;
@@ -785,7 +797,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
           if (d.cin[i] > 0) xin[i] = reinterpret_cast<const float*>(c.ws + u.pooled_off[i]);
       } else if (d.stride == 2 && !u.std_conv) {
         PoolArgs pa;
-        pa.n = 0;
+        pa.n = 0; pa.a16 = c.a16 ? 1 : 0; pa.pad = 0;
         int blk = 0;
         for (int i = 0; i < d.n_in; ++i) {
           if (d.cin[i] == 0) continue;
@@ -859,7 +871,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
       }
       if (next && next->d.kind == CSN_UNIT_CLS) {
         Up2Args ua;
-        ua.in = bd.logits; ua.out = c.y; ua.planes = S; ua.H = P.H; ua.W = P.W;
+        ua.in = bd.logits; ua.out = c.y; ua.planes = S; ua.H = P.H; ua.W = P.W; ua.in16 = c.a16 ? 1 : 0;
         LAUNCH_TRY(csn_launch_up2(ua, c.stream));
         { const int ms_ = c.mark("bilinear_up2_kernel"); if (ms_ != CSN_OK) return ms_; }
       }
@@ -874,7 +886,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
         a.w[k] = d.dil_ch[k] ? c.pk(u.ms_w[k]) : nullptr;
       }
       a.cin = d.cin[0]; a.cout = d.cout[0]; a.H = P.H >> act.lvl; a.W = P.W >> act.lvl; a.B = S;
-      a.scale = c.sc(u.ms_epi); a.shift = c.sh(u.ms_epi); a.alpha = c.al(u.ms_epi);
+      a.scale = c.sc(u.ms_epi); a.shift = c.sh(u.ms_epi); a.alpha = c.al(u.ms_epi); a.a16 = c.a16 ? 1 : 0; a.pad = 0;
       LAUNCH_TRY(csn_launch_ms(a, c.stream));
       { const int ms_ = c.mark("msblock_kernel"); if (ms_ != CSN_OK) return ms_; }
     } break;
@@ -888,6 +900,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
       }
       Up2Args ua;
       ua.in = reinterpret_cast<const float*>(c.ws + u.logits_off); ua.out = c.y; ua.planes = S; ua.H = P.H; ua.W = P.W;
+      ua.in16 = c.a16 ? 1 : 0;
       LAUNCH_TRY(csn_launch_up2(ua, c.stream));
       { const int ms_ = c.mark("bilinear_up2_kernel"); if (ms_ != CSN_OK) return ms_; }
     } break;
@@ -1335,6 +1348,7 @@ int csn_plan_set_option(csn_plan* P, int32_t option, int32_t value) {
     case CSN_OPT_TILED3: P->tiled3 = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_FUSE_ILB: P->fuse_ilb = value < 0 ? 0 : value; drop_graph(P); return CSN_OK;
     case CSN_OPT_OVERLAP: P->overlap = value != 0; P->overlap_bwd = value == 2; drop_graph(P); return CSN_OK;
+    case CSN_OPT_TRAIN_BF16: P->act16 = value != 0; drop_graph(P); return CSN_OK;
     default: return CSN_E_INVALID;
   }
 }
@@ -1509,6 +1523,12 @@ static int forward_train_body(csn_plan* P, const float* x, float* y, void* works
   if (P->S != P->B) { g_hip_err = "train mode needs the whole batch in one slice (sub_batch = 0)"; return CSN_E_UNSUPPORTED; }
   const int nu = (int)P->units.size();
   Ctx c{*P, x, y, static_cast<char*>(workspace), stream};
+  if (P->act16) {   // bf16 activations: needs the training buffers (the bf16 copy of x lives there)
+    if (!P->train) { g_hip_err = "CSN_OPT_TRAIN_BF16 needs csn_plan_enable_training"; return CSN_E_STATE; }
+    c.a16 = true;
+    const int64_t nx = (int64_t)P->S * P->acts[0].channels * P->H * P->W;   // H, W are multiples of 16
+    LAUNCH_TRY(csn_launch_to_bf16(x, c.ws + P->x16_off, nx, stream));
+  }
   for (int u = 0; u < nu; ++u) {
     const UnitPlan& up = P->units[u];
     const csn_unit_desc& d = up.d;
@@ -1522,7 +1542,7 @@ static int forward_train_body(csn_plan* P, const float* x, float* y, void* works
       const int64_t hw = (int64_t)(P->H >> act.lvl) * (P->W >> act.lvl);
       float* z = c.act_out(d.out_act[j]);      // raw conv output (its own buffer when training is enabled)
       double* part = reinterpret_cast<double*>(c.ws + up.stats_off[j]);
-      BnStatsArgs sa; sa.z = z; sa.partial = part; sa.S = P->S; sa.C = d.cout[j]; sa.HW = hw;
+      BnStatsArgs sa; sa.z = z; sa.partial = part; sa.S = P->S; sa.C = d.cout[j]; sa.HW = hw; sa.a16 = c.a16 ? 1 : 0;
       LAUNCH_TRY(csn_launch_bn_stats(sa, stream));
       BnFinalizeArgs fa; fa.partial = part; fa.arena = arena;
       fa.scale = P->packed + up.out_epi[j].scale; fa.shift = P->packed + up.out_epi[j].shift;
@@ -1536,7 +1556,7 @@ static int forward_train_body(csn_plan* P, const float* x, float* y, void* works
       aa.gapabs = reinterpret_cast<float*>(c.ws + up.gap_off[j]);
       aa.scale = fa.scale; aa.shift = fa.shift; aa.alpha = P->packed + up.out_epi[j].alpha;
       aa.arena = arena; aa.penalty = penalty; aa.off_weight = d.bn[j].weight; aa.HW = hw; aa.S = P->S; aa.C = d.cout[j];
-      aa.flop_w = flop_w[u * CSN_MAX_BRANCH + j];
+      aa.flop_w = flop_w[u * CSN_MAX_BRANCH + j]; aa.a16 = c.a16 ? 1 : 0;
       LAUNCH_TRY(csn_launch_bn_apply(aa, stream));
     }
   }

@@ -83,9 +83,10 @@ static inline void c3_contract_emu(csn_f4 (&acc)[2][4], const float* w0, int wp,
 
 // WCH = false: the pass's whole weight image is staged once per block (small images);
 // WCH = true: only the current chunk's columns live in LDS (large images: 42 KB per block, 3 blocks per CU).
-template <bool RAW, bool WCH>
+template <bool RAW, bool WCH, typename AT>
 __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_c3_kernel(PwArgs a_byval) {
   CSN_DYN_SMEM(float, lds);
+  constexpr unsigned E = (unsigned)sizeof(AT);   // bytes per activation element
   const CSN_CONST_AS PwArgs* a = CSN_KERNARG(PwArgs, a_byval);
   PwPassP ps = &a->pass[0];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_c3_kernel(PwArgs a_byval) {
     const int py_ = y0 + 2 * wave + (lane >> 5), px_ = x0 + (lane & 31);
     const bool valid = py_ < Hr && px_ < Wr;
     const int gy = min(py_, Hr - 1), gx = min(px_, Wr - 1);
-    const unsigned ovoff = (unsigned)(gy * Wr + gx) * 4u;
+    const unsigned ovoff = (unsigned)(gy * Wr + gx) * E;
     for (int row0 = 0; row0 < nrows; row0 += 32) {
       const bool two = nrows - row0 > 16;
       csn_f4 acc[2][4];
@@ -155,23 +156,23 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_c3_kernel(PwArgs a_byval) {
       // issue the loads of a plain (not pooled) chunk: out-of-image / past-the-slice elements get an out-of-range offset -> 0
       auto prefetch = [&](const C3Chunk& c) {
         const int C = ps->src[c.s].C;
-        const csn_buf rb = csn_make_buf_n(ps->src[c.s].ptr + (int64_t)b * ps->src[c.s].Ctot * (Hr * Wr),
-                                          (unsigned)(ps->src[c.s].Ctot * Hr * Wr) * 4u);
-        const unsigned HW4 = (unsigned)(Hr * Wr) * 4u;
+        const csn_buf rb = csn_make_buf_n(act_cast<AT>(ps->src[c.s].ptr) + (int64_t)b * ps->src[c.s].Ctot * (Hr * Wr),
+                                          (unsigned)(ps->src[c.s].Ctot * Hr * Wr) * E);
+        const unsigned HW4 = (unsigned)(Hr * Wr) * E;
         const int xx = x0 + lx;
-        const unsigned colo = xx < Wr ? (unsigned)xx * 4u : OOB;
+        const unsigned colo = xx < Wr ? (unsigned)xx * E : OOB;
 #pragma unroll
         for (int i = 0; i < 20; ++i) {
           const int ch = c.c_lo + 2 * r8 + i / 10, yy = y0 - 1 + (i % 10);
           const bool ok = ch < C && yy >= 0 && yy < Hr;
-          pf[i] = csn_ld1(rb, ok ? (unsigned)ch * HW4 + (unsigned)(yy * Wr) * 4u + colo : OOB, 0u);
+          pf[i] = csn_bufacc<AT>::ld1(rb, ok ? (unsigned)ch * HW4 + (unsigned)(yy * Wr) * E + colo : OOB, 0u);
         }
         {
           const int ch = c.c_lo + hch, yy = y0 - 1 + hrow;
           const bool ok = tid < C3_CC * (C3_TY + 2) && ch < C && yy >= 0 && yy < Hr;
-          const unsigned ro = (unsigned)ch * HW4 + (unsigned)(yy * Wr) * 4u;
-          pf[20] = csn_ld1(rb, ok && x0 > 0 ? ro + (unsigned)(x0 - 1) * 4u : OOB, 0u);
-          pf[21] = csn_ld1(rb, ok && x0 + C3_TX < Wr ? ro + (unsigned)(x0 + C3_TX) * 4u : OOB, 0u);
+          const unsigned ro = (unsigned)ch * HW4 + (unsigned)(yy * Wr) * E;
+          pf[20] = csn_bufacc<AT>::ld1(rb, ok && x0 > 0 ? ro + (unsigned)(x0 - 1) * E : OOB, 0u);
+          pf[21] = csn_bufacc<AT>::ld1(rb, ok && x0 + C3_TX < Wr ? ro + (unsigned)(x0 + C3_TX) * E : OOB, 0u);
         }
       };
       auto commit = [&]() {
@@ -186,13 +187,13 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_c3_kernel(PwArgs a_byval) {
       auto stage_pooled = [&](const C3Chunk& c) {
         const int C = ps->src[c.s].C;
         const int Hs = 2 * Hr, Ws = 2 * Wr;
-        const csn_buf rb = csn_make_buf_n(ps->src[c.s].ptr + (int64_t)b * ps->src[c.s].Ctot * (Hs * Ws),
-                                          (unsigned)(ps->src[c.s].Ctot * Hs * Ws) * 4u);
-        const unsigned HW4 = (unsigned)(Hs * Ws) * 4u, P4 = (unsigned)Ws * 4u;
+        const csn_buf rb = csn_make_buf_n(act_cast<AT>(ps->src[c.s].ptr) + (int64_t)b * ps->src[c.s].Ctot * (Hs * Ws),
+                                          (unsigned)(ps->src[c.s].Ctot * Hs * Ws) * E);
+        const unsigned HW4 = (unsigned)(Hs * Ws) * E, P4 = (unsigned)Ws * E;
         auto pooled = [&](int ch, int yy, int xx) {
           const bool ok = ch < C && yy >= 0 && yy < Hr && xx >= 0 && xx < Wr;
-          const unsigned o = ok ? (unsigned)ch * HW4 + (unsigned)(2 * yy) * P4 + (unsigned)xx * 8u : OOB;
-          const float2 t0 = csn_ld2(rb, o, 0u), t1 = csn_ld2(rb, ok ? o + P4 : OOB, 0u);
+          const unsigned o = ok ? (unsigned)ch * HW4 + (unsigned)(2 * yy) * P4 + (unsigned)xx * (2u * E) : OOB;
+          const float2 t0 = csn_bufacc<AT>::ld2(rb, o, 0u), t1 = csn_bufacc<AT>::ld2(rb, ok ? o + P4 : OOB, 0u);
           return fmaxf(fmaxf(t0.x, t0.y), fmaxf(t1.x, t1.y));
         };
 #pragma unroll 5
@@ -252,15 +253,15 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_c3_kernel(PwArgs a_byval) {
         float ly, lxw;
         csn_bilin(gy, 0.5f, Hs, yy0, yy1, ly);
         csn_bilin(gx, 0.5f, Ws, xx0, xx1, lxw);
-        zcs4 = (unsigned)(Hs * Ws) * 4u;
-        zb = csn_make_buf(ps->src[ntap].ptr + (int64_t)b * ps->src[ntap].Ctot * (Hs * Ws));
-        zo00 = (unsigned)(yy0 * Ws + xx0) * 4u; zo01 = (unsigned)(yy0 * Ws + xx1) * 4u;
-        zo10 = (unsigned)(yy1 * Ws + xx0) * 4u; zo11 = (unsigned)(yy1 * Ws + xx1) * 4u;
+        zcs4 = (unsigned)(Hs * Ws) * E;
+        zb = csn_make_buf(act_cast<AT>(ps->src[ntap].ptr) + (int64_t)b * ps->src[ntap].Ctot * (Hs * Ws));
+        zo00 = (unsigned)(yy0 * Ws + xx0) * E; zo01 = (unsigned)(yy0 * Ws + xx1) * E;
+        zo10 = (unsigned)(yy1 * Ws + xx0) * E; zo11 = (unsigned)(yy1 * Ws + xx1) * E;
         zw00 = (1.f - ly) * (1.f - lxw); zw01 = (1.f - ly) * lxw; zw10 = ly * (1.f - lxw); zw11 = ly * lxw;
       }
       // ---- epilogue: transpose through the wave's scratch, (+ z), folded BN + PReLU, 128-byte row segments
-      const unsigned cs4 = (unsigned)(Hr * Wr) * 4u;
-      const csn_buf ob = csn_make_buf(ps->out + (int64_t)b * ps->out_ctot * (Hr * Wr));
+      const unsigned cs4 = (unsigned)(Hr * Wr) * E;
+      const csn_buf ob = csn_make_buf(act_cast<AT>(ps->out) + (int64_t)b * ps->out_ctot * (Hr * Wr));
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         if (t == 1 && !two) break;
@@ -278,11 +279,11 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_c3_kernel(PwArgs a_byval) {
           float v = xb[rr * PW_EP + lane];
           if (has_z) {
             const unsigned so = (unsigned)(a->z_c0 + rbase + rr) * zcs4;
-            v += zw00 * csn_ld1(zb, zo00, so) + zw01 * csn_ld1(zb, zo01, so) + zw10 * csn_ld1(zb, zo10, so) +
-                 zw11 * csn_ld1(zb, zo11, so);
+            v += zw00 * csn_bufacc<AT>::ld1(zb, zo00, so) + zw01 * csn_bufacc<AT>::ld1(zb, zo01, so) +
+                 zw10 * csn_bufacc<AT>::ld1(zb, zo10, so) + zw11 * csn_bufacc<AT>::ld1(zb, zo11, so);
           }
           const float val = RAW ? v : csn_epi(v, scale[rr], shift[rr], alpha[rr]);
-          if (valid) csn_st1(ob, ovoff, (unsigned)(rbase + rr) * cs4, val);
+          if (valid) csn_bufacc<AT>::st1(ob, ovoff, (unsigned)(rbase + rr) * cs4, val);
         }
       }
     }
@@ -319,10 +320,12 @@ int csn_launch_c3(const PwArgs& a, int raw, void* stream) {
 #ifndef CSN_CPU_EMU
   static bool attr_done = false;
   if (!attr_done) {
-    const void* fns[4] = {reinterpret_cast<const void*>(&goct_c3_kernel<false, false>),
-                          reinterpret_cast<const void*>(&goct_c3_kernel<false, true>),
-                          reinterpret_cast<const void*>(&goct_c3_kernel<true, false>),
-                          reinterpret_cast<const void*>(&goct_c3_kernel<true, true>)};
+    const void* fns[6] = {reinterpret_cast<const void*>(&goct_c3_kernel<false, false, float>),
+                          reinterpret_cast<const void*>(&goct_c3_kernel<false, true, float>),
+                          reinterpret_cast<const void*>(&goct_c3_kernel<true, false, float>),
+                          reinterpret_cast<const void*>(&goct_c3_kernel<true, true, float>),
+                          reinterpret_cast<const void*>(&goct_c3_kernel<true, false, csn_bf16>),
+                          reinterpret_cast<const void*>(&goct_c3_kernel<true, true, csn_bf16>)};
     for (const void* f : fns) {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return (int)e;
@@ -330,9 +333,15 @@ int csn_launch_c3(const PwArgs& a, int raw, void* stream) {
     attr_done = true;
   }
 #endif
-  if (raw && wch) CSN_LAUNCH((goct_c3_kernel<true, true>), grid, dim3(CSN_BLOCK), lds, stream, a);
-  else if (raw) CSN_LAUNCH((goct_c3_kernel<true, false>), grid, dim3(CSN_BLOCK), lds, stream, a);
-  else if (wch) CSN_LAUNCH((goct_c3_kernel<false, true>), grid, dim3(CSN_BLOCK), lds, stream, a);
-  else CSN_LAUNCH((goct_c3_kernel<false, false>), grid, dim3(CSN_BLOCK), lds, stream, a);
+  if (a.a16) {   // bf16 activations: train mode only (raw sums; BN runs as its own passes)
+    if (!raw) return -1;
+    if (wch) CSN_LAUNCH((goct_c3_kernel<true, true, csn_bf16>), grid, dim3(CSN_BLOCK), lds, stream, a);
+    else CSN_LAUNCH((goct_c3_kernel<true, false, csn_bf16>), grid, dim3(CSN_BLOCK), lds, stream, a);
+    return (int)hipGetLastError();
+  }
+  if (raw && wch) CSN_LAUNCH((goct_c3_kernel<true, true, float>), grid, dim3(CSN_BLOCK), lds, stream, a);
+  else if (raw) CSN_LAUNCH((goct_c3_kernel<true, false, float>), grid, dim3(CSN_BLOCK), lds, stream, a);
+  else if (wch) CSN_LAUNCH((goct_c3_kernel<false, true, float>), grid, dim3(CSN_BLOCK), lds, stream, a);
+  else CSN_LAUNCH((goct_c3_kernel<false, false, float>), grid, dim3(CSN_BLOCK), lds, stream, a);
   return (int)hipGetLastError();
 }

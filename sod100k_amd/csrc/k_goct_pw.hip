@@ -62,7 +62,7 @@ __device__ __forceinline__ void pw_contract(const float* wl, int stride, const f
 // are gathered into the panel and contracted, then every tile is transposed through the panel so that each
 // lane gets ITS pixel back and the wave stores 256 contiguous bytes per output channel (buffer stores: one
 // VGPR offset per lane, the channel offset rides in an SGPR; lanes outside the image are exec-masked).
-template <int NT, bool RAW>
+template <int NT, bool RAW, typename AT>
 __device__ __forceinline__ void pw_sweep(PwPassP ps, const float* wl0, float* xb, int row0, int b, int gy, int gx,
                                          int Hr, int Wr, unsigned ovoff, bool valid, int lane, float& red) {
   const int cin = ps->cin, cin4 = ps->cin4, nrows = ps->nrows, stride = ps->w_stride;
@@ -77,21 +77,21 @@ __device__ __forceinline__ void pw_sweep(PwPassP ps, const float* wl0, float* xb
   for (int kc = 0; kc < cin4; kc += PW_KC) {
     const int kend = min(kc + PW_KC, cin4);
     CSN_WAVE_SYNC();  // previous panel fully consumed
-    if (kc < c1) pw_gather_slice<PW_XP>(ps, 0, kc, min(kend, c1), xb + lane, PW_KC, b, gy, gx, Hr, Wr);
+    if (kc < c1) pw_gather_slice<AT, PW_XP>(ps, 0, kc, min(kend, c1), xb + lane, PW_KC, b, gy, gx, Hr, Wr);
     if (max(kc, c1) < min(kend, c2)) {
       const int r0 = max(kc, c1) - kc;
-      pw_gather_slice<PW_XP>(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xb + r0 * PW_XP + lane, PW_KC - r0, b, gy, gx, Hr, Wr);
+      pw_gather_slice<AT, PW_XP>(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xb + r0 * PW_XP + lane, PW_KC - r0, b, gy, gx, Hr, Wr);
     }
     if (max(kc, c2) < min(kend, cin)) {
       const int r0 = max(kc, c2) - kc;
-      pw_gather_slice<PW_XP>(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xb + r0 * PW_XP + lane, PW_KC - r0, b, gy, gx, Hr, Wr);
+      pw_gather_slice<AT, PW_XP>(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xb + r0 * PW_XP + lane, PW_KC - r0, b, gy, gx, Hr, Wr);
     }
     for (int k = max(cin, kc); k < kend; ++k) xb[(k - kc) * PW_XP + lane] = 0.f;  // pad to a multiple of 4
     CSN_WAVE_SYNC();  // panel complete
     pw_contract<NT>(wl0 + row0 * stride + kc, stride, xb, kend - kc, lane, acc);
   }
-  const unsigned cs4 = (unsigned)(Hr * Wr) * 4u;
-  const csn_buf ob = csn_make_buf(ps->out + (int64_t)b * ps->out_ctot * (Hr * Wr));
+  const unsigned cs4 = (unsigned)(Hr * Wr) * (unsigned)sizeof(AT);
+  const csn_buf ob = csn_make_buf(act_cast<AT>(ps->out) + (int64_t)b * ps->out_ctot * (Hr * Wr));
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     CSN_WAVE_SYNC();
@@ -112,14 +112,14 @@ __device__ __forceinline__ void pw_sweep(PwPassP ps, const float* wl0, float* xb
 #pragma unroll 4
     for (int rr = 0; rr < rn; ++rr) {
       const float val = RAW ? xb[rr * PW_EP + lane] : csn_epi(xb[rr * PW_EP + lane], scale[rr], shift[rr], alpha[rr]);
-      if (valid) csn_st1(ob, ovoff, (unsigned)(rbase + rr) * cs4, val);
+      if (valid) csn_bufacc<AT>::st1(ob, ovoff, (unsigned)(rbase + rr) * cs4, val);
     }
   }
 }
 
 // RAW = true: plain store (train-mode raw convolution outputs, every backward-data launch) -- its own symbol, so
 // kernel traces keep the eval-mode launches (BN + PReLU epilogue) apart from the training ones.
-template <bool RAW>
+template <bool RAW, typename AT>
 __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
   CSN_DYN_SMEM(float, lds);
   const CSN_CONST_AS PwArgs* a = CSN_KERNARG(PwArgs, a_byval);
@@ -166,15 +166,15 @@ __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
         const int py_ = (ty0 >> r) + (p >> txl), px_ = (tx0 >> r) + (p & ((1 << txl) - 1));
         const bool valid = p < npx && py_ < Hr && px_ < Wr;
         const int gy = min(py_, Hr - 1), gx = min(px_, Wr - 1);     // lanes off the image gather a valid pixel
-        const unsigned ovoff = (unsigned)(gy * Wr + gx) * 4u;        // ... and store nothing (exec-masked)
+        const unsigned ovoff = (unsigned)(gy * Wr + gx) * (unsigned)sizeof(AT);        // ... and store nothing (exec-masked)
         float red = 0.f;
         for (int row0 = 0; row0 < nrows; row0 += 32) {
-          if (nrows - row0 <= 16) pw_sweep<1, RAW>(ps, wl0, xb, row0, b, gy, gx, Hr, Wr, ovoff, valid, lane, red);
-          else pw_sweep<2, RAW>(ps, wl0, xb, row0, b, gy, gx, Hr, Wr, ovoff, valid, lane, red);
+          if (nrows - row0 <= 16) pw_sweep<1, RAW, AT>(ps, wl0, xb, row0, b, gy, gx, Hr, Wr, ovoff, valid, lane, red);
+          else pw_sweep<2, RAW, AT>(ps, wl0, xb, row0, b, gy, gx, Hr, Wr, ovoff, valid, lane, red);
         }
         if (!RAW && ps->red_w && valid) {   // out: [B][1][Hr][Wr]
-          const csn_buf ob = csn_make_buf(ps->out + (int64_t)b * (Hr * Wr));
-          csn_st1(ob, ovoff, 0, red + csn_const(ps->red_b)[0]);
+          const csn_buf ob = csn_make_buf(act_cast<AT>(ps->out) + (int64_t)b * (Hr * Wr));
+          csn_bufacc<AT>::st1(ob, ovoff, 0, red + csn_const(ps->red_b)[0]);
         }
       }
       gbase += ng;
@@ -191,16 +191,23 @@ int csn_launch_pw(const PwArgs& a, int raw, void* stream) {
   static bool attr_done = false;
   if (!attr_done) {
     // units with a large weight image may use the full 160 KiB of LDS of a CDNA4 CU
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&goct_pw_kernel<false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&goct_pw_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
+    const void* fns[4] = {reinterpret_cast<const void*>(&goct_pw_kernel<false, float>),
+                          reinterpret_cast<const void*>(&goct_pw_kernel<true, float>),
+                          reinterpret_cast<const void*>(&goct_pw_kernel<false, csn_bf16>),
+                          reinterpret_cast<const void*>(&goct_pw_kernel<true, csn_bf16>)};
+    for (const void* f : fns) {
+      const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+    }
     attr_done = true;
   }
 #endif
-  if (raw) CSN_LAUNCH(goct_pw_kernel<true>, grid, dim3(CSN_BLOCK), lds, stream, a);
-  else CSN_LAUNCH(goct_pw_kernel<false>, grid, dim3(CSN_BLOCK), lds, stream, a);
+  if (a.a16) {
+    if (raw) CSN_LAUNCH((goct_pw_kernel<true, csn_bf16>), grid, dim3(CSN_BLOCK), lds, stream, a);
+    else CSN_LAUNCH((goct_pw_kernel<false, csn_bf16>), grid, dim3(CSN_BLOCK), lds, stream, a);
+  } else {
+    if (raw) CSN_LAUNCH((goct_pw_kernel<true, float>), grid, dim3(CSN_BLOCK), lds, stream, a);
+    else CSN_LAUNCH((goct_pw_kernel<false, float>), grid, dim3(CSN_BLOCK), lds, stream, a);
+  }
   return (int)hipGetLastError();
 }

@@ -101,20 +101,21 @@ struct DwRow {
   float v[6];  // [0]=x0-1, [1..4]=x0..x0+3, [5]=x0+4
 };
 
-template <bool VEC>
+template <bool VEC, typename AT = float>
 __device__ __forceinline__ DwRow dw_load_row(csn_buf rb, int y, int x0, int W, bool has_l, bool has_r) {
   DwRow r;
-  const unsigned o = (unsigned)(y * W + x0) * 4u;   // y = -1 wraps to a huge offset -> out of range -> 0
+  constexpr unsigned E = (unsigned)sizeof(AT);
+  const unsigned o = (unsigned)(y * W + x0) * E;   // y = -1 wraps to a huge offset -> out of range -> 0
   if (VEC) {
-    const float4 c = csn_ld4(rb, o, 0);
+    const float4 c = csn_bufacc<AT>::ld4(rb, o, 0);
     r.v[1] = c.x; r.v[2] = c.y; r.v[3] = c.z; r.v[4] = c.w;
-    const float l = csn_ld1(rb, o - 4u, 0), rr = csn_ld1(rb, o + 16u, 0);
+    const float l = csn_bufacc<AT>::ld1(rb, o - E, 0), rr = csn_bufacc<AT>::ld1(rb, o + 4u * E, 0);
     r.v[0] = has_l ? l : 0.f;
     r.v[5] = has_r ? rr : 0.f;
   } else {
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const float t = csn_ld1(rb, o + (unsigned)(i - 1) * 4u, 0);
+      const float t = csn_bufacc<AT>::ld1(rb, o + (unsigned)(i - 1) * E, 0);
       const int xx = x0 + i - 1;
       r.v[i] = (xx >= 0 && xx < W) ? t : 0.f;
     }
@@ -122,8 +123,8 @@ __device__ __forceinline__ DwRow dw_load_row(csn_buf rb, int y, int x0, int W, b
   return r;
 }
 
-template <bool VEC>
-__device__ __forceinline__ void dw_emit(float* __restrict__ op, int y, int yend, int x0, int W,
+template <bool VEC, typename AT = float>
+__device__ __forceinline__ void dw_emit(AT* __restrict__ op, int y, int yend, int x0, int W,
                                         const float (&w)[9], float sc, float sh, float al, const DwRow& top,
                                         const DwRow& mid, const DwRow& bot) {
   if (y >= yend) return;
@@ -141,17 +142,17 @@ __device__ __forceinline__ void dw_emit(float* __restrict__ op, int y, int yend,
     acc = fmaf(w[8], bot.v[j + 2], acc);
     o[j] = csn_epi(acc, sc, sh, al);
   }
-  float* q = op + (int64_t)y * W + x0;
+  AT* q = op + (int64_t)y * W + x0;
   if (VEC) {
-    *reinterpret_cast<float4*>(q) = make_float4(o[0], o[1], o[2], o[3]);
+    act_st4(q, make_float4(o[0], o[1], o[2], o[3]));
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (x0 + j < W) q[j] = o[j];
+      if (x0 + j < W) act_st(q + j, o[j]);
   }
 }
 
-template <bool VEC>
+template <bool VEC, typename AT>
 __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
   int bid = blockIdx.x;
   int k = 0;
@@ -171,8 +172,8 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
   const int x0 = (tx * br.LX + lx) * 4;
   const int y0 = (ty * br.NY + ly) * br.R;
   if (x0 >= W || y0 >= H) return;
-  const csn_buf rb = csn_make_buf_n(br.in + (int64_t)pc * H * W, (unsigned)(H * W) * 4u);
-  float* __restrict__ op = br.out + (int64_t)pc * H * W;
+  const csn_buf rb = csn_make_buf_n(act_cast<AT>(br.in) + (int64_t)pc * H * W, (unsigned)(H * W) * (unsigned)sizeof(AT));
+  AT* __restrict__ op = act_cast<AT>(br.out) + (int64_t)pc * H * W;
   float w[9];
   csn_cfp w9 = csn_const(br.w9);
 #pragma unroll
@@ -180,18 +181,18 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
   const float sc = csn_const(br.scale)[c], sh = csn_const(br.shift)[c], al = csn_const(br.alpha)[c];
   const bool has_l = x0 > 0, has_r = x0 + 4 < W;
 
-  DwRow r0 = dw_load_row<VEC>(rb, y0 - 1, x0, W, has_l, has_r);
-  DwRow r1 = dw_load_row<VEC>(rb, y0, x0, W, has_l, has_r);
+  DwRow r0 = dw_load_row<VEC, AT>(rb, y0 - 1, x0, W, has_l, has_r);
+  DwRow r1 = dw_load_row<VEC, AT>(rb, y0, x0, W, has_l, has_r);
   const int yend = min(y0 + br.R, H);
   for (int y = y0; y < yend; y += 4) {
-    const DwRow n0 = dw_load_row<VEC>(rb, y + 1, x0, W, has_l, has_r);
-    const DwRow n1 = dw_load_row<VEC>(rb, y + 2, x0, W, has_l, has_r);
-    const DwRow n2 = dw_load_row<VEC>(rb, y + 3, x0, W, has_l, has_r);
-    const DwRow n3 = dw_load_row<VEC>(rb, y + 4, x0, W, has_l, has_r);
-    dw_emit<VEC>(op, y, yend, x0, W, w, sc, sh, al, r0, r1, n0);
-    dw_emit<VEC>(op, y + 1, yend, x0, W, w, sc, sh, al, r1, n0, n1);
-    dw_emit<VEC>(op, y + 2, yend, x0, W, w, sc, sh, al, n0, n1, n2);
-    dw_emit<VEC>(op, y + 3, yend, x0, W, w, sc, sh, al, n1, n2, n3);
+    const DwRow n0 = dw_load_row<VEC, AT>(rb, y + 1, x0, W, has_l, has_r);
+    const DwRow n1 = dw_load_row<VEC, AT>(rb, y + 2, x0, W, has_l, has_r);
+    const DwRow n2 = dw_load_row<VEC, AT>(rb, y + 3, x0, W, has_l, has_r);
+    const DwRow n3 = dw_load_row<VEC, AT>(rb, y + 4, x0, W, has_l, has_r);
+    dw_emit<VEC, AT>(op, y, yend, x0, W, w, sc, sh, al, r0, r1, n0);
+    dw_emit<VEC, AT>(op, y + 1, yend, x0, W, w, sc, sh, al, r1, n0, n1);
+    dw_emit<VEC, AT>(op, y + 2, yend, x0, W, w, sc, sh, al, n0, n1, n2);
+    dw_emit<VEC, AT>(op, y + 3, yend, x0, W, w, sc, sh, al, n1, n2, n3);
     r0 = n2;
     r1 = n3;
   }
@@ -371,16 +372,20 @@ int csn_launch_dw(const DwArgs& a, void* stream) {
   if (nblk <= 0) return 0;
   bool vec = true;  // float4 path needs every branch width to be a multiple of 4
   for (int k = 0; k < a.nbr; ++k) vec = vec && (a.br[k].W % 4 == 0);
-  if (vec) {
-    CSN_LAUNCH((dw3x3_bn_prelu_kernel<true>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+  if (a.a16) {
+    if (vec) CSN_LAUNCH((dw3x3_bn_prelu_kernel<true, csn_bf16>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+    else CSN_LAUNCH((dw3x3_bn_prelu_kernel<false, csn_bf16>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+  } else if (vec) {
+    CSN_LAUNCH((dw3x3_bn_prelu_kernel<true, float>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
   } else {
-    CSN_LAUNCH((dw3x3_bn_prelu_kernel<false>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+    CSN_LAUNCH((dw3x3_bn_prelu_kernel<false, float>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
   }
   return (int)hipGetLastError();
 }
 
 // -------------------------------------------------------------------------------------- avg-pool
 // out[y][x] = mean of the 2x2 input window.  A lane produces 2 output pixels from two float4 loads.
+template <typename AT>
 __global__ __launch_bounds__(CSN_BLOCK) void avgpool2_kernel(PoolArgs a) {
   int bid = blockIdx.x;
   int k = 0;
@@ -397,29 +402,31 @@ __global__ __launch_bounds__(CSN_BLOCK) void avgpool2_kernel(PoolArgs a) {
   const int rem = (int)(idx - (int64_t)plane * per_plane);
   const int y = rem / Wp, xp = rem - y * Wp;
   const int Wi = Wo * 2;
-  const float* __restrict__ ip = a.in[k] + ((int64_t)plane * Ho * 2 + 2 * y) * Wi + 4 * xp;
-  float* __restrict__ op = a.out[k] + ((int64_t)plane * Ho + y) * Wo + 2 * xp;
+  const AT* __restrict__ ip = act_cast<AT>(a.in[k]) + ((int64_t)plane * Ho * 2 + 2 * y) * Wi + 4 * xp;
+  AT* __restrict__ op = act_cast<AT>(a.out[k]) + ((int64_t)plane * Ho + y) * Wo + 2 * xp;
   if ((Wo & 1) == 0) {
-    const float4 r0 = *reinterpret_cast<const float4*>(ip);
-    const float4 r1 = *reinterpret_cast<const float4*>(ip + Wi);
+    const float4 r0 = act_ld4(ip);
+    const float4 r1 = act_ld4(ip + Wi);
     float2 o;
     o.x = (r0.x + r0.y + r1.x + r1.y) * 0.25f;
     o.y = (r0.z + r0.w + r1.z + r1.w) * 0.25f;
-    *reinterpret_cast<float2*>(op) = o;
+    act_st2(op, o);
   } else {
-    op[0] = (ip[0] + ip[1] + ip[Wi] + ip[Wi + 1]) * 0.25f;
-    if (2 * xp + 1 < Wo) op[1] = (ip[2] + ip[3] + ip[Wi + 2] + ip[Wi + 3]) * 0.25f;
+    act_st(op, (act_ld(ip) + act_ld(ip + 1) + act_ld(ip + Wi) + act_ld(ip + Wi + 1)) * 0.25f);
+    if (2 * xp + 1 < Wo) act_st(op + 1, (act_ld(ip + 2) + act_ld(ip + 3) + act_ld(ip + Wi + 2) + act_ld(ip + Wi + 3)) * 0.25f);
   }
 }
 
 int csn_launch_pool(const PoolArgs& a, void* stream) {
   const int nblk = a.blk_end[a.n - 1];
   if (nblk <= 0) return 0;
-  CSN_LAUNCH(avgpool2_kernel, dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+  if (a.a16) CSN_LAUNCH((avgpool2_kernel<csn_bf16>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+  else CSN_LAUNCH((avgpool2_kernel<float>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------ final bilinear x2
+template <typename TI>
 __global__ __launch_bounds__(CSN_BLOCK) void bilinear_up2_kernel(Up2Args a) {
   const int H = a.H, W = a.W, Hi = H >> 1, Wi = W >> 1;
   const int64_t idx = (int64_t)blockIdx.x * CSN_BLOCK + threadIdx.x;
@@ -432,9 +439,9 @@ __global__ __launch_bounds__(CSN_BLOCK) void bilinear_up2_kernel(Up2Args a) {
   float ly, lx;
   csn_bilin(y, 0.5f, Hi, y0, y1, ly);
   csn_bilin(x, 0.5f, Wi, x0, x1, lx);
-  const float* __restrict__ p = a.in + (int64_t)plane * Hi * Wi;
-  const float v0 = (1.f - lx) * p[y0 * Wi + x0] + lx * p[y0 * Wi + x1];
-  const float v1 = (1.f - lx) * p[y1 * Wi + x0] + lx * p[y1 * Wi + x1];
+  const TI* __restrict__ p = act_cast<TI>(a.in) + (int64_t)plane * Hi * Wi;
+  const float v0 = (1.f - lx) * act_ld(p + y0 * Wi + x0) + lx * act_ld(p + y0 * Wi + x1);
+  const float v1 = (1.f - lx) * act_ld(p + y1 * Wi + x0) + lx * act_ld(p + y1 * Wi + x1);
   a.out[idx] = (1.f - ly) * v0 + ly * v1;
 }
 
@@ -442,7 +449,8 @@ int csn_launch_up2(const Up2Args& a, void* stream) {
   const int64_t total = (int64_t)a.planes * a.H * a.W;
   const int nblk = (int)((total + CSN_BLOCK - 1) / CSN_BLOCK);
   if (nblk <= 0) return 0;
-  CSN_LAUNCH(bilinear_up2_kernel, dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+  if (a.in16) CSN_LAUNCH((bilinear_up2_kernel<csn_bf16>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);   // out stays float (the caller's y)
+  else CSN_LAUNCH((bilinear_up2_kernel<float>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
 }
 

@@ -24,7 +24,9 @@ __device__ __forceinline__ unsigned ms_tap_mask(int y, int x, int H, int W, int 
   return vm;
 }
 
+template <typename AT>
 __global__ __launch_bounds__(CSN_BLOCK) void msblock_kernel(MsArgs a) {
+  constexpr unsigned E = (unsigned)sizeof(AT);
   const int H = a.H, W = a.W;
   const int hw = H * W;
   // 1-D grid, XCD-aware: workgroups go round-robin to the 8 XCDs (blockIdx.x & 7).  The five dilation blocks of a
@@ -39,10 +41,10 @@ __global__ __launch_bounds__(CSN_BLOCK) void msblock_kernel(MsArgs a) {
   const bool valid = p0 < hw;
   const int p = valid ? p0 : hw - 1;
   const int y = p / W, x = p - y * W;
-  const csn_buf rb = csn_make_buf_n(a.in + (int64_t)b * a.cin * hw, (unsigned)(a.cin * hw) * 4u);
-  const unsigned lo = (unsigned)p * 4u;
-  const unsigned cs4 = (unsigned)hw * 4u;
-  float* __restrict__ op = a.out + (int64_t)b * a.cout * hw + p;
+  const csn_buf rb = csn_make_buf_n(act_cast<AT>(a.in) + (int64_t)b * a.cin * hw, (unsigned)(a.cin * hw) * E);
+  const unsigned lo = (unsigned)p * E;
+  const unsigned cs4 = (unsigned)hw * E;
+  AT* __restrict__ op = act_cast<AT>(a.out) + (int64_t)b * a.cout * hw + p;
   csn_cfp scale = csn_const(a.scale), shift = csn_const(a.shift), alpha = csn_const(a.alpha);
   const int cinp = (a.cin + 1) & ~1;
   {
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void msblock_kernel(MsArgs a) {
     const unsigned vm = ms_tap_mask(y, x, H, W, dil);
     int toff[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) toff[t] = ((t / 3 - 1) * W + (t % 3 - 1)) * dil * 4;
+    for (int t = 0; t < 9; ++t) toff[t] = ((t / 3 - 1) * W + (t % 3 - 1)) * dil * (int)E;
     const int ngrp = (nco + 7) >> 3;
     for (int g = 0; g < ngrp; ++g) {
       float acc[8];
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void msblock_kernel(MsArgs a) {
         for (int u = 0; u < 2; ++u) {
           const unsigned so = (unsigned)min(ci + u, a.cin - 1) * cs4;   // pad channel: its weights are zero
 #pragma unroll
-          for (int t = 0; t < 9; ++t) v[u][t] = csn_ld1(rb, lo + (unsigned)toff[t], so);
+          for (int t = 0; t < 9; ++t) v[u][t] = csn_bufacc<AT>::ld1(rb, lo + (unsigned)toff[t], so);
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void msblock_kernel(MsArgs a) {
         const int lc = g * 8 + co;
         if (lc < nco && valid) {
           const int oc = a.cobase[d] + lc;
-          op[(int64_t)oc * hw] = csn_epi(acc[co], scale[oc], shift[oc], alpha[oc]);
+          act_st(op + (int64_t)oc * hw, csn_epi(acc[co], scale[oc], shift[oc], alpha[oc]));
         }
       }
     }
@@ -244,7 +246,7 @@ int csn_launch_ms(const MsArgs& a, void* stream) {
   static const bool force_old = !(std::getenv("CSN_MS_TILED") && std::getenv("CSN_MS_TILED")[0] == '1');
   int RB0, CC0, RB1, CC1;
   size_t l0, l1;
-  if (!force_old && ms2_geometry(a, 4, RB0, CC0, l0) && ms2_geometry(a, 16, RB1, CC1, l1)) {
+  if (!force_old && !a.a16 && ms2_geometry(a, 4, RB0, CC0, l0) && ms2_geometry(a, 16, RB1, CC1, l1)) {
     if (a.dch[0] + a.dch[1] + a.dch[2] > 0)
       CSN_LAUNCH(msblock2_kernel<0>, dim3((unsigned)(a.B * ((a.H + RB0 - 1) / RB0))), dim3(CSN_BLOCK), l0, stream, a, RB0, CC0);
     if (a.dch[3] + a.dch[4] > 0)
@@ -253,6 +255,7 @@ int csn_launch_ms(const MsArgs& a, void* stream) {
   }
   const int tiles = ((hw + CSN_BLOCK - 1) / CSN_BLOCK) * a.B;
   const dim3 grid((unsigned)(((tiles + 7) / 8) * 5 * 8));
-  CSN_LAUNCH(msblock_kernel, grid, dim3(CSN_BLOCK), 0, stream, a);
+  if (a.a16) CSN_LAUNCH((msblock_kernel<csn_bf16>), grid, dim3(CSN_BLOCK), 0, stream, a);
+  else CSN_LAUNCH((msblock_kernel<float>), grid, dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
 }

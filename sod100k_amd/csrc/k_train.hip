@@ -73,22 +73,22 @@ __device__ __forceinline__ double bn_block_sum(double v, double* sm) {
 }
 
 // grid (nslab, C): block (slab, c) reduces one chunk of one plane of channel c.
+template <typename AT>
 __global__ __launch_bounds__(CSN_BLOCK) void bn_stats_kernel(BnStatsArgs a) {
   CSN_DYN_SMEM(double, sm);
   const int c = blockIdx.y, slab = blockIdx.x;
   const BnRange r = bn_range(slab, a.cpp, a.C, c, a.HW);
-  const float* __restrict__ p = a.z + r.base;
+  const AT* __restrict__ p = act_cast<AT>(a.z) + r.base;
   double s1 = 0.0, s2 = 0.0;
   if ((a.HW & 3) == 0) {
-    const float4* p4 = reinterpret_cast<const float4*>(p);
     for (int i = (r.beg >> 2) + threadIdx.x; i < (r.end >> 2); i += CSN_BLOCK) {
-      const float4 v = p4[i];
+      const float4 v = act_ld4(p + 4 * i);
       s1 += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
       s2 += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
     }
   } else {
     for (int i = r.beg + threadIdx.x; i < r.end; i += CSN_BLOCK) {
-      const double v = (double)p[i];
+      const double v = (double)act_ld(p + i);
       s1 += v;
       s2 += v * v;
     }
@@ -131,28 +131,27 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_finalize_kernel(BnFinalizeArgs a
 
 // grid (C, S): block (c, n) streams one plane: y = PReLU(z*scale + shift) (z is kept for the backward pass), and
 // the plane sum feeds the penalty 0.5 * w * |mean_hw y| * gamma^2 (fp64 atomic; w == 0: unit is not hooked).
+template <typename AT>
 __global__ __launch_bounds__(CSN_BLOCK) void bn_apply_gap_kernel(BnApplyArgs a) {
   CSN_DYN_SMEM(double, sm);
   const int c = blockIdx.x, n = blockIdx.y;
   const int64_t hw = a.HW;
-  const float* __restrict__ p = a.z + ((int64_t)n * a.C + c) * hw;
-  float* __restrict__ q = a.y + ((int64_t)n * a.C + c) * hw;
+  const AT* __restrict__ p = act_cast<AT>(a.z) + ((int64_t)n * a.C + c) * hw;
+  AT* __restrict__ q = act_cast<AT>(a.y) + ((int64_t)n * a.C + c) * hw;
   const float sc = a.scale[c], sh = a.shift[c], al = a.alpha[c];
   double s = 0.0;
   if ((hw & 3) == 0) {
-    const float4* p4 = reinterpret_cast<const float4*>(p);
-    float4* q4 = reinterpret_cast<float4*>(q);
     for (int64_t i = threadIdx.x; i < (hw >> 2); i += CSN_BLOCK) {
-      float4 v = p4[i];
+      float4 v = act_ld4(p + 4 * i);
       v.x = csn_epi(v.x, sc, sh, al); v.y = csn_epi(v.y, sc, sh, al);
       v.z = csn_epi(v.z, sc, sh, al); v.w = csn_epi(v.w, sc, sh, al);
-      q4[i] = v;
+      act_st4(q + 4 * i, v);
       s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
     }
   } else {
     for (int64_t i = threadIdx.x; i < hw; i += CSN_BLOCK) {
-      const float v = csn_epi(p[i], sc, sh, al);
-      q[i] = v;
+      const float v = csn_epi(act_ld(p + i), sc, sh, al);
+      act_st(q + i, v);
       s += (double)v;
     }
   }
@@ -183,12 +182,14 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_penalty_kernel(BnApplyArgs a) {
 //   dbeta = sum dbn    dgamma = sum dbn*xhat    dz = gamma*invstd * (dbn - mean(dbn) - xhat*mean(dbn*xhat))
 // (ATen batch_norm_backward / prelu_backward semantics).  dy may arrive from two consumers (the stage outputs feed
 // both the next stage and the CSF head); the sums are fp64, one partial per (channel, slab) -> deterministic.
+template <typename AT>
 __device__ __forceinline__ float bnb_dy(const BnBwdArgs& a, int64_t i) {
-  float v = a.dyA[i];
-  if (a.dyB) v += a.dyB[i];
+  float v = act_ld(act_cast<AT>(a.dyA) + i);
+  if (a.dyB) v += act_ld(act_cast<AT>(a.dyB) + i);
   return v;
 }
 
+template <typename AT>
 __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_reduce_kernel(BnBwdArgs a) {
   CSN_DYN_SMEM(double, sm);
   const int c = blockIdx.y, slab = blockIdx.x;
@@ -203,17 +204,18 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_reduce_kernel(BnBwdArgs a) {
     if (!(bn > 0.f)) s2 += (double)dy * (double)bn;
   };
   if ((a.HW & 3) == 0) {   // chunks start on float4 boundaries (bn_range)
-    const float4* z4 = reinterpret_cast<const float4*>(a.z + r.base);
-    const float4* a4 = reinterpret_cast<const float4*>(a.dyA + r.base);
-    const float4* b4 = a.dyB ? reinterpret_cast<const float4*>(a.dyB + r.base) : nullptr;
+    const AT* z4 = act_cast<AT>(a.z) + r.base;
+    const AT* a4 = act_cast<AT>(a.dyA) + r.base;
+    const AT* b4 = a.dyB ? act_cast<AT>(a.dyB) + r.base : nullptr;
     for (int i = (r.beg >> 2) + threadIdx.x; i < (r.end >> 2); i += CSN_BLOCK) {
-      const float4 z = z4[i];
-      float4 d = a4[i];
-      if (b4) { const float4 e = b4[i]; d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
+      const float4 z = act_ld4(z4 + 4 * i);
+      float4 d = act_ld4(a4 + 4 * i);
+      if (b4) { const float4 e = act_ld4(b4 + 4 * i); d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
       acc(z.x, d.x); acc(z.y, d.y); acc(z.z, d.z); acc(z.w, d.w);
     }
   } else {
-    for (int i = r.beg + threadIdx.x; i < r.end; i += CSN_BLOCK) acc(a.z[r.base + i], bnb_dy(a, r.base + i));
+    for (int i = r.beg + threadIdx.x; i < r.end; i += CSN_BLOCK)
+      acc(act_ld(act_cast<AT>(a.z) + r.base + i), bnb_dy<AT>(a, r.base + i));
   }
   s0 = bn_block_sum(s0, sm);
   s1 = bn_block_sum(s1, sm);
@@ -254,6 +256,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_finalize_kernel(BnBwdArgs a)
 }
 
 // grid (C, S): dz written over z (same index, same thread)
+template <typename AT>
 __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_apply_kernel(BnBwdArgs a) {
   const int c = blockIdx.x, n = blockIdx.y;
   const int64_t hw = a.HW;
@@ -267,39 +270,41 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_apply_kernel(BnBwdArgs a) {
     return gi * (dbn - m1 - (z - mu) * is * m2);
   };
   if ((hw & 3) == 0) {
-    float4* z4 = reinterpret_cast<float4*>(a.z + base);
-    const float4* a4 = reinterpret_cast<const float4*>(a.dyA + base);
-    const float4* b4 = a.dyB ? reinterpret_cast<const float4*>(a.dyB + base) : nullptr;
+    AT* z4 = act_cast<AT>(a.z) + base;
+    const AT* a4 = act_cast<AT>(a.dyA) + base;
+    const AT* b4 = a.dyB ? act_cast<AT>(a.dyB) + base : nullptr;
     for (int64_t i = threadIdx.x; i < (hw >> 2); i += CSN_BLOCK) {
-      float4 z = z4[i], d = a4[i];
-      if (b4) { const float4 e = b4[i]; d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
+      float4 z = act_ld4(z4 + 4 * i), d = act_ld4(a4 + 4 * i);
+      if (b4) { const float4 e = act_ld4(b4 + 4 * i); d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
       z.x = f(z.x, d.x); z.y = f(z.y, d.y); z.z = f(z.z, d.z); z.w = f(z.w, d.w);
-      z4[i] = z;
+      act_st4(z4 + 4 * i, z);
     }
   } else {
-    for (int64_t i = threadIdx.x; i < hw; i += CSN_BLOCK) a.z[base + i] = f(a.z[base + i], bnb_dy(a, base + i));
+    AT* zp = act_cast<AT>(a.z) + base;
+    for (int64_t i = threadIdx.x; i < hw; i += CSN_BLOCK) act_st(zp + i, f(act_ld(zp + i), bnb_dy<AT>(a, base + i)));
   }
 }
 
 // depthwise 3x3 weight gradient: dW[c][t] = 100 * sum_{n,p} dz[n,c,p] * x[n,c,p + off(t)]   (conv2d.py:104)
+template <typename AT>
 __global__ __launch_bounds__(CSN_BLOCK) void dw_wgrad_kernel(DwWgradArgs a) {
   CSN_DYN_SMEM(double, sm);
   const int c = blockIdx.y, slab = blockIdx.x;
   const int H = a.H, W = a.W;
   const BnRange r = bn_range(slab, a.cpp, a.C, c, (int64_t)H * W);
-  const float* __restrict__ gp = a.dz + r.base;
-  const float* __restrict__ xp = a.x + r.base;
+  const AT* __restrict__ gp = act_cast<AT>(a.dz) + r.base;
+  const AT* __restrict__ xp = act_cast<AT>(a.x) + r.base;
   float s[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) s[t] = 0.f;
   for (int p = r.beg + threadIdx.x; p < r.end; p += CSN_BLOCK) {   // <= 32 terms per lane: fp32 partials
     const int y = p / W, x = p - y * W;
-    const float g = gp[p];
+    const float g = act_ld(gp + p);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
       const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
-      const float v = xp[in ? yy * W + xx : p];
+      const float v = act_ld(xp + (in ? yy * W + xx : p));
       s[t] = fmaf(g, in ? v : 0.f, s[t]);
     }
   }
@@ -331,6 +336,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw_wgrad_finalize_kernel(DwWgradArg
 // Source pixel s receives from the outputs o in [f*s - f/2, f*s + f + f/2 - 1] (2f candidates per axis, f = 2 or 4);
 // the weight of each candidate is read off the forward's own index computation (csn_bilin), so the border clamping
 // is the adjoint of exactly what the forward did.
+template <typename TI, typename TO>
 __global__ __launch_bounds__(CSN_BLOCK) void adjup_kernel(AdjUpArgs a) {
   const int Hl = a.Hl, Wl = a.Wl, f = a.f;
   const int Hh = Hl * f, Wh = Wl * f;
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void adjup_kernel(AdjUpArgs a) {
     const int64_t pl = e / (Hl * Wl);
     const int r = (int)(e - pl * Hl * Wl);
     const int ys = r / Wl, xs = r - ys * Wl;
-    const float* ip = a.in + pl * (int64_t)Hh * Wh;
+    const TI* ip = act_cast<TI>(a.in) + pl * (int64_t)Hh * Wh;
     float wx[8];
     const int ox0 = xs * f - (f >> 1), oy0 = ys * f - (f >> 1);
 #pragma unroll
@@ -358,19 +364,20 @@ __global__ __launch_bounds__(CSN_BLOCK) void adjup_kernel(AdjUpArgs a) {
       int y0, y1; float ly;
       csn_bilin(oy, inv, Hl, y0, y1, ly);
       const float wy = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
-      const float* row = ip + (int64_t)oy * Wh;
+      const TI* row = ip + (int64_t)oy * Wh;
       float t = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        if (j < 2 * f) t = fmaf(wx[j], row[min(max(ox0 + j, 0), Wh - 1)], t);
+        if (j < 2 * f) t = fmaf(wx[j], act_ld(row + min(max(ox0 + j, 0), Wh - 1)), t);
       acc = fmaf(wy, t, acc);
     }
-    a.out[e] = acc;
+    act_st(act_cast<TO>(a.out) + e, acc);
   }
 }
 
 // f = 2, even source width: one thread produces TWO neighbouring source pixels (xs even) from the 4 x 6 window of
 // outputs they receive from -- per row one aligned float4 (columns 2 xs .. 2 xs + 3) and the two edge columns.
+template <typename TI, typename TO>
 __global__ __launch_bounds__(CSN_BLOCK) void adjup2_pair_kernel(AdjUpArgs a) {
   const int Hl = a.Hl, Wl = a.Wl, Wp = Wl >> 1;
   const int Hh = Hl * 2, Wh = Wl * 2;
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void adjup2_pair_kernel(AdjUpArgs a) {
     const int64_t pl = e / (Hl * Wp);
     const int r = (int)(e - pl * Hl * Wp);
     const int ys = r / Wp, xs = (r - ys * Wp) * 2;
-    const float* ip = a.in + pl * (int64_t)Hh * Wh;
+    const TI* ip = act_cast<TI>(a.in) + pl * (int64_t)Hh * Wh;
     // column weights of the six outputs 2 xs - 1 .. 2 xs + 4 towards source columns xs and xs + 1
     float w0[6], w1[6];
 #pragma unroll
@@ -399,9 +406,9 @@ __global__ __launch_bounds__(CSN_BLOCK) void adjup2_pair_kernel(AdjUpArgs a) {
       int y0, y1; float ly;
       csn_bilin(oy, 0.5f, Hl, y0, y1, ly);
       const float wy = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
-      const float* row = ip + (int64_t)oy * Wh + 2 * xs;
-      const float4 c = *reinterpret_cast<const float4*>(row);
-      const float l = row[xs > 0 ? -1 : 0], rr = row[2 * xs + 4 < Wh ? 4 : 3];
+      const TI* row = ip + (int64_t)oy * Wh + 2 * xs;
+      const float4 c = act_ld4(row);
+      const float l = act_ld(row + (xs > 0 ? -1 : 0)), rr = act_ld(row + (2 * xs + 4 < Wh ? 4 : 3));
       const float v[6] = {l, c.x, c.y, c.z, c.w, rr};
       float t0 = 0.f, t1 = 0.f;
 #pragma unroll
@@ -409,12 +416,13 @@ __global__ __launch_bounds__(CSN_BLOCK) void adjup2_pair_kernel(AdjUpArgs a) {
       a0 = fmaf(wy, t0, a0);
       a1 = fmaf(wy, t1, a1);
     }
-    float* op = a.out + pl * (int64_t)Hl * Wl + (int64_t)ys * Wl + xs;
-    *reinterpret_cast<float2*>(op) = make_float2(a0, a1);
+    TO* op = act_cast<TO>(a.out) + pl * (int64_t)Hl * Wl + (int64_t)ys * Wl + xs;
+    act_st2(op, make_float2(a0, a1));
   }
 }
 
 // adjoint of avg_pool2d(2, 2): dx[p] = 0.25 * dxp[p >> 1]
+template <typename AT>
 __global__ __launch_bounds__(CSN_BLOCK) void avgpool2_bwd_kernel(PoolBwdArgs a) {
   const int Hh = a.Hl * 2, Wh = a.Wl * 2;
   const int64_t tot = (int64_t)a.planes * Hh * Wh;
@@ -422,12 +430,13 @@ __global__ __launch_bounds__(CSN_BLOCK) void avgpool2_bwd_kernel(PoolBwdArgs a) 
     const int64_t pl = e / ((int64_t)Hh * Wh);
     const int r = (int)(e - pl * Hh * Wh);
     const int y = r / Wh, x = r - y * Wh;
-    a.dx[e] = 0.25f * a.t[pl * (int64_t)a.Hl * a.Wl + (y >> 1) * a.Wl + (x >> 1)];
+    act_st(act_cast<AT>(a.dx) + e, 0.25f * act_ld(act_cast<AT>(a.t) + pl * (int64_t)a.Hl * a.Wl + (y >> 1) * a.Wl + (x >> 1)));
   }
 }
 
 // backward of max_pool2d(f, f): the window's gradient goes to its FIRST maximum in row-major order (ATen's
 // `val > maxval` scan), added to dx (the own-resolution term was written before).  One thread per window.
+template <typename AT>
 __global__ __launch_bounds__(CSN_BLOCK) void maxpool_bwd_add_kernel(PoolBwdArgs a) {
   const int f = a.f, Hl = a.Hl, Wl = a.Wl;
   const int Wh = Wl * f;
@@ -437,23 +446,26 @@ __global__ __launch_bounds__(CSN_BLOCK) void maxpool_bwd_add_kernel(PoolBwdArgs 
     const int64_t pl = e / (Hl * Wl);
     const int r = (int)(e - pl * Hl * Wl);
     const int yl = r / Wl, xl = r - yl * Wl;
-    const float* xp = a.x + pl * hwh + (int64_t)(yl * f) * Wh + xl * f;
-    float best = xp[0];
+    const AT* xp = act_cast<AT>(a.x) + pl * hwh + (int64_t)(yl * f) * Wh + xl * f;
+    float best = act_ld(xp);
     int bi = 0;
     for (int dy = 0; dy < f; ++dy)
       for (int dx = 0; dx < f; ++dx) {
-        const float v = xp[dy * Wh + dx];
+        const float v = act_ld(xp + dy * Wh + dx);
         if (v > best || v != v) { best = v; bi = dy * Wh + dx; }
       }
-    a.dx[pl * hwh + (int64_t)(yl * f) * Wh + xl * f + bi] += a.t[e];
+    AT* dp = act_cast<AT>(a.dx) + pl * hwh + (int64_t)(yl * f) * Wh + xl * f + bi;
+    act_st(dp, act_ld(dp) + act_ld(act_cast<AT>(a.t) + e));
   }
 }
 
 // dst[0] = sum in[0..n)   (cls bias gradient): per-block fp64 partials, then one block in a fixed order
+template <typename AT>
 __global__ __launch_bounds__(CSN_BLOCK) void sum_partial_kernel(const float* in, int64_t n, double* partial) {
   CSN_DYN_SMEM(double, sm);
   double s = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * CSN_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CSN_BLOCK) s += (double)in[i];
+  for (int64_t i = (int64_t)blockIdx.x * CSN_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * CSN_BLOCK)
+    s += (double)act_ld(act_cast<AT>(in) + i);
   s = bn_block_sum(s, sm);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
@@ -508,10 +520,17 @@ __global__ __launch_bounds__(CSN_BLOCK) void adam_kernel(AdamArgs a) {
   }
 }
 
+// launch the float or the bfloat16 instantiation of a kernel template
+#define CSN_LAUNCH_AT(a16, kern, grid, block, smem, stream, ...)                                   \
+  do {                                                                                              \
+    if (a16) CSN_LAUNCH((kern<csn_bf16>), grid, block, smem, stream, __VA_ARGS__);                  \
+    else CSN_LAUNCH((kern<float>), grid, block, smem, stream, __VA_ARGS__);                         \
+  } while (0)
+
 int csn_launch_bn_stats(const BnStatsArgs& a0, void* stream) {
   BnStatsArgs a = a0;
   a.cpp = bn_cpp(a.S, a.HW);
-  CSN_LAUNCH(bn_stats_kernel, dim3(a.S * a.cpp, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
+  CSN_LAUNCH_AT(a.a16, bn_stats_kernel, dim3(a.S * a.cpp, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   return (int)hipGetLastError();
 }
 int csn_launch_bn_finalize(const BnFinalizeArgs& a0, void* stream) {
@@ -521,7 +540,7 @@ int csn_launch_bn_finalize(const BnFinalizeArgs& a0, void* stream) {
   return (int)hipGetLastError();
 }
 int csn_launch_bn_apply(const BnApplyArgs& a, void* stream) {
-  CSN_LAUNCH(bn_apply_gap_kernel, dim3(a.C, a.S), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
+  CSN_LAUNCH_AT(a.a16, bn_apply_gap_kernel, dim3(a.C, a.S), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   if (a.flop_w != 0.f) CSN_LAUNCH(bn_penalty_kernel, dim3(1), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   return (int)hipGetLastError();
 }
@@ -532,39 +551,55 @@ int csn_launch_bn_bwd(const BnBwdArgs& a0, void* stream) {
   BnBwdArgs a = a0;
   a.cpp = bn_cpp(a.S, a.HW);
   a.nslab = a.S * a.cpp;
-  CSN_LAUNCH(bn_bwd_reduce_kernel, dim3(a.nslab, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
+  CSN_LAUNCH_AT(a.a16, bn_bwd_reduce_kernel, dim3(a.nslab, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   CSN_LAUNCH(bn_bwd_finalize_kernel, dim3(a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
-  CSN_LAUNCH(bn_bwd_apply_kernel, dim3(a.C, a.S), dim3(CSN_BLOCK), 0, stream, a);
+  CSN_LAUNCH_AT(a.a16, bn_bwd_apply_kernel, dim3(a.C, a.S), dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
 }
 int csn_launch_dw_wgrad(const DwWgradArgs& a0, void* stream) {
   DwWgradArgs a = a0;
   a.cpp = bn_cpp(a.S, (int64_t)a.H * a.W);
   a.nslab = a.S * a.cpp;
-  CSN_LAUNCH(dw_wgrad_kernel, dim3(a.nslab, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
+  CSN_LAUNCH_AT(a.a16, dw_wgrad_kernel, dim3(a.nslab, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   CSN_LAUNCH(dw_wgrad_finalize_kernel, dim3(a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   return (int)hipGetLastError();
 }
+// in16 / out16: element type of the source / destination (the logits gradient arrives as float whatever the mode)
 int csn_launch_adjup(const AdjUpArgs& a, void* stream) {
-  if (a.f == 2 && (a.Wl & 1) == 0) {
-    CSN_LAUNCH(adjup2_pair_kernel, dim3(grid_for((int64_t)a.planes * a.Hl * (a.Wl >> 1))), dim3(CSN_BLOCK), 0, stream, a);
-    return (int)hipGetLastError();
+  const bool pair = a.f == 2 && (a.Wl & 1) == 0;
+  const dim3 grid(grid_for((int64_t)a.planes * a.Hl * (pair ? (a.Wl >> 1) : a.Wl))), block(CSN_BLOCK);
+  if (pair) {
+    if (a.in16 && a.out16) CSN_LAUNCH((adjup2_pair_kernel<csn_bf16, csn_bf16>), grid, block, 0, stream, a);
+    else if (a.out16) CSN_LAUNCH((adjup2_pair_kernel<float, csn_bf16>), grid, block, 0, stream, a);
+    else CSN_LAUNCH((adjup2_pair_kernel<float, float>), grid, block, 0, stream, a);
+  } else {
+    if (a.in16 && a.out16) CSN_LAUNCH((adjup_kernel<csn_bf16, csn_bf16>), grid, block, 0, stream, a);
+    else if (a.out16) CSN_LAUNCH((adjup_kernel<float, csn_bf16>), grid, block, 0, stream, a);
+    else CSN_LAUNCH((adjup_kernel<float, float>), grid, block, 0, stream, a);
   }
-  CSN_LAUNCH(adjup_kernel, dim3(grid_for((int64_t)a.planes * a.Hl * a.Wl)), dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
 }
 int csn_launch_avgpool2_bwd(const PoolBwdArgs& a, void* stream) {
-  CSN_LAUNCH(avgpool2_bwd_kernel, dim3(grid_for((int64_t)a.planes * a.Hl * a.Wl * 4)), dim3(CSN_BLOCK), 0, stream, a);
+  CSN_LAUNCH_AT(a.a16, avgpool2_bwd_kernel, dim3(grid_for((int64_t)a.planes * a.Hl * a.Wl * 4)), dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
 }
 int csn_launch_maxpool_bwd_add(const PoolBwdArgs& a, void* stream) {
-  CSN_LAUNCH(maxpool_bwd_add_kernel, dim3(grid_for((int64_t)a.planes * a.Hl * a.Wl)), dim3(CSN_BLOCK), 0, stream, a);
+  CSN_LAUNCH_AT(a.a16, maxpool_bwd_add_kernel, dim3(grid_for((int64_t)a.planes * a.Hl * a.Wl)), dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
 }
-int csn_launch_sum_to_grad(const float* in, int64_t n, float* dst, double* partial, void* stream) {
+int csn_launch_sum_to_grad(const float* in, int64_t n, float* dst, double* partial, int a16, void* stream) {
   const int nblk = grid_for(n) < 512 ? grid_for(n) : 512;
-  CSN_LAUNCH(sum_partial_kernel, dim3(nblk), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, in, n, partial);
+  CSN_LAUNCH_AT(a16, sum_partial_kernel, dim3(nblk), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, in, n, partial);
   CSN_LAUNCH(sum_final_kernel, dim3(1), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, partial, nblk, dst);
+  return (int)hipGetLastError();
+}
+// x (float, the caller's batch) -> the bf16 copy the train-mode kernels read
+__global__ __launch_bounds__(CSN_BLOCK) void to_bf16_kernel(const float* __restrict__ in, csn_bf16* __restrict__ out, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * CSN_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * CSN_BLOCK)
+    act_st4(out + 4 * i, act_ld4(in + 4 * i));
+}
+int csn_launch_to_bf16(const float* in, void* out, int64_t n, void* stream) {   // n: multiple of 4
+  CSN_LAUNCH(to_bf16_kernel, dim3(grid_for(n >> 2)), dim3(CSN_BLOCK), 0, stream, in, reinterpret_cast<csn_bf16*>(out), n >> 2);
   return (int)hipGetLastError();
 }
 int csn_launch_bce(const float* y, const float* t, float* dy, int64_t n, double* loss, void* stream) {

@@ -51,12 +51,13 @@ __device__ __forceinline__ void wg_mma(const float* dzp, const float* xp, int la
 
 // Not inlined on purpose: hipcc otherwise keeps the address arithmetic of every gather mode of all three call
 // sites live at once (390 VGPRs, one wave per SIMD); as a call the kernel needs 125.
+template <typename AT>
 __device__ __attribute__((noinline)) void wg_gather(PwPassP ps, int s, int c_lo, int c_hi, float* xrow, int rmax, int b,
                                                    int y, int x, int Hr, int Wr) {
-  pw_gather_slice<WG_P>(ps, s, c_lo, c_hi, xrow, rmax, b, y, x, Hr, Wr);
+  pw_gather_slice<AT, WG_P>(ps, s, c_lo, c_hi, xrow, rmax, b, y, x, Hr, Wr);
 }
 
-template <int NT>
+template <int NT, typename AT>
 __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_wgrad_kernel(WgArgs a_byval) {
   CSN_DYN_SMEM(float, lds);
   WgArgsP a = CSN_KERNARG(WgArgs, a_byval);
@@ -86,9 +87,9 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_wgrad_kernel(WgArgs a_byval
       const int y = pc / Wr, x = pc - y * Wr;
       __syncthreads();   // previous group's dz panel fully consumed
       {
-        const float* ap = a->a + (int64_t)b * a->a_ctot * HW + pc;
+        const AT* ap = act_cast<AT>(a->a) + (int64_t)b * a->a_ctot * HW + pc;
         for (int r = wave; r < nrows; r += 4) {
-          const float v = ap[(int64_t)r * HW];
+          const float v = act_ld(ap + (int64_t)r * HW);
           dzp[r * WG_P + lane] = valid ? v : 0.f;   // pixels past the plane contribute nothing
         }
       }
@@ -96,14 +97,14 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_wgrad_kernel(WgArgs a_byval
       if (active) {
         const int kend = min(kc + 16, cin);
         CSN_WAVE_SYNC();
-        if (kc < c1) wg_gather(ps, 0, kc, min(kend, c1), xp + lane, 16, b, y, x, Hr, Wr);
+        if (kc < c1) wg_gather<AT>(ps, 0, kc, min(kend, c1), xp + lane, 16, b, y, x, Hr, Wr);
         if (max(kc, c1) < min(kend, c2)) {
           const int r0 = max(kc, c1) - kc;
-          wg_gather(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
+          wg_gather<AT>(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
         }
         if (max(kc, c2) < min(kend, cin)) {
           const int r0 = max(kc, c2) - kc;
-          wg_gather(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
+          wg_gather<AT>(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
         }
         for (int k = max(cin, kc); k < kc + 16; ++k) xp[(k - kc) * WG_P + lane] = 0.f;
         CSN_WAVE_SYNC();
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_wgrad_kernel(WgArgs a_byval
 // Variant for few, small passes (K <= 64 gathered channels, <= 48 rows: every 1x1 unit of stages 0-3): each wave
 // owns its pixel groups AND all k chunks, with a private dz panel -- no block barrier in the loop, no idle wave
 // when K < 64.  The four waves' accumulators are added through LDS once, at the end.
-template <int NT, int NCH>
+template <int NT, int NCH, typename AT>
 __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_wgrad_wave_kernel(WgArgs a_byval) {
   CSN_DYN_SMEM(float, lds);
   WgArgsP a = CSN_KERNARG(WgArgs, a_byval);
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_wgrad_wave_kernel(WgArgs a_
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[c][t][i] = 0.f;
-  const unsigned cs4 = (unsigned)HW * 4u;
+  const unsigned cs4 = (unsigned)HW * (unsigned)sizeof(AT);
   // block-uniform trip count (the CPU emulation maps the wave hand-offs to block barriers): a wave without a group
   // left walks the last group with an all-zero dz panel
   for (int g0 = blockIdx.x * 4; g0 < a->ngroups; g0 += a->nblk * 4) {
@@ -156,8 +157,8 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_wgrad_wave_kernel(WgArgs a_
     const int y = pc / Wr, x = pc - y * Wr;
     CSN_WAVE_SYNC();   // previous group's panels fully consumed
     for (int r0 = 0; r0 < nrows; r0 += 16) {
-      const csn_buf rb = csn_make_buf(a->a + ((int64_t)b * a->a_ctot + r0) * HW);
-      pw_batch_own<16, WG_P>(rb, (unsigned)pc * 4u, cs4, 0, min(16, nrows - r0), 16, dzp + r0 * WG_P + lane);
+      const csn_buf rb = csn_make_buf(act_cast<AT>(a->a) + ((int64_t)b * a->a_ctot + r0) * HW);
+      pw_batch_own<AT, 16, WG_P>(rb, (unsigned)pc * (unsigned)sizeof(AT), cs4, 0, min(16, nrows - r0), 16, dzp + r0 * WG_P + lane);
     }
     if (!valid)   // pixels past the plane contribute nothing
       for (int r = 0; r < nrows; ++r) dzp[r * WG_P + lane] = 0.f;
@@ -167,14 +168,14 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_wgrad_wave_kernel(WgArgs a_
       if (kc < k16) {
         const int kend = min(kc + 16, cin);
         CSN_WAVE_SYNC();
-        if (kc < c1) wg_gather(ps, 0, kc, min(kend, c1), xp + lane, 16, b, y, x, Hr, Wr);
+        if (kc < c1) wg_gather<AT>(ps, 0, kc, min(kend, c1), xp + lane, 16, b, y, x, Hr, Wr);
         if (max(kc, c1) < min(kend, c2)) {
           const int r0 = max(kc, c1) - kc;
-          wg_gather(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
+          wg_gather<AT>(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
         }
         if (max(kc, c2) < min(kend, cin)) {
           const int r0 = max(kc, c2) - kc;
-          wg_gather(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
+          wg_gather<AT>(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
         }
         for (int k = max(cin, kc); k < kc + 16; ++k) xp[(k - kc) * WG_P + lane] = 0.f;
         CSN_WAVE_SYNC();
@@ -243,28 +244,33 @@ int csn_wgrad_blocks(int rows16, int k16, int ngroups) {
   return units < WG_MAX_BLOCKS ? units : WG_MAX_BLOCKS;
 }
 
-int csn_launch_wgrad(const WgArgs& a, void* stream) {
-  if (a.rows16 > 16 * WG_MAX_NT) return -1;
+template <typename AT>
+static int launch_wgrad_t(const WgArgs& a, void* stream) {
   if (wgrad_wave_fits(a)) {
     const int nt = a.rows16 >> 4, nch = a.k16 <= 32 ? 2 : 4;
     const size_t wl = (size_t)4 * (a.rows16 + 16) * WG_P * sizeof(float);
     const dim3 grid(a.nblk), block(CSN_BLOCK);
-    if (nt == 1 && nch == 2) CSN_LAUNCH((goct_wgrad_wave_kernel<1, 2>), grid, block, wl, stream, a);
-    else if (nt == 1) CSN_LAUNCH((goct_wgrad_wave_kernel<1, 4>), grid, block, wl, stream, a);
-    else if (nt == 2 && nch == 2) CSN_LAUNCH((goct_wgrad_wave_kernel<2, 2>), grid, block, wl, stream, a);
-    else if (nt == 2) CSN_LAUNCH((goct_wgrad_wave_kernel<2, 4>), grid, block, wl, stream, a);
-    else CSN_LAUNCH((goct_wgrad_wave_kernel<3, 4>), grid, block, wl, stream, a);
+    if (nt == 1 && nch == 2) CSN_LAUNCH((goct_wgrad_wave_kernel<1, 2, AT>), grid, block, wl, stream, a);
+    else if (nt == 1) CSN_LAUNCH((goct_wgrad_wave_kernel<1, 4, AT>), grid, block, wl, stream, a);
+    else if (nt == 2 && nch == 2) CSN_LAUNCH((goct_wgrad_wave_kernel<2, 2, AT>), grid, block, wl, stream, a);
+    else if (nt == 2) CSN_LAUNCH((goct_wgrad_wave_kernel<2, 4, AT>), grid, block, wl, stream, a);
+    else CSN_LAUNCH((goct_wgrad_wave_kernel<3, 4, AT>), grid, block, wl, stream, a);
     return (int)hipGetLastError();
   }
   const size_t lds = ((size_t)a.rows16 * WG_P + 4 * 16 * WG_P) * sizeof(float);
   switch (a.rows16 >> 4) {
-    case 1: CSN_LAUNCH(goct_wgrad_kernel<1>, dim3(a.nblk), dim3(CSN_BLOCK), lds, stream, a); break;
-    case 2: CSN_LAUNCH(goct_wgrad_kernel<2>, dim3(a.nblk), dim3(CSN_BLOCK), lds, stream, a); break;
-    case 3: CSN_LAUNCH(goct_wgrad_kernel<3>, dim3(a.nblk), dim3(CSN_BLOCK), lds, stream, a); break;
-    case 4: CSN_LAUNCH(goct_wgrad_kernel<4>, dim3(a.nblk), dim3(CSN_BLOCK), lds, stream, a); break;
-    default: CSN_LAUNCH(goct_wgrad_kernel<5>, dim3(a.nblk), dim3(CSN_BLOCK), lds, stream, a); break;
+    case 1: CSN_LAUNCH((goct_wgrad_kernel<1, AT>), dim3(a.nblk), dim3(CSN_BLOCK), lds, stream, a); break;
+    case 2: CSN_LAUNCH((goct_wgrad_kernel<2, AT>), dim3(a.nblk), dim3(CSN_BLOCK), lds, stream, a); break;
+    case 3: CSN_LAUNCH((goct_wgrad_kernel<3, AT>), dim3(a.nblk), dim3(CSN_BLOCK), lds, stream, a); break;
+    case 4: CSN_LAUNCH((goct_wgrad_kernel<4, AT>), dim3(a.nblk), dim3(CSN_BLOCK), lds, stream, a); break;
+    default: CSN_LAUNCH((goct_wgrad_kernel<5, AT>), dim3(a.nblk), dim3(CSN_BLOCK), lds, stream, a); break;
   }
   return (int)hipGetLastError();
+}
+
+int csn_launch_wgrad(const WgArgs& a, void* stream) {
+  if (a.rows16 > 16 * WG_MAX_NT) return -1;
+  return a.a16 ? launch_wgrad_t<csn_bf16>(a, stream) : launch_wgrad_t<float>(a, stream);
 }
 
 int csn_launch_wgrad_reduce(const WgReduceArgs& a, void* stream) {

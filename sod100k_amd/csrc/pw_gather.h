@@ -28,33 +28,33 @@ typedef const CSN_CONST_AS PwPass* PwPassP;
 // offset.  Every batch issues ALL its loads before the first use (fixed trip count, channel index clamped
 // instead of predicated: a predicated load would be waited for at the join), so a lane has 16-32 loads
 // in flight; rows written past the slice are overwritten by the next slice / the zero padding.
-template <int NB, int XP>
+template <typename AT, int NB, int XP>
 __device__ __forceinline__ void pw_batch_own(csn_buf rb, unsigned lo, unsigned cs4, int k0, int n, int rmax,
                                              float* xrow) {
   float v[NB];
 #pragma unroll
-  for (int j = 0; j < NB; ++j) v[j] = csn_ld1(rb, lo, (unsigned)min(k0 + j, n - 1) * cs4);
+  for (int j = 0; j < NB; ++j) v[j] = csn_bufacc<AT>::ld1(rb, lo, (unsigned)min(k0 + j, n - 1) * cs4);
 #pragma unroll
   for (int j = 0; j < NB; ++j)
     if (k0 + j < rmax) xrow[(k0 + j) * XP] = v[j];
 }
 
-template <int NB, int XP>
+template <typename AT, int NB, int XP>
 __device__ __forceinline__ void pw_batch_pool2(csn_buf rb, unsigned lo, unsigned cs4, unsigned ws4, int k0, int n,
                                                int rmax, float* xrow) {
   float2 a0[NB], a1[NB];
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const unsigned so = (unsigned)min(k0 + j, n - 1) * cs4;
-    a0[j] = csn_ld2(rb, lo, so);
-    a1[j] = csn_ld2(rb, lo, so + ws4);
+    a0[j] = csn_bufacc<AT>::ld2(rb, lo, so);
+    a1[j] = csn_bufacc<AT>::ld2(rb, lo, so + ws4);
   }
 #pragma unroll
   for (int j = 0; j < NB; ++j)
     if (k0 + j < rmax) xrow[(k0 + j) * XP] = fmaxf(fmaxf(a0[j].x, a0[j].y), fmaxf(a1[j].x, a1[j].y));
 }
 
-template <int NB, int XP>
+template <typename AT, int NB, int XP>
 __device__ __forceinline__ void pw_batch_pool4(csn_buf rb, unsigned lo, unsigned cs4, unsigned ws4, int k0, int n,
                                                int rmax, float* xrow) {
   float4 q[NB][4];
@@ -62,7 +62,7 @@ __device__ __forceinline__ void pw_batch_pool4(csn_buf rb, unsigned lo, unsigned
   for (int j = 0; j < NB; ++j) {
     const unsigned so = (unsigned)min(k0 + j, n - 1) * cs4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) q[j][r] = csn_ld4(rb, lo, so + r * ws4);
+    for (int r = 0; r < 4; ++r) q[j][r] = csn_bufacc<AT>::ld4(rb, lo, so + r * ws4);
   }
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
@@ -73,7 +73,7 @@ __device__ __forceinline__ void pw_batch_pool4(csn_buf rb, unsigned lo, unsigned
   }
 }
 
-template <int NB, int XP>
+template <typename AT, int NB, int XP>
 __device__ __forceinline__ void pw_batch_up(csn_buf rb, unsigned o00, unsigned o01, unsigned o10, unsigned o11,
                                             float w00, float w01, float w10, float w11, unsigned cs4, int k0, int n,
                                             int rmax, float* xrow) {
@@ -81,10 +81,10 @@ __device__ __forceinline__ void pw_batch_up(csn_buf rb, unsigned o00, unsigned o
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const unsigned so = (unsigned)min(k0 + j, n - 1) * cs4;
-    t0[j] = csn_ld1(rb, o00, so);
-    t1[j] = csn_ld1(rb, o01, so);
-    t2[j] = csn_ld1(rb, o10, so);
-    t3[j] = csn_ld1(rb, o11, so);
+    t0[j] = csn_bufacc<AT>::ld1(rb, o00, so);
+    t1[j] = csn_bufacc<AT>::ld1(rb, o01, so);
+    t2[j] = csn_bufacc<AT>::ld1(rb, o10, so);
+    t3[j] = csn_bufacc<AT>::ld1(rb, o11, so);
   }
 #pragma unroll
   for (int j = 0; j < NB; ++j)
@@ -93,7 +93,7 @@ __device__ __forceinline__ void pw_batch_up(csn_buf rb, unsigned o00, unsigned o
 
 // 3x3 taps of an own-resolution slice: gathered entry kk = 9*ch + t, t = 3*(dy+1) + (dx+1).  `vm` has
 // bit t set when tap t of this lane's pixel lies inside the image (zero padding otherwise).
-template <int NB, int XP>
+template <typename AT, int NB, int XP>
 __device__ __forceinline__ void pw_batch_taps(csn_buf rb, unsigned lo, unsigned cs4, int Wr, int dil, unsigned vm,
                                               int k_lo, int k0, int n, int rmax, float* xrow) {
   float v[NB];
@@ -103,7 +103,7 @@ __device__ __forceinline__ void pw_batch_taps(csn_buf rb, unsigned lo, unsigned 
     const int kk = k_lo + min(k0 + j, n - 1);
     const int ch = kk / 9, t = kk - 9 * ch;
     const int dy = t / 3 - 1, dx = t - 3 * (t / 3) - 1;
-    v[j] = csn_ld1(rb, lo + (unsigned)((dy * Wr + dx) * dil * 4), (unsigned)ch * cs4);
+    v[j] = csn_bufacc<AT>::ld1(rb, lo + (unsigned)((dy * Wr + dx) * dil * (int)sizeof(AT)), (unsigned)ch * cs4);
     m[j] = (vm >> t) & 1u;
   }
 #pragma unroll
@@ -112,7 +112,7 @@ __device__ __forceinline__ void pw_batch_taps(csn_buf rb, unsigned lo, unsigned 
 }
 
 // 3x3 taps of a 2x2-max-pooled slice (source at twice the resolution).
-template <int NB, int XP>
+template <typename AT, int NB, int XP>
 __device__ __forceinline__ void pw_batch_pool2_taps(csn_buf rb, unsigned lo, unsigned cs4, unsigned ws4, unsigned vm,
                                                     int k_lo, int k0, int n, int rmax, float* xrow) {
   float2 a0[NB], a1[NB];
@@ -122,9 +122,9 @@ __device__ __forceinline__ void pw_batch_pool2_taps(csn_buf rb, unsigned lo, uns
     const int kk = k_lo + min(k0 + j, n - 1);
     const int ch = kk / 9, t = kk - 9 * ch;
     const int dy = t / 3 - 1, dx = t - 3 * (t / 3) - 1;
-    const unsigned vo = lo + (unsigned)(2 * dy) * ws4 + (unsigned)(8 * dx);
-    a0[j] = csn_ld2(rb, vo, (unsigned)ch * cs4);
-    a1[j] = csn_ld2(rb, vo + ws4, (unsigned)ch * cs4);
+    const unsigned vo = lo + (unsigned)(2 * dy) * ws4 + (unsigned)(2 * (int)sizeof(AT) * dx);
+    a0[j] = csn_bufacc<AT>::ld2(rb, vo, (unsigned)ch * cs4);
+    a1[j] = csn_bufacc<AT>::ld2(rb, vo + ws4, (unsigned)ch * cs4);
     m[j] = (vm >> t) & 1u;
   }
 #pragma unroll
@@ -135,9 +135,10 @@ __device__ __forceinline__ void pw_batch_pool2_taps(csn_buf rb, unsigned lo, uns
 
 // 3x3 taps of a zero-stuffed slice (source at half the resolution): the adjoint of a stride-2 3x3 convolution.
 // Tap t of output pixel (y, x) reads source ((y + dy) / 2, (x + dx) / 2) when both coordinates are even and inside.
-template <int NB, int XP>
+template <typename AT, int NB, int XP>
 __device__ __forceinline__ void pw_batch_taps_ups2(csn_buf rb, int y, int x, int Hr, int Wr, int Ws, unsigned cs4,
                                                    int k_lo, int k0, int n, int rmax, float* xrow) {
+  constexpr unsigned E = (unsigned)sizeof(AT);
   float v[NB];
   bool m[NB];
 #pragma unroll
@@ -146,7 +147,7 @@ __device__ __forceinline__ void pw_batch_taps_ups2(csn_buf rb, int y, int x, int
     const int ch = kk / 9, t = kk - 9 * ch;
     const int h = y + t / 3 - 1, w = x + (t - 3 * (t / 3)) - 1;
     m[j] = h >= 0 && w >= 0 && h < Hr && w < Wr && ((h | w) & 1) == 0;
-    v[j] = csn_ld1(rb, m[j] ? (unsigned)((h >> 1) * Ws + (w >> 1)) * 4u : 0u, (unsigned)ch * cs4);
+    v[j] = csn_bufacc<AT>::ld1(rb, m[j] ? (unsigned)((h >> 1) * Ws + (w >> 1)) * E : 0u, (unsigned)ch * cs4);
   }
 #pragma unroll
   for (int j = 0; j < NB; ++j)
@@ -163,61 +164,62 @@ __device__ __forceinline__ unsigned pw_tap_mask(int y, int x, int Hr, int Wr, in
   return vm;
 }
 
-template <int XP>
+template <typename AT, int XP>
 __device__ __forceinline__ void pw_gather_slice(PwPassP ps, int s, int c_lo, int c_hi, float* xrow, int rmax, int b,
                                                 int y, int x, int Hr, int Wr) {
   const int mode = ps->src[s].mode;
   const int n = c_hi - c_lo;   // 1..16
+  constexpr unsigned E = (unsigned)sizeof(AT);   // bytes per element
   if (mode == PW_OWN) {
     const unsigned cs = (unsigned)(Hr * Wr);
-    const csn_buf rb = csn_make_buf(ps->src[s].ptr + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
-    const unsigned lo = (unsigned)(y * Wr + x) * 4u;
-    if (n <= 8) pw_batch_own<8, XP>(rb, lo, cs * 4u, 0, n, rmax, xrow);
-    else for (int k0 = 0; k0 < n; k0 += 16) pw_batch_own<16, XP>(rb, lo, cs * 4u, k0, n, rmax, xrow);
+    const csn_buf rb = csn_make_buf(act_cast<AT>(ps->src[s].ptr) + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
+    const unsigned lo = (unsigned)(y * Wr + x) * E;
+    if (n <= 8) pw_batch_own<AT, 8, XP>(rb, lo, cs * E, 0, n, rmax, xrow);
+    else for (int k0 = 0; k0 < n; k0 += 16) pw_batch_own<AT, 16, XP>(rb, lo, cs * E, k0, n, rmax, xrow);
   } else if (mode == PW_POOL2) {
     const unsigned Ws = (unsigned)Wr * 2u;
     const unsigned cs = (unsigned)(Hr * 2) * Ws;
-    const csn_buf rb = csn_make_buf(ps->src[s].ptr + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
-    const unsigned lo = ((unsigned)(2 * y) * Ws + 2u * x) * 4u;
-    for (int k0 = 0; k0 < n; k0 += 8) pw_batch_pool2<8, XP>(rb, lo, cs * 4u, Ws * 4u, k0, n, rmax, xrow);
+    const csn_buf rb = csn_make_buf(act_cast<AT>(ps->src[s].ptr) + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
+    const unsigned lo = ((unsigned)(2 * y) * Ws + 2u * x) * E;
+    for (int k0 = 0; k0 < n; k0 += 8) pw_batch_pool2<AT, 8, XP>(rb, lo, cs * E, Ws * E, k0, n, rmax, xrow);
   } else if (mode == PW_POOL4) {
     const unsigned Ws = (unsigned)Wr * 4u;
     const unsigned cs = (unsigned)(Hr * 4) * Ws;
-    const csn_buf rb = csn_make_buf(ps->src[s].ptr + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
-    const unsigned lo = ((unsigned)(4 * y) * Ws + 4u * x) * 4u;
-    for (int k0 = 0; k0 < n; k0 += 2) pw_batch_pool4<2, XP>(rb, lo, cs * 4u, Ws * 4u, k0, n, rmax, xrow);
+    const csn_buf rb = csn_make_buf(act_cast<AT>(ps->src[s].ptr) + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
+    const unsigned lo = ((unsigned)(4 * y) * Ws + 4u * x) * E;
+    for (int k0 = 0; k0 < n; k0 += 2) pw_batch_pool4<AT, 2, XP>(rb, lo, cs * E, Ws * E, k0, n, rmax, xrow);
   } else if (mode == PW_TAPS) {
     const unsigned cs = (unsigned)(Hr * Wr);
     const int dil = ps->src[s].dil;
-    const csn_buf rb = csn_make_buf_n(ps->src[s].ptr + (int64_t)b * ps->src[s].Ctot * cs,
-                                      (unsigned)ps->src[s].Ctot * cs * 4u);
-    const unsigned lo = (unsigned)(y * Wr + x) * 4u;
+    const csn_buf rb = csn_make_buf_n(act_cast<AT>(ps->src[s].ptr) + (int64_t)b * ps->src[s].Ctot * cs,
+                                      (unsigned)ps->src[s].Ctot * cs * E);
+    const unsigned lo = (unsigned)(y * Wr + x) * E;
     const unsigned vm = pw_tap_mask(y, x, Hr, Wr, dil);
-    for (int k0 = 0; k0 < n; k0 += 16) pw_batch_taps<16, XP>(rb, lo, cs * 4u, Wr, dil, vm, c_lo, k0, n, rmax, xrow);
+    for (int k0 = 0; k0 < n; k0 += 16) pw_batch_taps<AT, 16, XP>(rb, lo, cs * E, Wr, dil, vm, c_lo, k0, n, rmax, xrow);
   } else if (mode == PW_POOL2_TAPS) {
     const unsigned Ws = (unsigned)Wr * 2u;
     const unsigned cs = (unsigned)(Hr * 2) * Ws;
-    const csn_buf rb = csn_make_buf_n(ps->src[s].ptr + (int64_t)b * ps->src[s].Ctot * cs,
-                                      (unsigned)ps->src[s].Ctot * cs * 4u);
-    const unsigned lo = ((unsigned)(2 * y) * Ws + 2u * x) * 4u;
+    const csn_buf rb = csn_make_buf_n(act_cast<AT>(ps->src[s].ptr) + (int64_t)b * ps->src[s].Ctot * cs,
+                                      (unsigned)ps->src[s].Ctot * cs * E);
+    const unsigned lo = ((unsigned)(2 * y) * Ws + 2u * x) * E;
     const unsigned vm = pw_tap_mask(y, x, Hr, Wr, 1);
-    for (int k0 = 0; k0 < n; k0 += 8) pw_batch_pool2_taps<8, XP>(rb, lo, cs * 4u, Ws * 4u, vm, c_lo, k0, n, rmax, xrow);
+    for (int k0 = 0; k0 < n; k0 += 8) pw_batch_pool2_taps<AT, 8, XP>(rb, lo, cs * E, Ws * E, vm, c_lo, k0, n, rmax, xrow);
   } else if (mode == PW_TAPS_S2) {   // Conv2dX100 with stride 2 (csnet.py:751-754): taps (2y + dy, 2x + dx), zero padding
     const unsigned Ws = (unsigned)Wr * 2u;
     const unsigned cs = (unsigned)(Hr * 2) * Ws;
-    const csn_buf rb = csn_make_buf_n(ps->src[s].ptr + (int64_t)b * ps->src[s].Ctot * cs,
-                                      (unsigned)ps->src[s].Ctot * cs * 4u);
-    const unsigned lo = ((unsigned)(2 * y) * Ws + 2u * x) * 4u;
+    const csn_buf rb = csn_make_buf_n(act_cast<AT>(ps->src[s].ptr) + (int64_t)b * ps->src[s].Ctot * cs,
+                                      (unsigned)ps->src[s].Ctot * cs * E);
+    const unsigned lo = ((unsigned)(2 * y) * Ws + 2u * x) * E;
     unsigned vm = 0x1ffu;            // only the top row / left column can fall outside
     if (y == 0) vm &= ~0x007u;
     if (x == 0) vm &= ~0x049u;
-    for (int k0 = 0; k0 < n; k0 += 16) pw_batch_taps<16, XP>(rb, lo, cs * 4u, (int)Ws, 1, vm, c_lo, k0, n, rmax, xrow);
+    for (int k0 = 0; k0 < n; k0 += 16) pw_batch_taps<AT, 16, XP>(rb, lo, cs * E, (int)Ws, 1, vm, c_lo, k0, n, rmax, xrow);
   } else if (mode == PW_TAPS_UPS2) {
     const int Hs = Hr >> 1, Ws = Wr >> 1;
     const unsigned cs = (unsigned)(Hs * Ws);
-    const csn_buf rb = csn_make_buf_n(ps->src[s].ptr + (int64_t)b * ps->src[s].Ctot * cs,
-                                      (unsigned)ps->src[s].Ctot * cs * 4u);
-    for (int k0 = 0; k0 < n; k0 += 16) pw_batch_taps_ups2<16, XP>(rb, y, x, Hr, Wr, Ws, cs * 4u, c_lo, k0, n, rmax, xrow);
+    const csn_buf rb = csn_make_buf_n(act_cast<AT>(ps->src[s].ptr) + (int64_t)b * ps->src[s].Ctot * cs,
+                                      (unsigned)ps->src[s].Ctot * cs * E);
+    for (int k0 = 0; k0 < n; k0 += 16) pw_batch_taps_ups2<AT, 16, XP>(rb, y, x, Hr, Wr, Ws, cs * E, c_lo, k0, n, rmax, xrow);
   } else {  // bilinear from a 2x / 4x coarser branch, align_corners=False
     const int sh = mode == PW_UP2 ? 1 : 2;
     const int Hs = Hr >> sh, Ws = Wr >> sh;
@@ -226,12 +228,12 @@ __device__ __forceinline__ void pw_gather_slice(PwPassP ps, int s, int c_lo, int
     csn_bilin(y, mode == PW_UP2 ? 0.5f : 0.25f, Hs, y0, y1, ly);
     csn_bilin(x, mode == PW_UP2 ? 0.5f : 0.25f, Ws, x0, x1, lx);
     const unsigned cs = (unsigned)(Hs * Ws);
-    const csn_buf rb = csn_make_buf(ps->src[s].ptr + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
-    const unsigned o00 = (unsigned)(y0 * Ws + x0) * 4u, o01 = (unsigned)(y0 * Ws + x1) * 4u,
-                   o10 = (unsigned)(y1 * Ws + x0) * 4u, o11 = (unsigned)(y1 * Ws + x1) * 4u;
+    const csn_buf rb = csn_make_buf(act_cast<AT>(ps->src[s].ptr) + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
+    const unsigned o00 = (unsigned)(y0 * Ws + x0) * E, o01 = (unsigned)(y0 * Ws + x1) * E,
+                   o10 = (unsigned)(y1 * Ws + x0) * E, o11 = (unsigned)(y1 * Ws + x1) * E;
     const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
     for (int k0 = 0; k0 < n; k0 += 8)
-      pw_batch_up<8, XP>(rb, o00, o01, o10, o11, w00, w01, w10, w11, cs * 4u, k0, n, rmax, xrow);
+      pw_batch_up<AT, 8, XP>(rb, o00, o01, o10, o11, w00, w01, w10, w11, cs * E, k0, n, rmax, xrow);
   }
 }
 

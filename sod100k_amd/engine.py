@@ -202,6 +202,37 @@ class Engine:
                                                                          info.width)
 
 
+    # ---- train-step probes (debug / parity): typed views of the workspace ----
+    def _ws_tensor(self, off: int, act_id: int, bf16: bool) -> torch.Tensor:
+        info = N.ActInfo()
+        N.check(self.lib, self.lib.csn_plan_act_info(self.plan, act_id, C.byref(info)), "csn_plan_act_info")
+        shape = (info.batch, info.channels, info.height, info.width)
+        n = info.batch * info.channels * info.height * info.width
+        if bf16:
+            return self.workspace[off:off + 2 * n].view(torch.bfloat16).view(shape)
+        return self.workspace[off:off + 4 * n].view(torch.float32).view(shape)
+
+    def train_probe(self, act_id: int, what: str) -> torch.Tensor:
+        """float32 copy of a train-step tensor of activation `act_id`: "act", "z" (raw conv output after the forward, dz after
+        the backward), "grad0" / "grad1" (gradient contributed by the first / second consumer)."""
+        ti = N.TrainActInfo()
+        N.check(self.lib, self.lib.csn_plan_train_act_info(self.plan, act_id, C.byref(ti)), "csn_plan_train_act_info")
+        bf16 = bool(ti.bf16)
+        off = {"act": ti.x16_offset_bytes if (act_id == 0 and bf16) else ti.act_offset_bytes, "z": ti.z_offset_bytes,
+               "grad0": ti.grad_offset_bytes[0], "grad1": ti.grad_offset_bytes[1]}[what]
+        if off < 0:
+            raise ValueError(f"activation {act_id} has no '{what}' buffer")
+        return self._ws_tensor(off, act_id, bf16).to(torch.float32).clone()
+
+    def n_consumers(self, act_id: int) -> int:
+        ti = N.TrainActInfo()
+        N.check(self.lib, self.lib.csn_plan_train_act_info(self.plan, act_id, C.byref(ti)), "csn_plan_train_act_info")
+        return int(ti.n_consumers)
+
+    def unit_in_slot(self, unit: int, branch: int) -> int:
+        return int(self.lib.csn_plan_unit_in_slot(self.plan, unit, branch))
+
+
 def _stream_of(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
 

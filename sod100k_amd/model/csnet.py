@@ -467,7 +467,8 @@ class CSNet(nn.Module):
                 raise RuntimeError("sod100k_amd.CSNet runs on ROCm devices only (hand-written HIP kernels); "
                                    "move the model and the input to the GPU (`model.cuda()`, `x.cuda()`).")
             lib = N.load()
-        key = (tuple(x.shape), x.device, bool(train))
+        bf16 = bool(train) and getattr(self, "_train_act_dtype", "fp32") == "bf16"
+        key = (tuple(x.shape), x.device, bool(train), bf16)
         eng = self._engines.get(key)
         if eng is None:
             B, _, H, W = x.shape
@@ -476,8 +477,19 @@ class CSNet(nn.Module):
             units, acts, names = self.describe(arena.offsets)
             eng = Engine(lib, units, acts, B, H, W, x.device, sub_batch=0 if train else self._sub_batch,
                          unit_names=names, train=train)
+            if bf16:
+                eng.set_option(N.OPT_TRAIN_BF16, 1)
             self._engines[key] = eng
         return eng
+
+    def set_train_act_dtype(self, dtype: str = "fp32"):
+        """Storage type of the train step's activations and activation gradients in HBM: "fp32" (default; the reference's
+        arithmetic) or "bf16" (BASELINE config 3: bfloat16 storage, fp32 arithmetic / statistics / parameters / optimizer).
+        Eval-mode forwards are always fp32."""
+        if dtype not in ("fp32", "bf16"):
+            raise ValueError("train activation dtype must be 'fp32' or 'bf16'")
+        self._train_act_dtype = dtype
+        return self
 
     def forward(self, x):
         if x.dim() != 4 or x.shape[1] != 3 or x.dtype != torch.float32:

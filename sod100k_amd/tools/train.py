@@ -45,8 +45,10 @@ class FusedTrainer:
     """One train step = forward(train) + BCE + backward + [gradient all-reduce] + Adam, all on flat device buffers."""
 
     def __init__(self, model, lr=1e-4, weight_decay=5e-3, betas=(0.9, 0.99), eps=1e-8, flops_weight=0.0,
-                 batchsize=None, lib=None):
+                 batchsize=None, lib=None, act_dtype=None):
         self.model = model
+        if act_dtype is not None:          # "bf16": BASELINE config 3 (bfloat16 activation storage, fp32 everything else)
+            model.set_train_act_dtype(act_dtype)
         self.lr, self.betas, self.eps = float(lr), betas, float(eps)
         self.flops_weight = float(flops_weight)
         self.batchsize = batchsize

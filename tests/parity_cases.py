@@ -9,6 +9,7 @@ import os
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 from oracle import csnet_oracle as O, inputs as I
 from sod100k_amd import _native as N
@@ -542,3 +543,193 @@ def check_train_step_well_conditioned(lib, device, manifest, B=2, size=64):
     assert not bad, f"{len(bad)} of {len(errs)} gradients further from fp64 than twice the fp32 oracle: {list(bad.items())[:5]}"
     assert rel <= 1.5 * rel32 + 1e-4, (rel, rel32)
     return rel, rel32
+
+
+def check_train_step_bf16(lib, device, manifest, B=2, size=32, state="well"):
+    """BASELINE config 3's dtype: one train step with bfloat16 activation storage (CSN_OPT_TRAIN_BF16).  Judged against
+    (a) the oracle with the SAME storage points rounded through bf16 (oracle.bf16_activations) and (b) the plain fp32
+    oracle, with the emulated-bf16 oracle's own distance from fp32 as the yardstick: the kernels may not be further from
+    the fp32 step than twice what bf16 storage itself costs.  SURVEY 8(c): loss / gradient norms at ~1e-2 relative."""
+    sd = well_conditioned_state(manifest) if state == "well" else O.load_weights(manifest)
+    m = M.build_model(predefine=manifest)
+    m.load_state_dict(sd)
+    m = m.to(device)
+    m._lib = lib if device.type == "cpu" else None
+    m.set_train_act_dtype("bf16")
+    m.train(); m.set_batchsize(B); m.clear_flops(); m.flops_hook(1.0)
+    x = torch.from_numpy(I.randn_batch(41, B, size, size))
+    t = torch.from_numpy(I.binary_target(42, B, size, size))
+    xd, td = x.to(device), t.to(device)
+    y, pen = m._train_forward_raw(xd)
+    loss, dy = bce_and_grad(m._lib or N.load(), y, td)
+    flat = m._train_backward_raw(xd, dy, 3.0 / B)
+    cfg = O.load_layer_config_json(manifest)
+    kw = dict(expandflop=1.0, flops_weight=3.0, batchsize=B, lr=0.0, wd=0.0)
+    r32 = O.train_step(cfg, {k: v.clone() for k, v in sd.items()}, x, t, **kw)
+    sd16 = {k: v.clone() for k, v in sd.items()}
+    r16 = O.train_step(cfg, sd16, x, t, act_dtype="bf16", **kw)
+    # logits: bf16 storage through ~60 layers
+    ref_out = float((r16["out"] - r32["out"]).abs().max())
+    got_out = float((y.cpu() - r32["out"]).abs().max())
+    assert got_out <= 2.0 * ref_out + 1e-3, (got_out, ref_out)
+    assert float((y.cpu() - r16["out"]).abs().max()) <= 2.0 * ref_out + 1e-3
+    assert abs(float(loss) - r16["loss_bce"]) <= 5e-3 * max(1.0, abs(r16["loss_bce"])), (float(loss), r16["loss_bce"])
+    assert abs(float(loss) - r32["loss_bce"]) <= 1e-2 * max(1.0, abs(r32["loss_bce"])), (float(loss), r32["loss_bce"])
+    assert abs(float(pen) / B - r16["penalty"]) <= 5e-3 * max(1.0, abs(r16["penalty"])), (float(pen) / B, r16["penalty"])
+    assert abs(float(pen) / B - r32["penalty"]) <= 1e-2 * max(1.0, abs(r32["penalty"])), (float(pen) / B, r32["penalty"])
+    # BN running statistics (taken from the stored bf16 z)
+    got = m.state_dict()
+    worst_rs = 0.0
+    for k, v in sd16.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            worst_rs = max(worst_rs, ((got[k].cpu() - v).abs() / (1 + v.abs())).max().item())
+    assert worst_rs <= 2e-2, worst_rs     # deep layers: 8 samples per channel at this size, each rounded to 8 bits
+    # Gradients are NOT compared at whole-step level: through the 60 batch-normalised layers a storage rounding is amplified
+    # by ~5e4 (the fp32 oracle is 3e-3 away from fp64; two bf16 runs that differ in one rounding point are O(1) apart in the
+    # early stages).  check_train_units_local judges every unit's backward on the device's own upstream gradients instead.
+    gn = float(flat.double().norm())
+    assert np.isfinite(gn) and gn > 0
+    return dict(running_stats=worst_rs, logits=got_out, logits_ref=ref_out, loss=float(loss), loss32=r32["loss_bce"],
+                loss16=r16["loss_bce"], grad_norm=gn)
+
+
+# ---------------------------------------------------------------------------------------------------
+# unit-local checks of the train step: every unit's forward and backward judged on the tensors the device itself
+# produced for its inputs / upstream gradients, so that errors do not travel through the 60 batch-normalised layers
+# (whole-step comparisons amplify a storage rounding by ~5e4 -- the fp32 oracle is 3e-3 from fp64, bf16 storage O(1))
+# ---------------------------------------------------------------------------------------------------
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def check_train_units_local(lib, device, manifest, B=2, size=64, act_dtype="bf16", state="shipped", flops_weight=3.0,
+                            tol_fwd=None, tol_bwd=None, seed=51):
+    """Returns the worst relative L2 deviations {z, act, dz, dx, dparam} over all units."""
+    import contextlib
+    bf16 = act_dtype == "bf16"
+    # bf16: one rounding of the output (2^-9 rms) + rare flips of rounded inputs; fp32: summation order only
+    tol_fwd = tol_fwd if tol_fwd is not None else (2e-3 if bf16 else 2e-5)
+    tol_bwd = tol_bwd if tol_bwd is not None else (3e-2 if bf16 else 2e-4)
+    sd = well_conditioned_state(manifest) if state == "well" else O.load_weights(manifest)
+    m = M.build_model(predefine=manifest)
+    m.load_state_dict(sd)
+    m = m.to(device)
+    m._lib = lib if device.type == "cpu" else None
+    m.set_train_act_dtype(act_dtype)
+    m.train(); m.set_batchsize(B); m.clear_flops(); m.flops_hook(1.0)
+    x = torch.from_numpy(I.randn_batch(seed, B, size, size))
+    t = torch.from_numpy(I.binary_target(seed + 1, B, size, size))
+    xd, td = x.to(device), t.to(device)
+    y, pen = m._train_forward_raw(xd)
+    eng = m.engine_for(xd, train=True)
+    units, acts, names = m.describe(m._arena.offsets)
+    n_acts = len(acts)
+    A = {0: (eng.train_probe(0, "act").cpu() if bf16 else x.clone())}
+    Z = {}
+    for a in range(1, n_acts):
+        A[a] = eng.train_probe(a, "act").cpu()
+        Z[a] = eng.train_probe(a, "z").cpu()
+    loss, dy = bce_and_grad(m._lib or N.load(), y, td)
+    flat = m._train_backward_raw(xd, dy, flops_weight / B).cpu()
+    DZ = {a: eng.train_probe(a, "z").cpu() for a in range(1, n_acts)}
+    G = {}
+    for a in range(1, n_acts):
+        for s in range(eng.n_consumers(a)):
+            G[(a, s)] = eng.train_probe(a, f"grad{s}").cpu()
+    cfg = O.load_layer_config_json(manifest)
+    blocks = {b["name"]: b for b in O.block_table(cfg)}
+    cfg3 = cfg[len(blocks):len(blocks) + 3]
+    offs = m._arena.offsets
+    pshape = {k: p.shape for k, p in m.named_parameters()}
+    flop_tab = m._flop_tab
+    worst = dict(z=0.0, act=0.0, dz=0.0, dx=0.0, dparam=0.0)
+    bad = []
+
+    def note(kind, name, got, ref, tol, floor=0.0):
+        # relative L2, with an absolute floor for tensors that are (nearly) zero
+        e = float((got.double() - ref.double()).norm())
+        n = float(ref.double().norm())
+        r = e / (n + floor + 1e-30)
+        worst[kind] = max(worst[kind], r)
+        if r > tol:
+            bad.append((kind, name, r, n))
+
+    ctx = O.bf16_activations() if bf16 else contextlib.nullcontext()
+    for ui, (u, name) in enumerate(zip(units, names)):
+        n_in, n_out = int(u.n_in), int(u.n_out)
+        xs = []
+        for i in range(n_in):
+            if u.cin[i] > 0:
+                xs.append(A[int(u.in_act[i])].clone().requires_grad_(int(u.in_act[i]) > 0))
+            else:
+                xs.append(None)
+        pkeys = [k for k in pshape if k.startswith(name + ".")]
+        loc = {k: v.clone() for k, v in sd.items() if k.startswith(name + ".")}
+        for k in pkeys:
+            loc[k].requires_grad_(True)
+        O.Z_CAPTURE = []
+        try:
+            with ctx:
+                if name == "cls_layer":
+                    out = O._st(F.conv2d(xs[0], loc["cls_layer.weight"], loc["cls_layer.bias"]))
+                    ys = [F.interpolate(out, x.shape[2:], mode="bilinear", align_corners=False)]
+                elif name.endswith(".conv1x1"):
+                    blk = blocks[name[:-len(".conv1x1")]]
+                    a_in, _ = O._alphas(blk["inlist"]); a_out, _ = O._alphas(blk["outlist"])
+                    k = 3 if (blk["first"] or blk["stride"] == 2) else 1
+                    ys = O.goct_cbr(xs, loc, name, a_in, a_out, k, blk["stride"], True)
+                elif ".conv3x3_" in name:
+                    ys = O.simplified_cbr(xs, loc, name, True)
+                elif name == "oct_fuse.fuse":
+                    ys = O.goct_cbr(xs, loc, name, O._alphas(cfg3[0][0])[0], O._alphas(cfg3[1][0])[0], 1, 1, True)
+                elif name.startswith("oct_fuse.ms.convs."):
+                    ys = [O.ms_block(xs[0], loc, name, cfg3[1][2][int(name.rsplit(".", 1)[1])], True)]
+                elif name == "oct_fuse.fuse1x1":
+                    ys = O.goct_cbr(xs, loc, name, O._alphas(cfg3[1][1])[0], [1], 1, 1, True)
+                else:
+                    raise AssertionError(f"unit {name}?")
+                if isinstance(ys, torch.Tensor):
+                    ys = [ys]
+                zs = list(O.Z_CAPTURE)
+                for z in zs:
+                    z.retain_grad()
+                # forward: the device's z / activation of this unit against the local recomputation
+                outs = [j for j in range(n_out) if u.cout[j] > 0] if name != "cls_layer" else [0]
+                live = [yy for yy in ys if yy is not None]
+                assert len(live) == len(outs), (name, len(live), len(outs))
+                total = None
+                for q, j in enumerate(outs):
+                    if name == "cls_layer":
+                        note("act", name, y.cpu(), live[q], tol_fwd)
+                        up = dy.cpu()
+                    else:
+                        a = int(u.out_act[j])
+                        note("z", f"{name}[{j}]", Z[a], zs[q].detach(), tol_fwd)
+                        note("act", f"{name}[{j}]", A[a], live[q].detach(), tol_fwd)
+                        up = G[(a, 0)] + (G[(a, 1)] if (a, 1) in G else 0.0)
+                        w = flop_tab[ui * N.MAX_BRANCH + j]
+                        if w != 0.0:   # Oct_bn_hook (csnet.py:391-410): 0.5 w sum |mean_hw y| gamma^2, y detached; /batchsize
+                            gam = loc[[k for k in pkeys if k.endswith(f"bns.{j}.weight")][0]]
+                            gap = live[q].detach().mean(dim=(2, 3)).abs().sum(0)
+                            term = (flops_weight / B) * 0.5 * w * (gap * gam * gam).sum()
+                            total = term if total is None else total + term
+                    term = (live[q] * up).sum()
+                    total = term if total is None else total + term
+                total.backward()
+        finally:
+            O.Z_CAPTURE = None
+        gmax = max(float(loc[k].grad.norm()) if loc[k].grad is not None else 0.0 for k in pkeys)
+        for k in pkeys:
+            g = flat[offs[k]:offs[k] + int(np.prod(pshape[k]))].view(pshape[k])
+            ref = loc[k].grad if loc[k].grad is not None else torch.zeros_like(loc[k])
+            note("dparam", k, g, ref, tol_bwd, floor=1e-3 * gmax)
+        if name != "cls_layer":
+            for q, j in enumerate(outs):
+                note("dz", f"{name}[{j}]", DZ[int(u.out_act[j])], zs[q].grad, tol_bwd)
+        for i in range(n_in):
+            a = int(u.in_act[i])
+            if u.cin[i] > 0 and a > 0:
+                note("dx", f"{name}<-{i}", G[(a, eng.unit_in_slot(ui, i))], xs[i].grad, tol_bwd)
+    assert not bad, f"{len(bad)} unit-local deviations over tolerance, worst first: {sorted(bad, key=lambda b: -b[2])[:8]}"
+    return worst

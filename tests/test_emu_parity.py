@@ -77,3 +77,19 @@ def test_emu_pre_post_processing(emu_lib, x2_manifest):
 def test_emu_train_step_well_conditioned(emu_lib, x2_manifest):
     """Gradients on a well-conditioned state of the shipped architecture: no further from fp64 than the fp32 reference."""
     print("rel-L2 vs fp64: kernels %.2e, fp32 oracle %.2e" % P.check_train_step_well_conditioned(emu_lib, torch.device("cpu"), x2_manifest, B=2, size=32))
+
+
+def test_emu_train_step_bf16(emu_lib, x2_manifest):
+    """BASELINE config 3's dtype (bfloat16 activation storage) on the CPU emulation of the kernels."""
+    print(P.check_train_step_bf16(emu_lib, CPU, x2_manifest, B=2, size=32))
+
+
+import pytest
+
+
+@pytest.mark.parametrize("act_dtype,B,size,state", [("fp32", 2, 64, "shipped"), ("fp32", 3, 48, "well"), ("bf16", 2, 64, "shipped"),
+                                                    ("bf16", 3, 48, "well"), ("bf16", 2, 16, "shipped")])
+def test_emu_train_units_local(emu_lib, x2_manifest, act_dtype, B, size, state):
+    """Every unit's train-mode forward and backward (dz, dx per consumer slot, every parameter gradient) against the oracle
+    applied to the tensors the kernels themselves produced around that unit -- no error amplification through depth."""
+    print(P.check_train_units_local(emu_lib, CPU, x2_manifest, B=B, size=size, act_dtype=act_dtype, state=state))

@@ -192,3 +192,22 @@ def test_gpu_resizes(hip):
     lib, dev = hip
     RC.check_resize_bilinear(lib, dev)
     RC.check_pre_post(lib, dev)
+
+
+@pytest.mark.parametrize("act_dtype,B,size,state", [("fp32", 4, 96, "shipped"), ("fp32", 2, 224, "well"), ("bf16", 4, 96, "shipped"),
+                                                    ("bf16", 2, 224, "shipped"), ("bf16", 3, 48, "well"), ("bf16", 2, 16, "shipped")])
+def test_gpu_train_units_local(hip, x2_manifest, act_dtype, B, size, state):
+    """Every unit's train-mode forward and backward (z, activation, dz, dx per consumer slot, every parameter gradient)
+    against the oracle applied to the tensors the kernels themselves produced around that unit: no amplification through
+    the 60 batch-normalised layers, so the bounds are tight (fp32: 2e-5 forward / 2e-4 backward relative L2; bf16 storage,
+    BASELINE config 3: 2e-3 / 3e-2)."""
+    lib, dev = hip
+    print(P.check_train_units_local(lib, dev, x2_manifest, B=B, size=size, act_dtype=act_dtype, state=state))
+
+
+def test_gpu_train_step_bf16(hip, x2_manifest):
+    """bf16 activation storage, whole step: logits / loss / penalty / BN statistics against the oracle with the same storage
+    points rounded through bf16 and against the plain fp32 oracle (~1e-2 relative)."""
+    lib, dev = hip
+    print(P.check_train_step_bf16(lib, dev, x2_manifest, B=4, size=96, state="shipped"))
+    print(P.check_train_step_bf16(lib, dev, x2_manifest, B=2, size=64, state="well"))

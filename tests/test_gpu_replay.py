@@ -251,3 +251,64 @@ def test_gpu_train_batch256_properties(hip, x2_manifest):
     for k, v in sd.items():                        # the oracle's forward updated sd's running statistics in place
         if k.endswith("running_mean") or k.endswith("running_var"):
             assert ((got[k] - v).abs() / (1 + v.abs())).max().item() <= 1e-4, k
+
+
+def test_gpu_train_bf16_replay_and_batch256(hip, x2_manifest):
+    """BASELINE config 3 as stated: batch 256, bfloat16 activation storage.  Replayed steps are bit-identical to the eager one
+    (lr = 0), a batch of 64 x 4 images reproduces the batch-4 step, and loss / penalty / BN statistics match the oracle's
+    bf16-emulating train-mode forward of the same 256 images."""
+    from sod100k_amd.tools.train import FusedTrainer
+    lib, dev = hip
+    B, R = 256, 4
+    base = torch.from_numpy(I.randn_batch(80, R))
+    tb = torch.from_numpy(I.binary_target(81, R))
+
+    def run(x, t, steps=1):
+        m, sd = P.make_model(lib, x2_manifest, dev)
+        m.train(); m.set_batchsize(x.shape[0]); m.clear_flops(); m.flops_hook(1.0)
+        tr = FusedTrainer(m, lr=0.0, weight_decay=0.0, flops_weight=3.0, batchsize=x.shape[0], lib=lib, act_dtype="bf16")
+        xd, td = x.to(dev), t.to(dev)
+        outs = []
+        for _ in range(steps):
+            loss, pen = tr.step(xd, td)
+            m.clear_flops()
+            outs.append((float(loss), float(pen), tr.grad.clone()))
+        stats = {k: v.cpu().clone() for k, v in m.state_dict().items() if "running_" in k}
+        del tr, m
+        torch.cuda.empty_cache()
+        return stats, outs
+
+    _, o4 = run(base, tb)
+    gen = torch.Generator().manual_seed(82)
+    xr = torch.randn(B, 3, 224, 224, generator=gen)
+    trg = (torch.rand(B, 1, 224, 224, generator=gen) > 0.5).float()
+    got, o256 = run(xr, trg, steps=6)
+    for step, (l, p, g) in enumerate(o256):
+        assert np.isfinite(l) and torch.isfinite(g).all()
+        assert l == o256[0][0] and p == o256[0][1] and torch.equal(g, o256[0][2]), f"step {step}: replay differs from eager"
+    _, orep = run(base.repeat(B // R, 1, 1, 1), tb.repeat(B // R, 1, 1, 1))
+    l4, p4, g4 = o4[0]
+    l, p, g = orep[0]
+    rel = float((g - g4).double().norm() / g4.double().norm())
+    print(f"bf16 batch 256 (64 x 4 images) vs batch 4: loss {l:.6f} / {l4:.6f}, penalty {p:.6f} / {p4:.6f}, gradient rel-L2 {rel:.2e}")
+    assert abs(l - l4) <= 1e-4 * max(1.0, abs(l4)), (l, l4)
+    assert abs(p - p4) <= 1e-4 * max(1.0, abs(p4)), (p, p4)
+    assert rel <= 5e-2, rel        # identical batch statistics -> identical stored tensors up to rare rounding flips
+    sd = O.load_weights(x2_manifest)
+    cfg = O.load_layer_config_json(x2_manifest)
+
+    class GapTaps(dict):
+        def __setitem__(self, k, v):
+            super().__setitem__(k, [None if t is None else torch.nn.functional.adaptive_avg_pool2d(t, 1) for t in v])
+
+    taps = GapTaps()
+    with torch.no_grad(), O.bf16_activations():
+        out = O.csnet_forward(cfg, sd, xr, training=True, taps=taps)
+        bce = float(torch.nn.functional.binary_cross_entropy_with_logits(out, trg))
+        pen = float(O.gap_penalty(sd, taps, O.flop_weights(cfg, 1.0), B))
+    print(f"bf16 batch 256 vs bf16-emulating oracle: bce {o256[0][0]:.6f} / {bce:.6f}, penalty {o256[0][1]:.6f} / {pen:.6f}")
+    assert abs(o256[0][0] - bce) <= 2e-3 * max(1.0, abs(bce))
+    assert abs(o256[0][1] - pen) <= 5e-3 * max(1.0, abs(pen))
+    for k, v in sd.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert ((got[k] - v).abs() / (1 + v.abs())).max().item() <= 2e-3, k
