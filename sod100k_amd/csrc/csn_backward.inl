@@ -32,10 +32,18 @@ struct DataLaunch {
   int lvl_lo = 0;     // to_tmp: level of the temporary
 };
 
+struct WgRowSrc {     // `n` consecutive channels, starting at c0, of the tensor (kind, idx) with ctot channels
+  int kind = SRC_DZ, idx = 0, c0 = 0, ctot = 0, n = 0;
+};
+
 struct WgPlan {
   PwLaunchPlan L;     // one pass, r = 0, L.lvl = absolute level (weight image unused)
-  int a_kind = SRC_DZ, a_idx = 0, a_c0 = 0, a_ctot = 0;
+  std::vector<WgRowSrc> rows;   // the dz rows of the pass, source after source (sum of n == nrows of the pass)
   std::vector<WgBlock> blocks;
+  void one_source(int kind, int idx, int c0, int ctot) {
+    WgRowSrc r; r.kind = kind; r.idx = idx; r.c0 = c0; r.ctot = ctot; r.n = L.passes[0].nrows;
+    rows.assign(1, r);
+  }
 };
 
 struct UnitBwd {
@@ -104,7 +112,67 @@ int plan_goct_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
     ub.adj.push_back(a);
     return (int)ub.adj.size() - 1;
   };
-  // ---- weight gradients: one launch per forward pass (the z launch pairs with the adjoint-upsampled dz_0)
+  // ---- weight gradients.  Multi-branch 1x1 units: the low -> high blocks move the bilinear adjoint onto dz (the same
+  // adjoint-upsampled dz_j the input gradient needs) and are contracted at the LOW resolution,
+  //     dW[co_j][ci_i] = sum_{p at res i} adjoint_up(dz_j)[co_j][p] * x_i[ci_i][p]          (i > j)
+  // so no weight-gradient launch gathers bilinear taps (4 loads per channel and pixel at the finest resolution) and the
+  // pass at resolution r is  [adj(dz_0); ..; adj(dz_{r-1}); dz_r] x x_r  (rows = consecutive rows of W, columns = block r)
+  // plus  dz_r x [pool(x_0); ..; pool(x_{r-1})]  for the high -> low blocks.
+  const bool regroup = d.ksize == 1 && !u.std_conv && (d.n_in > 1 || d.n_out > 1) && cout_tot <= WG_MAX_ROWS &&
+                       std::getenv("CSN_WGRAD_REGROUP") == nullptr;
+  if (regroup) {
+    for (int r = 0; r < d.n_in; ++r) {
+      if (d.cin[r] == 0) continue;
+      WgPlan w;
+      w.L.lvl = base + r;
+      PwPassPlan q;
+      q.r = 0; q.nsrc = 1; q.src_kind[0] = SRC_IN; q.src_branch[0] = r; q.src_C[0] = d.cin[r]; q.src_mode[0] = PW_OWN;
+      q.K = d.cin[r];
+      int first = -1;
+      for (int j = 0; j <= r && j < d.n_out; ++j) {
+        if (d.cout[j] == 0) continue;
+        if (r - j > 2) FAIL(CSN_E_UNSUPPORTED, "bilinear factor > 4");
+        if (first < 0) first = j;
+        WgRowSrc rs;
+        rs.c0 = 0; rs.ctot = d.cout[j]; rs.n = d.cout[j];
+        if (j == r) { rs.kind = SRC_DZ; rs.idx = j; }
+        else { rs.kind = SRC_ADJ; rs.idx = adj_index(j, r); }
+        w.rows.push_back(rs);
+        q.nrows += d.cout[j];
+      }
+      if (q.nrows == 0) continue;
+      w.L.passes.push_back(q);
+      WgBlock g;
+      g.dst = d.w_off[0] + (int64_t)co_off[first] * cin_tot + ci_off[r]; g.ld = cin_tot; g.ncol = d.cin[r]; g.col = 0;
+      g.scale = 1.f; g.tk = 0;
+      w.blocks.push_back(g);
+      ub.wg.push_back(w);
+    }
+    for (int j = 1; j < d.n_out; ++j) {
+      if (d.cout[j] == 0) continue;
+      WgPlan w;
+      w.L.lvl = base + j;
+      PwPassPlan q;
+      q.r = 0; q.nrows = d.cout[j];
+      for (int i = 0; i < j && i < d.n_in; ++i) {
+        if (d.cin[i] == 0) continue;
+        if (j - i > 2) FAIL(CSN_E_UNSUPPORTED, "max-pool factor");
+        const int s = q.nsrc++;
+        q.src_kind[s] = SRC_IN; q.src_branch[s] = i; q.src_C[s] = d.cin[i]; q.src_mode[s] = j - i == 1 ? PW_POOL2 : PW_POOL4;
+        WgBlock g;
+        g.dst = d.w_off[0] + (int64_t)co_off[j] * cin_tot + ci_off[i]; g.ld = cin_tot; g.ncol = d.cin[i]; g.col = q.K;
+        g.scale = 1.f; g.tk = 0;
+        w.blocks.push_back(g);
+        q.K += d.cin[i];
+      }
+      if (q.nsrc == 0) continue;
+      w.L.passes.push_back(q);
+      w.one_source(SRC_DZ, j, 0, d.cout[j]);
+      ub.wg.push_back(w);
+    }
+  }
+  // ... everything else: one launch per forward pass (the z launch pairs with the adjoint-upsampled dz_0)
+  if (!regroup)
   for (const PwLaunchPlan& L : u.pwl)
     for (const PwPassPlan& pp : L.passes) {
       PwPassPlan q = pp;
@@ -114,11 +182,8 @@ int plan_goct_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
       }
       if (q.nsrc == 0 || q.K == 0) continue;
       WgPlan w = make_wg(L, q);
-      if (pp.out_kind == OUT_Z) {
-        w.a_kind = SRC_ADJ; w.a_idx = adj_index(0, 1); w.a_c0 = pp.out_c0; w.a_ctot = u.z_C;
-      } else {
-        w.a_kind = SRC_DZ; w.a_idx = pp.out_branch; w.a_c0 = pp.out_c0; w.a_ctot = d.cout[pp.out_branch];
-      }
+      if (pp.out_kind == OUT_Z) w.one_source(SRC_ADJ, adj_index(0, 1), pp.out_c0, u.z_C);
+      else w.one_source(SRC_DZ, pp.out_branch, pp.out_c0, d.cout[pp.out_branch]);
       ub.wg.push_back(w);
     }
   // ---- input gradients
@@ -227,7 +292,7 @@ int plan_ms_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
     }
     if (ps.nsrc == 0) break;
     WgPlan wg = make_wg(L, ps);
-    wg.a_kind = SRC_IN; wg.a_idx = 0; wg.a_c0 = 0; wg.a_ctot = cin;
+    wg.one_source(SRC_IN, 0, 0, cin);
     ub.wg.push_back(wg);
   }
   if (!ub.need_dx[0]) return CSN_OK;
@@ -279,7 +344,7 @@ int plan_cls_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
   ub.need_dx[0] = d.in_act[0] > 0;
   {
     WgPlan wg = make_wg(u.pwl[0], u.pwl[0].passes[0]);
-    wg.a_kind = SRC_DZ; wg.a_idx = 0; wg.a_c0 = 0; wg.a_ctot = 1;
+    wg.one_source(SRC_DZ, 0, 0, 1);
     ub.wg.push_back(wg);
   }
   if (!ub.need_dx[0]) return CSN_OK;
@@ -322,8 +387,16 @@ int run_wgrad(const BwdCtx& b, const WgPlan& w, const PwBind& bd) {
   fill_pass(b.c, w.L, pp, bd, a.ps);
   a.Hr = P.H >> w.L.lvl; a.Wr = P.W >> w.L.lvl; a.B = P.S;
   const int64_t hw = (int64_t)a.Hr * a.Wr;
-  const float* ab = w.a_kind == SRC_ADJ ? bd.adj[w.a_idx] : (w.a_kind == SRC_IN ? bd.in[w.a_idx] : bd.dz[w.a_idx]);
-  a.a_ctot = w.a_ctot;
+  auto row_base = [&](const WgRowSrc& r) {
+    return r.kind == SRC_ADJ ? bd.adj[r.idx] : (r.kind == SRC_IN ? bd.in[r.idx] : bd.dz[r.idx]);
+  };
+  if (w.rows.empty() || w.rows.size() > 3 || (w.rows.size() > 1 && pp.nrows > WG_MAX_ROWS)) return CSN_E_INVALID;
+  a.nrs = (int)w.rows.size();
+  for (int q = 0; q < 3; ++q) { a.rs[q].ptr = nullptr; a.rs[q].ctot = 0; a.rs[q].n = 0; }
+  for (int q = 0; q < a.nrs; ++q) {
+    a.rs[q].ptr = b.c.eo(row_base(w.rows[q]), (int64_t)w.rows[q].c0 * hw);
+    a.rs[q].ctot = w.rows[q].ctot; a.rs[q].n = w.rows[q].n;
+  }
   a.gpp = (int)((hw + 63) / 64);
   a.ngroups = a.gpp * P.S;
   a.k16 = (pp.K + 15) & ~15;
@@ -333,9 +406,12 @@ int run_wgrad(const BwdCtx& b, const WgPlan& w, const PwBind& bd) {
   for (int r0 = 0; r0 < pp.nrows; r0 += WG_MAX_ROWS) {
     const int nr = std::min(WG_MAX_ROWS, pp.nrows - r0);
     a.ps.nrows = nr;
-    a.a = b.c.eo(ab, (int64_t)(w.a_c0 + r0) * hw);
+    if (a.nrs == 1) {   // row chunks of a single source
+      a.rs[0].ptr = b.c.eo(row_base(w.rows[0]), (int64_t)(w.rows[0].c0 + r0) * hw);
+      a.rs[0].n = nr;
+    }
     a.rows16 = (nr + 15) & ~15;
-    a.nblk = csn_wgrad_blocks(a.rows16, a.k16, a.ngroups);
+    a.nblk = csn_wgrad_blocks(a);
     LAUNCH_TRY(csn_launch_wgrad(a, b.c.stream));
     WgReduceArgs r;
     r.partial = a.partial; r.grad = b.grad;
@@ -475,7 +551,8 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
   }
   for (const WgPlan& w : ub.wg) {
     // a pass that reads the adjoint-upsampled dz lives in the shared scratch, which the next unit overwrites: main lane
-    bool scratch_free = w.a_kind != SRC_ADJ;
+    bool scratch_free = true;
+    for (const WgRowSrc& r : w.rows) scratch_free = scratch_free && r.kind != SRC_ADJ;
     for (int s2 = 0; s2 < w.L.passes[0].nsrc; ++s2)
       scratch_free = scratch_free && (w.L.passes[0].src_kind[s2] == SRC_IN || w.L.passes[0].src_kind[s2] == SRC_DZ);
     const int st = run_wgrad(scratch_free ? bs : b, w, bd);

@@ -80,7 +80,7 @@ struct DwArgs {
 enum PwMode { PW_OWN = 0, PW_POOL2 = 1, PW_POOL4 = 2, PW_UP2 = 3, PW_UP4 = 4, PW_TAPS = 5, PW_POOL2_TAPS = 6,
               PW_TAPS_S2 = 7,     // 3x3 taps with stride 2 of a source at twice the resolution (std_conv, csnet.py:751-754)
               PW_TAPS_UPS2 = 8 }; // its adjoint: 3x3 taps of a zero-stuffed source at half the resolution
-static inline bool pw_mode_taps(int m) { return m == PW_TAPS || m == PW_POOL2_TAPS || m == PW_TAPS_S2 || m == PW_TAPS_UPS2; }
+__host__ __device__ static inline bool pw_mode_taps(int m) { return m == PW_TAPS || m == PW_POOL2_TAPS || m == PW_TAPS_S2 || m == PW_TAPS_UPS2; }
 struct PwSrc {
   const float* ptr;  // first channel of the slice inside [B][Ctot][H_s][W_s]
   int32_t C;         // channels of the slice
@@ -197,10 +197,14 @@ struct Up2Args {
 // ---------------------------------------------------------------------------------------------
 #define WG_MAX_BLOCKS 512
 #define WG_MAX_ROWS 80     // output channels per launch (5 MFMA row tiles)
+struct WgRows {         // one source of dz rows: `n` consecutive channels starting at `ptr` inside [B][ctot][Hr][Wr]
+  const float* ptr;
+  int32_t ctot, n;
+};
 struct WgArgs {
   PwPass ps;            // gather descriptor of the forward pass (src, cin, nrows); out/epilogue fields unused
-  const float* a;       // dz: first of ps.nrows channels inside [B][a_ctot][Hr][Wr]
-  int32_t a_ctot;
+  WgRows rs[3];         // the ps.nrows rows of dz, source after source (dz of a branch, adjoint-upsampled dz of finer ones)
+  int32_t nrs;
   int32_t Hr, Wr, B;
   int32_t gpp;          // 64-pixel groups per image plane
   int32_t ngroups;      // B * gpp
@@ -223,7 +227,7 @@ struct WgReduceArgs {
   int32_t nblocks, nblk, nrows, K, rows16, k16;
 };
 int csn_launch_wgrad(const WgArgs& a, void* stream);
-int csn_wgrad_blocks(int rows16, int k16, int ngroups);   // partial slices (= blocks) the launch will use
+int csn_wgrad_blocks(const WgArgs& a);   // partial slices (= blocks) the launch will use (ps, rows16, k16, ngroups set)
 int csn_launch_wgrad_reduce(const WgReduceArgs& a, void* stream);
 
 // ---------------------------------------------------------------------------------------------

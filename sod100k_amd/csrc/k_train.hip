@@ -72,6 +72,29 @@ __device__ __forceinline__ double bn_block_sum(double v, double* sm) {
 #endif
 }
 
+// N sums at once: the same summation tree per value as bn_block_sum, one pair of barriers for all of them
+template <int N>
+__device__ __forceinline__ void bn_block_sum_n(double (&v)[N], double* sm) {
+#ifdef CSN_CPU_EMU
+  for (int t = 0; t < N; ++t) v[t] = bn_block_sum(v[t], sm);
+#else
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int t = 0; t < N; ++t) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[t] += __shfl_xor(v[t], o, 64);
+  }
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int t = 0; t < N; ++t) sm[(tid >> 6) * N + t] = v[t];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < N; ++t) v[t] = (sm[t] + sm[N + t]) + (sm[2 * N + t] + sm[3 * N + t]);
+  __syncthreads();
+#endif
+}
+
 // grid (nslab, C): block (slab, c) reduces one chunk of one plane of channel c.
 template <typename AT>
 __global__ __launch_bounds__(CSN_BLOCK) void bn_stats_kernel(BnStatsArgs a) {
@@ -93,11 +116,11 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_stats_kernel(BnStatsArgs a) {
       s2 += v * v;
     }
   }
-  s1 = bn_block_sum(s1, sm);
-  s2 = bn_block_sum(s2, sm);
+  double sv[2] = {s1, s2};
+  bn_block_sum_n<2>(sv, sm);
   if (threadIdx.x == 0) {
-    a.partial[((int64_t)c * BN_NSLAB + slab) * 2 + 0] = s1;
-    a.partial[((int64_t)c * BN_NSLAB + slab) * 2 + 1] = s2;
+    a.partial[((int64_t)c * BN_NSLAB + slab) * 2 + 0] = sv[0];
+    a.partial[((int64_t)c * BN_NSLAB + slab) * 2 + 1] = sv[1];
   }
 }
 
@@ -217,12 +240,11 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_reduce_kernel(BnBwdArgs a) {
     for (int i = r.beg + threadIdx.x; i < r.end; i += CSN_BLOCK)
       acc(act_ld(act_cast<AT>(a.z) + r.base + i), bnb_dy<AT>(a, r.base + i));
   }
-  s0 = bn_block_sum(s0, sm);
-  s1 = bn_block_sum(s1, sm);
-  s2 = bn_block_sum(s2, sm);
+  double sv[3] = {s0, s1, s2};
+  bn_block_sum_n<3>(sv, sm);
   if (threadIdx.x == 0) {
     double* o = a.partial + ((int64_t)c * BN_NSLAB + slab) * 3;
-    o[0] = s0; o[1] = s1; o[2] = s2;
+    o[0] = sv[0]; o[1] = sv[1]; o[2] = sv[2];
   }
 }
 
@@ -286,9 +308,13 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_apply_kernel(BnBwdArgs a) {
 }
 
 // depthwise 3x3 weight gradient: dW[c][t] = 100 * sum_{n,p} dz[n,c,p] * x[n,c,p + off(t)]   (conv2d.py:104)
+// A lane owns QUADS of four consecutive pixels of a row (W % 4 == 0, chunks start on multiples of four): one vector load
+// of dz, three of x (rows y - 1, y, y + 1; rows outside the plane fall out of the bounded buffer range and read as 0) plus
+// the two edge columns per row -- 2.5 load instructions per pixel instead of 10.  <= 8 quads per lane: fp32 partials.
 template <typename AT>
 __global__ __launch_bounds__(CSN_BLOCK) void dw_wgrad_kernel(DwWgradArgs a) {
   CSN_DYN_SMEM(double, sm);
+  constexpr unsigned E = (unsigned)sizeof(AT);
   const int c = blockIdx.y, slab = blockIdx.x;
   const int H = a.H, W = a.W;
   const BnRange r = bn_range(slab, a.cpp, a.C, c, (int64_t)H * W);
@@ -297,21 +323,47 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw_wgrad_kernel(DwWgradArgs a) {
   float s[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) s[t] = 0.f;
-  for (int p = r.beg + threadIdx.x; p < r.end; p += CSN_BLOCK) {   // <= 32 terms per lane: fp32 partials
-    const int y = p / W, x = p - y * W;
-    const float g = act_ld(gp + p);
+  if ((W & 3) == 0) {
+    const csn_buf xb = csn_make_buf_n(xp, (unsigned)(H * W) * E);
+    for (int q = (r.beg >> 2) + threadIdx.x; q < (r.end >> 2); q += CSN_BLOCK) {
+      const int p = q << 2;
+      const int y = p / W, x0 = p - y * W;
+      const float4 g = act_ld4(gp + p);
+      const bool has_l = x0 > 0, has_r = x0 + 4 < W;
+      float v[3][6];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-      const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
-      const float v = act_ld(xp + (in ? yy * W + xx : p));
-      s[t] = fmaf(g, in ? v : 0.f, s[t]);
+      for (int dy = 0; dy < 3; ++dy) {
+        const unsigned o = (unsigned)((y + dy - 1) * W + x0) * E;   // row -1 wraps to a huge offset, row H is past the plane: 0
+        const float4 cv = csn_bufacc<AT>::ld4(xb, o, 0);
+        const float l = csn_bufacc<AT>::ld1(xb, o - E, 0), rr = csn_bufacc<AT>::ld1(xb, o + 4u * E, 0);
+        v[dy][0] = has_l ? l : 0.f; v[dy][1] = cv.x; v[dy][2] = cv.y; v[dy][3] = cv.z; v[dy][4] = cv.w; v[dy][5] = has_r ? rr : 0.f;
+      }
+      const float gq[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[t] = fmaf(gq[j], v[t / 3][t % 3 + j], s[t]);
+    }
+  } else {
+    for (int p = r.beg + threadIdx.x; p < r.end; p += CSN_BLOCK) {   // <= 32 terms per lane: fp32 partials
+      const int y = p / W, x = p - y * W;
+      const float g = act_ld(gp + p);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const float v = act_ld(xp + (in ? yy * W + xx : p));
+        s[t] = fmaf(g, in ? v : 0.f, s[t]);
+      }
     }
   }
+  double sv[9];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const double rs = bn_block_sum((double)s[t], sm);
-    if (threadIdx.x == 0) a.partial[((int64_t)c * BN_NSLAB + slab) * 9 + t] = rs;
+  for (int t = 0; t < 9; ++t) sv[t] = (double)s[t];
+  bn_block_sum_n<9>(sv, sm);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) a.partial[((int64_t)c * BN_NSLAB + slab) * 9 + t] = sv[t];
   }
 }
 
@@ -325,10 +377,10 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw_wgrad_finalize_kernel(DwWgradArg
   for (int k = threadIdx.x; k < a.nslab; k += CSN_BLOCK)
 #pragma unroll
     for (int t = 0; t < 9; ++t) s[t] += a.partial[((int64_t)c * BN_NSLAB + k) * 9 + t];
+  bn_block_sum_n<9>(s, sm);
+  if (threadIdx.x == 0) {
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const double r = bn_block_sum(s[t], sm);
-    if (threadIdx.x == 0) a.grad[a.off_w + c * 9 + t] = (float)(100.0 * r);
+    for (int t = 0; t < 9; ++t) a.grad[a.off_w + c * 9 + t] = (float)(100.0 * s[t]);
   }
 }
 

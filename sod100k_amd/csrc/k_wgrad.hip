@@ -51,10 +51,36 @@ __device__ __forceinline__ void wg_mma(const float* dzp, const float* xp, int la
 
 // Not inlined on purpose: hipcc otherwise keeps the address arithmetic of every gather mode of all three call
 // sites live at once (390 VGPRs, one wave per SIMD); as a call the kernel needs 125.
-template <typename AT>
+template <typename AT, int MODES>
 __device__ __attribute__((noinline)) void wg_gather(PwPassP ps, int s, int c_lo, int c_hi, float* xrow, int rmax, int b,
                                                    int y, int x, int Hr, int Wr) {
-  pw_gather_slice<AT, WG_P>(ps, s, c_lo, c_hi, xrow, rmax, b, y, x, Hr, Wr);
+#ifdef CSN_CPU_EMU
+  pw_gather_slice<AT, WG_P, MODES>(ps, s, c_lo, c_hi, xrow, rmax, b, y, x, Hr, Wr);
+#else
+  // arguments of a real call travel in VGPRs: without these the image index (and with it every buffer resource) counts as
+  // divergent and each gather load turns into a waterfall loop
+  {
+    const unsigned long long pv = (unsigned long long)ps;
+    const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)pv), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(pv >> 32));
+    ps = (PwPassP)(((unsigned long long)hi32 << 32) | lo32);
+  }
+  s = __builtin_amdgcn_readfirstlane(s); c_lo = __builtin_amdgcn_readfirstlane(c_lo); c_hi = __builtin_amdgcn_readfirstlane(c_hi);
+  rmax = __builtin_amdgcn_readfirstlane(rmax); b = __builtin_amdgcn_readfirstlane(b);
+  Hr = __builtin_amdgcn_readfirstlane(Hr); Wr = __builtin_amdgcn_readfirstlane(Wr);
+  // xrow points into the block's LDS panel, but a generic pointer parameter of a real call compiles to flat_store (counted in
+  // vmcnt AND lgkmcnt: every panel write then waits for the gather's global loads): go through the LDS address space
+  typedef __attribute__((address_space(3))) float* lds_fp;
+  pw_gather_slice<AT, WG_P, MODES, lds_fp>(ps, s, c_lo, c_hi, (lds_fp)xrow, rmax, b, y, x, Hr, Wr);
+#endif
+}
+
+// two smaller functions instead of one with every mode: the all-mode body ran out of SGPRs in the bf16 instantiation (the
+// return address then goes through a scratch-saved VGPR on every call)
+template <typename AT>
+__device__ __forceinline__ void wg_gather_any(PwPassP ps, int s, int c_lo, int c_hi, float* xrow, int rmax, int b, int y,
+                                              int x, int Hr, int Wr) {
+  if (pw_mode_taps(ps->src[s].mode)) wg_gather<AT, 2>(ps, s, c_lo, c_hi, xrow, rmax, b, y, x, Hr, Wr);
+  else wg_gather<AT, 1>(ps, s, c_lo, c_hi, xrow, rmax, b, y, x, Hr, Wr);
 }
 
 template <int NT, typename AT>
@@ -62,7 +88,14 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_wgrad_kernel(WgArgs a_byval
   CSN_DYN_SMEM(float, lds);
   WgArgsP a = CSN_KERNARG(WgArgs, a_byval);
   PwPassP ps = &a->ps;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+#ifdef CSN_CPU_EMU
+  const int wave = tid >> 6;
+#else
+  // wave-uniform by construction, but the compiler cannot know: without this every buffer resource derived from the wave's
+  // group index lives in VGPRs and each load becomes a waterfall loop with a full vmcnt(0) wait
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
   const int rows16 = a->rows16, k16 = a->k16, nrows = ps->nrows;
   const int Hr = a->Hr, Wr = a->Wr, HW = Hr * Wr;
   float* dzp = lds;                                       // [rows16][WG_P], shared by the block
@@ -87,24 +120,29 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_wgrad_kernel(WgArgs a_byval
       const int y = pc / Wr, x = pc - y * Wr;
       __syncthreads();   // previous group's dz panel fully consumed
       {
-        const AT* ap = act_cast<AT>(a->a) + (int64_t)b * a->a_ctot * HW + pc;
-        for (int r = wave; r < nrows; r += 4) {
-          const float v = act_ld(ap + (int64_t)r * HW);
-          dzp[r * WG_P + lane] = valid ? v : 0.f;   // pixels past the plane contribute nothing
+        int rb = 0;
+        for (int q = 0; q < a->nrs; ++q) {
+          const int nq = a->rs[q].n;
+          const AT* ap = act_cast<AT>(a->rs[q].ptr) + (int64_t)b * a->rs[q].ctot * HW + pc;
+          for (int r = wave; r < nq; r += 4) {
+            const float v = act_ld(ap + (int64_t)r * HW);
+            dzp[(rb + r) * WG_P + lane] = valid ? v : 0.f;   // pixels past the plane contribute nothing
+          }
+          rb += nq;
         }
       }
       __syncthreads();
       if (active) {
         const int kend = min(kc + 16, cin);
         CSN_WAVE_SYNC();
-        if (kc < c1) wg_gather<AT>(ps, 0, kc, min(kend, c1), xp + lane, 16, b, y, x, Hr, Wr);
+        if (kc < c1) wg_gather_any<AT>(ps, 0, kc, min(kend, c1), xp + lane, 16, b, y, x, Hr, Wr);
         if (max(kc, c1) < min(kend, c2)) {
           const int r0 = max(kc, c1) - kc;
-          wg_gather<AT>(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
+          wg_gather_any<AT>(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
         }
         if (max(kc, c2) < min(kend, cin)) {
           const int r0 = max(kc, c2) - kc;
-          wg_gather<AT>(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
+          wg_gather_any<AT>(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
         }
         for (int k = max(cin, kc); k < kc + 16; ++k) xp[(k - kc) * WG_P + lane] = 0.f;
         CSN_WAVE_SYNC();
@@ -129,7 +167,14 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_wgrad_wave_kernel(WgArgs a_
   CSN_DYN_SMEM(float, lds);
   WgArgsP a = CSN_KERNARG(WgArgs, a_byval);
   PwPassP ps = &a->ps;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+#ifdef CSN_CPU_EMU
+  const int wave = tid >> 6;
+#else
+  // wave-uniform by construction, but the compiler cannot know: without this every buffer resource derived from the wave's
+  // group index lives in VGPRs and each load becomes a waterfall loop with a full vmcnt(0) wait
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
   const int rows16 = a->rows16, k16 = a->k16, nrows = ps->nrows;
   const int Hr = a->Hr, Wr = a->Wr, HW = Hr * Wr;
   const int wfloats = (rows16 + 16) * WG_P;
@@ -156,9 +201,17 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_wgrad_wave_kernel(WgArgs a_
     const int pc = valid ? p : HW - 1;
     const int y = pc / Wr, x = pc - y * Wr;
     CSN_WAVE_SYNC();   // previous group's panels fully consumed
-    for (int r0 = 0; r0 < nrows; r0 += 16) {
-      const csn_buf rb = csn_make_buf(act_cast<AT>(a->a) + ((int64_t)b * a->a_ctot + r0) * HW);
-      pw_batch_own<AT, 16, WG_P>(rb, (unsigned)pc * (unsigned)sizeof(AT), cs4, 0, min(16, nrows - r0), 16, dzp + r0 * WG_P + lane);
+    {
+      int rbase = 0;
+      for (int q = 0; q < a->nrs; ++q) {
+        const int nq = a->rs[q].n;
+        for (int r0 = 0; r0 < nq; r0 += 16) {
+          const csn_buf rb = csn_make_buf(act_cast<AT>(a->rs[q].ptr) + ((int64_t)b * a->rs[q].ctot + r0) * HW);
+          pw_batch_own<AT, 16, WG_P>(rb, (unsigned)pc * (unsigned)sizeof(AT), cs4, 0, min(16, nq - r0), 16,
+                                     dzp + (rbase + r0) * WG_P + lane);
+        }
+        rbase += nq;
+      }
     }
     if (!valid)   // pixels past the plane contribute nothing
       for (int r = 0; r < nrows; ++r) dzp[r * WG_P + lane] = 0.f;
@@ -168,14 +221,14 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_wgrad_wave_kernel(WgArgs a_
       if (kc < k16) {
         const int kend = min(kc + 16, cin);
         CSN_WAVE_SYNC();
-        if (kc < c1) wg_gather<AT>(ps, 0, kc, min(kend, c1), xp + lane, 16, b, y, x, Hr, Wr);
+        if (kc < c1) wg_gather_any<AT>(ps, 0, kc, min(kend, c1), xp + lane, 16, b, y, x, Hr, Wr);
         if (max(kc, c1) < min(kend, c2)) {
           const int r0 = max(kc, c1) - kc;
-          wg_gather<AT>(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
+          wg_gather_any<AT>(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
         }
         if (max(kc, c2) < min(kend, cin)) {
           const int r0 = max(kc, c2) - kc;
-          wg_gather<AT>(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
+          wg_gather_any<AT>(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
         }
         for (int k = max(cin, kc); k < kc + 16; ++k) xp[(k - kc) * WG_P + lane] = 0.f;
         CSN_WAVE_SYNC();
@@ -237,10 +290,8 @@ __global__ __launch_bounds__(CSN_BLOCK) void wgrad_reduce_kernel(WgReduceArgs a)
 // wave-private variant: 4 groups per block step; returns false when the pass does not fit it
 static bool wgrad_wave_fits(const WgArgs& a) { return a.k16 <= 64 && a.rows16 <= 48; }
 
-int csn_wgrad_blocks(int rows16, int k16, int ngroups) {
-  WgArgs t;
-  t.rows16 = rows16; t.k16 = k16;
-  const int units = wgrad_wave_fits(t) ? (ngroups + 3) / 4 : ngroups;
+int csn_wgrad_blocks(const WgArgs& a) {
+  const int units = wgrad_wave_fits(a) ? (a.ngroups + 3) / 4 : a.ngroups;
   return units < WG_MAX_BLOCKS ? units : WG_MAX_BLOCKS;
 }
 

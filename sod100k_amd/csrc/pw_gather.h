@@ -22,15 +22,16 @@ typedef float csn_f4 __attribute__((ext_vector_type(4)));
 
 typedef const CSN_CONST_AS PwPass* PwPassP;
 
+// LP: type of the panel pointer (float*, or an LDS address-space pointer when the caller is not inlined into the kernel).
 // Gather channels [c_lo, c_hi) of one slice for this lane's pixel into the panel rows starting at xrow
 // (`rmax` rows are left in the panel).  Loads go through a buffer resource whose base is channel c_lo of
 // image b (wave-uniform, SGPRs); the lane contributes one 32-bit byte offset, the channel a uniform SGPR
 // offset.  Every batch issues ALL its loads before the first use (fixed trip count, channel index clamped
 // instead of predicated: a predicated load would be waited for at the join), so a lane has 16-32 loads
 // in flight; rows written past the slice are overwritten by the next slice / the zero padding.
-template <typename AT, int NB, int XP>
+template <typename AT, int NB, int XP, typename LP>
 __device__ __forceinline__ void pw_batch_own(csn_buf rb, unsigned lo, unsigned cs4, int k0, int n, int rmax,
-                                             float* xrow) {
+                                             LP xrow) {
   float v[NB];
 #pragma unroll
   for (int j = 0; j < NB; ++j) v[j] = csn_bufacc<AT>::ld1(rb, lo, (unsigned)min(k0 + j, n - 1) * cs4);
@@ -39,9 +40,9 @@ __device__ __forceinline__ void pw_batch_own(csn_buf rb, unsigned lo, unsigned c
     if (k0 + j < rmax) xrow[(k0 + j) * XP] = v[j];
 }
 
-template <typename AT, int NB, int XP>
+template <typename AT, int NB, int XP, typename LP>
 __device__ __forceinline__ void pw_batch_pool2(csn_buf rb, unsigned lo, unsigned cs4, unsigned ws4, int k0, int n,
-                                               int rmax, float* xrow) {
+                                               int rmax, LP xrow) {
   float2 a0[NB], a1[NB];
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
@@ -54,9 +55,9 @@ __device__ __forceinline__ void pw_batch_pool2(csn_buf rb, unsigned lo, unsigned
     if (k0 + j < rmax) xrow[(k0 + j) * XP] = fmaxf(fmaxf(a0[j].x, a0[j].y), fmaxf(a1[j].x, a1[j].y));
 }
 
-template <typename AT, int NB, int XP>
+template <typename AT, int NB, int XP, typename LP>
 __device__ __forceinline__ void pw_batch_pool4(csn_buf rb, unsigned lo, unsigned cs4, unsigned ws4, int k0, int n,
-                                               int rmax, float* xrow) {
+                                               int rmax, LP xrow) {
   float4 q[NB][4];
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
@@ -73,10 +74,10 @@ __device__ __forceinline__ void pw_batch_pool4(csn_buf rb, unsigned lo, unsigned
   }
 }
 
-template <typename AT, int NB, int XP>
+template <typename AT, int NB, int XP, typename LP>
 __device__ __forceinline__ void pw_batch_up(csn_buf rb, unsigned o00, unsigned o01, unsigned o10, unsigned o11,
                                             float w00, float w01, float w10, float w11, unsigned cs4, int k0, int n,
-                                            int rmax, float* xrow) {
+                                            int rmax, LP xrow) {
   float t0[NB], t1[NB], t2[NB], t3[NB];
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
@@ -93,9 +94,9 @@ __device__ __forceinline__ void pw_batch_up(csn_buf rb, unsigned o00, unsigned o
 
 // 3x3 taps of an own-resolution slice: gathered entry kk = 9*ch + t, t = 3*(dy+1) + (dx+1).  `vm` has
 // bit t set when tap t of this lane's pixel lies inside the image (zero padding otherwise).
-template <typename AT, int NB, int XP>
+template <typename AT, int NB, int XP, typename LP>
 __device__ __forceinline__ void pw_batch_taps(csn_buf rb, unsigned lo, unsigned cs4, int Wr, int dil, unsigned vm,
-                                              int k_lo, int k0, int n, int rmax, float* xrow) {
+                                              int k_lo, int k0, int n, int rmax, LP xrow) {
   float v[NB];
   unsigned m[NB];
 #pragma unroll
@@ -112,9 +113,9 @@ __device__ __forceinline__ void pw_batch_taps(csn_buf rb, unsigned lo, unsigned 
 }
 
 // 3x3 taps of a 2x2-max-pooled slice (source at twice the resolution).
-template <typename AT, int NB, int XP>
+template <typename AT, int NB, int XP, typename LP>
 __device__ __forceinline__ void pw_batch_pool2_taps(csn_buf rb, unsigned lo, unsigned cs4, unsigned ws4, unsigned vm,
-                                                    int k_lo, int k0, int n, int rmax, float* xrow) {
+                                                    int k_lo, int k0, int n, int rmax, LP xrow) {
   float2 a0[NB], a1[NB];
   unsigned m[NB];
 #pragma unroll
@@ -135,9 +136,9 @@ __device__ __forceinline__ void pw_batch_pool2_taps(csn_buf rb, unsigned lo, uns
 
 // 3x3 taps of a zero-stuffed slice (source at half the resolution): the adjoint of a stride-2 3x3 convolution.
 // Tap t of output pixel (y, x) reads source ((y + dy) / 2, (x + dx) / 2) when both coordinates are even and inside.
-template <typename AT, int NB, int XP>
+template <typename AT, int NB, int XP, typename LP>
 __device__ __forceinline__ void pw_batch_taps_ups2(csn_buf rb, int y, int x, int Hr, int Wr, int Ws, unsigned cs4,
-                                                   int k_lo, int k0, int n, int rmax, float* xrow) {
+                                                   int k_lo, int k0, int n, int rmax, LP xrow) {
   constexpr unsigned E = (unsigned)sizeof(AT);
   float v[NB];
   bool m[NB];
@@ -164,31 +165,33 @@ __device__ __forceinline__ unsigned pw_tap_mask(int y, int x, int Hr, int Wr, in
   return vm;
 }
 
-template <typename AT, int XP>
-__device__ __forceinline__ void pw_gather_slice(PwPassP ps, int s, int c_lo, int c_hi, float* xrow, int rmax, int b,
+// MODES 1: the caller guarantees a 1x1 slice (own / max-pool / bilinear) and the 3x3 tap modes are compiled out;
+// MODES 2: the reverse (tap slices only); 0: everything
+template <typename AT, int XP, int MODES = 0, typename LP = float*>
+__device__ __forceinline__ void pw_gather_slice(PwPassP ps, int s, int c_lo, int c_hi, LP xrow, int rmax, int b,
                                                 int y, int x, int Hr, int Wr) {
   const int mode = ps->src[s].mode;
   const int n = c_hi - c_lo;   // 1..16
   constexpr unsigned E = (unsigned)sizeof(AT);   // bytes per element
-  if (mode == PW_OWN) {
+  if (MODES != 2 && mode == PW_OWN) {
     const unsigned cs = (unsigned)(Hr * Wr);
     const csn_buf rb = csn_make_buf(act_cast<AT>(ps->src[s].ptr) + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
     const unsigned lo = (unsigned)(y * Wr + x) * E;
     if (n <= 8) pw_batch_own<AT, 8, XP>(rb, lo, cs * E, 0, n, rmax, xrow);
     else for (int k0 = 0; k0 < n; k0 += 16) pw_batch_own<AT, 16, XP>(rb, lo, cs * E, k0, n, rmax, xrow);
-  } else if (mode == PW_POOL2) {
+  } else if (MODES != 2 && mode == PW_POOL2) {
     const unsigned Ws = (unsigned)Wr * 2u;
     const unsigned cs = (unsigned)(Hr * 2) * Ws;
     const csn_buf rb = csn_make_buf(act_cast<AT>(ps->src[s].ptr) + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
     const unsigned lo = ((unsigned)(2 * y) * Ws + 2u * x) * E;
     for (int k0 = 0; k0 < n; k0 += 8) pw_batch_pool2<AT, 8, XP>(rb, lo, cs * E, Ws * E, k0, n, rmax, xrow);
-  } else if (mode == PW_POOL4) {
+  } else if (MODES != 2 && mode == PW_POOL4) {
     const unsigned Ws = (unsigned)Wr * 4u;
     const unsigned cs = (unsigned)(Hr * 4) * Ws;
     const csn_buf rb = csn_make_buf(act_cast<AT>(ps->src[s].ptr) + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
     const unsigned lo = ((unsigned)(4 * y) * Ws + 4u * x) * E;
     for (int k0 = 0; k0 < n; k0 += 2) pw_batch_pool4<AT, 2, XP>(rb, lo, cs * E, Ws * E, k0, n, rmax, xrow);
-  } else if (mode == PW_TAPS) {
+  } else if (MODES != 1 && mode == PW_TAPS) {
     const unsigned cs = (unsigned)(Hr * Wr);
     const int dil = ps->src[s].dil;
     const csn_buf rb = csn_make_buf_n(act_cast<AT>(ps->src[s].ptr) + (int64_t)b * ps->src[s].Ctot * cs,
@@ -196,7 +199,7 @@ __device__ __forceinline__ void pw_gather_slice(PwPassP ps, int s, int c_lo, int
     const unsigned lo = (unsigned)(y * Wr + x) * E;
     const unsigned vm = pw_tap_mask(y, x, Hr, Wr, dil);
     for (int k0 = 0; k0 < n; k0 += 16) pw_batch_taps<AT, 16, XP>(rb, lo, cs * E, Wr, dil, vm, c_lo, k0, n, rmax, xrow);
-  } else if (mode == PW_POOL2_TAPS) {
+  } else if (MODES != 1 && mode == PW_POOL2_TAPS) {
     const unsigned Ws = (unsigned)Wr * 2u;
     const unsigned cs = (unsigned)(Hr * 2) * Ws;
     const csn_buf rb = csn_make_buf_n(act_cast<AT>(ps->src[s].ptr) + (int64_t)b * ps->src[s].Ctot * cs,
@@ -204,7 +207,7 @@ __device__ __forceinline__ void pw_gather_slice(PwPassP ps, int s, int c_lo, int
     const unsigned lo = ((unsigned)(2 * y) * Ws + 2u * x) * E;
     const unsigned vm = pw_tap_mask(y, x, Hr, Wr, 1);
     for (int k0 = 0; k0 < n; k0 += 8) pw_batch_pool2_taps<AT, 8, XP>(rb, lo, cs * E, Ws * E, vm, c_lo, k0, n, rmax, xrow);
-  } else if (mode == PW_TAPS_S2) {   // Conv2dX100 with stride 2 (csnet.py:751-754): taps (2y + dy, 2x + dx), zero padding
+  } else if (MODES != 1 && mode == PW_TAPS_S2) {   // Conv2dX100 with stride 2 (csnet.py:751-754): taps (2y + dy, 2x + dx), zero padding
     const unsigned Ws = (unsigned)Wr * 2u;
     const unsigned cs = (unsigned)(Hr * 2) * Ws;
     const csn_buf rb = csn_make_buf_n(act_cast<AT>(ps->src[s].ptr) + (int64_t)b * ps->src[s].Ctot * cs,
@@ -214,13 +217,13 @@ __device__ __forceinline__ void pw_gather_slice(PwPassP ps, int s, int c_lo, int
     if (y == 0) vm &= ~0x007u;
     if (x == 0) vm &= ~0x049u;
     for (int k0 = 0; k0 < n; k0 += 16) pw_batch_taps<AT, 16, XP>(rb, lo, cs * E, (int)Ws, 1, vm, c_lo, k0, n, rmax, xrow);
-  } else if (mode == PW_TAPS_UPS2) {
+  } else if (MODES != 1 && mode == PW_TAPS_UPS2) {
     const int Hs = Hr >> 1, Ws = Wr >> 1;
     const unsigned cs = (unsigned)(Hs * Ws);
     const csn_buf rb = csn_make_buf_n(act_cast<AT>(ps->src[s].ptr) + (int64_t)b * ps->src[s].Ctot * cs,
                                       (unsigned)ps->src[s].Ctot * cs * E);
     for (int k0 = 0; k0 < n; k0 += 16) pw_batch_taps_ups2<AT, 16, XP>(rb, y, x, Hr, Wr, Ws, cs * E, c_lo, k0, n, rmax, xrow);
-  } else {  // bilinear from a 2x / 4x coarser branch, align_corners=False
+  } else if (MODES != 2) {  // bilinear from a 2x / 4x coarser branch, align_corners=False
     const int sh = mode == PW_UP2 ? 1 : 2;
     const int Hs = Hr >> sh, Ws = Wr >> sh;
     int y0, y1, x0, x1;

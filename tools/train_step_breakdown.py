@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Per-kernel time of ONE train step from a rocprofv3 --kernel-trace csv: the last fp32 step and the last bf16 step
+(steps are delimited by bce_logits_kernel launches).  usage: train_step_breakdown.py <trace_kernel_trace.csv>"""
+import collections
+import csv
+import re
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("bce_logits")]
+
+
+def step_table(a, b):
+    tot = collections.OrderedDict()
+    for r in rows[a:b]:
+        n = re.sub(r"^void ", "", r["Kernel_Name"].split("(")[0])
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        c = tot.setdefault(n, [0, 0.0])
+        c[0] += 1
+        c[1] += d
+    return tot
+
+
+def is16(tab):
+    return any("csn_bf16" in k for k in tab)
+
+
+steps = [step_table(idx[i], idx[i + 1]) for i in range(len(idx) - 1)]
+f32 = [s for s in steps if not is16(s)]
+b16 = [s for s in steps if is16(s)]
+for name, tab in (("fp32", f32[-1] if f32 else None), ("bf16", b16[-1] if b16 else None)):
+    if tab is None:
+        continue
+    print(f"## {name}: {sum(v[1] for v in tab.values()) / 1e3:.2f} ms of kernel time in one step")
+    for k, v in sorted(tab.items(), key=lambda kv: -kv[1][1])[:32]:
+        print(f"{v[1] / 1e3:8.2f} ms {v[0]:4d}  {k[:90]}")
