@@ -118,35 +118,42 @@ int plan_goct_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
   // so no weight-gradient launch gathers bilinear taps (4 loads per channel and pixel at the finest resolution) and the
   // pass at resolution r is  [adj(dz_0); ..; adj(dz_{r-1}); dz_r] x x_r  (rows = consecutive rows of W, columns = block r)
   // plus  dz_r x [pool(x_0); ..; pool(x_{r-1})]  for the high -> low blocks.
-  const bool regroup = d.ksize == 1 && !u.std_conv && (d.n_in > 1 || d.n_out > 1) && cout_tot <= WG_MAX_ROWS &&
-                       std::getenv("CSN_WGRAD_REGROUP") == nullptr;
+  bool regroup = d.ksize == 1 && !u.std_conv && (d.n_in > 1 || d.n_out > 1) && std::getenv("CSN_WGRAD_REGROUP") == nullptr;
+  for (int j = 0; j < d.n_out; ++j) regroup = regroup && d.cout[j] <= WG_MAX_ROWS;
   if (regroup) {
     for (int r = 0; r < d.n_in; ++r) {
       if (d.cin[r] == 0) continue;
-      WgPlan w;
-      w.L.lvl = base + r;
-      PwPassPlan q;
-      q.r = 0; q.nsrc = 1; q.src_kind[0] = SRC_IN; q.src_branch[0] = r; q.src_C[0] = d.cin[r]; q.src_mode[0] = PW_OWN;
-      q.K = d.cin[r];
-      int first = -1;
-      for (int j = 0; j <= r && j < d.n_out; ++j) {
-        if (d.cout[j] == 0) continue;
-        if (r - j > 2) FAIL(CSN_E_UNSUPPORTED, "bilinear factor > 4");
-        if (first < 0) first = j;
-        WgRowSrc rs;
-        rs.c0 = 0; rs.ctot = d.cout[j]; rs.n = d.cout[j];
-        if (j == r) { rs.kind = SRC_DZ; rs.idx = j; }
-        else { rs.kind = SRC_ADJ; rs.idx = adj_index(j, r); }
-        w.rows.push_back(rs);
-        q.nrows += d.cout[j];
+      // rows = the output branches j <= r, as many per launch as the kernel holds (80 rows)
+      int j = 0;
+      while (j <= r && j < d.n_out) {
+        WgPlan w;
+        w.L.lvl = base + r;
+        PwPassPlan q;
+        q.r = 0; q.nsrc = 1; q.src_kind[0] = SRC_IN; q.src_branch[0] = r; q.src_C[0] = d.cin[r]; q.src_mode[0] = PW_OWN;
+        q.K = d.cin[r];
+        int first = -1;
+        for (; j <= r && j < d.n_out; ++j) {
+          if (d.cout[j] == 0) continue;
+          if (r - j > 2) FAIL(CSN_E_UNSUPPORTED, "bilinear factor > 4");
+          // <= 48 rows (and K <= 64) keeps the launch on the wave-private kernel (no block barrier per pixel group)
+          const int row_cap = d.cin[r] <= 64 ? 48 : WG_MAX_ROWS;
+          if ((q.nrows > 0 && q.nrows + d.cout[j] > row_cap) || w.rows.size() == 3) break;
+          if (first < 0) first = j;
+          WgRowSrc rs;
+          rs.c0 = 0; rs.ctot = d.cout[j]; rs.n = d.cout[j];
+          if (j == r) { rs.kind = SRC_DZ; rs.idx = j; }
+          else { rs.kind = SRC_ADJ; rs.idx = adj_index(j, r); }
+          w.rows.push_back(rs);
+          q.nrows += d.cout[j];
+        }
+        if (q.nrows == 0) continue;
+        w.L.passes.push_back(q);
+        WgBlock g;
+        g.dst = d.w_off[0] + (int64_t)co_off[first] * cin_tot + ci_off[r]; g.ld = cin_tot; g.ncol = d.cin[r]; g.col = 0;
+        g.scale = 1.f; g.tk = 0;
+        w.blocks.push_back(g);
+        ub.wg.push_back(w);
       }
-      if (q.nrows == 0) continue;
-      w.L.passes.push_back(q);
-      WgBlock g;
-      g.dst = d.w_off[0] + (int64_t)co_off[first] * cin_tot + ci_off[r]; g.ld = cin_tot; g.ncol = d.cin[r]; g.col = 0;
-      g.scale = 1.f; g.tk = 0;
-      w.blocks.push_back(g);
-      ub.wg.push_back(w);
     }
     for (int j = 1; j < d.n_out; ++j) {
       if (d.cout[j] == 0) continue;
@@ -343,8 +350,18 @@ int plan_cls_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
   const csn_unit_desc& d = u.d;
   ub.need_dx[0] = d.in_act[0] > 0;
   {
-    WgPlan wg = make_wg(u.pwl[0], u.pwl[0].passes[0]);
-    wg.one_source(SRC_DZ, 0, 0, 1);
+    // dW[0][ci] = sum_p dlogit[p] * x[ci][p]: ONE row against 79 gathered channels would leave 15 of the 16 MFMA rows and
+    // the wave-private kernel (K <= 64) unused -- swap the roles: rows = the input channels, gathered = the logit gradient
+    WgPlan wg;
+    wg.L.lvl = u.pwl[0].lvl;
+    PwPassPlan q;
+    q.r = 0; q.nsrc = 1; q.src_kind[0] = SRC_DZ; q.src_branch[0] = 0; q.src_C[0] = 1; q.src_mode[0] = PW_OWN;
+    q.K = 1; q.nrows = d.cin[0];
+    wg.L.passes.push_back(q);
+    WgBlock g;
+    g.dst = d.w_off[0]; g.ld = d.cin[0]; g.ncol = 1; g.col = 0; g.scale = 1.f; g.tk = 1;
+    wg.blocks.push_back(g);
+    wg.one_source(SRC_IN, 0, 0, d.cin[0]);
     ub.wg.push_back(wg);
   }
   if (!ub.need_dx[0]) return CSN_OK;
@@ -399,12 +416,19 @@ int run_wgrad(const BwdCtx& b, const WgPlan& w, const PwBind& bd) {
   }
   a.gpp = (int)((hw + 63) / 64);
   a.ngroups = a.gpp * P.S;
+  if (std::getenv("CSN_DEBUG_WGRAD")) {
+    std::fprintf(stderr, "wgrad: %dx%d rows %d K %d src", a.Hr, a.Wr, pp.nrows, pp.K);
+    for (int q = 0; q < pp.nsrc; ++q) std::fprintf(stderr, " (mode %d C %d dil %d)", pp.src_mode[q], pp.src_C[q], pp.src_dil[q]);
+    std::fprintf(stderr, " rowsrc %d\n", a.nrs);
+  }
   a.k16 = (pp.K + 15) & ~15;
   a.partial = reinterpret_cast<float*>(b.c.ws + (b.c.side ? P.wg2_off : P.wg_off));
   a.a16 = b.c.a16 ? 1 : 0; a.pad = 0;
   // the kernel holds at most 80 output channels (5 MFMA row tiles) per launch: wider passes go in row chunks
-  for (int r0 = 0; r0 < pp.nrows; r0 += WG_MAX_ROWS) {
-    const int nr = std::min(WG_MAX_ROWS, pp.nrows - r0);
+  // ... and passes with K <= 64 in chunks of 48 rows, which keeps them on the wave-private kernel
+  const int row_chunk = (a.nrs == 1 && a.k16 <= 64 && pp.nrows > 48) ? 48 : WG_MAX_ROWS;
+  for (int r0 = 0; r0 < pp.nrows; r0 += row_chunk) {
+    const int nr = std::min(row_chunk, pp.nrows - r0);
     a.ps.nrows = nr;
     if (a.nrs == 1) {   // row chunks of a single source
       a.rs[0].ptr = b.c.eo(row_base(w.rows[0]), (int64_t)(w.rows[0].c0 + r0) * hw);

@@ -229,6 +229,9 @@ struct WgReduceArgs {
 int csn_launch_wgrad(const WgArgs& a, void* stream);
 int csn_wgrad_blocks(const WgArgs& a);   // partial slices (= blocks) the launch will use (ps, rows16, k16, ngroups set)
 int csn_launch_wgrad_reduce(const WgReduceArgs& a, void* stream);
+bool csn_wgrad_c3_eligible(const WgArgs& a);                 // k_wgrad_c3.hip: LDS-tiled weight gradient of 3x3 tap passes
+int csn_wgrad_c3_blocks(const WgArgs& a);
+int csn_launch_wgrad_c3(const WgArgs& a, void* stream);
 
 // ---------------------------------------------------------------------------------------------
 // train-mode BatchNorm + PReLU + GAP penalty (see k_train.hip)
