@@ -13,29 +13,49 @@
 //   bn_finalize_kernel  per channel: mean / biased var -> folded scale/shift for the apply pass, running-stat
 //                       update in the caller's parameter arena;
 //   bn_apply_gap_kernel y = PReLU(z*scale + shift) in place (float4 stream), per-(n,c) plane sum -> penalty.
+#include <cstdlib>
+
 #include "csn_kernels.h"
 
 #define BN_NSLAB CSN_BN_NSLAB   // max slabs per channel; a launch uses gridDim.x <= BN_NSLAB of them
 
-// A channel's S*HW elements are S contiguous planes; a slab is one chunk of one plane (cpp chunks per plane), so a
-// block streams contiguous memory and never divides: slab = n*cpp + chunk.  About 8K elements per slab.
-static inline int bn_cpp(int S, int64_t hw) {
+// A channel's S*HW elements are S contiguous planes.  A slab is either one chunk of one plane (cpp > 0 chunks per plane,
+// about 8K elements each: slab = n*cpp + chunk) or, for small planes, -cpp whole planes of consecutive images (cpp < 0), so
+// that a block streams >= 16K elements before it pays the reduction tail while the launch still has >= 1024 blocks.
+static inline int bn_cpp(int S, int C, int64_t hw) {
   int64_t cpp = (hw + 8191) / 8192;
   if (cpp < 1) cpp = 1;
   while (cpp > 1 && cpp * S > BN_NSLAB) --cpp;
+  if (cpp == 1) {
+    int64_t ipp = 16384 / (hw > 0 ? hw : 1);
+    const int64_t cap = (int64_t)S * C / 1024;
+    if (ipp > cap) ipp = cap;
+    const char* fe = std::getenv("CSN_BN_IPP");   // tests: exercise the multi-image slabs at small batches
+    const int forced = fe ? std::atoi(fe) : 0;
+    if (forced > 0) ipp = forced < S ? forced : S;
+    if (ipp > 1) return (int)-ipp;
+  }
   return (int)cpp;
 }
+static inline int bn_nslab(int S, int cpp) { return cpp > 0 ? S * cpp : (S + (-cpp) - 1) / (-cpp); }
 
-struct BnRange { int64_t base; int beg, end; };   // element range [beg, end) of the plane at `base`
+struct BnRange { int64_t base; int beg, end, nimg; };   // element range [beg, end) of `nimg` planes, the first at `base`
 
-__device__ __forceinline__ BnRange bn_range(int slab, int cpp, int C, int c, int64_t hw) {
+__device__ __forceinline__ BnRange bn_range(int slab, int cpp, int S, int C, int c, int64_t hw) {
+  BnRange r;
+  if (cpp < 0) {
+    const int ipp = -cpp, n0 = slab * ipp;
+    r.base = ((int64_t)n0 * C + c) * hw;
+    r.beg = 0; r.end = (int)hw; r.nimg = min(ipp, S - n0);
+    return r;
+  }
   const int n = slab / cpp, ch = slab - n * cpp;
   int per = (int)((hw + cpp - 1) / cpp);
   per = (per + 3) & ~3;   // chunks start on a float4 boundary
-  BnRange r;
   r.base = ((int64_t)n * C + c) * hw;
   r.beg = min(ch * per, (int)hw);
   r.end = min(r.beg + per, (int)hw);
+  r.nimg = 1;
   return r;
 }
 
@@ -100,20 +120,22 @@ template <typename AT>
 __global__ __launch_bounds__(CSN_BLOCK) void bn_stats_kernel(BnStatsArgs a) {
   CSN_DYN_SMEM(double, sm);
   const int c = blockIdx.y, slab = blockIdx.x;
-  const BnRange r = bn_range(slab, a.cpp, a.C, c, a.HW);
-  const AT* __restrict__ p = act_cast<AT>(a.z) + r.base;
+  const BnRange r = bn_range(slab, a.cpp, a.S, a.C, c, a.HW);
   double s1 = 0.0, s2 = 0.0;
-  if ((a.HW & 3) == 0) {
-    for (int i = (r.beg >> 2) + threadIdx.x; i < (r.end >> 2); i += CSN_BLOCK) {
-      const float4 v = act_ld4(p + 4 * i);
-      s1 += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
-      s2 += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
-    }
-  } else {
-    for (int i = r.beg + threadIdx.x; i < r.end; i += CSN_BLOCK) {
-      const double v = (double)act_ld(p + i);
-      s1 += v;
-      s2 += v * v;
+  for (int img = 0; img < r.nimg; ++img) {
+    const AT* __restrict__ p = act_cast<AT>(a.z) + r.base + (int64_t)img * a.C * a.HW;
+    if ((a.HW & 3) == 0) {
+      for (int i = (r.beg >> 2) + threadIdx.x; i < (r.end >> 2); i += CSN_BLOCK) {
+        const float4 v = act_ld4(p + 4 * i);
+        s1 += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+        s2 += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+      }
+    } else {
+      for (int i = r.beg + threadIdx.x; i < r.end; i += CSN_BLOCK) {
+        const double v = (double)act_ld(p + i);
+        s1 += v;
+        s2 += v * v;
+      }
     }
   }
   double sv[2] = {s1, s2};
@@ -216,7 +238,7 @@ template <typename AT>
 __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_reduce_kernel(BnBwdArgs a) {
   CSN_DYN_SMEM(double, sm);
   const int c = blockIdx.y, slab = blockIdx.x;
-  const BnRange r = bn_range(slab, a.cpp, a.C, c, a.HW);
+  const BnRange r0 = bn_range(slab, a.cpp, a.S, a.C, c, a.HW);
   const float sc = a.scale[c], sh = a.shift[c], al = a.alpha[c], mu = a.mean[c], is = a.invstd[c];
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   auto acc = [&](float z, float dy) {
@@ -226,6 +248,9 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_reduce_kernel(BnBwdArgs a) {
     s1 += (double)dbn * (double)((z - mu) * is);
     if (!(bn > 0.f)) s2 += (double)dy * (double)bn;
   };
+  for (int img = 0; img < r0.nimg; ++img) {
+  BnRange r = r0;
+  r.base += (int64_t)img * a.C * a.HW;
   if ((a.HW & 3) == 0) {   // chunks start on float4 boundaries (bn_range)
     const AT* z4 = act_cast<AT>(a.z) + r.base;
     const AT* a4 = act_cast<AT>(a.dyA) + r.base;
@@ -239,6 +264,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_reduce_kernel(BnBwdArgs a) {
   } else {
     for (int i = r.beg + threadIdx.x; i < r.end; i += CSN_BLOCK)
       acc(act_ld(act_cast<AT>(a.z) + r.base + i), bnb_dy<AT>(a, r.base + i));
+  }
   }
   double sv[3] = {s0, s1, s2};
   bn_block_sum_n<3>(sv, sm);
@@ -317,12 +343,13 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw_wgrad_kernel(DwWgradArgs a) {
   constexpr unsigned E = (unsigned)sizeof(AT);
   const int c = blockIdx.y, slab = blockIdx.x;
   const int H = a.H, W = a.W;
-  const BnRange r = bn_range(slab, a.cpp, a.C, c, (int64_t)H * W);
-  const AT* __restrict__ gp = act_cast<AT>(a.dz) + r.base;
-  const AT* __restrict__ xp = act_cast<AT>(a.x) + r.base;
+  const BnRange r = bn_range(slab, a.cpp, a.S, a.C, c, (int64_t)H * W);
   float s[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) s[t] = 0.f;
+  for (int img = 0; img < r.nimg; ++img) {
+  const AT* __restrict__ gp = act_cast<AT>(a.dz) + r.base + (int64_t)img * a.C * H * W;
+  const AT* __restrict__ xp = act_cast<AT>(a.x) + r.base + (int64_t)img * a.C * H * W;
   if ((W & 3) == 0) {
     const csn_buf xb = csn_make_buf_n(xp, (unsigned)(H * W) * E);
     for (int q = (r.beg >> 2) + threadIdx.x; q < (r.end >> 2); q += CSN_BLOCK) {
@@ -356,6 +383,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw_wgrad_kernel(DwWgradArgs a) {
         s[t] = fmaf(g, in ? v : 0.f, s[t]);
       }
     }
+  }
   }
   double sv[9];
 #pragma unroll
@@ -581,13 +609,13 @@ __global__ __launch_bounds__(CSN_BLOCK) void adam_kernel(AdamArgs a) {
 
 int csn_launch_bn_stats(const BnStatsArgs& a0, void* stream) {
   BnStatsArgs a = a0;
-  a.cpp = bn_cpp(a.S, a.HW);
-  CSN_LAUNCH_AT(a.a16, bn_stats_kernel, dim3(a.S * a.cpp, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
+  a.cpp = bn_cpp(a.S, a.C, a.HW);
+  CSN_LAUNCH_AT(a.a16, bn_stats_kernel, dim3(bn_nslab(a.S, a.cpp), a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   return (int)hipGetLastError();
 }
 int csn_launch_bn_finalize(const BnFinalizeArgs& a0, void* stream) {
   BnFinalizeArgs a = a0;
-  a.nslab = a.S * bn_cpp(a.S, a.count / a.S);
+  a.nslab = bn_nslab(a.S, bn_cpp(a.S, a.C, a.count / a.S));
   CSN_LAUNCH(bn_finalize_kernel, dim3(a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   return (int)hipGetLastError();
 }
@@ -601,8 +629,8 @@ static inline int grid_for(int64_t n) { return (int)((n + CSN_BLOCK - 1) / CSN_B
 
 int csn_launch_bn_bwd(const BnBwdArgs& a0, void* stream) {
   BnBwdArgs a = a0;
-  a.cpp = bn_cpp(a.S, a.HW);
-  a.nslab = a.S * a.cpp;
+  a.cpp = bn_cpp(a.S, a.C, a.HW);
+  a.nslab = bn_nslab(a.S, a.cpp);
   CSN_LAUNCH_AT(a.a16, bn_bwd_reduce_kernel, dim3(a.nslab, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   CSN_LAUNCH(bn_bwd_finalize_kernel, dim3(a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   CSN_LAUNCH_AT(a.a16, bn_bwd_apply_kernel, dim3(a.C, a.S), dim3(CSN_BLOCK), 0, stream, a);
@@ -610,8 +638,8 @@ int csn_launch_bn_bwd(const BnBwdArgs& a0, void* stream) {
 }
 int csn_launch_dw_wgrad(const DwWgradArgs& a0, void* stream) {
   DwWgradArgs a = a0;
-  a.cpp = bn_cpp(a.S, (int64_t)a.H * a.W);
-  a.nslab = a.S * a.cpp;
+  a.cpp = bn_cpp(a.S, a.C, (int64_t)a.H * a.W);
+  a.nslab = bn_nslab(a.S, a.cpp);
   CSN_LAUNCH_AT(a.a16, dw_wgrad_kernel, dim3(a.nslab, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   CSN_LAUNCH(dw_wgrad_finalize_kernel, dim3(a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   return (int)hipGetLastError();

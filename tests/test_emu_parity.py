@@ -93,3 +93,11 @@ def test_emu_train_units_local(emu_lib, x2_manifest, act_dtype, B, size, state):
     """Every unit's train-mode forward and backward (dz, dx per consumer slot, every parameter gradient) against the oracle
     applied to the tensors the kernels themselves produced around that unit -- no error amplification through depth."""
     print(P.check_train_units_local(emu_lib, CPU, x2_manifest, B=B, size=size, act_dtype=act_dtype, state=state))
+
+
+@pytest.mark.parametrize("act_dtype,ipp", [("fp32", 2), ("bf16", 3)])
+def test_emu_train_units_local_multi_image_slabs(emu_lib, x2_manifest, monkeypatch, act_dtype, ipp):
+    """The BN / depthwise reductions hand several whole planes to one block when the batch is large (batch 256: 5-20 images
+    per block); CSN_BN_IPP forces that path at a batch the emulator can run (5 images: slabs of ipp, ..., remainder)."""
+    monkeypatch.setenv("CSN_BN_IPP", str(ipp))
+    print(P.check_train_units_local(emu_lib, CPU, x2_manifest, B=5, size=32, act_dtype=act_dtype, state="well"))
