@@ -276,6 +276,21 @@ struct BnApplyArgs {
 int csn_launch_bn_stats(const BnStatsArgs& a, void* stream);
 int csn_launch_bn_finalize(const BnFinalizeArgs& a, void* stream);
 int csn_launch_bn_apply(const BnApplyArgs& a, void* stream);
+#define CSN_PEN_JOBS 112
+struct BnPenaltyJob {     // one hooked (unit, output branch): its |GAP| table [C][S], gamma offset, branch weight
+  const float* gapabs;
+  int64_t off_weight;
+  int32_t C, S;
+  float flop_w;
+  int32_t pad;
+};
+struct BnPenaltyArgs {
+  BnPenaltyJob job[CSN_PEN_JOBS];
+  const float* arena;
+  double* partial;
+  int32_t first, n;
+};
+int csn_launch_bn_penalty(const BnPenaltyJob* jobs, int njobs, const float* arena, double* partial, double* penalty, void* stream);
 
 struct BnBwdArgs {
   const float* dyA;    // gradient w.r.t. the branch output y, from its first consumer

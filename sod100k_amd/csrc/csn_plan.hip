@@ -179,6 +179,8 @@ struct csn_plan {
   bool profiling = false;
   size_t ev_used = 0;
   // ---- training (csn_plan_enable_training) ----
+  int64_t pen_off = -1;                         // penalty job terms (workspace bytes), pen_slots doubles
+  int pen_slots = 0;
   bool train = false;
   bool act16 = false;                           // CSN_OPT_TRAIN_BF16: train-mode activations / gradients are bfloat16
   int64_t x16_off = -1;                         // bf16 copy of the input batch (workspace bytes)
@@ -1305,6 +1307,8 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
     bl.job(CSN_PREP_FILL, maxc, P->ident.scale, -1, -1, -1, -1, 1.f);
     bl.job(CSN_PREP_FILL, maxc, P->ident.shift, -1, -1, -1, -1, 0.f);
     bl.job(CSN_PREP_FILL, maxc, P->ident.alpha, -1, -1, -1, -1, 1.f);
+    P->pen_slots = (int)P->units.size() * CSN_MAX_BRANCH;
+    P->pen_off = bl.alloc_ws((int64_t)P->pen_slots * sizeof(double));   // per-job penalty terms of a train-mode forward
     for (auto& u : P->units)
       if (u.d.kind != CSN_UNIT_CLS)
         for (int j = 0; j < u.d.n_out; ++j)
@@ -1523,6 +1527,7 @@ static int forward_train_body(csn_plan* P, const float* x, float* y, void* works
   if (P->S != P->B) { g_hip_err = "train mode needs the whole batch in one slice (sub_batch = 0)"; return CSN_E_UNSUPPORTED; }
   const int nu = (int)P->units.size();
   Ctx c{*P, x, y, static_cast<char*>(workspace), stream};
+  std::vector<BnPenaltyJob> pen_jobs;
   if (P->act16) {   // bf16 activations: needs the training buffers (the bf16 copy of x lives there)
     if (!P->train) { g_hip_err = "CSN_OPT_TRAIN_BF16 needs csn_plan_enable_training"; return CSN_E_STATE; }
     c.a16 = true;
@@ -1558,7 +1563,19 @@ static int forward_train_body(csn_plan* P, const float* x, float* y, void* works
       aa.arena = arena; aa.penalty = penalty; aa.off_weight = d.bn[j].weight; aa.HW = hw; aa.S = P->S; aa.C = d.cout[j];
       aa.flop_w = flop_w[u * CSN_MAX_BRANCH + j]; aa.a16 = c.a16 ? 1 : 0;
       LAUNCH_TRY(csn_launch_bn_apply(aa, stream));
+      if (aa.flop_w != 0.f) {
+        BnPenaltyJob pj;
+        pj.gapabs = aa.gapabs; pj.off_weight = aa.off_weight; pj.C = aa.C; pj.S = aa.S; pj.flop_w = aa.flop_w; pj.pad = 0;
+        pen_jobs.push_back(pj);
+      }
     }
+  }
+  // the Oct_bn_hook penalty of all hooked sub-modules: two launches at the end of the forward (partials live in the first
+  // unit's statistics slab, which the backward pass does not read)
+  if (!pen_jobs.empty()) {
+    if ((int64_t)pen_jobs.size() > (int64_t)P->pen_slots) return CSN_E_UNSUPPORTED;
+    LAUNCH_TRY(csn_launch_bn_penalty(pen_jobs.data(), (int)pen_jobs.size(), arena,
+                                     reinterpret_cast<double*>(c.ws + P->pen_off), penalty, stream));
   }
   return CSN_OK;
 }

@@ -206,19 +206,27 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_apply_gap_kernel(BnApplyArgs a) 
   }
 }
 
-// penalty += 0.5 * w * sum_c gamma_c^2 * sum_n |gap[c][n]|   (Oct_bn_hook, csnet.py:391-410).  One block, fixed
-// summation order, plain read-modify-write of the device scalar (launches are stream ordered): deterministic, and no
-// fp64 atomics from thousands of blocks on one address.
-__global__ __launch_bounds__(CSN_BLOCK) void bn_penalty_kernel(BnApplyArgs a) {
+// penalty += sum_j 0.5 * w_j * sum_c gamma_c^2 * sum_n |gap_j[c][n]|   (Oct_bn_hook, csnet.py:391-410) over all hooked
+// (unit, branch) pairs j of the forward.  One block per job (fixed summation order), then ONE thread adds the job terms to the
+// device scalar in job order -- the same sequence of fp64 additions as one launch per job, without ~100 tiny launches per
+// step; no floating-point atomics.
+__global__ __launch_bounds__(CSN_BLOCK) void bn_penalty_jobs_kernel(BnPenaltyArgs a) {
   CSN_DYN_SMEM(double, sm);
+  const BnPenaltyJob j = a.job[blockIdx.x];
   double t = 0.0;
-  const int total = a.C * a.S;        // lanes walk the [C][S] table linearly (coalesced), fp64 accumulation
+  const int total = j.C * j.S;        // lanes walk the [C][S] table linearly (coalesced), fp64 accumulation
   for (int i = threadIdx.x; i < total; i += CSN_BLOCK) {
-    const double g = (double)a.arena[a.off_weight + i / a.S];
-    t += (double)a.gapabs[i] * (g * g);
+    const double g = (double)a.arena[j.off_weight + i / j.S];
+    t += (double)j.gapabs[i] * (g * g);
   }
   t = bn_block_sum(t, sm);
-  if (threadIdx.x == 0) *a.penalty += 0.5 * (double)a.flop_w * t;
+  if (threadIdx.x == 0) a.partial[a.first + blockIdx.x] = 0.5 * (double)j.flop_w * t;
+}
+__global__ void bn_penalty_sum_kernel(const double* partial, int n, double* penalty) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double p = *penalty;
+  for (int i = 0; i < n; ++i) p += partial[i];
+  *penalty = p;
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -621,7 +629,19 @@ int csn_launch_bn_finalize(const BnFinalizeArgs& a0, void* stream) {
 }
 int csn_launch_bn_apply(const BnApplyArgs& a, void* stream) {
   CSN_LAUNCH_AT(a.a16, bn_apply_gap_kernel, dim3(a.C, a.S), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
-  if (a.flop_w != 0.f) CSN_LAUNCH(bn_penalty_kernel, dim3(1), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
+  return (int)hipGetLastError();
+}
+// all penalty terms of one forward: jobs in forward order, `partial` holds >= njobs doubles
+int csn_launch_bn_penalty(const BnPenaltyJob* jobs, int njobs, const float* arena, double* partial, double* penalty, void* stream) {
+  if (njobs <= 0) return 0;
+  for (int first = 0; first < njobs; first += CSN_PEN_JOBS) {   // the job table rides in the kernel arguments (< 4 KB)
+    BnPenaltyArgs a;
+    const int n = njobs - first < CSN_PEN_JOBS ? njobs - first : CSN_PEN_JOBS;
+    for (int i = 0; i < n; ++i) a.job[i] = jobs[first + i];
+    a.arena = arena; a.partial = partial; a.first = first; a.n = n;
+    CSN_LAUNCH(bn_penalty_jobs_kernel, dim3(n), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
+  }
+  CSN_LAUNCH(bn_penalty_sum_kernel, dim3(1), dim3(64), 0, stream, (const double*)partial, njobs, penalty);
   return (int)hipGetLastError();
 }
 
