@@ -64,7 +64,7 @@ __device__ __forceinline__ void pw_contract(const float* wl, int stride, const f
 // VGPR offset per lane, the channel offset rides in an SGPR; lanes outside the image are exec-masked).
 template <int NT, bool RAW, typename AT>
 __device__ __forceinline__ void pw_sweep(PwPassP ps, const float* wl0, float* xb, int row0, int b, int gy, int gx,
-                                         int Hr, int Wr, unsigned ovoff, bool valid, int lane, float& red) {
+                                         int Hr, int Wr, unsigned ovoff, bool valid, int lane, float& red, unsigned pair_el) {
   const int cin = ps->cin, cin4 = ps->cin4, nrows = ps->nrows, stride = ps->w_stride;
   const int c1 = ps->src[0].K, c2 = c1 + ps->src[1].K;
   csn_f4 acc[NT][4];
@@ -77,14 +77,14 @@ __device__ __forceinline__ void pw_sweep(PwPassP ps, const float* wl0, float* xb
   for (int kc = 0; kc < cin4; kc += PW_KC) {
     const int kend = min(kc + PW_KC, cin4);
     CSN_WAVE_SYNC();  // previous panel fully consumed
-    if (kc < c1) pw_gather_slice<AT, PW_XP>(ps, 0, kc, min(kend, c1), xb + lane, PW_KC, b, gy, gx, Hr, Wr);
+    if (kc < c1) pw_gather_slice<AT, PW_XP>(ps, 0, kc, min(kend, c1), xb + lane, PW_KC, b, gy, gx, Hr, Wr, pair_el);
     if (max(kc, c1) < min(kend, c2)) {
       const int r0 = max(kc, c1) - kc;
-      pw_gather_slice<AT, PW_XP>(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xb + r0 * PW_XP + lane, PW_KC - r0, b, gy, gx, Hr, Wr);
+      pw_gather_slice<AT, PW_XP>(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xb + r0 * PW_XP + lane, PW_KC - r0, b, gy, gx, Hr, Wr, pair_el);
     }
     if (max(kc, c2) < min(kend, cin)) {
       const int r0 = max(kc, c2) - kc;
-      pw_gather_slice<AT, PW_XP>(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xb + r0 * PW_XP + lane, PW_KC - r0, b, gy, gx, Hr, Wr);
+      pw_gather_slice<AT, PW_XP>(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xb + r0 * PW_XP + lane, PW_KC - r0, b, gy, gx, Hr, Wr, pair_el);
     }
     for (int k = max(cin, kc); k < kend; ++k) xb[(k - kc) * PW_XP + lane] = 0.f;  // pad to a multiple of 4
     CSN_WAVE_SYNC();  // panel complete
@@ -167,10 +167,18 @@ __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
         const bool valid = p < npx && py_ < Hr && px_ < Wr;
         const int gy = min(py_, Hr - 1), gx = min(px_, Wr - 1);     // lanes off the image gather a valid pixel
         const unsigned ovoff = (unsigned)(gy * Wr + gx) * (unsigned)sizeof(AT);        // ... and store nothing (exec-masked)
+        // pixel pair (2q, 2q + 1) of the group, q = lane & 31: neighbours in a row (tile widths are even), clamped into the
+        // plane like the lane's own pixel -- own-resolution slices are fetched two pixels per lane (pw_batch_own_pair)
+        unsigned pair_el = CSN_NO_PAIR;
+        if ((Wr & 1) == 0) {
+          const int p2 = (c << 6) + 2 * (lane & 31);
+          const int qy = min((ty0 >> r) + (p2 >> txl), Hr - 1), qx = min((tx0 >> r) + (p2 & ((1 << txl) - 1)), Wr - 2);
+          pair_el = (unsigned)(qy * Wr + qx);
+        }
         float red = 0.f;
         for (int row0 = 0; row0 < nrows; row0 += 32) {
-          if (nrows - row0 <= 16) pw_sweep<1, RAW, AT>(ps, wl0, xb, row0, b, gy, gx, Hr, Wr, ovoff, valid, lane, red);
-          else pw_sweep<2, RAW, AT>(ps, wl0, xb, row0, b, gy, gx, Hr, Wr, ovoff, valid, lane, red);
+          if (nrows - row0 <= 16) pw_sweep<1, RAW, AT>(ps, wl0, xb, row0, b, gy, gx, Hr, Wr, ovoff, valid, lane, red, pair_el);
+          else pw_sweep<2, RAW, AT>(ps, wl0, xb, row0, b, gy, gx, Hr, Wr, ovoff, valid, lane, red, pair_el);
         }
         if (!RAW && ps->red_w && valid) {   // out: [B][1][Hr][Wr]
           const csn_buf ob = csn_make_buf(act_cast<AT>(ps->out) + (int64_t)b * (Hr * Wr));

@@ -53,9 +53,9 @@ __device__ __forceinline__ void wg_mma(const float* dzp, const float* xp, int la
 // sites live at once (390 VGPRs, one wave per SIMD); as a call the kernel needs 125.
 template <typename AT, int MODES>
 __device__ __attribute__((noinline)) void wg_gather(PwPassP ps, int s, int c_lo, int c_hi, float* xrow, int rmax, int b,
-                                                   int y, int x, int Hr, int Wr) {
+                                                   int y, int x, int Hr, int Wr, unsigned pair_elem) {
 #ifdef CSN_CPU_EMU
-  pw_gather_slice<AT, WG_P, MODES>(ps, s, c_lo, c_hi, xrow, rmax, b, y, x, Hr, Wr);
+  pw_gather_slice<AT, WG_P, MODES>(ps, s, c_lo, c_hi, xrow, rmax, b, y, x, Hr, Wr, pair_elem);
 #else
   // arguments of a real call travel in VGPRs: without these the image index (and with it every buffer resource) counts as
   // divergent and each gather load turns into a waterfall loop
@@ -70,7 +70,7 @@ __device__ __attribute__((noinline)) void wg_gather(PwPassP ps, int s, int c_lo,
   // xrow points into the block's LDS panel, but a generic pointer parameter of a real call compiles to flat_store (counted in
   // vmcnt AND lgkmcnt: every panel write then waits for the gather's global loads): go through the LDS address space
   typedef __attribute__((address_space(3))) float* lds_fp;
-  pw_gather_slice<AT, WG_P, MODES, lds_fp>(ps, s, c_lo, c_hi, (lds_fp)xrow, rmax, b, y, x, Hr, Wr);
+  pw_gather_slice<AT, WG_P, MODES, lds_fp>(ps, s, c_lo, c_hi, (lds_fp)xrow, rmax, b, y, x, Hr, Wr, pair_elem);
 #endif
 }
 
@@ -78,9 +78,9 @@ __device__ __attribute__((noinline)) void wg_gather(PwPassP ps, int s, int c_lo,
 // return address then goes through a scratch-saved VGPR on every call)
 template <typename AT>
 __device__ __forceinline__ void wg_gather_any(PwPassP ps, int s, int c_lo, int c_hi, float* xrow, int rmax, int b, int y,
-                                              int x, int Hr, int Wr) {
-  if (pw_mode_taps(ps->src[s].mode)) wg_gather<AT, 2>(ps, s, c_lo, c_hi, xrow, rmax, b, y, x, Hr, Wr);
-  else wg_gather<AT, 1>(ps, s, c_lo, c_hi, xrow, rmax, b, y, x, Hr, Wr);
+                                              int x, int Hr, int Wr, unsigned pair_elem) {
+  if (pw_mode_taps(ps->src[s].mode)) wg_gather<AT, 2>(ps, s, c_lo, c_hi, xrow, rmax, b, y, x, Hr, Wr, pair_elem);
+  else wg_gather<AT, 1>(ps, s, c_lo, c_hi, xrow, rmax, b, y, x, Hr, Wr, pair_elem);
 }
 
 template <int NT, typename AT>
@@ -114,7 +114,10 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_wgrad_kernel(WgArgs a_byval
       for (int i = 0; i < 4; ++i) acc[t][i] = 0.f;
     for (int g = blockIdx.x; g < a->ngroups; g += a->nblk) {
       const int b = g / a->gpp;
-      const int p = (g - b * a->gpp) * 64 + lane;
+      const int gp0 = (g - b * a->gpp) * 64;    // first pixel of the group (uniform)
+      const int p = gp0 + lane;
+      // pixel pair of this lane in the paired gathers (clamped into the plane; planes with an odd pixel count: none)
+      const unsigned pair_el = (HW & 1) ? CSN_NO_PAIR : min((unsigned)gp0 + 2u * (lane & 31), (unsigned)HW - 2u);
       const bool valid = p < HW;
       const int pc = valid ? p : HW - 1;
       const int y = pc / Wr, x = pc - y * Wr;
@@ -135,14 +138,14 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_wgrad_kernel(WgArgs a_byval
       if (active) {
         const int kend = min(kc + 16, cin);
         CSN_WAVE_SYNC();
-        if (kc < c1) wg_gather_any<AT>(ps, 0, kc, min(kend, c1), xp + lane, 16, b, y, x, Hr, Wr);
+        if (kc < c1) wg_gather_any<AT>(ps, 0, kc, min(kend, c1), xp + lane, 16, b, y, x, Hr, Wr, pair_el);
         if (max(kc, c1) < min(kend, c2)) {
           const int r0 = max(kc, c1) - kc;
-          wg_gather_any<AT>(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
+          wg_gather_any<AT>(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr, pair_el);
         }
         if (max(kc, c2) < min(kend, cin)) {
           const int r0 = max(kc, c2) - kc;
-          wg_gather_any<AT>(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
+          wg_gather_any<AT>(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr, pair_el);
         }
         for (int k = max(cin, kc); k < kc + 16; ++k) xp[(k - kc) * WG_P + lane] = 0.f;
         CSN_WAVE_SYNC();
@@ -196,7 +199,9 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_wgrad_wave_kernel(WgArgs a_
   for (int g0 = blockIdx.x * 4; g0 < a->ngroups; g0 += a->nblk * 4) {
     const int g = min(g0 + wave, a->ngroups - 1);
     const int b = g / a->gpp;
-    const int p = (g - b * a->gpp) * 64 + lane;
+    const int gp0 = (g - b * a->gpp) * 64;      // first pixel of the group (wave-uniform)
+    const int p = gp0 + lane;
+    const unsigned pair_el = (HW & 1) ? CSN_NO_PAIR : min((unsigned)gp0 + 2u * (lane & 31), (unsigned)HW - 2u);
     const bool valid = p < HW && g0 + wave < a->ngroups;
     const int pc = valid ? p : HW - 1;
     const int y = pc / Wr, x = pc - y * Wr;
@@ -207,12 +212,21 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_wgrad_wave_kernel(WgArgs a_
         const int nq = a->rs[q].n;
         for (int r0 = 0; r0 < nq; r0 += 16) {
           const csn_buf rb = csn_make_buf(act_cast<AT>(a->rs[q].ptr) + ((int64_t)b * a->rs[q].ctot + r0) * HW);
-          pw_batch_own<AT, 16, WG_P>(rb, (unsigned)pc * (unsigned)sizeof(AT), cs4, 0, min(16, nq - r0), 16,
-                                     dzp + (rbase + r0) * WG_P + lane);
+          if (CSN_PAIR_GATHER(AT) && (HW & 1) == 0) {   // two pixels per lane, two rows per load (pw_batch_own_pair)
+            constexpr unsigned E = (unsigned)sizeof(AT);
+            const int pq = lane & 31, half = lane >> 5, nn = min(16, nq - r0);
+            const unsigned pb = min((unsigned)gp0 + 2u * pq, (unsigned)HW - 2u);
+            pw_batch_own_pair<AT, 16, WG_P>(rb, pb * E + ((nn >= 2 && half) ? (unsigned)HW * E : 0u), half, (unsigned)HW * E, 0, nn,
+                                            16, dzp + (rbase + r0) * WG_P + 2 * pq);
+          } else {
+            pw_batch_own<AT, 16, WG_P>(rb, (unsigned)pc * (unsigned)sizeof(AT), cs4, 0, min(16, nq - r0), 16,
+                                       dzp + (rbase + r0) * WG_P + lane);
+          }
         }
         rbase += nq;
       }
     }
+    CSN_WAVE_SYNC();   // the paired loads wrote other lanes' pixels
     if (!valid)   // pixels past the plane contribute nothing
       for (int r = 0; r < nrows; ++r) dzp[r * WG_P + lane] = 0.f;
 #pragma unroll
@@ -221,14 +235,14 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_wgrad_wave_kernel(WgArgs a_
       if (kc < k16) {
         const int kend = min(kc + 16, cin);
         CSN_WAVE_SYNC();
-        if (kc < c1) wg_gather_any<AT>(ps, 0, kc, min(kend, c1), xp + lane, 16, b, y, x, Hr, Wr);
+        if (kc < c1) wg_gather_any<AT>(ps, 0, kc, min(kend, c1), xp + lane, 16, b, y, x, Hr, Wr, pair_el);
         if (max(kc, c1) < min(kend, c2)) {
           const int r0 = max(kc, c1) - kc;
-          wg_gather_any<AT>(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
+          wg_gather_any<AT>(ps, 1, max(kc, c1) - c1, min(kend, c2) - c1, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr, pair_el);
         }
         if (max(kc, c2) < min(kend, cin)) {
           const int r0 = max(kc, c2) - kc;
-          wg_gather_any<AT>(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr);
+          wg_gather_any<AT>(ps, 2, max(kc, c2) - c2, min(kend, cin) - c2, xp + r0 * WG_P + lane, 16 - r0, b, y, x, Hr, Wr, pair_el);
         }
         for (int k = max(cin, kc); k < kc + 16; ++k) xp[(k - kc) * WG_P + lane] = 0.f;
         CSN_WAVE_SYNC();

@@ -18,6 +18,12 @@ typedef float csn_f4 __attribute__((ext_vector_type(4)));
 #define CSN_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #endif
 
+// paired gathers (pw_batch_own_pair): bf16 always; float by default too (measured: train step 95.6 -> 91.7 ms), -DCSN_PAIR_F32=0 for A/B
+#ifndef CSN_PAIR_F32
+#define CSN_PAIR_F32 1
+#endif
+#define CSN_PAIR_GATHER(AT) (sizeof(AT) == 2 || CSN_PAIR_F32)
+
 #define PW_EP 68   // pitch of the epilogue transpose: rows 4 apart land on the other half of the banks
 
 typedef const CSN_CONST_AS PwPass* PwPassP;
@@ -38,6 +44,33 @@ __device__ __forceinline__ void pw_batch_own(csn_buf rb, unsigned lo, unsigned c
 #pragma unroll
   for (int j = 0; j < NB; ++j)
     if (k0 + j < rmax) xrow[(k0 + j) * XP] = v[j];
+}
+
+// Groups of 64 CONSECUTIVE pixels (weight-gradient kernels): lanes 0-31 fetch the group's 32 pixel pairs of one channel (one
+// dword of two bf16 / one dwordx2 of two floats per lane) and lanes 32-63 those of the next channel -- one load instruction
+// per TWO channels.  16-bit loads retire at the 32-bit instruction rate (tools/probes/ld16_probe.hip), and these kernels are
+// bound by the number of instructions, so this halves the gather's cost in the bf16 mode.  `pair_off` = byte offset of
+// this lane's pixel pair inside the plane (+ one plane for the upper half, 0 there when the slice has a single channel),
+// xpair = panel base + 2 * (lane & 31), half = lane >> 5.  Rows past the slice repeat its last channel pair (same data, same
+// row: harmless); rows >= rmax are not written.
+template <typename AT, int NB, int XP, typename LP>
+__device__ __forceinline__ void pw_batch_own_pair(csn_buf rb, unsigned pair_off, int half, unsigned cs2, int k0, int n, int rmax,
+                                                  LP xpair) {
+  float2 v[NB / 2];
+  int row[NB / 2];
+  const int last = n >= 2 ? n - 2 : 0;
+#pragma unroll
+  for (int j = 0; j < NB / 2; ++j) {
+    const int cb = min(k0 + 2 * j, last);
+    row[j] = cb + (n >= 2 ? half : 0);
+    v[j] = csn_bufacc<AT>::ld2(rb, pair_off, (unsigned)cb * cs2);
+  }
+#pragma unroll
+  for (int j = 0; j < NB / 2; ++j)
+    if (row[j] < rmax) {
+      xpair[row[j] * XP] = v[j].x;
+      xpair[row[j] * XP + 1] = v[j].y;
+    }
 }
 
 template <typename AT, int NB, int XP, typename LP>
@@ -167,15 +200,31 @@ __device__ __forceinline__ unsigned pw_tap_mask(int y, int x, int Hr, int Wr, in
 
 // MODES 1: the caller guarantees a 1x1 slice (own / max-pool / bilinear) and the 3x3 tap modes are compiled out;
 // MODES 2: the reverse (tap slices only); 0: everything
+// pair_elem: element index inside the plane of the pixel PAIR this lane fetches in the paired own-resolution gather -- pixels
+// 2q, 2q + 1 of the wave's group, q = lane & 31, which must be neighbours in memory (clamped into the plane by the caller);
+// CSN_NO_PAIR: not available (odd plane / row width).
+#define CSN_NO_PAIR 0xffffffffu
 template <typename AT, int XP, int MODES = 0, typename LP = float*>
 __device__ __forceinline__ void pw_gather_slice(PwPassP ps, int s, int c_lo, int c_hi, LP xrow, int rmax, int b,
-                                                int y, int x, int Hr, int Wr) {
+                                                int y, int x, int Hr, int Wr, unsigned pair_elem = CSN_NO_PAIR) {
   const int mode = ps->src[s].mode;
   const int n = c_hi - c_lo;   // 1..16
   constexpr unsigned E = (unsigned)sizeof(AT);   // bytes per element
   if (MODES != 2 && mode == PW_OWN) {
     const unsigned cs = (unsigned)(Hr * Wr);
     const csn_buf rb = csn_make_buf(act_cast<AT>(ps->src[s].ptr) + ((int64_t)b * ps->src[s].Ctot + c_lo) * cs);
+    if (CSN_PAIR_GATHER(AT) && pair_elem != CSN_NO_PAIR) {
+      // a lane writes OTHER lanes' panel columns here: everything the previous slice wrote to those rows (its clamped
+      // duplicates past the slice end) must be in the panel first.  A wave runs in lockstep, so on the device this is only a
+      // compiler fence; the CPU emulation (lanes = sequential fibers) needs the hand-off.
+      CSN_WAVE_SYNC();
+      const int lane = (int)(threadIdx.x & 63), q = lane & 31, half = lane >> 5;
+      const unsigned pair_off = pair_elem * E + ((n >= 2 && half) ? cs * E : 0u);
+      LP xpair = xrow - lane + 2 * q;
+      if (n <= 8) pw_batch_own_pair<AT, 8, XP>(rb, pair_off, half, cs * E, 0, n, rmax, xpair);
+      else pw_batch_own_pair<AT, 16, XP>(rb, pair_off, half, cs * E, 0, n, rmax, xpair);
+      return;
+    }
     const unsigned lo = (unsigned)(y * Wr + x) * E;
     if (n <= 8) pw_batch_own<AT, 8, XP>(rb, lo, cs * E, 0, n, rmax, xrow);
     else for (int k0 = 0; k0 < n; k0 += 16) pw_batch_own<AT, 16, XP>(rb, lo, cs * E, k0, n, rmax, xrow);
