@@ -548,7 +548,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
       br.w9 = c.pk(ub.dwf_w[k]);
       br.scale = c.pk(P.ident.scale); br.shift = c.pk(P.ident.shift); br.alpha = c.pk(P.ident.alpha);
       br.w9b = br.scale_b = br.shift_b = br.alpha_b = nullptr;
-      br.pool = nullptr; br.skip_out = 0;
+      br.pool = nullptr; br.skip_out = 0; br.stats = nullptr;
       br.C = d.cout[k]; br.H = H; br.W = W;
       const int cols = (br.W + 3) / 4;
       br.LX = cols < 64 ? cols : 64;

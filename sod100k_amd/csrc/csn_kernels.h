@@ -49,6 +49,8 @@ struct DwBranch {
   const float* scale_b;
   const float* shift_b;
   const float* alpha_b;
+  double* stats;         // single-unit kernel, train mode: BN statistics partials [C][CSN_BN_NSLAB][2] of the stored output,
+                         // one per (image, tile): slab = b * tiles_x * tiles_y + tile (null: none)
   float* pool;           // dw3x3x2 only: 2x2 average of the pair's output [B*C][H/2][W/2] for the stride-2 unit that
                          // follows (csnet.py:679-680), null = none;  skip_out: that unit is the only reader
   int32_t skip_out;
@@ -256,7 +258,7 @@ struct BnFinalizeArgs {
   int64_t count;      // S * HW
   int32_t C;
   int32_t S;
-  int32_t nslab;      // set by the launcher
+  int32_t nslab;      // set by the launcher; > 0 on entry: partials were written by the convolution kernel, that many per channel
 };
 struct BnApplyArgs {
   const float* z;     // raw conv output (kept for the backward pass)

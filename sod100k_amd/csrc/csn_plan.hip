@@ -571,6 +571,7 @@ struct Ctx {
   bool lanes = false; // eval forward outside profiling: independent launches may go to the plan's auxiliary streams
   bool side = false;  // backward: this context enqueues on the weight-gradient side lane (own partial buffers)
   bool a16 = false;   // bf16 train mode: every activation tensor in the workspace is bfloat16
+  bool dw_stats = false;   // train-mode forward: depthwise units reduce their own BN statistics
   const float* sc(const Epi& e) const { return P.packed + (raw ? P.ident.scale : e.scale); }
   const float* sh(const Epi& e) const { return P.packed + (raw ? P.ident.shift : e.shift); }
   const float* al(const Epi& e) const { return P.packed + (raw ? P.ident.alpha : e.alpha); }
@@ -615,6 +616,27 @@ int choose_dw_rows(int H, int NY) {
     if (s > best_s + 1e-9) { best_s = s; best = R; }
   }
   return best;
+}
+
+// statistics partials per channel when the train-mode depthwise kernel reduces its own output (one per image and tile), 0 when
+// they would not fit the [C][CSN_BN_NSLAB] table
+int dw_stats_slabs(const csn_plan& P, int lvl) {
+  if (std::getenv("CSN_DW_STATS") && std::getenv("CSN_DW_STATS")[0] == '0') return 0;
+  const int H = P.H >> lvl, W = P.W >> lvl;
+  const int cols = (W + 3) / 4;
+  const int LX = cols < 64 ? cols : 64, NY = CSN_BLOCK / LX;
+  const int tiles_x = (cols + LX - 1) / LX;
+  const int R = choose_dw_rows(H, NY);
+  const int tiles_y = (H + NY * R - 1) / (NY * R);
+  const int64_t n = (int64_t)P.S * tiles_x * tiles_y;
+  return n <= CSN_BN_NSLAB ? (int)n : 0;
+}
+// ... for every branch of a depthwise unit, or for none
+bool dw_unit_stats(const csn_plan& P, const UnitPlan& u) {
+  if (u.d.kind != CSN_UNIT_DW) return false;
+  for (int k = 0; k < u.d.n_in; ++k)
+    if (u.d.cout[k] > 0 && dw_stats_slabs(P, P.acts[u.d.in_act[k]].lvl) == 0) return false;
+  return true;
 }
 
 // pointers a launch's sources / outputs resolve to, by SrcKind / OutKind and branch
@@ -763,7 +785,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
         br.w9 = c.pk(u.dw_w[k]);
         br.scale = c.sc(u.dw_epi[k]); br.shift = c.sh(u.dw_epi[k]); br.alpha = c.al(u.dw_epi[k]);
         br.w9b = br.scale_b = br.shift_b = br.alpha_b = nullptr;
-        br.pool = nullptr; br.skip_out = 0;
+        br.pool = nullptr; br.skip_out = 0; br.stats = nullptr;
         br.C = d.cout[k]; br.H = P.H >> act.lvl; br.W = P.W >> act.lvl;
         const int cols = (br.W + 3) / 4;
         br.LX = cols < 64 ? cols : 64;
@@ -785,8 +807,16 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
         br.tiles_y = (br.H + br.NY * br.R - 1) / (br.NY * br.R);
         blk += br.tiles_x * br.tiles_y * br.C * S;
         br.blk_end = blk;
+        // train-mode forward: the kernel also leaves the BN statistics partials of its (stored) output
+        if (c.dw_stats && !fused && dw_stats_slabs(P, act.lvl) > 0)
+          br.stats = reinterpret_cast<double*>(c.ws + u.stats_off[k]);
       }
       if (a.nbr == 0) return CSN_OK;
+      if (c.dw_stats) {   // all branches or none (one kernel instantiation per launch)
+        bool all = true;
+        for (int q = 0; q < a.nbr; ++q) all = all && a.br[q].stats != nullptr;
+        if (!all) for (int q = 0; q < a.nbr; ++q) a.br[q].stats = nullptr;
+      }
       if (fused) LAUNCH_TRY(csn_launch_dw2(a, c.stream));
       else LAUNCH_TRY(csn_launch_dw(a, c.stream));
       { const int ms_ = c.mark(fused ? "dw3x3x2_bn_prelu_kernel" : "dw3x3_bn_prelu_kernel"); if (ms_ != CSN_OK) return ms_; }
@@ -1534,10 +1564,12 @@ static int forward_train_body(csn_plan* P, const float* x, float* y, void* works
     const int64_t nx = (int64_t)P->S * P->acts[0].channels * P->H * P->W;   // H, W are multiples of 16
     LAUNCH_TRY(csn_launch_to_bf16(x, c.ws + P->x16_off, nx, stream));
   }
+  c.dw_stats = true;
   for (int u = 0; u < nu; ++u) {
     const UnitPlan& up = P->units[u];
     const csn_unit_desc& d = up.d;
     c.raw = d.kind != CSN_UNIT_CLS;
+    const bool stats_done = dw_unit_stats(*P, up);     // the depthwise kernel writes the statistics partials itself
     const int st = run_unit(c, up, nullptr);           // raw z of every output branch (no depthwise fusion)
     if (st != CSN_OK) return st;
     if (d.kind == CSN_UNIT_CLS) continue;
@@ -1548,8 +1580,9 @@ static int forward_train_body(csn_plan* P, const float* x, float* y, void* works
       float* z = c.act_out(d.out_act[j]);      // raw conv output (its own buffer when training is enabled)
       double* part = reinterpret_cast<double*>(c.ws + up.stats_off[j]);
       BnStatsArgs sa; sa.z = z; sa.partial = part; sa.S = P->S; sa.C = d.cout[j]; sa.HW = hw; sa.a16 = c.a16 ? 1 : 0;
-      LAUNCH_TRY(csn_launch_bn_stats(sa, stream));
+      if (!stats_done) LAUNCH_TRY(csn_launch_bn_stats(sa, stream));
       BnFinalizeArgs fa; fa.partial = part; fa.arena = arena;
+      fa.nslab = stats_done ? dw_stats_slabs(*P, act.lvl) : 0;
       fa.scale = P->packed + up.out_epi[j].scale; fa.shift = P->packed + up.out_epi[j].shift;
       fa.off_weight = d.bn[j].weight; fa.off_bias = d.bn[j].bias; fa.off_rmean = d.bn[j].running_mean;
       fa.off_rvar = d.bn[j].running_var; fa.count = (int64_t)P->S * hw; fa.C = d.cout[j]; fa.S = P->S;

@@ -6,6 +6,7 @@
 //   avg-pool 2x2/2   gOctaveConv stride==2 prologue  csnet.py:679-680
 //   bilinear         F.interpolate(size=x.size()[2:], 'bilinear', align_corners=False)  csnet.py:382-385
 #include "csn_kernels.h"
+#include "csn_reduce.h"
 
 // ------------------------------------------------------------------------------------------ prep
 __global__ __launch_bounds__(CSN_BLOCK) void csn_prep_kernel(const CsnPrepJob* __restrict__ jobs,
@@ -123,10 +124,12 @@ __device__ __forceinline__ DwRow dw_load_row(csn_buf rb, int y, int x0, int W, b
   return r;
 }
 
-template <bool VEC, typename AT = float>
+// STATS: also accumulate sum / sum of squares of the values as STORED (train mode: the raw conv output z whose batch
+// statistics the BatchNorm that follows needs -- saves bn_stats_kernel's pass over z)
+template <bool VEC, typename AT = float, bool STATS = false>
 __device__ __forceinline__ void dw_emit(AT* __restrict__ op, int y, int yend, int x0, int W,
                                         const float (&w)[9], float sc, float sh, float al, const DwRow& top,
-                                        const DwRow& mid, const DwRow& bot) {
+                                        const DwRow& mid, const DwRow& bot, double* st = nullptr) {
   if (y >= yend) return;
   float o[4];
 #pragma unroll
@@ -143,6 +146,15 @@ __device__ __forceinline__ void dw_emit(AT* __restrict__ op, int y, int yend, in
     o[j] = csn_epi(acc, sc, sh, al);
   }
   AT* q = op + (int64_t)y * W + x0;
+  if (STATS) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (VEC || x0 + j < W) {
+        const double v = (double)(sizeof(AT) == 2 ? csn_bf2f(csn_f2bf(o[j])) : o[j]);
+        st[0] += v;
+        st[1] += v * v;
+      }
+  }
   if (VEC) {
     act_st4(q, make_float4(o[0], o[1], o[2], o[3]));
   } else {
@@ -152,8 +164,9 @@ __device__ __forceinline__ void dw_emit(AT* __restrict__ op, int y, int yend, in
   }
 }
 
-template <bool VEC, typename AT>
+template <bool VEC, typename AT, bool STATS>
 __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
+  CSN_DYN_SMEM(double, sm);   // STATS only
   int bid = blockIdx.x;
   int k = 0;
   if (a.nbr > 1 && bid >= a.br[0].blk_end) k = 1;
@@ -167,34 +180,45 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
   const int tx = tile % br.tiles_x, ty = tile / br.tiles_x;
   const int tid = threadIdx.x;
   const int lx = tid % br.LX, ly = tid / br.LX;
-  if (ly >= br.NY) return;
   const int H = br.H, W = br.W;
   const int x0 = (tx * br.LX + lx) * 4;
   const int y0 = (ty * br.NY + ly) * br.R;
-  if (x0 >= W || y0 >= H) return;
-  const csn_buf rb = csn_make_buf_n(act_cast<AT>(br.in) + (int64_t)pc * H * W, (unsigned)(H * W) * (unsigned)sizeof(AT));
-  AT* __restrict__ op = act_cast<AT>(br.out) + (int64_t)pc * H * W;
-  float w[9];
-  csn_cfp w9 = csn_const(br.w9);
+  const bool active = ly < br.NY && x0 < W && y0 < H;
+  double st[2] = {0.0, 0.0};
+  if (active) {
+    const csn_buf rb = csn_make_buf_n(act_cast<AT>(br.in) + (int64_t)pc * H * W, (unsigned)(H * W) * (unsigned)sizeof(AT));
+    AT* __restrict__ op = act_cast<AT>(br.out) + (int64_t)pc * H * W;
+    float w[9];
+    csn_cfp w9 = csn_const(br.w9);
 #pragma unroll
-  for (int i = 0; i < 9; ++i) w[i] = w9[c * 9 + i];
-  const float sc = csn_const(br.scale)[c], sh = csn_const(br.shift)[c], al = csn_const(br.alpha)[c];
-  const bool has_l = x0 > 0, has_r = x0 + 4 < W;
+    for (int i = 0; i < 9; ++i) w[i] = w9[c * 9 + i];
+    const float sc = csn_const(br.scale)[c], sh = csn_const(br.shift)[c], al = csn_const(br.alpha)[c];
+    const bool has_l = x0 > 0, has_r = x0 + 4 < W;
 
-  DwRow r0 = dw_load_row<VEC, AT>(rb, y0 - 1, x0, W, has_l, has_r);
-  DwRow r1 = dw_load_row<VEC, AT>(rb, y0, x0, W, has_l, has_r);
-  const int yend = min(y0 + br.R, H);
-  for (int y = y0; y < yend; y += 4) {
-    const DwRow n0 = dw_load_row<VEC, AT>(rb, y + 1, x0, W, has_l, has_r);
-    const DwRow n1 = dw_load_row<VEC, AT>(rb, y + 2, x0, W, has_l, has_r);
-    const DwRow n2 = dw_load_row<VEC, AT>(rb, y + 3, x0, W, has_l, has_r);
-    const DwRow n3 = dw_load_row<VEC, AT>(rb, y + 4, x0, W, has_l, has_r);
-    dw_emit<VEC, AT>(op, y, yend, x0, W, w, sc, sh, al, r0, r1, n0);
-    dw_emit<VEC, AT>(op, y + 1, yend, x0, W, w, sc, sh, al, r1, n0, n1);
-    dw_emit<VEC, AT>(op, y + 2, yend, x0, W, w, sc, sh, al, n0, n1, n2);
-    dw_emit<VEC, AT>(op, y + 3, yend, x0, W, w, sc, sh, al, n1, n2, n3);
-    r0 = n2;
-    r1 = n3;
+    DwRow r0 = dw_load_row<VEC, AT>(rb, y0 - 1, x0, W, has_l, has_r);
+    DwRow r1 = dw_load_row<VEC, AT>(rb, y0, x0, W, has_l, has_r);
+    const int yend = min(y0 + br.R, H);
+    for (int y = y0; y < yend; y += 4) {
+      const DwRow n0 = dw_load_row<VEC, AT>(rb, y + 1, x0, W, has_l, has_r);
+      const DwRow n1 = dw_load_row<VEC, AT>(rb, y + 2, x0, W, has_l, has_r);
+      const DwRow n2 = dw_load_row<VEC, AT>(rb, y + 3, x0, W, has_l, has_r);
+      const DwRow n3 = dw_load_row<VEC, AT>(rb, y + 4, x0, W, has_l, has_r);
+      dw_emit<VEC, AT, STATS>(op, y, yend, x0, W, w, sc, sh, al, r0, r1, n0, st);
+      dw_emit<VEC, AT, STATS>(op, y + 1, yend, x0, W, w, sc, sh, al, r1, n0, n1, st);
+      dw_emit<VEC, AT, STATS>(op, y + 2, yend, x0, W, w, sc, sh, al, n0, n1, n2, st);
+      dw_emit<VEC, AT, STATS>(op, y + 3, yend, x0, W, w, sc, sh, al, n1, n2, n3, st);
+      r0 = n2;
+      r1 = n3;
+    }
+  }
+  if (STATS) {   // one (sum, sum of squares) partial per (image, tile) of the channel: slab = b * tiles + tile
+    bn_block_sum_n<2>(st, sm);
+    if (tid == 0) {
+      const int b = pc / br.C;
+      double* o = br.stats + ((int64_t)c * CSN_BN_NSLAB + (int64_t)b * tiles + tile) * 2;
+      o[0] = st[0];
+      o[1] = st[1];
+    }
   }
 }
 
@@ -372,14 +396,23 @@ int csn_launch_dw(const DwArgs& a, void* stream) {
   if (nblk <= 0) return 0;
   bool vec = true;  // float4 path needs every branch width to be a multiple of 4
   for (int k = 0; k < a.nbr; ++k) vec = vec && (a.br[k].W % 4 == 0);
+  bool stats = true;   // every branch of the launch carries a statistics table (train-mode forward), or none does
+  for (int k = 0; k < a.nbr; ++k) stats = stats && a.br[k].stats != nullptr;
+  const size_t sml = stats ? CSN_BLOCK * sizeof(double) : 0;
+#define DW_LAUNCH(V, T)                                                                                        \
+  do {                                                                                                         \
+    if (stats) CSN_LAUNCH((dw3x3_bn_prelu_kernel<V, T, true>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);   \
+    else CSN_LAUNCH((dw3x3_bn_prelu_kernel<V, T, false>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);          \
+  } while (0)
   if (a.a16) {
-    if (vec) CSN_LAUNCH((dw3x3_bn_prelu_kernel<true, csn_bf16>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
-    else CSN_LAUNCH((dw3x3_bn_prelu_kernel<false, csn_bf16>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+    if (vec) DW_LAUNCH(true, csn_bf16);
+    else DW_LAUNCH(false, csn_bf16);
   } else if (vec) {
-    CSN_LAUNCH((dw3x3_bn_prelu_kernel<true, float>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+    DW_LAUNCH(true, float);
   } else {
-    CSN_LAUNCH((dw3x3_bn_prelu_kernel<false, float>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+    DW_LAUNCH(false, float);
   }
+#undef DW_LAUNCH
   return (int)hipGetLastError();
 }
 
