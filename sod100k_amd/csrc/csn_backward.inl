@@ -540,7 +540,32 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
       DwWgradArgs w;
       w.a16 = c.a16 ? 1 : 0;
       w.dz = bd.dz[k]; w.x = bd.in[k]; w.partial = reinterpret_cast<double*>(c.ws + (cs.side ? P.red2_off : P.red_off)); w.grad = b.grad;
-      w.off_w = d.w_off[k]; w.C = d.cout[k]; w.S = S; w.H = H; w.W = W;
+      w.off_w = d.w_off[k]; w.C = d.cout[k]; w.S = S; w.H = H; w.W = W; w.nslab = 0;
+      // input and weight gradient in ONE pass over dz and x when both are wanted and the per-(image, tile) partials fit
+      // the reduction table; the branches go one after the other (they share the partial buffer)
+      const int fslabs = (ub.need_dx[k] && !std::getenv("CSN_DW_BWD_SPLIT")) ? dw_stats_slabs(P, act.lvl) : 0;
+      if (fslabs > 0) {
+        DwArgs f;
+        f.nbr = 1; f.B = S; f.a16 = c.a16 ? 1 : 0; f.pad = 0;
+        DwBranch& fb = f.br[0];
+        fb.in = bd.dz[k]; fb.out = bd.dx[k]; fb.xin = bd.in[k];
+        fb.w9 = c.pk(ub.dwf_w[k]);
+        fb.scale = c.pk(P.ident.scale); fb.shift = c.pk(P.ident.shift); fb.alpha = c.pk(P.ident.alpha);
+        fb.w9b = fb.scale_b = fb.shift_b = fb.alpha_b = nullptr;
+        fb.pool = nullptr; fb.skip_out = 0; fb.stats = w.partial;
+        fb.C = d.cout[k]; fb.H = H; fb.W = W;
+        const int fcols = (W + 3) / 4;
+        fb.LX = fcols < 64 ? fcols : 64;
+        fb.NY = CSN_BLOCK / fb.LX;
+        fb.tiles_x = (fcols + fb.LX - 1) / fb.LX;
+        fb.R = choose_dw_rows(H, fb.NY);
+        fb.tiles_y = (H + fb.NY * fb.R - 1) / (fb.NY * fb.R);
+        fb.blk_end = fb.tiles_x * fb.tiles_y * fb.C * S;
+        LAUNCH_TRY(csn_launch_dw_bwd(f, cs.stream));
+        w.nslab = fslabs;                                   // partials are there: finalise only
+        LAUNCH_TRY(csn_launch_dw_wgrad(w, cs.stream));
+        continue;
+      }
       LAUNCH_TRY(csn_launch_dw_wgrad(w, cs.stream));
       if (!ub.need_dx[k]) continue;
       DwBranch& br = a.br[a.nbr++];
@@ -548,7 +573,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
       br.w9 = c.pk(ub.dwf_w[k]);
       br.scale = c.pk(P.ident.scale); br.shift = c.pk(P.ident.shift); br.alpha = c.pk(P.ident.alpha);
       br.w9b = br.scale_b = br.shift_b = br.alpha_b = nullptr;
-      br.pool = nullptr; br.skip_out = 0; br.stats = nullptr;
+      br.pool = nullptr; br.skip_out = 0; br.stats = nullptr; br.xin = nullptr;
       br.C = d.cout[k]; br.H = H; br.W = W;
       const int cols = (br.W + 3) / 4;
       br.LX = cols < 64 ? cols : 64;

@@ -49,6 +49,7 @@ struct DwBranch {
   const float* scale_b;
   const float* shift_b;
   const float* alpha_b;
+  const float* xin;      // dw3x3_bwd_kernel: the unit's forward input x (stats then holds the weight-gradient partials [C][NSLAB][9])
   double* stats;         // single-unit kernel, train mode: BN statistics partials [C][CSN_BN_NSLAB][2] of the stored output,
                          // one per (image, tile): slab = b * tiles_x * tiles_y + tile (null: none)
   float* pool;           // dw3x3x2 only: 2x2 average of the pair's output [B*C][H/2][W/2] for the stride-2 unit that
@@ -374,6 +375,7 @@ int csn_launch_val_mae(const float* logits, int hi, int wi, const float* target,
 int csn_launch_prep(const CsnPrepJob* jobs_dev, int njobs, const float* arena, float* packed, void* stream);
 int csn_launch_dw(const DwArgs& a, void* stream);
 int csn_launch_dw2(const DwArgs& a, void* stream);
+int csn_launch_dw_bwd(const DwArgs& a, void* stream);   // input + weight gradient of a depthwise unit in one pass
 size_t csn_dw2_lds_bytes(const DwArgs& a);
 int csn_launch_pw(const PwArgs& a, int raw, void* stream);
 bool csn_c3_eligible(const PwArgs& a);                        // one pass of 3x3 tap slices (k_goct_c3.hip)

@@ -785,7 +785,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
         br.w9 = c.pk(u.dw_w[k]);
         br.scale = c.sc(u.dw_epi[k]); br.shift = c.sh(u.dw_epi[k]); br.alpha = c.al(u.dw_epi[k]);
         br.w9b = br.scale_b = br.shift_b = br.alpha_b = nullptr;
-        br.pool = nullptr; br.skip_out = 0; br.stats = nullptr;
+        br.pool = nullptr; br.skip_out = 0; br.stats = nullptr; br.xin = nullptr;
         br.C = d.cout[k]; br.H = P.H >> act.lvl; br.W = P.W >> act.lvl;
         const int cols = (br.W + 3) / 4;
         br.LX = cols < 64 ? cols : 64;

@@ -222,6 +222,95 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
   }
 }
 
+// -------------------------------------------------------------- depthwise backward: input AND weight gradient
+// One pass over dz and x for both gradients of a depthwise unit (conv2d.py:104: y = conv(x, 100 w)):
+//     dx[p]  = sum_t 100 w[8 - t] dz[p + off(t)]              (the forward kernel with flipped taps)
+//     dW[t] += dz[p] * x[p + off(t)]                          (x100 in the finaliser)
+// Same tile / lane mapping as dw3x3_bn_prelu_kernel; a lane keeps rolling three-row windows of dz AND of x, so every row of
+// either tensor is loaded once per lane (the stand-alone weight-gradient kernel re-read dz and gathered ten values per quad).
+// The nine per-lane sums (<= 64 terms, fp32) are reduced per block in fp64: one partial per (channel, image, tile).
+template <bool VEC, typename AT>
+__global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
+  CSN_DYN_SMEM(double, sm);
+  int bid = blockIdx.x;
+  int k = 0;
+  if (a.nbr > 1 && bid >= a.br[0].blk_end) k = 1;
+  if (a.nbr > 2 && bid >= a.br[1].blk_end) k = 2;
+  const DwBranch br = a.br[k];
+  if (k > 0) bid -= a.br[k - 1].blk_end;
+  const int tiles = br.tiles_x * br.tiles_y;
+  const int tile = bid % tiles;
+  const int pc = bid / tiles;  // b*C + c
+  const int c = pc % br.C;
+  const int tx = tile % br.tiles_x, ty = tile / br.tiles_x;
+  const int tid = threadIdx.x;
+  const int lx = tid % br.LX, ly = tid / br.LX;
+  const int H = br.H, W = br.W;
+  const int x0 = (tx * br.LX + lx) * 4;
+  const int y0 = (ty * br.NY + ly) * br.R;
+  const bool active = ly < br.NY && x0 < W && y0 < H;
+  float s[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) s[t] = 0.f;
+  if (active) {
+    const unsigned nb = (unsigned)(H * W) * (unsigned)sizeof(AT);
+    const csn_buf gb = csn_make_buf_n(act_cast<AT>(br.in) + (int64_t)pc * H * W, nb);     // dz
+    const csn_buf xb = csn_make_buf_n(act_cast<AT>(br.xin) + (int64_t)pc * H * W, nb);    // x
+    AT* __restrict__ op = act_cast<AT>(br.out) + (int64_t)pc * H * W;
+    float w[9];
+    csn_cfp w9 = csn_const(br.w9);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) w[i] = w9[c * 9 + i];
+    const bool has_l = x0 > 0, has_r = x0 + 4 < W;
+    DwRow g0 = dw_load_row<VEC, AT>(gb, y0 - 1, x0, W, has_l, has_r);
+    DwRow g1 = dw_load_row<VEC, AT>(gb, y0, x0, W, has_l, has_r);
+    DwRow u0 = dw_load_row<VEC, AT>(xb, y0 - 1, x0, W, has_l, has_r);
+    DwRow u1 = dw_load_row<VEC, AT>(xb, y0, x0, W, has_l, has_r);
+    const int yend = min(y0 + br.R, H);
+    for (int y = y0; y < yend; ++y) {
+      const DwRow g2 = dw_load_row<VEC, AT>(gb, y + 1, x0, W, has_l, has_r);
+      const DwRow u2 = dw_load_row<VEC, AT>(xb, y + 1, x0, W, has_l, has_r);
+      dw_emit<VEC, AT>(op, y, yend, x0, W, w, 1.f, 0.f, 1.f, g0, g1, g2);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float g = (VEC || x0 + j < W) ? g1.v[j + 1] : 0.f;
+        s[0] = fmaf(g, u0.v[j], s[0]); s[1] = fmaf(g, u0.v[j + 1], s[1]); s[2] = fmaf(g, u0.v[j + 2], s[2]);
+        s[3] = fmaf(g, u1.v[j], s[3]); s[4] = fmaf(g, u1.v[j + 1], s[4]); s[5] = fmaf(g, u1.v[j + 2], s[5]);
+        s[6] = fmaf(g, u2.v[j], s[6]); s[7] = fmaf(g, u2.v[j + 1], s[7]); s[8] = fmaf(g, u2.v[j + 2], s[8]);
+      }
+      g0 = g1; g1 = g2;
+      u0 = u1; u1 = u2;
+    }
+  }
+  double sv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) sv[t] = (double)s[t];
+  bn_block_sum_n<9>(sv, sm);
+  if (tid == 0) {
+    const int b = pc / br.C;
+    double* o = br.stats + ((int64_t)c * CSN_BN_NSLAB + (int64_t)b * tiles + tile) * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) o[t] = sv[t];
+  }
+}
+
+int csn_launch_dw_bwd(const DwArgs& a, void* stream) {
+  const int nblk = a.br[a.nbr - 1].blk_end;
+  if (nblk <= 0) return 0;
+  bool vec = true;
+  for (int k = 0; k < a.nbr; ++k) vec = vec && (a.br[k].W % 4 == 0);
+  const size_t sml = CSN_BLOCK * sizeof(double);
+  if (a.a16) {
+    if (vec) CSN_LAUNCH((dw3x3_bwd_kernel<true, csn_bf16>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);
+    else CSN_LAUNCH((dw3x3_bwd_kernel<false, csn_bf16>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);
+  } else if (vec) {
+    CSN_LAUNCH((dw3x3_bwd_kernel<true, float>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);
+  } else {
+    CSN_LAUNCH((dw3x3_bwd_kernel<false, float>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);
+  }
+  return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------- two depthwise units back to back
 // conv3x3_1 -> conv3x3_2 of an ILBlock (csnet.py:74-75) in one pass over HBM: the block computes the first
 // unit's output for its rows plus one halo row above and below into LDS (never written to HBM), then the

@@ -601,11 +601,14 @@ int csn_launch_bn_bwd(const BnBwdArgs& a0, void* stream) {
   CSN_LAUNCH_AT(a.a16, bn_bwd_apply_kernel, dim3(a.C, a.S), dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
 }
+// a0.nslab > 0 on entry: the partials were already written (by dw3x3_bwd_kernel, that many per channel): finalise only
 int csn_launch_dw_wgrad(const DwWgradArgs& a0, void* stream) {
   DwWgradArgs a = a0;
-  a.cpp = bn_cpp(a.S, a.C, (int64_t)a.H * a.W);
-  a.nslab = bn_nslab(a.S, a.cpp);
-  CSN_LAUNCH_AT(a.a16, dw_wgrad_kernel, dim3(a.nslab, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
+  if (a.nslab <= 0) {
+    a.cpp = bn_cpp(a.S, a.C, (int64_t)a.H * a.W);
+    a.nslab = bn_nslab(a.S, a.cpp);
+    CSN_LAUNCH_AT(a.a16, dw_wgrad_kernel, dim3(a.nslab, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
+  }
   CSN_LAUNCH(dw_wgrad_finalize_kernel, dim3(a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   return (int)hipGetLastError();
 }
