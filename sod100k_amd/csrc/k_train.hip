@@ -631,7 +631,47 @@ int csn_launch_avgpool2_bwd(const PoolBwdArgs& a, void* stream) {
   CSN_LAUNCH_AT(a.a16, avgpool2_bwd_kernel, dim3(grid_for((int64_t)a.planes * a.Hl * a.Wl * 4)), dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
 }
+// f = 2, even low-resolution width: one thread routes TWO neighbouring windows -- the 2 x 4 block of x and of dx as aligned
+// four-element vectors (read-modify-write of dx), the two gradients as a pair.  Same first-maximum rule.
+template <typename AT>
+__global__ __launch_bounds__(CSN_BLOCK) void maxpool2_bwd_add_pair_kernel(PoolBwdArgs a) {
+  const int Hl = a.Hl, Wl = a.Wl, Wp = Wl >> 1;
+  const int Wh = Wl * 2;
+  const int64_t hwh = (int64_t)Hl * 2 * Wh;
+  const int64_t tot = (int64_t)a.planes * Hl * Wp;
+  for (int64_t e = (int64_t)blockIdx.x * CSN_BLOCK + threadIdx.x; e < tot; e += (int64_t)gridDim.x * CSN_BLOCK) {
+    const int64_t pl = e / (Hl * Wp);
+    const int r = (int)(e - pl * Hl * Wp);
+    const int yl = r / Wp, xl = (r - yl * Wp) * 2;
+    const int64_t o = pl * hwh + (int64_t)(yl * 2) * Wh + xl * 2;
+    const float4 x0 = act_ld4(act_cast<AT>(a.x) + o), x1 = act_ld4(act_cast<AT>(a.x) + o + Wh);
+    const float2 t = act_ld2(act_cast<AT>(a.t) + pl * (int64_t)Hl * Wl + (int64_t)yl * Wl + xl);
+    float4 d0 = act_ld4(act_cast<AT>(a.dx) + o), d1 = act_ld4(act_cast<AT>(a.dx) + o + Wh);
+    {   // window 0: (x0.x, x0.y; x1.x, x1.y), scan order row-major, `v > best || v != v`
+      float best = x0.x; int bi = 0;
+      if (x0.y > best || x0.y != x0.y) { best = x0.y; bi = 1; }
+      if (x1.x > best || x1.x != x1.x) { best = x1.x; bi = 2; }
+      if (x1.y > best || x1.y != x1.y) { best = x1.y; bi = 3; }
+      if (bi == 0) d0.x += t.x; else if (bi == 1) d0.y += t.x; else if (bi == 2) d1.x += t.x; else d1.y += t.x;
+    }
+    {   // window 1: (x0.z, x0.w; x1.z, x1.w)
+      float best = x0.z; int bi = 0;
+      if (x0.w > best || x0.w != x0.w) { best = x0.w; bi = 1; }
+      if (x1.z > best || x1.z != x1.z) { best = x1.z; bi = 2; }
+      if (x1.w > best || x1.w != x1.w) { best = x1.w; bi = 3; }
+      if (bi == 0) d0.z += t.y; else if (bi == 1) d0.w += t.y; else if (bi == 2) d1.z += t.y; else d1.w += t.y;
+    }
+    act_st4(act_cast<AT>(a.dx) + o, d0);
+    act_st4(act_cast<AT>(a.dx) + o + Wh, d1);
+  }
+}
+
 int csn_launch_maxpool_bwd_add(const PoolBwdArgs& a, void* stream) {
+  if (a.f == 2 && (a.Wl & 1) == 0) {
+    CSN_LAUNCH_AT(a.a16, maxpool2_bwd_add_pair_kernel, dim3(grid_for((int64_t)a.planes * a.Hl * (a.Wl >> 1))), dim3(CSN_BLOCK), 0,
+                  stream, a);
+    return (int)hipGetLastError();
+  }
   CSN_LAUNCH_AT(a.a16, maxpool_bwd_add_kernel, dim3(grid_for((int64_t)a.planes * a.Hl * a.Wl)), dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
 }

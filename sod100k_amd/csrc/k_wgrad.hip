@@ -284,7 +284,8 @@ __global__ __launch_bounds__(CSN_BLOCK) void wgrad_reduce_kernel(WgReduceArgs a)
   if (k < a.K) {
     const float* p = a.partial + (int64_t)r * a.k16 + k;
     const int64_t stride = (int64_t)a.rows16 * a.k16;
-    for (int b = grp; b < a.nblk; b += 4) s += (double)p[b * stride];
+#pragma unroll 8
+    for (int b = grp; b < a.nblk; b += 4) s += (double)p[b * stride];   // independent loads: keep eight in flight
   }
   sm[threadIdx.x] = s;
   __syncthreads();
