@@ -189,7 +189,8 @@ __global__ __launch_bounds__(CSN_BLOCK, 2) void goct_wgrad_c3_kernel(WgArgs a_by
 
 // one pass of plain 3x3 tap slices (dilation 1; own resolution or 2x2 max-pooled), at most 32 rows
 bool csn_wgrad_c3_eligible(const WgArgs& a) {
-  static const bool off = std::getenv("CSN_WGRAD_TILED3") && std::getenv("CSN_WGRAD_TILED3")[0] == '0';
+  const char* env = std::getenv("CSN_WGRAD_TILED3");
+  const bool off = env && env[0] == '0';
   if (off || a.ps.nsrc < 1 || a.rows16 > W3_MAX_ROWS) return false;
   for (int s = 0; s < a.ps.nsrc; ++s) {
     const int m = a.ps.src[s].mode;

@@ -648,6 +648,7 @@ def check_train_units_local(lib, device, manifest, B=2, size=64, act_dtype="bf16
 
     def note(kind, name, got, ref, tol, floor=0.0):
         # relative L2, with an absolute floor for tensors that are (nearly) zero
+        got, ref = got.detach(), ref.detach()
         e = float((got.double() - ref.double()).norm())
         n = float(ref.double().norm())
         r = e / (n + floor + 1e-30)

@@ -2,6 +2,7 @@
 
 No GPU is needed: this checks the index arithmetic / data flow of every kernel and of the plan before the
 MI355X run; the ``-m gpu`` twins in test_gpu_parity.py are the parity tests proper."""
+import numpy as np
 import torch
 
 from oracle import inputs as I
@@ -101,3 +102,57 @@ def test_emu_train_units_local_multi_image_slabs(emu_lib, x2_manifest, monkeypat
     per block); CSN_BN_IPP forces that path at a batch the emulator can run (5 images: slabs of ipp, ..., remainder)."""
     monkeypatch.setenv("CSN_BN_IPP", str(ipp))
     print(P.check_train_units_local(emu_lib, CPU, x2_manifest, B=5, size=32, act_dtype=act_dtype, state="well"))
+
+
+@pytest.mark.parametrize("act_dtype", ["fp32", "bf16"])
+def test_emu_train_units_local_fallback_paths(emu_lib, x2_manifest, monkeypatch, act_dtype):
+    """The round-1 schemes stay in the library as fallbacks (batches whose per-(image, tile) partials do not fit the reduction
+    table, rows beyond the wave kernel, ...): one weight-gradient launch per forward pass with bilinear gathers, 3x3 weight
+    gradients on the per-pixel kernel, stand-alone BN statistics / depthwise weight-gradient passes."""
+    for k, v in (("CSN_WGRAD_REGROUP", "1"), ("CSN_WGRAD_TILED3", "0"), ("CSN_DW_STATS", "0"), ("CSN_DW_BWD_SPLIT", "1")):
+        monkeypatch.setenv(k, v)
+    print(P.check_train_units_local(emu_lib, CPU, x2_manifest, B=2, size=48, act_dtype=act_dtype, state="shipped"))
+
+
+def test_emu_bf16_trainer_steps_and_eval_afterwards(emu_lib, x2_manifest):
+    """FusedTrainer in bf16 storage mode: a few optimizer steps move the parameters, the loss stays finite and close to the
+    fp32 trainer's, and the eval-mode forward afterwards is the fp32 path (equal to the oracle on the updated state)."""
+    from sod100k_amd.tools.train import FusedTrainer
+    from oracle import csnet_oracle as O
+    x = torch.from_numpy(I.randn_batch(90, 2, 32, 32))
+    t = torch.from_numpy(I.binary_target(91, 2, 32, 32))
+    losses = {}
+    for dt in ("fp32", "bf16"):
+        m, sd = P.make_model(emu_lib, x2_manifest, CPU)
+        m.train(); m.set_batchsize(2); m.clear_flops(); m.flops_hook(1.0)
+        tr = FusedTrainer(m, lr=1e-4, weight_decay=5e-3, eps=1e-3, flops_weight=3.0, batchsize=2, lib=emu_lib, act_dtype=dt)
+        ls = []
+        for _ in range(3):
+            loss, pen = tr.step(x, t)
+            m.clear_flops()
+            ls.append(float(loss))
+        assert all(np.isfinite(ls)), (dt, ls)
+        losses[dt] = ls
+        if dt == "bf16":
+            m.eval()
+            with torch.no_grad():
+                y = m(x)
+                cur = {k: v.detach().clone() for k, v in m.state_dict().items()}
+                ref = O.csnet_forward(O.load_layer_config_json(x2_manifest), cur, x)
+            assert (y - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+    assert abs(losses["bf16"][0] - losses["fp32"][0]) <= 2e-2 * max(1.0, abs(losses["fp32"][0])), losses
+
+
+def test_bf16_option_needs_training_buffers(emu_lib, x2_manifest):
+    """CSN_OPT_TRAIN_BF16 on a plan without csn_plan_enable_training: csn_forward_train refuses (CSN_E_STATE), never a silent
+    fp32 run."""
+    from sod100k_amd import _native as N
+    m, _ = P.make_model(emu_lib, x2_manifest, CPU)
+    x = torch.from_numpy(I.randn_batch(92, 1, 32, 32))
+    m.train()
+    eng = m.engine_for(x, train=False)
+    eng.set_option(N.OPT_TRAIN_BF16, 1)
+    eng.refresh(m._arena.flat)
+    with pytest.raises(RuntimeError):
+        eng.forward_train(x, m._arena.flat, [0.0] * (len(m.describe(m._arena.offsets)[0]) * N.MAX_BRANCH),
+                          torch.zeros(1, dtype=torch.float64))
