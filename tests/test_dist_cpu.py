@@ -59,7 +59,7 @@ def test_config_loader_accepts_reference_keys(tmp_path):
         cfg.merge_from_file(str(bad))
 
 
-def _train_worker(rank, world, port, out):
+def _train_worker(rank, world, port, out, act_dtype=None):
     """Data-parallel train step on two ranks (CPU emulation of the kernels + gloo all-reduce of the flat gradient)."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -76,7 +76,7 @@ def _train_worker(rank, world, port, out):
     man = os.path.join(ROOT, "sod100k_amd", "data", "csnet-L-x2.json")
     m, _ = P.make_model(lib, man, torch.device("cpu"))
     m.train(); m.set_batchsize(2); m.clear_flops(); m.flops_hook(1.0)
-    tr = FusedTrainer(m, lr=0.0, weight_decay=0.0, flops_weight=3.0, batchsize=2, lib=lib)
+    tr = FusedTrainer(m, lr=0.0, weight_decay=0.0, flops_weight=3.0, batchsize=2, lib=lib, act_dtype=act_dtype)
     x = torch.from_numpy(I.randn_batch(10, 4, 32, 32))[2 * rank:2 * rank + 2]
     t = torch.from_numpy(I.binary_target(11, 4, 32, 32))[2 * rank:2 * rank + 2]
     loss, pen = tr.step(x, t, world_size=world)
@@ -119,6 +119,39 @@ def test_two_rank_gradient_allreduce(emu_lib):
         g = flat[offs[name]:offs[name] + p.numel()].view(p.shape).double()
         ref = (grads[name] / 2).double()
         assert float((g - ref).norm()) <= 2e-3 * float(ref.norm()) + 1e-6 * gmax, name
+
+
+def test_two_rank_gradient_allreduce_bf16(emu_lib):
+    """The same data-parallel step with bfloat16 activation storage (BASELINE config 4's kernels in config 3's dtype).  Whole-step
+    gradients of this network are not comparable across rounding variants (see check_train_units_local), so the two ranks'
+    all-reduced gradient is checked against the SAME kernels run shard by shard in one process: the collective averages, per-GPU
+    BN statistics, deterministic kernels -> bit-identical."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import inputs as I
+    from sod100k_amd.tools.train import FusedTrainer
+    import parity_cases as P
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q, "bf16")) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
+    [p.join(60) for p in procs]
+    assert np.array_equal(res[0][3], res[1][3])
+    man = os.path.join(ROOT, "sod100k_amd", "data", "csnet-L-x2.json")
+    x = torch.from_numpy(I.randn_batch(10, 4, 32, 32))
+    t = torch.from_numpy(I.binary_target(11, 4, 32, 32))
+    acc = None
+    for s in range(2):
+        m, _ = P.make_model(emu_lib, man, torch.device("cpu"))
+        m.train(); m.set_batchsize(2); m.clear_flops(); m.flops_hook(1.0)
+        tr = FusedTrainer(m, lr=0.0, weight_decay=0.0, flops_weight=3.0, batchsize=2, lib=emu_lib, act_dtype="bf16")
+        loss, pen = tr.step(x[2 * s:2 * s + 2], t[2 * s:2 * s + 2])
+        assert float(loss) == res[s][1] and float(pen) == res[s][2]
+        acc = tr.grad.clone() if acc is None else acc + tr.grad
+    assert torch.equal(acc / 2, torch.from_numpy(res[0][3]))
 
 
 def test_bench_self_spawns_two_ranks(emu_lib):
