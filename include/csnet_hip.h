@@ -119,9 +119,12 @@ void csn_plan_destroy(csn_plan* plan);
  * CSN_OPT_TRAIN_BF16 [0]: BASELINE config 3's dtype -- csn_forward_train / csn_backward keep every activation and activation
  * gradient in the workspace as bfloat16 (round-to-nearest-even on store; all arithmetic, the BN statistics, the weight
  * gradients, parameters and optimizer state stay fp32 / fp64).  x, y, dy at the boundary stay float.  Needs
- * csn_plan_enable_training; csn_forward (eval) is unaffected and stays fp32 (the 1e-4 parity configuration). */
+ * csn_plan_enable_training; csn_forward (eval) is unaffected and stays fp32 (the 1e-4 parity configuration).
+ * CSN_OPT_PW4 [1]: 1x1 gOctaveCBR units with two input branches run on pw4_kernel (k_pw4.hip: lane = low pixel + its 2x2
+ * high quad, v_mfma_f32_4x4x1 straight from the load registers, no LDS panel / transpose); 0 = goct_pw_kernel for every
+ * 1x1 unit (the round-1/2 path; also what the train-mode forward and the input gradients still use). */
 enum csn_option { CSN_OPT_FUSE_DW = 1, CSN_OPT_GRAPH = 2, CSN_OPT_FUSE_CLS = 3, CSN_OPT_TILED3 = 4, CSN_OPT_FUSE_ILB = 5,
-                  CSN_OPT_OVERLAP = 6, CSN_OPT_TRAIN_BF16 = 7 };
+                  CSN_OPT_OVERLAP = 6, CSN_OPT_TRAIN_BF16 = 7, CSN_OPT_PW4 = 8 };
 int csn_plan_set_option(csn_plan* plan, int32_t option, int32_t value);
 
 size_t csn_plan_workspace_bytes(const csn_plan* plan);

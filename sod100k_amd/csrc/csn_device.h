@@ -65,6 +65,13 @@ static inline void csn_st1(csn_buf b, unsigned voff, unsigned soff, float v) {
   const unsigned o = voff + soff;
   if (o + 4u <= b.n && o + 4u > o && o >= voff) *reinterpret_cast<float*>(const_cast<char*>(b.p) + o) = v;
 }
+static inline void csn_st2(csn_buf b, unsigned voff, unsigned soff, float2 v) {
+  const unsigned o = voff + soff;
+  if (o + 8u <= b.n && o + 8u > o && o >= voff) {
+    float* q = reinterpret_cast<float*>(const_cast<char*>(b.p) + o);
+    q[0] = v.x; q[1] = v.y;
+  }
+}
 static inline float4 csn_ld4(csn_buf b, unsigned voff, unsigned soff) {
   const unsigned o = voff + soff;
   if (!(o + 16u <= b.n && o + 16u > o)) return make_float4(0.f, 0.f, 0.f, 0.f);
@@ -106,6 +113,11 @@ __device__ __forceinline__ float csn_ld1(csn_buf b, unsigned voff, unsigned soff
 // bounded resource must span everything the soffset can reach
 __device__ __forceinline__ void csn_st1(csn_buf b, unsigned voff, unsigned soff, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), b, voff, soff, 0);
+}
+__device__ __forceinline__ void csn_st2(csn_buf b, unsigned voff, unsigned soff, float2 v) {
+  csn_u2 u;
+  u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y);
+  __builtin_amdgcn_raw_buffer_store_b64(u, b, voff, soff, 0);
 }
 __device__ __forceinline__ float2 csn_ld2(csn_buf b, unsigned voff, unsigned soff) {
   const csn_u2 v = __builtin_amdgcn_raw_buffer_load_b64(b, voff, soff, 0);

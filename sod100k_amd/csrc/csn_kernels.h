@@ -27,6 +27,9 @@ enum CsnPrepKind {
   CSN_PREP_C3T = 9,
   // ... of a transposed block with flipped taps (backward data): element (r, c, t) = src0[c*p0 + r*9 + (8 - t)]
   CSN_PREP_C3T_T = 10,
+  // 1x1 block -> pw4_kernel's image [k][4][P] (k_pw4.hip): n = rows, p1 = channels, p0 = source row pitch, p2 = P,
+  // p3 = t0 | (k0 << 8):  dst[((k0 + c)*4 + (r & 3))*p2 + t0 + (r >> 2)] = p0f * src0[r*p0 + c]
+  CSN_PREP_PW4 = 11,
 };
 struct CsnPrepJob {
   int32_t kind, n, p0, p1, p2, p3;
@@ -128,6 +131,34 @@ struct PwArgs {
   int32_t w3_stride, w3_floats, z_c0;
   int32_t a16;         // activations are bfloat16 (bf16 train mode), else float
 };
+
+// ---------------------------------------------------------------------------------------------
+// gOctConv 1x1 (+BN+PReLU) of a two-branch unit, lane = low pixel + its 2x2 high quad, v_mfma_f32_4x4x1 from the
+// load registers (see k_pw4.hip)
+// ---------------------------------------------------------------------------------------------
+#define PW4_MAX_GROUPS 4
+#define PW4_PITCH(NT4) (((NT4) % 16) == 0 ? (NT4) + 4 : (NT4))   // floats per (channel, row-in-tile) of the weight image
+struct Pw4Group { int32_t r0h, nth, r0l, ntl; };   // M group: first high / low output channel (multiples of 4) and row tiles (of 4 channels)
+struct Pw4Args {
+  const float* xh;     // [B][CH][2 Hl][2 Wl]
+  const float* xl;     // [B][CL][Hl][Wl]
+  float* yh;           // [B][OH][2 Hl][2 Wl]
+  float* yl;           // [B][OL][Hl][Wl]   (unused when the unit has no low output)
+  const float* wimg;   // [ngroups][CH + CL][4][P]: element (g, k, i, t) = W[row 4 t + i of group g's tile list][gathered channel k],
+                       // tiles 0 .. nth-1 = high rows, nth .. nth+ntl-1 = low rows, zero padded
+  const float* ep_h;   // folded BN / PReLU records {scale, shift, alpha, 0} per high / low output channel (padded to whole tiles)
+  const float* ep_l;
+  int32_t CH, CL, OH, OL;
+  int32_t Hl, Wl, B;
+  int32_t twl;              // log2 of the tile width in low pixels (tile = 2^twl x 64 / 2^twl)
+  int32_t tiles_x, tiles_y;
+  int32_t ngroups, gimg_floats;
+  int32_t nth, ntl;         // instantiation: row tiles per group
+  int32_t max_grid, pad;
+  Pw4Group grp[PW4_MAX_GROUPS];
+};
+bool csn_pw4_pick(int nth, int ntl, int* pnth, int* pntl);
+int csn_launch_pw4(const Pw4Args& a, int raw, void* stream);
 
 // ---------------------------------------------------------------------------------------------
 // a whole 1x1 ILBlock (gOctaveCBR 1x1 -> depthwise 3x3 -> depthwise 3x3) per wave strip (see k_ilb.hip)

@@ -125,6 +125,11 @@ struct UnitPlan {
   IlbRolePlan ilb[2];
   int ilb_ok = 0;
   int ilb_width = 0;            // width of the finest output branch (CSN_OPT_FUSE_ILB threshold)
+  // GOCT 1x1, two input branches: plan of pw4_kernel (k_pw4.hip); pw4 = 0: the unit does not qualify
+  int pw4 = 0;
+  int pw4_nth = 0, pw4_ntl = 0, pw4_ng = 0, pw4_gimg = 0;
+  Pw4Group pw4_grp[PW4_MAX_GROUPS] = {};
+  int64_t pw4_wimg = -1, pw4_ep[2] = {-1, -1};
   // MS
   int64_t ms_w[5] = {-1, -1, -1, -1, -1};
   Epi ms_epi;
@@ -150,6 +155,9 @@ struct csn_plan {
   bool fuse_dw = true;
   bool fuse_cls = true;   // CSN_OPT_FUSE_CLS
   bool tiled3 = true;     // CSN_OPT_TILED3
+  bool pw4 = true;        // CSN_OPT_PW4: two-branch 1x1 units on pw4_kernel (k_pw4.hip)
+  int pw4_grid = 2048;    // its block cap (CSN_PW4_GRID, experiments)
+  int pw4_twl = 4;        // log2 of its widest tile in low pixels (CSN_PW4_TWL, experiments)
   bool overlap_bwd = false;   // CSN_OPT_OVERLAP value 2: also the weight-gradient side lane of csn_backward
   bool overlap = true;    // CSN_OPT_OVERLAP: independent launches of a unit (and the MSBlocks) on parallel stream lanes
   hipStream_t lane[2] = {nullptr, nullptr};      // auxiliary lanes (lane 0 = the caller's stream)
@@ -354,6 +362,8 @@ void add_launch(std::vector<PwLaunchPlan>& dst, PwLaunchPlan L) {
   }
 }
 
+int plan_pw4(Builder& bl, UnitPlan& u, const int* ci_off, const int* co_off, int cin_tot);
+
 int plan_goct(Builder& bl, UnitPlan& u) {
   csn_plan& P = bl.P;
   const csn_unit_desc& d = u.d;
@@ -470,6 +480,57 @@ int plan_goct(Builder& bl, UnitPlan& u) {
     if (st != CSN_OK) return st;
     if (l.passes.size() != 1) u.c3 = 0;   // csn_c3_eligible
   }
+  return plan_pw4(bl, u, ci_off, co_off, cin_tot);
+}
+
+// Two-branch 1x1 unit on pw4_kernel (k_pw4.hip): M groups, weight image [group][K][4][P], interleaved epilogue records.
+int plan_pw4(Builder& bl, UnitPlan& u, const int* ci_off, const int* co_off, int cin_tot) {
+  const csn_unit_desc& d = u.d;
+  if (d.ksize != 1 || d.stride != 1 || u.std_conv || d.n_in != 2 || d.cin[0] <= 0 || d.cin[1] <= 0 || d.cout[0] <= 0) return CSN_OK;
+  const int OH = d.cout[0], OL = d.n_out >= 2 ? d.cout[1] : 0;
+  if (d.n_out > 2) return CSN_OK;
+  const int nth_tot = (OH + 3) / 4, ntl_tot = (OL + 3) / 4;
+  int ng = 0, pn = 0, pl = 0;
+  for (int g = 1; g <= PW4_MAX_GROUPS; ++g) {
+    int a = 0, b = 0;
+    if (!csn_pw4_pick((nth_tot + g - 1) / g, (ntl_tot + g - 1) / g, &a, &b)) continue;
+    if (16 * a + 4 * b > 100 && g < PW4_MAX_GROUPS) continue;   // accumulators: leave room for two load batches in flight
+    ng = g; pn = a; pl = b;
+    break;
+  }
+  if (ng == 0) return CSN_OK;
+  const int CH = d.cin[0], CL = d.cin[1], K = CH + CL;
+  const int NT4 = (pn + pl + 3) & ~3, Pp = PW4_PITCH(NT4);
+  u.pw4_nth = pn; u.pw4_ntl = pl; u.pw4_ng = ng; u.pw4_gimg = K * 4 * Pp;
+  if ((int64_t)ng * u.pw4_gimg * 4 > 64 * 1024) return CSN_OK;
+  u.pw4_wimg = bl.alloc_packed((int64_t)ng * u.pw4_gimg);
+  const int gh = (nth_tot + ng - 1) / ng, gl = (ntl_tot + ng - 1) / ng;
+  for (int g = 0; g < ng; ++g) {
+    Pw4Group& G = u.pw4_grp[g];
+    G.r0h = 4 * g * gh; G.nth = std::max(0, std::min(gh, nth_tot - g * gh));
+    G.r0l = 4 * g * gl; G.ntl = std::max(0, std::min(gl, ntl_tot - g * gl));
+    const int64_t img = u.pw4_wimg + (int64_t)g * u.pw4_gimg;
+    const int nrh = std::min(4 * G.nth, OH - G.r0h), nrl = std::min(4 * G.ntl, OL - G.r0l);
+    for (int i = 0; i < 2; ++i) {   // gathered channels: branch 0 first (k0 = 0), then branch 1 (k0 = CH)
+      const int k0 = i == 0 ? 0 : CH;
+      if (nrh > 0)
+        bl.job(CSN_PREP_PW4, nrh, img, d.w_off[0] + (int64_t)(co_off[0] + G.r0h) * cin_tot + ci_off[i], -1, -1, -1, 1.f,
+               cin_tot, d.cin[i], Pp, 0 | (k0 << 8));
+      if (nrl > 0)
+        bl.job(CSN_PREP_PW4, nrl, img, d.w_off[0] + (int64_t)(co_off[1] + G.r0l) * cin_tot + ci_off[i], -1, -1, -1, 1.f,
+               cin_tot, d.cin[i], Pp, pn | (k0 << 8));
+    }
+  }
+  for (int j = 0; j < 2; ++j) {
+    const int C = j == 0 ? OH : OL;
+    if (C == 0) continue;
+    const int rows = 4 * ng * (j == 0 ? pn : pl) + 4;   // whole tiles of every group are readable
+    u.pw4_ep[j] = bl.alloc_packed((int64_t)rows * 4);
+    bl.job(CSN_PREP_BN_SCALE, C, u.pw4_ep[j], d.bn[j].weight, d.bn[j].running_var, -1, -1, 1.f, 0, 0, 4, 0);
+    bl.job(CSN_PREP_BN_SHIFT, C, u.pw4_ep[j], d.bn[j].weight, d.bn[j].running_var, d.bn[j].bias, d.bn[j].running_mean, 1.f, 0, 0, 4, 1);
+    bl.job(CSN_PREP_COPY, C, u.pw4_ep[j], d.bn[j].prelu, -1, -1, -1, 1.f, 0, 0, 4, 2);
+  }
+  u.pw4 = 1;
   return CSN_OK;
 }
 
@@ -849,6 +910,28 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
         for (int i = 0; i < d.n_in; ++i)
           if (d.cin[i] > 0) xin[i] = c.act_in(d.in_act[i]);
       }
+      if (P.pw4 && u.pw4 && !c.raw && !c.a16 && !(next && next->d.kind == CSN_UNIT_CLS)) {
+        Pw4Args a;
+        a.xh = xin[0]; a.xl = xin[1];
+        a.yh = c.act_out(d.out_act[0]);
+        a.yl = (d.n_out >= 2 && d.cout[1] > 0) ? c.act_out(d.out_act[1]) : nullptr;
+        a.wimg = c.pk(u.pw4_wimg);
+        a.ep_h = c.pk(u.pw4_ep[0]);
+        a.ep_l = u.pw4_ep[1] >= 0 ? c.pk(u.pw4_ep[1]) : nullptr;
+        a.CH = d.cin[0]; a.CL = d.cin[1]; a.OH = d.cout[0]; a.OL = d.n_out >= 2 ? d.cout[1] : 0;
+        a.Hl = P.H >> (u.base_lvl + 1); a.Wl = P.W >> (u.base_lvl + 1); a.B = S;
+        int twl = 0;
+        while (twl < P.pw4_twl && (1 << twl) < a.Wl) ++twl;
+        a.twl = twl;
+        a.tiles_x = (a.Wl + (1 << twl) - 1) >> twl;
+        a.tiles_y = (a.Hl + (64 >> twl) - 1) / (64 >> twl);
+        a.ngroups = u.pw4_ng; a.gimg_floats = u.pw4_gimg; a.nth = u.pw4_nth; a.ntl = u.pw4_ntl;
+        a.max_grid = P.pw4_grid; a.pad = 0;
+        for (int g = 0; g < PW4_MAX_GROUPS; ++g) a.grp[g] = u.pw4_grp[g];
+        LAUNCH_TRY(csn_launch_pw4(a, 0, c.stream));
+        { const int ms_ = c.mark("pw4_kernel"); if (ms_ != CSN_OK) return ms_; }
+        break;
+      }
       PwBind bd;
       for (int i = 0; i < 3; ++i) bd.in[i] = xin[i];
       for (int j = 0; j < d.n_out; ++j)
@@ -1221,6 +1304,8 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   if (!P) return CSN_E_NOMEM;
   P->B = B; P->H = H; P->W = W;
   P->S = (sub_batch <= 0 || sub_batch > B) ? B : sub_batch;
+  if (const char* v = std::getenv("CSN_PW4_GRID")) { if (std::atoi(v) >= 8) P->pw4_grid = std::atoi(v); }
+  if (const char* v = std::getenv("CSN_PW4_TWL")) { if (std::atoi(v) >= 2 && std::atoi(v) <= 6) P->pw4_twl = std::atoi(v); }
   Builder bl(*P);
   P->acts.resize(n_acts);
   for (int i = 0; i < n_acts; ++i) {
@@ -1380,6 +1465,7 @@ int csn_plan_set_option(csn_plan* P, int32_t option, int32_t value) {
     case CSN_OPT_GRAPH: P->use_graph = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_FUSE_CLS: P->fuse_cls = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_TILED3: P->tiled3 = value != 0; drop_graph(P); return CSN_OK;
+    case CSN_OPT_PW4: P->pw4 = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_FUSE_ILB: P->fuse_ilb = value < 0 ? 0 : value; drop_graph(P); return CSN_OK;
     case CSN_OPT_OVERLAP: P->overlap = value != 0; P->overlap_bwd = value == 2; drop_graph(P); return CSN_OK;
     case CSN_OPT_TRAIN_BF16: P->act16 = value != 0; drop_graph(P); return CSN_OK;
@@ -1621,6 +1707,7 @@ const char* csn_unit_kernel_name(const csn_plan* P, int32_t u) {
     if (P->units[u].fuse_next || (u > 0 && P->units[u - 1].fuse_next)) return "dw3x3x2_bn_prelu_kernel";
   }
   if (P->tiled3 && P->units[u].c3) return "goct_c3_kernel";
+  if (P->pw4 && P->units[u].pw4 && !(P->fuse_cls && P->units[u].fuse_cls)) return "pw4_kernel";
   return P->units[u].kname;
 }
 

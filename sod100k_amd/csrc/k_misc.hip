@@ -80,6 +80,14 @@ __global__ __launch_bounds__(CSN_BLOCK) void csn_prep_kernel(const CsnPrepJob* _
     case CSN_PREP_FLIP9:
       for (int i = tid; i < j.n; i += CSN_BLOCK) dst[i] = j.p0f * arena[j.src0 + (i / 9) * 9 + 8 - (i % 9)];
       break;
+    case CSN_PREP_PW4: {
+      const int ncol = j.p1, t0 = j.p3 & 0xff, k0 = j.p3 >> 8;
+      const int tot = j.n * ncol;
+      for (int i = tid; i < tot; i += CSN_BLOCK) {
+        const int r = i / ncol, c = i - r * ncol;
+        dst[((int64_t)(k0 + c) * 4 + (r & 3)) * j.p2 + t0 + (r >> 2)] = j.p0f * arena[j.src0 + (int64_t)r * j.p0 + c];
+      }
+    } break;
     default:
       break;
   }
