@@ -122,9 +122,12 @@ void csn_plan_destroy(csn_plan* plan);
  * csn_plan_enable_training; csn_forward (eval) is unaffected and stays fp32 (the 1e-4 parity configuration).
  * CSN_OPT_PW4 [1]: 1x1 gOctaveCBR units with two input branches run on pw4_kernel (k_pw4.hip: lane = low pixel + its 2x2
  * high quad, v_mfma_f32_4x4x1 straight from the load registers, no LDS panel / transpose); 0 = goct_pw_kernel for every
- * 1x1 unit (the round-1/2 path; also what the train-mode forward and the input gradients still use). */
+ * 1x1 unit (the round-1/2 path; also what the train-mode forward and the input gradients still use).
+ * CSN_OPT_C3Q [1]: 3x3 gOctConv forward passes at an even resolution run on c3q_kernel (k_c3q.hip: lane = 2x2 output quad,
+ * v_mfma_f32_4x4x1 from the load registers, max-pooled copies of the finer branch written by pool2_kernel); 0 =
+ * goct_c3_kernel (which also serves bf16 storage, odd sizes and the backward-data launches). */
 enum csn_option { CSN_OPT_FUSE_DW = 1, CSN_OPT_GRAPH = 2, CSN_OPT_FUSE_CLS = 3, CSN_OPT_TILED3 = 4, CSN_OPT_FUSE_ILB = 5,
-                  CSN_OPT_OVERLAP = 6, CSN_OPT_TRAIN_BF16 = 7, CSN_OPT_PW4 = 8 };
+                  CSN_OPT_OVERLAP = 6, CSN_OPT_TRAIN_BF16 = 7, CSN_OPT_PW4 = 8, CSN_OPT_C3Q = 9 };
 int csn_plan_set_option(csn_plan* plan, int32_t option, int32_t value);
 
 size_t csn_plan_workspace_bytes(const csn_plan* plan);

@@ -122,6 +122,12 @@ class _RoundBF16(torch.autograd.Function):
 
 _ACT_BF16 = False
 Z_CAPTURE = None     # tests: set to a list to collect every BatchNorm input (the raw conv outputs z) in call order
+# tests (unit-local train checks): PReLU has a kink at 0, so a pre-activation that is zero to within fp32 rounding may
+# legitimately take either branch on the device.  PRELU_Y: set to a list to collect every pre-activation (BatchNorm output) in
+# call order; PRELU_FLIP: {call index: bool mask} of elements that take the OTHER branch (value unchanged to ~1e-9, derivative
+# swapped between 1 and alpha).
+PRELU_Y = None
+PRELU_FLIP = None
 
 
 class bf16_activations:
@@ -185,7 +191,14 @@ def bn_prelu(x, sd, bn_prefix, prelu_key, training):
                      training, BN_MOMENTUM, BN_EPS)
     if training:
         sd[bn_prefix + ".num_batches_tracked"] += 1
-    return _st(F.prelu(y, sd[prelu_key]))
+    out = F.prelu(y, sd[prelu_key])
+    if PRELU_Y is not None:
+        idx = len(PRELU_Y)
+        PRELU_Y.append(y.detach())
+        if PRELU_FLIP is not None and idx in PRELU_FLIP:
+            al = sd[prelu_key].view(1, -1, 1, 1)
+            out = torch.where(PRELU_FLIP[idx], torch.where(y >= 0, al * y, y), out)
+    return _st(out)
 
 
 def goct_cbr(xs, sd, prefix, alpha_in, alpha_out, k, stride, training):

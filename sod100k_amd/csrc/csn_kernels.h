@@ -30,6 +30,9 @@ enum CsnPrepKind {
   // 1x1 block -> pw4_kernel's image [k][4][P] (k_pw4.hip): n = rows, p1 = channels, p0 = source row pitch, p2 = P,
   // p3 = t0 | (k0 << 8):  dst[((k0 + c)*4 + (r & 3))*p2 + t0 + (r >> 2)] = p0f * src0[r*p0 + c]
   CSN_PREP_PW4 = 11,
+  // 3x3 block -> c3q_kernel's image (k_c3q.hip): n = rows, p1 = channels, p0 = source row pitch, p2 = P, p3 = t0 | (k0 << 8):
+  //   dst[((k0 + 9*c + t)*4 + (r & 3))*p2 + t0 + (r >> 2)] = p0f * src0[r*p0 + 9*c + t]
+  CSN_PREP_C3Q = 12,
 };
 struct CsnPrepJob {
   int32_t kind, n, p0, p1, p2, p3;
@@ -159,6 +162,33 @@ struct Pw4Args {
 };
 bool csn_pw4_pick(int nth, int ntl, int* pnth, int* pntl);
 int csn_launch_pw4(const Pw4Args& a, int raw, void* stream);
+
+// ---------------------------------------------------------------------------------------------
+// gOctConv 3x3 pass, lane = 2x2 output quad, v_mfma_f32_4x4x1 from the load registers (see k_c3q.hip)
+// ---------------------------------------------------------------------------------------------
+struct C3qSrc {
+  const float* ptr;    // [B][Ctot][H][W] at the pass resolution
+  int32_t C, Ctot;
+};
+struct C3qArgs {
+  C3qSrc src[3];       // 3x3 tap slices in weight-column order (gathered entry = 9 * channel + 3 * (dy + 1) + (dx + 1))
+  int32_t nsrc;
+  int32_t z_ctot;
+  const float* z;      // raw tensor [B][z_ctot][H/2][W/2] whose bilinear x2 is added to rows z_c0 + r (null: none)
+  int32_t z_c0;
+  int32_t out_c0;      // first output channel of the launch inside `out`
+  float* out;          // [B][out_ctot][H][W]
+  const float* ep;     // {scale, shift, alpha, 0} per output row of the launch, padded to whole tiles of every group
+  const float* wimg;   // [ngroups][K][4][P]: element (g, k, i, t) = W[row r0_g + 4 t + i][gathered entry k], zero padded
+  int32_t out_ctot, nrows;
+  int32_t H, W, B;
+  int32_t twl, tiles_x, tiles_y;   // tile = 2^twl x 64 / 2^twl quads
+  int32_t ngroups, gimg_floats, nt;
+  int32_t max_grid;
+  int32_t grp_r0[PW4_MAX_GROUPS], grp_nt[PW4_MAX_GROUPS];   // first row / row tiles of every M group
+};
+int csn_c3q_max_tiles(void);
+int csn_launch_c3q(const C3qArgs& a, int raw, void* stream);
 
 // ---------------------------------------------------------------------------------------------
 // a whole 1x1 ILBlock (gOctaveCBR 1x1 -> depthwise 3x3 -> depthwise 3x3) per wave strip (see k_ilb.hip)
@@ -413,5 +443,6 @@ bool csn_c3_eligible(const PwArgs& a);                        // one pass of 3x3
 int csn_launch_c3(const PwArgs& a, int raw, void* stream);   // raw: plain-store instantiation (no BN/PReLU epilogue)
 int csn_launch_ms(const MsArgs& a, void* stream);
 int csn_launch_pool(const PoolArgs& a, void* stream);
+int csn_launch_maxpool(const PoolArgs& a, void* stream);   // 2x2 max instead of the mean (float)
 int csn_launch_up2(const Up2Args& a, void* stream);
 int csn_kernels_init(void);  // function attributes (max dynamic LDS)

@@ -77,6 +77,7 @@ struct PwPassPlan {
   int w_off = 0, w_stride = 0;         // inside the launch's weight image
   int out_kind = OUT_ACT, out_branch = 0, out_c0 = 0, out_ctot = 0;
   Epi epi;                             // tables already offset to the first row of the pass
+  csn_bn_off bn = {-1, -1, -1, -1, -1};  // arena offsets of the BN / PReLU tensors of row 0 (OUT_ACT passes; c3q records)
   std::vector<WBlock> wb;
 };
 
@@ -88,12 +89,17 @@ struct PwLaunchPlan {
   // goct_c3_kernel's tap-major image of a single 3x3 pass (k_goct_c3.hip); -1: the launch does not qualify
   int64_t wimg3 = -1;
   int w3_stride = 0, w3_floats = 0, z_c0 = 0;
+  // c3q_kernel's plan of the same kind of launch (k_c3q.hip, forward only); c3q = 0: the launch does not qualify
+  int c3q = 0, c3q_nt = 0, c3q_ng = 0, c3q_gimg = 0, c3q_ntap = 0, c3q_z = 0;
+  int c3q_r0[PW4_MAX_GROUPS] = {0, 0, 0, 0}, c3q_gnt[PW4_MAX_GROUPS] = {0, 0, 0, 0};
+  int64_t c3q_wimg = -1, c3q_ep = -1;
 };
 
 struct UnitPlan {
   csn_unit_desc d;
   int base_lvl = 0;                      // lvl of branch 0 of the unit's compute resolution
   int64_t pooled_off[3] = {-1, -1, -1};  // workspace byte offsets of the 2x2 avg-pooled inputs (stride 2)
+  int64_t mp_off[3] = {-1, -1, -1};      // ... of the 2x2 max-pooled inputs (3x3 high -> low slices of c3q_kernel)
   int64_t z_off = -1;                    // workspace byte offset of the 3x3 low->high partial sums
   int z_C = 0;
   int64_t logits_off = -1;               // CLS: logits at H/2
@@ -155,6 +161,8 @@ struct csn_plan {
   bool fuse_dw = true;
   bool fuse_cls = true;   // CSN_OPT_FUSE_CLS
   bool tiled3 = true;     // CSN_OPT_TILED3
+  bool c3q = true;        // CSN_OPT_C3Q: eval-mode 3x3 passes on c3q_kernel (k_c3q.hip)
+  int c3q_cap = 4;        // its row tiles per M group (CSN_C3Q_NT, experiments)
   bool pw4 = true;        // CSN_OPT_PW4: two-branch 1x1 units on pw4_kernel (k_pw4.hip)
   int pw4_grid = 2048;    // its block cap (CSN_PW4_GRID, experiments)
   int pw4_twl = 4;        // log2 of its widest tile in low pixels (CSN_PW4_TWL, experiments)
@@ -303,6 +311,46 @@ int finish_launch(Builder& bl, PwLaunchPlan& L) {
         col += ((C + 15) / 16) * 144;
       }
       if (tail) L.z_c0 = ps.wb[ntap].eye_col0;
+      // ---- c3q_kernel: forward passes (no transposed blocks) on whole tensors at an even resolution ----
+      bool q = (((bl.P.H >> L.lvl) | (bl.P.W >> L.lvl)) & 1) == 0 && ps.out_kind != OUT_DX && ps.out_kind != OUT_TMP;
+      for (int s = 0; s < ntap; ++s)
+        q = q && ps.wb[s].tk == 0 && ps.src_kind[s] == SRC_IN && ps.src_c0[s] == 0 &&
+            (ps.src_ctot[s] == 0 || ps.src_ctot[s] == ps.src_C[s]);
+      if (q) {
+        const int cap = std::max(1, std::min(bl.P.c3q_cap, csn_c3q_max_tiles()));
+        const int nt_tot = (ps.nrows + 3) / 4;
+        int ng = (nt_tot + cap - 1) / cap;
+        if (ng > PW4_MAX_GROUPS) ng = PW4_MAX_GROUPS;
+        const int nt = (nt_tot + ng - 1) / ng;
+        int K = 0;
+        for (int s = 0; s < ntap; ++s) K += 9 * ps.src_C[s];
+        const int Pp = PW4_PITCH((nt + 3) & ~3);
+        const int64_t gimg = (int64_t)K * 4 * Pp;
+        if (nt <= csn_c3q_max_tiles() && gimg * ng * 4 <= 150 * 1024) {
+          L.c3q = 1; L.c3q_nt = nt; L.c3q_ng = ng; L.c3q_gimg = (int)gimg; L.c3q_ntap = ntap; L.c3q_z = tail ? 1 : 0;
+          L.c3q_wimg = bl.alloc_packed(gimg * ng);
+          for (int g = 0; g < ng; ++g) {
+            L.c3q_r0[g] = 4 * g * nt;
+            L.c3q_gnt[g] = std::max(0, std::min(nt, nt_tot - g * nt));
+            const int nr = std::min(4 * L.c3q_gnt[g], ps.nrows - L.c3q_r0[g]);
+            int kb = 0;
+            for (int s = 0; s < ntap && nr > 0; ++s) {
+              const WBlock& w = ps.wb[s];
+              bl.job(CSN_PREP_C3Q, nr, L.c3q_wimg + g * gimg, w.src + (int64_t)L.c3q_r0[g] * w.ld, -1, -1, -1, w.scale, w.ld,
+                     ps.src_C[s], Pp, 0 | (kb << 8));
+              kb += 9 * ps.src_C[s];
+            }
+          }
+          if (ps.out_kind == OUT_ACT && bn_ok(ps.bn)) {
+            L.c3q_ep = bl.alloc_packed((int64_t)(4 * ng * nt + 4) * 4);
+            bl.job(CSN_PREP_BN_SCALE, ps.nrows, L.c3q_ep, ps.bn.weight, ps.bn.running_var, -1, -1, 1.f, 0, 0, 4, 0);
+            bl.job(CSN_PREP_BN_SHIFT, ps.nrows, L.c3q_ep, ps.bn.weight, ps.bn.running_var, ps.bn.bias, ps.bn.running_mean, 1.f, 0, 0, 4, 1);
+            bl.job(CSN_PREP_COPY, ps.nrows, L.c3q_ep, ps.bn.prelu, -1, -1, -1, 1.f, 0, 0, 4, 2);
+          } else if (ps.out_kind == OUT_ACT) {
+            L.c3q = 0;
+          }
+        }
+      }
     }
   }
   return CSN_OK;
@@ -326,6 +374,7 @@ void push_row_chunks(std::vector<PwLaunchPlan>& dst, const PwLaunchPlan& L) {
     q.nrows = std::min(rows, ps.nrows - r0);
     q.out_c0 = ps.out_c0 + r0;
     q.epi.scale += r0; q.epi.shift += r0; q.epi.alpha += r0;
+    if (bn_ok(q.bn)) { q.bn.weight += r0; q.bn.bias += r0; q.bn.running_mean += r0; q.bn.running_var += r0; q.bn.prelu += r0; }
     for (WBlock& w : q.wb) {
       if (w.eye) { w.eye_rows = q.nrows; w.eye_col0 = r0; }
       else if (w.tk > 0) w.src += (int64_t)r0 * w.tk;
@@ -435,6 +484,7 @@ int plan_goct(Builder& bl, UnitPlan& u) {
     if (d.cout[j] == 0) continue;
     PwPassPlan ps;
     ps.r = j; ps.nrows = d.cout[j]; ps.out_kind = OUT_ACT; ps.out_branch = j; ps.out_ctot = d.cout[j]; ps.epi = epi[j];
+    ps.bn = d.bn[j];
     auto add = [&](int kind, int branch, int C, int mode, const WBlock& wproto) {
       if (ps.nsrc >= 3) return false;
       const int s = ps.nsrc++;
@@ -474,6 +524,9 @@ int plan_goct(Builder& bl, UnitPlan& u) {
     L.passes.push_back(ps);
   }
   add_launch(u.pwl, L);
+  if (d.ksize == 3 && !u.std_conv)   // 2x2 max-pooled copies of the inputs that feed a high -> low 3x3 slice (c3q_kernel)
+    for (int i = 0; i + 1 < d.n_out && i < d.n_in; ++i)
+      if (d.cin[i] > 0 && d.cout[i + 1] > 0) u.mp_off[i] = bl.alloc_ws(bl.act_bytes(d.cin[i], base + i + 1));
   u.c3 = d.ksize == 3 && !std_s2;
   for (PwLaunchPlan& l : u.pwl) {
     const int st = finish_launch(bl, l);
@@ -703,6 +756,7 @@ bool dw_unit_stats(const csn_plan& P, const UnitPlan& u) {
 // pointers a launch's sources / outputs resolve to, by SrcKind / OutKind and branch
 struct PwBind {
   const float* in[3] = {nullptr, nullptr, nullptr};    // SRC_IN: unit input branch i (pooled copy for stride 2)
+  const float* mp[3] = {nullptr, nullptr, nullptr};    // 2x2 max-pooled copy of input branch i (c3q_kernel's high -> low slices)
   const float* z = nullptr;                            // SRC_Z
   const float* dz[3] = {nullptr, nullptr, nullptr};    // SRC_DZ
   const float* adj[4] = {nullptr, nullptr, nullptr, nullptr};   // SRC_ADJ
@@ -793,6 +847,40 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
   // raw: every pass of the launch stores plain sums (train-mode conv outputs, gradients, scratch)
   bool all_raw = true;
   for (const PwPassPlan& pp : L.passes) all_raw = all_raw && (pp.out_kind == OUT_DX || pp.out_kind == OUT_TMP || (c.raw && pp.out_kind != OUT_LOGITS));
+  if (P.c3q && P.tiled3 && L.c3q && !c.a16) {   // 3x3 forward pass: lane = output quad, operands from the load registers
+    const PwPassPlan& pp = L.passes[0];
+    bool ok = true;
+    C3qArgs q;
+    q.nsrc = L.c3q_ntap;
+    for (int s = 0; s < 3; ++s) { q.src[s].ptr = nullptr; q.src[s].C = 0; q.src[s].Ctot = 0; }
+    for (int s = 0; s < L.c3q_ntap; ++s) {
+      const int br = pp.src_branch[s];
+      q.src[s].ptr = pp.src_mode[s] == PW_POOL2_TAPS ? bd.mp[br] : bd.in[br];
+      q.src[s].C = pp.src_C[s]; q.src[s].Ctot = pp.src_C[s];
+      ok = ok && q.src[s].ptr != nullptr;
+    }
+    q.z = L.c3q_z ? bd.z : nullptr; q.z_ctot = L.c3q_z ? pp.src_C[L.c3q_ntap] : 0; q.z_c0 = L.z_c0;
+    ok = ok && (!L.c3q_z || q.z != nullptr);
+    float* ob = pp.out_kind == OUT_Z ? bd.zout : bd.act[pp.out_branch];
+    ok = ok && ob != nullptr && (pp.out_kind == OUT_Z || pp.out_kind == OUT_ACT) && !bd.red_w;
+    if (ok) {
+      q.out = ob; q.out_c0 = pp.out_c0; q.out_ctot = pp.out_ctot; q.nrows = pp.nrows;
+      q.ep = L.c3q_ep >= 0 ? c.pk(L.c3q_ep) : nullptr;
+      q.wimg = c.pk(L.c3q_wimg);
+      q.H = a.H0; q.W = a.W0; q.B = a.B;
+      const int Wq = q.W >> 1, Hq = q.H >> 1;
+      int twl = 0;
+      while (twl < P.pw4_twl && (1 << twl) < Wq) ++twl;
+      q.twl = twl;
+      q.tiles_x = (Wq + (1 << twl) - 1) >> twl;
+      q.tiles_y = (Hq + (64 >> twl) - 1) / (64 >> twl);
+      q.ngroups = L.c3q_ng; q.gimg_floats = L.c3q_gimg; q.nt = L.c3q_nt; q.max_grid = P.pw4_grid;
+      for (int g = 0; g < PW4_MAX_GROUPS; ++g) { q.grp_r0[g] = L.c3q_r0[g]; q.grp_nt[g] = L.c3q_gnt[g]; }
+      const bool rawq = c.raw || pp.out_kind == OUT_Z;
+      LAUNCH_TRY(csn_launch_c3q(q, rawq ? 1 : 0, c.stream));
+      return c.mark("c3q_kernel");
+    }
+  }
   if (P.tiled3 && csn_c3_eligible(a) && (!c.a16 || all_raw)) {   // 3x3 pass: LDS-tiled implicit GEMM
     LAUNCH_TRY(csn_launch_c3(a, all_raw ? 1 : 0, c.stream));
     return c.mark("goct_c3_kernel");
@@ -905,7 +993,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
           pa.blk_end[k] = blk;
         }
         LAUNCH_TRY(csn_launch_pool(pa, c.stream));
-        { const int ms_ = c.mark("avgpool2_kernel"); if (ms_ != CSN_OK) return ms_; }
+        { const int ms_ = c.mark("pool2_kernel"); if (ms_ != CSN_OK) return ms_; }
       } else {
         for (int i = 0; i < d.n_in; ++i)
           if (d.cin[i] > 0) xin[i] = c.act_in(d.in_act[i]);
@@ -936,6 +1024,29 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
       for (int i = 0; i < 3; ++i) bd.in[i] = xin[i];
       for (int j = 0; j < d.n_out; ++j)
         if (d.cout[j] > 0) bd.act[j] = c.act_out(d.out_act[j]);
+      if (P.c3q && P.tiled3 && !c.a16 && d.ksize == 3) {   // 2x2 max-pooled copies for the high -> low slices of c3q_kernel
+        bool uses = false;
+        for (const PwLaunchPlan& L : u.pwl) uses = uses || L.c3q;
+        PoolArgs pa;
+        pa.n = 0; pa.a16 = 0; pa.pad = 0;
+        int blk = 0;
+        for (int i = 0; i < d.n_in && uses; ++i) {
+          if (u.mp_off[i] < 0 || !xin[i]) continue;
+          const int k = pa.n++;
+          pa.in[k] = xin[i];
+          pa.out[k] = reinterpret_cast<float*>(c.ws + u.mp_off[i]);
+          bd.mp[i] = pa.out[k];
+          pa.planes[k] = S * d.cin[i];
+          pa.Ho[k] = P.H >> (u.base_lvl + i + 1); pa.Wo[k] = P.W >> (u.base_lvl + i + 1);
+          const int64_t lanes = (int64_t)pa.planes[k] * pa.Ho[k] * ((pa.Wo[k] + 1) / 2);
+          blk += (int)((lanes + CSN_BLOCK - 1) / CSN_BLOCK);
+          pa.blk_end[k] = blk;
+        }
+        if (pa.n > 0) {
+          LAUNCH_TRY(csn_launch_maxpool(pa, c.stream));
+          { const int ms_ = c.mark("pool2_kernel"); if (ms_ != CSN_OK) return ms_; }
+        }
+      }
       if (u.z_off >= 0) bd.z = bd.zout = reinterpret_cast<float*>(c.ws + u.z_off);
       if (next && next->d.kind == CSN_UNIT_CLS) {   // cls_layer (csnet.py:306-308,381) rides in this unit's epilogue
         const PwLaunchPlan& CL = next->pwl[0];
@@ -1305,6 +1416,7 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   P->B = B; P->H = H; P->W = W;
   P->S = (sub_batch <= 0 || sub_batch > B) ? B : sub_batch;
   if (const char* v = std::getenv("CSN_PW4_GRID")) { if (std::atoi(v) >= 8) P->pw4_grid = std::atoi(v); }
+  if (const char* v = std::getenv("CSN_C3Q_NT")) { if (std::atoi(v) >= 1) P->c3q_cap = std::atoi(v); }
   if (const char* v = std::getenv("CSN_PW4_TWL")) { if (std::atoi(v) >= 2 && std::atoi(v) <= 6) P->pw4_twl = std::atoi(v); }
   Builder bl(*P);
   P->acts.resize(n_acts);
@@ -1466,6 +1578,7 @@ int csn_plan_set_option(csn_plan* P, int32_t option, int32_t value) {
     case CSN_OPT_FUSE_CLS: P->fuse_cls = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_TILED3: P->tiled3 = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_PW4: P->pw4 = value != 0; drop_graph(P); return CSN_OK;
+    case CSN_OPT_C3Q: P->c3q = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_FUSE_ILB: P->fuse_ilb = value < 0 ? 0 : value; drop_graph(P); return CSN_OK;
     case CSN_OPT_OVERLAP: P->overlap = value != 0; P->overlap_bwd = value == 2; drop_graph(P); return CSN_OK;
     case CSN_OPT_TRAIN_BF16: P->act16 = value != 0; drop_graph(P); return CSN_OK;
@@ -1706,7 +1819,11 @@ const char* csn_unit_kernel_name(const csn_plan* P, int32_t u) {
   if (P->fuse_dw && P->units[u].d.kind == CSN_UNIT_DW) {
     if (P->units[u].fuse_next || (u > 0 && P->units[u - 1].fuse_next)) return "dw3x3x2_bn_prelu_kernel";
   }
-  if (P->tiled3 && P->units[u].c3) return "goct_c3_kernel";
+  if (P->tiled3 && P->units[u].c3) {
+    bool q = P->c3q;
+    for (const PwLaunchPlan& L : P->units[u].pwl) q = q && L.c3q;
+    return q ? "c3q_kernel" : "goct_c3_kernel";
+  }
   if (P->pw4 && P->units[u].pw4 && !(P->fuse_cls && P->units[u].fuse_cls)) return "pw4_kernel";
   return P->units[u].kname;
 }

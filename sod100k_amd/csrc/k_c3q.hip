@@ -1,0 +1,235 @@
+// k_c3q.hip -- gOctConv 3x3 passes, lane = 2x2 output quad, v_mfma_f32_4x4x1_16B_f32 straight from the load registers.
+//
+// Reference semantics (CSNet/model/csnet.py:664-726 with kernel_size 3, padding 1): for output branch j
+//     y_j = conv3x3(x_j) [+ conv3x3(max_pool2(x_{j-1}))] [+ bilinear_up2(z)],   z = conv3x3(x_{j+1}) (its own launch)
+// followed by BN + PReLU (gOctaveCBR 778-792); stage0.0 and the stride-2 entry units of stages 2-4 (33-40, 703-716).
+//
+// MI355X mapping (round 3; the eval-mode replacement of goct_c3_kernel, profiles/r3_notes.md).  A 3x3 convolution has
+// nine matrix-pipe products per loaded value, so it is bound by the fp32 matrix rate, not by bytes; goct_c3_kernel's LDS
+// tile + 16x16x4 MFMA reached ~35 % of that rate (two block barriers per 16-channel chunk, 2 blocks per CU, 16-row / 16-
+// channel padding).  Here
+//   * a LANE owns the output quad (2y + qy, 2x + qx) and, per input channel, the 4x4 window around it in 16 registers
+//     (four 64-bit centre loads + eight edge dwords through a bounded buffer resource whose out-of-range offsets return 0 =
+//     the zero padding); a high -> low slice (conv of the 2x2 max-pooled finer branch) reads a max-pooled copy written by
+//     maxpool2_kernel in front of the launch (k_misc.hip): pooling inside the gather would hold 64 raw registers per channel;
+//   * v_mfma_f32_4x4x1_16B_f32 per (channel, tap, row tile, quad pixel): B = the window register of that pixel and tap,
+//     A = W[4t + (lane & 3)][channel, tap] from the LDS image (one ds_read_b128 = four row tiles, shared by the four quad
+//     pixels), D = four consecutive output channels of the lane's own pixel.  Rows padded to 4, K not padded, 36 NT
+//     MFMAs per channel against 12 loads: the next channel's window is in flight while this one is contracted, no barrier
+//     after the weight image is staged, one or two waves per SIMD keep the matrix pipe busy;
+//   * the low -> high term bilinear_up2(z) is added to the accumulators in the epilogue from the 3x3 neighbourhood of the
+//     quad's parent pixel (the same lane-local interpolation as k_pw4.hip), then folded BN + PReLU, 64-bit stores.
+// Output channels are cut into M groups of NT row tiles (16 NT accumulator registers); the groups of a tile run on
+// neighbouring waves.  Needs even H and W (every shipped geometry; goct_c3_kernel stays as the fallback and serves
+// the train-mode / backward launches).
+#include "pw4_common.h"
+
+#ifndef C3Q_OCC
+#define C3Q_OCC 2
+#endif
+
+namespace {
+
+struct C3qGeo {        // per item, per lane
+  unsigned row[4];     // byte offset of (window row r, column 2x) inside a channel plane; 0x80000000 when the row is outside
+  unsigned dl, dr;     // add to a row offset for the left (column 2x - 1) / right (column 2x + 2) edge; out of range when outside
+};
+
+// 4x4 window of one channel at the pass resolution
+__device__ __forceinline__ void c3q_load_own(csn_buf rb, const C3qGeo& g, unsigned so, float (&v)[16]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float2 c = csn_ld2(rb, g.row[r], so);
+    v[4 * r + 1] = c.x; v[4 * r + 2] = c.y;
+    v[4 * r] = csn_ld1(rb, g.row[r] + g.dl, so);
+    v[4 * r + 3] = csn_ld1(rb, g.row[r] + g.dr, so);
+  }
+}
+
+// nine taps of one channel: wk = image rows of (channel, tap 0) (each [4][P] floats)
+template <int NT, int P>
+__device__ __forceinline__ void c3q_channel(const float (&v)[16], const float* wk, csn_f4 (&acc)[4][NT]) {
+  constexpr int NT4 = (NT + 3) & ~3;
+#pragma unroll
+  for (int t9 = 0; t9 < 9; ++t9) {
+    const int ty = t9 / 3, tx = t9 - 3 * ty;
+    Pw4A<NT4> a;
+    pw4_load_a<NT4, P>(wk + t9 * 4 * P, a);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) pw4_mfma<NT4>(a, t, v[4 * ((s >> 1) + ty) + (s & 1) + tx], acc[s][t]);
+  }
+}
+
+}  // namespace
+
+template <int NT, bool RAW>
+__global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q_kernel(C3qArgs a_byval) {
+  constexpr int NT4 = (NT + 3) & ~3, P = PW4_PITCH(NT4);
+  CSN_DYN_SMEM(float, lds);
+  const CSN_CONST_AS C3qArgs* a = CSN_KERNARG(C3qArgs, a_byval);
+  const int tid = threadIdx.x;
+  {
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(a->wimg);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    const int n4 = (a->ngroups * a->gimg_floats) >> 2;
+    for (int i = tid; i < n4; i += CSN_BLOCK) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = pw4_uniform(tid >> 6);
+  const int H = a->H, W = a->W, Hq = H >> 1, Wq = W >> 1;
+  const unsigned cs = (unsigned)(H * W) * 4u;
+  const int twl = a->twl;
+  const int lx = lane & ((1 << twl) - 1), ly = lane >> twl;
+  const int ng = a->ngroups;
+  const int tiles_xy = a->tiles_x * a->tiles_y;
+  const int nitems = tiles_xy * a->B * ng;
+  const int nslot = (int)(gridDim.x >> 3) * 4;
+  const int chunk = (((nitems + 7) >> 3) + ng - 1) / ng * ng;
+  const int xcd = blockIdx.x & 7;
+  const int iend = min((xcd + 1) * chunk, nitems);
+#ifdef CSN_CPU_EMU
+  const float* wl_lane = lds;
+#else
+  const float* wl_lane = lds + (lane & 3) * P;
+#endif
+  for (int item = xcd * chunk + (int)(blockIdx.x >> 3) * 4 + wave; item < iend; item += nslot) {
+    const int tile = item / ng, g = item - tile * ng;
+    const int b = tile / tiles_xy, txy = tile - b * tiles_xy;
+    const int ty = txy / a->tiles_x, tx = txy - ty * a->tiles_x;
+    const int yq = (ty << (6 - twl)) + ly, xq = (tx << twl) + lx;
+    const bool valid = yq < Hq && xq < Wq;
+    const int y = min(yq, Hq - 1), x = min(xq, Wq - 1);
+    const float* wg = wl_lane + g * a->gimg_floats;
+
+    csn_f4 acc[4][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[s][t][i] = 0.f;
+
+    const bool has_l = x > 0, has_r = 2 * x + 2 < W;
+    int krow = 0;   // image row (= gathered entry) of the slice's first channel, tap 0
+    for (int s = 0; s < a->nsrc; ++s) {
+      const int C = a->src[s].C;
+      C3qGeo geo;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int yy = 2 * y - 1 + r;
+        geo.row[r] = (yy >= 0 && yy < H) ? (unsigned)(yy * W + 2 * x) * 4u : 0x80000000u;
+      }
+      geo.dl = has_l ? 0xfffffffcu : 0x40000000u;
+      geo.dr = has_r ? 8u : 0x40000000u;
+      const csn_buf rb = csn_make_buf_n(a->src[s].ptr + (int64_t)b * a->src[s].Ctot * (int64_t)(cs >> 2), (unsigned)a->src[s].Ctot * cs);
+      // channel c is contracted while channel c + 1 is in flight: two register sets, channels walked in pairs
+      float vA[16], vB[16];
+      c3q_load_own(rb, geo, 0u, vA);
+      PW4_FENCE();
+      const int nf = C - 1;
+      int c = 0;
+      for (int p = 0; p < (nf >> 1); ++p) {
+        c3q_load_own(rb, geo, (unsigned)(c + 1) * cs, vB);
+        PW4_FENCE();
+        c3q_channel<NT, P>(vA, wg + (krow + 9 * c) * 4 * P, acc);
+        c3q_load_own(rb, geo, (unsigned)(c + 2) * cs, vA);
+        PW4_FENCE();
+        c3q_channel<NT, P>(vB, wg + (krow + 9 * (c + 1)) * 4 * P, acc);
+        c += 2;
+      }
+      if (nf & 1) {
+        c3q_load_own(rb, geo, (unsigned)(c + 1) * cs, vB);
+        PW4_FENCE();
+        c3q_channel<NT, P>(vA, wg + (krow + 9 * c) * 4 * P, acc);
+        ++c;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) vA[i] = vB[i];
+      }
+      c3q_channel<NT, P>(vA, wg + (krow + 9 * c) * 4 * P, acc);
+      krow += 9 * C;
+    }
+
+    // ---- epilogue: + bilinear_up2(z), folded BN + PReLU, 64-bit stores of the quad rows ----
+    const int r0 = a->grp_r0[g], nt = a->grp_nt[g];
+    const unsigned o0 = (unsigned)((2 * y) * W + 2 * x) * 4u, o1 = o0 + (unsigned)W * 4u;
+    const unsigned sv0 = valid ? o0 : 0x80000000u, sv1 = valid ? o1 : 0x80000000u;
+    const csn_buf ob = csn_make_buf_n(a->out + (int64_t)b * a->out_ctot * (int64_t)(cs >> 2), (unsigned)a->out_ctot * cs);
+    csn_cfp ep = csn_const(a->ep) + 4 * r0;
+    unsigned oz[9];
+    csn_buf zb = ob;
+    const unsigned csz = cs >> 2;
+    if (a->z) {
+      const int yy[3] = {max(y - 1, 0), y, min(y + 1, Hq - 1)};
+      const int xx[3] = {max(x - 1, 0), x, min(x + 1, Wq - 1)};
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) oz[3 * r + c] = (unsigned)(yy[r] * Wq + xx[c]) * 4u;
+      zb = csn_make_buf_n(a->z + (int64_t)b * a->z_ctot * (int64_t)(csz >> 2), (unsigned)a->z_ctot * csz);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t < nt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * t + i;
+          float zq[4] = {0.f, 0.f, 0.f, 0.f};
+          if (a->z) {
+            float zv[9];
+            const unsigned zo = (unsigned)min(a->z_c0 + r0 + r, a->z_ctot - 1) * csz;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) zv[k] = csn_ld1(zb, oz[k], zo);
+            pw4_up2_quad(zv, zq);
+          }
+          float o[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const float zsum = acc[s][t][i] + zq[s];
+            o[s] = RAW ? zsum : pw4_epi(zsum, ep[4 * r], ep[4 * r + 1], ep[4 * r + 2]);
+          }
+          const unsigned so = (unsigned)(a->out_c0 + r0 + r) * cs;
+          csn_st2(ob, sv0, so, make_float2(o[0], o[1]));
+          csn_st2(ob, sv1, so, make_float2(o[2], o[3]));
+        }
+      }
+    }
+  }
+}
+
+// ---- instantiation table -----------------------------------------------------------------------------------------
+#define C3Q_INST_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+
+typedef void (*C3qFn)(C3qArgs);
+struct C3qEntry { int nt; C3qFn fn[2]; };
+#define C3Q_ENTRY(N) {N, {c3q_kernel<N, false>, c3q_kernel<N, true>}},
+static const C3qEntry g_c3q_table[] = {C3Q_INST_LIST(C3Q_ENTRY)};
+
+int csn_c3q_max_tiles(void) { return 7; }
+
+int csn_launch_c3q(const C3qArgs& a, int raw, void* stream) {
+  const C3qEntry* e = nullptr;
+  for (size_t i = 0; i < sizeof(g_c3q_table) / sizeof(g_c3q_table[0]); ++i)
+    if (g_c3q_table[i].nt == a.nt) e = &g_c3q_table[i];
+  if (!e) return 1;
+  const int nitems = a.tiles_x * a.tiles_y * a.B * a.ngroups;
+  int nblk = (nitems + 3) / 4;
+  if (nblk > a.max_grid) nblk = a.max_grid;
+  const dim3 grid((nblk + 7) & ~7);
+  const size_t lds = (size_t)a.ngroups * a.gimg_floats * sizeof(float);
+#ifndef CSN_CPU_EMU
+  static bool attr_done = false;
+  if (!attr_done) {
+    for (size_t i = 0; i < sizeof(g_c3q_table) / sizeof(g_c3q_table[0]); ++i)
+      for (int r = 0; r < 2; ++r) {
+        const hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(g_c3q_table[i].fn[r]),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (er != hipSuccess) return (int)er;
+      }
+    attr_done = true;
+  }
+#endif
+  CSN_LAUNCH(e->fn[raw ? 1 : 0], grid, dim3(CSN_BLOCK), lds, stream, a);
+  return (int)hipGetLastError();
+}

@@ -80,6 +80,14 @@ __global__ __launch_bounds__(CSN_BLOCK) void csn_prep_kernel(const CsnPrepJob* _
     case CSN_PREP_FLIP9:
       for (int i = tid; i < j.n; i += CSN_BLOCK) dst[i] = j.p0f * arena[j.src0 + (i / 9) * 9 + 8 - (i % 9)];
       break;
+    case CSN_PREP_C3Q: {
+      const int ncol = j.p1 * 9, t0 = j.p3 & 0xff, k0 = j.p3 >> 8;
+      const int tot = j.n * ncol;
+      for (int i = tid; i < tot; i += CSN_BLOCK) {
+        const int r = i / ncol, c = i - r * ncol;
+        dst[((int64_t)(k0 + c) * 4 + (r & 3)) * j.p2 + t0 + (r >> 2)] = j.p0f * arena[j.src0 + (int64_t)r * j.p0 + c];
+      }
+    } break;
     case CSN_PREP_PW4: {
       const int ncol = j.p1, t0 = j.p3 & 0xff, k0 = j.p3 >> 8;
       const int tot = j.n * ncol;
@@ -514,9 +522,10 @@ int csn_launch_dw(const DwArgs& a, void* stream) {
 }
 
 // -------------------------------------------------------------------------------------- avg-pool
-// out[y][x] = mean of the 2x2 input window.  A lane produces 2 output pixels from two float4 loads.
-template <typename AT>
-__global__ __launch_bounds__(CSN_BLOCK) void avgpool2_kernel(PoolArgs a) {
+// out[y][x] = mean (MAX: maximum, F.max_pool2d(x, 2, 2) of csnet.py:708-714) of the 2x2 input window.  A lane produces 2
+// output pixels from two float4 loads.
+template <typename AT, bool MAX>
+__global__ __launch_bounds__(CSN_BLOCK) void pool2_kernel(PoolArgs a) {
   int bid = blockIdx.x;
   int k = 0;
   if (a.n > 1 && bid >= a.blk_end[0]) k = 1;
@@ -538,20 +547,36 @@ __global__ __launch_bounds__(CSN_BLOCK) void avgpool2_kernel(PoolArgs a) {
     const float4 r0 = act_ld4(ip);
     const float4 r1 = act_ld4(ip + Wi);
     float2 o;
-    o.x = (r0.x + r0.y + r1.x + r1.y) * 0.25f;
-    o.y = (r0.z + r0.w + r1.z + r1.w) * 0.25f;
+    if (MAX) {
+      o.x = fmaxf(fmaxf(r0.x, r0.y), fmaxf(r1.x, r1.y));
+      o.y = fmaxf(fmaxf(r0.z, r0.w), fmaxf(r1.z, r1.w));
+    } else {
+      o.x = (r0.x + r0.y + r1.x + r1.y) * 0.25f;
+      o.y = (r0.z + r0.w + r1.z + r1.w) * 0.25f;
+    }
     act_st2(op, o);
   } else {
-    act_st(op, (act_ld(ip) + act_ld(ip + 1) + act_ld(ip + Wi) + act_ld(ip + Wi + 1)) * 0.25f);
-    if (2 * xp + 1 < Wo) act_st(op + 1, (act_ld(ip + 2) + act_ld(ip + 3) + act_ld(ip + Wi + 2) + act_ld(ip + Wi + 3)) * 0.25f);
+    const float a0 = act_ld(ip), a1 = act_ld(ip + 1), a2 = act_ld(ip + Wi), a3 = act_ld(ip + Wi + 1);
+    act_st(op, MAX ? fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)) : (a0 + a1 + a2 + a3) * 0.25f);
+    if (2 * xp + 1 < Wo) {
+      const float b0 = act_ld(ip + 2), b1 = act_ld(ip + 3), b2 = act_ld(ip + Wi + 2), b3 = act_ld(ip + Wi + 3);
+      act_st(op + 1, MAX ? fmaxf(fmaxf(b0, b1), fmaxf(b2, b3)) : (b0 + b1 + b2 + b3) * 0.25f);
+    }
   }
 }
 
 int csn_launch_pool(const PoolArgs& a, void* stream) {
   const int nblk = a.blk_end[a.n - 1];
   if (nblk <= 0) return 0;
-  if (a.a16) CSN_LAUNCH((avgpool2_kernel<csn_bf16>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
-  else CSN_LAUNCH((avgpool2_kernel<float>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+  if (a.a16) CSN_LAUNCH((pool2_kernel<csn_bf16, false>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+  else CSN_LAUNCH((pool2_kernel<float, false>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+  return (int)hipGetLastError();
+}
+
+int csn_launch_maxpool(const PoolArgs& a, void* stream) {   // float tensors only (eval-mode 3x3 passes, k_c3q.hip)
+  const int nblk = a.blk_end[a.n - 1];
+  if (nblk <= 0) return 0;
+  CSN_LAUNCH((pool2_kernel<float, true>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
 }
 

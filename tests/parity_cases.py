@@ -657,69 +657,98 @@ def check_train_units_local(lib, device, manifest, B=2, size=64, act_dtype="bf16
             bad.append((kind, name, r, n))
 
     ctx = O.bf16_activations() if bf16 else contextlib.nullcontext()
+    kink_units = []
     for ui, (u, name) in enumerate(zip(units, names)):
         n_in, n_out = int(u.n_in), int(u.n_out)
-        xs = []
-        for i in range(n_in):
-            if u.cin[i] > 0:
-                xs.append(A[int(u.in_act[i])].clone().requires_grad_(int(u.in_act[i]) > 0))
-            else:
-                xs.append(None)
         pkeys = [k for k in pshape if k.startswith(name + ".")]
-        loc = {k: v.clone() for k, v in sd.items() if k.startswith(name + ".")}
-        for k in pkeys:
-            loc[k].requires_grad_(True)
-        O.Z_CAPTURE = []
-        try:
-            with ctx:
-                if name == "cls_layer":
-                    out = O._st(F.conv2d(xs[0], loc["cls_layer.weight"], loc["cls_layer.bias"]))
-                    ys = [F.interpolate(out, x.shape[2:], mode="bilinear", align_corners=False)]
-                elif name.endswith(".conv1x1"):
-                    blk = blocks[name[:-len(".conv1x1")]]
-                    a_in, _ = O._alphas(blk["inlist"]); a_out, _ = O._alphas(blk["outlist"])
-                    k = 3 if (blk["first"] or blk["stride"] == 2) else 1
-                    ys = O.goct_cbr(xs, loc, name, a_in, a_out, k, blk["stride"], True)
-                elif ".conv3x3_" in name:
-                    ys = O.simplified_cbr(xs, loc, name, True)
-                elif name == "oct_fuse.fuse":
-                    ys = O.goct_cbr(xs, loc, name, O._alphas(cfg3[0][0])[0], O._alphas(cfg3[1][0])[0], 1, 1, True)
-                elif name.startswith("oct_fuse.ms.convs."):
-                    ys = [O.ms_block(xs[0], loc, name, cfg3[1][2][int(name.rsplit(".", 1)[1])], True)]
-                elif name == "oct_fuse.fuse1x1":
-                    ys = O.goct_cbr(xs, loc, name, O._alphas(cfg3[1][1])[0], [1], 1, 1, True)
+        outs = [j for j in range(n_out) if u.cout[j] > 0] if name != "cls_layer" else [0]
+
+        def local(flips):
+            """The unit recomputed by the oracle from the device's own inputs / upstream gradients; ``flips``: PReLU elements
+            (per BatchNorm call) that take the other branch -- see O.PRELU_FLIP."""
+            xs = []
+            for i in range(n_in):
+                if u.cin[i] > 0:
+                    xs.append(A[int(u.in_act[i])].clone().requires_grad_(int(u.in_act[i]) > 0))
                 else:
-                    raise AssertionError(f"unit {name}?")
-                if isinstance(ys, torch.Tensor):
-                    ys = [ys]
-                zs = list(O.Z_CAPTURE)
-                for z in zs:
-                    z.retain_grad()
-                # forward: the device's z / activation of this unit against the local recomputation
-                outs = [j for j in range(n_out) if u.cout[j] > 0] if name != "cls_layer" else [0]
-                live = [yy for yy in ys if yy is not None]
-                assert len(live) == len(outs), (name, len(live), len(outs))
-                total = None
-                for q, j in enumerate(outs):
+                    xs.append(None)
+            loc = {k: v.clone() for k, v in sd.items() if k.startswith(name + ".")}
+            for k in pkeys:
+                loc[k].requires_grad_(True)
+            O.Z_CAPTURE = []
+            O.PRELU_Y = []
+            O.PRELU_FLIP = flips
+            try:
+                with ctx:
                     if name == "cls_layer":
-                        note("act", name, y.cpu(), live[q], tol_fwd)
-                        up = dy.cpu()
+                        out = O._st(F.conv2d(xs[0], loc["cls_layer.weight"], loc["cls_layer.bias"]))
+                        ys = [F.interpolate(out, x.shape[2:], mode="bilinear", align_corners=False)]
+                    elif name.endswith(".conv1x1"):
+                        blk = blocks[name[:-len(".conv1x1")]]
+                        a_in, _ = O._alphas(blk["inlist"]); a_out, _ = O._alphas(blk["outlist"])
+                        k = 3 if (blk["first"] or blk["stride"] == 2) else 1
+                        ys = O.goct_cbr(xs, loc, name, a_in, a_out, k, blk["stride"], True)
+                    elif ".conv3x3_" in name:
+                        ys = O.simplified_cbr(xs, loc, name, True)
+                    elif name == "oct_fuse.fuse":
+                        ys = O.goct_cbr(xs, loc, name, O._alphas(cfg3[0][0])[0], O._alphas(cfg3[1][0])[0], 1, 1, True)
+                    elif name.startswith("oct_fuse.ms.convs."):
+                        ys = [O.ms_block(xs[0], loc, name, cfg3[1][2][int(name.rsplit(".", 1)[1])], True)]
+                    elif name == "oct_fuse.fuse1x1":
+                        ys = O.goct_cbr(xs, loc, name, O._alphas(cfg3[1][1])[0], [1], 1, 1, True)
                     else:
-                        a = int(u.out_act[j])
-                        note("z", f"{name}[{j}]", Z[a], zs[q].detach(), tol_fwd)
-                        note("act", f"{name}[{j}]", A[a], live[q].detach(), tol_fwd)
-                        up = G[(a, 0)] + (G[(a, 1)] if (a, 1) in G else 0.0)
-                        w = flop_tab[ui * N.MAX_BRANCH + j]
-                        if w != 0.0:   # Oct_bn_hook (csnet.py:391-410): 0.5 w sum |mean_hw y| gamma^2, y detached; /batchsize
-                            gam = loc[[k for k in pkeys if k.endswith(f"bns.{j}.weight")][0]]
-                            gap = live[q].detach().mean(dim=(2, 3)).abs().sum(0)
-                            term = (flops_weight / B) * 0.5 * w * (gap * gam * gam).sum()
-                            total = term if total is None else total + term
-                    term = (live[q] * up).sum()
-                    total = term if total is None else total + term
-                total.backward()
-        finally:
-            O.Z_CAPTURE = None
+                        raise AssertionError(f"unit {name}?")
+                    if isinstance(ys, torch.Tensor):
+                        ys = [ys]
+                    zs = list(O.Z_CAPTURE)
+                    pre = list(O.PRELU_Y)
+                    for z in zs:
+                        z.retain_grad()
+                    live = [yy for yy in ys if yy is not None]
+                    assert len(live) == len(outs), (name, len(live), len(outs))
+                    total = None
+                    for q, j in enumerate(outs):
+                        if name == "cls_layer":
+                            up = dy.cpu()
+                        else:
+                            a = int(u.out_act[j])
+                            up = G[(a, 0)] + (G[(a, 1)] if (a, 1) in G else 0.0)
+                            w = flop_tab[ui * N.MAX_BRANCH + j]
+                            if w != 0.0:   # Oct_bn_hook (csnet.py:391-410): 0.5 w sum |mean_hw y| gamma^2, y detached; /batchsize
+                                gam = loc[[k for k in pkeys if k.endswith(f"bns.{j}.weight")][0]]
+                                gap = live[q].detach().mean(dim=(2, 3)).abs().sum(0)
+                                term = (flops_weight / B) * 0.5 * w * (gap * gam * gam).sum()
+                                total = term if total is None else total + term
+                        term = (live[q] * up).sum()
+                        total = term if total is None else total + term
+                    total.backward()
+            finally:
+                O.Z_CAPTURE = None
+                O.PRELU_Y = None
+                O.PRELU_FLIP = None
+            return xs, loc, zs, live, pre
+
+        xs, loc, zs, live, pre = local(None)
+        if name != "cls_layer" and not bf16:
+            # PReLU kink: an element whose pre-activation is zero to within rounding may take either branch on the device.
+            # Where the device's dz says it took the other one, the oracle follows (only inside that band).
+            flips = {}
+            for q, j in enumerate(outs):
+                d = (DZ[int(u.out_act[j])].double() - zs[q].grad.double()).abs()
+                band = pre[q].abs() <= 1e-5 * float(pre[q].abs().max())
+                m = band & (d > 20 * tol_bwd * float(zs[q].grad.double().pow(2).mean().sqrt()))
+                if bool(m.any()):
+                    flips[q] = m
+            if flips:
+                kink_units.append((name, {q: int(m.sum()) for q, m in flips.items()}))
+                xs, loc, zs, live, pre = local(flips)
+        for q, j in enumerate(outs):
+            if name == "cls_layer":
+                note("act", name, y.cpu(), live[q], tol_fwd)
+            else:
+                a = int(u.out_act[j])
+                note("z", f"{name}[{j}]", Z[a], zs[q].detach(), tol_fwd)
+                note("act", f"{name}[{j}]", A[a], live[q].detach(), tol_fwd)
         gmax = max(float(loc[k].grad.norm()) if loc[k].grad is not None else 0.0 for k in pkeys)
         for k in pkeys:
             g = flat[offs[k]:offs[k] + int(np.prod(pshape[k]))].view(pshape[k])
@@ -733,4 +762,7 @@ def check_train_units_local(lib, device, manifest, B=2, size=64, act_dtype="bf16
             if u.cin[i] > 0 and a > 0:
                 note("dx", f"{name}<-{i}", G[(a, eng.unit_in_slot(ui, i))], xs[i].grad, tol_bwd)
     assert not bad, f"{len(bad)} unit-local deviations over tolerance, worst first: {sorted(bad, key=lambda b: -b[2])[:8]}"
+    assert sum(sum(v.values()) for _, v in kink_units) <= 16, f"too many PReLU kink elements re-branched: {kink_units}"
+    if kink_units:
+        worst["kink_elements"] = kink_units
     return worst
