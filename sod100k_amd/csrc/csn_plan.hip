@@ -131,11 +131,17 @@ struct UnitPlan {
   IlbRolePlan ilb[2];
   int ilb_ok = 0;
   int ilb_width = 0;            // width of the finest output branch (CSN_OPT_FUSE_ILB threshold)
-  // GOCT 1x1, two input branches: plan of pw4_kernel (k_pw4.hip); pw4 = 0: the unit does not qualify
+  // GOCT 1x1 with two or three input branches: launches of pw4_kernel (k_pw4.hip); pw4 = 0: the unit does not qualify
+  struct Pw4Launch {
+    int hi_out = -1, lo_out = -1;    // output branch written from the high / low rows (-1: none)
+    int use_x2 = 0;                  // third input branch (single-output forms)
+    int nth = 0, ntl = 0, ng = 0, gimg = 0;
+    Pw4Group grp[PW4_MAX_GROUPS] = {};
+    int64_t wimg = -1, ep[2] = {-1, -1};
+  };
+  std::vector<Pw4Launch> pw4l;
   int pw4 = 0;
-  int pw4_nth = 0, pw4_ntl = 0, pw4_ng = 0, pw4_gimg = 0;
-  Pw4Group pw4_grp[PW4_MAX_GROUPS] = {};
-  int64_t pw4_wimg = -1, pw4_ep[2] = {-1, -1};
+  int pw4_old_mask = 0;              // output branches that stay on goct_pw_kernel (CSFHead.fuse's lowest branch)
   // MS
   int64_t ms_w[5] = {-1, -1, -1, -1, -1};
   Epi ms_epi;
@@ -536,12 +542,11 @@ int plan_goct(Builder& bl, UnitPlan& u) {
   return plan_pw4(bl, u, ci_off, co_off, cin_tot);
 }
 
-// Two-branch 1x1 unit on pw4_kernel (k_pw4.hip): M groups, weight image [group][K][4][P], interleaved epilogue records.
-int plan_pw4(Builder& bl, UnitPlan& u, const int* ci_off, const int* co_off, int cin_tot) {
+// 1x1 unit with two or three input branches on pw4_kernel (k_pw4.hip): per launch M groups, weight image [group][K][4][P]
+// (gathered channels: branch 0, 1, 2 in order), interleaved epilogue records.
+int plan_pw4_launch(Builder& bl, UnitPlan& u, const int* ci_off, const int* co_off, int cin_tot, int hi_out, int lo_out, int use_x2) {
   const csn_unit_desc& d = u.d;
-  if (d.ksize != 1 || d.stride != 1 || u.std_conv || d.n_in != 2 || d.cin[0] <= 0 || d.cin[1] <= 0 || d.cout[0] <= 0) return CSN_OK;
-  const int OH = d.cout[0], OL = d.n_out >= 2 ? d.cout[1] : 0;
-  if (d.n_out > 2) return CSN_OK;
+  const int OH = hi_out >= 0 ? d.cout[hi_out] : 0, OL = lo_out >= 0 ? d.cout[lo_out] : 0;
   const int nth_tot = (OH + 3) / 4, ntl_tot = (OL + 3) / 4;
   int ng = 0, pn = 0, pl = 0;
   for (int g = 1; g <= PW4_MAX_GROUPS; ++g) {
@@ -551,38 +556,69 @@ int plan_pw4(Builder& bl, UnitPlan& u, const int* ci_off, const int* co_off, int
     ng = g; pn = a; pl = b;
     break;
   }
-  if (ng == 0) return CSN_OK;
-  const int CH = d.cin[0], CL = d.cin[1], K = CH + CL;
+  if (ng == 0) return -1;
+  const int nin = use_x2 ? 3 : 2;
+  int K = 0;
+  for (int i = 0; i < nin; ++i) K += d.cin[i];
   const int NT4 = (pn + pl + 3) & ~3, Pp = PW4_PITCH(NT4);
-  u.pw4_nth = pn; u.pw4_ntl = pl; u.pw4_ng = ng; u.pw4_gimg = K * 4 * Pp;
-  if ((int64_t)ng * u.pw4_gimg * 4 > 64 * 1024) return CSN_OK;
-  u.pw4_wimg = bl.alloc_packed((int64_t)ng * u.pw4_gimg);
+  UnitPlan::Pw4Launch L;
+  L.hi_out = hi_out; L.lo_out = lo_out; L.use_x2 = use_x2;
+  L.nth = pn; L.ntl = pl; L.ng = ng; L.gimg = K * 4 * Pp;
+  if ((int64_t)ng * L.gimg * 4 > 150 * 1024) return -1;
+  L.wimg = bl.alloc_packed((int64_t)ng * L.gimg);
   const int gh = (nth_tot + ng - 1) / ng, gl = (ntl_tot + ng - 1) / ng;
   for (int g = 0; g < ng; ++g) {
-    Pw4Group& G = u.pw4_grp[g];
+    Pw4Group& G = L.grp[g];
     G.r0h = 4 * g * gh; G.nth = std::max(0, std::min(gh, nth_tot - g * gh));
     G.r0l = 4 * g * gl; G.ntl = std::max(0, std::min(gl, ntl_tot - g * gl));
-    const int64_t img = u.pw4_wimg + (int64_t)g * u.pw4_gimg;
+    const int64_t img = L.wimg + (int64_t)g * L.gimg;
     const int nrh = std::min(4 * G.nth, OH - G.r0h), nrl = std::min(4 * G.ntl, OL - G.r0l);
-    for (int i = 0; i < 2; ++i) {   // gathered channels: branch 0 first (k0 = 0), then branch 1 (k0 = CH)
-      const int k0 = i == 0 ? 0 : CH;
+    int k0 = 0;
+    for (int i = 0; i < nin; ++i) {   // gathered channels: branch 0 first, then 1, then 2
       if (nrh > 0)
-        bl.job(CSN_PREP_PW4, nrh, img, d.w_off[0] + (int64_t)(co_off[0] + G.r0h) * cin_tot + ci_off[i], -1, -1, -1, 1.f,
+        bl.job(CSN_PREP_PW4, nrh, img, d.w_off[0] + (int64_t)(co_off[hi_out] + G.r0h) * cin_tot + ci_off[i], -1, -1, -1, 1.f,
                cin_tot, d.cin[i], Pp, 0 | (k0 << 8));
       if (nrl > 0)
-        bl.job(CSN_PREP_PW4, nrl, img, d.w_off[0] + (int64_t)(co_off[1] + G.r0l) * cin_tot + ci_off[i], -1, -1, -1, 1.f,
+        bl.job(CSN_PREP_PW4, nrl, img, d.w_off[0] + (int64_t)(co_off[lo_out] + G.r0l) * cin_tot + ci_off[i], -1, -1, -1, 1.f,
                cin_tot, d.cin[i], Pp, pn | (k0 << 8));
+      k0 += d.cin[i];
     }
   }
-  for (int j = 0; j < 2; ++j) {
-    const int C = j == 0 ? OH : OL;
-    if (C == 0) continue;
-    const int rows = 4 * ng * (j == 0 ? pn : pl) + 4;   // whole tiles of every group are readable
-    u.pw4_ep[j] = bl.alloc_packed((int64_t)rows * 4);
-    bl.job(CSN_PREP_BN_SCALE, C, u.pw4_ep[j], d.bn[j].weight, d.bn[j].running_var, -1, -1, 1.f, 0, 0, 4, 0);
-    bl.job(CSN_PREP_BN_SHIFT, C, u.pw4_ep[j], d.bn[j].weight, d.bn[j].running_var, d.bn[j].bias, d.bn[j].running_mean, 1.f, 0, 0, 4, 1);
-    bl.job(CSN_PREP_COPY, C, u.pw4_ep[j], d.bn[j].prelu, -1, -1, -1, 1.f, 0, 0, 4, 2);
+  for (int q = 0; q < 2; ++q) {
+    const int j = q == 0 ? hi_out : lo_out;
+    if (j < 0) continue;
+    const int C = d.cout[j];
+    const int rows = 4 * ng * (q == 0 ? pn : pl) + 4;   // whole tiles of every group are readable
+    L.ep[q] = bl.alloc_packed((int64_t)rows * 4);
+    bl.job(CSN_PREP_BN_SCALE, C, L.ep[q], d.bn[j].weight, d.bn[j].running_var, -1, -1, 1.f, 0, 0, 4, 0);
+    bl.job(CSN_PREP_BN_SHIFT, C, L.ep[q], d.bn[j].weight, d.bn[j].running_var, d.bn[j].bias, d.bn[j].running_mean, 1.f, 0, 0, 4, 1);
+    bl.job(CSN_PREP_COPY, C, L.ep[q], d.bn[j].prelu, -1, -1, -1, 1.f, 0, 0, 4, 2);
   }
+  u.pw4l.push_back(L);
+  return 0;
+}
+
+int plan_pw4(Builder& bl, UnitPlan& u, const int* ci_off, const int* co_off, int cin_tot) {
+  const csn_unit_desc& d = u.d;
+  if (d.ksize != 1 || d.stride != 1 || u.std_conv || d.n_in < 2 || d.cin[0] <= 0 || d.cin[1] <= 0 || d.cout[0] <= 0) return CSN_OK;
+  bool ok = true;
+  if (d.n_in == 2) {
+    if (d.n_out > 2) return CSN_OK;
+    ok = plan_pw4_launch(bl, u, ci_off, co_off, cin_tot, 0, (d.n_out >= 2 && d.cout[1] > 0) ? 1 : -1, 0) == 0;
+  } else {   // CSFHead.fuse / fuse1x1: one single-output launch per output branch 0 / 1, the lowest branch stays where it was
+    const int x2 = d.cin[2] > 0 ? 1 : 0;
+    ok = plan_pw4_launch(bl, u, ci_off, co_off, cin_tot, 0, -1, x2) == 0;
+    if (ok && d.n_out >= 2 && d.cout[1] > 0) ok = plan_pw4_launch(bl, u, ci_off, co_off, cin_tot, -1, 1, x2) == 0;
+    if (d.n_out >= 3 && d.cout[2] > 0) {
+      u.pw4_old_mask = 1 << 2;
+      for (const PwLaunchPlan& L : u.pwl) {   // ... which needs that branch in a launch of its own
+        bool has2 = false, other = false;
+        for (const PwPassPlan& pp : L.passes) { has2 = has2 || pp.out_branch == 2; other = other || pp.out_branch != 2; }
+        if (has2 && other) ok = false;
+      }
+    }
+  }
+  if (!ok) { u.pw4l.clear(); u.pw4_old_mask = 0; return CSN_OK; }
   u.pw4 = 1;
   return CSN_OK;
 }
@@ -998,26 +1034,71 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
         for (int i = 0; i < d.n_in; ++i)
           if (d.cin[i] > 0) xin[i] = c.act_in(d.in_act[i]);
       }
-      if (P.pw4 && u.pw4 && !c.raw && !c.a16 && !(next && next->d.kind == CSN_UNIT_CLS)) {
-        Pw4Args a;
-        a.xh = xin[0]; a.xl = xin[1];
-        a.yh = c.act_out(d.out_act[0]);
-        a.yl = (d.n_out >= 2 && d.cout[1] > 0) ? c.act_out(d.out_act[1]) : nullptr;
-        a.wimg = c.pk(u.pw4_wimg);
-        a.ep_h = c.pk(u.pw4_ep[0]);
-        a.ep_l = u.pw4_ep[1] >= 0 ? c.pk(u.pw4_ep[1]) : nullptr;
-        a.CH = d.cin[0]; a.CL = d.cin[1]; a.OH = d.cout[0]; a.OL = d.n_out >= 2 ? d.cout[1] : 0;
-        a.Hl = P.H >> (u.base_lvl + 1); a.Wl = P.W >> (u.base_lvl + 1); a.B = S;
-        int twl = 0;
-        while (twl < P.pw4_twl && (1 << twl) < a.Wl) ++twl;
-        a.twl = twl;
-        a.tiles_x = (a.Wl + (1 << twl) - 1) >> twl;
-        a.tiles_y = (a.Hl + (64 >> twl) - 1) / (64 >> twl);
-        a.ngroups = u.pw4_ng; a.gimg_floats = u.pw4_gimg; a.nth = u.pw4_nth; a.ntl = u.pw4_ntl;
-        a.max_grid = P.pw4_grid; a.pad = 0;
-        for (int g = 0; g < PW4_MAX_GROUPS; ++g) a.grp[g] = u.pw4_grp[g];
-        LAUNCH_TRY(csn_launch_pw4(a, 0, c.stream));
-        { const int ms_ = c.mark("pw4_kernel"); if (ms_ != CSN_OK) return ms_; }
+      const bool cls_next = next && next->d.kind == CSN_UNIT_CLS;
+      if (P.pw4 && u.pw4 && !c.raw && !c.a16 && (!cls_next || (u.pw4l.size() == 1 && u.pw4l[0].lo_out < 0))) {
+        // launches of the unit are independent of each other: parallel stream lanes (see below)
+        std::vector<const PwLaunchPlan*> old;
+        for (const PwLaunchPlan& L : u.pwl) {
+          bool keep = false;
+          for (const PwPassPlan& pp : L.passes) keep = keep || ((u.pw4_old_mask >> pp.out_branch) & 1);
+          if (keep) old.push_back(&L);
+        }
+        const int nl = (int)u.pw4l.size() + (int)old.size();
+        const bool fork = c.lanes && nl >= 2 && nl <= 3;
+        if (fork) { const int st0 = lanes_fork(c, nl - 1); if (st0 != CSN_OK) return st0; }
+        int lane = 0;
+        for (const UnitPlan::Pw4Launch& L : u.pw4l) {
+          Ctx cl = c;
+          if (fork && lane > 0) cl.stream = c.P.lane[lane - 1];
+          ++lane;
+          Pw4Args a;
+          a.xh = xin[0]; a.xl = xin[1]; a.x2 = L.use_x2 ? xin[2] : nullptr;
+          a.yh = L.hi_out >= 0 ? c.act_out(d.out_act[L.hi_out]) : nullptr;
+          a.yl = L.lo_out >= 0 ? c.act_out(d.out_act[L.lo_out]) : nullptr;
+          a.red_w = a.red_b = nullptr; a.logits = nullptr;
+          if (cls_next) {   // cls_layer (csnet.py:306-308,381) rides in this unit's epilogue
+            const PwLaunchPlan& CL = next->pwl[0];
+            a.red_w = c.pk(CL.wimg + CL.passes[0].w_off);   // row 0 of its (zero padded) weight image
+            a.red_b = c.pk(CL.passes[0].epi.shift);
+            a.logits = reinterpret_cast<float*>(c.ws + next->logits_off);
+          }
+          a.wimg = c.pk(L.wimg);
+          a.ep_h = L.ep[0] >= 0 ? c.pk(L.ep[0]) : nullptr;
+          a.ep_l = L.ep[1] >= 0 ? c.pk(L.ep[1]) : nullptr;
+          a.CH = d.cin[0]; a.CL = d.cin[1]; a.C2 = L.use_x2 ? d.cin[2] : 0; a.pad2 = 0;
+          a.OH = L.hi_out >= 0 ? d.cout[L.hi_out] : 0; a.OL = L.lo_out >= 0 ? d.cout[L.lo_out] : 0;
+          a.Hl = P.H >> (u.base_lvl + 1); a.Wl = P.W >> (u.base_lvl + 1); a.B = S;
+          int twl = 0;
+          while (twl < P.pw4_twl && (1 << twl) < a.Wl) ++twl;
+          a.twl = twl;
+          a.tiles_x = (a.Wl + (1 << twl) - 1) >> twl;
+          a.tiles_y = (a.Hl + (64 >> twl) - 1) / (64 >> twl);
+          a.ngroups = L.ng; a.gimg_floats = L.gimg; a.nth = L.nth; a.ntl = L.ntl;
+          a.max_grid = P.pw4_grid; a.pad = 0;
+          for (int g = 0; g < PW4_MAX_GROUPS; ++g) a.grp[g] = L.grp[g];
+          LAUNCH_TRY(csn_launch_pw4(a, 0, cl.stream));
+          { const int ms_ = cl.mark("pw4_kernel"); if (ms_ != CSN_OK) return ms_; }
+        }
+        if (!old.empty()) {
+          PwBind bo;
+          for (int i = 0; i < 3; ++i) bo.in[i] = xin[i];
+          for (int j = 0; j < d.n_out; ++j)
+            if (d.cout[j] > 0) bo.act[j] = c.act_out(d.out_act[j]);
+          for (const PwLaunchPlan* L : old) {
+            Ctx cl = c;
+            if (fork && lane > 0) cl.stream = c.P.lane[lane - 1];
+            ++lane;
+            const int st = launch_pw(cl, *L, bo);
+            if (st != CSN_OK) return st;
+          }
+        }
+        if (fork) { const int st1 = lanes_join(c, nl - 1); if (st1 != CSN_OK) return st1; }
+        if (cls_next) {
+          Up2Args ua;
+          ua.in = reinterpret_cast<const float*>(c.ws + next->logits_off); ua.out = c.y; ua.planes = S; ua.H = P.H; ua.W = P.W; ua.in16 = 0;
+          LAUNCH_TRY(csn_launch_up2(ua, c.stream));
+          { const int ms_ = c.mark("bilinear_up2_kernel"); if (ms_ != CSN_OK) return ms_; }
+        }
         break;
       }
       PwBind bd;
@@ -1824,7 +1905,9 @@ const char* csn_unit_kernel_name(const csn_plan* P, int32_t u) {
     for (const PwLaunchPlan& L : P->units[u].pwl) q = q && L.c3q;
     return q ? "c3q_kernel" : "goct_c3_kernel";
   }
-  if (P->pw4 && P->units[u].pw4 && !(P->fuse_cls && P->units[u].fuse_cls)) return "pw4_kernel";
+  if (P->pw4 && P->units[u].pw4 &&
+      !(P->fuse_cls && P->units[u].fuse_cls && !(P->units[u].pw4l.size() == 1 && P->units[u].pw4l[0].lo_out < 0)))
+    return "pw4_kernel";
   return P->units[u].kname;
 }
 

@@ -26,6 +26,12 @@
 //   * HBM traffic = unit inputs once + outputs once; tiles are walked in the XCD-aware order of k_goct_pw.hip.
 #include "pw4_common.h"
 
+// Three-branch units (CSFHead.fuse / fuse1x1, csnet.py:152-206) add a third input x2 at half the resolution of branch l; it
+// is supported by the single-output forms of the kernel: NTL = 0 (only y_h: x2 enters through bilinear x4 of the 3x3
+// neighbourhood of the lane's parent pixel, separable three-tap weights that depend on the lane's parity) and NTH = 0 (only
+// y_l: the usual four-tap bilinear x2).  With `red_w` the rows are not stored but reduced to ONE channel
+// red_b + sum_r red_w[r] * PReLU(BN(y_r)) -- cls_layer (csnet.py:306-308,381) riding in fuse1x1's epilogue; the M groups of
+// a tile are then walked by the same wave so that the sum stays in its registers.
 #ifndef PW4_HB
 #define PW4_HB 2    // high-branch channels per load batch (2 x 64-bit loads each; measured: 2 beats 4 and 8, profiles/r3_notes.md)
 #endif
@@ -38,8 +44,93 @@
 
 
 
-template <int NTH, int NTL, bool RAW>
-__global__ __launch_bounds__(CSN_BLOCK, PW4_OCC) void pw4_kernel(Pw4Args a_byval) {
+
+namespace {
+
+// bilinear taps of the third input (tensor at half the resolution of branch l: H2 x W2) for the lane's low pixel (y, x)
+struct Pw4X2 {
+  unsigned o[9];        // NTL = 0: 3x3 neighbourhood of the parent pixel (y >> 1, x >> 1), clamped; NTH = 0: o[0..3] = the four taps
+  float wy[2][3];       // NTL = 0: row weights of quad row dy over (parent row - 1, parent row, parent row + 1)
+  float wx[2][3];       //          column weights of quad column dx
+  float w4[4];          // NTH = 0: weights of the four taps
+};
+
+// upsample_bilinear2d, align_corners=False, scale 4: quad row Y = 2y + dy has source (Y + 0.5) / 4 - 0.5 = parent + {-0.375,
+// -0.125, +0.125, +0.375} for Y & 3 = 0..3; clamped neighbours reproduce PyTorch's clamped source index at the borders
+__device__ __forceinline__ void pw4_up4_weights(int ylow, float (&w)[2][3]) {
+  const bool odd = ylow & 1;
+  w[0][0] = odd ? 0.f : 0.375f; w[0][1] = odd ? 0.875f : 0.625f; w[0][2] = odd ? 0.125f : 0.f;
+  w[1][0] = odd ? 0.f : 0.125f; w[1][1] = odd ? 0.625f : 0.875f; w[1][2] = odd ? 0.375f : 0.f;
+}
+
+template <bool HI>
+__device__ __forceinline__ void pw4_x2_geo(int y, int x, int H2, int W2, Pw4X2& g) {
+  const int py = y >> 1, px = x >> 1;
+  if (HI) {
+    const int yy[3] = {max(py - 1, 0), py, min(py + 1, H2 - 1)};
+    const int xx[3] = {max(px - 1, 0), px, min(px + 1, W2 - 1)};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) g.o[3 * r + c] = (unsigned)(yy[r] * W2 + xx[c]) * 4u;
+    pw4_up4_weights(y, g.wy);
+    pw4_up4_weights(x, g.wx);
+  } else {   // scale 2: source y / 2 - 0.25 -> (py - 1: 0.25, py: 0.75) for even y, (py: 0.75, py + 1: 0.25) for odd y
+    const int ya = max((y & 1) ? py : py - 1, 0), yb = min((y & 1) ? py + 1 : py, H2 - 1);
+    const int xa = max((x & 1) ? px : px - 1, 0), xb = min((x & 1) ? px + 1 : px, W2 - 1);
+    const float wyb = (y & 1) ? 0.25f : 0.75f, wxb = (x & 1) ? 0.25f : 0.75f;
+    g.o[0] = (unsigned)(ya * W2 + xa) * 4u; g.o[1] = (unsigned)(ya * W2 + xb) * 4u;
+    g.o[2] = (unsigned)(yb * W2 + xa) * 4u; g.o[3] = (unsigned)(yb * W2 + xb) * 4u;
+    g.w4[0] = (1.f - wyb) * (1.f - wxb); g.w4[1] = (1.f - wyb) * wxb; g.w4[2] = wyb * (1.f - wxb); g.w4[3] = wyb * wxb;
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void pw4_load_x2(csn_buf rb, const Pw4X2& g, unsigned so, float (&v)[N]) {
+#pragma unroll
+  for (int t = 0; t < N; ++t) v[t] = csn_ld1(rb, g.o[t], so);
+}
+
+// one channel of the third input: NTL = 0 -> quad values by separable three-tap interpolation -> high rows;
+// NTH = 0 -> one value -> low rows
+template <int NTH, int NTL, int P, int N>
+__device__ __forceinline__ void pw4_x2_channel(const float (&v)[N], const Pw4X2& g, const float* wk,
+                                               csn_f4 (&acch)[4][NTH > 0 ? NTH : 1], csn_f4 (&accl)[NTL > 0 ? NTL : 1]) {
+  constexpr int NT4 = (NTH + NTL + 3) & ~3;
+  Pw4A<NT4> a;
+  pw4_load_a<NT4, P>(wk, a);
+  if (NTH > 0) {
+    float h[2][3];
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        h[dx][r] = fmaf(g.wx[dx][2], v[(3 * r + 2) % N], fmaf(g.wx[dx][1], v[(3 * r + 1) % N], g.wx[dx][0] * v[(3 * r) % N]));
+    float q[4];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx)
+        q[2 * dy + dx] = fmaf(g.wy[dy][2], h[dx][2], fmaf(g.wy[dy][1], h[dx][1], g.wy[dy][0] * h[dx][0]));
+#pragma unroll
+    for (int t = 0; t < NTH; ++t)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) pw4_mfma<NT4>(a, t, q[s], acch[s][t]);
+  } else {
+    const float m = fmaf(g.w4[3], v[3 % N], fmaf(g.w4[2], v[2 % N], fmaf(g.w4[1], v[1 % N], g.w4[0] * v[0])));
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) pw4_mfma<NT4>(a, NTH + t, m, accl[t]);
+  }
+}
+
+}  // namespace
+
+// MODE 0: BN + PReLU epilogue, rows stored; 1 (RAW): plain sums stored; 2 (RED): BN + PReLU, rows reduced with red_w
+template <int NTH, int NTL, int MODE>
+__global__ __launch_bounds__(CSN_BLOCK, (16 * NTH + 4 * NTL <= 92 && !(NTL == 0 && NTH >= 5) && PW4_OCC < 3) ? 3 : PW4_OCC)
+void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulators leave room (the high-only forms carry the
+                                     // third input's staging registers: two waves from five row tiles on)
+  constexpr bool RAW = MODE == 1, RED = MODE == 2;
   constexpr int HB = PW4_HB, LB = PW4_LB;
   constexpr int NT4 = (NTH + NTL + 3) & ~3, P = PW4_PITCH(NT4);
   CSN_DYN_SMEM(float, lds);
@@ -57,9 +148,11 @@ __global__ __launch_bounds__(CSN_BLOCK, PW4_OCC) void pw4_kernel(Pw4Args a_byval
   const unsigned csl = (unsigned)(Hl * Wl) * 4u, csh = csl * 4u;   // channel strides in bytes
   const int twl = a->twl;
   const int lx = lane & ((1 << twl) - 1), ly = lane >> twl;
-  const int ng = a->ngroups;
+  constexpr bool gloop = RED;                 // row reduction: the groups of a tile are walked by one wave
+  const int ng = gloop ? 1 : a->ngroups;      // items per tile
   const int tiles_xy = a->tiles_x * a->tiles_y;
   const int nitems = tiles_xy * a->B * ng;
+  constexpr int NX2 = NTL == 0 ? 9 : 4;
   // XCD-aware order (see k_goct_pw.hip): XCD x = blockIdx.x & 7 walks the contiguous item range [x * chunk, (x + 1) * chunk)
   const int nslot = (int)(gridDim.x >> 3) * 4;
   const int chunk = (((nitems + 7) >> 3) + ng - 1) / ng * ng;   // whole tiles per XCD
@@ -71,7 +164,7 @@ __global__ __launch_bounds__(CSN_BLOCK, PW4_OCC) void pw4_kernel(Pw4Args a_byval
   const float* wl_lane = lds + (lane & 3) * P;
 #endif
   for (int item = xcd * chunk + (int)(blockIdx.x >> 3) * 4 + wave; item < iend; item += nslot) {
-    const int tile = item / ng, g = item - tile * ng;
+    const int tile = item / ng, g_first = item - tile * ng;
     const int b = tile / tiles_xy, txy = tile - b * tiles_xy;
     const int ty = txy / a->tiles_x, tx = txy - ty * a->tiles_x;
     const int y = (ty << (6 - twl)) + ly, x = (tx << twl) + lx;
@@ -89,6 +182,15 @@ __global__ __launch_bounds__(CSN_BLOCK, PW4_OCC) void pw4_kernel(Pw4Args a_byval
     const unsigned oh0 = (unsigned)((2 * yc) * Wh + 2 * xc) * 4u, oh1 = oh0 + (unsigned)Wh * 4u;
     const csn_buf rbh = csn_make_buf_n(a->xh + (int64_t)b * CH * (int64_t)(csh >> 2), (unsigned)CH * csh);
     const csn_buf rbl = csn_make_buf_n(a->xl + (int64_t)b * CL * (int64_t)(csl >> 2), (unsigned)CL * csl);
+    const int C2 = (NTH == 0 || NTL == 0) ? a->C2 : 0;
+    const unsigned cs2 = csl >> 2;
+    const csn_buf rb2 = csn_make_buf_n(C2 > 0 ? a->x2 + (int64_t)b * C2 * (int64_t)(cs2 >> 2) : a->xl, C2 > 0 ? (unsigned)C2 * cs2 : 4u);
+    Pw4X2 g2;
+    if (C2 > 0) pw4_x2_geo<NTL == 0>(yc, xc, Hl >> 1, Wl >> 1, g2);
+    float red[4] = {0.f, 0.f, 0.f, 0.f};
+    const unsigned sv0 = valid ? oh0 : 0x80000000u, sv1 = valid ? oh1 : 0x80000000u;
+    const int g_last = gloop ? a->ngroups : g_first + 1;
+    for (int g = g_first; g < g_last; ++g) {
     const float* wg = wl_lane + g * a->gimg_floats;
 
     csn_f4 acch[4][NTH > 0 ? NTH : 1], accl[NTL > 0 ? NTL : 1];
@@ -156,11 +258,37 @@ __global__ __launch_bounds__(CSN_BLOCK, PW4_OCC) void pw4_kernel(Pw4Args a_byval
         for (int t = 0; t < 9; ++t) lA[j][t] = lB[j][t];
     }
     pw4_lo_batch<NTH, NTL, LB, P, true>(lA, wgl + c0 * 4 * P, CL - c0, acch, accl);
+    // ---- third input (single-output forms only), one channel per step, the next one in flight ----
+    if ((NTH == 0 || NTL == 0) && C2 > 0) {
+      const float* wg2 = wgl + CL * 4 * P;
+      float xA[NX2], xB[NX2];
+      pw4_load_x2<NX2>(rb2, g2, 0u, xA);
+      PW4_FENCE();
+      const int nf2 = C2 - 1;
+      int c = 0;
+      for (int p = 0; p < (nf2 >> 1); ++p) {
+        pw4_load_x2<NX2>(rb2, g2, (unsigned)(c + 1) * cs2, xB);
+        PW4_FENCE();
+        pw4_x2_channel<NTH, NTL, P, NX2>(xA, g2, wg2 + c * 4 * P, acch, accl);
+        pw4_load_x2<NX2>(rb2, g2, (unsigned)(c + 2) * cs2, xA);
+        PW4_FENCE();
+        pw4_x2_channel<NTH, NTL, P, NX2>(xB, g2, wg2 + (c + 1) * 4 * P, acch, accl);
+        c += 2;
+      }
+      if (nf2 & 1) {
+        pw4_load_x2<NX2>(rb2, g2, (unsigned)(c + 1) * cs2, xB);
+        PW4_FENCE();
+        pw4_x2_channel<NTH, NTL, P, NX2>(xA, g2, wg2 + c * 4 * P, acch, accl);
+        ++c;
+#pragma unroll
+        for (int t = 0; t < NX2; ++t) xA[t] = xB[t];
+      }
+      pw4_x2_channel<NTH, NTL, P, NX2>(xA, g2, wg2 + c * 4 * P, acch, accl);
+    }
 
     // ---- epilogue: folded BN + PReLU, the accumulators are the store registers.  Row tiles past the group's list (an
     // instantiation wider than the group) are skipped; rows past the tensor's last channel inside the last tile fall out
     // of the bounded resource and are dropped by the hardware ----
-    const unsigned sv0 = valid ? oh0 : 0x80000000u, sv1 = valid ? oh1 : 0x80000000u;
     if (NTH > 0) {
       const int r0 = a->grp[g].r0h, nt = a->grp[g].nth;
       const csn_buf ob = csn_make_buf_n(a->yh + (int64_t)b * a->OH * (int64_t)(csh >> 2), (unsigned)a->OH * csh);
@@ -174,6 +302,12 @@ __global__ __launch_bounds__(CSN_BLOCK, PW4_OCC) void pw4_kernel(Pw4Args a_byval
             float o[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) o[s] = RAW ? acch[s][t][i] : pw4_epi(acch[s][t][i], ep[4 * r], ep[4 * r + 1], ep[4 * r + 2]);
+            if (RED) {   // fused 1x1 consumer: accumulate red_w[row] * y per quad pixel, nothing is stored here
+              const float rw = csn_const(a->red_w)[r0 + r];
+#pragma unroll
+              for (int s = 0; s < 4; ++s) red[s] = fmaf(rw, o[s], red[s]);
+              continue;
+            }
             const unsigned so = (unsigned)(r0 + r) * csh;
             csn_st2(ob, sv0, so, make_float2(o[0], o[1]));
             csn_st2(ob, sv1, so, make_float2(o[2], o[3]));
@@ -198,16 +332,26 @@ __global__ __launch_bounds__(CSN_BLOCK, PW4_OCC) void pw4_kernel(Pw4Args a_byval
         }
       }
     }
+    }   // groups of the tile
+    if (RED && NTH > 0) {   // logits: [B][1][2 Hl][2 Wl]
+      const csn_buf lb = csn_make_buf_n(a->logits + (int64_t)b * (int64_t)(csh >> 2), csh);
+      const float rb0 = csn_const(a->red_b)[0];
+      csn_st2(lb, sv0, 0u, make_float2(red[0] + rb0, red[1] + rb0));
+      csn_st2(lb, sv1, 0u, make_float2(red[2] + rb0, red[3] + rb0));
+    }
   }
 }
 
 // ---- instantiation table -----------------------------------------------------------------------------------------
 #define PW4_INST_LIST(X) \
-  X(3, 3) X(3, 4) X(4, 3) X(4, 4) X(5, 3) X(4, 6) X(4, 0) X(5, 0) X(6, 0) X(2, 2) X(3, 0) X(2, 0) X(1, 1) X(5, 2) X(2, 5)
+  X(3, 3) X(3, 4) X(4, 3) X(4, 4) X(5, 3) X(4, 6) X(4, 0) X(5, 0) X(6, 0) X(2, 2) X(3, 0) X(2, 0) X(1, 1) X(5, 2) X(2, 5) \
+  X(1, 0) X(0, 1) X(0, 2) X(0, 3) X(0, 4) X(0, 5) X(0, 6)
 
 typedef void (*Pw4Fn)(Pw4Args);
-struct Pw4Entry { int nth, ntl; Pw4Fn fn[2]; };
-#define PW4_ENTRY(H, L) {H, L, {pw4_kernel<H, L, false>, pw4_kernel<H, L, true>}},
+struct Pw4Entry { int nth, ntl; Pw4Fn fn[3]; };
+template <int H, int L> struct Pw4RedFn { static Pw4Fn get() { return nullptr; } };
+template <int H> struct Pw4RedFn<H, 0> { static Pw4Fn get() { return pw4_kernel<H, 0, 2>; } };   // row reduction: high-only forms
+#define PW4_ENTRY(H, L) {H, L, {pw4_kernel<H, L, 0>, pw4_kernel<H, L, 1>, Pw4RedFn<H, L>::get()}},
 static const Pw4Entry g_pw4_table[] = {PW4_INST_LIST(PW4_ENTRY)};
 
 // smallest instantiation that covers (nth, ntl) row tiles per group (ntl = 0 must stay 0: no low output), or {0, 0}
@@ -215,7 +359,7 @@ bool csn_pw4_pick(int nth, int ntl, int* pnth, int* pntl) {
   int best = -1, best_cost = 1 << 30;
   for (size_t i = 0; i < sizeof(g_pw4_table) / sizeof(g_pw4_table[0]); ++i) {
     const Pw4Entry& e = g_pw4_table[i];
-    if (e.nth < nth || e.ntl < ntl || (ntl == 0) != (e.ntl == 0)) continue;
+    if (e.nth < nth || e.ntl < ntl || (ntl == 0) != (e.ntl == 0) || (nth == 0) != (e.nth == 0)) continue;
     const int cost = 16 * e.nth + 4 * e.ntl;
     if (cost < best_cost) { best_cost = cost; best = (int)i; }
   }
@@ -229,11 +373,20 @@ int csn_launch_pw4(const Pw4Args& a, int raw, void* stream) {
   for (size_t i = 0; i < sizeof(g_pw4_table) / sizeof(g_pw4_table[0]); ++i)
     if (g_pw4_table[i].nth == a.nth && g_pw4_table[i].ntl == a.ntl) e = &g_pw4_table[i];
   if (!e) return 1;   // hipErrorInvalidValue
-  const int nitems = a.tiles_x * a.tiles_y * a.B * a.ngroups;
+  const int mode = a.red_w ? 2 : (raw ? 1 : 0);
+  if (!e->fn[mode]) return 1;
+  const int nitems = a.tiles_x * a.tiles_y * a.B * (a.red_w ? 1 : a.ngroups);
   int nblk = (nitems + 3) / 4;
   if (nblk > a.max_grid) nblk = a.max_grid;
   const dim3 grid((nblk + 7) & ~7);
   const size_t lds = (size_t)a.ngroups * a.gimg_floats * sizeof(float);
-  CSN_LAUNCH(e->fn[raw ? 1 : 0], grid, dim3(CSN_BLOCK), lds, stream, a);
+#ifndef CSN_CPU_EMU
+  if (lds > 64 * 1024) {
+    const hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(e->fn[mode]),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (er != hipSuccess) return (int)er;
+  }
+#endif
+  CSN_LAUNCH(e->fn[mode], grid, dim3(CSN_BLOCK), lds, stream, a);
   return (int)hipGetLastError();
 }
