@@ -125,9 +125,13 @@ void csn_plan_destroy(csn_plan* plan);
  * 1x1 unit (the round-1/2 path; also what the train-mode forward and the input gradients still use).
  * CSN_OPT_C3Q [1]: 3x3 gOctConv forward passes at an even resolution run on c3q_kernel (k_c3q.hip: lane = 2x2 output quad,
  * v_mfma_f32_4x4x1 from the load registers, max-pooled copies of the finer branch written by pool2_kernel); 0 =
- * goct_c3_kernel (which also serves bf16 storage, odd sizes and the backward-data launches). */
+ * goct_c3_kernel (which also serves bf16 storage, odd sizes and the backward-data launches).
+ * CSN_OPT_SLICE_LANES [0]: with sub_batch < B, up to three batch slices run concurrently on the plan's stream lanes, each in
+ * its own workspace region (set BEFORE csn_plan_workspace_bytes, which then reports that many regions); the per-launch
+ * latency of the small maps of one slice is covered by the other slices' launches.  Results are identical to the
+ * sequential slices (same kernels on the same data). */
 enum csn_option { CSN_OPT_FUSE_DW = 1, CSN_OPT_GRAPH = 2, CSN_OPT_FUSE_CLS = 3, CSN_OPT_TILED3 = 4, CSN_OPT_FUSE_ILB = 5,
-                  CSN_OPT_OVERLAP = 6, CSN_OPT_TRAIN_BF16 = 7, CSN_OPT_PW4 = 8, CSN_OPT_C3Q = 9 };
+                  CSN_OPT_OVERLAP = 6, CSN_OPT_TRAIN_BF16 = 7, CSN_OPT_PW4 = 8, CSN_OPT_C3Q = 9, CSN_OPT_SLICE_LANES = 10 };
 int csn_plan_set_option(csn_plan* plan, int32_t option, int32_t value);
 
 size_t csn_plan_workspace_bytes(const csn_plan* plan);

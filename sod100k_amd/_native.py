@@ -29,6 +29,7 @@ OPT_OVERLAP = 6
 OPT_TRAIN_BF16 = 7
 OPT_PW4 = 8
 OPT_C3Q = 9
+OPT_SLICE_LANES = 10
 
 
 class ActDesc(C.Structure):

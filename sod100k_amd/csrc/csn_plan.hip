@@ -167,11 +167,14 @@ struct csn_plan {
   bool fuse_dw = true;
   bool fuse_cls = true;   // CSN_OPT_FUSE_CLS
   bool tiled3 = true;     // CSN_OPT_TILED3
+  int slice_lanes = 0;    // CSN_OPT_SLICE_LANES: batch slices (sub_batch < B) run concurrently on the plan's stream lanes, each
+                          // in its own workspace region
   bool c3q = true;        // CSN_OPT_C3Q: eval-mode 3x3 passes on c3q_kernel (k_c3q.hip)
   int c3q_cap = 4;        // its row tiles per M group (CSN_C3Q_NT, experiments)
   bool pw4 = true;        // CSN_OPT_PW4: two-branch 1x1 units on pw4_kernel (k_pw4.hip)
   int pw4_grid = 2048;    // its block cap (CSN_PW4_GRID, experiments)
   int pw4_twl = 4;        // log2 of its widest tile in low pixels (CSN_PW4_TWL, experiments)
+  bool pw4_nosplit = false;   // CSN_PW4_NOSPLIT: no extra M groups on small maps (experiments)
   bool overlap_bwd = false;   // CSN_OPT_OVERLAP value 2: also the weight-gradient side lane of csn_backward
   bool overlap = true;    // CSN_OPT_OVERLAP: independent launches of a unit (and the MSBlocks) on parallel stream lanes
   hipStream_t lane[2] = {nullptr, nullptr};      // auxiliary lanes (lane 0 = the caller's stream)
@@ -323,8 +326,13 @@ int finish_launch(Builder& bl, PwLaunchPlan& L) {
         q = q && ps.wb[s].tk == 0 && ps.src_kind[s] == SRC_IN && ps.src_c0[s] == 0 &&
             (ps.src_ctot[s] == 0 || ps.src_ctot[s] == ps.src_C[s]);
       if (q) {
-        const int cap = std::max(1, std::min(bl.P.c3q_cap, csn_c3q_max_tiles()));
+        int cap = std::max(1, std::min(bl.P.c3q_cap, csn_c3q_max_tiles()));
         const int nt_tot = (ps.nrows + 3) / 4;
+        {   // small maps: more, shorter items (measured per unit with CSN_C3Q_NT: 56^2 quads want 3 tiles, 28^2 and below 2)
+          const int Hq = bl.P.H >> (L.lvl + 1), Wq = bl.P.W >> (L.lvl + 1);
+          const int64_t tiles = (int64_t)bl.P.S * ((Hq * Wq + 63) / 64);
+          while (cap > 2 && !bl.P.pw4_nosplit && tiles * ((nt_tot + cap - 1) / cap) < 1536) --cap;
+        }
         int ng = (nt_tot + cap - 1) / cap;
         if (ng > PW4_MAX_GROUPS) ng = PW4_MAX_GROUPS;
         const int nt = (nt_tot + ng - 1) / ng;
@@ -548,11 +556,19 @@ int plan_pw4_launch(Builder& bl, UnitPlan& u, const int* ci_off, const int* co_o
   const csn_unit_desc& d = u.d;
   const int OH = hi_out >= 0 ? d.cout[hi_out] : 0, OL = lo_out >= 0 ? d.cout[lo_out] : 0;
   const int nth_tot = (OH + 3) / 4, ntl_tot = (OL + 3) / 4;
+  // M groups: as few as the accumulator budget allows (a group re-reads the inputs and repeats the interpolation
+  // arithmetic) -- but a small map needs more items than that to occupy the 1024 SIMDs, and its items are short
+  const int Hl_ = bl.P.H >> (u.base_lvl + 1), Wl_ = bl.P.W >> (u.base_lvl + 1);
+  const int64_t tiles = (int64_t)bl.P.S * ((Hl_ * Wl_ + 63) / 64);
+  int gmin = 1;
+  if (!bl.P.pw4_nosplit)
+    while (gmin < PW4_MAX_GROUPS && tiles * gmin < 1536 && gmin < std::max(nth_tot, ntl_tot)) ++gmin;
+  const int budget = (lo_out < 0 && use_x2) ? 164 : (lo_out < 0 ? 116 : 100);
   int ng = 0, pn = 0, pl = 0;
-  for (int g = 1; g <= PW4_MAX_GROUPS; ++g) {
+  for (int g = gmin; g <= PW4_MAX_GROUPS; ++g) {
     int a = 0, b = 0;
     if (!csn_pw4_pick((nth_tot + g - 1) / g, (ntl_tot + g - 1) / g, &a, &b)) continue;
-    if (16 * a + 4 * b > 100 && g < PW4_MAX_GROUPS) continue;   // accumulators: leave room for two load batches in flight
+    if (16 * a + 4 * b > budget && g < PW4_MAX_GROUPS) continue;
     ng = g; pn = a; pl = b;
     break;
   }
@@ -1497,6 +1513,7 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   P->B = B; P->H = H; P->W = W;
   P->S = (sub_batch <= 0 || sub_batch > B) ? B : sub_batch;
   if (const char* v = std::getenv("CSN_PW4_GRID")) { if (std::atoi(v) >= 8) P->pw4_grid = std::atoi(v); }
+  if (std::getenv("CSN_PW4_NOSPLIT")) P->pw4_nosplit = true;
   if (const char* v = std::getenv("CSN_C3Q_NT")) { if (std::atoi(v) >= 1) P->c3q_cap = std::atoi(v); }
   if (const char* v = std::getenv("CSN_PW4_TWL")) { if (std::atoi(v) >= 2 && std::atoi(v) <= 6) P->pw4_twl = std::atoi(v); }
   Builder bl(*P);
@@ -1660,6 +1677,7 @@ int csn_plan_set_option(csn_plan* P, int32_t option, int32_t value) {
     case CSN_OPT_TILED3: P->tiled3 = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_PW4: P->pw4 = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_C3Q: P->c3q = value != 0; drop_graph(P); return CSN_OK;
+    case CSN_OPT_SLICE_LANES: P->slice_lanes = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_FUSE_ILB: P->fuse_ilb = value < 0 ? 0 : value; drop_graph(P); return CSN_OK;
     case CSN_OPT_OVERLAP: P->overlap = value != 0; P->overlap_bwd = value == 2; drop_graph(P); return CSN_OK;
     case CSN_OPT_TRAIN_BF16: P->act16 = value != 0; drop_graph(P); return CSN_OK;
@@ -1667,7 +1685,11 @@ int csn_plan_set_option(csn_plan* P, int32_t option, int32_t value) {
   }
 }
 
-size_t csn_plan_workspace_bytes(const csn_plan* P) { return P ? (size_t)P->ws_bytes : 0; }
+size_t csn_plan_workspace_bytes(const csn_plan* P) {
+  if (!P) return 0;
+  const int nslices = (P->B + P->S - 1) / P->S;
+  return (size_t)P->ws_bytes * (size_t)((P->slice_lanes && nslices > 1) ? std::min(nslices, 3) : 1);
+}
 int32_t csn_plan_num_units(const csn_plan* P) { return P ? (int32_t)P->units.size() : 0; }
 
 int csn_plan_act_info(const csn_plan* P, int32_t id, csn_act_info* out) {
@@ -1710,18 +1732,30 @@ static int forward_body(csn_plan* P, const float* x, float* y, void* workspace, 
   }
   const int64_t in_stride = (int64_t)P->acts[0].channels * P->H * P->W, out_stride = (int64_t)P->H * P->W;
   const int reps = prof ? (iters > 0 ? iters : 1) : 1;
+  // concurrent slices: slice i runs on stream lane i % nconc in workspace region i % nconc (the small maps of the deep
+  // stages are latency-bound per launch: two half-batches side by side fill the gaps a single chain of launches leaves)
+  const int nslices = (P->B + P->S - 1) / P->S;
+  int nconc = 1;
+  if (P->slice_lanes && nslices > 1 && !prof && lanes_ready(P)) nconc = std::min(nslices, 3);
+  if (nconc > 1) {
+    Ctx c0{*P, x, y, static_cast<char*>(workspace), stream};
+    const int st = lanes_fork(c0, nconc - 1);
+    if (st != CSN_OK) return st;
+  }
   for (int it = 0; it < reps; ++it) {
-    for (int b0 = 0; b0 < P->B; b0 += P->S) {
+    for (int b0 = 0, si = 0; b0 < P->B; b0 += P->S, ++si) {
       // the last slice may overlap the previous one when S does not divide B (same results, written twice)
       const int start = (b0 + P->S <= P->B) ? b0 : P->B - P->S;
-      Ctx c{*P, x + start * in_stride, y + start * out_stride, static_cast<char*>(workspace), stream};
+      const int ln = si % nconc;
+      Ctx c{*P, x + start * in_stride, y + start * out_stride, static_cast<char*>(workspace) + (int64_t)ln * P->ws_bytes,
+            ln == 0 ? stream : (void*)P->lane[ln - 1]};
       std::vector<int> unit_of_tag;
       if (prof) {
         P->profiling = true; P->ev_used = 0; P->tags.clear();
         const int st0 = c.mark("start");
         if (st0 != CSN_OK) { P->profiling = false; return st0; }
       }
-      c.lanes = lanes_ready(P) && !prof;
+      c.lanes = lanes_ready(P) && !prof && nconc == 1;
       for (int u = 0; u < nu; ++u) {
         // consecutive MSBlocks (one per CSFHead branch, csnet.py:92-113) read different tensors: one lane each
         if (c.lanes && P->units[u].d.kind == CSN_UNIT_MS) {
@@ -1768,6 +1802,11 @@ static int forward_body(csn_plan* P, const float* x, float* y, void* workspace, 
         }
       }
     }
+  }
+  if (nconc > 1) {
+    Ctx c0{*P, x, y, static_cast<char*>(workspace), stream};
+    const int st = lanes_join(c0, nconc - 1);
+    if (st != CSN_OK) return st;
   }
   if (prof) {
     for (int u = 0; u < nu; ++u) unit_ms[u] /= (float)reps;

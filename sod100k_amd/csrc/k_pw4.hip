@@ -85,10 +85,14 @@ __device__ __forceinline__ void pw4_x2_geo(int y, int x, int H2, int W2, Pw4X2& 
   }
 }
 
-template <int N>
-__device__ __forceinline__ void pw4_load_x2(csn_buf rb, const Pw4X2& g, unsigned so, float (&v)[N]) {
+template <int N, int XB>
+__device__ __forceinline__ void pw4_load_x2(csn_buf rb, const Pw4X2& g, unsigned cs, int c0, int C, float (&v)[XB][N]) {
 #pragma unroll
-  for (int t = 0; t < N; ++t) v[t] = csn_ld1(rb, g.o[t], so);
+  for (int j = 0; j < XB; ++j) {
+    const unsigned so = (unsigned)min(c0 + j, C - 1) * cs;
+#pragma unroll
+    for (int t = 0; t < N; ++t) v[j][t] = csn_ld1(rb, g.o[t], so);
+  }
 }
 
 // one channel of the third input: NTL = 0 -> quad values by separable three-tap interpolation -> high rows;
@@ -131,7 +135,9 @@ __global__ __launch_bounds__(CSN_BLOCK, (16 * NTH + 4 * NTL <= 92 && !(NTL == 0 
 void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulators leave room (the high-only forms carry the
                                      // third input's staging registers: two waves from five row tiles on)
   constexpr bool RAW = MODE == 1, RED = MODE == 2;
-  constexpr int HB = PW4_HB, LB = PW4_LB;
+  // load batches: the low-only form contracts ~2 MFMAs per loaded value and has few accumulators -- its batches are deep
+  // (every batch is one exposed memory round trip per item)
+  constexpr int HB = NTH == 0 ? 8 : PW4_HB, LB = NTH == 0 ? 8 : PW4_LB;
   constexpr int NT4 = (NTH + NTL + 3) & ~3, P = PW4_PITCH(NT4);
   CSN_DYN_SMEM(float, lds);
   const CSN_CONST_AS Pw4Args* a = CSN_KERNARG(Pw4Args, a_byval);
@@ -152,7 +158,8 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
   const int ng = gloop ? 1 : a->ngroups;      // items per tile
   const int tiles_xy = a->tiles_x * a->tiles_y;
   const int nitems = tiles_xy * a->B * ng;
-  constexpr int NX2 = NTL == 0 ? 9 : 4;
+  constexpr int NX2 = NTL == 0 ? 9 : 4;      // taps per channel of the third input
+  constexpr int XB = NTL == 0 ? 1 : 4;       // ... and channels per step
   // XCD-aware order (see k_goct_pw.hip): XCD x = blockIdx.x & 7 walks the contiguous item range [x * chunk, (x + 1) * chunk)
   const int nslot = (int)(gridDim.x >> 3) * 4;
   const int chunk = (((nitems + 7) >> 3) + ng - 1) / ng * ng;   // whole tiles per XCD
@@ -258,32 +265,39 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
         for (int t = 0; t < 9; ++t) lA[j][t] = lB[j][t];
     }
     pw4_lo_batch<NTH, NTL, LB, P, true>(lA, wgl + c0 * 4 * P, CL - c0, acch, accl);
-    // ---- third input (single-output forms only), one channel per step, the next one in flight ----
+    // ---- third input (single-output forms only), XB channels per step, the next step in flight ----
     if ((NTH == 0 || NTL == 0) && C2 > 0) {
       const float* wg2 = wgl + CL * 4 * P;
-      float xA[NX2], xB[NX2];
-      pw4_load_x2<NX2>(rb2, g2, 0u, xA);
+      float xA[XB][NX2], xB[XB][NX2];
+      pw4_load_x2<NX2, XB>(rb2, g2, cs2, 0, C2, xA);
       PW4_FENCE();
-      const int nf2 = C2 - 1;
+      const int nf2 = (C2 - 1) / XB;
       int c = 0;
       for (int p = 0; p < (nf2 >> 1); ++p) {
-        pw4_load_x2<NX2>(rb2, g2, (unsigned)(c + 1) * cs2, xB);
+        pw4_load_x2<NX2, XB>(rb2, g2, cs2, c + XB, C2, xB);
         PW4_FENCE();
-        pw4_x2_channel<NTH, NTL, P, NX2>(xA, g2, wg2 + c * 4 * P, acch, accl);
-        pw4_load_x2<NX2>(rb2, g2, (unsigned)(c + 2) * cs2, xA);
+#pragma unroll
+        for (int j = 0; j < XB; ++j) pw4_x2_channel<NTH, NTL, P, NX2>(xA[j], g2, wg2 + (c + j) * 4 * P, acch, accl);
+        pw4_load_x2<NX2, XB>(rb2, g2, cs2, c + 2 * XB, C2, xA);
         PW4_FENCE();
-        pw4_x2_channel<NTH, NTL, P, NX2>(xB, g2, wg2 + (c + 1) * 4 * P, acch, accl);
-        c += 2;
+#pragma unroll
+        for (int j = 0; j < XB; ++j) pw4_x2_channel<NTH, NTL, P, NX2>(xB[j], g2, wg2 + (c + XB + j) * 4 * P, acch, accl);
+        c += 2 * XB;
       }
       if (nf2 & 1) {
-        pw4_load_x2<NX2>(rb2, g2, (unsigned)(c + 1) * cs2, xB);
+        pw4_load_x2<NX2, XB>(rb2, g2, cs2, c + XB, C2, xB);
         PW4_FENCE();
-        pw4_x2_channel<NTH, NTL, P, NX2>(xA, g2, wg2 + c * 4 * P, acch, accl);
-        ++c;
 #pragma unroll
-        for (int t = 0; t < NX2; ++t) xA[t] = xB[t];
+        for (int j = 0; j < XB; ++j) pw4_x2_channel<NTH, NTL, P, NX2>(xA[j], g2, wg2 + (c + j) * 4 * P, acch, accl);
+        c += XB;
+#pragma unroll
+        for (int j = 0; j < XB; ++j)
+#pragma unroll
+          for (int t = 0; t < NX2; ++t) xA[j][t] = xB[j][t];
       }
-      pw4_x2_channel<NTH, NTL, P, NX2>(xA, g2, wg2 + c * 4 * P, acch, accl);
+#pragma unroll
+      for (int j = 0; j < XB; ++j)
+        if (c + j < C2) pw4_x2_channel<NTH, NTL, P, NX2>(xA[j], g2, wg2 + (c + j) * 4 * P, acch, accl);
     }
 
     // ---- epilogue: folded BN + PReLU, the accumulators are the store registers.  Row tiles past the group's list (an
@@ -345,7 +359,7 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
 // ---- instantiation table -----------------------------------------------------------------------------------------
 #define PW4_INST_LIST(X) \
   X(3, 3) X(3, 4) X(4, 3) X(4, 4) X(5, 3) X(4, 6) X(4, 0) X(5, 0) X(6, 0) X(2, 2) X(3, 0) X(2, 0) X(1, 1) X(5, 2) X(2, 5) \
-  X(1, 0) X(0, 1) X(0, 2) X(0, 3) X(0, 4) X(0, 5) X(0, 6)
+  X(1, 0) X(0, 1) X(0, 2) X(0, 3) X(0, 4) X(0, 5) X(0, 6) X(8, 0) X(10, 0) X(7, 0) X(2, 3) X(3, 2) X(2, 1) X(1, 2) X(1, 3) X(2, 4)
 
 typedef void (*Pw4Fn)(Pw4Args);
 struct Pw4Entry { int nth, ntl; Pw4Fn fn[3]; };

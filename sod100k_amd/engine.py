@@ -108,6 +108,8 @@ class Engine:
             N.check(lib, lib.csn_plan_enable_training(plan), "csn_plan_enable_training")
         if os.environ.get("CSN_TILED3") is not None:      # A/B switches for measurements
             self.set_option(N.OPT_TILED3, int(os.environ["CSN_TILED3"]))
+        if os.environ.get("CSN_SLICE_LANES") is not None:   # before the workspace query: one region per concurrent slice
+            self.set_option(N.OPT_SLICE_LANES, int(os.environ["CSN_SLICE_LANES"]))
         if os.environ.get("CSN_C3Q") is not None:
             self.set_option(N.OPT_C3Q, int(os.environ["CSN_C3Q"]))
         if os.environ.get("CSN_PW4") is not None:
