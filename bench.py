@@ -174,7 +174,7 @@ def main():
     from sod100k_amd import dist as D
     world = D.init(device=dev)
     nranks = world
-    if world > 1:
+    if D.active():
         import torch.distributed as tdist
         nranks = tdist.get_world_size()
         probe = torch.ones(1, device=dev)
@@ -252,17 +252,24 @@ def main():
         bytes_per_launch = d["bytes"] / d["launches"]
         us_per_launch = d["ms"] * 1e3 / d["launches"]
         achieved = bytes_per_launch / (us_per_launch * 1e-6) / 1e9
-        traffic = None
+        # HBM traffic of the dominant kernel: NOT a quantity of this run -- rocprofv3 cannot run inside the bench; it is the
+        # per-launch average of the committed counter passes (tools/gpu_pmc_hbm.sh, FETCH_SIZE / WRITE_SIZE calibrated with
+        # tools/probes/fetch_cal), labelled with where it came from
+        traffic = traffic_src = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                fwd_bytes = pj.get(dom, {}).get("hbm_bytes_per_forward")
+                if fwd_bytes:
+                    traffic = int(fwd_bytes / d["launches"])       # per launch of THIS run's launch count
+                traffic_src = "profiles/pmc_latest.json: " + pj.get("_source", "")
             except Exception:
                 traffic = None
         total_alg = sum(nbytes)
         total_ms = sum(v["ms"] for v in agg.values() if "ms" in v)
         roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
                         bytes_per_launch=int(bytes_per_launch), us_per_launch=round(us_per_launch, 2),
                         launches_per_step=d["launches"],
                         whole_step=dict(algorithmic_bytes=int(total_alg), events_ms=round(total_ms, 3),
@@ -278,6 +285,12 @@ def main():
                                     for k, v in agg.items() if "ms" in v})
 
     sub_b = eng_sub(eng, B)
+    lat_b1 = None
+    if not emu and rank == 0:
+        try:
+            lat_b1 = latency_b1(model, dev)
+        except Exception as e:       # a secondary data point must never take the headline line down
+            lat_b1 = {"error": f"{type(e).__name__}: {e}"}
     # ---- second data point: the full train step (fwd train-mode + BCE + backward + gradient all-reduce + Adam) ----
     train = train16 = None
     if args.train_steps > 0:
@@ -340,7 +353,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" if not emu else "INVALID: CPU plumbing run with emulated kernels (tests only)",
-            "nranks": nranks, "backend": ("gloo" if emu else "nccl (RCCL)") if world > 1 else "none",
+            "nranks": nranks, "backend": ("gloo" if emu else "nccl (RCCL)") if D.active() else "none",
+            "rccl_env": D.rccl_env(),
             "config": {"workload": "CSNet-100K (csnet-L-x2 shipped checkpoint) fp32 eval forward, "
                                    f"batch {B} x 3x{S}x{S} per GPU, inputs resident in HBM",
                        "batch_per_gpu": B, "global_batch": B * world, "sub_batch": sub_b,
@@ -351,6 +365,8 @@ def main():
         }
         if ev_stats is not None:
             out["hip_events"] = ev_stats
+        if lat_b1 is not None:
+            out["latency_b1"] = lat_b1
         if train is not None:
             out["train_step"] = train
         if train16 is not None:
@@ -361,6 +377,43 @@ def main():
             out["cpu_baseline"] = cpu_baseline(man)
         print(json.dumps(out))
     D.finalize()
+
+
+def latency_b1(model, dev, n=200):
+    """The reference's actual inference loop (CSNet/test.py:87-96): ONE picture at a time -- device resize + normalise
+    (csn_resize_normalize_nchw), the replayed B = 1 forward, sigmoid + resize back + uint8 (csn_saliency_resize_u8) --
+    timed per picture with HIP events on the launch stream."""
+    import torch
+    from sod100k_amd import _native as N
+    lib = getattr(model, "_lib", None) or N.load()
+    h, w = 300, 400
+    pic = torch.rand(1, h, w, 3, generator=torch.Generator().manual_seed(3)).to(dev)
+    x1 = torch.empty(1, 3, 224, 224, device=dev)                 # fixed buffers: the forward replays its hipGraph
+    y1 = torch.empty(1, 1, 224, 224, device=dev)
+    u8 = torch.empty(h, w, dtype=torch.uint8, device=dev)
+    eng = model.engine_for(x1)
+    eng.refresh(model._arena.flat)
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def one():
+        N.check(lib, lib.csn_resize_normalize_nchw(pic.data_ptr(), x1.data_ptr(), 1, h, w, 224, 224, st), "csn_resize_normalize_nchw")
+        eng.forward(x1, out=y1)
+        N.check(lib, lib.csn_saliency_resize_u8(y1.data_ptr(), u8.data_ptr(), 224, 224, h, w, st), "csn_saliency_resize_u8")
+
+    for _ in range(10):
+        one()
+    torch.cuda.synchronize(dev)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a_, b_ in evs:
+        a_.record(); one(); b_.record()
+    torch.cuda.synchronize(dev)
+    ts = sorted(a_.elapsed_time(b_) for a_, b_ in evs)
+    eng.profile(x1, iters=2)
+    launches = sum(int(v[1]) for v in eng.kernel_stats().values())
+    return {"what": "one 300x400 picture: resize+normalise -> B=1 224x224 forward (hipGraph replay) -> sigmoid+resize back+uint8, "
+                    "HIP events per picture", "pictures": n, "median_ms": round(statistics.median(ts), 4), "min_ms": round(ts[0], 4),
+            "p90_ms": round(ts[int(0.9 * (n - 1))], 4), "kernel_launches_per_forward": launches,
+            "images_per_sec_at_median": round(1e3 / statistics.median(ts), 1)}
 
 
 def csf_point(dev, batch, steps):

@@ -108,10 +108,8 @@ void csn_plan_destroy(csn_plan* plan);
  * feeds it (CSFHead.fuse1x1), whose 79-channel output is then never written; 0 = separate launches (probes).
  * CSN_OPT_TILED3 [1]: 3x3 gOctConv passes run as an LDS-tiled implicit GEMM (goct_c3_kernel); 0 = per-pixel tap
  * gathers in goct_pw_kernel (same arithmetic up to the summation order inside a k step).
- * CSN_OPT_FUSE_ILB [0]: value w > 0: a 1x1 ILBlock (conv1x1 -> conv3x3_1 -> conv3x3_2, csnet.py:72-76) whose finest output
- * branch is at least w pixels wide runs as ONE kernel (ilb_kernel: one wave per column strip, every intermediate in
- * registers).  Parity-green, but measured SLOWER than the unit-level kernels on MI355X (2.2 vs 1.8 ms for the 14 blocks
- * at batch 64, profiles/r2_notes.md), hence off by default.
+ * CSN_OPT_FUSE_ILB: retired in round 3 (the register-resident whole-ILBlock kernel of round 2 measured slower than the unit
+ * kernels -- profiles/r2_notes.md -- and the unit kernels have since been replaced); the value is accepted and ignored.
  * CSN_OPT_OVERLAP [1]: launches that do not depend on each other -- {z -> high pass} || {low pass} of a 3x3 unit, the
  * per-branch launches of CSFHead.fuse, the three MSBlocks -- are enqueued on parallel stream lanes (fork / join by events on
  * the caller's stream; parallel branches of the hipGraph); 0 = one stream, strictly in order; 2 = additionally all

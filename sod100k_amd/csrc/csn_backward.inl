@@ -543,7 +543,9 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
       w.off_w = d.w_off[k]; w.C = d.cout[k]; w.S = S; w.H = H; w.W = W; w.nslab = 0;
       // input and weight gradient in ONE pass over dz and x when both are wanted and the per-(image, tile) partials fit
       // the reduction table; the branches go one after the other (they share the partial buffer)
-      const int fslabs = (ub.need_dx[k] && !std::getenv("CSN_DW_BWD_SPLIT")) ? dw_stats_slabs(P, act.lvl) : 0;
+      // (not on the weight-gradient side lane: the fused kernel also writes the input gradient the NEXT unit's backward on
+      // the caller's stream reads -- there the split path keeps dx on the main lane)
+      const int fslabs = (ub.need_dx[k] && !cs.side && !std::getenv("CSN_DW_BWD_SPLIT")) ? dw_stats_slabs(P, act.lvl) : 0;
       if (fslabs > 0) {
         DwArgs f;
         f.nbr = 1; f.B = S; f.a16 = c.a16 ? 1 : 0; f.pad = 0;

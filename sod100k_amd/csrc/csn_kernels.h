@@ -196,37 +196,6 @@ int csn_c3q_max_tiles(void);
 int csn_launch_c3q(const C3qArgs& a, int raw, void* stream);
 
 // ---------------------------------------------------------------------------------------------
-// a whole 1x1 ILBlock (gOctaveCBR 1x1 -> depthwise 3x3 -> depthwise 3x3) per wave strip (see k_ilb.hip)
-// ---------------------------------------------------------------------------------------------
-#ifndef ILB_LANEW
-#define ILB_LANEW 0    // 0: weights through the scalar cache (s_load); 1: lane-resident in VGPRs + v_readlane (slower, measured)
-#endif
-#define ILB_SW 56      // output columns of a wave strip
-#define ILB_HALO 4     // lane 0 <-> column (strip start - 4): the two 3x3 stages need the 1x1 output two columns out
-struct IlbRole {       // one output branch of the block
-  const float* x_own;  // input branch at this resolution   [B][C_own][H][W]        (null / C_own = 0: absent)
-  const float* x_oth;  // role 0: the lower input branch     [B][C_oth][H/2][W/2]    (bilinear x2 after the conv)
-                       // role 1: the higher input branch    [B][C_oth][2H][2W]      (2x2 max-pool before the conv)
-  float* out;          // output of the second depthwise unit [B][n_out][H][W]
-  float* pool;         // 2x2 average of `out` [B][n_out][H/2][W/2] for a stride-2 unit that follows (null: none)
-  const float* wt;     // per channel group, ILB_LANEW: [NC][64] W[c][k_own], [NC][64] W[c][k_oth], [NC][64] records;
-                       // else [K8own][NC] [K8oth][NC] transposed 1x1 weights, then [NC][32] records.  Zero padded.  Record =
-                       // {scaleA, shiftA, alphaA, 0, w1[9], scaleB, shiftB, alphaB, w2[9], scaleC, shiftC, alphaC, 0...}
-  int32_t C_own, C_oth, K8own, K8oth;
-  int32_t n_out, ngroups, gsize, group_stride;
-  int32_t H, W;
-  int32_t strips, segs, seg_rows;
-  int32_t items_img;   // segs * strips * ngroups
-  int32_t skip_out;    // `out` has no reader besides the pooled copy
-  int32_t nc;          // channel-group template width (8, 12, 16, 20), >= gsize
-};
-struct IlbArgs {
-  IlbRole role[2];
-  int32_t B, items, nc, pool;   // items / nc: filled per role by the launcher; pool: the block feeds a stride-2 unit
-};
-int csn_launch_ilb(const IlbArgs& a, void* stream);
-
-// ---------------------------------------------------------------------------------------------
 // MSBlock: five dilated 3x3 convs (x100 folded) -> channel concat -> BN -> PReLU (see k_ms.hip)
 // ---------------------------------------------------------------------------------------------
 struct MsArgs {

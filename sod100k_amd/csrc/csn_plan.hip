@@ -121,16 +121,6 @@ struct UnitPlan {
   int64_t tr_mean[3] = {-1, -1, -1}, tr_invstd[3] = {-1, -1, -1}, tr_m1m2[3] = {-1, -1, -1};
   int64_t gap_off[3] = {-1, -1, -1};
   int in_slot[3] = {-1, -1, -1};
-  // GOCT heading a fusable 1x1 ILBlock (this unit + the depthwise pair that follows): tables of k_ilb.hip
-  struct IlbRolePlan {
-    int present = 0;
-    int C_own = 0, C_oth = 0, K8own = 0, K8oth = 0, n_out = 0, nc = 0, ngroups = 0, gsize = 0, group_stride = 0;
-    int64_t wt = -1;            // packed-buffer offset
-    int lvl = 0;                // activation level of this output branch
-  };
-  IlbRolePlan ilb[2];
-  int ilb_ok = 0;
-  int ilb_width = 0;            // width of the finest output branch (CSN_OPT_FUSE_ILB threshold)
   // GOCT 1x1 with two or three input branches: launches of pw4_kernel (k_pw4.hip); pw4 = 0: the unit does not qualify
   struct Pw4Launch {
     int hi_out = -1, lo_out = -1;    // output branch written from the high / low rows (-1: none)
@@ -179,8 +169,6 @@ struct csn_plan {
   bool overlap = true;    // CSN_OPT_OVERLAP: independent launches of a unit (and the MSBlocks) on parallel stream lanes
   hipStream_t lane[2] = {nullptr, nullptr};      // auxiliary lanes (lane 0 = the caller's stream)
   hipEvent_t lane_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  int fuse_ilb = 0;       // CSN_OPT_FUSE_ILB: minimum width of the finest output branch; 0 = off (default: measured slower
-                          // than the unit-level kernels on MI355X, profiles/r2_notes.md)
   Epi ident;   // identity epilogue (scale 1, shift 0, alpha 1): train mode runs the conv kernels raw
   bool use_graph = true;
   // hipGraph of one whole csn_forward (all batch slices), captured on a plan-owned stream on the second
@@ -1234,172 +1222,6 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
 }
 
 
-// ---- fused 1x1 ILBlock (k_ilb.hip) ----------------------------------------------------------------------------
-static int env_int(const char* name, int dflt) {
-  const char* v = std::getenv(name);
-  return v && *v ? std::atoi(v) : dflt;
-}
-
-// channel-group width for n output channels contracted over K inputs: estimated VALU work per wave row
-// (packed FMAs for the contraction, ~36 operations per channel for the two depthwise stages and the three epilogues,
-// the input gather once per group), weighted by what the register budget of a group width does to the occupancy
-int choose_ilb_nc(int n, int K) {
-  const int forced = env_int("CSN_ILB_NC", 0);
-  if (forced == 8 || forced == 12 || forced == 16 || forced == 20) return forced;
-  static const int cand[4] = {8, 12, 16, 20};
-  static const double occ[4] = {1.0, 1.1, 1.25, 1.3};
-  int best = 16;
-  double best_c = 1e30;
-  for (int i = 0; i < 4; ++i) {
-    const int nc = cand[i];
-    const int G = (n + nc - 1) / nc;
-    const double c = G * (nc * (K + 36) * 0.5 + 3.0 * K) * occ[i];
-    if (c < best_c - 1e-9) { best_c = c; best = nc; }
-  }
-  return best;
-}
-
-// Does unit k (1x1 gOctaveCBR) head an ILBlock that ilb_kernel can run, and if so lay out its tables.
-int plan_ilb(Builder& bl, int k) {
-  csn_plan& P = bl.P;
-  const int nu = (int)P.units.size();
-  if (k + 2 >= nu) return CSN_OK;
-  UnitPlan& u = P.units[k];
-  const csn_unit_desc& d = u.d;
-  if (d.kind != CSN_UNIT_GOCT || d.ksize != 1 || d.stride != 1 || u.std_conv || d.n_in > 2 || d.n_out > 2) return CSN_OK;
-  const UnitPlan& u1 = P.units[k + 1];
-  const UnitPlan& u2 = P.units[k + 2];
-  if (!u1.fuse_next || u1.d.kind != CSN_UNIT_DW || u2.d.kind != CSN_UNIT_DW || u1.d.n_in != d.n_out) return CSN_OK;
-  for (int j = 0; j < d.n_out; ++j) {
-    if (d.cout[j] != u1.d.cin[j]) return CSN_OK;
-    if (d.cout[j] == 0) continue;
-    if (d.out_act[j] != u1.d.in_act[j]) return CSN_OK;
-    for (int q = 0; q < nu; ++q) {            // the 1x1 output has no reader besides the first depthwise unit
-      if (q == k + 1) continue;
-      for (int s = 0; s < CSN_MAX_BRANCH; ++s)
-        if (s < P.units[q].d.n_in && P.units[q].d.cin[s] > 0 && P.units[q].d.in_act[s] == d.out_act[j]) return CSN_OK;
-    }
-    const int Hj = P.H >> (u.base_lvl + j), Wj = P.W >> (u.base_lvl + j);
-    if (u1.pool_unit >= 0 && ((Hj | Wj) & 1)) return CSN_OK;
-  }
-  int cin_tot = 0, ci_off[3] = {0, 0, 0}, co_off[3] = {0, 0, 0}, cout_tot = 0;
-  for (int i = 0; i < d.n_in; ++i) { ci_off[i] = cin_tot; cin_tot += d.cin[i]; }
-  for (int j = 0; j < d.n_out; ++j) { co_off[j] = cout_tot; cout_tot += d.cout[j]; }
-  u.ilb_width = 0;
-  for (int j = 0; j < d.n_out; ++j) {
-    if (d.cout[j] == 0) continue;
-    if (u.ilb_width == 0) u.ilb_width = P.W >> (u.base_lvl + j);
-    UnitPlan::IlbRolePlan& r = u.ilb[j];
-    const int io = j, it = 1 - j;            // own / other input branch
-    r.present = 1;
-    r.lvl = u.base_lvl + j;
-    r.C_own = io < d.n_in ? d.cin[io] : 0;
-    r.C_oth = it < d.n_in ? d.cin[it] : 0;
-    r.K8own = (r.C_own + 7) & ~7;
-    r.K8oth = (r.C_oth + 7) & ~7;
-    r.n_out = d.cout[j];
-    r.nc = choose_ilb_nc(r.n_out, r.C_own + r.C_oth);
-    r.ngroups = (r.n_out + r.nc - 1) / r.nc;
-    r.gsize = (r.n_out + r.ngroups - 1) / r.ngroups;
-#if ILB_LANEW
-    if (r.C_own > 64 || r.C_oth > 64) return CSN_OK;      // one lane per input channel
-    r.group_stride = 3 * r.nc * 64;
-    const int rstride = 64;
-#else
-    r.group_stride = (r.K8own + r.K8oth) * r.nc + r.nc * 32;
-    const int rstride = 32;
-#endif
-    r.wt = bl.alloc_packed((int64_t)r.ngroups * r.group_stride);
-    for (int g = 0; g < r.ngroups; ++g) {
-      const int c0 = g * r.gsize, ng = std::min(r.gsize, r.n_out - c0);
-      const int64_t base = r.wt + (int64_t)g * r.group_stride;
-      const int64_t wrow = d.w_off[0] + (int64_t)(co_off[j] + c0) * cin_tot;
-#if ILB_LANEW
-      // rows [c][64]: dst[c * 64 + k] = W[co0 + c][ci0 + k]
-      if (r.C_own > 0) bl.job(CSN_PREP_ROWS, ng, base, wrow + ci_off[io], -1, -1, -1, 1.f, cin_tot, r.C_own, 64, 0);
-      if (r.C_oth > 0)
-        bl.job(CSN_PREP_ROWS, ng, base + (int64_t)r.nc * 64, wrow + ci_off[it], -1, -1, -1, 1.f, cin_tot, r.C_oth, 64, 0);
-      const int64_t rec = base + (int64_t)2 * r.nc * 64;
-#else
-      // transposed weight rows [k][nc]: dst[ci * nc + co] = W[co0 + co][ci0 + ci]
-      if (r.C_own > 0)
-        bl.job(CSN_PREP_ROWS_T, r.C_own, base, wrow + ci_off[io], -1, -1, -1, 1.f, cin_tot, ng, r.nc, 0 | (1 << 24));
-      if (r.C_oth > 0)
-        bl.job(CSN_PREP_ROWS_T, r.C_oth, base + (int64_t)r.K8own * r.nc, wrow + ci_off[it], -1, -1, -1, 1.f, cin_tot, ng,
-               r.nc, 0 | (1 << 24));
-      const int64_t rec = base + (int64_t)(r.K8own + r.K8oth) * r.nc;
-#endif
-      auto bn_rec = [&](const csn_bn_off& bn, int at) {
-        bl.job(CSN_PREP_BN_SCALE, ng, rec, bn.weight + c0, bn.running_var + c0, -1, -1, 1.f, 0, 0, rstride, at);
-        bl.job(CSN_PREP_BN_SHIFT, ng, rec, bn.weight + c0, bn.running_var + c0, bn.bias + c0, bn.running_mean + c0, 1.f, 0, 0,
-               rstride, at + 1);
-        bl.job(CSN_PREP_COPY, ng, rec, bn.prelu + c0, -1, -1, -1, 1.f, 0, 0, rstride, at + 2);
-      };
-      bn_rec(d.bn[j], 0);
-      bl.job(CSN_PREP_ROWS, ng, rec, u1.d.w_off[j] + (int64_t)c0 * 9, -1, -1, -1, 100.f, 9, 9, rstride, 4);    // conv2d.py:104
-      bn_rec(u1.d.bn[j], 13);
-      bl.job(CSN_PREP_ROWS, ng, rec, u2.d.w_off[j] + (int64_t)c0 * 9, -1, -1, -1, 100.f, 9, 9, rstride, 16);
-      bn_rec(u2.d.bn[j], 25);
-    }
-  }
-  u.ilb_ok = 1;
-  return CSN_OK;
-}
-
-// Launch ilb_kernel for the block headed by unit k (one launch per channel-group width in use).
-int run_ilb(const Ctx& c, int k) {
-  const csn_plan& P = c.P;
-  const UnitPlan& u = P.units[k];
-  const UnitPlan& u1 = P.units[k + 1];
-  const UnitPlan& u2 = P.units[k + 2];
-  const csn_unit_desc& d = u.d;
-  IlbRole role[2];
-  std::memset(role, 0, sizeof(role));
-  const int seg_env = env_int("CSN_ILB_SEG", 0);
-  for (int j = 0; j < 2; ++j) {
-    const UnitPlan::IlbRolePlan& r = u.ilb[j];
-    if (!r.present) continue;
-    IlbRole& R = role[j];
-    const int io = j, it = 1 - j;
-    R.x_own = r.C_own > 0 ? c.act_in(d.in_act[io]) : nullptr;
-    R.x_oth = r.C_oth > 0 ? c.act_in(d.in_act[it]) : nullptr;
-    R.out = c.act_out(u2.d.out_act[j]);
-    R.pool = nullptr;
-    R.skip_out = 0;
-    if (u1.pool_unit >= 0) {
-      R.pool = reinterpret_cast<float*>(c.ws + P.units[u1.pool_unit].pooled_off[j]);
-      R.skip_out = u1.pool_skip[j];
-    }
-    R.wt = c.pk(r.wt);
-    R.C_own = r.C_own; R.C_oth = r.C_oth; R.K8own = r.K8own; R.K8oth = r.K8oth;
-    R.n_out = r.n_out; R.ngroups = r.ngroups; R.gsize = r.gsize; R.group_stride = r.group_stride;
-    R.H = P.H >> r.lvl; R.W = P.W >> r.lvl;
-    R.strips = (R.W + ILB_SW - 1) / ILB_SW;
-    // row segments: enough waves to fill the chip about once at this group width's occupancy
-    const int occ = r.nc <= 8 ? 4 : r.nc <= 12 ? 3 : 2;
-    const int64_t per_seg = (int64_t)P.S * R.strips * R.ngroups;
-    int segs = (int)((256 * 4 * occ + per_seg / 2) / per_seg);
-    segs = std::max(1, std::min(segs, std::max(1, R.H / 4)));
-    R.seg_rows = (((R.H + segs - 1) / segs) + 1) & ~1;
-    if (seg_env > 0) R.seg_rows = (seg_env + 1) & ~1;
-    R.segs = (R.H + R.seg_rows - 1) / R.seg_rows;
-    R.items_img = R.segs * R.strips * R.ngroups;
-    R.nc = r.nc;
-  }
-  IlbArgs a;
-  std::memset(&a, 0, sizeof(a));
-  a.role[0] = role[0];
-  a.role[1] = role[1];
-  a.B = P.S;
-  a.pool = u1.pool_unit >= 0 ? 1 : 0;
-  LAUNCH_TRY(csn_launch_ilb(a, c.stream));
-  {
-    const int ms_ = c.mark("ilb_kernel");
-    if (ms_ != CSN_OK) return ms_;
-  }
-  return CSN_OK;
-}
-
 }  // namespace
 
 static void drop_slot(csn_plan::GraphSlot& s) {
@@ -1605,11 +1427,6 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
       P->units[k].pool_skip[i] = only ? 1 : 0;
     }
   }
-  // whole-ILBlock fusion (k_ilb.hip): a 1x1 unit followed by its fusable depthwise pair
-  for (int k = 0; k + 2 < n_units; ++k) {
-    const int st = plan_ilb(bl, k);
-    if (st != CSN_OK) { delete P; return st; }
-  }
   // cls fusion: a single-output, single-launch 1x1 unit whose only reader is the cls_layer that follows it
   for (int k = 0; k + 1 < n_units; ++k) {
     const csn_unit_desc& a = P->units[k].d;
@@ -1678,7 +1495,7 @@ int csn_plan_set_option(csn_plan* P, int32_t option, int32_t value) {
     case CSN_OPT_PW4: P->pw4 = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_C3Q: P->c3q = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_SLICE_LANES: P->slice_lanes = value != 0; drop_graph(P); return CSN_OK;
-    case CSN_OPT_FUSE_ILB: P->fuse_ilb = value < 0 ? 0 : value; drop_graph(P); return CSN_OK;
+    case CSN_OPT_FUSE_ILB: return CSN_OK;   // retired (round 3): accepted and ignored
     case CSN_OPT_OVERLAP: P->overlap = value != 0; P->overlap_bwd = value == 2; drop_graph(P); return CSN_OK;
     case CSN_OPT_TRAIN_BF16: P->act16 = value != 0; drop_graph(P); return CSN_OK;
     default: return CSN_E_INVALID;
@@ -1714,10 +1531,6 @@ int csn_plan_refresh_params(csn_plan* P, const float* arena, int64_t arena_float
   P->params_ready = true;
   P->bn_tables_train = false;
   return CSN_OK;
-}
-
-static bool ilb_active(const csn_plan* P, int u) {
-  return P->fuse_ilb > 0 && P->fuse_dw && P->units[u].ilb_ok && P->units[u].ilb_width >= P->fuse_ilb;
 }
 
 static int forward_body(csn_plan* P, const float* x, float* y, void* workspace, void* stream, int32_t iters,
@@ -1773,13 +1586,6 @@ static int forward_body(csn_plan* P, const float* x, float* y, void* workspace, 
             u += m - 1;
             continue;
           }
-        }
-        if (ilb_active(P, u)) {      // conv1x1 + conv3x3_1 + conv3x3_2 of an ILBlock in one kernel
-          const int st = run_ilb(c, u);
-          if (st != CSN_OK) { P->profiling = false; return st; }
-          if (prof) unit_of_tag.resize(P->tags.size(), u);
-          u += 2;
-          continue;
         }
         const bool fuse = u + 1 < nu && ((P->fuse_dw && P->units[u].fuse_next) || (P->fuse_cls && P->units[u].fuse_cls));
         const size_t t0 = P->tags.size();
@@ -1934,8 +1740,6 @@ static int forward_train_body(csn_plan* P, const float* x, float* y, void* works
 
 const char* csn_unit_kernel_name(const csn_plan* P, int32_t u) {
   if (!P || u < 0 || u >= (int)P->units.size()) return "";
-  for (int h = std::max(0, u - 2); h <= u; ++h)
-    if (ilb_active(P, h)) return "ilb_kernel";
   if (P->fuse_dw && P->units[u].d.kind == CSN_UNIT_DW) {
     if (P->units[u].fuse_next || (u > 0 && P->units[u - 1].fuse_next)) return "dw3x3x2_bn_prelu_kernel";
   }

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void csn_prep_kernel(const CsnPrepJob* _
   float* dst = packed + j.dst;
   const float eps = 1e-5f;  // nn.BatchNorm2d default
   switch (j.kind) {
-    case CSN_PREP_COPY:      // p2 > 0: strided destination dst[i * p2 + p3] (per-channel records of k_ilb.hip)
+    case CSN_PREP_COPY:      // p2 > 0: strided destination dst[i * p2 + p3] (interleaved per-channel records)
       for (int i = tid; i < j.n; i += CSN_BLOCK) dst[j.p2 > 0 ? (int64_t)i * j.p2 + j.p3 : i] = j.p0f * arena[j.src0 + i];
       break;
     case CSN_PREP_FILL:
@@ -784,14 +784,13 @@ __global__ __launch_bounds__(CSN_BLOCK) void val_mae_kernel(const float* __restr
     if ((int)threadIdx.x < st) sm[threadIdx.x] += sm[threadIdx.x + st];
     __syncthreads();
   }
-  if (threadIdx.x == 0) atomicAdd(mae, sm[0] / (double)n);
+  // ONE block per picture (launcher): fixed summation order inside the block, and the running sum over pictures is a plain
+  // read-modify-write ordered by the stream -- no floating-point atomics, the validation MAE is reproducible bit for bit
+  if (threadIdx.x == 0) *mae += sm[0] / (double)n;
 }
 
 int csn_launch_val_mae(const float* logits, int hi, int wi, const float* target, int h, int w, double* mae, void* stream) {
-  const int64_t n = (int64_t)h * w;
-  int nblk = (int)((n + CSN_BLOCK - 1) / CSN_BLOCK);
-  if (nblk > 256) nblk = 256;
-  CSN_LAUNCH(val_mae_kernel, dim3(nblk), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, logits, hi, wi, target, h, w,
+  CSN_LAUNCH(val_mae_kernel, dim3(1), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, logits, hi, wi, target, h, w,
              (float)hi / (float)h, (float)wi / (float)w, mae);
   return (int)hipGetLastError();
 }

@@ -208,166 +208,8 @@ __global__ __launch_bounds__(CSN_BLOCK) void msq_kernel(MsArgs a) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------ LDS-tiled version
-// The per-pixel kernel above re-reads the input five times (once per dilation block: 4.4x the algorithmic bytes in the
-// round-1 counter profile) and issues 45 tap loads per input channel and pixel.  Here a block owns a band of rows over the
-// full width and stages the band + halo of a few input channels in LDS (zero rows / columns outside the image = the
-// convolutions' zero padding, no masks); a thread owns FOUR consecutive pixels of a row, reads its taps as aligned 128-bit
-// LDS accesses (dilations 1 and 2 pick theirs out of the three quads around the pixel, 4 / 8 / 16 are aligned by
-// construction) and keeps 8 accumulators per dilation and pixel; weights are wave-uniform (s_load), each serving four
-// pixels.  Two passes so that the accumulators fit: dilations {1, 2, 4} (halo 4) and {8, 16} (halo 16).
-template <int PASS>
-__global__ __launch_bounds__(CSN_BLOCK, PASS == 0 ? 2 : 3) void msblock2_kernel(MsArgs a, int RB, int CC) {
-  CSN_DYN_SMEM(float, lds);
-  constexpr int ND = PASS == 0 ? 3 : 2;          // dilations of this pass
-  constexpr int D0 = PASS == 0 ? 0 : 3;          // index of the first one (dilation 2^index)
-  constexpr int HALO = PASS == 0 ? 4 : 16;
-  const int H = a.H, W = a.W, hw = H * W;
-  const int QW = W >> 2;
-  const int WP = W + 2 * HALO, RT = RB + 2 * HALO;
-  const int bands = (H + RB - 1) / RB;
-  const int b = blockIdx.x / bands, band = blockIdx.x - b * bands;
-  const int y0 = band * RB;
-  const int tid = threadIdx.x;
-  const int qy = tid / QW, qx = tid - qy * QW;
-  const bool active = qy < RB && y0 + qy < H;
-  // staging roles: thread (tr, tq) copies quad tq of tile rows tr, tr + rps, ...
-  const int QWP = WP >> 2;
-  const int tq = tid % QWP, tr = tid / QWP, rps = CSN_BLOCK / QWP;
-  const int scol = 4 * tq - HALO;                 // source column of the quad (outside [0, W): zero padding)
-  const float* __restrict__ src = a.in + (int64_t)b * a.cin * hw;
-  float acc[ND][8][4];
-#pragma unroll
-  for (int d = 0; d < ND; ++d)
-#pragma unroll
-    for (int co = 0; co < 8; ++co)
-#pragma unroll
-      for (int p = 0; p < 4; ++p) acc[d][co][p] = 0.f;
-  const int plane = RT * WP;
-  for (int c0 = 0; c0 < a.cin; c0 += CC) {
-    const int nc = min(CC, a.cin - c0);
-    __syncthreads();
-    if (tr < rps) {
-      for (int cc = 0; cc < nc; ++cc) {
-        const float* __restrict__ sp = src + (int64_t)(c0 + cc) * hw;
-        for (int r = tr; r < RT; r += rps) {
-          const int yy = y0 - HALO + r;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (yy >= 0 && yy < H && scol >= 0 && scol < W) v = *reinterpret_cast<const float4*>(sp + (int64_t)yy * W + scol);
-          *reinterpret_cast<float4*>(lds + cc * plane + r * WP + 4 * tq) = v;
-        }
-      }
-    }
-    __syncthreads();
-    if (!active) continue;
-    for (int cc = 0; cc < nc; ++cc) {
-      const float* tp = lds + cc * plane + (qy + HALO) * WP + HALO + 4 * qx;   // this thread's quad, dilation-free position
-#pragma unroll
-      for (int d = 0; d < ND; ++d) {
-        const int dil = 1 << (D0 + d);
-        const int nco = a.dch[D0 + d];
-        if (nco == 0) continue;
-        csn_cfp wc = csn_const(a.w[D0 + d]) + (int64_t)(c0 + cc) * 72;
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-          const float* rp = tp + (dy - 1) * dil * WP;
-          float tl[4], tc[4], trr[4];          // the four pixels' taps dx = -1, 0, +1
-          const float4 C = *reinterpret_cast<const float4*>(rp);
-          tc[0] = C.x; tc[1] = C.y; tc[2] = C.z; tc[3] = C.w;
-          if (dil >= 4) {
-            const float4 L = *reinterpret_cast<const float4*>(rp - dil), R = *reinterpret_cast<const float4*>(rp + dil);
-            tl[0] = L.x; tl[1] = L.y; tl[2] = L.z; tl[3] = L.w;
-            trr[0] = R.x; trr[1] = R.y; trr[2] = R.z; trr[3] = R.w;
-          } else {
-            const float4 L = *reinterpret_cast<const float4*>(rp - 4), R = *reinterpret_cast<const float4*>(rp + 4);
-            if (dil == 1) {
-              tl[0] = L.w; tl[1] = C.x; tl[2] = C.y; tl[3] = C.z;
-              trr[0] = C.y; trr[1] = C.z; trr[2] = C.w; trr[3] = R.x;
-            } else {
-              tl[0] = L.z; tl[1] = L.w; tl[2] = C.x; tl[3] = C.y;
-              trr[0] = C.z; trr[1] = C.w; trr[2] = R.x; trr[3] = R.y;
-            }
-          }
-          csn_cfp w0 = wc + (3 * dy) * 8, w1 = w0 + 8, w2 = w0 + 16;
-#pragma unroll
-          for (int co = 0; co < 4; ++co)
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-              acc[d][co][p] = fmaf(w2[co], trr[p], fmaf(w1[co], tc[p], fmaf(w0[co], tl[p], acc[d][co][p])));
-          if (nco > 4) {
-#pragma unroll
-            for (int co = 4; co < 8; ++co)
-#pragma unroll
-              for (int p = 0; p < 4; ++p)
-                acc[d][co][p] = fmaf(w2[co], trr[p], fmaf(w1[co], tc[p], fmaf(w0[co], tl[p], acc[d][co][p])));
-          }
-        }
-      }
-    }
-  }
-  if (!active) return;
-  csn_cfp scale = csn_const(a.scale), shift = csn_const(a.shift), alpha = csn_const(a.alpha);
-  float* __restrict__ op = a.out + (int64_t)b * a.cout * hw + (int64_t)(y0 + qy) * W + 4 * qx;
-#pragma unroll
-  for (int d = 0; d < ND; ++d) {
-    const int nco = a.dch[D0 + d];
-#pragma unroll
-    for (int co = 0; co < 8; ++co) {
-      if (co < nco) {
-        const int oc = a.cobase[D0 + d] + co;
-        const float sc = scale[oc], sh = shift[oc], al = alpha[oc];
-        *reinterpret_cast<float4*>(op + (int64_t)oc * hw) =
-            make_float4(csn_epi(acc[d][co][0], sc, sh, al), csn_epi(acc[d][co][1], sc, sh, al),
-                        csn_epi(acc[d][co][2], sc, sh, al), csn_epi(acc[d][co][3], sc, sh, al));
-      }
-    }
-  }
-}
-
-// geometry of the tiled version: rows per band / channels per staged chunk (0: the shape does not qualify)
-static bool ms2_geometry(const MsArgs& a, int halo, int& RB, int& CC, size_t& lds) {
-  if ((a.W & 3) || a.W < 4 || (a.W >> 2) > CSN_BLOCK) return false;
-  for (int d = 0; d < 5; ++d)
-    if (a.dch[d] > 8) return false;
-  const int QW = a.W >> 2;
-  RB = CSN_BLOCK / QW;
-  if (RB > a.H) RB = a.H;
-  if (RB >= 8) RB &= ~7;                      // whole bands of 8 / 16 / 24 rows
-  const int WP = a.W + 2 * halo, RT = RB + 2 * halo;
-  if ((WP >> 2) > CSN_BLOCK) return false;
-  const size_t plane = (size_t)RT * WP * sizeof(float);
-  CC = (int)((48 * 1024) / plane);
-  if (CC < 1) CC = 1;
-  if (CC > 8) CC = 8;
-  if (CC > a.cin) CC = a.cin;
-  lds = plane * CC;
-  return lds <= 96 * 1024;
-}
-
 int csn_launch_ms(const MsArgs& a, void* stream) {
   const int hw = a.H * a.W;
-#ifndef CSN_CPU_EMU
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&msblock2_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&msblock2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
-#endif
-  // the LDS-tiled version measured 2.6x SLOWER than the per-pixel kernel on MI355X (0.69 vs 0.26 ms for the three MSBlocks at
-  // batch 64, profiles/r2_notes.md): opt-in only (CSN_MS_TILED=1, tests)
-  static const bool force_old = !(std::getenv("CSN_MS_TILED") && std::getenv("CSN_MS_TILED")[0] == '1');
-  int RB0, CC0, RB1, CC1;
-  size_t l0, l1;
-  if (!force_old && !a.a16 && ms2_geometry(a, 4, RB0, CC0, l0) && ms2_geometry(a, 16, RB1, CC1, l1)) {
-    if (a.dch[0] + a.dch[1] + a.dch[2] > 0)
-      CSN_LAUNCH(msblock2_kernel<0>, dim3((unsigned)(a.B * ((a.H + RB0 - 1) / RB0))), dim3(CSN_BLOCK), l0, stream, a, RB0, CC0);
-    if (a.dch[3] + a.dch[4] > 0)
-      CSN_LAUNCH(msblock2_kernel<1>, dim3((unsigned)(a.B * ((a.H + RB1 - 1) / RB1))), dim3(CSN_BLOCK), l1, stream, a, RB1, CC1);
-    return (int)hipGetLastError();
-  }
   static const bool quad = !(std::getenv("CSN_MS_QUAD") && std::getenv("CSN_MS_QUAD")[0] == '0');
   // four pixels per lane (float, rows of whole quads); small maps keep one pixel per lane (28^2 x 64 images is 320 blocks of
   // quads: 42 us against 29 us, profiles/r3_notes.md)

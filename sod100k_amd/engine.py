@@ -91,7 +91,7 @@ class Engine:
 
     def __init__(self, lib: C.CDLL, units: Sequence[N.UnitDesc], acts: Sequence[Tuple[int, int]],
                  B: int, H: int, W: int, device: torch.device, sub_batch: int = 0,
-                 unit_names: Optional[Sequence[str]] = None, train: bool = False):
+                 unit_names: Optional[Sequence[str]] = None, train: bool = False, slice_lanes: bool = False):
         self.lib = lib
         self.B, self.H, self.W = B, H, W
         self.sub_batch = sub_batch
@@ -108,16 +108,14 @@ class Engine:
             N.check(lib, lib.csn_plan_enable_training(plan), "csn_plan_enable_training")
         if os.environ.get("CSN_TILED3") is not None:      # A/B switches for measurements
             self.set_option(N.OPT_TILED3, int(os.environ["CSN_TILED3"]))
-        if os.environ.get("CSN_SLICE_LANES") is not None:   # before the workspace query: one region per concurrent slice
-            self.set_option(N.OPT_SLICE_LANES, int(os.environ["CSN_SLICE_LANES"]))
+        if slice_lanes:       # before the workspace query: one workspace region per concurrent slice
+            self.set_option(N.OPT_SLICE_LANES, 1)
         if os.environ.get("CSN_C3Q") is not None:
             self.set_option(N.OPT_C3Q, int(os.environ["CSN_C3Q"]))
         if os.environ.get("CSN_PW4") is not None:
             self.set_option(N.OPT_PW4, int(os.environ["CSN_PW4"]))
         if os.environ.get("CSN_OVERLAP") is not None:
             self.set_option(N.OPT_OVERLAP, int(os.environ["CSN_OVERLAP"]))
-        if os.environ.get("CSN_FUSE_ILB") is not None:
-            self.set_option(N.OPT_FUSE_ILB, int(os.environ["CSN_FUSE_ILB"]))
         self.n_units = len(units)
         self.n_acts = len(acts)
         nbytes = int(lib.csn_plan_workspace_bytes(plan))

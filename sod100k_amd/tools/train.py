@@ -97,8 +97,8 @@ class FusedTrainer:
                                                        self.loss.data_ptr(), self._stream(y)), "csn_bce_with_logits")
         bs = self.batchsize or B
         model._train_backward_raw(x, dy, self.flops_weight / bs, grad=self.grad)
-        if world_size > 1:          # the step's only collective: average the flat gradient over the data-parallel ranks
-            from sod100k_amd.dist import allreduce_mean_
+        from sod100k_amd.dist import allreduce_mean_, active
+        if world_size > 1 or active():   # the step's only collective: average the flat gradient over the data-parallel ranks
             allreduce_mean_(self.grad, world_size)
         self.steps += 1
         flat = model._arena.flat
@@ -239,8 +239,15 @@ def run(cfg, device="cuda", synthetic=0, max_steps=0, val_batches=None, lib=None
     os.makedirs(check_point_dir, exist_ok=True)
     # epoch-0 build: writes layer_config_0.bin / layer_config_latest.bin (init path) and checkpoint/checkpoint_init.pth.tar,
     # which finetune.py:96-99 reads back (CSNet_training/model/csnet.py:903-945)
-    model = model_lib.build_model(basic_split=cfg.MODEL.BASIC_SPLIT, predefine=cfg.AUTO.PREDEFINE,
-                                  save_path=layer_config_dir, expand=cfg.AUTO.EXPAND)
+    # Only rank 0 writes files; the other ranks wait and build from the layer_config it left (or from AUTO.PREDEFINE).
+    if rank == 0:
+        model = model_lib.build_model(basic_split=cfg.MODEL.BASIC_SPLIT, predefine=cfg.AUTO.PREDEFINE,
+                                      save_path=layer_config_dir, expand=cfg.AUTO.EXPAND)
+    if D.active():
+        torch.distributed.barrier()
+    if rank != 0:
+        pre = cfg.AUTO.PREDEFINE if os.path.isfile(cfg.AUTO.PREDEFINE) else os.path.join(layer_config_dir, 'layer_config_0.bin')
+        model = model_lib.build_model(basic_split=cfg.MODEL.BASIC_SPLIT, predefine=pre, save_path='tmp', expand=cfg.AUTO.EXPAND)
     if cfg.AUTO.FLOPS.ENABLE:
         if cfg.AUTO.FLOPS.EXPAND != -1.0:
             model.flops_hook(expandflop=cfg.AUTO.FLOPS.EXPAND)
@@ -269,6 +276,8 @@ def run(cfg, device="cuda", synthetic=0, max_steps=0, val_batches=None, lib=None
             print("=> loaded checkpoint '{}' (epoch {})".format(cfg.DATA.RESUME, checkpoint['epoch']))
         else:
             print("=> no checkpoint found at '{}'".format(cfg.DATA.RESUME))
+    # every rank initialised its own random weights (and PRETRAIN may match only some keys): one model for all replicas
+    D.broadcast_model_(model, src=0)
     if cfg.SOLVER.ADJUST_STEP and cfg.SOLVER.LR_SCHEDULER != 'step':
         raise ValueError("Unsupported scheduler.")
     best_mae, best_epoch, done = 1000000, -1, 0

@@ -121,6 +121,46 @@ def test_two_rank_gradient_allreduce(emu_lib):
         assert float((g - ref).norm()) <= 2e-3 * float(ref.norm()) + 1e-6 * gmax, name
 
 
+def _run_worker(rank, world, port, out, tmp):
+    """The training caller itself on two ranks: un-pruned random initialisation, one synthetic step."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import ctypes
+    torch.set_num_threads(2)
+    torch.manual_seed(1000 + rank)          # different random initialisations on purpose
+    from sod100k_amd import _native as N
+    from sod100k_amd.configs import defaults
+    from sod100k_amd.tools import train as T
+    lib = N.bind(ctypes.CDLL(os.path.join(ROOT, "tests", "emu", "libcsnet_emu.so")))
+    cfg = defaults()
+    cfg.merge_from_file(os.path.join(ROOT, "sod100k_amd", "configs", "csnet-L-x2_train.yml"))
+    cfg.merge_from_list(["DATA.SAVEDIR", tmp, "DATA.BATCH_SIZE", 2, "DATA.IMAGE_H", 32, "DATA.IMAGE_W", 32, "AUTO.EXPAND", 0.5,
+                         "SOLVER.MAX_EPOCHS", 1])
+    tr = T.run(cfg, device="cpu", synthetic=1, max_steps=1, lib=lib)
+    files = sorted(os.listdir(os.path.join(tmp, cfg.TASK, "layer_configs")))
+    params = torch.cat([p.detach().flatten() for p in tr.model.parameters()])   # BN running statistics stay per replica
+    out.put((rank, params.clone().numpy(), files))
+    from sod100k_amd import dist as D
+    D.finalize()
+
+
+def test_two_rank_training_caller_starts_from_one_model(emu_lib, tmp_path):
+    """tools/train.py:run on two ranks: rank 0 alone writes layer_config / checkpoint_init, both replicas hold
+    rank 0's initialisation, and after one step (all-reduced gradient, same Adam update) every parameter still agrees bit
+    for bit (the BatchNorm running statistics are per replica, as without SyncBN in the reference)."""
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_run_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted((q.get(timeout=900) for _ in procs), key=lambda r: r[0])
+    [p.join(60) for p in procs]
+    assert res[0][1].shape == res[1][1].shape and np.array_equal(res[0][1], res[1][1])
+    assert "layer_config_0.bin" in res[0][2]
+
+
 def test_two_rank_gradient_allreduce_bf16(emu_lib):
     """The same data-parallel step with bfloat16 activation storage (BASELINE config 4's kernels in config 3's dtype).  Whole-step
     gradients of this network are not comparable across rounding variants (see check_train_units_local), so the two ranks'
