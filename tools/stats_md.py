@@ -21,6 +21,16 @@ def main():
                         f"{r.get('us_per_launch')} us/launch (HIP events, serialised), {r.get('launches_per_step')} launches/step\n\n")
             except Exception as e:
                 o.write(f"(bench line not readable: {e})\n\n")
+        fam = {}
+        for r in rows:
+            k = r["Name"].replace("void ", "").split("<")[0].split("(")[0]
+            f_ = fam.setdefault(k, [0, 0.0])
+            f_[0] += int(r["Calls"]); f_[1] += float(r["TotalDurationNs"])
+        o.write("By kernel family (template instantiations merged; avg us = what `roofline.us_per_launch` averages over):\n\n")
+        o.write("| kernel family | calls | total ms | avg us |\n|---|---|---|---|\n")
+        for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:14]:
+            o.write(f"| {k} | {c} | {t / 1e6:.2f} | {t / c / 1e3:.2f} |\n")
+        o.write("\nBy instantiation:\n\n")
         o.write("| kernel | calls | total ms | avg us | % | min us | max us |\n|---|---|---|---|---|---|---|\n")
         for r in rows[:40]:
             name = r["Name"].replace("|", "/")[:70]
