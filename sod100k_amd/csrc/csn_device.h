@@ -78,6 +78,13 @@ static inline float4 csn_ld4(csn_buf b, unsigned voff, unsigned soff) {
   const float* q = reinterpret_cast<const float*>(b.p + o);
   return make_float4(q[0], q[1], q[2], q[3]);
 }
+static inline void csn_st4(csn_buf b, unsigned voff, unsigned soff, float4 v) {
+  const unsigned o = voff + soff;
+  if (o + 16u <= b.n && o + 16u > o && o >= voff) {
+    float* q = reinterpret_cast<float*>(const_cast<char*>(b.p) + o);
+    q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+  }
+}
 static inline unsigned short csn_ld_u16(csn_buf b, unsigned voff, unsigned soff) {
   const unsigned o = voff + soff;
   return o + 2u <= b.n && o + 2u > o ? *reinterpret_cast<const unsigned short*>(b.p + o) : (unsigned short)0;
@@ -95,6 +102,10 @@ static inline uint2 csn_ld_u64(csn_buf b, unsigned voff, unsigned soff) {
 static inline void csn_st_u16(csn_buf b, unsigned voff, unsigned soff, unsigned short v) {
   const unsigned o = voff + soff;
   if (o + 2u <= b.n && o + 2u > o && o >= voff) *reinterpret_cast<unsigned short*>(const_cast<char*>(b.p) + o) = v;
+}
+static inline void csn_st_u32(csn_buf b, unsigned voff, unsigned soff, unsigned v) {
+  const unsigned o = voff + soff;
+  if (o + 4u <= b.n && o + 4u > o && o >= voff) *reinterpret_cast<unsigned*>(const_cast<char*>(b.p) + o) = v;
 }
 #else
 typedef __amdgpu_buffer_rsrc_t csn_buf;
@@ -127,6 +138,11 @@ __device__ __forceinline__ float4 csn_ld4(csn_buf b, unsigned voff, unsigned sof
   const csn_u4 v = __builtin_amdgcn_raw_buffer_load_b128(b, voff, soff, 0);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+__device__ __forceinline__ void csn_st4(csn_buf b, unsigned voff, unsigned soff, float4 v) {
+  csn_u4 u;
+  u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(u, b, voff, soff, 0);
+}
 __device__ __forceinline__ unsigned short csn_ld_u16(csn_buf b, unsigned voff, unsigned soff) {
   return (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(b, voff, soff, 0);
 }
@@ -139,6 +155,9 @@ __device__ __forceinline__ uint2 csn_ld_u64(csn_buf b, unsigned voff, unsigned s
 }
 __device__ __forceinline__ void csn_st_u16(csn_buf b, unsigned voff, unsigned soff, unsigned short v) {
   __builtin_amdgcn_raw_buffer_store_b16(v, b, voff, soff, 0);
+}
+__device__ __forceinline__ void csn_st_u32(csn_buf b, unsigned voff, unsigned soff, unsigned v) {
+  __builtin_amdgcn_raw_buffer_store_b32(v, b, voff, soff, 0);
 }
 #endif
 
@@ -204,6 +223,7 @@ template <> struct csn_bufacc<float> {
   static __device__ __forceinline__ float2 ld2(csn_buf b, unsigned voff, unsigned soff) { return csn_ld2(b, voff, soff); }
   static __device__ __forceinline__ float4 ld4(csn_buf b, unsigned voff, unsigned soff) { return csn_ld4(b, voff, soff); }
   static __device__ __forceinline__ void st1(csn_buf b, unsigned voff, unsigned soff, float v) { csn_st1(b, voff, soff, v); }
+  static __device__ __forceinline__ void st2(csn_buf b, unsigned voff, unsigned soff, float2 v) { csn_st2(b, voff, soff, v); }
 };
 template <> struct csn_bufacc<csn_bf16> {
   static __device__ __forceinline__ float ld1(csn_buf b, unsigned voff, unsigned soff) { return csn_bf2f(csn_ld_u16(b, voff, soff)); }
@@ -216,6 +236,7 @@ template <> struct csn_bufacc<csn_bf16> {
     return make_float4(csn_bits_f(u.x << 16), csn_bits_f(u.x & 0xffff0000u), csn_bits_f(u.y << 16), csn_bits_f(u.y & 0xffff0000u));
   }
   static __device__ __forceinline__ void st1(csn_buf b, unsigned voff, unsigned soff, float v) { csn_st_u16(b, voff, soff, csn_f2bf(v)); }
+  static __device__ __forceinline__ void st2(csn_buf b, unsigned voff, unsigned soff, float2 v) { csn_st_u32(b, voff, soff, csn_pack_bf2(v.x, v.y)); }
 };
 
 // Folded epilogue of one output channel: y = z*scale + shift; y = y >= 0 ? y : alpha*y

@@ -33,6 +33,10 @@ enum CsnPrepKind {
   // 3x3 block -> c3q_kernel's image (k_c3q.hip): n = rows, p1 = channels, p0 = source row pitch, p2 = P, p3 = t0 | (k0 << 8):
   //   dst[((k0 + 9*c + t)*4 + (r & 3))*p2 + t0 + (r >> 2)] = p0f * src0[r*p0 + 9*c + t]
   CSN_PREP_C3Q = 12,
+  // transposed 1x1 block (backward data) -> the image of CSN_PREP_PW4: n = rows (= input channels ci), p1 = columns (= output
+  // channels co), p0 = source row pitch, p2 = P, p3 = t0 | (k0 << 8):
+  //   dst[((k0 + c)*4 + (r & 3))*p2 + t0 + (r >> 2)] = p0f * src0[c*p0 + r]
+  CSN_PREP_PW4_T = 13,
 };
 struct CsnPrepJob {
   int32_t kind, n, p0, p1, p2, p3;
@@ -162,11 +166,32 @@ struct Pw4Args {
   int32_t tiles_x, tiles_y;
   int32_t ngroups, gimg_floats;
   int32_t nth, ntl;         // instantiation: row tiles per group
-  int32_t max_grid, pad;
+  int32_t max_grid;
+  int32_t a16;              // activation tensors are bfloat16 (raw launches of the bf16 train mode), else float
   Pw4Group grp[PW4_MAX_GROUPS];
 };
 bool csn_pw4_pick(int nth, int ntl, int* pnth, int* pntl);
 int csn_launch_pw4(const Pw4Args& a, int raw, void* stream);
+
+// ---------------------------------------------------------------------------------------------
+// plain 1x1 contraction over own-resolution slices, raw output (input-gradient launches; see k_pwq.hip)
+// ---------------------------------------------------------------------------------------------
+struct PwqSrc {
+  const float* ptr;    // first channel of the slice inside [B][Ctot][HW]
+  int32_t C, Ctot;
+};
+struct PwqArgs {
+  PwqSrc src[3];       // gathered entries = the channels of the slices, one after the other
+  int32_t nsrc, nrows;
+  float* out;          // first of the nrows channels written inside [B][out_ctot][HW]
+  const float* wimg;   // [ngroups][K][4][P] (CSN_PREP_PW4 / CSN_PREP_PW4_T), zero padded
+  int32_t out_ctot, HW, B;
+  int32_t ngroups, gimg_floats, nt, max_grid;
+  int32_t a16;         // tensors are bfloat16
+  int32_t grp_r0[PW4_MAX_GROUPS], grp_nt[PW4_MAX_GROUPS];
+};
+int csn_pwq_max_tiles(void);
+int csn_launch_pwq(const PwqArgs& a, void* stream);
 
 // ---------------------------------------------------------------------------------------------
 // gOctConv 3x3 pass, lane = 2x2 output quad, v_mfma_f32_4x4x1 from the load registers (see k_c3q.hip)
@@ -190,6 +215,7 @@ struct C3qArgs {
   int32_t twl, tiles_x, tiles_y;   // tile = 2^twl x 64 / 2^twl quads
   int32_t ngroups, gimg_floats, nt;
   int32_t max_grid;
+  int32_t a16, pad_;    // activation tensors (sources, z, out) are bfloat16: raw launches of the bf16 train mode
   int32_t grp_r0[PW4_MAX_GROUPS], grp_nt[PW4_MAX_GROUPS];   // first row / row tiles of every M group
 };
 int csn_c3q_max_tiles(void);

@@ -93,6 +93,10 @@ struct PwLaunchPlan {
   int c3q = 0, c3q_nt = 0, c3q_ng = 0, c3q_gimg = 0, c3q_ntap = 0, c3q_z = 0;
   int c3q_r0[PW4_MAX_GROUPS] = {0, 0, 0, 0}, c3q_gnt[PW4_MAX_GROUPS] = {0, 0, 0, 0};
   int64_t c3q_wimg = -1, c3q_ep = -1;
+  // pwq_kernel's plan (k_pwq.hip): one pass of own-resolution slices, raw output (input-gradient launches); 0: not eligible
+  int pwq = 0, pwq_nt = 0, pwq_ng = 0, pwq_gimg = 0;
+  int pwq_r0[PW4_MAX_GROUPS] = {0, 0, 0, 0}, pwq_gnt[PW4_MAX_GROUPS] = {0, 0, 0, 0};
+  int64_t pwq_wimg = -1;
 };
 
 struct UnitPlan {
@@ -274,6 +278,40 @@ int finish_launch(Builder& bl, PwLaunchPlan& L) {
       else
         bl.job(CSN_PREP_ROWS, ps.nrows, L.wimg + ps.w_off, w.src, -1, -1, -1, w.scale, w.ld, w.ncol, ps.w_stride, w.col);
     }
+  // ---- pwq_kernel: one pass of plain own-resolution slices on whole planes of a multiple of four elements ----
+  if (L.passes.size() == 1 && L.passes[0].r == 0 && L.passes[0].nsrc > 0) {
+    const PwPassPlan& ps = L.passes[0];
+    const int64_t hw = (int64_t)(bl.P.H >> L.lvl) * (bl.P.W >> L.lvl);
+    bool q = (hw & 3) == 0 && (ps.out_kind == OUT_DX || ps.out_kind == OUT_TMP);
+    for (int s = 0; s < ps.nsrc; ++s) q = q && ps.src_mode[s] == PW_OWN && !ps.wb[s].eye && ps.wb[s].tk <= 1;
+    const int nt_tot = (ps.nrows + 3) / 4;
+    const int ng = (nt_tot + csn_pwq_max_tiles() - 1) / csn_pwq_max_tiles();
+    if (q && ng >= 1 && ng <= PW4_MAX_GROUPS) {
+      const int nt = (nt_tot + ng - 1) / ng;
+      const int Pp = PW4_PITCH((nt + 3) & ~3);
+      const int64_t gimg = (int64_t)ps.K * 4 * Pp;
+      if (gimg * ng * 4 <= 150 * 1024) {
+        L.pwq = 1; L.pwq_nt = nt; L.pwq_ng = ng; L.pwq_gimg = (int)gimg;
+        L.pwq_wimg = bl.alloc_packed(gimg * ng);
+        for (int g = 0; g < ng; ++g) {
+          L.pwq_r0[g] = 4 * g * nt;
+          L.pwq_gnt[g] = std::max(0, std::min(nt, nt_tot - g * nt));
+          const int nr = std::min(4 * L.pwq_gnt[g], ps.nrows - L.pwq_r0[g]);
+          int kb = 0;
+          for (int s = 0; s < ps.nsrc && nr > 0; ++s) {
+            const WBlock& w = ps.wb[s];
+            if (w.tk > 0)
+              bl.job(CSN_PREP_PW4_T, nr, L.pwq_wimg + g * gimg, w.src + L.pwq_r0[g], -1, -1, -1, w.scale, w.ld, ps.src_C[s], Pp,
+                     0 | (kb << 8));
+            else
+              bl.job(CSN_PREP_PW4, nr, L.pwq_wimg + g * gimg, w.src + (int64_t)L.pwq_r0[g] * w.ld, -1, -1, -1, w.scale, w.ld,
+                     ps.src_C[s], Pp, 0 | (kb << 8));
+            kb += ps.src_C[s];
+          }
+        }
+      }
+    }
+  }
   // ---- tap-major image for goct_c3_kernel: one pass at the launch resolution, 3x3 tap slices (dilation 1) first, at
   // most one bilinear slice (identity block) last
   if (L.passes.size() == 1 && L.passes[0].r == 0) {
@@ -887,7 +925,24 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
   // raw: every pass of the launch stores plain sums (train-mode conv outputs, gradients, scratch)
   bool all_raw = true;
   for (const PwPassPlan& pp : L.passes) all_raw = all_raw && (pp.out_kind == OUT_DX || pp.out_kind == OUT_TMP || (c.raw && pp.out_kind != OUT_LOGITS));
-  if (P.c3q && P.tiled3 && L.c3q && !c.a16) {   // 3x3 forward pass: lane = output quad, operands from the load registers
+  if (P.pw4 && L.pwq && all_raw) {   // input-gradient launch of a 1x1 unit: plain contraction over flat planes
+    const PwPass& ps = a.pass[0];
+    PwqArgs q;
+    q.nsrc = ps.nsrc; q.nrows = ps.nrows;
+    for (int s = 0; s < 3; ++s) { q.src[s].ptr = ps.src[s].ptr; q.src[s].C = ps.src[s].C; q.src[s].Ctot = ps.src[s].Ctot; }
+    q.out = ps.out; q.out_ctot = ps.out_ctot;
+    q.wimg = c.pk(L.pwq_wimg);
+    q.HW = a.H0 * a.W0; q.B = a.B;
+    q.ngroups = L.pwq_ng; q.gimg_floats = L.pwq_gimg; q.nt = L.pwq_nt; q.max_grid = P.pw4_grid; q.a16 = c.a16 ? 1 : 0;
+    for (int g = 0; g < PW4_MAX_GROUPS; ++g) { q.grp_r0[g] = L.pwq_r0[g]; q.grp_nt[g] = L.pwq_gnt[g]; }
+    bool ok = q.out != nullptr;
+    for (int s = 0; s < q.nsrc; ++s) ok = ok && q.src[s].ptr != nullptr;
+    if (ok) {
+      LAUNCH_TRY(csn_launch_pwq(q, c.stream));
+      return c.mark("pwq_kernel");
+    }
+  }
+  if (P.c3q && P.tiled3 && L.c3q && (!c.a16 || c.raw)) {   // 3x3 forward pass: lane = output quad, operands from the load registers
     const PwPassPlan& pp = L.passes[0];
     bool ok = true;
     C3qArgs q;
@@ -915,6 +970,7 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
       q.tiles_x = (Wq + (1 << twl) - 1) >> twl;
       q.tiles_y = (Hq + (64 >> twl) - 1) / (64 >> twl);
       q.ngroups = L.c3q_ng; q.gimg_floats = L.c3q_gimg; q.nt = L.c3q_nt; q.max_grid = P.pw4_grid;
+      q.a16 = c.a16 ? 1 : 0; q.pad_ = 0;
       for (int g = 0; g < PW4_MAX_GROUPS; ++g) { q.grp_r0[g] = L.c3q_r0[g]; q.grp_nt[g] = L.c3q_gnt[g]; }
       const bool rawq = c.raw || pp.out_kind == OUT_Z;
       LAUNCH_TRY(csn_launch_c3q(q, rawq ? 1 : 0, c.stream));
@@ -1039,7 +1095,8 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
           if (d.cin[i] > 0) xin[i] = c.act_in(d.in_act[i]);
       }
       const bool cls_next = next && next->d.kind == CSN_UNIT_CLS;
-      if (P.pw4 && u.pw4 && !c.raw && !c.a16 && (!cls_next || (u.pw4l.size() == 1 && u.pw4l[0].lo_out < 0))) {
+      // (eval: BN + PReLU epilogue, float; train-mode forward: raw sums, float or bfloat16 storage)
+      if (P.pw4 && u.pw4 && (c.raw || !c.a16) && (!cls_next || (!c.raw && u.pw4l.size() == 1 && u.pw4l[0].lo_out < 0))) {
         // launches of the unit are independent of each other: parallel stream lanes (see below)
         std::vector<const PwLaunchPlan*> old;
         for (const PwLaunchPlan& L : u.pwl) {
@@ -1078,9 +1135,9 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
           a.tiles_x = (a.Wl + (1 << twl) - 1) >> twl;
           a.tiles_y = (a.Hl + (64 >> twl) - 1) / (64 >> twl);
           a.ngroups = L.ng; a.gimg_floats = L.gimg; a.nth = L.nth; a.ntl = L.ntl;
-          a.max_grid = P.pw4_grid; a.pad = 0;
+          a.max_grid = P.pw4_grid; a.a16 = c.a16 ? 1 : 0;
           for (int g = 0; g < PW4_MAX_GROUPS; ++g) a.grp[g] = L.grp[g];
-          LAUNCH_TRY(csn_launch_pw4(a, 0, cl.stream));
+          LAUNCH_TRY(csn_launch_pw4(a, c.raw ? 1 : 0, cl.stream));
           { const int ms_ = cl.mark("pw4_kernel"); if (ms_ != CSN_OK) return ms_; }
         }
         if (!old.empty()) {
@@ -1109,11 +1166,11 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
       for (int i = 0; i < 3; ++i) bd.in[i] = xin[i];
       for (int j = 0; j < d.n_out; ++j)
         if (d.cout[j] > 0) bd.act[j] = c.act_out(d.out_act[j]);
-      if (P.c3q && P.tiled3 && !c.a16 && d.ksize == 3) {   // 2x2 max-pooled copies for the high -> low slices of c3q_kernel
+      if (P.c3q && P.tiled3 && (!c.a16 || c.raw) && d.ksize == 3) {   // 2x2 max-pooled copies for the high -> low slices of c3q_kernel
         bool uses = false;
         for (const PwLaunchPlan& L : u.pwl) uses = uses || L.c3q;
         PoolArgs pa;
-        pa.n = 0; pa.a16 = 0; pa.pad = 0;
+        pa.n = 0; pa.a16 = c.a16 ? 1 : 0; pa.pad = 0;
         int blk = 0;
         for (int i = 0; i < d.n_in && uses; ++i) {
           if (u.mp_off[i] < 0 || !xin[i]) continue;

@@ -36,13 +36,14 @@ struct C3qGeo {        // per item, per lane
 };
 
 // 4x4 window of one channel at the pass resolution
+template <typename AT>
 __device__ __forceinline__ void c3q_load_own(csn_buf rb, const C3qGeo& g, unsigned so, float (&v)[16]) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const float2 c = csn_ld2(rb, g.row[r], so);
+    const float2 c = csn_bufacc<AT>::ld2(rb, g.row[r], so);
     v[4 * r + 1] = c.x; v[4 * r + 2] = c.y;
-    v[4 * r] = csn_ld1(rb, g.row[r] + g.dl, so);
-    v[4 * r + 3] = csn_ld1(rb, g.row[r] + g.dr, so);
+    v[4 * r] = csn_bufacc<AT>::ld1(rb, g.row[r] + g.dl, so);
+    v[4 * r + 3] = csn_bufacc<AT>::ld1(rb, g.row[r] + g.dr, so);
   }
 }
 
@@ -64,9 +65,11 @@ __device__ __forceinline__ void c3q_channel(const float (&v)[16], const float* w
 
 }  // namespace
 
-template <int NT, bool RAW>
+// AT: element type of the activation tensors (float; csn_bf16 = the bf16 train mode's storage, RAW launches only)
+template <int NT, bool RAW, typename AT = float>
 __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q_kernel(C3qArgs a_byval) {
   constexpr int NT4 = (NT + 3) & ~3, P = PW4_PITCH(NT4);
+  constexpr unsigned E = (unsigned)sizeof(AT);
   CSN_DYN_SMEM(float, lds);
   const CSN_CONST_AS C3qArgs* a = CSN_KERNARG(C3qArgs, a_byval);
   const int tid = threadIdx.x;
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q_kernel(C3qArgs a_byval
   __syncthreads();
   const int lane = tid & 63, wave = pw4_uniform(tid >> 6);
   const int H = a->H, W = a->W, Hq = H >> 1, Wq = W >> 1;
-  const unsigned cs = (unsigned)(H * W) * 4u;
+  const unsigned cs = (unsigned)(H * W) * E;
   const int twl = a->twl;
   const int lx = lane & ((1 << twl) - 1), ly = lane >> twl;
   const int ng = a->ngroups;
@@ -119,28 +122,29 @@ __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q_kernel(C3qArgs a_byval
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int yy = 2 * y - 1 + r;
-        geo.row[r] = (yy >= 0 && yy < H) ? (unsigned)(yy * W + 2 * x) * 4u : 0x80000000u;
+        geo.row[r] = (yy >= 0 && yy < H) ? (unsigned)(yy * W + 2 * x) * E : 0x80000000u;
       }
-      geo.dl = has_l ? 0xfffffffcu : 0x40000000u;
-      geo.dr = has_r ? 8u : 0x40000000u;
-      const csn_buf rb = csn_make_buf_n(a->src[s].ptr + (int64_t)b * a->src[s].Ctot * (int64_t)(cs >> 2), (unsigned)a->src[s].Ctot * cs);
+      geo.dl = has_l ? 0u - E : 0x40000000u;
+      geo.dr = has_r ? 2u * E : 0x40000000u;
+      const csn_buf rb = csn_make_buf_n(reinterpret_cast<const char*>(a->src[s].ptr) + (int64_t)b * a->src[s].Ctot * (int64_t)cs,
+                                        (unsigned)a->src[s].Ctot * cs);
       // channel c is contracted while channel c + 1 is in flight: two register sets, channels walked in pairs
       float vA[16], vB[16];
-      c3q_load_own(rb, geo, 0u, vA);
+      c3q_load_own<AT>(rb, geo, 0u, vA);
       PW4_FENCE();
       const int nf = C - 1;
       int c = 0;
       for (int p = 0; p < (nf >> 1); ++p) {
-        c3q_load_own(rb, geo, (unsigned)(c + 1) * cs, vB);
+        c3q_load_own<AT>(rb, geo, (unsigned)(c + 1) * cs, vB);
         PW4_FENCE();
         c3q_channel<NT, P>(vA, wg + (krow + 9 * c) * 4 * P, acc);
-        c3q_load_own(rb, geo, (unsigned)(c + 2) * cs, vA);
+        c3q_load_own<AT>(rb, geo, (unsigned)(c + 2) * cs, vA);
         PW4_FENCE();
         c3q_channel<NT, P>(vB, wg + (krow + 9 * (c + 1)) * 4 * P, acc);
         c += 2;
       }
       if (nf & 1) {
-        c3q_load_own(rb, geo, (unsigned)(c + 1) * cs, vB);
+        c3q_load_own<AT>(rb, geo, (unsigned)(c + 1) * cs, vB);
         PW4_FENCE();
         c3q_channel<NT, P>(vA, wg + (krow + 9 * c) * 4 * P, acc);
         ++c;
@@ -153,9 +157,9 @@ __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q_kernel(C3qArgs a_byval
 
     // ---- epilogue: + bilinear_up2(z), folded BN + PReLU, 64-bit stores of the quad rows ----
     const int r0 = a->grp_r0[g], nt = a->grp_nt[g];
-    const unsigned o0 = (unsigned)((2 * y) * W + 2 * x) * 4u, o1 = o0 + (unsigned)W * 4u;
+    const unsigned o0 = (unsigned)((2 * y) * W + 2 * x) * E, o1 = o0 + (unsigned)W * E;
     const unsigned sv0 = valid ? o0 : 0x80000000u, sv1 = valid ? o1 : 0x80000000u;
-    const csn_buf ob = csn_make_buf_n(a->out + (int64_t)b * a->out_ctot * (int64_t)(cs >> 2), (unsigned)a->out_ctot * cs);
+    const csn_buf ob = csn_make_buf_n(reinterpret_cast<char*>(a->out) + (int64_t)b * a->out_ctot * (int64_t)cs, (unsigned)a->out_ctot * cs);
     csn_cfp ep = csn_const(a->ep) + 4 * r0;
     unsigned oz[9];
     csn_buf zb = ob;
@@ -166,8 +170,8 @@ __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q_kernel(C3qArgs a_byval
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) oz[3 * r + c] = (unsigned)(yy[r] * Wq + xx[c]) * 4u;
-      zb = csn_make_buf_n(a->z + (int64_t)b * a->z_ctot * (int64_t)(csz >> 2), (unsigned)a->z_ctot * csz);
+        for (int c = 0; c < 3; ++c) oz[3 * r + c] = (unsigned)(yy[r] * Wq + xx[c]) * E;
+      zb = csn_make_buf_n(reinterpret_cast<const char*>(a->z) + (int64_t)b * a->z_ctot * (int64_t)csz, (unsigned)a->z_ctot * csz);
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q_kernel(C3qArgs a_byval
             float zv[9];
             const unsigned zo = (unsigned)min(a->z_c0 + r0 + r, a->z_ctot - 1) * csz;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) zv[k] = csn_ld1(zb, oz[k], zo);
+            for (int k = 0; k < 9; ++k) zv[k] = csn_bufacc<AT>::ld1(zb, oz[k], zo);
             pw4_up2_quad(zv, zq);
           }
           float o[4];
@@ -190,8 +194,8 @@ __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q_kernel(C3qArgs a_byval
             o[s] = RAW ? zsum : pw4_epi(zsum, ep[4 * r], ep[4 * r + 1], ep[4 * r + 2]);
           }
           const unsigned so = (unsigned)(a->out_c0 + r0 + r) * cs;
-          csn_st2(ob, sv0, so, make_float2(o[0], o[1]));
-          csn_st2(ob, sv1, so, make_float2(o[2], o[3]));
+          csn_bufacc<AT>::st2(ob, sv0, so, make_float2(o[0], o[1]));
+          csn_bufacc<AT>::st2(ob, sv1, so, make_float2(o[2], o[3]));
         }
       }
     }
@@ -202,8 +206,8 @@ __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q_kernel(C3qArgs a_byval
 #define C3Q_INST_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
 typedef void (*C3qFn)(C3qArgs);
-struct C3qEntry { int nt; C3qFn fn[2]; };
-#define C3Q_ENTRY(N) {N, {c3q_kernel<N, false>, c3q_kernel<N, true>}},
+struct C3qEntry { int nt; C3qFn fn[3]; };   // BN + PReLU / raw / raw with bfloat16 tensors
+#define C3Q_ENTRY(N) {N, {c3q_kernel<N, false>, c3q_kernel<N, true>, c3q_kernel<N, true, csn_bf16>}},
 static const C3qEntry g_c3q_table[] = {C3Q_INST_LIST(C3Q_ENTRY)};
 
 int csn_c3q_max_tiles(void) { return 7; }
@@ -222,7 +226,7 @@ int csn_launch_c3q(const C3qArgs& a, int raw, void* stream) {
   static bool attr_done = false;
   if (!attr_done) {
     for (size_t i = 0; i < sizeof(g_c3q_table) / sizeof(g_c3q_table[0]); ++i)
-      for (int r = 0; r < 2; ++r) {
+      for (int r = 0; r < 3; ++r) {
         const hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(g_c3q_table[i].fn[r]),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (er != hipSuccess) return (int)er;
@@ -230,6 +234,7 @@ int csn_launch_c3q(const C3qArgs& a, int raw, void* stream) {
     attr_done = true;
   }
 #endif
-  CSN_LAUNCH(e->fn[raw ? 1 : 0], grid, dim3(CSN_BLOCK), lds, stream, a);
+  if (a.a16 && !raw) return 1;   // bfloat16 tensors: train-mode (raw) launches only
+  CSN_LAUNCH(e->fn[raw ? (a.a16 ? 2 : 1) : 0], grid, dim3(CSN_BLOCK), lds, stream, a);
   return (int)hipGetLastError();
 }

@@ -88,6 +88,14 @@ __global__ __launch_bounds__(CSN_BLOCK) void csn_prep_kernel(const CsnPrepJob* _
         dst[((int64_t)(k0 + c) * 4 + (r & 3)) * j.p2 + t0 + (r >> 2)] = j.p0f * arena[j.src0 + (int64_t)r * j.p0 + c];
       }
     } break;
+    case CSN_PREP_PW4_T: {
+      const int ncol = j.p1, t0 = j.p3 & 0xff, k0 = j.p3 >> 8;
+      const int tot = j.n * ncol;
+      for (int i = tid; i < tot; i += CSN_BLOCK) {
+        const int r = i / ncol, c = i - r * ncol;
+        dst[((int64_t)(k0 + c) * 4 + (r & 3)) * j.p2 + t0 + (r >> 2)] = j.p0f * arena[j.src0 + (int64_t)c * j.p0 + r];
+      }
+    } break;
     case CSN_PREP_PW4: {
       const int ncol = j.p1, t0 = j.p3 & 0xff, k0 = j.p3 >> 8;
       const int tot = j.n * ncol;
@@ -573,10 +581,11 @@ int csn_launch_pool(const PoolArgs& a, void* stream) {
   return (int)hipGetLastError();
 }
 
-int csn_launch_maxpool(const PoolArgs& a, void* stream) {   // float tensors only (eval-mode 3x3 passes, k_c3q.hip)
+int csn_launch_maxpool(const PoolArgs& a, void* stream) {   // max-pooled copies for the 3x3 passes of k_c3q.hip
   const int nblk = a.blk_end[a.n - 1];
   if (nblk <= 0) return 0;
-  CSN_LAUNCH((pool2_kernel<float, true>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+  if (a.a16) CSN_LAUNCH((pool2_kernel<csn_bf16, true>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
+  else CSN_LAUNCH((pool2_kernel<float, true>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
 }
 

@@ -64,7 +64,7 @@ __device__ __forceinline__ void pw4_up4_weights(int ylow, float (&w)[2][3]) {
 }
 
 template <bool HI>
-__device__ __forceinline__ void pw4_x2_geo(int y, int x, int H2, int W2, Pw4X2& g) {
+__device__ __forceinline__ void pw4_x2_geo(int y, int x, int H2, int W2, unsigned E, Pw4X2& g) {
   const int py = y >> 1, px = x >> 1;
   if (HI) {
     const int yy[3] = {max(py - 1, 0), py, min(py + 1, H2 - 1)};
@@ -72,26 +72,26 @@ __device__ __forceinline__ void pw4_x2_geo(int y, int x, int H2, int W2, Pw4X2& 
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) g.o[3 * r + c] = (unsigned)(yy[r] * W2 + xx[c]) * 4u;
+      for (int c = 0; c < 3; ++c) g.o[3 * r + c] = (unsigned)(yy[r] * W2 + xx[c]) * E;
     pw4_up4_weights(y, g.wy);
     pw4_up4_weights(x, g.wx);
   } else {   // scale 2: source y / 2 - 0.25 -> (py - 1: 0.25, py: 0.75) for even y, (py: 0.75, py + 1: 0.25) for odd y
     const int ya = max((y & 1) ? py : py - 1, 0), yb = min((y & 1) ? py + 1 : py, H2 - 1);
     const int xa = max((x & 1) ? px : px - 1, 0), xb = min((x & 1) ? px + 1 : px, W2 - 1);
     const float wyb = (y & 1) ? 0.25f : 0.75f, wxb = (x & 1) ? 0.25f : 0.75f;
-    g.o[0] = (unsigned)(ya * W2 + xa) * 4u; g.o[1] = (unsigned)(ya * W2 + xb) * 4u;
-    g.o[2] = (unsigned)(yb * W2 + xa) * 4u; g.o[3] = (unsigned)(yb * W2 + xb) * 4u;
+    g.o[0] = (unsigned)(ya * W2 + xa) * E; g.o[1] = (unsigned)(ya * W2 + xb) * E;
+    g.o[2] = (unsigned)(yb * W2 + xa) * E; g.o[3] = (unsigned)(yb * W2 + xb) * E;
     g.w4[0] = (1.f - wyb) * (1.f - wxb); g.w4[1] = (1.f - wyb) * wxb; g.w4[2] = wyb * (1.f - wxb); g.w4[3] = wyb * wxb;
   }
 }
 
-template <int N, int XB>
+template <int N, int XB, typename AT = float>
 __device__ __forceinline__ void pw4_load_x2(csn_buf rb, const Pw4X2& g, unsigned cs, int c0, int C, float (&v)[XB][N]) {
 #pragma unroll
   for (int j = 0; j < XB; ++j) {
     const unsigned so = (unsigned)min(c0 + j, C - 1) * cs;
 #pragma unroll
-    for (int t = 0; t < N; ++t) v[j][t] = csn_ld1(rb, g.o[t], so);
+    for (int t = 0; t < N; ++t) v[j][t] = csn_bufacc<AT>::ld1(rb, g.o[t], so);
   }
 }
 
@@ -130,11 +130,13 @@ __device__ __forceinline__ void pw4_x2_channel(const float (&v)[N], const Pw4X2&
 }  // namespace
 
 // MODE 0: BN + PReLU epilogue, rows stored; 1 (RAW): plain sums stored; 2 (RED): BN + PReLU, rows reduced with red_w
-template <int NTH, int NTL, int MODE>
+// AT: element type of the activation tensors (float; csn_bf16 = the bf16 train mode's storage, RAW only)
+template <int NTH, int NTL, int MODE, typename AT = float>
 __global__ __launch_bounds__(CSN_BLOCK, (16 * NTH + 4 * NTL <= 92 && !(NTL == 0 && NTH >= 5) && PW4_OCC < 3) ? 3 : PW4_OCC)
 void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulators leave room (the high-only forms carry the
                                      // third input's staging registers: two waves from five row tiles on)
   constexpr bool RAW = MODE == 1, RED = MODE == 2;
+  constexpr unsigned E = (unsigned)sizeof(AT);
   // load batches: the low-only form contracts ~2 MFMAs per loaded value and has few accumulators -- its batches are deep
   // (every batch is one exposed memory round trip per item)
   constexpr int HB = NTH == 0 ? 8 : PW4_HB, LB = NTH == 0 ? 8 : PW4_LB;
@@ -151,7 +153,7 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
   __syncthreads();
   const int lane = tid & 63, wave = pw4_uniform(tid >> 6);
   const int CH = a->CH, CL = a->CL, Hl = a->Hl, Wl = a->Wl, Wh = 2 * Wl;
-  const unsigned csl = (unsigned)(Hl * Wl) * 4u, csh = csl * 4u;   // channel strides in bytes
+  const unsigned csl = (unsigned)(Hl * Wl) * E, csh = csl * 4u;   // channel strides in bytes
   const int twl = a->twl;
   const int lx = lane & ((1 << twl) - 1), ly = lane >> twl;
   constexpr bool gloop = RED;                 // row reduction: the groups of a tile are walked by one wave
@@ -184,16 +186,17 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) ol[3 * r + c] = (unsigned)(yy[r] * Wl + xx[c]) * 4u;
+        for (int c = 0; c < 3; ++c) ol[3 * r + c] = (unsigned)(yy[r] * Wl + xx[c]) * E;
     }
-    const unsigned oh0 = (unsigned)((2 * yc) * Wh + 2 * xc) * 4u, oh1 = oh0 + (unsigned)Wh * 4u;
-    const csn_buf rbh = csn_make_buf_n(a->xh + (int64_t)b * CH * (int64_t)(csh >> 2), (unsigned)CH * csh);
-    const csn_buf rbl = csn_make_buf_n(a->xl + (int64_t)b * CL * (int64_t)(csl >> 2), (unsigned)CL * csl);
+    const unsigned oh0 = (unsigned)((2 * yc) * Wh + 2 * xc) * E, oh1 = oh0 + (unsigned)Wh * E;
+    const csn_buf rbh = csn_make_buf_n(reinterpret_cast<const char*>(a->xh) + (int64_t)b * CH * (int64_t)csh, (unsigned)CH * csh);
+    const csn_buf rbl = csn_make_buf_n(reinterpret_cast<const char*>(a->xl) + (int64_t)b * CL * (int64_t)csl, (unsigned)CL * csl);
     const int C2 = (NTH == 0 || NTL == 0) ? a->C2 : 0;
     const unsigned cs2 = csl >> 2;
-    const csn_buf rb2 = csn_make_buf_n(C2 > 0 ? a->x2 + (int64_t)b * C2 * (int64_t)(cs2 >> 2) : a->xl, C2 > 0 ? (unsigned)C2 * cs2 : 4u);
+    const csn_buf rb2 = csn_make_buf_n(C2 > 0 ? reinterpret_cast<const char*>(a->x2) + (int64_t)b * C2 * (int64_t)cs2
+                                              : reinterpret_cast<const char*>(a->xl), C2 > 0 ? (unsigned)C2 * cs2 : 4u);
     Pw4X2 g2;
-    if (C2 > 0) pw4_x2_geo<NTL == 0>(yc, xc, Hl >> 1, Wl >> 1, g2);
+    if (C2 > 0) pw4_x2_geo<NTL == 0>(yc, xc, Hl >> 1, Wl >> 1, E, g2);
     float red[4] = {0.f, 0.f, 0.f, 0.f};
     const unsigned sv0 = valid ? oh0 : 0x80000000u, sv1 = valid ? oh1 : 0x80000000u;
     const int g_last = gloop ? a->ngroups : g_first + 1;
@@ -217,28 +220,28 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
     // ends up in set A ----
     float2 hA[HB][2], hB[HB][2];
     float lA[LB][9], lB[LB][9];
-    pw4_load_hi<HB>(rbh, oh0, oh1, csh, 0, CH, hA);
+    pw4_load_hi<HB, AT>(rbh, oh0, oh1, csh, 0, CH, hA);
       PW4_FENCE();
     const int nfh = (CH - 1) / HB;   // full batches in front of the last one
     int k0 = 0;
     for (int p = 0; p < (nfh >> 1); ++p) {
-      pw4_load_hi<HB>(rbh, oh0, oh1, csh, k0 + HB, CH, hB);
+      pw4_load_hi<HB, AT>(rbh, oh0, oh1, csh, k0 + HB, CH, hB);
       PW4_FENCE();
       pw4_hi_batch<NTH, NTL, HB, P, false>(hA, wg + k0 * 4 * P, HB, acch, accl);
-      pw4_load_hi<HB>(rbh, oh0, oh1, csh, k0 + 2 * HB, CH, hA);
+      pw4_load_hi<HB, AT>(rbh, oh0, oh1, csh, k0 + 2 * HB, CH, hA);
       PW4_FENCE();
       pw4_hi_batch<NTH, NTL, HB, P, false>(hB, wg + (k0 + HB) * 4 * P, HB, acch, accl);
       k0 += 2 * HB;
     }
     if (nfh & 1) {
-      pw4_load_hi<HB>(rbh, oh0, oh1, csh, k0 + HB, CH, hB);
+      pw4_load_hi<HB, AT>(rbh, oh0, oh1, csh, k0 + HB, CH, hB);
       PW4_FENCE();
       pw4_hi_batch<NTH, NTL, HB, P, false>(hA, wg + k0 * 4 * P, HB, acch, accl);
       k0 += HB;
 #pragma unroll
       for (int j = 0; j < HB; ++j) { hA[j][0] = hB[j][0]; hA[j][1] = hB[j][1]; }
     }
-    pw4_load_lo<LB>(rbl, ol, csl, 0, CL, lA);
+    pw4_load_lo<LB, AT>(rbl, ol, csl, 0, CL, lA);
       PW4_FENCE();
     pw4_hi_batch<NTH, NTL, HB, P, true>(hA, wg + k0 * 4 * P, CH - k0, acch, accl);
     // ---- low-branch channels, same scheme ----
@@ -246,16 +249,16 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
     const int nfl = (CL - 1) / LB;
     int c0 = 0;
     for (int p = 0; p < (nfl >> 1); ++p) {
-      pw4_load_lo<LB>(rbl, ol, csl, c0 + LB, CL, lB);
+      pw4_load_lo<LB, AT>(rbl, ol, csl, c0 + LB, CL, lB);
       PW4_FENCE();
       pw4_lo_batch<NTH, NTL, LB, P, false>(lA, wgl + c0 * 4 * P, LB, acch, accl);
-      pw4_load_lo<LB>(rbl, ol, csl, c0 + 2 * LB, CL, lA);
+      pw4_load_lo<LB, AT>(rbl, ol, csl, c0 + 2 * LB, CL, lA);
       PW4_FENCE();
       pw4_lo_batch<NTH, NTL, LB, P, false>(lB, wgl + (c0 + LB) * 4 * P, LB, acch, accl);
       c0 += 2 * LB;
     }
     if (nfl & 1) {
-      pw4_load_lo<LB>(rbl, ol, csl, c0 + LB, CL, lB);
+      pw4_load_lo<LB, AT>(rbl, ol, csl, c0 + LB, CL, lB);
       PW4_FENCE();
       pw4_lo_batch<NTH, NTL, LB, P, false>(lA, wgl + c0 * 4 * P, LB, acch, accl);
       c0 += LB;
@@ -269,23 +272,23 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
     if ((NTH == 0 || NTL == 0) && C2 > 0) {
       const float* wg2 = wgl + CL * 4 * P;
       float xA[XB][NX2], xB[XB][NX2];
-      pw4_load_x2<NX2, XB>(rb2, g2, cs2, 0, C2, xA);
+      pw4_load_x2<NX2, XB, AT>(rb2, g2, cs2, 0, C2, xA);
       PW4_FENCE();
       const int nf2 = (C2 - 1) / XB;
       int c = 0;
       for (int p = 0; p < (nf2 >> 1); ++p) {
-        pw4_load_x2<NX2, XB>(rb2, g2, cs2, c + XB, C2, xB);
+        pw4_load_x2<NX2, XB, AT>(rb2, g2, cs2, c + XB, C2, xB);
         PW4_FENCE();
 #pragma unroll
         for (int j = 0; j < XB; ++j) pw4_x2_channel<NTH, NTL, P, NX2>(xA[j], g2, wg2 + (c + j) * 4 * P, acch, accl);
-        pw4_load_x2<NX2, XB>(rb2, g2, cs2, c + 2 * XB, C2, xA);
+        pw4_load_x2<NX2, XB, AT>(rb2, g2, cs2, c + 2 * XB, C2, xA);
         PW4_FENCE();
 #pragma unroll
         for (int j = 0; j < XB; ++j) pw4_x2_channel<NTH, NTL, P, NX2>(xB[j], g2, wg2 + (c + XB + j) * 4 * P, acch, accl);
         c += 2 * XB;
       }
       if (nf2 & 1) {
-        pw4_load_x2<NX2, XB>(rb2, g2, cs2, c + XB, C2, xB);
+        pw4_load_x2<NX2, XB, AT>(rb2, g2, cs2, c + XB, C2, xB);
         PW4_FENCE();
 #pragma unroll
         for (int j = 0; j < XB; ++j) pw4_x2_channel<NTH, NTL, P, NX2>(xA[j], g2, wg2 + (c + j) * 4 * P, acch, accl);
@@ -305,7 +308,7 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
     // of the bounded resource and are dropped by the hardware ----
     if (NTH > 0) {
       const int r0 = a->grp[g].r0h, nt = a->grp[g].nth;
-      const csn_buf ob = csn_make_buf_n(a->yh + (int64_t)b * a->OH * (int64_t)(csh >> 2), (unsigned)a->OH * csh);
+      const csn_buf ob = csn_make_buf_n(reinterpret_cast<char*>(a->yh) + (int64_t)b * a->OH * (int64_t)csh, (unsigned)a->OH * csh);
       csn_cfp ep = csn_const(a->ep_h) + 4 * r0;
 #pragma unroll
       for (int t = 0; t < NTH; ++t) {
@@ -323,15 +326,15 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
               continue;
             }
             const unsigned so = (unsigned)(r0 + r) * csh;
-            csn_st2(ob, sv0, so, make_float2(o[0], o[1]));
-            csn_st2(ob, sv1, so, make_float2(o[2], o[3]));
+            csn_bufacc<AT>::st2(ob, sv0, so, make_float2(o[0], o[1]));
+            csn_bufacc<AT>::st2(ob, sv1, so, make_float2(o[2], o[3]));
           }
         }
       }
     }
     if (NTL > 0) {
       const int r0 = a->grp[g].r0l, nt = a->grp[g].ntl;
-      const csn_buf ob = csn_make_buf_n(a->yl + (int64_t)b * a->OL * (int64_t)(csl >> 2), (unsigned)a->OL * csl);
+      const csn_buf ob = csn_make_buf_n(reinterpret_cast<char*>(a->yl) + (int64_t)b * a->OL * (int64_t)csl, (unsigned)a->OL * csl);
       csn_cfp ep = csn_const(a->ep_l) + 4 * r0;
       const unsigned sv = valid ? ol[4] : 0x80000000u;
 #pragma unroll
@@ -341,7 +344,7 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
           for (int i = 0; i < 4; ++i) {
             const int r = 4 * t + i;
             const float o = RAW ? accl[t][i] : pw4_epi(accl[t][i], ep[4 * r], ep[4 * r + 1], ep[4 * r + 2]);
-            csn_st1(ob, sv, (unsigned)(r0 + r) * csl, o);
+            csn_bufacc<AT>::st1(ob, sv, (unsigned)(r0 + r) * csl, o);
           }
         }
       }
@@ -362,10 +365,10 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
   X(1, 0) X(0, 1) X(0, 2) X(0, 3) X(0, 4) X(0, 5) X(0, 6) X(8, 0) X(10, 0) X(7, 0) X(2, 3) X(3, 2) X(2, 1) X(1, 2) X(1, 3) X(2, 4)
 
 typedef void (*Pw4Fn)(Pw4Args);
-struct Pw4Entry { int nth, ntl; Pw4Fn fn[3]; };
+struct Pw4Entry { int nth, ntl; Pw4Fn fn[4]; };   // BN + PReLU / raw / row reduction / raw with bfloat16 tensors
 template <int H, int L> struct Pw4RedFn { static Pw4Fn get() { return nullptr; } };
 template <int H> struct Pw4RedFn<H, 0> { static Pw4Fn get() { return pw4_kernel<H, 0, 2>; } };   // row reduction: high-only forms
-#define PW4_ENTRY(H, L) {H, L, {pw4_kernel<H, L, 0>, pw4_kernel<H, L, 1>, Pw4RedFn<H, L>::get()}},
+#define PW4_ENTRY(H, L) {H, L, {pw4_kernel<H, L, 0>, pw4_kernel<H, L, 1>, Pw4RedFn<H, L>::get(), pw4_kernel<H, L, 1, csn_bf16>}},
 static const Pw4Entry g_pw4_table[] = {PW4_INST_LIST(PW4_ENTRY)};
 
 // smallest instantiation that covers (nth, ntl) row tiles per group (ntl = 0 must stay 0: no low output), or {0, 0}
@@ -387,7 +390,8 @@ int csn_launch_pw4(const Pw4Args& a, int raw, void* stream) {
   for (size_t i = 0; i < sizeof(g_pw4_table) / sizeof(g_pw4_table[0]); ++i)
     if (g_pw4_table[i].nth == a.nth && g_pw4_table[i].ntl == a.ntl) e = &g_pw4_table[i];
   if (!e) return 1;   // hipErrorInvalidValue
-  const int mode = a.red_w ? 2 : (raw ? 1 : 0);
+  const int mode = a.red_w ? 2 : (raw ? (a.a16 ? 3 : 1) : 0);
+  if (a.a16 && !raw) return 1;   // bfloat16 tensors: train-mode (raw) launches only
   if (!e->fn[mode]) return 1;
   const int nitems = a.tiles_x * a.tiles_y * a.B * (a.red_w ? 1 : a.ngroups);
   int nblk = (nitems + 3) / 4;

@@ -1,0 +1,172 @@
+// k_pwq.hip -- plain 1x1 contraction over own-resolution slices, raw output: the input-gradient launches of the 1x1 units.
+//
+// Backward of gOctaveConv with 1x1 kernels (CSNet/model/csnet.py:664-726, adjoint of 716-717 / 702-707 / 708-714):
+//     dx_i = sum_{j = i} W_ij^T dz_j  +  sum_{j < i} W_ij^T adjoint_up(dz_j)  +  sum_{j > i} maxpool_bwd(W_ij^T dz_j)
+// csn_backward.inl turns every term into a contraction whose sources are ALL at the pass resolution (dz_j itself, the
+// adjoint-upsampled dz_j written by adjup*_kernel, the low-resolution temporary that maxpool*_bwd_add routes afterwards):
+//     out[r][p] = sum_s sum_c Wt[r][k_s + c] * src_s[c][p],   Wt = transposed weight blocks (CSN_PREP_PW4_T)
+// -- no resampling, no epilogue.  A 1x1 convolution does not see the image geometry, so the planes are walked as flat
+// arrays: a LANE owns four consecutive elements of the plane (one aligned 128-bit load per channel, a wave reads 1 KB
+// rows), v_mfma_f32_4x4x1_16B_f32 straight from the load registers exactly as in k_pw4.hip (B = the lane's value, A = four
+// rows of Wt from the LDS image, D = four consecutive output channels of the lane's own element), 128-bit stores.
+// Replaces goct_pw_kernel<true> for these launches (round 3): ~3,000 instructions per 64 elements there, ~25 per channel
+// and 256 elements here; float and bfloat16 storage.  Needs H * W % 4 == 0 (else the launch stays on goct_pw_kernel).
+#include "pw4_common.h"
+
+#ifndef PWQ_CB
+#define PWQ_CB 4     // channels per load batch
+#endif
+
+namespace {
+
+template <typename AT, int CB>
+__device__ __forceinline__ void pwq_load(csn_buf rb, unsigned off, unsigned cs, int c0, int C, float4 (&v)[CB]) {
+#pragma unroll
+  for (int j = 0; j < CB; ++j) v[j] = csn_bufacc<AT>::ld4(rb, off, (unsigned)min(c0 + j, C - 1) * cs);
+}
+
+template <int NT, int P, int CB, bool GUARD>
+__device__ __forceinline__ void pwq_batch(const float4 (&v)[CB], const float* wk, int n, csn_f4 (&acc)[4][NT]) {
+  constexpr int NT4 = (NT + 3) & ~3;
+#pragma unroll
+  for (int j = 0; j < CB; ++j) {
+    if (GUARD && j >= n) break;
+    Pw4A<NT4> a;
+    pw4_load_a<NT4, P>(wk + j * 4 * P, a);
+    const float q[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) pw4_mfma<NT4>(a, t, q[s], acc[s][t]);
+  }
+}
+
+}  // namespace
+
+template <int NT, typename AT>
+__global__ __launch_bounds__(CSN_BLOCK, 16 * NT <= 96 ? 3 : 2) void pwq_kernel(PwqArgs a_byval) {
+  constexpr int NT4 = (NT + 3) & ~3, P = PW4_PITCH(NT4), CB = PWQ_CB;
+  constexpr unsigned E = (unsigned)sizeof(AT);
+  CSN_DYN_SMEM(float, lds);
+  const CSN_CONST_AS PwqArgs* a = CSN_KERNARG(PwqArgs, a_byval);
+  const int tid = threadIdx.x;
+  {
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(a->wimg);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    const int n4 = (a->ngroups * a->gimg_floats) >> 2;
+    for (int i = tid; i < n4; i += CSN_BLOCK) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = pw4_uniform(tid >> 6);
+  const int hw = a->HW, nq = hw >> 2;                 // elements / lane quads per plane
+  const unsigned cs = (unsigned)hw * E;
+  const int ng = a->ngroups;
+  const int tiles_img = (nq + 63) >> 6;
+  const int nitems = tiles_img * a->B * ng;
+  const int nslot = (int)(gridDim.x >> 3) * 4;
+  const int chunk = (((nitems + 7) >> 3) + ng - 1) / ng * ng;
+  const int xcd = blockIdx.x & 7;
+  const int iend = min((xcd + 1) * chunk, nitems);
+#ifdef CSN_CPU_EMU
+  const float* wl_lane = lds;
+#else
+  const float* wl_lane = lds + (lane & 3) * P;
+#endif
+  for (int item = xcd * chunk + (int)(blockIdx.x >> 3) * 4 + wave; item < iend; item += nslot) {
+    const int tile = item / ng, g = item - tile * ng;
+    const int b = tile / tiles_img, t = tile - b * tiles_img;
+    const int q0 = (t << 6) + lane;
+    const bool valid = q0 < nq;
+    const unsigned off = (unsigned)min(q0, nq - 1) * 4u * E;
+    const float* wg = wl_lane + g * a->gimg_floats;
+    csn_f4 acc[4][NT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[s][tt][i] = 0.f;
+    int krow = 0;
+    for (int s = 0; s < a->nsrc; ++s) {
+      const int C = a->src[s].C;
+      const csn_buf rb = csn_make_buf_n(reinterpret_cast<const char*>(a->src[s].ptr) + (int64_t)b * a->src[s].Ctot * (int64_t)cs,
+                                        (unsigned)C * cs);
+      // batch c0 is contracted while batch c0 + CB is in flight (two register sets, batches walked in pairs, the last --
+      // possibly partial -- batch ends up in set A)
+      float4 vA[CB], vB[CB];
+      pwq_load<AT, CB>(rb, off, cs, 0, C, vA);
+      PW4_FENCE();
+      const int nf = (C - 1) / CB;
+      int c0 = 0;
+      for (int p = 0; p < (nf >> 1); ++p) {
+        pwq_load<AT, CB>(rb, off, cs, c0 + CB, C, vB);
+        PW4_FENCE();
+        pwq_batch<NT, P, CB, false>(vA, wg + (krow + c0) * 4 * P, CB, acc);
+        pwq_load<AT, CB>(rb, off, cs, c0 + 2 * CB, C, vA);
+        PW4_FENCE();
+        pwq_batch<NT, P, CB, false>(vB, wg + (krow + c0 + CB) * 4 * P, CB, acc);
+        c0 += 2 * CB;
+      }
+      if (nf & 1) {
+        pwq_load<AT, CB>(rb, off, cs, c0 + CB, C, vB);
+        PW4_FENCE();
+        pwq_batch<NT, P, CB, false>(vA, wg + (krow + c0) * 4 * P, CB, acc);
+        c0 += CB;
+#pragma unroll
+        for (int j = 0; j < CB; ++j) vA[j] = vB[j];
+      }
+      pwq_batch<NT, P, CB, true>(vA, wg + (krow + c0) * 4 * P, C - c0, acc);
+      krow += C;
+    }
+    // ---- raw stores: rows past the group's tile list are skipped, rows past the last channel fall out of the resource ----
+    const int r0 = a->grp_r0[g], nt = a->grp_nt[g];
+    const csn_buf ob = csn_make_buf_n(reinterpret_cast<char*>(a->out) + (int64_t)b * a->out_ctot * (int64_t)cs, (unsigned)a->nrows * cs);
+    const unsigned sv = valid ? off : 0x80000000u;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+      if (tt < nt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const unsigned so = (unsigned)(r0 + 4 * tt + i) * cs;
+          const float4 o = make_float4(acc[0][tt][i], acc[1][tt][i], acc[2][tt][i], acc[3][tt][i]);
+          if (sizeof(AT) == 4) {
+            csn_st4(ob, sv, so, o);
+          } else {
+            csn_bufacc<AT>::st2(ob, sv, so, make_float2(o.x, o.y));
+            csn_bufacc<AT>::st2(ob, sv + 2u * E, so, make_float2(o.z, o.w));
+          }
+        }
+      }
+    }
+  }
+}
+
+#define PWQ_INST_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6)
+typedef void (*PwqFn)(PwqArgs);
+struct PwqEntry { int nt; PwqFn fn[2]; };
+#define PWQ_ENTRY(N) {N, {pwq_kernel<N, float>, pwq_kernel<N, csn_bf16>}},
+static const PwqEntry g_pwq_table[] = {PWQ_INST_LIST(PWQ_ENTRY)};
+
+int csn_pwq_max_tiles(void) { return 6; }
+
+int csn_launch_pwq(const PwqArgs& a, void* stream) {
+  const PwqEntry* e = nullptr;
+  for (size_t i = 0; i < sizeof(g_pwq_table) / sizeof(g_pwq_table[0]); ++i)
+    if (g_pwq_table[i].nt == a.nt) e = &g_pwq_table[i];
+  if (!e) return 1;
+  const int nq = a.HW >> 2;
+  const int nitems = ((nq + 63) >> 6) * a.B * a.ngroups;
+  int nblk = (nitems + 3) / 4;
+  if (nblk > a.max_grid) nblk = a.max_grid;
+  const dim3 grid((nblk + 7) & ~7);
+  const size_t lds = (size_t)a.ngroups * a.gimg_floats * sizeof(float);
+#ifndef CSN_CPU_EMU
+  if (lds > 64 * 1024) {
+    const hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(e->fn[a.a16 ? 1 : 0]),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (er != hipSuccess) return (int)er;
+  }
+#endif
+  CSN_LAUNCH(e->fn[a.a16 ? 1 : 0], grid, dim3(CSN_BLOCK), lds, stream, a);
+  return (int)hipGetLastError();
+}

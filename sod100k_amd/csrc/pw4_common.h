@@ -36,23 +36,23 @@ __device__ __forceinline__ void pw4_mfma(const Pw4A<NT4>& a, int t, float x, csn
 #endif
 }
 
-template <int HB>
+template <int HB, typename AT = float>
 __device__ __forceinline__ void pw4_load_hi(csn_buf rb, unsigned o0, unsigned o1, unsigned cs, int k0, int C, float2 (&v)[HB][2]) {
 #pragma unroll
   for (int j = 0; j < HB; ++j) {
     const unsigned so = (unsigned)min(k0 + j, C - 1) * cs;
-    v[j][0] = csn_ld2(rb, o0, so);
-    v[j][1] = csn_ld2(rb, o1, so);
+    v[j][0] = csn_bufacc<AT>::ld2(rb, o0, so);
+    v[j][1] = csn_bufacc<AT>::ld2(rb, o1, so);
   }
 }
 
-template <int LB>
+template <int LB, typename AT = float>
 __device__ __forceinline__ void pw4_load_lo(csn_buf rb, const unsigned (&o)[9], unsigned cs, int k0, int C, float (&v)[LB][9]) {
 #pragma unroll
   for (int j = 0; j < LB; ++j) {
     const unsigned so = (unsigned)min(k0 + j, C - 1) * cs;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) v[j][t] = csn_ld1(rb, o[t], so);
+    for (int t = 0; t < 9; ++t) v[j][t] = csn_bufacc<AT>::ld1(rb, o[t], so);
   }
 }
 
