@@ -198,12 +198,13 @@ int csn_adam_step(float* p, const float* g, float* m, float* v, const float* wd,
  *   ((img - mean) / std, test.py:68-69,86);
  * csn_saliency_u8: logits -> (sigmoid(y) * 255).astype(uint8), truncation as numpy does (test.py:92-96).
  * The resizes of test.py:76-85 / 94-96 (skimage.transform.resize, order 1, mode='reflect', anti_aliasing=False = bilinear
- * with half-pixel centres; the mirrored border sample coincides with the clamped one) on the device as well:
+ * with half-pixel centres, source coordinates outside the image MIRRORED about the edge pixel centre -- what skimage's
+ * scipy.ndimage.zoom(order=1, mode='mirror', grid_mode=True) call computes) on the device as well:
  * csn_resize_normalize_nchw: B float images Hi x Wi x 3 in [0,1] -> resize to H x W -> normalise -> NCHW;
  * csn_saliency_resize_u8: logits H x W -> sigmoid -> resize to h x w -> (p * 255) truncated to uint8;
  * csn_resize_bilinear: planar float tensors [planes][Hi][Wi] -> [planes][Ho][Wo].
- * skimage is not available to the build: these are checked against torch's F.interpolate(align_corners=False) and
- * through properties (identity, constants, affine ramps), i.e. parity with skimage itself is unpinned. */
+ * skimage is not available to the build; the rule is pinned against scipy.ndimage.zoom (the routine skimage calls) and
+ * through properties (identity, constants, affine ramps) in tests/resize_cases.py. */
 int csn_normalize_nchw(const float* hwc, float* nchw, int64_t B, int64_t H, int64_t W, void* stream);
 int csn_saliency_u8(const float* logits, uint8_t* out, int64_t n, void* stream);
 int csn_resize_normalize_nchw(const float* hwc, float* nchw, int32_t B, int32_t Hi, int32_t Wi, int32_t H, int32_t W, void* stream);

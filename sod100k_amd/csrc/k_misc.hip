@@ -643,15 +643,23 @@ __global__ __launch_bounds__(CSN_BLOCK) void normalize_nchw_kernel(const float* 
 
 // ---------------------------------------------------------------------------------------------- resize (f-2)
 // The resizes either side of the forward in the inference caller (test.py:76-85,94-96): skimage.transform.resize(order 1,
-// mode='reflect', anti_aliasing=False) = bilinear interpolation with half-pixel centres,  src = (dst + 0.5) * in / out - 0.5.
-// 'reflect' only matters for source coordinates below 0 / above n - 1, where the mirrored neighbour IS the edge sample for
-// every |excess| <= 1, so it coincides with clamping (F.interpolate(mode='bilinear', align_corners=False, antialias=False)).
+// mode='reflect', anti_aliasing=False) = scipy.ndimage.zoom(order=1, mode='mirror', grid_mode=True) (skimage maps its
+// 'reflect' to ndimage's 'mirror'): bilinear interpolation with half-pixel centres, src = (dst + 0.5) * in / out - 0.5, and
+// a source coordinate outside [0, n - 1] is MIRRORED about the centre of the edge pixel -- src = -0.25 samples
+// 0.75 a + 0.25 b, not a (clamping, which is what F.interpolate does, differs in the border rows / columns of
+// every upsampled picture).  Pinned against scipy.ndimage.zoom in tests/resize_cases.py.
+__device__ __forceinline__ int csn_mirror(int i, int n) {
+  if (n <= 1) return 0;
+  if (i < 0) i = -i;
+  if (i > n - 1) i = 2 * (n - 1) - i;
+  return min(max(i, 0), n - 1);
+}
 __device__ __forceinline__ void csn_resize_coord(int dst, float scale, int n, int& i0, int& i1, float& l1) {
-  float src = (static_cast<float>(dst) + 0.5f) * scale - 0.5f;
-  src = src < 0.f ? 0.f : src;
-  i0 = min(static_cast<int>(src), n - 1);
-  i1 = min(i0 + 1, n - 1);
-  l1 = src - static_cast<float>(i0);
+  const float src = (static_cast<float>(dst) + 0.5f) * scale - 0.5f;
+  const float f = floorf(src);
+  l1 = src - f;
+  i0 = csn_mirror(static_cast<int>(f), n);
+  i1 = csn_mirror(static_cast<int>(f) + 1, n);
 }
 
 // pre: B images H_i x W_i x 3 (float, [0,1]) -> bilinear resize to H x W -> (v - mean) / std -> [B][3][H][W]

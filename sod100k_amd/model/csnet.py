@@ -470,7 +470,14 @@ class CSNet(nn.Module):
         bf16 = bool(train) and getattr(self, "_train_act_dtype", "fp32") == "bf16"
         key = (tuple(x.shape), x.device, bool(train), bf16)
         eng = self._engines.get(key)
+        if eng is not None:
+            self._engines[key] = self._engines.pop(key)      # most recently used last
         if eng is None:
+            # a plan holds its workspace and graphs: native-resolution inference (test.py:80-85) meets a new (B, H, W) per
+            # picture size, so the least recently used plans are dropped beyond CSN_MAX_ENGINES
+            cap = max(1, int(os.environ.get("CSN_MAX_ENGINES", "8")))
+            while len(self._engines) >= cap:
+                self._engines.pop(next(iter(self._engines)))
             B, _, H, W = x.shape
             if H % 16 or W % 16:
                 raise ValueError("CSNet needs H and W to be multiples of 16 (cf. test.py:80-85)")

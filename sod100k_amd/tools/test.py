@@ -51,8 +51,8 @@ def run_pictures(model, imgs, cfg_h, cfg_w, batch, device, lib=None):
     out = [None] * len(imgs)
     for (h, w, H, W), members in groups.items():
         for i in range(0, len(members), batch):
-            chunk = members[i:i + batch]
-            hwc = np.stack([imgs[k] for k in chunk] + [np.zeros((h, w, 3), np.float32)] * (batch - len(chunk)))
+            chunk = members[i:i + batch]      # a short last chunk runs at its own batch size (no padded pictures)
+            hwc = np.stack([imgs[k] for k in chunk])
             with torch.no_grad():
                 x = E.resize_normalize_nchw(lib, torch.from_numpy(hwc.astype(np.float32)).to(device), H, W)
                 pred = model(x)

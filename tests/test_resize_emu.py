@@ -22,7 +22,8 @@ def test_resize_pre_post(emu_lib):
 
 def test_caller_native_resolution_and_fixed_size(emu_lib, x2_manifest):
     """run_pictures: pictures of different sizes, (a) at the configured 224 x 224, (b) with IMAGE_H/W = 0 at their own size
-    rounded up to multiples of 16 (test.py:76-85); maps against the oracle with torch's bilinear resizes either side."""
+    rounded up to multiples of 16 (test.py:76-85); maps against the oracle with skimage's resize rule (scipy.ndimage.zoom,
+    resize_cases.sk_resize) either side."""
     import parity_cases as P
     from sod100k_amd.tools import test as T
     m, sd = P.make_model(emu_lib, x2_manifest, torch.device("cpu"))
@@ -37,10 +38,10 @@ def test_caller_native_resolution_and_fixed_size(emu_lib, x2_manifest):
             if cfg_hw == (0, 0):
                 assert (H, W) == (-(-h // 16) * 16, -(-w // 16) * 16)
             t = torch.from_numpy(im.astype(np.float32)).permute(2, 0, 1)[None]
-            x = (F.interpolate(t, size=(H, W), mode="bilinear", align_corners=False) - RC.MEAN) / RC.STD
+            x = (RC.sk_resize(t[0], H, W)[None] - RC.MEAN) / RC.STD
             with torch.no_grad():
                 y = O.csnet_forward(lc, sd, x)
-            p = F.interpolate(torch.sigmoid(y), size=(h, w), mode="bilinear", align_corners=False)[0, 0]
+            p = RC.sk_resize(torch.sigmoid(y)[0], h, w)[0]
             want = (p.numpy() * 255).astype(np.uint8)
             assert got.shape == (h, w) and got.dtype == np.uint8
             d = np.abs(got.astype(int) - want.astype(int))
