@@ -274,6 +274,7 @@ def main():
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
                         bytes_per_launch=int(bytes_per_launch), us_per_launch=round(us_per_launch, 2),
                         launches_per_step=d["launches"],
+                        event_bracket_us=round(eng.profile_bracket_us(), 2),   # subtracted from every per-launch interval
                         whole_step=dict(algorithmic_bytes=int(total_alg), events_ms=round(total_ms, 3),
                                         achieved=round(total_alg / (total_ms * 1e-3) / 1e9, 1),
                                         frac=round(total_alg / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),

@@ -233,6 +233,9 @@ int csn_forward_profile(csn_plan* plan, const float* x, float* y, void* workspac
  * the launch stream; entry i gives the kernel name, its total milliseconds per forward and its launch count
  * per forward (so ms / launches is the mean launch duration rocprofv3 --stats reports for that name). */
 int32_t csn_profile_num_kernels(const csn_plan* plan);
+/* microseconds an event pair adds to one launch (measured on empty launches by the last csn_forward_profile call and already
+ * subtracted from every per-unit / per-kernel time it reports, so that they agree with a kernel trace's durations) */
+double csn_profile_bracket_us(const csn_plan* plan);
 int csn_profile_kernel(const csn_plan* plan, int32_t i, const char** name, double* ms_per_forward, int32_t* launches);
 
 /* Name of the dominant kernel of unit `u` (static string) and the algorithmic bytes it moves per

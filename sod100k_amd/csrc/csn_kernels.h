@@ -445,4 +445,5 @@ int csn_launch_ms(const MsArgs& a, void* stream);
 int csn_launch_pool(const PoolArgs& a, void* stream);
 int csn_launch_maxpool(const PoolArgs& a, void* stream);   // 2x2 max instead of the mean (float)
 int csn_launch_up2(const Up2Args& a, void* stream);
+int csn_launch_nop(void* stream);
 int csn_kernels_init(void);  // function attributes (max dynamic LDS)

@@ -195,6 +195,7 @@ struct csn_plan {
   std::vector<KStat> kstats;         // aggregated over the last csn_forward_profile call
   bool profiling = false;
   size_t ev_used = 0;
+  float bracket_ms = 0.f;            // what an event pair adds to one (empty) launch: subtracted from every profiled interval
   // ---- training (csn_plan_enable_training) ----
   int64_t pen_off = -1;                         // penalty job terms (workspace bytes), pen_slots doubles
   int pen_slots = 0;
@@ -1602,6 +1603,25 @@ static int forward_body(csn_plan* P, const float* x, float* y, void* workspace, 
   }
   const int64_t in_stride = (int64_t)P->acts[0].channels * P->H * P->W, out_stride = (int64_t)P->H * P->W;
   const int reps = prof ? (iters > 0 ? iters : 1) : 1;
+#ifndef CSN_CPU_EMU
+  if (prof) {
+    // An interval between two events around a launch = the kernel + the dispatch / event latency of the pair.  The pair's own
+    // cost is measured on empty launches (median of 15) and subtracted, so that the per-kernel times agree with the
+    // durations a kernel trace (rocprofv3) reports for the same launches.
+    const int NB = 16;
+    while (P->ev.size() < (size_t)NB) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); P->ev.push_back(e); }
+    HIP_TRY(hipEventRecord(P->ev[0], (hipStream_t)stream));
+    for (int i = 1; i < NB; ++i) {
+      LAUNCH_TRY(csn_launch_nop(stream));
+      HIP_TRY(hipEventRecord(P->ev[i], (hipStream_t)stream));
+    }
+    HIP_TRY(hipEventSynchronize(P->ev[NB - 1]));
+    std::vector<float> br;
+    for (int i = 1; i < NB; ++i) { float ms = 0.f; HIP_TRY(hipEventElapsedTime(&ms, P->ev[i - 1], P->ev[i])); br.push_back(ms); }
+    std::sort(br.begin(), br.end());
+    P->bracket_ms = br[br.size() / 2];
+  }
+#endif
   // concurrent slices: slice i runs on stream lane i % nconc in workspace region i % nconc (the small maps of the deep
   // stages are latency-bound per launch: two half-batches side by side fill the gaps a single chain of launches leaves)
   const int nslices = (P->B + P->S - 1) / P->S;
@@ -1657,6 +1677,7 @@ static int forward_body(csn_plan* P, const float* x, float* y, void* workspace, 
         for (size_t i = 1; i < P->ev_used; ++i) {
           float ms = 0.f;
           HIP_TRY(hipEventElapsedTime(&ms, P->ev[i - 1], P->ev[i]));
+          ms = std::max(ms - P->bracket_ms, 0.25f * ms);      // the event pair's own cost (see above)
           unit_ms[unit_of_tag[i]] += ms;
           bool found = false;
           for (auto& k : P->kstats)
@@ -1812,6 +1833,7 @@ const char* csn_unit_kernel_name(const csn_plan* P, int32_t u) {
 }
 
 int32_t csn_profile_num_kernels(const csn_plan* P) { return P ? (int32_t)P->kstats.size() : 0; }
+double csn_profile_bracket_us(const csn_plan* P) { return P ? 1e3 * (double)P->bracket_ms : 0.0; }
 
 int csn_profile_kernel(const csn_plan* P, int32_t i, const char** name, double* ms_per_forward, int32_t* launches) {
   if (!P || i < 0 || i >= (int)P->kstats.size() || !name || !ms_per_forward || !launches) return CSN_E_INVALID;

@@ -842,4 +842,11 @@ int csn_launch_resize_bilinear(const float* in, float* out, int planes, int Hi, 
   return (int)hipGetLastError();
 }
 
+// an empty launch: csn_forward_profile brackets it with events to calibrate what an event pair adds to a launch
+__global__ void csn_nop_kernel() {}
+int csn_launch_nop(void* stream) {
+  CSN_LAUNCH(csn_nop_kernel, dim3(1), dim3(64), 0, stream);
+  return (int)hipGetLastError();
+}
+
 int csn_kernels_init(void) { return 0; }

@@ -184,6 +184,10 @@ class Engine:
         nbytes = [int(self.lib.csn_unit_algorithmic_bytes(self.plan, u)) for u in range(self.n_units)]
         return list(ms), names, nbytes
 
+    def profile_bracket_us(self) -> float:
+        """What an event pair added to one launch in the last ``profile`` call (already subtracted from its times)."""
+        return float(self.lib.csn_profile_bracket_us(self.plan))
+
     def kernel_stats(self):
         """{kernel name: (ms per forward, launches per forward)} of the last ``profile`` call."""
         out = {}

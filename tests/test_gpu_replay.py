@@ -3,6 +3,7 @@ csn_plan.hip csn_forward) and of the train step (run_graphed: two eager calls, c
 fourth), plus size-independent properties of the train step at BASELINE config 3's batch of 256.
 
 The other GPU tests call ``model(x)``, which allocates a fresh output per call and therefore always runs eagerly."""
+import gc
 import os
 
 import numpy as np
@@ -206,6 +207,7 @@ def test_gpu_train_batch256_properties(hip, x2_manifest):
             outs.append((float(loss), float(pen), tr.grad.clone()))
         stats = {k: v.cpu().clone() for k, v in m.state_dict().items() if "running_" in k}
         del tr, m                                  # a batch-256 training workspace is 61 GiB: one at a time
+        gc.collect()                               # (model <-> parameter arena is a reference cycle: refcounts alone do not free it)
         torch.cuda.empty_cache()
         return stats, outs
 
@@ -275,6 +277,7 @@ def test_gpu_train_bf16_replay_and_batch256(hip, x2_manifest):
             outs.append((float(loss), float(pen), tr.grad.clone()))
         stats = {k: v.cpu().clone() for k, v in m.state_dict().items() if "running_" in k}
         del tr, m
+        gc.collect()
         torch.cuda.empty_cache()
         return stats, outs
 
