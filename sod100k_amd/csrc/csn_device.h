@@ -239,6 +239,31 @@ template <> struct csn_bufacc<csn_bf16> {
   static __device__ __forceinline__ void st2(csn_buf b, unsigned voff, unsigned soff, float2 v) { csn_st_u32(b, voff, soff, csn_pack_bf2(v.x, v.y)); }
 };
 
+#ifndef CSN_FILL_U
+#define CSN_FILL_U 8   // steps of loads in flight (1: the plain loop, A/B builds)
+#endif
+// Block-wide copy of a weight image into LDS, 16 bytes per thread and step, EIGHT steps of loads in flight before the first
+// LDS write: a plain `dst[i] = src[i]` loop compiles to load / s_waitcnt vmcnt(0) / ds_write per 4 KB -- one L2 round trip
+// each, 7-37 of them in front of every block's first item (round 3: 5-25 us of the small launches).
+__device__ __forceinline__ void csn_fill_lds16(float* lds, const float* __restrict__ img, int n4, int tid) {
+  const float4* __restrict__ src = reinterpret_cast<const float4*>(img);
+  float4* dst = reinterpret_cast<float4*>(lds);
+  constexpr int U = CSN_FILL_U;
+  for (int i0 = tid; i0 < n4; i0 += U * CSN_BLOCK) {
+    float4 v[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) v[j] = src[min(i0 + j * CSN_BLOCK, n4 - 1)];
+#ifndef CSN_CPU_EMU
+#pragma unroll
+    for (int j = 0; j < U; ++j)   // a use right here: keeps the loads from being sunk into the guarded stores below
+      asm volatile("" : "+v"(v[j].x), "+v"(v[j].y), "+v"(v[j].z), "+v"(v[j].w));
+#endif
+#pragma unroll
+    for (int j = 0; j < U; ++j)
+      if (i0 + j * CSN_BLOCK < n4) dst[i0 + j * CSN_BLOCK] = v[j];
+  }
+}
+
 // Folded epilogue of one output channel: y = z*scale + shift; y = y >= 0 ? y : alpha*y
 // (nn.BatchNorm2d in eval mode followed by nn.PReLU; for cls_layer scale=1, shift=bias, alpha=1).
 struct CsnEpi {

@@ -150,17 +150,18 @@ struct Pw4Args {
   const float* xh;     // [B][CH][2 Hl][2 Wl]
   const float* xl;     // [B][CL][Hl][Wl]
   const float* x2;     // [B][C2][Hl / 2][Wl / 2]: third input of a three-branch unit (single-output forms only; null / C2 = 0: none)
+  const float* xq;     // [B][CQ][4 Hl][4 Wl]: input two levels finer, 4x4 max-pooled on the way in (low-only form; null / CQ = 0: none)
   float* yh;           // [B][OH][2 Hl][2 Wl]
   float* yl;           // [B][OL][Hl][Wl]   (unused when the unit has no low output)
   const float* red_w;  // row reduction (cls_layer in fuse1x1's epilogue): zero-padded weights per high row; null: rows are stored
   const float* red_b;
   float* logits;       // [B][1][2 Hl][2 Wl]
-  const float* wimg;   // [ngroups][CH + CL + C2][4][P]: element (g, k, i, t) = W[row 4 t + i of group g's tile list][gathered channel k],
+  const float* wimg;   // [ngroups][CH + CL + C2 + CQ][4][P]: element (g, k, i, t) = W[row 4 t + i of group g's tile list][gathered channel k],
                        // tiles 0 .. nth-1 = high rows, nth .. nth+ntl-1 = low rows, zero padded
   const float* ep_h;   // folded BN / PReLU records {scale, shift, alpha, 0} per high / low output channel (padded to whole tiles)
   const float* ep_l;
   int32_t CH, CL, OH, OL;
-  int32_t C2, pad2;
+  int32_t C2, CQ;
   int32_t Hl, Wl, B;
   int32_t twl;              // log2 of the tile width in low pixels (tile = 2^twl x 64 / 2^twl)
   int32_t tiles_x, tiles_y;

@@ -129,6 +129,7 @@ struct UnitPlan {
   struct Pw4Launch {
     int hi_out = -1, lo_out = -1;    // output branch written from the high / low rows (-1: none)
     int use_x2 = 0;                  // third input branch (single-output forms)
+    int bh = 0, bl = 1, bq = -1;     // input branches bound to xh / xl (x2 = bl + 1) / xq
     int nth = 0, ntl = 0, ng = 0, gimg = 0;
     Pw4Group grp[PW4_MAX_GROUPS] = {};
     int64_t wimg = -1, ep[2] = {-1, -1};
@@ -168,6 +169,7 @@ struct csn_plan {
   bool pw4 = true;        // CSN_OPT_PW4: two-branch 1x1 units on pw4_kernel (k_pw4.hip)
   int pw4_grid = 2048;    // its block cap (CSN_PW4_GRID, experiments)
   int pw4_twl = 4;        // log2 of its widest tile in low pixels (CSN_PW4_TWL, experiments)
+  bool pw4_no_q = false;      // CSN_PW4_NOQ: CSFHead.fuse's lowest output branch stays on goct_pw_kernel (experiments)
   bool pw4_nosplit = false;   // CSN_PW4_NOSPLIT: no extra M groups on small maps (experiments)
   bool overlap_bwd = false;   // CSN_OPT_OVERLAP value 2: also the weight-gradient side lane of csn_backward
   bool overlap = true;    // CSN_OPT_OVERLAP: independent launches of a unit (and the MSBlocks) on parallel stream lanes
@@ -579,13 +581,16 @@ int plan_goct(Builder& bl, UnitPlan& u) {
 
 // 1x1 unit with two or three input branches on pw4_kernel (k_pw4.hip): per launch M groups, weight image [group][K][4][P]
 // (gathered channels: branch 0, 1, 2 in order), interleaved epilogue records.
-int plan_pw4_launch(Builder& bl, UnitPlan& u, const int* ci_off, const int* co_off, int cin_tot, int hi_out, int lo_out, int use_x2) {
+// Input branches: bh -> xh (twice the resolution of bl), bl -> xl, bl + 1 -> x2 (use_x2), bq -> xq (four times the resolution
+// of bl, low-only form); the defaults are the unit's branches 0, 1, 2.
+int plan_pw4_launch(Builder& bl, UnitPlan& u, const int* ci_off, const int* co_off, int cin_tot, int hi_out, int lo_out, int use_x2,
+                    int bh = 0, int bl_ = 1, int bq = -1) {
   const csn_unit_desc& d = u.d;
   const int OH = hi_out >= 0 ? d.cout[hi_out] : 0, OL = lo_out >= 0 ? d.cout[lo_out] : 0;
   const int nth_tot = (OH + 3) / 4, ntl_tot = (OL + 3) / 4;
   // M groups: as few as the accumulator budget allows (a group re-reads the inputs and repeats the interpolation
   // arithmetic) -- but a small map needs more items than that to occupy the 1024 SIMDs, and its items are short
-  const int Hl_ = bl.P.H >> (u.base_lvl + 1), Wl_ = bl.P.W >> (u.base_lvl + 1);
+  const int Hl_ = bl.P.H >> (u.base_lvl + bl_), Wl_ = bl.P.W >> (u.base_lvl + bl_);
   const int64_t tiles = (int64_t)bl.P.S * ((Hl_ * Wl_ + 63) / 64);
   int gmin = 1;
   if (!bl.P.pw4_nosplit)
@@ -600,12 +605,12 @@ int plan_pw4_launch(Builder& bl, UnitPlan& u, const int* ci_off, const int* co_o
     break;
   }
   if (ng == 0) return -1;
-  const int nin = use_x2 ? 3 : 2;
+  const int src[4] = {bh, bl_, use_x2 ? bl_ + 1 : -1, bq};   // gathered channel order of the weight image
   int K = 0;
-  for (int i = 0; i < nin; ++i) K += d.cin[i];
+  for (int i = 0; i < 4; ++i) K += src[i] >= 0 ? d.cin[src[i]] : 0;
   const int NT4 = (pn + pl + 3) & ~3, Pp = PW4_PITCH(NT4);
   UnitPlan::Pw4Launch L;
-  L.hi_out = hi_out; L.lo_out = lo_out; L.use_x2 = use_x2;
+  L.hi_out = hi_out; L.lo_out = lo_out; L.use_x2 = use_x2; L.bh = bh; L.bl = bl_; L.bq = bq;
   L.nth = pn; L.ntl = pl; L.ng = ng; L.gimg = K * 4 * Pp;
   if ((int64_t)ng * L.gimg * 4 > 150 * 1024) return -1;
   L.wimg = bl.alloc_packed((int64_t)ng * L.gimg);
@@ -617,7 +622,9 @@ int plan_pw4_launch(Builder& bl, UnitPlan& u, const int* ci_off, const int* co_o
     const int64_t img = L.wimg + (int64_t)g * L.gimg;
     const int nrh = std::min(4 * G.nth, OH - G.r0h), nrl = std::min(4 * G.ntl, OL - G.r0l);
     int k0 = 0;
-    for (int i = 0; i < nin; ++i) {   // gathered channels: branch 0 first, then 1, then 2
+    for (int s = 0; s < 4; ++s) {   // gathered channels: xh, xl, x2, xq
+      const int i = src[s];
+      if (i < 0 || d.cin[i] <= 0) continue;
       if (nrh > 0)
         bl.job(CSN_PREP_PW4, nrh, img, d.w_off[0] + (int64_t)(co_off[hi_out] + G.r0h) * cin_tot + ci_off[i], -1, -1, -1, 1.f,
                cin_tot, d.cin[i], Pp, 0 | (k0 << 8));
@@ -652,12 +659,17 @@ int plan_pw4(Builder& bl, UnitPlan& u, const int* ci_off, const int* co_off, int
     const int x2 = d.cin[2] > 0 ? 1 : 0;
     ok = plan_pw4_launch(bl, u, ci_off, co_off, cin_tot, 0, -1, x2) == 0;
     if (ok && d.n_out >= 2 && d.cout[1] > 0) ok = plan_pw4_launch(bl, u, ci_off, co_off, cin_tot, -1, 1, x2) == 0;
-    if (d.n_out >= 3 && d.cout[2] > 0) {
-      u.pw4_old_mask = 1 << 2;
-      for (const PwLaunchPlan& L : u.pwl) {   // ... which needs that branch in a launch of its own
-        bool has2 = false, other = false;
-        for (const PwPassPlan& pp : L.passes) { has2 = has2 || pp.out_branch == 2; other = other || pp.out_branch != 2; }
-        if (has2 && other) ok = false;
+    if (ok && d.n_out >= 3 && d.cout[2] > 0) {
+      // the lowest output branch: W_22 x2 + W_21 maxpool2(x1) + W_20 maxpool4(x0) -- the low-only form one level down
+      const int W0 = bl.P.W >> u.base_lvl, H0 = bl.P.H >> u.base_lvl;
+      const bool fits = x2 && !bl.P.pw4_no_q && (W0 % 4) == 0 && (H0 % 4) == 0;
+      if (!fits || plan_pw4_launch(bl, u, ci_off, co_off, cin_tot, -1, 2, 0, 1, 2, 0) != 0) {
+        u.pw4_old_mask = 1 << 2;   // stays on goct_pw_kernel
+        for (const PwLaunchPlan& L : u.pwl) {   // ... which needs that branch in a launch of its own
+          bool has2 = false, other = false;
+          for (const PwPassPlan& pp : L.passes) { has2 = has2 || pp.out_branch == 2; other = other || pp.out_branch != 2; }
+          if (has2 && other) ok = false;
+        }
       }
     }
   }
@@ -1114,7 +1126,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
           if (fork && lane > 0) cl.stream = c.P.lane[lane - 1];
           ++lane;
           Pw4Args a;
-          a.xh = xin[0]; a.xl = xin[1]; a.x2 = L.use_x2 ? xin[2] : nullptr;
+          a.xh = xin[L.bh]; a.xl = xin[L.bl]; a.x2 = L.use_x2 ? xin[L.bl + 1] : nullptr; a.xq = L.bq >= 0 ? xin[L.bq] : nullptr;
           a.yh = L.hi_out >= 0 ? c.act_out(d.out_act[L.hi_out]) : nullptr;
           a.yl = L.lo_out >= 0 ? c.act_out(d.out_act[L.lo_out]) : nullptr;
           a.red_w = a.red_b = nullptr; a.logits = nullptr;
@@ -1127,9 +1139,9 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
           a.wimg = c.pk(L.wimg);
           a.ep_h = L.ep[0] >= 0 ? c.pk(L.ep[0]) : nullptr;
           a.ep_l = L.ep[1] >= 0 ? c.pk(L.ep[1]) : nullptr;
-          a.CH = d.cin[0]; a.CL = d.cin[1]; a.C2 = L.use_x2 ? d.cin[2] : 0; a.pad2 = 0;
+          a.CH = d.cin[L.bh]; a.CL = d.cin[L.bl]; a.C2 = L.use_x2 ? d.cin[L.bl + 1] : 0; a.CQ = L.bq >= 0 ? d.cin[L.bq] : 0;
           a.OH = L.hi_out >= 0 ? d.cout[L.hi_out] : 0; a.OL = L.lo_out >= 0 ? d.cout[L.lo_out] : 0;
-          a.Hl = P.H >> (u.base_lvl + 1); a.Wl = P.W >> (u.base_lvl + 1); a.B = S;
+          a.Hl = P.H >> (u.base_lvl + L.bl); a.Wl = P.W >> (u.base_lvl + L.bl); a.B = S;
           int twl = 0;
           while (twl < P.pw4_twl && (1 << twl) < a.Wl) ++twl;
           a.twl = twl;
@@ -1394,6 +1406,7 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   P->S = (sub_batch <= 0 || sub_batch > B) ? B : sub_batch;
   if (const char* v = std::getenv("CSN_PW4_GRID")) { if (std::atoi(v) >= 8) P->pw4_grid = std::atoi(v); }
   if (std::getenv("CSN_PW4_NOSPLIT")) P->pw4_nosplit = true;
+  if (std::getenv("CSN_PW4_NOQ")) P->pw4_no_q = true;
   if (const char* v = std::getenv("CSN_C3Q_NT")) { if (std::atoi(v) >= 1) P->c3q_cap = std::atoi(v); }
   if (const char* v = std::getenv("CSN_PW4_TWL")) { if (std::atoi(v) >= 2 && std::atoi(v) <= 6) P->pw4_twl = std::atoi(v); }
   Builder bl(*P);

@@ -73,12 +73,7 @@ __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q_kernel(C3qArgs a_byval
   CSN_DYN_SMEM(float, lds);
   const CSN_CONST_AS C3qArgs* a = CSN_KERNARG(C3qArgs, a_byval);
   const int tid = threadIdx.x;
-  {
-    const float4* __restrict__ src = reinterpret_cast<const float4*>(a->wimg);
-    float4* dst = reinterpret_cast<float4*>(lds);
-    const int n4 = (a->ngroups * a->gimg_floats) >> 2;
-    for (int i = tid; i < n4; i += CSN_BLOCK) dst[i] = src[i];
-  }
+  csn_fill_lds16(lds, a->wimg, (a->ngroups * a->gimg_floats) >> 2, tid);
   __syncthreads();
   const int lane = tid & 63, wave = pw4_uniform(tid >> 6);
   const int H = a->H, W = a->W, Hq = H >> 1, Wq = W >> 1;

@@ -125,12 +125,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 4) void goct_pw_kernel(PwArgs a_byval) {
   const CSN_CONST_AS PwArgs* a = CSN_KERNARG(PwArgs, a_byval);
   const int tid = threadIdx.x;
   // ---- stage the unit's weight image (all passes, rows padded to 16, zero filled) into LDS once ----
-  {
-    const float4* __restrict__ src = reinterpret_cast<const float4*>(a->wimg);
-    float4* dst = reinterpret_cast<float4*>(lds);
-    const int n4 = a->wimg_floats >> 2;
-    for (int i = tid; i < n4; i += CSN_BLOCK) dst[i] = src[i];
-  }
+  csn_fill_lds16(lds, a->wimg, a->wimg_floats >> 2, tid);
   __syncthreads();
 
   const int wave = tid >> 6, lane = tid & 63;

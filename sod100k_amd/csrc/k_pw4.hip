@@ -29,7 +29,8 @@
 // Three-branch units (CSFHead.fuse / fuse1x1, csnet.py:152-206) add a third input x2 at half the resolution of branch l; it
 // is supported by the single-output forms of the kernel: NTL = 0 (only y_h: x2 enters through bilinear x4 of the 3x3
 // neighbourhood of the lane's parent pixel, separable three-tap weights that depend on the lane's parity) and NTH = 0 (only
-// y_l: the usual four-tap bilinear x2).  With `red_w` the rows are not stored but reduced to ONE channel
+// y_l: the usual four-tap bilinear x2; this form also takes a fourth input xq at FOUR times the resolution of branch l, through a
+// 4x4 max-pool -- CSFHead.fuse's lowest output branch, F.max_pool2d(x, 4, 4) of csnet.py:708-714).  With `red_w` the rows are not stored but reduced to ONE channel
 // red_b + sum_r red_w[r] * PReLU(BN(y_r)) -- cls_layer (csnet.py:306-308,381) riding in fuse1x1's epilogue; the M groups of
 // a tile are then walked by the same wave so that the sum stays in its registers.
 #ifndef PW4_HB
@@ -127,6 +128,29 @@ __device__ __forceinline__ void pw4_x2_channel(const float (&v)[N], const Pw4X2&
   }
 }
 
+// fourth input (low-only form): 4x4 max-pool of a tensor at four times the resolution of branch l; o = byte offset of
+// (4 y, 4 x) inside a channel plane (16-byte aligned: W is a multiple of 4 there), ws = its row pitch in bytes
+template <int QB, typename AT>
+__device__ __forceinline__ void pw4_load_xq(csn_buf rb, unsigned o, unsigned ws, unsigned cs, int c0, int C, float4 (&v)[QB][4]) {
+#pragma unroll
+  for (int j = 0; j < QB; ++j) {
+    const unsigned so = (unsigned)min(c0 + j, C - 1) * cs;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[j][r] = csn_bufacc<AT>::ld4(rb, o + (unsigned)r * ws, so);
+  }
+}
+template <int NTL, int P>
+__device__ __forceinline__ void pw4_xq_channel(const float4 (&v)[4], const float* wk, csn_f4 (&accl)[NTL > 0 ? NTL : 1]) {
+  constexpr int NT4 = (NTL + 3) & ~3;
+  Pw4A<NT4> a;
+  pw4_load_a<NT4, P>(wk, a);
+  float m = fmaxf(fmaxf(v[0].x, v[0].y), fmaxf(v[0].z, v[0].w));
+#pragma unroll
+  for (int r = 1; r < 4; ++r) m = fmaxf(m, fmaxf(fmaxf(v[r].x, v[r].y), fmaxf(v[r].z, v[r].w)));
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) pw4_mfma<NT4>(a, t, m, accl[t]);
+}
+
 }  // namespace
 
 // MODE 0: BN + PReLU epilogue, rows stored; 1 (RAW): plain sums stored; 2 (RED): BN + PReLU, rows reduced with red_w
@@ -144,12 +168,7 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
   CSN_DYN_SMEM(float, lds);
   const CSN_CONST_AS Pw4Args* a = CSN_KERNARG(Pw4Args, a_byval);
   const int tid = threadIdx.x;
-  {
-    const float4* __restrict__ src = reinterpret_cast<const float4*>(a->wimg);
-    float4* dst = reinterpret_cast<float4*>(lds);
-    const int n4 = (a->ngroups * a->gimg_floats) >> 2;
-    for (int i = tid; i < n4; i += CSN_BLOCK) dst[i] = src[i];
-  }
+  csn_fill_lds16(lds, a->wimg, (a->ngroups * a->gimg_floats) >> 2, tid);
   __syncthreads();
   const int lane = tid & 63, wave = pw4_uniform(tid >> 6);
   const int CH = a->CH, CL = a->CL, Hl = a->Hl, Wl = a->Wl, Wh = 2 * Wl;
@@ -301,6 +320,46 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
 #pragma unroll
       for (int j = 0; j < XB; ++j)
         if (c + j < C2) pw4_x2_channel<NTH, NTL, P, NX2>(xA[j], g2, wg2 + (c + j) * 4 * P, acch, accl);
+    }
+
+    // ---- fourth input (low-only form): 4x4 max-pool of xq, two channels per step ----
+    if (NTH == 0 && a->CQ > 0) {
+      constexpr int QB = 2;
+      const int CQ = a->CQ;
+      const unsigned csq = csl * 16u, wsq = (unsigned)(4 * Wl) * E;
+      const csn_buf rbq = csn_make_buf_n(reinterpret_cast<const char*>(a->xq) + (int64_t)b * CQ * (int64_t)csq, (unsigned)CQ * csq);
+      const unsigned oq = (unsigned)((4 * yc) * (4 * Wl) + 4 * xc) * E;
+      const float* wgq = wgl + (CL + C2) * 4 * P;
+      float4 qA[QB][4], qB[QB][4];
+      pw4_load_xq<QB, AT>(rbq, oq, wsq, csq, 0, CQ, qA);
+      PW4_FENCE();
+      const int nfq = (CQ - 1) / QB;
+      int c = 0;
+      for (int p = 0; p < (nfq >> 1); ++p) {
+        pw4_load_xq<QB, AT>(rbq, oq, wsq, csq, c + QB, CQ, qB);
+        PW4_FENCE();
+#pragma unroll
+        for (int j = 0; j < QB; ++j) pw4_xq_channel<NTL, P>(qA[j], wgq + (c + j) * 4 * P, accl);
+        pw4_load_xq<QB, AT>(rbq, oq, wsq, csq, c + 2 * QB, CQ, qA);
+        PW4_FENCE();
+#pragma unroll
+        for (int j = 0; j < QB; ++j) pw4_xq_channel<NTL, P>(qB[j], wgq + (c + QB + j) * 4 * P, accl);
+        c += 2 * QB;
+      }
+      if (nfq & 1) {
+        pw4_load_xq<QB, AT>(rbq, oq, wsq, csq, c + QB, CQ, qB);
+        PW4_FENCE();
+#pragma unroll
+        for (int j = 0; j < QB; ++j) pw4_xq_channel<NTL, P>(qA[j], wgq + (c + j) * 4 * P, accl);
+        c += QB;
+#pragma unroll
+        for (int j = 0; j < QB; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) qA[j][r] = qB[j][r];
+      }
+#pragma unroll
+      for (int j = 0; j < QB; ++j)
+        if (c + j < CQ) pw4_xq_channel<NTL, P>(qA[j], wgq + (c + j) * 4 * P, accl);
     }
 
     // ---- epilogue: folded BN + PReLU, the accumulators are the store registers.  Row tiles past the group's list (an

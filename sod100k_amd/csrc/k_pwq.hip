@@ -50,12 +50,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 16 * NT <= 96 ? 3 : 2) void pwq_kernel(P
   CSN_DYN_SMEM(float, lds);
   const CSN_CONST_AS PwqArgs* a = CSN_KERNARG(PwqArgs, a_byval);
   const int tid = threadIdx.x;
-  {
-    const float4* __restrict__ src = reinterpret_cast<const float4*>(a->wimg);
-    float4* dst = reinterpret_cast<float4*>(lds);
-    const int n4 = (a->ngroups * a->gimg_floats) >> 2;
-    for (int i = tid; i < n4; i += CSN_BLOCK) dst[i] = src[i];
-  }
+  csn_fill_lds16(lds, a->wimg, (a->ngroups * a->gimg_floats) >> 2, tid);
   __syncthreads();
   const int lane = tid & 63, wave = pw4_uniform(tid >> 6);
   const int hw = a->HW, nq = hw >> 2;                 // elements / lane quads per plane

@@ -156,3 +156,23 @@ def test_bf16_option_needs_training_buffers(emu_lib, x2_manifest):
     with pytest.raises(RuntimeError):
         eng.forward_train(x, m._arena.flat, [0.0] * (len(m.describe(m._arena.offsets)[0]) * N.MAX_BRANCH),
                           torch.zeros(1, dtype=torch.float64))
+
+
+def test_emu_fuse_lowest_branch_both_routes(emu_lib, x2_manifest, monkeypatch):
+    """CSFHead.fuse's lowest output branch (W_22 x2 + W_21 maxpool2(x1) + W_20 maxpool4(x0), csnet.py:708-714) runs on
+    pw4_kernel's low-only form with the 4x4-pooled fourth input; CSN_PW4_NOQ keeps it on goct_pw_kernel.  Both against
+    the oracle, and the launch census says which one ran."""
+    x = torch.from_numpy(I.randn_batch(11, 2, 32, 64))
+    census = {}
+    for noq in (False, True):
+        if noq:
+            monkeypatch.setenv("CSN_PW4_NOQ", "1")
+        m, sd = P.make_model(emu_lib, x2_manifest, CPU)
+        y = m(x)
+        ref = P.oracle_forward(x2_manifest, sd, x)
+        assert (y - ref).abs().max().item() <= P.TOL
+        eng = m.engine_for(x)
+        eng.profile(x, iters=1)
+        census[noq] = {k: v[1] for k, v in eng.kernel_stats().items()}
+    assert census[False]["pw4_kernel"] == census[True]["pw4_kernel"] + 1, census
+    assert census[False].get("goct_pw_kernel", 0) == census[True].get("goct_pw_kernel", 0) - 1, census
