@@ -654,6 +654,8 @@ int plan_pw4(Builder& bl, UnitPlan& u, const int* ci_off, const int* co_off, int
   bool ok = true;
   if (d.n_in == 2) {
     if (d.n_out > 2) return CSN_OK;
+    // (a launch per output branch, so that each resampling is done once instead of once per M group, was measured and is
+    // slower on every map: profiles/r3_notes.md)
     ok = plan_pw4_launch(bl, u, ci_off, co_off, cin_tot, 0, (d.n_out >= 2 && d.cout[1] > 0) ? 1 : -1, 0) == 0;
   } else {   // CSFHead.fuse / fuse1x1: one single-output launch per output branch 0 / 1, the lowest branch stays where it was
     const int x2 = d.cin[2] > 0 ? 1 : 0;

@@ -14,6 +14,12 @@
 
 #include "csn_kernels.h"
 
+#ifdef CSN_CPU_EMU
+#define CSN_SCHED_FENCE()
+#else
+#define CSN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 __device__ __forceinline__ unsigned ms_tap_mask(int y, int x, int H, int W, int dil) {
   unsigned vm = 0;
 #pragma unroll
@@ -208,12 +214,190 @@ __global__ __launch_bounds__(CSN_BLOCK) void msq_kernel(MsArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// msr_kernel: msq_kernel with vertical reuse.  A lane of msq_kernel loads 9 pieces per channel for one quad of pixels and no
+// piece is used twice (the taps of a dilated window do not overlap); the launch is bound by the number of tap loads going
+// through L1 (profiles/r3_notes.md).  Here a lane owns R quads in rows y0, y0 + d, ..., y0 + (R - 1) d of one column block:
+// the rows y0 - d .. y0 + R d serve all of them -- 3 (R + 2) piece loads per channel for R quads instead of 9 R (R = 4: half,
+// for launches with <= 3 output channels per dilation; R = 2: two thirds, <= 8 output channels, there with the next channel's
+// rows in flight during the FMAs -- few waves per SIMD on the 56^2 map).  Measured alternatives (R = 6, 8; two pixels per
+// lane; double buffering with R = 4): profiles/r3_notes.md.  Lanes of one (image, dilation): x quads
+// fastest, then the d row residues, then the groups of R d rows; items are WAVES (64 lanes of one image and dilation), all
+// waves of an image on one XCD.
+template <int DC, int R>
+__device__ __forceinline__ void msr_load(csn_buf rb, const unsigned (&ro)[R + 2], unsigned dl, unsigned dr, unsigned so,
+                                         float (&v)[R + 2][12]) {
+#pragma unroll
+  for (int r = 0; r < R + 2; ++r) {
+    if (DC == 4) {
+      const float4 l = csn_ld4(rb, ro[r] + dl, so), c = csn_ld4(rb, ro[r], so), rr = csn_ld4(rb, ro[r] + dr, so);
+      v[r][0] = l.x; v[r][1] = l.y; v[r][2] = l.z; v[r][3] = l.w;
+      v[r][4] = c.x; v[r][5] = c.y; v[r][6] = c.z; v[r][7] = c.w;
+      v[r][8] = rr.x; v[r][9] = rr.y; v[r][10] = rr.z; v[r][11] = rr.w;
+    } else {
+      const float2 l = csn_ld2(rb, ro[r] + dl, so), rr = csn_ld2(rb, ro[r] + dr, so);
+      const float4 c = csn_ld4(rb, ro[r], so);
+      v[r][0] = 0.f; v[r][1] = 0.f; v[r][2] = l.x; v[r][3] = l.y;
+      v[r][4] = c.x; v[r][5] = c.y; v[r][6] = c.z; v[r][7] = c.w;
+      v[r][8] = rr.x; v[r][9] = rr.y; v[r][10] = 0.f; v[r][11] = 0.f;
+    }
+  }
+}
+
+template <int NCO, int DC, int R>
+__device__ __forceinline__ void msr_fma(const float (&v)[R + 2][12], csn_cfp wc, float (&acc)[R][NCO][4]) {
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int tr = t / 3, dx = t % 3 - 1;
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) {
+      const float w = wc[t * 8 + co];
+#pragma unroll
+      for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[i][co][p] = fmaf(w, v[i + tr][4 + DC * dx + p], acc[i][co][p]);
+    }
+  }
+}
+
+template <int NCO, int DC, int R, bool DB>
+__device__ __forceinline__ void msr_group(const MsArgs& a, csn_buf rb, const unsigned (&ro)[R + 2], unsigned dl, unsigned dr,
+                                          unsigned cs4, int cinp, csn_cfp wg, float* __restrict__ op, int hw, int rstride, int g,
+                                          int d, const bool (&st)[R]) {
+  float acc[R][NCO][4];
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+#pragma unroll
+    for (int co = 0; co < NCO; ++co)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) acc[i][co][p] = 0.f;
+  const int cin = a.cin;
+  if (DB) {   // channel c + 1 in flight while channel c is contracted (two register sets)
+    float vA[R + 2][12], vB[R + 2][12];
+    msr_load<DC, R>(rb, ro, dl, dr, 0u, vA);
+    CSN_SCHED_FENCE();
+    for (int ci = 0; ci < cin; ci += 2) {
+      msr_load<DC, R>(rb, ro, dl, dr, (unsigned)min(ci + 1, cin - 1) * cs4, vB);
+      CSN_SCHED_FENCE();
+      msr_fma<NCO, DC, R>(vA, wg + ci * 72, acc);
+      msr_load<DC, R>(rb, ro, dl, dr, (unsigned)min(ci + 2, cin - 1) * cs4, vA);
+      CSN_SCHED_FENCE();
+      if (ci + 1 < cin) msr_fma<NCO, DC, R>(vB, wg + (ci + 1) * 72, acc);
+    }
+  } else {
+    for (int ci = 0; ci < cin; ++ci) {
+      float v[R + 2][12];
+      msr_load<DC, R>(rb, ro, dl, dr, (unsigned)ci * cs4, v);
+      msr_fma<NCO, DC, R>(v, wg + ci * 72, acc);
+    }
+  }
+  csn_cfp scale = csn_const(a.scale), shift = csn_const(a.shift), alpha = csn_const(a.alpha);
+#pragma unroll
+  for (int co = 0; co < NCO; ++co) {
+    const int oc = a.cobase[d] + g * 8 + co;
+    const float sc = scale[oc], shf = shift[oc], al = alpha[oc];
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+      if (st[i]) {
+        float* q = op + (int64_t)oc * hw + (int64_t)i * rstride;
+        *reinterpret_cast<float4*>(q) = make_float4(csn_epi(acc[i][co][0], sc, shf, al), csn_epi(acc[i][co][1], sc, shf, al),
+                                                    csn_epi(acc[i][co][2], sc, shf, al), csn_epi(acc[i][co][3], sc, shf, al));
+      }
+  }
+}
+
+// waves per (image, dilation): QW column quads x 2^d row residues x groups of R 2^d rows
+__host__ __device__ inline int msr_waves(int H, int QW, int d, int R) {
+  const int span = R << d;
+  return (QW * (((H + span - 1) / span) << d) + 63) >> 6;
+}
+
+template <int R, bool DB>
+__global__ __launch_bounds__(CSN_BLOCK) void msr_kernel(MsArgs a) {
+  const int H = a.H, W = a.W, QW = W >> 2;
+  const int hw = H * W;
+  int wmax = 0;
+#pragma unroll
+  for (int dd = 0; dd < 5; ++dd)
+    if (a.dch[dd] > 0) wmax = max(wmax, msr_waves(H, QW, dd, R));
+  const int bpi = (5 * wmax + 3) >> 2;                 // blocks per image
+  const int slot = blockIdx.x >> 3;
+  const int b = (slot / bpi) * 8 + (int)(blockIdx.x & 7);
+  if (b >= a.B) return;
+#ifdef CSN_CPU_EMU
+  const int wave = (int)threadIdx.x >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#endif
+  const int w = (slot % bpi) * 4 + wave;
+  const int d = w / wmax, wv = w - d * wmax;
+  if (d >= 5) return;
+  const int nco = a.dch[d];
+  if (nco == 0 || wv >= msr_waves(H, QW, d, R)) return;
+  const int dil = 1 << d, span = R << d;
+  const int idx = wv * 64 + ((int)threadIdx.x & 63);
+  const int xq = idx % QW, rest = idx / QW;
+  const int y0 = (rest >> d) * span + (rest & (dil - 1));
+  const int x0 = 4 * xq;
+  const bool valid = y0 < H;   // (rows past the last group: lanes idle)
+  const csn_buf rb = csn_make_buf_n(a.in + (int64_t)b * a.cin * hw, (unsigned)(a.cin * hw) * 4u);
+  unsigned ro[R + 2];
+#pragma unroll
+  for (int r = 0; r < R + 2; ++r) {
+    const int yy = y0 + (r - 1) * dil;
+    ro[r] = (valid && yy >= 0 && yy < H) ? (unsigned)(yy * W + x0) * 4u : 0x80000000u;
+  }
+  bool st[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) st[i] = valid && y0 + i * dil < H;
+  // left / right piece: a quad at x0 -+ dil (dil >= 4), else the two columns next to the quad
+  const int step = dil >= 4 ? dil : 2, rstep = dil >= 4 ? dil : 4;
+  const int rlast = dil >= 4 ? 3 : 1;   // last column of the right piece
+  const unsigned dl = x0 - step >= 0 ? (unsigned)(-step * 4) : 0x40000000u;
+  const unsigned dr = x0 + rstep + rlast < W ? (unsigned)(rstep * 4) : 0x40000000u;
+  float* __restrict__ op = a.out + (int64_t)b * a.cout * hw + (int64_t)(valid ? y0 : 0) * W + x0;
+  const int cinp = (a.cin + 1) & ~1;
+  const int ngrp = (nco + 7) >> 3;
+  for (int g = 0; g < ngrp; ++g) {
+    csn_cfp wg = csn_const(a.w[d]) + (int64_t)g * cinp * 72;
+    const int live = min(8, nco - 8 * g);
+#define MSR_ARGS a, rb, ro, dl, dr, (unsigned)hw * 4u, cinp, wg, op, hw, dil * W, g, d, st
+#define MSR_CASE(N)                                                                \
+  case N:                                                                           \
+    if (d == 0) msr_group<N, 1, R, DB>(MSR_ARGS);                               \
+    else if (d == 1) msr_group<N, 2, R, DB>(MSR_ARGS);                          \
+    else msr_group<N, 4, R, DB>(MSR_ARGS);                                      \
+    break;
+    if (R > 2) {
+      switch (live) { MSR_CASE(1) MSR_CASE(2) default: MSR_CASE(3) }
+    } else {
+      switch (live) { MSR_CASE(1) MSR_CASE(2) MSR_CASE(3) MSR_CASE(4) MSR_CASE(5) MSR_CASE(6) MSR_CASE(7) default: MSR_CASE(8) }
+    }
+#undef MSR_CASE
+#undef MSR_ARGS
+  }
+}
+
 int csn_launch_ms(const MsArgs& a, void* stream) {
   const int hw = a.H * a.W;
   static const bool quad = !(std::getenv("CSN_MS_QUAD") && std::getenv("CSN_MS_QUAD")[0] == '0');
+  static const int rows = std::getenv("CSN_MS_ROWS") ? std::atoi(std::getenv("CSN_MS_ROWS")) : 1;   // 0: msq_kernel
   // four pixels per lane (float, rows of whole quads); small maps keep one pixel per lane (28^2 x 64 images is 320 blocks of
   // quads: 42 us against 29 us, profiles/r3_notes.md)
   if (quad && !a.a16 && (a.W & 3) == 0 && a.H * (a.W >> 2) >= 512) {
+    int mx = 0;
+    for (int d = 0; d < 5; ++d) mx = a.dch[d] > mx ? a.dch[d] : mx;
+    if (rows > 0) {   // R quads per lane in dilation-strided rows (profiles/r3_notes.md: 94 -> 68 us, 62 -> 57 us)
+      const int R = mx <= 3 ? 4 : 2;
+      int wmax = 0;
+      for (int d = 0; d < 5; ++d)
+        if (a.dch[d] > 0) { const int wv = msr_waves(a.H, a.W >> 2, d, R); wmax = wv > wmax ? wv : wmax; }
+      const int bpi = (5 * wmax + 3) >> 2;
+      const dim3 grid((unsigned)(((a.B + 7) / 8) * bpi * 8));
+      if (R == 4) CSN_LAUNCH((msr_kernel<4, false>), grid, dim3(CSN_BLOCK), 0, stream, a);
+      else CSN_LAUNCH((msr_kernel<2, true>), grid, dim3(CSN_BLOCK), 0, stream, a);
+      return (int)hipGetLastError();
+    }
     const int tq = ((a.H * (a.W >> 2) + CSN_BLOCK - 1) / CSN_BLOCK) * a.B;
     CSN_LAUNCH(msq_kernel, dim3((unsigned)(((tq + 7) / 8) * 5 * 8)), dim3(CSN_BLOCK), 0, stream, a);
     return (int)hipGetLastError();
