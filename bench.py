@@ -321,12 +321,22 @@ def main():
             tdt = D.timed_region(tstep, args.train_steps, sync=sync, device=dev)
             t_alg = train_algorithmic_bytes(model) // 4 * esz * TB if not emu else 0
             t_bw = t_alg / (tdt / args.train_steps) / 1e9
+            # HBM traffic of one step: the committed counter passes (tools/gpu_pmc_train.sh), not a quantity of this run
+            t_traffic = t_src = None
+            try:
+                pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_train_latest.json")))
+                if TB == 256 and act_dtype in pj:
+                    t_traffic = int(pj[act_dtype]["hbm_bytes_per_step"])
+                    t_src = "profiles/pmc_train_latest.json: " + pj.get("_source", "")
+            except Exception:
+                pass
             rec = {"value": round(world * TB * args.train_steps / tdt, 1), "unit": "images/sec",
                    "ms_per_step": round(tdt / args.train_steps * 1e3, 3), "steps": args.train_steps,
                    "batch_per_gpu": TB, "dtype": "f32" if esz == 4 else "bf16 activations, f32 arithmetic / parameters / optimizer",
                    "loss": round(float(tr.loss), 6),
                    "roofline": {"bound": "hbm", "achieved": round(t_bw, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(t_bw / HBM_PEAK_GBS, 4), "bytes_per_step": int(t_alg),
+                                "traffic": t_traffic, "traffic_source": t_src,
                                 "what": f"algorithmic (3*in + 7*out) x {esz} B per unit (SURVEY 8(d)) / whole-step time"},
                    "what": "train-mode forward (batch-stat BN + penalty) + BCE + backward + "
                            + ("RCCL all-reduce of the flat gradient + " if world > 1 else "") + "Adam, csnet-L-x2 weights"}
