@@ -180,7 +180,7 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
   const int tiles_xy = a->tiles_x * a->tiles_y;
   const int nitems = tiles_xy * a->B * ng;
   constexpr int NX2 = NTL == 0 ? 9 : 4;      // taps per channel of the third input
-  constexpr int XB = NTL == 0 ? 1 : 4;       // ... and channels per step
+  constexpr int XB = NTL == 0 ? 1 : 4;       // ... and channels per step (high-only forms: 2 / 4 per step measured, no gain)
   // XCD-aware order (see k_goct_pw.hip): XCD x = blockIdx.x & 7 walks the contiguous item range [x * chunk, (x + 1) * chunk)
   const int nslot = (int)(gridDim.x >> 3) * 4;
   const int chunk = (((nitems + 7) >> 3) + ng - 1) / ng * ng;   // whole tiles per XCD
