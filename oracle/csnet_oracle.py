@@ -120,7 +120,24 @@ class _RoundBF16(torch.autograd.Function):
         return g.to(torch.bfloat16).to(g.dtype)
 
 
+class _RoundBF16Fwd(torch.autograd.Function):
+    """Stored as bfloat16 on the way forward only: the gradient w.r.t. this tensor is consumed where it is formed and never
+    goes to memory (HIP path: dz of a depthwise unit, formed on load inside dw3x3_bwd_kernel since round 3)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 _ACT_BF16 = False
+# bf16 storage emulation: is dz of a depthwise unit a stored tensor?  False = the HIP default (one-pass depthwise backward with
+# the BatchNorm backward's apply step fused in); tests that force the two-pass fallback (CSN_DW_BWD_SPLIT, CSN_BN_BWD_FUSE=0)
+# set it to True.
+DW_DZ_STORED = False
 Z_CAPTURE = None     # tests: set to a list to collect every BatchNorm input (the raw conv outputs z) in call order
 # tests (unit-local train checks): PReLU has a kink at 0, so a pre-activation that is zero to within fp32 rounding may
 # legitimately take either branch on the device.  PRELU_Y: set to a list to collect every pre-activation (BatchNorm output) in
@@ -181,9 +198,14 @@ def goct_conv(xs, weight, alpha_in, alpha_out, stride, padding):
     return [sum(v) if len(v) else None for v in ysets]     # python sum: 0 + y0 + y1 (:720-722)
 
 
-def bn_prelu(x, sd, bn_prefix, prelu_key, training):
+def bn_prelu(x, sd, bn_prefix, prelu_key, training, dz_stored=True):
     """nn.BatchNorm2d (eps 1e-5, momentum 0.1) followed by per-channel nn.PReLU."""
-    x = _st(x)       # the raw conv output z is a stored tensor (statistics are taken from what was stored)
+    # the raw conv output z is a stored tensor (statistics are taken from what was stored); so is its gradient dz, except
+    # where the consumer forms it on load (dz_stored False)
+    if dz_stored or not _ACT_BF16:
+        x = _st(x)
+    else:
+        x = _RoundBF16Fwd.apply(x)
     if Z_CAPTURE is not None:
         Z_CAPTURE.append(x)
     y = F.batch_norm(x, sd[bn_prefix + ".running_mean"], sd[bn_prefix + ".running_var"],
@@ -227,7 +249,7 @@ def simplified_cbr(xs, sd, prefix, training):
             continue
         w = sd[f"{prefix}.convs.{i}.weight"]
         y = F.conv2d(x, 100.0 * w, None, 1, 1, 1, w.shape[0])          # conv2d.py:104
-        ys.append(bn_prelu(y, sd, f"{prefix}.bns.{i}", f"{prefix}.prelus.{i}.weight", training))
+        ys.append(bn_prelu(y, sd, f"{prefix}.bns.{i}", f"{prefix}.prelus.{i}.weight", training, dz_stored=DW_DZ_STORED))
     return ys
 
 

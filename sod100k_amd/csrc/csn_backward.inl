@@ -453,7 +453,8 @@ int run_wgrad(const BwdCtx& b, const WgPlan& w, const PwBind& bd) {
   return CSN_OK;
 }
 
-int run_bn_bwd(const BwdCtx& b, int ui, const UnitPlan& u, int j) {
+// skip_apply: reduce + finalise only (the unit's depthwise backward forms dz on load); keep: the arguments, for that kernel
+int run_bn_bwd(const BwdCtx& b, int ui, const UnitPlan& u, int j, bool skip_apply = false, BnBwdArgs* keep = nullptr) {
   const csn_plan& P = b.c.P;
   const csn_unit_desc& d = u.d;
   const int act = d.out_act[j];
@@ -474,8 +475,17 @@ int run_bn_bwd(const BwdCtx& b, int ui, const UnitPlan& u, int j) {
   a.flop_w = b.flop_w[ui * CSN_MAX_BRANCH + j];
   a.pen_scale = b.pen_scale;
   a.a16 = b.c.a16 ? 1 : 0;
+  a.skip_apply = skip_apply ? 1 : 0;
   LAUNCH_TRY(csn_launch_bn_bwd(a, b.c.stream));
+  if (keep) *keep = a;
   return CSN_OK;
+}
+
+// depthwise unit, branch k: input and weight gradient in ONE pass over dz and x (dw3x3_bwd_kernel) -- when both are wanted and
+// the per-(image, tile) partials fit the reduction table; not on the weight-gradient side lane (the fused kernel also writes the
+// input gradient that the NEXT unit's backward on the caller's stream reads)
+int dw_fused_slabs(const csn_plan& P, const UnitBwd& ub, int k, int lvl, bool side) {
+  return (ub.need_dx[k] && !side && !std::getenv("CSN_DW_BWD_SPLIT")) ? dw_stats_slabs(P, lvl) : 0;
 }
 
 int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
@@ -487,6 +497,8 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
   const int S = P.S;
   char* scratch = c.ws + P.scratch_off;
   PwBind bd;
+  BnBwdArgs bnargs[CSN_MAX_BRANCH];
+  bool bn_fused[CSN_MAX_BRANCH] = {false, false, false};
   if (d.kind == CSN_UNIT_CLS) {
     float* dlh = reinterpret_cast<float*>(c.ws + u.logits_off);   // gradient of the half-resolution logits
     AdjUpArgs ua;
@@ -500,8 +512,13 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
   } else {
     for (int j = 0; j < d.n_out; ++j) {
       if (d.cout[j] == 0) continue;
-      const int st = run_bn_bwd(b, ui, u, j);
+      // depthwise units on the one-pass backward kernel: that kernel forms dz on load, the apply pass is skipped (round 3)
+      bool fuse_apply = false;
+      if (d.kind == CSN_UNIT_DW && P.bn_bwd_fuse)
+        fuse_apply = dw_fused_slabs(P, ub, j, P.acts[d.in_act[j]].lvl, c.lanes) > 0;
+      const int st = run_bn_bwd(b, ui, u, j, fuse_apply, &bnargs[j]);
       if (st != CSN_OK) return st;
+      bn_fused[j] = fuse_apply;
       bd.dz[j] = reinterpret_cast<const float*>(c.ws + P.tz_off[d.out_act[j]]);
     }
     for (int i = 0; i < d.n_in; ++i) {
@@ -541,16 +558,19 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
       w.a16 = c.a16 ? 1 : 0;
       w.dz = bd.dz[k]; w.x = bd.in[k]; w.partial = reinterpret_cast<double*>(c.ws + (cs.side ? P.red2_off : P.red_off)); w.grad = b.grad;
       w.off_w = d.w_off[k]; w.C = d.cout[k]; w.S = S; w.H = H; w.W = W; w.nslab = 0;
-      // input and weight gradient in ONE pass over dz and x when both are wanted and the per-(image, tile) partials fit
-      // the reduction table; the branches go one after the other (they share the partial buffer)
-      // (not on the weight-gradient side lane: the fused kernel also writes the input gradient the NEXT unit's backward on
-      // the caller's stream reads -- there the split path keeps dx on the main lane)
-      const int fslabs = (ub.need_dx[k] && !cs.side && !std::getenv("CSN_DW_BWD_SPLIT")) ? dw_stats_slabs(P, act.lvl) : 0;
+      // one-pass kernel (see dw_fused_slabs); the branches go one after the other (they share the partial buffer)
+      const int fslabs = dw_fused_slabs(P, ub, k, act.lvl, cs.side);
       if (fslabs > 0) {
         DwArgs f;
         f.nbr = 1; f.B = S; f.a16 = c.a16 ? 1 : 0; f.pad = 0;
         DwBranch& fb = f.br[0];
         fb.in = bd.dz[k]; fb.out = bd.dx[k]; fb.xin = bd.in[k];
+        if (bn_fused[k]) {   // dz from dy and z on load
+          const BnBwdArgs& ba = bnargs[k];
+          fb.in = ba.dyA; fb.dy2 = ba.dyB; fb.zraw = ba.z;
+          fb.bn_scale = ba.scale; fb.bn_shift = ba.shift; fb.bn_alpha = ba.alpha; fb.bn_mean = ba.mean; fb.bn_invstd = ba.invstd;
+          fb.bn_m1m2 = ba.m1m2; fb.bn_gamma = ba.arena + ba.off_weight;
+        }
         fb.w9 = c.pk(ub.dwf_w[k]);
         fb.scale = c.pk(P.ident.scale); fb.shift = c.pk(P.ident.shift); fb.alpha = c.pk(P.ident.alpha);
         fb.w9b = fb.scale_b = fb.shift_b = fb.alpha_b = nullptr;
@@ -564,6 +584,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
         fb.tiles_y = (H + fb.NY * fb.R - 1) / (fb.NY * fb.R);
         fb.blk_end = fb.tiles_x * fb.tiles_y * fb.C * S;
         LAUNCH_TRY(csn_launch_dw_bwd(f, cs.stream));
+        if (bn_fused[k] && P.debug_dz) LAUNCH_TRY(csn_launch_bn_bwd_apply(bnargs[k], cs.stream));   // probes only: dz over z, afterwards
         w.nslab = fslabs;                                   // partials are there: finalise only
         LAUNCH_TRY(csn_launch_dw_wgrad(w, cs.stream));
         continue;

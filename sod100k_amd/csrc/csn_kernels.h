@@ -69,6 +69,19 @@ struct DwBranch {
   int32_t LX, NY, R;          // lanes per row (4 px each), lane rows per block, rows per lane
   int32_t tiles_x, tiles_y;   // tiles per plane
   int32_t blk_end;            // exclusive prefix sum of blocks over branches
+  // dw3x3_bwd_kernel with the BatchNorm backward's apply pass fused in (zraw non-null): `in` is then the gradient w.r.t. the
+  // unit's OUTPUT y from its first consumer, dy2 the second consumer's (null: none), zraw the saved raw conv output, and
+  //   dz = gamma * invstd * (dbn - m1 - (z - mean) * invstd * m2),  dbn = (z * scale + shift > 0 ? 1 : alpha) * (dy + dy2)
+  // is formed per loaded element (exactly bn_bwd_apply_kernel's arithmetic) instead of being written and read back
+  const float* zraw = nullptr;
+  const float* dy2 = nullptr;
+  const float* bn_scale = nullptr;   // train-mode folded tables of the unit's own BatchNorm, [C] each
+  const float* bn_shift = nullptr;
+  const float* bn_alpha = nullptr;
+  const float* bn_mean = nullptr;
+  const float* bn_invstd = nullptr;
+  const float* bn_m1m2 = nullptr;    // [C][2] from bn_bwd_finalize_kernel
+  const float* bn_gamma = nullptr;   // [C] in the parameter arena
 };
 struct DwArgs {
   DwBranch br[3];
@@ -378,8 +391,10 @@ struct BnBwdArgs {
   float pen_scale;     // d loss / d (penalty sum) = FLOPS.WEIGHT / batchsize  (train.py:91,210)
   int32_t nslab, cpp;  // set by the launcher
   int32_t a16;         // dy / z are bfloat16
+  int32_t skip_apply;  // reduce + finalise only: the consumer of dz forms it on load (dw3x3_bwd_kernel, DwBranch::zraw)
 };
 int csn_launch_bn_bwd(const BnBwdArgs& a, void* stream);
+int csn_launch_bn_bwd_apply(const BnBwdArgs& a, void* stream);   // the apply pass alone (debug: materialise dz for the probes)
 
 struct DwWgradArgs {
   const float* dz;

@@ -170,6 +170,8 @@ struct csn_plan {
   int pw4_grid = 2048;    // its block cap (CSN_PW4_GRID, experiments)
   int pw4_twl = 4;        // log2 of its widest tile in low pixels (CSN_PW4_TWL, experiments)
   bool pw4_no_q = false;      // CSN_PW4_NOQ: CSFHead.fuse's lowest output branch stays on goct_pw_kernel (experiments)
+  bool bn_bwd_fuse = true;    // depthwise backward forms dz on load, the BatchNorm backward's apply pass is skipped (CSN_BN_BWD_FUSE=0: off)
+  bool debug_dz = false;      // CSN_DEBUG_DZ: ... and the apply pass still runs AFTER that kernel, so that the probes see dz (tests)
   bool pw4_nosplit = false;   // CSN_PW4_NOSPLIT: no extra M groups on small maps (experiments)
   bool overlap_bwd = false;   // CSN_OPT_OVERLAP value 2: also the weight-gradient side lane of csn_backward
   bool overlap = true;    // CSN_OPT_OVERLAP: independent launches of a unit (and the MSBlocks) on parallel stream lanes
@@ -1409,6 +1411,8 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   if (const char* v = std::getenv("CSN_PW4_GRID")) { if (std::atoi(v) >= 8) P->pw4_grid = std::atoi(v); }
   if (std::getenv("CSN_PW4_NOSPLIT")) P->pw4_nosplit = true;
   if (std::getenv("CSN_PW4_NOQ")) P->pw4_no_q = true;
+  if (const char* v = std::getenv("CSN_BN_BWD_FUSE")) P->bn_bwd_fuse = v[0] != '0';
+  if (const char* v = std::getenv("CSN_DEBUG_DZ")) P->debug_dz = v[0] != '0';
   if (const char* v = std::getenv("CSN_C3Q_NT")) { if (std::atoi(v) >= 1) P->c3q_cap = std::atoi(v); }
   if (const char* v = std::getenv("CSN_PW4_TWL")) { if (std::atoi(v) >= 2 && std::atoi(v) <= 6) P->pw4_twl = std::atoi(v); }
   Builder bl(*P);

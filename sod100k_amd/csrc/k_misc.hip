@@ -253,7 +253,10 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
 // Same tile / lane mapping as dw3x3_bn_prelu_kernel; a lane keeps rolling three-row windows of dz AND of x, so every row of
 // either tensor is loaded once per lane (the stand-alone weight-gradient kernel re-read dz and gathered ten values per quad).
 // The nine per-lane sums (<= 64 terms, fp32) are reduced per block in fp64: one partial per (channel, image, tile).
-template <bool VEC, typename AT>
+// BNF: the BatchNorm backward's apply pass is fused in -- dz is formed per loaded element from dy (+ dy2) and the saved z
+// with the channel's (block-uniform) tables, bit for bit bn_bwd_apply_kernel's arithmetic; rows / columns outside the plane
+// are masked to zero AFTER the formula (z = dy = 0 does not give dz = 0).  Saves the write and the re-read of dz (round 3).
+template <bool VEC, typename AT, bool BNF>
 __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
   CSN_DYN_SMEM(double, sm);
   int bid = blockIdx.x;
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
   for (int t = 0; t < 9; ++t) s[t] = 0.f;
   if (active) {
     const unsigned nb = (unsigned)(H * W) * (unsigned)sizeof(AT);
-    const csn_buf gb = csn_make_buf_n(act_cast<AT>(br.in) + (int64_t)pc * H * W, nb);     // dz
+    const csn_buf gb = csn_make_buf_n(act_cast<AT>(br.in) + (int64_t)pc * H * W, nb);     // dz (BNF: dy of the first consumer)
     const csn_buf xb = csn_make_buf_n(act_cast<AT>(br.xin) + (int64_t)pc * H * W, nb);    // x
     AT* __restrict__ op = act_cast<AT>(br.out) + (int64_t)pc * H * W;
     float w[9];
@@ -286,13 +289,45 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) w[i] = w9[c * 9 + i];
     const bool has_l = x0 > 0, has_r = x0 + 4 < W;
-    DwRow g0 = dw_load_row<VEC, AT>(gb, y0 - 1, x0, W, has_l, has_r);
-    DwRow g1 = dw_load_row<VEC, AT>(gb, y0, x0, W, has_l, has_r);
+    // BNF: the row of dz from dy (+ dy2) and z
+    const bool has2 = BNF && br.dy2 != nullptr;
+    const csn_buf zb = csn_make_buf_n(act_cast<AT>(BNF ? br.zraw : br.in) + (int64_t)pc * H * W, nb);
+    const csn_buf g2b = csn_make_buf_n(act_cast<AT>(has2 ? br.dy2 : br.in) + (int64_t)pc * H * W, nb);
+    float bsc = 0.f, bsh = 0.f, bal = 0.f, bmu = 0.f, bis = 0.f, bm1 = 0.f, bm2 = 0.f, bgi = 0.f;
+    if (BNF) {
+      bsc = csn_const(br.bn_scale)[c]; bsh = csn_const(br.bn_shift)[c]; bal = csn_const(br.bn_alpha)[c];
+      bmu = csn_const(br.bn_mean)[c]; bis = csn_const(br.bn_invstd)[c];
+      bm1 = csn_const(br.bn_m1m2)[2 * c]; bm2 = csn_const(br.bn_m1m2)[2 * c + 1];
+      bgi = csn_const(br.bn_gamma)[c] * bis;
+    }
+    auto load_g = [&](int y) {
+      DwRow g = dw_load_row<VEC, AT>(gb, y, x0, W, has_l, has_r);
+      if (BNF) {
+        const DwRow z = dw_load_row<VEC, AT>(zb, y, x0, W, has_l, has_r);
+        if (has2) {
+          const DwRow e = dw_load_row<VEC, AT>(g2b, y, x0, W, has_l, has_r);
+#pragma unroll
+          for (int i = 0; i < 6; ++i) g.v[i] += e.v[i];
+        }
+        const bool rowin = y >= 0 && y < H;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const float bn = z.v[i] * bsc + bsh;
+          const float dbn = bn > 0.f ? g.v[i] : bal * g.v[i];
+          const float dzv = bgi * (dbn - bm1 - (z.v[i] - bmu) * bis * bm2);
+          const bool colin = i == 0 ? has_l : (i == 5 ? has_r : (VEC || x0 + i - 1 < W));
+          g.v[i] = (rowin && colin) ? dzv : 0.f;
+        }
+      }
+      return g;
+    };
+    DwRow g0 = load_g(y0 - 1);
+    DwRow g1 = load_g(y0);
     DwRow u0 = dw_load_row<VEC, AT>(xb, y0 - 1, x0, W, has_l, has_r);
     DwRow u1 = dw_load_row<VEC, AT>(xb, y0, x0, W, has_l, has_r);
     const int yend = min(y0 + br.R, H);
     for (int y = y0; y < yend; ++y) {
-      const DwRow g2 = dw_load_row<VEC, AT>(gb, y + 1, x0, W, has_l, has_r);
+      const DwRow g2 = load_g(y + 1);
       const DwRow u2 = dw_load_row<VEC, AT>(xb, y + 1, x0, W, has_l, has_r);
       dw_emit<VEC, AT>(op, y, yend, x0, W, w, 1.f, 0.f, 1.f, g0, g1, g2);
 #pragma unroll
@@ -324,14 +359,23 @@ int csn_launch_dw_bwd(const DwArgs& a, void* stream) {
   bool vec = true;
   for (int k = 0; k < a.nbr; ++k) vec = vec && (a.br[k].W % 4 == 0);
   const size_t sml = CSN_BLOCK * sizeof(double);
+  bool bnf = a.br[0].zraw != nullptr;   // (all branches of a launch alike)
+  for (int k = 1; k < a.nbr; ++k)
+    if ((a.br[k].zraw != nullptr) != bnf) return 1;
+#define DWB_LAUNCH(V, T)                                                                                  \
+  do {                                                                                                   \
+    if (bnf) CSN_LAUNCH((dw3x3_bwd_kernel<V, T, true>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);    \
+    else CSN_LAUNCH((dw3x3_bwd_kernel<V, T, false>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);       \
+  } while (0)
   if (a.a16) {
-    if (vec) CSN_LAUNCH((dw3x3_bwd_kernel<true, csn_bf16>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);
-    else CSN_LAUNCH((dw3x3_bwd_kernel<false, csn_bf16>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);
+    if (vec) DWB_LAUNCH(true, csn_bf16);
+    else DWB_LAUNCH(false, csn_bf16);
   } else if (vec) {
-    CSN_LAUNCH((dw3x3_bwd_kernel<true, float>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);
+    DWB_LAUNCH(true, float);
   } else {
-    CSN_LAUNCH((dw3x3_bwd_kernel<false, float>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);
+    DWB_LAUNCH(false, float);
   }
+#undef DWB_LAUNCH
   return (int)hipGetLastError();
 }
 

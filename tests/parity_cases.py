@@ -346,6 +346,33 @@ def check_train_step(lib, device, manifest, B=2, size=32, expandflop=1.0, flops_
     return worst, float(loss), float(pen) / B
 
 
+def check_bn_bwd_fusion_bit_identical(lib, device, manifest, B=2, size=32, act_dtype="fp32", seed=23):
+    """The depthwise backward with the BatchNorm backward's apply pass fused in (dz formed on load) against the two-pass
+    scheme (CSN_BN_BWD_FUSE=0: dz written by bn_bwd_apply_kernel, then read): the same arithmetic per element, so in fp32
+    every gradient is bit-identical; with bfloat16 storage the fused path skips one rounding of dz (close, not equal)."""
+    flats = []
+    for fuse in ("1", "0"):
+        os.environ["CSN_BN_BWD_FUSE"] = fuse
+        try:
+            m, _ = make_model(lib, manifest, device)
+            m.set_train_act_dtype(act_dtype)
+            m.train(); m.set_batchsize(B); m.clear_flops(); m.flops_hook(1.0)
+            x = torch.from_numpy(I.randn_batch(seed, B, size, size)).to(device)
+            t = torch.from_numpy(I.binary_target(seed + 1, B, size, size)).to(device)
+            y, pen = m._train_forward_raw(x)
+            loss, dy = bce_and_grad(m._lib or N.load(), y, t)
+            flats.append(m._train_backward_raw(x, dy, 3.0 / B).cpu().clone())
+        finally:
+            del os.environ["CSN_BN_BWD_FUSE"]
+    a, b = flats
+    if act_dtype == "fp32":
+        assert torch.equal(a, b), f"max-abs {float((a - b).abs().max()):.3e}"
+        return 0.0
+    rel = float((a.double() - b.double()).norm() / b.double().norm())
+    assert rel < 5e-2, rel
+    return rel
+
+
 def check_train_golden_step(lib, device, manifest, idx):
     """G5: gradients and parameters after ONE full train step of the reference itself (B=4, 224x224, seeds 10/11,
     FLOPS.WEIGHT 3, Adam lr 1e-4 / wd 5e-3 with the two parameter groups)."""
@@ -628,6 +655,18 @@ def _rel(a, b):
 def check_train_units_local(lib, device, manifest, B=2, size=64, act_dtype="bf16", state="shipped", flops_weight=3.0,
                             tol_fwd=None, tol_bwd=None, seed=51):
     """Returns the worst relative L2 deviations {z, act, dz, dx, dparam} over all units."""
+    import contextlib
+    bf16 = act_dtype == "bf16"
+    # the depthwise backward forms dz on load and skips the BatchNorm backward's apply pass; CSN_DEBUG_DZ (read at plan creation)
+    # lets that pass run AFTER the fused kernel so that the dz probes below exist -- the kernel under test is the product's
+    os.environ["CSN_DEBUG_DZ"] = "1"
+    try:
+        return _check_train_units_local(lib, device, manifest, B, size, act_dtype, state, flops_weight, tol_fwd, tol_bwd, seed)
+    finally:
+        del os.environ["CSN_DEBUG_DZ"]
+
+
+def _check_train_units_local(lib, device, manifest, B, size, act_dtype, state, flops_weight, tol_fwd, tol_bwd, seed):
     import contextlib
     bf16 = act_dtype == "bf16"
     # bf16: one rounding of the output (2^-9 rms) + rare flips of rounded inputs; fp32: summation order only

@@ -111,6 +111,8 @@ def test_emu_train_units_local_fallback_paths(emu_lib, x2_manifest, monkeypatch,
     gradients on the per-pixel kernel, stand-alone BN statistics / depthwise weight-gradient passes."""
     for k, v in (("CSN_WGRAD_REGROUP", "1"), ("CSN_WGRAD_TILED3", "0"), ("CSN_DW_STATS", "0"), ("CSN_DW_BWD_SPLIT", "1")):
         monkeypatch.setenv(k, v)
+    import oracle.csnet_oracle as O
+    monkeypatch.setattr(O, "DW_DZ_STORED", True)   # two-pass depthwise backward: dz goes through memory (bf16 rounding point)
     print(P.check_train_units_local(emu_lib, CPU, x2_manifest, B=2, size=48, act_dtype=act_dtype, state="shipped"))
 
 
@@ -176,3 +178,8 @@ def test_emu_fuse_lowest_branch_both_routes(emu_lib, x2_manifest, monkeypatch):
         census[noq] = {k: v[1] for k, v in eng.kernel_stats().items()}
     assert census[False]["pw4_kernel"] == census[True]["pw4_kernel"] + 1, census
     assert census[False].get("goct_pw_kernel", 0) == census[True].get("goct_pw_kernel", 0) - 1, census
+
+
+@pytest.mark.parametrize("act_dtype", ["fp32", "bf16"])
+def test_emu_bn_backward_apply_fused_into_depthwise_backward(emu_lib, x2_manifest, act_dtype):
+    print(P.check_bn_bwd_fusion_bit_identical(emu_lib, CPU, x2_manifest, B=2, size=32, act_dtype=act_dtype))
