@@ -133,11 +133,27 @@ class _RoundBF16Fwd(torch.autograd.Function):
         return g
 
 
+class _RoundBF16Bwd(torch.autograd.Function):
+    """The mirror image: the VALUE never goes to memory (HIP path: an activation whose only consumer is a depthwise unit is
+    formed on load from the stored z, round 3), its gradient does (the consumer writes dx)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
 _ACT_BF16 = False
-# bf16 storage emulation: is dz of a depthwise unit a stored tensor?  False = the HIP default (one-pass depthwise backward with
+# bf16 storage emulation of the one-pass depthwise kernels (HIP default; the tests that force the two-pass fallbacks -- CSN_DW_BWD_SPLIT,
+# CSN_BN_BWD_FUSE=0, CSN_BN_FWD_FUSE=0 -- flip these): DW_IN_STORED = is the activation a depthwise unit consumes a stored tensor
+# (ILBlock: the outputs of conv1x1 and conv3x3_1)?  DW_DZ_STORED =  False = the HIP default (one-pass depthwise backward with
 # the BatchNorm backward's apply step fused in); tests that force the two-pass fallback (CSN_DW_BWD_SPLIT, CSN_BN_BWD_FUSE=0)
 # set it to True.
 DW_DZ_STORED = False
+DW_IN_STORED = False
 Z_CAPTURE = None     # tests: set to a list to collect every BatchNorm input (the raw conv outputs z) in call order
 # tests (unit-local train checks): PReLU has a kink at 0, so a pre-activation that is zero to within fp32 rounding may
 # legitimately take either branch on the device.  PRELU_Y: set to a list to collect every pre-activation (BatchNorm output) in
@@ -198,7 +214,7 @@ def goct_conv(xs, weight, alpha_in, alpha_out, stride, padding):
     return [sum(v) if len(v) else None for v in ysets]     # python sum: 0 + y0 + y1 (:720-722)
 
 
-def bn_prelu(x, sd, bn_prefix, prelu_key, training, dz_stored=True):
+def bn_prelu(x, sd, bn_prefix, prelu_key, training, dz_stored=True, y_stored=True):
     """nn.BatchNorm2d (eps 1e-5, momentum 0.1) followed by per-channel nn.PReLU."""
     # the raw conv output z is a stored tensor (statistics are taken from what was stored); so is its gradient dz, except
     # where the consumer forms it on load (dz_stored False)
@@ -220,25 +236,27 @@ def bn_prelu(x, sd, bn_prefix, prelu_key, training, dz_stored=True):
         if PRELU_FLIP is not None and idx in PRELU_FLIP:
             al = sd[prelu_key].view(1, -1, 1, 1)
             out = torch.where(PRELU_FLIP[idx], torch.where(y >= 0, al * y, y), out)
+    if not y_stored and _ACT_BF16 and training:
+        return _RoundBF16Bwd.apply(out)
     return _st(out)
 
 
-def goct_cbr(xs, sd, prefix, alpha_in, alpha_out, k, stride, training):
+def goct_cbr(xs, sd, prefix, alpha_in, alpha_out, k, stride, training, y_stored=True):
     """gOctaveCBR.forward, csnet.py:778-792 (std_conv branch :779-786 uses Conv2dX100)."""
     w = sd[prefix + ".conv.weight"]
     pad = 1 if k == 3 else 0
     if len(alpha_in) == 1 and len(alpha_out) == 1:       # :751-754  Conv2dX100, real stride
         x = xs[0] if isinstance(xs, (list, tuple)) else xs
         y = F.conv2d(x, 100.0 * w, None, stride, pad)     # conv2d.py:104
-        return bn_prelu(y, sd, prefix + ".bns.0", prefix + ".prelus.0.weight", training)
+        return bn_prelu(y, sd, prefix + ".bns.0", prefix + ".prelus.0.weight", training, y_stored=y_stored)
     ys = goct_conv(xs, w, alpha_in, alpha_out, stride, pad)
     for j in range(len(ys)):
         if ys[j] is not None:
-            ys[j] = bn_prelu(ys[j], sd, f"{prefix}.bns.{j}", f"{prefix}.prelus.{j}.weight", training)
+            ys[j] = bn_prelu(ys[j], sd, f"{prefix}.bns.{j}", f"{prefix}.prelus.{j}.weight", training, y_stored=y_stored)
     return ys
 
 
-def simplified_cbr(xs, sd, prefix, training):
+def simplified_cbr(xs, sd, prefix, training, y_stored=True):
     """SimplifiedGOctConvBR.forward, csnet.py:838-851: depthwise 3x3 (x100) + BN + PReLU per branch."""
     if isinstance(xs, torch.Tensor):
         xs = [xs]
@@ -249,7 +267,8 @@ def simplified_cbr(xs, sd, prefix, training):
             continue
         w = sd[f"{prefix}.convs.{i}.weight"]
         y = F.conv2d(x, 100.0 * w, None, 1, 1, 1, w.shape[0])          # conv2d.py:104
-        ys.append(bn_prelu(y, sd, f"{prefix}.bns.{i}", f"{prefix}.prelus.{i}.weight", training, dz_stored=DW_DZ_STORED))
+        ys.append(bn_prelu(y, sd, f"{prefix}.bns.{i}", f"{prefix}.prelus.{i}.weight", training, dz_stored=DW_DZ_STORED,
+                           y_stored=y_stored))
     return ys
 
 
@@ -290,12 +309,12 @@ def il_block(xs, sd, blk, training, taps=None):
     a_out, _ = _alphas(blk["outlist"])
     k = 3 if (blk["first"] or blk["stride"] == 2) else 1           # :33-48
     p = blk["name"]
-    y = goct_cbr(xs, sd, p + ".conv1x1", a_in, a_out, k, blk["stride"], training)
+    y = goct_cbr(xs, sd, p + ".conv1x1", a_in, a_out, k, blk["stride"], training, y_stored=DW_IN_STORED)
     if isinstance(y, torch.Tensor):
         y = [y]
     if taps is not None:
         taps[p + ".conv1x1"] = y
-    y = simplified_cbr(y, sd, p + ".conv3x3_1", training)
+    y = simplified_cbr(y, sd, p + ".conv3x3_1", training, y_stored=DW_IN_STORED)
     if taps is not None:
         taps[p + ".conv3x3_1"] = y
     y = simplified_cbr(y, sd, p + ".conv3x3_2", training)

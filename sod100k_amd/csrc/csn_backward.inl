@@ -484,8 +484,14 @@ int run_bn_bwd(const BwdCtx& b, int ui, const UnitPlan& u, int j, bool skip_appl
 // depthwise unit, branch k: input and weight gradient in ONE pass over dz and x (dw3x3_bwd_kernel) -- when both are wanted and
 // the per-(image, tile) partials fit the reduction table; not on the weight-gradient side lane (the fused kernel also writes the
 // input gradient that the NEXT unit's backward on the caller's stream reads)
-int dw_fused_slabs(const csn_plan& P, const UnitBwd& ub, int k, int lvl, bool side) {
+// virt: the unit's input was never stored (csn_plan::virt_cons) -- then this IS the path, on the caller's stream
+int dw_fused_slabs(const csn_plan& P, const UnitBwd& ub, int k, int lvl, bool side, bool virt) {
+  if (virt) return dw_stats_slabs(P, lvl);
   return (ub.need_dx[k] && !side && !std::getenv("CSN_DW_BWD_SPLIT")) ? dw_stats_slabs(P, lvl) : 0;
+}
+inline bool dw_in_virtual(const csn_plan& P, int ui, int k) {
+  const int a = P.units[ui].d.in_act[k];
+  return !P.virt_cons.empty() && a > 0 && P.virt_cons[a] == ui;
 }
 
 int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
@@ -515,7 +521,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
       // depthwise units on the one-pass backward kernel: that kernel forms dz on load, the apply pass is skipped (round 3)
       bool fuse_apply = false;
       if (d.kind == CSN_UNIT_DW && P.bn_bwd_fuse)
-        fuse_apply = dw_fused_slabs(P, ub, j, P.acts[d.in_act[j]].lvl, c.lanes) > 0;
+        fuse_apply = dw_fused_slabs(P, ub, j, P.acts[d.in_act[j]].lvl, c.lanes, dw_in_virtual(P, ui, j)) > 0;
       const int st = run_bn_bwd(b, ui, u, j, fuse_apply, &bnargs[j]);
       if (st != CSN_OK) return st;
       bn_fused[j] = fuse_apply;
@@ -559,12 +565,22 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
       w.dz = bd.dz[k]; w.x = bd.in[k]; w.partial = reinterpret_cast<double*>(c.ws + (cs.side ? P.red2_off : P.red_off)); w.grad = b.grad;
       w.off_w = d.w_off[k]; w.C = d.cout[k]; w.S = S; w.H = H; w.W = W; w.nslab = 0;
       // one-pass kernel (see dw_fused_slabs); the branches go one after the other (they share the partial buffer)
-      const int fslabs = dw_fused_slabs(P, ub, k, act.lvl, cs.side);
+      const bool virt = dw_in_virtual(P, ui, k);
+      const int fslabs = dw_fused_slabs(P, ub, k, act.lvl, cs.side, virt);
       if (fslabs > 0) {
+        const Ctx& cf = (virt && cs.side) ? c : cs;   // (a never-stored input pins the unit to this kernel, on the caller's stream)
+        if (&cf == &c) w.partial = reinterpret_cast<double*>(c.ws + P.red_off);
         DwArgs f;
         f.nbr = 1; f.B = S; f.a16 = c.a16 ? 1 : 0; f.pad = 0;
         DwBranch& fb = f.br[0];
         fb.in = bd.dz[k]; fb.out = bd.dx[k]; fb.xin = bd.in[k];
+        if (virt) {   // x = PReLU(BN(z of the producer)) on load
+          const int ia = d.in_act[k];
+          const UnitPlan& pu = P.units[P.act_prod_unit[ia]];
+          const int pj = P.act_prod_branch[ia];
+          fb.xin = reinterpret_cast<const float*>(c.ws + P.tz_off[ia]);
+          fb.in_scale = c.pk(pu.out_epi[pj].scale); fb.in_shift = c.pk(pu.out_epi[pj].shift); fb.in_alpha = c.pk(pu.out_epi[pj].alpha);
+        }
         if (bn_fused[k]) {   // dz from dy and z on load
           const BnBwdArgs& ba = bnargs[k];
           fb.in = ba.dyA; fb.dy2 = ba.dyB; fb.zraw = ba.z;
@@ -583,10 +599,10 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
         fb.R = choose_dw_rows(H, fb.NY);
         fb.tiles_y = (H + fb.NY * fb.R - 1) / (fb.NY * fb.R);
         fb.blk_end = fb.tiles_x * fb.tiles_y * fb.C * S;
-        LAUNCH_TRY(csn_launch_dw_bwd(f, cs.stream));
-        if (bn_fused[k] && P.debug_dz) LAUNCH_TRY(csn_launch_bn_bwd_apply(bnargs[k], cs.stream));   // probes only: dz over z, afterwards
+        LAUNCH_TRY(csn_launch_dw_bwd(f, cf.stream));
+        if (bn_fused[k] && P.debug_dz) LAUNCH_TRY(csn_launch_bn_bwd_apply(bnargs[k], cf.stream));   // probes only: dz over z, afterwards
         w.nslab = fslabs;                                   // partials are there: finalise only
-        LAUNCH_TRY(csn_launch_dw_wgrad(w, cs.stream));
+        LAUNCH_TRY(csn_launch_dw_wgrad(w, cf.stream));
         continue;
       }
       LAUNCH_TRY(csn_launch_dw_wgrad(w, cs.stream));
@@ -736,6 +752,39 @@ int csn_plan_enable_training(csn_plan* P) {
       wg_floats = std::max(wg_floats, (int64_t)WG_MAX_BLOCKS * ((rows + 15) & ~15) * ((pp.K + 15) & ~15));
     }
   }
+  // activations that are never stored (csn_plan::virt_cons): only consumer = a depthwise unit whose forward leaves statistics
+  // partials per (image, tile) and whose backward is the one-pass kernel with the BatchNorm apply fused in
+  P->virt_cons.assign(na, -1);
+  P->act_prod_unit.assign(na, -1);
+  P->act_prod_branch.assign(na, -1);
+  for (int k = 0; k < nu; ++k) {
+    const UnitPlan& u = P->units[k];
+    if (u.d.kind == CSN_UNIT_CLS) continue;
+    for (int j = 0; j < u.d.n_out; ++j)
+      if (u.d.cout[j] > 0) { P->act_prod_unit[u.d.out_act[j]] = k; P->act_prod_branch[u.d.out_act[j]] = j; }
+  }
+  if (P->bn_fwd_fuse && P->bn_bwd_fuse && !std::getenv("CSN_DW_BWD_SPLIT"))
+    for (int k = 0; k < nu; ++k) {
+      UnitPlan& u = P->units[k];
+      if (u.d.kind != CSN_UNIT_DW) continue;
+      bool ok = true;
+      for (int i = 0; i < u.d.n_in && ok; ++i) {
+        if (u.d.cout[i] == 0) continue;
+        const int a = u.d.in_act[i];
+        ok = a > 0 && P->n_cons[a] == 1 && P->act_prod_unit[a] >= 0 && P->bwd[k].need_dx[i] &&
+             dw_stats_slabs(*P, P->acts[a].lvl) > 0;
+        if (ok) {
+          const int pk = P->units[P->act_prod_unit[a]].d.kind;
+          ok = pk == CSN_UNIT_GOCT || pk == CSN_UNIT_DW;
+        }
+      }
+      if (!ok) continue;
+      for (int i = 0; i < u.d.n_in; ++i) {
+        if (u.d.cout[i] == 0) continue;
+        P->virt_cons[u.d.in_act[i]] = k;
+        u.gapin_off[i] = bl.alloc_ws((int64_t)u.d.cout[i] * CSN_BN_NSLAB * sizeof(double));
+      }
+    }
   P->scratch_bytes = scratch;
   P->scratch_off = bl.alloc_ws(scratch > 0 ? scratch : 256);
   P->wg_off = bl.alloc_ws(wg_floats * (int64_t)sizeof(float));

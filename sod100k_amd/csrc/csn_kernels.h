@@ -82,7 +82,22 @@ struct DwBranch {
   const float* bn_invstd = nullptr;
   const float* bn_m1m2 = nullptr;    // [C][2] from bn_bwd_finalize_kernel
   const float* bn_gamma = nullptr;   // [C] in the parameter arena
+  // Train mode, input never stored (round 3): `in` (forward kernel) / `xin` (backward kernel) is the PRODUCER's raw conv
+  // output z and the unit's input x = PReLU(z * in_scale + in_shift) is formed per loaded element (csn_epi, exactly
+  // bn_apply_gap_kernel's arithmetic; positions outside the plane are zero AFTER the transform).  The forward kernel also
+  // leaves the plane sums of x that bn_apply_gap_kernel would have taken: one partial per (channel, image, tile) in gapin.
+  const float* in_scale = nullptr;   // [C] train-mode folded tables of the producer's BatchNorm
+  const float* in_shift = nullptr;
+  const float* in_alpha = nullptr;
+  double* gapin = nullptr;           // [C][CSN_BN_NSLAB], slab = b * tiles + tile (forward kernel only)
 };
+struct GapTilesArgs {                // gapabs[c][n] = | sum_tiles gapin[c][n * tiles + t] / HW |
+  const double* gapin;
+  float* gapabs;                     // [C][S]
+  int32_t C, S, tiles, pad;
+  int64_t HW;
+};
+int csn_launch_gap_tiles(const GapTilesArgs& a, void* stream);
 struct DwArgs {
   DwBranch br[3];
   int32_t nbr, B;

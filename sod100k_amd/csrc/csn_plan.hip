@@ -124,6 +124,7 @@ struct UnitPlan {
   // per-image |GAP| table (workspace bytes), consumer slot of every input branch in its activation's gradient list
   int64_t tr_mean[3] = {-1, -1, -1}, tr_invstd[3] = {-1, -1, -1}, tr_m1m2[3] = {-1, -1, -1};
   int64_t gap_off[3] = {-1, -1, -1};
+  int64_t gapin_off[3] = {-1, -1, -1};   // depthwise unit, training: per-tile plane sums of an input that is never stored (virt_cons)
   int in_slot[3] = {-1, -1, -1};
   // GOCT 1x1 with two or three input branches: launches of pw4_kernel (k_pw4.hip); pw4 = 0: the unit does not qualify
   struct Pw4Launch {
@@ -171,7 +172,9 @@ struct csn_plan {
   int pw4_twl = 4;        // log2 of its widest tile in low pixels (CSN_PW4_TWL, experiments)
   bool pw4_no_q = false;      // CSN_PW4_NOQ: CSFHead.fuse's lowest output branch stays on goct_pw_kernel (experiments)
   bool bn_bwd_fuse = true;    // depthwise backward forms dz on load, the BatchNorm backward's apply pass is skipped (CSN_BN_BWD_FUSE=0: off)
-  bool debug_dz = false;      // CSN_DEBUG_DZ: ... and the apply pass still runs AFTER that kernel, so that the probes see dz (tests)
+  bool bn_fwd_fuse = true;    // activations consumed only by a depthwise unit are formed on load (virt_cons; CSN_BN_FWD_FUSE=0: off)
+  bool debug_dz = false;      // CSN_DEBUG_DZ (tests): the skipped passes (y of virt_cons activations, dz below) still run for the probes
+  // CSN_DEBUG_DZ: ... and the apply pass still runs AFTER that kernel, so that the probes see dz (tests)
   bool pw4_nosplit = false;   // CSN_PW4_NOSPLIT: no extra M groups on small maps (experiments)
   bool overlap_bwd = false;   // CSN_OPT_OVERLAP value 2: also the weight-gradient side lane of csn_backward
   bool overlap = true;    // CSN_OPT_OVERLAP: independent launches of a unit (and the MSBlocks) on parallel stream lanes
@@ -209,6 +212,11 @@ struct csn_plan {
   std::vector<int64_t> tz_off;                  // per act: raw conv output z, later dz (workspace bytes)
   std::vector<std::array<int64_t, 2>> tg_off;   // per act: gradient buffer per consumer
   std::vector<int> n_cons;
+  // Training, activations that are never stored (round 3): the output of a unit whose ONLY consumer is a depthwise unit on the
+  // one-pass kernels -- that consumer forms y = PReLU(BN(z)) on load from the producer's raw output z (forward and backward) and
+  // leaves the plane sums the penalty needs, so the producer's bn_apply_gap pass (read z, write y) does not run.
+  std::vector<int> virt_cons;            // per act: index of that consumer unit, -1 = the activation is stored
+  std::vector<int> act_prod_unit, act_prod_branch;   // per act: producing unit / its output branch
   std::vector<int> orphan_acts;          // outputs without consumer: zero gradient (training)
   int64_t scratch_off = 0, scratch_bytes = 0;   // per-unit backward temporaries (shared by all units)
   int64_t red_off = 0;                          // fp64 partials of the BN / depthwise reductions
@@ -1043,6 +1051,16 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
         DwBranch& br = a.br[a.nbr++];
         const Act& act = P.acts[d.in_act[k]];
         br.in = c.act_in(d.in_act[k]);
+        const bool virt = c.raw && P.train && !P.virt_cons.empty() && d.in_act[k] > 0 &&
+                          P.virt_cons[d.in_act[k]] == (int)(&u - P.units.data());
+        if (virt) {   // the producer's raw output + its BatchNorm tables of this step (the activation itself is not stored)
+          const int ia = d.in_act[k];
+          const UnitPlan& pu = P.units[P.act_prod_unit[ia]];
+          const int pj = P.act_prod_branch[ia];
+          br.in = reinterpret_cast<const float*>(c.ws + P.tz_off[ia]);
+          br.in_scale = c.pk(pu.out_epi[pj].scale); br.in_shift = c.pk(pu.out_epi[pj].shift); br.in_alpha = c.pk(pu.out_epi[pj].alpha);
+          br.gapin = reinterpret_cast<double*>(c.ws + u.gapin_off[k]);
+        }
         br.out = c.act_out(fused ? next->d.out_act[k] : d.out_act[k]);
         br.w9 = c.pk(u.dw_w[k]);
         br.scale = c.sc(u.dw_epi[k]); br.shift = c.sh(u.dw_epi[k]); br.alpha = c.al(u.dw_epi[k]);
@@ -1082,6 +1100,17 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
       if (fused) LAUNCH_TRY(csn_launch_dw2(a, c.stream));
       else LAUNCH_TRY(csn_launch_dw(a, c.stream));
       { const int ms_ = c.mark(fused ? "dw3x3x2_bn_prelu_kernel" : "dw3x3_bn_prelu_kernel"); if (ms_ != CSN_OK) return ms_; }
+      for (int q = 0, k = 0; k < d.n_in; ++k) {   // |mean_hw y| tables of the producers whose y was formed on load here
+        if (d.cout[k] == 0) continue;
+        const DwBranch& br = a.br[q++];
+        if (br.gapin == nullptr) continue;
+        const int ia = d.in_act[k];
+        const UnitPlan& pu = P.units[P.act_prod_unit[ia]];
+        GapTilesArgs ga;
+        ga.gapin = br.gapin; ga.gapabs = reinterpret_cast<float*>(c.ws + pu.gap_off[P.act_prod_branch[ia]]);
+        ga.C = br.C; ga.S = S; ga.tiles = br.tiles_x * br.tiles_y; ga.pad = 0; ga.HW = (int64_t)br.H * br.W;
+        LAUNCH_TRY(csn_launch_gap_tiles(ga, c.stream));
+      }
     } break;
     case CSN_UNIT_GOCT: {
       // optional 2x2 avg-pool prologue of every input branch (csnet.py:679-680)
@@ -1413,6 +1442,7 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   if (std::getenv("CSN_PW4_NOQ")) P->pw4_no_q = true;
   if (const char* v = std::getenv("CSN_BN_BWD_FUSE")) P->bn_bwd_fuse = v[0] != '0';
   if (const char* v = std::getenv("CSN_DEBUG_DZ")) P->debug_dz = v[0] != '0';
+  if (const char* v = std::getenv("CSN_BN_FWD_FUSE")) P->bn_fwd_fuse = v[0] != '0';
   if (const char* v = std::getenv("CSN_C3Q_NT")) { if (std::atoi(v) >= 1) P->c3q_cap = std::atoi(v); }
   if (const char* v = std::getenv("CSN_PW4_TWL")) { if (std::atoi(v) >= 2 && std::atoi(v) <= 6) P->pw4_twl = std::atoi(v); }
   Builder bl(*P);
@@ -1819,7 +1849,14 @@ static int forward_train_body(csn_plan* P, const float* x, float* y, void* works
       aa.scale = fa.scale; aa.shift = fa.shift; aa.alpha = P->packed + up.out_epi[j].alpha;
       aa.arena = arena; aa.penalty = penalty; aa.off_weight = d.bn[j].weight; aa.HW = hw; aa.S = P->S; aa.C = d.cout[j];
       aa.flop_w = flop_w[u * CSN_MAX_BRANCH + j]; aa.a16 = c.a16 ? 1 : 0;
-      LAUNCH_TRY(csn_launch_bn_apply(aa, stream));
+      const bool virt = P->train && !P->virt_cons.empty() && P->virt_cons[d.out_act[j]] >= 0;
+      if (!virt) {
+        LAUNCH_TRY(csn_launch_bn_apply(aa, stream));
+      } else if (P->debug_dz) {   // probes only: y is materialised, the |GAP| table stays the consumer's
+        BnApplyArgs dbg = aa;
+        dbg.flop_w = 0.f;
+        LAUNCH_TRY(csn_launch_bn_apply(dbg, stream));
+      }
       if (aa.flop_w != 0.f) {
         BnPenaltyJob pj;
         pj.gapabs = aa.gapabs; pj.off_weight = aa.off_weight; pj.C = aa.C; pj.S = aa.S; pj.flop_w = aa.flop_w; pj.pad = 0;

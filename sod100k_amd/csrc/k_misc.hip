@@ -148,6 +148,21 @@ __device__ __forceinline__ DwRow dw_load_row(csn_buf rb, int y, int x0, int W, b
   return r;
 }
 
+// row of x = PReLU(z * sc + sh) from a row of the producer's raw output z (see DwBranch::in_scale); outside the plane: 0
+template <bool VEC, typename AT>
+__device__ __forceinline__ DwRow dw_load_row_bn(csn_buf rb, int y, int H, int x0, int W, bool has_l, bool has_r, float sc,
+                                                float sh, float al) {
+  DwRow r = dw_load_row<VEC, AT>(rb, y, x0, W, has_l, has_r);
+  const bool rowin = y >= 0 && y < H;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const bool colin = i == 0 ? has_l : (i == 5 ? has_r : (VEC || x0 + i - 1 < W));
+    const float v = csn_epi(r.v[i], sc, sh, al);
+    r.v[i] = (rowin && colin) ? v : 0.f;
+  }
+  return r;
+}
+
 // STATS: also accumulate sum / sum of squares of the values as STORED (train mode: the raw conv output z whose batch
 // statistics the BatchNorm that follows needs -- saves bn_stats_kernel's pass over z)
 template <bool VEC, typename AT = float, bool STATS = false>
@@ -188,7 +203,8 @@ __device__ __forceinline__ void dw_emit(AT* __restrict__ op, int y, int yend, in
   }
 }
 
-template <bool VEC, typename AT, bool STATS>
+// INBN (train mode, with STATS): the input is formed on load from the producer's raw output and its plane sums are taken
+template <bool VEC, typename AT, bool STATS, bool INBN = false>
 __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
   CSN_DYN_SMEM(double, sm);   // STATS only
   int bid = blockIdx.x;
@@ -208,7 +224,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
   const int x0 = (tx * br.LX + lx) * 4;
   const int y0 = (ty * br.NY + ly) * br.R;
   const bool active = ly < br.NY && x0 < W && y0 < H;
-  double st[2] = {0.0, 0.0};
+  double st[3] = {0.0, 0.0, 0.0};   // sum / sum of squares of the stored output; INBN: sum of the input over the lane's own rows
   if (active) {
     const csn_buf rb = csn_make_buf_n(act_cast<AT>(br.in) + (int64_t)pc * H * W, (unsigned)(H * W) * (unsigned)sizeof(AT));
     AT* __restrict__ op = act_cast<AT>(br.out) + (int64_t)pc * H * W;
@@ -218,15 +234,24 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
     for (int i = 0; i < 9; ++i) w[i] = w9[c * 9 + i];
     const float sc = csn_const(br.scale)[c], sh = csn_const(br.shift)[c], al = csn_const(br.alpha)[c];
     const bool has_l = x0 > 0, has_r = x0 + 4 < W;
-
-    DwRow r0 = dw_load_row<VEC, AT>(rb, y0 - 1, x0, W, has_l, has_r);
-    DwRow r1 = dw_load_row<VEC, AT>(rb, y0, x0, W, has_l, has_r);
     const int yend = min(y0 + br.R, H);
+    float isc = 1.f, ish = 0.f, ial = 1.f;
+    if (INBN) { isc = csn_const(br.in_scale)[c]; ish = csn_const(br.in_shift)[c]; ial = csn_const(br.in_alpha)[c]; }
+    float gsum = 0.f;   // <= 16 rows x 4 values per lane: fp32, then fp64 across the block
+    auto load_in = [&](int y) {
+      if (!INBN) return dw_load_row<VEC, AT>(rb, y, x0, W, has_l, has_r);
+      const DwRow r = dw_load_row_bn<VEC, AT>(rb, y, H, x0, W, has_l, has_r, isc, ish, ial);
+      if (y >= y0 && y < yend) gsum += (r.v[1] + r.v[2]) + (r.v[3] + r.v[4]);   // (columns past W are zero)
+      return r;
+    };
+
+    DwRow r0 = load_in(y0 - 1);
+    DwRow r1 = load_in(y0);
     for (int y = y0; y < yend; y += 4) {
-      const DwRow n0 = dw_load_row<VEC, AT>(rb, y + 1, x0, W, has_l, has_r);
-      const DwRow n1 = dw_load_row<VEC, AT>(rb, y + 2, x0, W, has_l, has_r);
-      const DwRow n2 = dw_load_row<VEC, AT>(rb, y + 3, x0, W, has_l, has_r);
-      const DwRow n3 = dw_load_row<VEC, AT>(rb, y + 4, x0, W, has_l, has_r);
+      const DwRow n0 = load_in(y + 1);
+      const DwRow n1 = load_in(y + 2);
+      const DwRow n2 = load_in(y + 3);
+      const DwRow n3 = load_in(y + 4);
       dw_emit<VEC, AT, STATS>(op, y, yend, x0, W, w, sc, sh, al, r0, r1, n0, st);
       dw_emit<VEC, AT, STATS>(op, y + 1, yend, x0, W, w, sc, sh, al, r1, n0, n1, st);
       dw_emit<VEC, AT, STATS>(op, y + 2, yend, x0, W, w, sc, sh, al, n0, n1, n2, st);
@@ -234,14 +259,22 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
       r0 = n2;
       r1 = n3;
     }
+    st[2] = (double)gsum;
   }
   if (STATS) {   // one (sum, sum of squares) partial per (image, tile) of the channel: slab = b * tiles + tile
-    bn_block_sum_n<2>(st, sm);
+    if (INBN) {
+      bn_block_sum_n<3>(st, sm);
+    } else {
+      double s2[2] = {st[0], st[1]};
+      bn_block_sum_n<2>(s2, sm);
+      st[0] = s2[0]; st[1] = s2[1];
+    }
     if (tid == 0) {
       const int b = pc / br.C;
       double* o = br.stats + ((int64_t)c * CSN_BN_NSLAB + (int64_t)b * tiles + tile) * 2;
       o[0] = st[0];
       o[1] = st[1];
+      if (INBN) br.gapin[(int64_t)c * CSN_BN_NSLAB + (int64_t)b * tiles + tile] = st[2];
     }
   }
 }
@@ -256,7 +289,8 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
 // BNF: the BatchNorm backward's apply pass is fused in -- dz is formed per loaded element from dy (+ dy2) and the saved z
 // with the channel's (block-uniform) tables, bit for bit bn_bwd_apply_kernel's arithmetic; rows / columns outside the plane
 // are masked to zero AFTER the formula (z = dy = 0 does not give dz = 0).  Saves the write and the re-read of dz (round 3).
-template <bool VEC, typename AT, bool BNF>
+// XBN: the unit's forward input x was never stored: it is formed on load from the producer's raw output (DwBranch::in_scale)
+template <bool VEC, typename AT, bool BNF, bool XBN = false>
 __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
   CSN_DYN_SMEM(double, sm);
   int bid = blockIdx.x;
@@ -321,14 +355,20 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
       }
       return g;
     };
+    float isc = 1.f, ish = 0.f, ial = 1.f;
+    if (XBN) { isc = csn_const(br.in_scale)[c]; ish = csn_const(br.in_shift)[c]; ial = csn_const(br.in_alpha)[c]; }
+    auto load_x = [&](int y) {
+      if (XBN) return dw_load_row_bn<VEC, AT>(xb, y, H, x0, W, has_l, has_r, isc, ish, ial);
+      return dw_load_row<VEC, AT>(xb, y, x0, W, has_l, has_r);
+    };
     DwRow g0 = load_g(y0 - 1);
     DwRow g1 = load_g(y0);
-    DwRow u0 = dw_load_row<VEC, AT>(xb, y0 - 1, x0, W, has_l, has_r);
-    DwRow u1 = dw_load_row<VEC, AT>(xb, y0, x0, W, has_l, has_r);
+    DwRow u0 = load_x(y0 - 1);
+    DwRow u1 = load_x(y0);
     const int yend = min(y0 + br.R, H);
     for (int y = y0; y < yend; ++y) {
       const DwRow g2 = load_g(y + 1);
-      const DwRow u2 = dw_load_row<VEC, AT>(xb, y + 1, x0, W, has_l, has_r);
+      const DwRow u2 = load_x(y + 1);
       dw_emit<VEC, AT>(op, y, yend, x0, W, w, 1.f, 0.f, 1.f, g0, g1, g2);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -359,13 +399,15 @@ int csn_launch_dw_bwd(const DwArgs& a, void* stream) {
   bool vec = true;
   for (int k = 0; k < a.nbr; ++k) vec = vec && (a.br[k].W % 4 == 0);
   const size_t sml = CSN_BLOCK * sizeof(double);
-  bool bnf = a.br[0].zraw != nullptr;   // (all branches of a launch alike)
+  const bool bnf = a.br[0].zraw != nullptr, xbn = a.br[0].in_scale != nullptr;   // (all branches of a launch alike)
   for (int k = 1; k < a.nbr; ++k)
-    if ((a.br[k].zraw != nullptr) != bnf) return 1;
-#define DWB_LAUNCH(V, T)                                                                                  \
-  do {                                                                                                   \
-    if (bnf) CSN_LAUNCH((dw3x3_bwd_kernel<V, T, true>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);    \
-    else CSN_LAUNCH((dw3x3_bwd_kernel<V, T, false>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);       \
+    if ((a.br[k].zraw != nullptr) != bnf || (a.br[k].in_scale != nullptr) != xbn) return 1;
+  if (xbn && !bnf) return 1;   // (the planner only skips an activation when its consumer runs the fully fused backward)
+#define DWB_LAUNCH(V, T)                                                                                         \
+  do {                                                                                                          \
+    if (xbn) CSN_LAUNCH((dw3x3_bwd_kernel<V, T, true, true>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);     \
+    else if (bnf) CSN_LAUNCH((dw3x3_bwd_kernel<V, T, true>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);      \
+    else CSN_LAUNCH((dw3x3_bwd_kernel<V, T, false>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);              \
   } while (0)
   if (a.a16) {
     if (vec) DWB_LAUNCH(true, csn_bf16);
@@ -556,10 +598,16 @@ int csn_launch_dw(const DwArgs& a, void* stream) {
   bool stats = true;   // every branch of the launch carries a statistics table (train-mode forward), or none does
   for (int k = 0; k < a.nbr; ++k) stats = stats && a.br[k].stats != nullptr;
   const size_t sml = stats ? CSN_BLOCK * sizeof(double) : 0;
-#define DW_LAUNCH(V, T)                                                                                        \
-  do {                                                                                                         \
-    if (stats) CSN_LAUNCH((dw3x3_bn_prelu_kernel<V, T, true>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);   \
-    else CSN_LAUNCH((dw3x3_bn_prelu_kernel<V, T, false>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);          \
+  bool inbn = true;    // ... and the same for the on-load input transform (needs the statistics partials' indexing)
+  for (int k = 0; k < a.nbr; ++k) inbn = inbn && a.br[k].in_scale != nullptr && a.br[k].gapin != nullptr;
+  for (int k = 0; k < a.nbr; ++k)
+    if (!inbn && a.br[k].in_scale != nullptr) return 1;
+  if (inbn && !stats) return 1;
+#define DW_LAUNCH(V, T)                                                                                              \
+  do {                                                                                                               \
+    if (inbn) CSN_LAUNCH((dw3x3_bn_prelu_kernel<V, T, true, true>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);    \
+    else if (stats) CSN_LAUNCH((dw3x3_bn_prelu_kernel<V, T, true>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);    \
+    else CSN_LAUNCH((dw3x3_bn_prelu_kernel<V, T, false>), dim3(nblk), dim3(CSN_BLOCK), 0, stream, a);                \
   } while (0)
   if (a.a16) {
     if (vec) DW_LAUNCH(true, csn_bf16);

@@ -151,6 +151,18 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_apply_gap_kernel(BnApplyArgs a) 
   }
 }
 
+// |mean_hw y| per (channel, image) from the per-tile plane sums the consuming depthwise kernel left (its input y was formed on
+// load and never stored, so bn_apply_gap_kernel did not run for it): fixed order over the tiles
+__global__ __launch_bounds__(CSN_BLOCK) void gap_tiles_kernel(GapTilesArgs a) {
+  const int i = blockIdx.x * CSN_BLOCK + threadIdx.x;
+  if (i >= a.C * a.S) return;
+  const int c = i / a.S, n = i - c * a.S;
+  const double* p = a.gapin + (int64_t)c * BN_NSLAB + (int64_t)n * a.tiles;
+  double s = 0.0;
+  for (int t = 0; t < a.tiles; ++t) s += p[t];
+  a.gapabs[i] = (float)fabs(s / (double)a.HW);
+}
+
 // penalty += sum_j 0.5 * w_j * sum_c gamma_c^2 * sum_n |gap_j[c][n]|   (Oct_bn_hook, csnet.py:391-410) over all hooked
 // (unit, branch) pairs j of the forward.  One block per job (fixed summation order), then ONE thread adds the job terms to the
 // device scalar in job order -- the same sequence of fp64 additions as one launch per job, without ~100 tiny launches per
@@ -599,6 +611,10 @@ int csn_launch_bn_bwd(const BnBwdArgs& a0, void* stream) {
   CSN_LAUNCH_AT(a.a16, bn_bwd_reduce_kernel, dim3(a.nslab, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   CSN_LAUNCH(bn_bwd_finalize_kernel, dim3(a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   if (!a.skip_apply) CSN_LAUNCH_AT(a.a16, bn_bwd_apply_kernel, dim3(a.C, a.S), dim3(CSN_BLOCK), 0, stream, a);
+  return (int)hipGetLastError();
+}
+int csn_launch_gap_tiles(const GapTilesArgs& a, void* stream) {
+  CSN_LAUNCH(gap_tiles_kernel, dim3((a.C * a.S + CSN_BLOCK - 1) / CSN_BLOCK), dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
 }
 int csn_launch_bn_bwd_apply(const BnBwdArgs& a, void* stream) {

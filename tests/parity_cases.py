@@ -347,9 +347,10 @@ def check_train_step(lib, device, manifest, B=2, size=32, expandflop=1.0, flops_
 
 
 def check_bn_bwd_fusion_bit_identical(lib, device, manifest, B=2, size=32, act_dtype="fp32", seed=23):
-    """The depthwise backward with the BatchNorm backward's apply pass fused in (dz formed on load) against the two-pass
-    scheme (CSN_BN_BWD_FUSE=0: dz written by bn_bwd_apply_kernel, then read): the same arithmetic per element, so in fp32
-    every gradient is bit-identical; with bfloat16 storage the fused path skips one rounding of dz (close, not equal)."""
+    """The one-pass depthwise kernels (input activation formed on load from the producer's z, dz formed on load in the
+    backward kernel) against the stored scheme (CSN_BN_BWD_FUSE=0 switches both off: y written by bn_apply_gap_kernel, dz by
+    bn_bwd_apply_kernel): the same arithmetic per element, so in fp32 the gradients are equal (see below for the one
+    exception)."""
     flats = []
     for fuse in ("1", "0"):
         os.environ["CSN_BN_BWD_FUSE"] = fuse
@@ -366,8 +367,13 @@ def check_bn_bwd_fusion_bit_identical(lib, device, manifest, B=2, size=32, act_d
             del os.environ["CSN_BN_BWD_FUSE"]
     a, b = flats
     if act_dtype == "fp32":
-        assert torch.equal(a, b), f"max-abs {float((a - b).abs().max()):.3e}"
-        return 0.0
+        # the one difference in fp32: the |GAP| table of a never-stored activation is summed per tile by its consumer instead
+        # of per plane by bn_apply_gap_kernel (fp64 partial sums in another order -> the float table may differ in its last
+        # bit, which reaches the BatchNorm weight gradients through the penalty term)
+        d = (a - b).abs()
+        nz = int((d > 0).sum())
+        assert float(d.max()) <= 1e-12 and nz <= a.numel() // 20, (float(d.max()), nz)
+        return float(d.max())
     rel = float((a.double() - b.double()).norm() / b.double().norm())
     assert rel < 5e-2, rel
     return rel
@@ -718,6 +724,19 @@ def _check_train_units_local(lib, device, manifest, B, size, act_dtype, state, f
             bad.append((kind, name, r, n))
 
     ctx = O.bf16_activations() if bf16 else contextlib.nullcontext()
+    if bf16 and not O.DW_IN_STORED:
+        # An activation whose only consumer is a depthwise unit is never stored: the consumer forms it on load from the stored z
+        # in fp32.  The "act" probe (CSN_DEBUG_DZ materialises it) went through a bf16 store; what the consumer saw is this:
+        for ui, (u, name) in enumerate(zip(units, names)):
+            if not (name.endswith(".conv1x1") and name[:-len(".conv1x1")] in blocks) and not name.endswith(".conv3x3_1"):
+                continue
+            for j in range(int(u.n_out)):
+                if u.cout[j] == 0:
+                    continue
+                a = int(u.out_act[j])
+                z = Z[a].float()
+                yb = F.batch_norm(z, None, None, sd[f"{name}.bns.{j}.weight"], sd[f"{name}.bns.{j}.bias"], True, 0.0, 1e-5)
+                A[a] = F.prelu(yb, sd[f"{name}.prelus.{j}.weight"])
     kink_units = []
     for ui, (u, name) in enumerate(zip(units, names)):
         n_in, n_out = int(u.n_in), int(u.n_out)
@@ -748,9 +767,9 @@ def _check_train_units_local(lib, device, manifest, B, size, act_dtype, state, f
                         blk = blocks[name[:-len(".conv1x1")]]
                         a_in, _ = O._alphas(blk["inlist"]); a_out, _ = O._alphas(blk["outlist"])
                         k = 3 if (blk["first"] or blk["stride"] == 2) else 1
-                        ys = O.goct_cbr(xs, loc, name, a_in, a_out, k, blk["stride"], True)
+                        ys = O.goct_cbr(xs, loc, name, a_in, a_out, k, blk["stride"], True, y_stored=O.DW_IN_STORED)
                     elif ".conv3x3_" in name:
-                        ys = O.simplified_cbr(xs, loc, name, True)
+                        ys = O.simplified_cbr(xs, loc, name, True, y_stored=O.DW_IN_STORED or name.endswith(".conv3x3_2"))
                     elif name == "oct_fuse.fuse":
                         ys = O.goct_cbr(xs, loc, name, O._alphas(cfg3[0][0])[0], O._alphas(cfg3[1][0])[0], 1, 1, True)
                     elif name.startswith("oct_fuse.ms.convs."):
