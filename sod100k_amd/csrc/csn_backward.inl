@@ -476,6 +476,15 @@ int run_bn_bwd(const BwdCtx& b, int ui, const UnitPlan& u, int j, bool skip_appl
   a.pen_scale = b.pen_scale;
   a.a16 = b.c.a16 ? 1 : 0;
   a.skip_apply = skip_apply ? 1 : 0;
+  a.nslab_in = 0;
+  if (!P.virt_cons.empty() && P.virt_cons[act] >= 0) {   // the only consumer's backward kernel has left the partial sums
+    const UnitPlan& cu = P.units[P.virt_cons[act]];
+    for (int i = 0; i < cu.d.n_in; ++i)
+      if (cu.d.cout[i] > 0 && cu.d.in_act[i] == act) {
+        a.partial = reinterpret_cast<double*>(b.c.ws + cu.bnred_off[i]);
+        a.nslab_in = dw_stats_slabs(P, A.lvl);
+      }
+  }
   LAUNCH_TRY(csn_launch_bn_bwd(a, b.c.stream));
   if (keep) *keep = a;
   return CSN_OK;
@@ -580,6 +589,8 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
           const int pj = P.act_prod_branch[ia];
           fb.xin = reinterpret_cast<const float*>(c.ws + P.tz_off[ia]);
           fb.in_scale = c.pk(pu.out_epi[pj].scale); fb.in_shift = c.pk(pu.out_epi[pj].shift); fb.in_alpha = c.pk(pu.out_epi[pj].alpha);
+          fb.in_mean = c.pk(pu.tr_mean[pj]); fb.in_invstd = c.pk(pu.tr_invstd[pj]);
+          fb.bnred = reinterpret_cast<double*>(c.ws + u.bnred_off[k]);
         }
         if (bn_fused[k]) {   // dz from dy and z on load
           const BnBwdArgs& ba = bnargs[k];
@@ -783,6 +794,7 @@ int csn_plan_enable_training(csn_plan* P) {
         if (u.d.cout[i] == 0) continue;
         P->virt_cons[u.d.in_act[i]] = k;
         u.gapin_off[i] = bl.alloc_ws((int64_t)u.d.cout[i] * CSN_BN_NSLAB * sizeof(double));
+        u.bnred_off[i] = bl.alloc_ws((int64_t)u.d.cout[i] * CSN_BN_NSLAB * 3 * sizeof(double));
       }
     }
   P->scratch_bytes = scratch;

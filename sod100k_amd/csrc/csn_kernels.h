@@ -90,6 +90,12 @@ struct DwBranch {
   const float* in_shift = nullptr;
   const float* in_alpha = nullptr;
   double* gapin = nullptr;           // [C][CSN_BN_NSLAB], slab = b * tiles + tile (forward kernel only)
+  // ... and the backward kernel, which produces the gradient w.r.t. that never-stored x (its only consumer), also takes the
+  // producer's BatchNorm-backward sums over its tile -- bn_bwd_reduce_kernel's three sums, from the z it loads anyway and the dx
+  // it has just computed: one partial per (channel, image, tile)
+  const float* in_mean = nullptr;    // [C] batch mean / 1 / sqrt(var + eps) of the producer's BatchNorm
+  const float* in_invstd = nullptr;
+  double* bnred = nullptr;           // [C][CSN_BN_NSLAB][3]
 };
 struct GapTilesArgs {                // gapabs[c][n] = | sum_tiles gapin[c][n * tiles + t] / HW |
   const double* gapin;
@@ -407,6 +413,8 @@ struct BnBwdArgs {
   int32_t nslab, cpp;  // set by the launcher
   int32_t a16;         // dy / z are bfloat16
   int32_t skip_apply;  // reduce + finalise only: the consumer of dz forms it on load (dw3x3_bwd_kernel, DwBranch::zraw)
+  int32_t nslab_in;    // > 0: `partial` already holds that many partials per channel (written by the depthwise backward of the
+                       // activation's only consumer, DwBranch::bnred): no reduce pass
 };
 int csn_launch_bn_bwd(const BnBwdArgs& a, void* stream);
 int csn_launch_bn_bwd_apply(const BnBwdArgs& a, void* stream);   // the apply pass alone (debug: materialise dz for the probes)

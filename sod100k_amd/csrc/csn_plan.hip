@@ -125,6 +125,7 @@ struct UnitPlan {
   int64_t tr_mean[3] = {-1, -1, -1}, tr_invstd[3] = {-1, -1, -1}, tr_m1m2[3] = {-1, -1, -1};
   int64_t gap_off[3] = {-1, -1, -1};
   int64_t gapin_off[3] = {-1, -1, -1};   // depthwise unit, training: per-tile plane sums of an input that is never stored (virt_cons)
+  int64_t bnred_off[3] = {-1, -1, -1};   // ... and the BatchNorm-backward sums of its producer, taken by this unit's backward kernel
   int in_slot[3] = {-1, -1, -1};
   // GOCT 1x1 with two or three input branches: launches of pw4_kernel (k_pw4.hip); pw4 = 0: the unit does not qualify
   struct Pw4Launch {

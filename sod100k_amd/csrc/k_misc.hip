@@ -151,8 +151,9 @@ __device__ __forceinline__ DwRow dw_load_row(csn_buf rb, int y, int x0, int W, b
 // row of x = PReLU(z * sc + sh) from a row of the producer's raw output z (see DwBranch::in_scale); outside the plane: 0
 template <bool VEC, typename AT>
 __device__ __forceinline__ DwRow dw_load_row_bn(csn_buf rb, int y, int H, int x0, int W, bool has_l, bool has_r, float sc,
-                                                float sh, float al) {
+                                                float sh, float al, float* zc = nullptr) {
   DwRow r = dw_load_row<VEC, AT>(rb, y, x0, W, has_l, has_r);
+  if (zc) { zc[0] = r.v[1]; zc[1] = r.v[2]; zc[2] = r.v[3]; zc[3] = r.v[4]; }   // the raw centre values z
   const bool rowin = y >= 0 && y < H;
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
@@ -168,7 +169,7 @@ __device__ __forceinline__ DwRow dw_load_row_bn(csn_buf rb, int y, int H, int x0
 template <bool VEC, typename AT = float, bool STATS = false>
 __device__ __forceinline__ void dw_emit(AT* __restrict__ op, int y, int yend, int x0, int W,
                                         const float (&w)[9], float sc, float sh, float al, const DwRow& top,
-                                        const DwRow& mid, const DwRow& bot, double* st = nullptr) {
+                                        const DwRow& mid, const DwRow& bot, double* st = nullptr, float* oret = nullptr) {
   if (y >= yend) return;
   float o[4];
 #pragma unroll
@@ -193,6 +194,10 @@ __device__ __forceinline__ void dw_emit(AT* __restrict__ op, int y, int yend, in
         st[0] += v;
         st[1] += v * v;
       }
+  }
+  if (oret) {   // the values as STORED
+#pragma unroll
+    for (int j = 0; j < 4; ++j) oret[j] = sizeof(AT) == 2 ? csn_bf2f(csn_f2bf(o[j])) : o[j];
   }
   if (VEC) {
     act_st4(q, make_float4(o[0], o[1], o[2], o[3]));
@@ -313,6 +318,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
   float s[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) s[t] = 0.f;
+  double rs[3] = {0.0, 0.0, 0.0};
   if (active) {
     const unsigned nb = (unsigned)(H * W) * (unsigned)sizeof(AT);
     const csn_buf gb = csn_make_buf_n(act_cast<AT>(br.in) + (int64_t)pc * H * W, nb);     // dz (BNF: dy of the first consumer)
@@ -357,19 +363,37 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
     };
     float isc = 1.f, ish = 0.f, ial = 1.f;
     if (XBN) { isc = csn_const(br.in_scale)[c]; ish = csn_const(br.in_shift)[c]; ial = csn_const(br.in_alpha)[c]; }
-    auto load_x = [&](int y) {
-      if (XBN) return dw_load_row_bn<VEC, AT>(xb, y, H, x0, W, has_l, has_r, isc, ish, ial);
+    float imu = 0.f, iis = 0.f;
+    if (XBN) { imu = csn_const(br.in_mean)[c]; iis = csn_const(br.in_invstd)[c]; }
+    float zc1[4] = {0.f, 0.f, 0.f, 0.f}, zc2[4];   // XBN: raw z of the producer at the centre columns of rows y, y + 1
+    auto load_x = [&](int y, float* zc) {
+      if (XBN) return dw_load_row_bn<VEC, AT>(xb, y, H, x0, W, has_l, has_r, isc, ish, ial, zc);
       return dw_load_row<VEC, AT>(xb, y, x0, W, has_l, has_r);
     };
     DwRow g0 = load_g(y0 - 1);
     DwRow g1 = load_g(y0);
-    DwRow u0 = load_x(y0 - 1);
-    DwRow u1 = load_x(y0);
+    DwRow u0 = load_x(y0 - 1, nullptr);
+    DwRow u1 = load_x(y0, zc1);
     const int yend = min(y0 + br.R, H);
     for (int y = y0; y < yend; ++y) {
       const DwRow g2 = load_g(y + 1);
-      const DwRow u2 = load_x(y + 1);
-      dw_emit<VEC, AT>(op, y, yend, x0, W, w, 1.f, 0.f, 1.f, g0, g1, g2);
+      const DwRow u2 = load_x(y + 1, zc2);
+      float dxv[4];
+      dw_emit<VEC, AT>(op, y, yend, x0, W, w, 1.f, 0.f, 1.f, g0, g1, g2, nullptr, XBN ? dxv : nullptr);
+      if (XBN) {   // the producer's BatchNorm-backward sums (bn_bwd_reduce_kernel's arithmetic): dy = the dx just stored
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (VEC || x0 + j < W) {
+            const float z = zc1[j], dy = dxv[j];
+            const float bn = z * isc + ish;
+            const float dbn = bn > 0.f ? dy : ial * dy;
+            rs[0] += (double)dbn;
+            rs[1] += (double)dbn * (double)((z - imu) * iis);
+            if (!(bn > 0.f)) rs[2] += (double)dy * (double)bn;
+          }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) zc1[j] = zc2[j];
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float g = (VEC || x0 + j < W) ? g1.v[j + 1] : 0.f;
@@ -385,11 +409,16 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
 #pragma unroll
   for (int t = 0; t < 9; ++t) sv[t] = (double)s[t];
   bn_block_sum_n<9>(sv, sm);
+  if (XBN) bn_block_sum_n<3>(rs, sm);
   if (tid == 0) {
     const int b = pc / br.C;
     double* o = br.stats + ((int64_t)c * CSN_BN_NSLAB + (int64_t)b * tiles + tile) * 9;
 #pragma unroll
     for (int t = 0; t < 9; ++t) o[t] = sv[t];
+    if (XBN) {
+      double* q = br.bnred + ((int64_t)c * CSN_BN_NSLAB + (int64_t)b * tiles + tile) * 3;
+      q[0] = rs[0]; q[1] = rs[1]; q[2] = rs[2];
+    }
   }
 }
 

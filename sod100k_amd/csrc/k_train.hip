@@ -608,7 +608,8 @@ int csn_launch_bn_bwd(const BnBwdArgs& a0, void* stream) {
   BnBwdArgs a = a0;
   a.cpp = bn_cpp(a.S, a.C, a.HW);
   a.nslab = bn_nslab(a.S, a.cpp);
-  CSN_LAUNCH_AT(a.a16, bn_bwd_reduce_kernel, dim3(a.nslab, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
+  if (a.nslab_in > 0) a.nslab = a.nslab_in;
+  else CSN_LAUNCH_AT(a.a16, bn_bwd_reduce_kernel, dim3(a.nslab, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   CSN_LAUNCH(bn_bwd_finalize_kernel, dim3(a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   if (!a.skip_apply) CSN_LAUNCH_AT(a.a16, bn_bwd_apply_kernel, dim3(a.C, a.S), dim3(CSN_BLOCK), 0, stream, a);
   return (int)hipGetLastError();
