@@ -661,7 +661,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
     if (ub.need_dx[i] && ub.zero_dx[i]) {
       const Act& A = P.acts[d.in_act[i]];
       const int lvl = ub.dxp_off[i] >= 0 ? u.base_lvl + i : A.lvl;
-      HIP_TRY(hipMemsetAsync(bd.dx[i], 0, (size_t)S * d.cin[i] * (P.H >> lvl) * (P.W >> lvl) * sizeof(float),
+      HIP_TRY(hipMemsetAsync(bd.dx[i], 0, (size_t)S * d.cin[i] * (P.H >> lvl) * (P.W >> lvl) * (c.a16 ? 2 : 4),
                              (hipStream_t)c.stream));
     }
   for (const DataLaunch& dl : ub.data) {
@@ -697,12 +697,40 @@ int csn_plan_enable_training(csn_plan* P) {
   if (P->S != P->B) { g_hip_err = "training needs the whole batch in one slice (sub_batch = 0)"; return CSN_E_UNSUPPORTED; }
   Builder bl(*P);
   const int na = (int)P->acts.size(), nu = (int)P->units.size();
+  if (P->act16) {
+    // CSN_OPT_TRAIN_BF16 is already set: re-lay the regions csn_plan_create allocated with 2-byte activation elements (the
+    // same allocation order; every field that holds one of the old offsets is mapped) and size everything below accordingly
+    std::vector<csn_plan::WsAlloc> old = P->ws_allocs;
+    P->ws_allocs.clear();
+    P->ws_bytes = 0;
+    P->act_half = true;
+    std::vector<std::pair<int64_t, int64_t>> map;
+    for (const csn_plan::WsAlloc& r : old) map.push_back({r.off, bl.alloc_ws(r.act ? r.bytes / 2 : r.bytes, r.act)});
+    auto mv = [&](int64_t& off) {
+      if (off < 0) return;
+      for (const auto& m : map)
+        if (m.first == off) { off = m.second; return; }
+      off = -2;   // (not a region of the workspace: caught below)
+    };
+    bool ok = true;
+    for (int i = 1; i < na; ++i) { mv(P->acts[i].ws_off); ok = ok && P->acts[i].ws_off != -2; }
+    mv(P->pen_off); ok = ok && P->pen_off != -2;
+    for (UnitPlan& u : P->units) {
+      for (int i = 0; i < 3; ++i) {
+        mv(u.pooled_off[i]); mv(u.mp_off[i]); mv(u.stats_off[i]); mv(u.gap_off[i]);
+        ok = ok && u.pooled_off[i] != -2 && u.mp_off[i] != -2 && u.stats_off[i] != -2 && u.gap_off[i] != -2;
+      }
+      mv(u.z_off); mv(u.logits_off);
+      ok = ok && u.z_off != -2 && u.logits_off != -2;
+    }
+    if (!ok) { g_hip_err = "workspace re-layout for bfloat16 tensors: unknown region"; return CSN_E_INVALID; }
+  }
   P->tz_off.assign(na, -1);
   P->tg_off.assign(na, std::array<int64_t, 2>{-1, -1});
   P->n_cons.assign(na, 0);
   int maxc = 1;
   for (int i = 1; i < na; ++i) {
-    P->tz_off[i] = bl.alloc_ws(bl.act_bytes(P->acts[i].channels, P->acts[i].lvl));
+    P->tz_off[i] = bl.alloc_act(P->acts[i].channels, P->acts[i].lvl);
     maxc = std::max(maxc, P->acts[i].channels);
   }
   for (int k = 0; k < nu; ++k) {
@@ -712,7 +740,7 @@ int csn_plan_enable_training(csn_plan* P) {
       if (u.d.cin[i] == 0 || a <= 0) continue;
       if (P->n_cons[a] >= 2) { g_hip_err = "an activation with more than two consumers"; return CSN_E_UNSUPPORTED; }
       u.in_slot[i] = P->n_cons[a]++;
-      P->tg_off[a][u.in_slot[i]] = bl.alloc_ws(bl.act_bytes(P->acts[a].channels, P->acts[a].lvl));
+      P->tg_off[a][u.in_slot[i]] = bl.alloc_act(P->acts[a].channels, P->acts[a].lvl);
     }
     if (u.d.kind == CSN_UNIT_CLS) continue;
     for (int j = 0; j < u.d.n_out; ++j) {
@@ -731,11 +759,11 @@ int csn_plan_enable_training(csn_plan* P) {
         // autograd would have it -- one zero-filled gradient buffer, cleared at the start of every backward
         const int a = u.d.out_act[j];
         P->n_cons[a] = 1;
-        P->tg_off[a][0] = bl.alloc_ws(bl.act_bytes(P->acts[a].channels, P->acts[a].lvl));
+        P->tg_off[a][0] = bl.alloc_act(P->acts[a].channels, P->acts[a].lvl);
         P->orphan_acts.push_back(a);
       }
   }
-  P->x16_off = bl.alloc_ws(bl.act_bytes(P->acts[0].channels, 0) / 2);   // bf16 copy of the input batch (CSN_OPT_TRAIN_BF16)
+  P->x16_off = bl.alloc_ws((int64_t)P->S * P->acts[0].channels * P->H * P->W * 2);   // bf16 copy of the input batch (CSN_OPT_TRAIN_BF16)
   P->red_off = bl.alloc_ws((int64_t)maxc * CSN_BN_NSLAB * 9 * sizeof(double));
   P->red2_off = bl.alloc_ws((int64_t)maxc * CSN_BN_NSLAB * 9 * sizeof(double));   // ... of the weight-gradient side lane
   P->bwd.clear();
@@ -856,7 +884,7 @@ int csn_backward(csn_plan* P, const float* x, const float* dy, void* workspace, 
     const BwdCtx b{c, arena, grad, flop_w, pen_scale};
     for (int a : P->orphan_acts)
       HIP_TRY(hipMemsetAsync(c.ws + P->tg_off[a][0], 0, (size_t)P->S * P->acts[a].channels * (P->H >> P->acts[a].lvl) *
-                                                           (P->W >> P->acts[a].lvl) * sizeof(float), (hipStream_t)s));
+                                                           (P->W >> P->acts[a].lvl) * (c.a16 ? 2 : 4), (hipStream_t)s));
     for (int u = (int)P->units.size() - 1; u >= 0; --u) {
       const int st = run_unit_bwd(b, u, dy);
       if (st != CSN_OK) return st;

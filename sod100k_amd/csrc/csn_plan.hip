@@ -209,6 +209,11 @@ struct csn_plan {
   int pen_slots = 0;
   bool train = false;
   bool act16 = false;                           // CSN_OPT_TRAIN_BF16: train-mode activations / gradients are bfloat16
+  // ... and, when the option was set BEFORE csn_plan_enable_training, every activation-typed region of the workspace is laid
+  // out for 2-byte elements (round 3: 61 -> 31 GiB at batch 256); such a plan runs the bf16 train step only
+  bool act_half = false;
+  struct WsAlloc { int64_t off, bytes; bool act; };
+  std::vector<WsAlloc> ws_allocs;               // every region of the workspace, in allocation order
   int64_t x16_off = -1;                         // bf16 copy of the input batch (workspace bytes)
   std::vector<int64_t> tz_off;                  // per act: raw conv output z, later dz (workspace bytes)
   std::vector<std::array<int64_t, 2>> tg_off;   // per act: gradient buffer per consumer
@@ -238,11 +243,14 @@ struct Builder {
     P.packed_floats += align_up(n > 0 ? n : 1, 4);
     return off;
   }
-  int64_t alloc_ws(int64_t bytes) {
+  // act: the region holds activation-typed elements (float, or bfloat16 in the bf16 train mode -- see relayout_half)
+  int64_t alloc_ws(int64_t bytes, bool act = false) {
     const int64_t off = P.ws_bytes;
-    P.ws_bytes += align_up(bytes, 256);
+    P.ws_bytes += align_up(bytes > 0 ? bytes : 1, 256);   // (never two regions at one offset: relayout_half maps by offset)
+    P.ws_allocs.push_back({off, bytes, act});
     return off;
   }
+  int64_t alloc_act(int C, int lvl) { return alloc_ws(act_bytes(C, lvl), true); }
   void job(int kind, int n, int64_t dst, int64_t s0 = -1, int64_t s1 = -1, int64_t s2 = -1, int64_t s3 = -1,
            float p0f = 1.f, int p0 = 0, int p1 = 0, int p2 = 0, int p3 = 0) {
     CsnPrepJob j;
@@ -259,7 +267,7 @@ struct Builder {
     return e;
   }
   int64_t act_bytes(int C, int lvl) const {
-    return (int64_t)P.S * C * (P.H >> lvl) * (P.W >> lvl) * (int64_t)sizeof(float);
+    return (int64_t)P.S * C * (P.H >> lvl) * (P.W >> lvl) * (int64_t)(P.act_half ? 2 : 4);
   }
 };
 
@@ -499,7 +507,7 @@ int plan_goct(Builder& bl, UnitPlan& u) {
       if (d.in_act[i] < 0 || d.in_act[i] >= (int)P.acts.size()) FAIL(CSN_E_INVALID, "in_act");
       const Act& a = P.acts[d.in_act[i]];
       if (a.channels != d.cin[i] || a.lvl + ds != base + i) FAIL(CSN_E_INVALID, "input resolution/channels");
-      if (ds && !std_s2) u.pooled_off[i] = bl.alloc_ws(bl.act_bytes(d.cin[i], base + i));
+      if (ds && !std_s2) u.pooled_off[i] = bl.alloc_act(d.cin[i], base + i);
     }
   const int nb = d.n_in > d.n_out ? d.n_in : d.n_out;
   if (((P.H >> (base + nb - 1)) << (base + nb - 1)) != P.H || ((P.W >> (base + nb - 1)) << (base + nb - 1)) != P.W)
@@ -517,7 +525,7 @@ int plan_goct(Builder& bl, UnitPlan& u) {
   if (d.ksize == 3 && (d.n_in > 2 || d.n_out > 2)) FAIL(CSN_E_UNSUPPORTED, "3x3 gOctConv with three branches");
   if (z_path) {
     u.z_C = d.cout[0];
-    u.z_off = bl.alloc_ws(bl.act_bytes(u.z_C, base + 1));
+    u.z_off = bl.alloc_act(u.z_C, base + 1);
     PwLaunchPlan L;
     L.lvl = base + 1;
     PwPassPlan ps;
@@ -580,7 +588,7 @@ int plan_goct(Builder& bl, UnitPlan& u) {
   add_launch(u.pwl, L);
   if (d.ksize == 3 && !u.std_conv)   // 2x2 max-pooled copies of the inputs that feed a high -> low 3x3 slice (c3q_kernel)
     for (int i = 0; i + 1 < d.n_out && i < d.n_in; ++i)
-      if (d.cin[i] > 0 && d.cout[i + 1] > 0) u.mp_off[i] = bl.alloc_ws(bl.act_bytes(d.cin[i], base + i + 1));
+      if (d.cin[i] > 0 && d.cout[i + 1] > 0) u.mp_off[i] = bl.alloc_act(d.cin[i], base + i + 1);
   u.c3 = d.ksize == 3 && !std_s2;
   for (PwLaunchPlan& l : u.pwl) {
     const int st = finish_launch(bl, l);
@@ -743,7 +751,7 @@ int plan_cls(Builder& bl, UnitPlan& u) {
   const Act& ai = P.acts[d.in_act[0]];
   if (ai.channels != d.cin[0] || ai.lvl != 1) FAIL(CSN_E_INVALID, "cls: input must be at H/2");  // csnet.py:380-385
   u.base_lvl = 1;
-  u.logits_off = bl.alloc_ws(bl.act_bytes(1, 1));
+  u.logits_off = bl.alloc_act(1, 1);
   PwLaunchPlan L;
   L.lvl = 1;
   PwPassPlan ps;
@@ -1452,7 +1460,7 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
     P->acts[i].channels = acts[i].channels;
     P->acts[i].lvl = acts[i].lvl;
     if (acts[i].channels <= 0 || acts[i].lvl < 0 || acts[i].lvl > 4) { delete P; return CSN_E_INVALID; }
-    P->acts[i].ws_off = (i == 0) ? -1 : bl.alloc_ws(bl.act_bytes(acts[i].channels, acts[i].lvl));
+    P->acts[i].ws_off = (i == 0) ? -1 : bl.alloc_act(acts[i].channels, acts[i].lvl);
   }
   P->units.resize(n_units);
   for (int k = 0; k < n_units; ++k) {
@@ -1605,7 +1613,9 @@ int csn_plan_set_option(csn_plan* P, int32_t option, int32_t value) {
     case CSN_OPT_SLICE_LANES: P->slice_lanes = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_FUSE_ILB: return CSN_OK;   // retired (round 3): accepted and ignored
     case CSN_OPT_OVERLAP: P->overlap = value != 0; P->overlap_bwd = value == 2; drop_graph(P); return CSN_OK;
-    case CSN_OPT_TRAIN_BF16: P->act16 = value != 0; drop_graph(P); return CSN_OK;
+    case CSN_OPT_TRAIN_BF16:
+      if (P->act_half && value == 0) { g_hip_err = "the workspace of this plan is laid out for bfloat16 tensors"; return CSN_E_STATE; }
+      P->act16 = value != 0; drop_graph(P); return CSN_OK;
     default: return CSN_E_INVALID;
   }
 }
@@ -1645,6 +1655,7 @@ static int forward_body(csn_plan* P, const float* x, float* y, void* workspace, 
                         float* unit_ms) {
   if (!P || !x || !y || !workspace) return CSN_E_INVALID;
   if (!P->params_ready || P->bn_tables_train) return CSN_E_STATE;   // train forward rewrote the BN tables
+  if (P->act_half) { g_hip_err = "plan laid out for the bfloat16 train step: no fp32 eval forward"; return CSN_E_STATE; }
   const int nu = (int)P->units.size();
   const bool prof = unit_ms != nullptr;
   if (prof) {

@@ -188,3 +188,25 @@ def test_emu_one_pass_depthwise_kernels_against_the_two_pass_scheme(emu_lib, x2_
     """fp32: activations formed on load + BatchNorm backward apply inside the depthwise backward = the stored scheme, gradient
     for gradient (bf16 storage has fewer rounding points that way: judged per unit by check_train_units_local)."""
     print(P.check_bn_bwd_fusion_bit_identical(emu_lib, CPU, x2_manifest, B=2, size=32, act_dtype="fp32"))
+
+
+def test_bf16_train_plan_has_bf16_sized_workspace(emu_lib, x2_manifest):
+    """With bfloat16 storage chosen before the training buffers are laid out, every activation-typed region of the workspace has
+    2-byte elements (batch 256: 61 -> 31 GiB); such a plan refuses the fp32 eval forward and a switch back to fp32 storage."""
+    from sod100k_amd import _native as N
+    x = torch.zeros(2, 3, 224, 224)   # (plans only: at this size the activations outweigh the fixed-size reduction tables)
+    sizes = {}
+    for dt in ("fp32", "bf16"):
+        m, _ = P.make_model(emu_lib, x2_manifest, CPU)
+        m.set_train_act_dtype(dt)
+        eng = m.engine_for(x, train=True)
+        sizes[dt] = eng.workspace.numel()
+        if dt == "bf16":
+            with pytest.raises(RuntimeError):
+                eng.forward(x)
+            with pytest.raises(RuntimeError):
+                eng.set_option(N.OPT_TRAIN_BF16, 0)
+    # the float / double tables (statistics partials, |GAP| tables, weight-gradient partials: 175 MB whatever the batch) do
+    # not shrink: 0.63 here, 0.54 at batch 8, 0.50 at batch 256
+    assert sizes["bf16"] < 0.65 * sizes["fp32"], sizes
+    print(sizes)

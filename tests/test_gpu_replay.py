@@ -276,6 +276,9 @@ def test_gpu_train_bf16_replay_and_batch256(hip, x2_manifest):
             m.clear_flops()
             outs.append((float(loss), float(pen), tr.grad.clone()))
         stats = {k: v.cpu().clone() for k, v in m.state_dict().items() if "running_" in k}
+        if x.shape[0] == B:   # bfloat16 tensors in bfloat16-sized regions: 31 GiB at batch 256 (61 GiB with fp32-sized slots)
+            gib = m.engine_for(xd, train=True).workspace.numel() / 2 ** 30
+            assert gib < 36.0, gib
         del tr, m
         gc.collect()
         torch.cuda.empty_cache()
