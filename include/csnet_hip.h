@@ -117,10 +117,13 @@ void csn_plan_destroy(csn_plan* plan);
  * CSN_OPT_TRAIN_BF16 [0]: BASELINE config 3's dtype -- csn_forward_train / csn_backward keep every activation and activation
  * gradient in the workspace as bfloat16 (round-to-nearest-even on store; all arithmetic, the BN statistics, the weight
  * gradients, parameters and optimizer state stay fp32 / fp64).  x, y, dy at the boundary stay float.  Needs
- * csn_plan_enable_training; csn_forward (eval) is unaffected and stays fp32 (the 1e-4 parity configuration).
+ * csn_plan_enable_training; csn_forward (eval) is unaffected and stays fp32 (the 1e-4 parity configuration).  Set BEFORE
+ * csn_plan_enable_training (and the workspace query), every activation-typed region of the workspace is laid out with 2-byte
+ * elements (batch 256: 61 -> 31 GiB); such a plan runs the bf16 train step only -- csn_forward and a switch back to 0 return
+ * CSN_E_STATE.  Set afterwards, the tensors keep fp32-sized regions (first half used) and the option can be toggled.
  * CSN_OPT_PW4 [1]: 1x1 gOctaveCBR units with two input branches run on pw4_kernel (k_pw4.hip: lane = low pixel + its 2x2
  * high quad, v_mfma_f32_4x4x1 straight from the load registers, no LDS panel / transpose); 0 = goct_pw_kernel for every
- * 1x1 unit (the round-1/2 path; also what the train-mode forward and the input gradients still use).
+ * 1x1 unit (the round-1/2 path; three-branch input gradients and odd geometries stay on it).
  * CSN_OPT_C3Q [1]: 3x3 gOctConv forward passes at an even resolution run on c3q_kernel (k_c3q.hip: lane = 2x2 output quad,
  * v_mfma_f32_4x4x1 from the load registers, max-pooled copies of the finer branch written by pool2_kernel); 0 =
  * goct_c3_kernel (which also serves bf16 storage, odd sizes and the backward-data launches).
