@@ -319,6 +319,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
 #pragma unroll
   for (int t = 0; t < 9; ++t) s[t] = 0.f;
   double rs[3] = {0.0, 0.0, 0.0};
+  float rf[3] = {0.f, 0.f, 0.f};   // per lane: <= 64 terms in fp32 (like the nine weight-gradient sums), fp64 across the block
   if (active) {
     const unsigned nb = (unsigned)(H * W) * (unsigned)sizeof(AT);
     const csn_buf gb = csn_make_buf_n(act_cast<AT>(br.in) + (int64_t)pc * H * W, nb);     // dz (BNF: dy of the first consumer)
@@ -387,9 +388,9 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
             const float z = zc1[j], dy = dxv[j];
             const float bn = z * isc + ish;
             const float dbn = bn > 0.f ? dy : ial * dy;
-            rs[0] += (double)dbn;
-            rs[1] += (double)dbn * (double)((z - imu) * iis);
-            if (!(bn > 0.f)) rs[2] += (double)dy * (double)bn;
+            rf[0] += dbn;
+            rf[1] = fmaf(dbn, (z - imu) * iis, rf[1]);
+            rf[2] = fmaf(bn > 0.f ? 0.f : dy, bn, rf[2]);
           }
 #pragma unroll
         for (int j = 0; j < 4; ++j) zc1[j] = zc2[j];
@@ -409,7 +410,11 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
 #pragma unroll
   for (int t = 0; t < 9; ++t) sv[t] = (double)s[t];
   bn_block_sum_n<9>(sv, sm);
-  if (XBN) bn_block_sum_n<3>(rs, sm);
+  if (XBN) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) rs[t] = (double)rf[t];
+    bn_block_sum_n<3>(rs, sm);
+  }
   if (tid == 0) {
     const int b = pc / br.C;
     double* o = br.stats + ((int64_t)c * CSN_BN_NSLAB + (int64_t)b * tiles + tile) * 9;
