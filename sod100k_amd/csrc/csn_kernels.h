@@ -64,6 +64,8 @@ struct DwBranch {
                          // one per (image, tile): slab = b * tiles_x * tiles_y + tile (null: none)
   float* pool;           // dw3x3x2 only: 2x2 average of the pair's output [B*C][H/2][W/2] for the stride-2 unit that
                          // follows (csnet.py:679-680), null = none;  skip_out: that unit is the only reader
+  float* pool_mp = nullptr;   // dw3x3x2 only, with `pool`: 2x2 MAXIMUM of those averages [B*C][H/4][W/4] -- the copy c3q_kernel's
+                              // high -> low slice of that stride-2 unit reads (F.max_pool2d, csnet.py:708-714); R % 4 == 0 then
   int32_t skip_out;
   int32_t C, H, W;
   int32_t LX, NY, R;          // lanes per row (4 px each), lane rows per block, rows per lane

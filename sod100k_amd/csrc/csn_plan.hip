@@ -118,6 +118,7 @@ struct UnitPlan {
   int pool_unit = -1;  // DW (first of a fused pair): index of the stride-2 unit whose pooled inputs the pair writes
   int pool_skip[3] = {0, 0, 0};   // ... and that unit is the only reader of branch i (full-resolution store skipped)
   int pooled_by_producer = 0;     // GOCT stride 2: the preceding fused depthwise pair delivers the pooled inputs
+  int mp_producer = -1;           // ... index of that pair's first unit
   Epi out_epi[3];                        // folded BN/PReLU tables of every output branch (train mode rewrites them)
   int64_t stats_off[3] = {-1, -1, -1};   // workspace byte offsets of the BN statistics partials
   // training (csn_plan_enable_training): per output branch batch mean / invstd / backward means (packed offsets),
@@ -176,6 +177,7 @@ struct csn_plan {
   bool bn_fwd_fuse = true;    // activations consumed only by a depthwise unit are formed on load (virt_cons; CSN_BN_FWD_FUSE=0: off)
   bool debug_dz = false;      // CSN_DEBUG_DZ (tests): the skipped passes (y of virt_cons activations, dz below) still run for the probes
   // CSN_DEBUG_DZ: ... and the apply pass still runs AFTER that kernel, so that the probes see dz (tests)
+  bool no_mp_fuse = false;    // CSN_NO_MP_FUSE: the max-pooled copies of c3q_kernel always come from pool2_kernel (experiments)
   bool pw4_nosplit = false;   // CSN_PW4_NOSPLIT: no extra M groups on small maps (experiments)
   bool overlap_bwd = false;   // CSN_OPT_OVERLAP value 2: also the weight-gradient side lane of csn_backward
   bool overlap = true;    // CSN_OPT_OVERLAP: independent launches of a unit (and the MSBlocks) on parallel stream lanes
@@ -816,13 +818,14 @@ struct Ctx {
 };
 
 // rows per lane of the fused depthwise pair: the intermediate tile (NY*R + 2 rows) must stay small in LDS
-int choose_dw2_rows(int H, int NY, int LX, bool even = false) {
-  int best = even ? 2 : 1;
+int choose_dw2_rows(int H, int NY, int LX, bool even = false, bool quad = false) {
+  const int step = quad ? 4 : (even ? 2 : 1);   // even: the pair also writes 2x2 averages; quad: ... and their 2x2 maxima
+  int best = step;
   double best_s = -1;
-  for (int R = even ? 2 : 1; R <= 16; R += even ? 2 : 1) {
+  for (int R = step; R <= 16; R += step) {
     const int rows = NY * R;
     const size_t lds = (size_t)(rows + 2) * (LX * 4 + 8) * 4;
-    if (lds > 36 * 1024 && R > (even ? 2 : 1)) break;
+    if (lds > 36 * 1024 && R > step) break;
     const int tiles = (H + rows - 1) / rows;
     const double eff = (double)H / ((double)tiles * rows);
     const double s = eff * rows / (rows + 4.0);   // halo rows are fetched and computed twice
@@ -857,6 +860,19 @@ int dw_stats_slabs(const csn_plan& P, int lvl) {
   const int64_t n = (int64_t)P.S * tiles_x * tiles_y;
   return n <= CSN_BN_NSLAB ? (int)n : 0;
 }
+// The fused depthwise pair in front of a stride-2 3x3 unit writes that unit's avg-pooled inputs; when the unit runs on c3q_kernel
+// its high -> low slice of branch k reads a 2x2 max-pooled copy of them: the pair writes that too (no pool2_kernel launch)
+bool dw_pair_writes_mp(const csn_plan& P, const UnitPlan& pair, int k) {
+  if (pair.pool_unit < 0 || !P.fuse_dw || !P.c3q || !P.tiled3 || P.no_mp_fuse) return false;
+  const UnitPlan& su = P.units[pair.pool_unit];
+  if (su.d.ksize != 3 || su.mp_off[k] < 0) return false;
+  bool uses = false;
+  for (const PwLaunchPlan& L : su.pwl) uses = uses || L.c3q;
+  const Act& act = P.acts[pair.d.in_act[k]];
+  const int H = P.H >> act.lvl, W = P.W >> act.lvl;
+  return uses && (H % 4) == 0 && (W % 4) == 0;
+}
+
 // ... for every branch of a depthwise unit, or for none
 bool dw_unit_stats(const csn_plan& P, const UnitPlan& u) {
   if (u.d.kind != CSN_UNIT_DW) return false;
@@ -1085,11 +1101,13 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
           br.scale_b = c.pk(next->dw_epi[k].scale); br.shift_b = c.pk(next->dw_epi[k].shift);
           br.alpha_b = c.pk(next->dw_epi[k].alpha);
           const bool pool = u.pool_unit >= 0 && (br.W % 4) == 0;
+          const bool mp = pool && dw_pair_writes_mp(P, u, k);
           if (pool) {   // the stride-2 unit that follows reads only the 2x2 averages
             br.pool = reinterpret_cast<float*>(c.ws + P.units[u.pool_unit].pooled_off[k]);
             br.skip_out = u.pool_skip[k];
+            if (mp) br.pool_mp = reinterpret_cast<float*>(c.ws + P.units[u.pool_unit].mp_off[k]);
           }
-          br.R = choose_dw2_rows(br.H, br.NY, br.LX, pool);
+          br.R = choose_dw2_rows(br.H, br.NY, br.LX, pool, mp);
         } else {
           br.R = choose_dw_rows(br.H, br.NY);
         }
@@ -1229,6 +1247,11 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
         int blk = 0;
         for (int i = 0; i < d.n_in && uses; ++i) {
           if (u.mp_off[i] < 0 || !xin[i]) continue;
+          if (d.stride == 2 && u.pooled_by_producer && P.fuse_dw && !c.raw && u.mp_producer >= 0 &&
+              dw_pair_writes_mp(P, P.units[u.mp_producer], i)) {   // the depthwise pair in front has written it
+            bd.mp[i] = reinterpret_cast<float*>(c.ws + u.mp_off[i]);
+            continue;
+          }
           const int k = pa.n++;
           pa.in[k] = xin[i];
           pa.out[k] = reinterpret_cast<float*>(c.ws + u.mp_off[i]);
@@ -1449,6 +1472,7 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   if (const char* v = std::getenv("CSN_PW4_GRID")) { if (std::atoi(v) >= 8) P->pw4_grid = std::atoi(v); }
   if (std::getenv("CSN_PW4_NOSPLIT")) P->pw4_nosplit = true;
   if (std::getenv("CSN_PW4_NOQ")) P->pw4_no_q = true;
+  if (std::getenv("CSN_NO_MP_FUSE")) P->no_mp_fuse = true;
   if (const char* v = std::getenv("CSN_BN_BWD_FUSE")) P->bn_bwd_fuse = v[0] != '0';
   if (const char* v = std::getenv("CSN_DEBUG_DZ")) P->debug_dz = v[0] != '0';
   if (const char* v = std::getenv("CSN_BN_FWD_FUSE")) P->bn_fwd_fuse = v[0] != '0';
@@ -1532,6 +1556,7 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
     if (!ok) continue;
     P->units[k].pool_unit = k + 2;
     P->units[k + 2].pooled_by_producer = 1;
+    P->units[k + 2].mp_producer = k;
     for (int i = 0; i < g.n_in; ++i) {
       if (g.cin[i] == 0) continue;
       bool only = true;

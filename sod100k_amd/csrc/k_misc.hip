@@ -557,6 +557,8 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3x2_bn_prelu_kernel(DwArgs a) {
     const int rs = ly * R;
     DwRow top = ld_row(rs), mid = ld_row(rs + 1);
     float* __restrict__ pp = br.pool ? br.pool + (int64_t)pc * (H >> 1) * (W >> 1) : nullptr;   // R is even then
+    float* __restrict__ pm = br.pool_mp ? br.pool_mp + (int64_t)pc * (H >> 2) * (W >> 2) : nullptr;   // R % 4 == 0 then
+    float mx = 0.f;             // maximum of the first average row of a group of four rows
     float e0 = 0.f, e1 = 0.f;   // left-to-right sums of the even row's two column pairs
     for (int q = 0; q < R; ++q) {
       const int y = yb + rs + q;
@@ -586,6 +588,10 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3x2_bn_prelu_kernel(DwArgs a) {
           pv.x = (e0 + o[0] + o[1]) * 0.25f;
           pv.y = (e1 + o[2] + o[3]) * 0.25f;
           *reinterpret_cast<float2*>(pp + (int64_t)(y >> 1) * (W >> 1) + (x0 >> 1)) = pv;
+          if (pm) {   // the lane's 4 x 4 block holds one 2x2 window of the averages (same values, max is order-free)
+            if ((q & 3) == 1) mx = fmaxf(pv.x, pv.y);
+            else pm[(int64_t)(y >> 2) * (W >> 2) + (x0 >> 2)] = fmaxf(mx, fmaxf(pv.x, pv.y));
+          }
         }
       }
       if (VEC) {

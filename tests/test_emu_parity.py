@@ -210,3 +210,23 @@ def test_bf16_train_plan_has_bf16_sized_workspace(emu_lib, x2_manifest):
     # not shrink: 0.63 here, 0.54 at batch 8, 0.50 at batch 256
     assert sizes["bf16"] < 0.65 * sizes["fp32"], sizes
     print(sizes)
+
+
+def test_emu_max_pooled_copies_from_the_depthwise_pair(emu_lib, x2_manifest, monkeypatch):
+    """The fused depthwise pair in front of a stride-2 3x3 unit writes the 2x2 averages AND their 2x2 maxima (the copy c3q_kernel's
+    high -> low slice reads, F.max_pool2d of csnet.py:708-714): three of the four pool2_kernel launches of the forward are gone
+    (the fourth pools the input image); CSN_NO_MP_FUSE keeps them.  Same logits, bit for bit."""
+    x = torch.from_numpy(I.randn_batch(13, 2, 64, 96))
+    out, census = {}, {}
+    for nofuse in (False, True):
+        if nofuse:
+            monkeypatch.setenv("CSN_NO_MP_FUSE", "1")
+        m, sd = P.make_model(emu_lib, x2_manifest, CPU)
+        out[nofuse] = m(x).clone()
+        eng = m.engine_for(x)
+        eng.profile(x, iters=1)
+        census[nofuse] = eng.kernel_stats().get("pool2_kernel", (0, 0))[1]
+    ref = P.oracle_forward(x2_manifest, sd, x)
+    assert (out[False] - ref).abs().max().item() <= P.TOL
+    assert torch.equal(out[False], out[True])
+    assert (census[False], census[True]) == (1, 4), census
