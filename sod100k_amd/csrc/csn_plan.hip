@@ -171,13 +171,14 @@ struct csn_plan {
   int c3q_cap = 4;        // its row tiles per M group (CSN_C3Q_NT, experiments)
   bool pw4 = true;        // CSN_OPT_PW4: two-branch 1x1 units on pw4_kernel (k_pw4.hip)
   int pw4_grid = 2048;    // its block cap (CSN_PW4_GRID, experiments)
-  int pw4_twl = 4;        // log2 of its widest tile in low pixels (CSN_PW4_TWL, experiments)
+  int pw4_twl = 6;        // log2 of its widest tile in low pixels: whole rows of up to 64 (CSN_PW4_TWL; 4 = 16 x 4 tiles: 1 % slower)
   bool pw4_no_q = false;      // CSN_PW4_NOQ: CSFHead.fuse's lowest output branch stays on goct_pw_kernel (experiments)
   bool bn_bwd_fuse = true;    // depthwise backward forms dz on load, the BatchNorm backward's apply pass is skipped (CSN_BN_BWD_FUSE=0: off)
   bool bn_fwd_fuse = true;    // activations consumed only by a depthwise unit are formed on load (virt_cons; CSN_BN_FWD_FUSE=0: off)
   bool debug_dz = false;      // CSN_DEBUG_DZ (tests): the skipped passes (y of virt_cons activations, dz below) still run for the probes
   // CSN_DEBUG_DZ: ... and the apply pass still runs AFTER that kernel, so that the probes see dz (tests)
   bool no_mp_fuse = false;    // CSN_NO_MP_FUSE: the max-pooled copies of c3q_kernel always come from pool2_kernel (experiments)
+  int c3q_twl = 6;        // ... of c3q_kernel's tile in output quads (CSN_C3Q_TWL)
   bool pw4_nosplit = false;   // CSN_PW4_NOSPLIT: no extra M groups on small maps (experiments)
   bool overlap_bwd = false;   // CSN_OPT_OVERLAP value 2: also the weight-gradient side lane of csn_backward
   bool overlap = true;    // CSN_OPT_OVERLAP: independent launches of a unit (and the MSBlocks) on parallel stream lanes
@@ -825,7 +826,7 @@ int choose_dw2_rows(int H, int NY, int LX, bool even = false, bool quad = false)
   for (int R = step; R <= 16; R += step) {
     const int rows = NY * R;
     const size_t lds = (size_t)(rows + 2) * (LX * 4 + 8) * 4;
-    if (lds > 36 * 1024 && R > step) break;
+    if (lds > 36 * 1024 && R > step) break;   // (56 KB = 56 rows at 224^2, 7 % instead of 12.5 % halo re-reads: 0.93 vs 0.82 ms)
     const int tiles = (H + rows - 1) / rows;
     const double eff = (double)H / ((double)tiles * rows);
     const double s = eff * rows / (rows + 4.0);   // halo rows are fetched and computed twice
@@ -1015,7 +1016,7 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
       q.H = a.H0; q.W = a.W0; q.B = a.B;
       const int Wq = q.W >> 1, Hq = q.H >> 1;
       int twl = 0;
-      while (twl < P.pw4_twl && (1 << twl) < Wq) ++twl;
+      while (twl < P.c3q_twl && (1 << twl) < Wq) ++twl;
       q.twl = twl;
       q.tiles_x = (Wq + (1 << twl) - 1) >> twl;
       q.tiles_y = (Hq + (64 >> twl) - 1) / (64 >> twl);
@@ -1473,6 +1474,7 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   if (std::getenv("CSN_PW4_NOSPLIT")) P->pw4_nosplit = true;
   if (std::getenv("CSN_PW4_NOQ")) P->pw4_no_q = true;
   if (std::getenv("CSN_NO_MP_FUSE")) P->no_mp_fuse = true;
+  if (const char* v = std::getenv("CSN_C3Q_TWL")) { if (std::atoi(v) >= 2 && std::atoi(v) <= 6) P->c3q_twl = std::atoi(v); }
   if (const char* v = std::getenv("CSN_BN_BWD_FUSE")) P->bn_bwd_fuse = v[0] != '0';
   if (const char* v = std::getenv("CSN_DEBUG_DZ")) P->debug_dz = v[0] != '0';
   if (const char* v = std::getenv("CSN_BN_FWD_FUSE")) P->bn_fwd_fuse = v[0] != '0';
