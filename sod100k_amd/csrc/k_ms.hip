@@ -99,125 +99,13 @@ __global__ __launch_bounds__(CSN_BLOCK) void msblock_kernel(MsArgs a) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------ four pixels per lane
-// Round 3 (profiles/r3_notes.md): the per-pixel kernel above is bound by L1 tag traffic, not arithmetic -- its tap loads are
-// 64 x 4 B rows shifted by the dilation, i.e. 2-3 cache lines per wave-load of which a third of the bytes is used (161 loads
-// per wave and dilation at 8.6 cycles each).  Here a lane owns FOUR consecutive pixels of a row (W % 4 == 0): for the
-// dilations 4, 8, 16 every tap of the quad is ONE aligned 128-bit load (whole cache lines, a quarter of the load
-// instructions), dilations 1 and 2 take the quad plus two edge pieces per row; row / column padding = out-of-range offsets
-// of a bounded buffer resource (a shifted quad is entirely inside or outside the row because x0, W and d are multiples of
-// 4, the edge pieces of d = 1, 2 likewise).  NCO x 4 accumulators, weights wave-uniform (s_load), one dilation per block.
-// DC: column step of the taps inside a lane's row window -- 1, 2 (those dilations) or 4 (dilations 4, 8, 16: whole quads)
-template <int NCO, int DC>
-__device__ __forceinline__ void msq_group(const MsArgs& a, csn_buf rb, const unsigned (&ro)[3], unsigned dl, unsigned dr,
-                                          unsigned cs4, int cinp, csn_cfp wg, float* __restrict__ op, int hw, int g, int d, bool valid) {
-  float acc[NCO][4];
-#pragma unroll
-  for (int co = 0; co < NCO; ++co)
-#pragma unroll
-    for (int p = 0; p < 4; ++p) acc[co][p] = 0.f;
-  for (int ci = 0; ci < a.cin; ++ci) {
-    const unsigned so = (unsigned)ci * cs4;
-    float v[3][12];   // row r: columns x0 - 4 .. x0 + 7 as far as the dilation needs them
-    if (DC == 4) {
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const float4 l = csn_ld4(rb, ro[r] + dl, so), c = csn_ld4(rb, ro[r], so), rr = csn_ld4(rb, ro[r] + dr, so);
-        v[r][0] = l.x; v[r][1] = l.y; v[r][2] = l.z; v[r][3] = l.w;
-        v[r][4] = c.x; v[r][5] = c.y; v[r][6] = c.z; v[r][7] = c.w;
-        v[r][8] = rr.x; v[r][9] = rr.y; v[r][10] = rr.z; v[r][11] = rr.w;
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const float2 l = csn_ld2(rb, ro[r] + dl, so), rr = csn_ld2(rb, ro[r] + dr, so);   // columns x0 - 2, x0 - 1 / x0 + 4, x0 + 5
-        const float4 c = csn_ld4(rb, ro[r], so);
-        v[r][0] = 0.f; v[r][1] = 0.f; v[r][2] = l.x; v[r][3] = l.y;
-        v[r][4] = c.x; v[r][5] = c.y; v[r][6] = c.z; v[r][7] = c.w;
-        v[r][8] = rr.x; v[r][9] = rr.y; v[r][10] = 0.f; v[r][11] = 0.f;
-      }
-    }
-    csn_cfp wc = wg + ci * 72;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int r = t / 3, dx = t % 3 - 1;
-#pragma unroll
-      for (int co = 0; co < NCO; ++co) {
-        const float w = wc[t * 8 + co];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) acc[co][p] = fmaf(w, v[r][4 + DC * dx + p], acc[co][p]);
-      }
-    }
-  }
-  csn_cfp scale = csn_const(a.scale), shift = csn_const(a.shift), alpha = csn_const(a.alpha);
-#pragma unroll
-  for (int co = 0; co < NCO; ++co) {
-    if (valid) {
-      const int oc = a.cobase[d] + g * 8 + co;
-      const float sc = scale[oc], shf = shift[oc], al = alpha[oc];
-      *reinterpret_cast<float4*>(op + (int64_t)oc * hw) =
-          make_float4(csn_epi(acc[co][0], sc, shf, al), csn_epi(acc[co][1], sc, shf, al), csn_epi(acc[co][2], sc, shf, al),
-                      csn_epi(acc[co][3], sc, shf, al));
-    }
-  }
-}
-
-__global__ __launch_bounds__(CSN_BLOCK) void msq_kernel(MsArgs a) {
-  const int H = a.H, W = a.W, QW = W >> 2;
-  const int hw = H * W, nq = H * QW;
-  const int ntx = (nq + CSN_BLOCK - 1) / CSN_BLOCK;
-  // same XCD-aware order as msblock_kernel: the five dilation blocks of a tile go to one XCD, back to back
-  const int slot = blockIdx.x >> 3;
-  const int tile = (slot / 5) * 8 + (blockIdx.x & 7);
-  if (tile >= ntx * a.B) return;
-  const int d = slot % 5;
-  const int nco = a.dch[d];
-  if (nco == 0) return;
-  const int b = tile / ntx;
-  const int q0 = (tile - b * ntx) * CSN_BLOCK + threadIdx.x;
-  const bool valid = q0 < nq;
-  const int q = valid ? q0 : nq - 1;
-  const int y = q / QW, x0 = 4 * (q - y * QW);
-  const int dil = 1 << d;
-  const csn_buf rb = csn_make_buf_n(a.in + (int64_t)b * a.cin * hw, (unsigned)(a.cin * hw) * 4u);
-  unsigned ro[3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const int yy = y + (r - 1) * dil;
-    ro[r] = (yy >= 0 && yy < H) ? (unsigned)(yy * W + x0) * 4u : 0x80000000u;
-  }
-  // left / right piece: a quad at x0 -+ dil (dil >= 4) or the two columns next to the quad (dil = 1, 2)
-  const int step = dil >= 4 ? dil : 2, rstep = dil >= 4 ? dil : 4;
-  const unsigned dl = x0 - step >= 0 ? (unsigned)(-step * 4) : 0x40000000u;
-  const unsigned dr = x0 + rstep + (dil >= 4 ? 3 : 1) < W ? (unsigned)(rstep * 4) : 0x40000000u;
-  float* __restrict__ op = a.out + (int64_t)b * a.cout * hw + (int64_t)y * W + x0;
-  const int cinp = (a.cin + 1) & ~1;
-  const int ngrp = (nco + 7) >> 3;
-  for (int g = 0; g < ngrp; ++g) {
-    csn_cfp wg = csn_const(a.w[d]) + (int64_t)g * cinp * 72;
-    const int live = min(8, nco - 8 * g);
-#define MSQ_CASE(N)                                                                                                        \
-  case N:                                                                                                                   \
-    if (d == 0) msq_group<N, 1>(a, rb, ro, dl, dr, (unsigned)hw * 4u, cinp, wg, op, hw, g, d, valid);                       \
-    else if (d == 1) msq_group<N, 2>(a, rb, ro, dl, dr, (unsigned)hw * 4u, cinp, wg, op, hw, g, d, valid);                  \
-    else msq_group<N, 4>(a, rb, ro, dl, dr, (unsigned)hw * 4u, cinp, wg, op, hw, g, d, valid);                              \
-    break;
-    switch (live) {
-      MSQ_CASE(1) MSQ_CASE(2) MSQ_CASE(3) MSQ_CASE(4) MSQ_CASE(5) MSQ_CASE(6) MSQ_CASE(7)
-      default:
-        if (d == 0) msq_group<8, 1>(a, rb, ro, dl, dr, (unsigned)hw * 4u, cinp, wg, op, hw, g, d, valid);
-        else if (d == 1) msq_group<8, 2>(a, rb, ro, dl, dr, (unsigned)hw * 4u, cinp, wg, op, hw, g, d, valid);
-        else msq_group<8, 4>(a, rb, ro, dl, dr, (unsigned)hw * 4u, cinp, wg, op, hw, g, d, valid);
-        break;
-    }
-#undef MSQ_CASE
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
-// msr_kernel: msq_kernel with vertical reuse.  A lane of msq_kernel loads 9 pieces per channel for one quad of pixels and no
-// piece is used twice (the taps of a dilated window do not overlap); the launch is bound by the number of tap loads going
-// through L1 (profiles/r3_notes.md).  Here a lane owns R quads in rows y0, y0 + d, ..., y0 + (R - 1) d of one column block:
+// msr_kernel: four pixels per lane with vertical reuse.  A lane owns QUADS of four consecutive pixels: for dilations 4 / 8 / 16 every
+// tap of a quad is one aligned 128-bit load (a shifted quad is entirely inside or outside the row because x0, W and d are multiples of
+// 4; row / column padding = out-of-range offsets of a bounded buffer resource), dilations 1 and 2 take the quad plus two edge pairs per
+// row; NCO x 4 accumulators per quad (v_pk_fma_f32 over pixel pairs), weights wave-uniform (s_load), one dilation per wave.  A lane
+// that owned ONE quad (msq_kernel, earlier in round 3) loaded 9 pieces per channel and used none twice (the taps of a dilated window do
+// not overlap): bound by the number of tap loads going through L1 (profiles/r3_notes.md).  Here a lane owns R quads in rows y0, y0 + d, ..., y0 + (R - 1) d of one column block:
 // the rows y0 - d .. y0 + R d serve all of them -- 3 (R + 2) piece loads per channel for R quads instead of 9 R (R = 4: half,
 // for launches with <= 3 output channels per dilation; R = 2: two thirds, <= 8 output channels, there with the next channel's
 // rows in flight during the FMAs -- few waves per SIMD on the 56^2 map).  Measured alternatives (R = 6, 8; two pixels per
@@ -380,26 +268,21 @@ __global__ __launch_bounds__(CSN_BLOCK) void msr_kernel(MsArgs a) {
 
 int csn_launch_ms(const MsArgs& a, void* stream) {
   const int hw = a.H * a.W;
-  static const bool quad = !(std::getenv("CSN_MS_QUAD") && std::getenv("CSN_MS_QUAD")[0] == '0');
-  static const int rows = std::getenv("CSN_MS_ROWS") ? std::atoi(std::getenv("CSN_MS_ROWS")) : 1;   // 0: msq_kernel
+  static const bool rows = !(std::getenv("CSN_MS_ROWS") && std::getenv("CSN_MS_ROWS")[0] == '0');   // 0: one pixel per lane everywhere
   // four pixels per lane (float, rows of whole quads); small maps keep one pixel per lane (28^2 x 64 images is 320 blocks of
   // quads: 42 us against 29 us, profiles/r3_notes.md)
-  if (quad && !a.a16 && (a.W & 3) == 0 && a.H * (a.W >> 2) >= 512) {
+  if (rows && !a.a16 && (a.W & 3) == 0 && a.H * (a.W >> 2) >= 512) {
     int mx = 0;
     for (int d = 0; d < 5; ++d) mx = a.dch[d] > mx ? a.dch[d] : mx;
-    if (rows > 0) {   // R quads per lane in dilation-strided rows (profiles/r3_notes.md: 94 -> 68 us, 62 -> 57 us)
-      const int R = mx <= 3 ? 4 : 2;
-      int wmax = 0;
-      for (int d = 0; d < 5; ++d)
-        if (a.dch[d] > 0) { const int wv = msr_waves(a.H, a.W >> 2, d, R); wmax = wv > wmax ? wv : wmax; }
-      const int bpi = (5 * wmax + 3) >> 2;
-      const dim3 grid((unsigned)(((a.B + 7) / 8) * bpi * 8));
-      if (R == 4) CSN_LAUNCH((msr_kernel<4, false>), grid, dim3(CSN_BLOCK), 0, stream, a);
-      else CSN_LAUNCH((msr_kernel<2, true>), grid, dim3(CSN_BLOCK), 0, stream, a);
-      return (int)hipGetLastError();
-    }
-    const int tq = ((a.H * (a.W >> 2) + CSN_BLOCK - 1) / CSN_BLOCK) * a.B;
-    CSN_LAUNCH(msq_kernel, dim3((unsigned)(((tq + 7) / 8) * 5 * 8)), dim3(CSN_BLOCK), 0, stream, a);
+    // R quads per lane in dilation-strided rows (profiles/r3_notes.md: 94 -> 68 us, 62 -> 57 us)
+    const int R = mx <= 3 ? 4 : 2;
+    int wmax = 0;
+    for (int d = 0; d < 5; ++d)
+      if (a.dch[d] > 0) { const int wv = msr_waves(a.H, a.W >> 2, d, R); wmax = wv > wmax ? wv : wmax; }
+    const int bpi = (5 * wmax + 3) >> 2;
+    const dim3 grid((unsigned)(((a.B + 7) / 8) * bpi * 8));
+    if (R == 4) CSN_LAUNCH((msr_kernel<4, false>), grid, dim3(CSN_BLOCK), 0, stream, a);
+    else CSN_LAUNCH((msr_kernel<2, true>), grid, dim3(CSN_BLOCK), 0, stream, a);
     return (int)hipGetLastError();
   }
   const int tiles = ((hw + CSN_BLOCK - 1) / CSN_BLOCK) * a.B;

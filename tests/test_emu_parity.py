@@ -230,3 +230,21 @@ def test_emu_max_pooled_copies_from_the_depthwise_pair(emu_lib, x2_manifest, mon
     assert (out[False] - ref).abs().max().item() <= P.TOL
     assert torch.equal(out[False], out[True])
     assert (census[False], census[True]) == (1, 4), census
+
+
+def test_emu_backward_with_weight_gradient_side_lane(emu_lib, x2_manifest, monkeypatch):
+    """CSN_OPT_OVERLAP = 2 moves the weight-gradient launches of csn_backward to a side lane (own partial buffers); the depthwise
+    units whose input was never stored stay on the one-pass kernel on the caller's stream (they also write the input gradient).
+    Same gradients as the default schedule, bit for bit (the emulator runs the lanes in order: this checks the bookkeeping --
+    buffers, partial tables, which kernel runs where -- not the concurrency)."""
+    flats = {}
+    for ov in ("1", "2"):
+        monkeypatch.setenv("CSN_OVERLAP", ov)
+        m, sd = P.make_model(emu_lib, x2_manifest, CPU)
+        m.train(); m.set_batchsize(2); m.clear_flops(); m.flops_hook(1.0)
+        x = torch.from_numpy(I.randn_batch(23, 2, 32, 32))
+        t = torch.from_numpy(I.binary_target(24, 2, 32, 32))
+        y, pen = m._train_forward_raw(x)
+        loss, dy = P.bce_and_grad(emu_lib, y, t)
+        flats[ov] = m._train_backward_raw(x, dy, 1.5).clone()
+    assert torch.equal(flats["1"], flats["2"]), float((flats["1"] - flats["2"]).abs().max())
