@@ -248,3 +248,22 @@ def test_emu_backward_with_weight_gradient_side_lane(emu_lib, x2_manifest, monke
         loss, dy = P.bce_and_grad(emu_lib, y, t)
         flats[ov] = m._train_backward_raw(x, dy, 1.5).clone()
     assert torch.equal(flats["1"], flats["2"]), float((flats["1"] - flats["2"]).abs().max())
+
+
+def test_emu_results_do_not_depend_on_the_tile_geometry(emu_lib, x2_manifest, monkeypatch):
+    """pw4_kernel / c3q_kernel tiles as 16 x 4 blocks (CSN_PW4_TWL = CSN_C3Q_TWL = 4) or as whole rows (6, the default): the same
+    per-pixel arithmetic in the same order -- eval logits, train-mode logits and all gradients are equal bit for bit."""
+    out = {}
+    for tw in ("4", "6"):
+        monkeypatch.setenv("CSN_PW4_TWL", tw)
+        monkeypatch.setenv("CSN_C3Q_TWL", tw)
+        m, sd = P.make_model(emu_lib, x2_manifest, CPU)
+        x = torch.from_numpy(I.randn_batch(5, 2, 96, 160))
+        t = torch.from_numpy(I.binary_target(6, 2, 96, 160))
+        ye = m(x).clone()
+        m.train(); m.set_batchsize(2); m.clear_flops(); m.flops_hook(1.0)
+        y, pen = m._train_forward_raw(x)
+        loss, dy = P.bce_and_grad(emu_lib, y, t)
+        out[tw] = (ye, y.clone(), m._train_backward_raw(x, dy, 1.5).clone())
+    for a, b in zip(out["4"], out["6"]):
+        assert torch.equal(a, b)
