@@ -37,7 +37,8 @@ import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-ALG_BYTES_PER_IMAGE = 169_704_640   # SURVEY.md 8(d), csnet-L-x2 fp32 224x224 (cross-checked below)
+ALG_BYTES_PER_IMAGE = 169_654_464   # csnet-L-x2 fp32 224x224: sum of csn_unit_algorithmic_bytes (SURVEY.md 8(d) says 169,704,640:
+                                    # it counts the 50,176 B final map twice); only used when the profile is skipped
 
 
 def _cpu_model():
@@ -186,6 +187,8 @@ def main():
 
     from sod100k_amd.model import csnet as M
     from sod100k_amd.checkpoint import load_manifest_state_dict
+    from sod100k_amd import _native as _N
+    N_SRC_SHA = _N.sources_sha16()
     man = os.path.join(ROOT, "sod100k_amd", "data", "csnet-L-x2.json")
     model = M.build_model(predefine=man)
     sd = load_manifest_state_dict(man)
@@ -253,11 +256,13 @@ def main():
         d = agg[dom]
         bytes_per_launch = d["bytes"] / d["launches"]
         us_per_launch = d["ms"] * 1e3 / d["launches"]
+        bracket_us = eng.profile_bracket_us()
         achieved = bytes_per_launch / (us_per_launch * 1e-6) / 1e9
         # HBM traffic of the dominant kernel: NOT a quantity of this run -- rocprofv3 cannot run inside the bench; it is the
         # per-launch average of the committed counter passes (tools/gpu_pmc_hbm.sh, FETCH_SIZE / WRITE_SIZE calibrated with
         # tools/probes/fetch_cal), labelled with where it came from
         traffic = traffic_src = None
+        traffic_tree_ok = False
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
@@ -266,15 +271,21 @@ def main():
                 if fwd_bytes:
                     traffic = int(fwd_bytes / d["launches"])       # per launch of THIS run's launch count
                 traffic_src = "profiles/pmc_latest.json: " + pj.get("_source", "")
+                traffic_tree_ok = pj.get("_kernel_sources_sha16") == N_SRC_SHA
             except Exception:
                 traffic = None
         total_alg = sum(nbytes)
         total_ms = sum(v["ms"] for v in agg.values() if "ms" in v)
         roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
+                        # the counter file was collected on exactly these kernel sources (sha256 over csrc/): else it is a stale number
+                        traffic_from_this_tree=bool(traffic_tree_ok), kernel_sources_sha16=N_SRC_SHA,
                         bytes_per_launch=int(bytes_per_launch), us_per_launch=round(us_per_launch, 2),
                         launches_per_step=d["launches"],
-                        event_bracket_us=round(eng.profile_bracket_us(), 2),   # subtracted from every per-launch interval
+                        event_bracket_us=round(bracket_us, 2),   # subtracted from every per-launch interval (measured on empty launches)
+                        # ... and the same figures WITHOUT that correction: the raw event-to-event interval per launch
+                        us_per_launch_raw=round(us_per_launch + bracket_us, 2),
+                        frac_raw=round(bytes_per_launch / ((us_per_launch + bracket_us) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                         whole_step=dict(algorithmic_bytes=int(total_alg), events_ms=round(total_ms, 3),
                                         achieved=round(total_alg / (total_ms * 1e-3) / 1e9, 1),
                                         frac=round(total_alg / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
@@ -323,11 +334,13 @@ def main():
             t_bw = t_alg / (tdt / args.train_steps) / 1e9
             # HBM traffic of one step: the committed counter passes (tools/gpu_pmc_train.sh), not a quantity of this run
             t_traffic = t_src = None
+            t_tree_ok = False
             try:
                 pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_train_latest.json")))
                 if TB == 256 and act_dtype in pj:
                     t_traffic = int(pj[act_dtype]["hbm_bytes_per_step"])
                     t_src = "profiles/pmc_train_latest.json: " + pj.get("_source", "")
+                    t_tree_ok = pj.get("_kernel_sources_sha16") == N_SRC_SHA
             except Exception:
                 pass
             rec = {"value": round(world * TB * args.train_steps / tdt, 1), "unit": "images/sec",
@@ -336,7 +349,7 @@ def main():
                    "loss": round(float(tr.loss), 6),
                    "roofline": {"bound": "hbm", "achieved": round(t_bw, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(t_bw / HBM_PEAK_GBS, 4), "bytes_per_step": int(t_alg),
-                                "traffic": t_traffic, "traffic_source": t_src,
+                                "traffic": t_traffic, "traffic_source": t_src, "traffic_from_this_tree": bool(t_tree_ok),
                                 "what": f"algorithmic (3*in + 7*out) x {esz} B per unit (SURVEY 8(d)) / whole-step time"},
                    "what": "train-mode forward (batch-stat BN + penalty) + BCE + backward + "
                            + ("RCCL all-reduce of the flat gradient + " if world > 1 else "") + "Adam, csnet-L-x2 weights"}

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CSN_ABI_VERSION 1
+#define CSN_ABI_VERSION 2   /* 2 (round 4): csn_profile_bracket_us, options 8-10, CSN_OPT_FUSE_ILB retired */
 #define CSN_MAX_BRANCH 3
 #define CSN_NDIL 5
 

@@ -6,6 +6,7 @@ The product path has exactly one backend: the hand-written HIP library compiled 
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
 import os
 import shutil
 import subprocess
@@ -15,7 +16,22 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # SOD100K_HIP_LIB: developer override (A/B builds of the same sources, e.g. the knock-out variants of profiles/r1_notes.md)
 LIB_PATH = os.environ.get("SOD100K_HIP_LIB") or os.path.join(CSRC, "libcsnet_hip.so")
-SOURCES = ("csn_plan.hip", "k_misc.hip", "k_goct_pw.hip", "k_ms.hip", "k_train.hip", "k_wgrad.hip", "k_wgrad_c3.hip", "k_goct_c3.hip", "k_csf.hip", "k_pw4.hip", "k_c3q.hip", "k_pwq.hip")
+SOURCES = ("csn_plan.hip", "k_misc.hip", "k_goct_pw.hip", "k_ms.hip", "k_train.hip", "k_wgrad.hip", "k_wgrad_c3.hip", "k_wgrad_bf.hip", "k_goct_c3.hip", "k_csf.hip", "k_pw4.hip", "k_c3q.hip", "k_pwq.hip")
+
+ABI_VERSION = 2       # include/csnet_hip.h CSN_ABI_VERSION: checked BEFORE the entry points are bound (a stale .so lacks the new ones)
+
+
+def sources_sha16() -> str:
+    """sha256[:16] over the kernel sources (csrc/*.hip, *.h, *.inl): stamps counter files / bench lines with the tree they belong to
+    (the GPU box has no .git)."""
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h", ".inl")):
+            h.update(f.encode())
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
 
 MAX_BRANCH = 3
 NDIL = 5
@@ -238,9 +254,13 @@ def load() -> C.CDLL:
                 f"{LIB_PATH} is missing.  Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  sod100k_amd has no CPU / PyTorch fallback by design.")
         _share_torch_hip_runtime()
-        _lib = bind(C.CDLL(LIB_PATH))
-        if _lib.csn_abi_version() != 1:
-            raise RuntimeError("libcsnet_hip.so ABI version mismatch")
+        raw = C.CDLL(LIB_PATH)
+        raw.csn_abi_version.restype = C.c_int
+        got = raw.csn_abi_version()
+        if got != ABI_VERSION:      # before bind(): a stale library fails here, not with an AttributeError on a new symbol
+            raise RuntimeError(f"{LIB_PATH}: ABI version {got}, this package needs {ABI_VERSION} -- rebuild "
+                               "(python -c 'import __graft_entry__ as g; g.build()')")
+        _lib = bind(raw)
     return _lib
 
 

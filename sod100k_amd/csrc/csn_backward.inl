@@ -691,10 +691,32 @@ csn_plan::~csn_plan() = default;
 
 extern "C" {
 
+static int enable_training_impl(csn_plan* P);
+
+// Transactional: everything the planning below lays out -- the bf16 re-layout of the workspace regions included -- is
+// committed only when the whole call succeeds; a failure (an unsupported graph, a backward plan that does not fit) leaves the
+// plan exactly as csn_plan_create built it, so that eval forwards and a later attempt see consistent offsets.
 int csn_plan_enable_training(csn_plan* P) {
   if (!P) return CSN_E_INVALID;
   if (P->train) return CSN_OK;
   if (P->S != P->B) { g_hip_err = "training needs the whole batch in one slice (sub_batch = 0)"; return CSN_E_UNSUPPORTED; }
+  struct Snapshot {
+    std::vector<Act> acts; std::vector<UnitPlan> units; std::vector<csn_plan::WsAlloc> ws_allocs; std::vector<CsnPrepJob> jobs;
+    int64_t ws_bytes, packed_floats, pen_off; bool act_half;
+  } snap{P->acts, P->units, P->ws_allocs, P->jobs, P->ws_bytes, P->packed_floats, P->pen_off, P->act_half};
+  const int st = enable_training_impl(P);
+  if (st != CSN_OK && P->packed != nullptr) {   // (packed == nullptr: the device buffers themselves are gone -- nothing to keep consistent)
+    P->acts = std::move(snap.acts); P->units = std::move(snap.units); P->ws_allocs = std::move(snap.ws_allocs);
+    P->jobs = std::move(snap.jobs);
+    P->ws_bytes = snap.ws_bytes; P->packed_floats = snap.packed_floats; P->pen_off = snap.pen_off; P->act_half = snap.act_half;
+    P->tz_off.clear(); P->tg_off.clear(); P->n_cons.clear(); P->virt_cons.clear(); P->act_prod_unit.clear();
+    P->act_prod_branch.clear(); P->orphan_acts.clear(); P->bwd.clear();
+    P->train = false;
+  }
+  return st;
+}
+
+static int enable_training_impl(csn_plan* P) {
   Builder bl(*P);
   const int na = (int)P->acts.size(), nu = (int)P->units.size();
   if (P->act16) {

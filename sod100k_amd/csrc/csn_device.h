@@ -43,6 +43,26 @@ __device__ __forceinline__ csn_cfp csn_const(const float* p) {
 
 #define CSN_BLOCK 256
 
+#ifndef CSN_CPU_EMU
+#include <mutex>
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: a process-wide "done" flag leaves the kernels of a second GPU
+// without it.  One bit per device ordinal, set under a mutex once the attributes of that device are in place.
+struct CsnPerDeviceOnce {
+  std::mutex mu;
+  unsigned long long mask = 0;
+  template <class F> int run(F&& set_attributes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    std::lock_guard<std::mutex> g(mu);
+    if (mask & bit) return 0;
+    const int st = set_attributes();
+    if (st == 0) mask |= bit;
+    return st;
+  }
+};
+#endif
+
 // Buffer-resource loads (CDNA "SRSRC" addressing): the wave-uniform base lives in 4 SGPRs, the per-lane
 // part is ONE 32-bit VGPR byte offset and a per-channel uniform byte offset rides in an SGPR, so a lane
 // needs a single address register for all channels of a gather.

@@ -333,6 +333,9 @@ int csn_launch_wgrad_reduce(const WgReduceArgs& a, void* stream);
 bool csn_wgrad_c3_eligible(const WgArgs& a);                 // k_wgrad_c3.hip: LDS-tiled weight gradient of 3x3 tap passes
 int csn_wgrad_c3_blocks(const WgArgs& a);
 int csn_launch_wgrad_c3(const WgArgs& a, void* stream);
+bool csn_wgrad_bf_eligible(const WgArgs& a);                 // k_wgrad_bf.hip: 1x1 passes of the bf16 train step on the bf16 matrix cores
+int csn_wgrad_bf_blocks(const WgArgs& a);
+int csn_launch_wgrad_bf(const WgArgs& a, void* stream);
 
 // ---------------------------------------------------------------------------------------------
 // train-mode BatchNorm + PReLU + GAP penalty (see k_train.hip)

@@ -165,6 +165,7 @@ struct csn_plan {
   bool fuse_dw = true;
   bool fuse_cls = true;   // CSN_OPT_FUSE_CLS
   bool tiled3 = true;     // CSN_OPT_TILED3
+  mutable int ws_regions_reported = 0;   // workspace regions the last csn_plan_workspace_bytes() call sized (0: never queried)
   int slice_lanes = 0;    // CSN_OPT_SLICE_LANES: batch slices (sub_batch < B) run concurrently on the plan's stream lanes, each
                           // in its own workspace region
   bool c3q = true;        // CSN_OPT_C3Q: eval-mode 3x3 passes on c3q_kernel (k_c3q.hip)
@@ -1616,6 +1617,12 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
 
 void csn_plan_destroy(csn_plan* P) {
   if (!P) return;
+#ifndef CSN_CPU_EMU
+  // callers enqueue asynchronously: the plan's last forward may still be running on the caller's stream and on the lanes when an
+  // LRU eviction (sod100k_amd/model/csnet.py engine_for) drops it -- graphs, lane streams, events and the packed weights must
+  // outlive that work.  Not legal (and not needed: nothing of this plan can be in flight) while a stream is capturing.
+  (void)hipDeviceSynchronize();
+#endif
   for (hipEvent_t ev : P->ev) (void)hipEventDestroy(ev);
 #ifndef CSN_CPU_EMU
   if (P->graph_exec) (void)hipGraphExecDestroy(P->graph_exec);
@@ -1650,7 +1657,8 @@ int csn_plan_set_option(csn_plan* P, int32_t option, int32_t value) {
 size_t csn_plan_workspace_bytes(const csn_plan* P) {
   if (!P) return 0;
   const int nslices = (P->B + P->S - 1) / P->S;
-  return (size_t)P->ws_bytes * (size_t)((P->slice_lanes && nslices > 1) ? std::min(nslices, 3) : 1);
+  P->ws_regions_reported = (P->slice_lanes && nslices > 1) ? std::min(nslices, 3) : 1;
+  return (size_t)P->ws_bytes * (size_t)P->ws_regions_reported;
 }
 int32_t csn_plan_num_units(const csn_plan* P) { return P ? (int32_t)P->units.size() : 0; }
 
@@ -1718,6 +1726,12 @@ static int forward_body(csn_plan* P, const float* x, float* y, void* workspace, 
   const int nslices = (P->B + P->S - 1) / P->S;
   int nconc = 1;
   if (P->slice_lanes && nslices > 1 && !prof && lanes_ready(P)) nconc = std::min(nslices, 3);
+  // the concurrent slices live in workspace + lane * ws_bytes: the caller's buffer was sized by csn_plan_workspace_bytes(), which
+  // must have seen the option (set afterwards, the extra regions would lie beyond the buffer -- ADVICE r3)
+  if (nconc > 1 && P->ws_regions_reported > 0 && nconc > P->ws_regions_reported) {
+    g_hip_err = "CSN_OPT_SLICE_LANES was set after csn_plan_workspace_bytes(): query the workspace size again";
+    return CSN_E_STATE;
+  }
   if (nconc > 1) {
     Ctx c0{*P, x, y, static_cast<char*>(workspace), stream};
     const int st = lanes_fork(c0, nconc - 1);

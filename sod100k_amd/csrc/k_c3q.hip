@@ -218,16 +218,17 @@ int csn_launch_c3q(const C3qArgs& a, int raw, void* stream) {
   const dim3 grid((nblk + 7) & ~7);
   const size_t lds = (size_t)a.ngroups * a.gimg_floats * sizeof(float);
 #ifndef CSN_CPU_EMU
-  static bool attr_done = false;
-  if (!attr_done) {
+  static CsnPerDeviceOnce attr_once;
+  const int ast = attr_once.run([&]() {
     for (size_t i = 0; i < sizeof(g_c3q_table) / sizeof(g_c3q_table[0]); ++i)
       for (int r = 0; r < 3; ++r) {
         const hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(g_c3q_table[i].fn[r]),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (er != hipSuccess) return (int)er;
       }
-    attr_done = true;
-  }
+    return 0;
+  });
+  if (ast != 0) return ast;
 #endif
   if (a.a16 && !raw) return 1;   // bfloat16 tensors: train-mode (raw) launches only
   CSN_LAUNCH(e->fn[raw ? (a.a16 ? 2 : 1) : 0], grid, dim3(CSN_BLOCK), lds, stream, a);

@@ -318,8 +318,8 @@ int csn_launch_c3(const PwArgs& a, int raw, void* stream) {
   const bool wch = (size_t)a.w3_floats * sizeof(float) > 40 * 1024;
   const size_t lds = (size_t)((wch ? C3_WCH : a.w3_floats) + C3_TILE) * sizeof(float);
 #ifndef CSN_CPU_EMU
-  static bool attr_done = false;
-  if (!attr_done) {
+  static CsnPerDeviceOnce attr_once;
+  const int ast = attr_once.run([&]() {
     const void* fns[6] = {reinterpret_cast<const void*>(&goct_c3_kernel<false, false, float>),
                           reinterpret_cast<const void*>(&goct_c3_kernel<false, true, float>),
                           reinterpret_cast<const void*>(&goct_c3_kernel<true, false, float>),
@@ -330,8 +330,9 @@ int csn_launch_c3(const PwArgs& a, int raw, void* stream) {
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return (int)e;
     }
-    attr_done = true;
-  }
+    return 0;
+  });
+  if (ast != 0) return ast;
 #endif
   if (a.a16) {   // bf16 activations: train mode only (raw sums; BN runs as its own passes)
     if (!raw) return -1;

@@ -191,8 +191,8 @@ int csn_launch_pw(const PwArgs& a, int raw, void* stream) {
   const dim3 grid((nblk + 7) & ~7);   // multiple of 8: see the XCD-aware tile order in the kernel
   const size_t lds = ((size_t)a.wimg_floats + 4 * PW_KC * PW_XP) * sizeof(float);
 #ifndef CSN_CPU_EMU
-  static bool attr_done = false;
-  if (!attr_done) {
+  static CsnPerDeviceOnce attr_once;
+  const int ast = attr_once.run([&]() {
     // units with a large weight image may use the full 160 KiB of LDS of a CDNA4 CU
     const void* fns[4] = {reinterpret_cast<const void*>(&goct_pw_kernel<false, float>),
                           reinterpret_cast<const void*>(&goct_pw_kernel<true, float>),
@@ -202,8 +202,9 @@ int csn_launch_pw(const PwArgs& a, int raw, void* stream) {
       const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return (int)e;
     }
-    attr_done = true;
-  }
+    return 0;
+  });
+  if (ast != 0) return ast;
 #endif
   if (a.a16) {
     if (raw) CSN_LAUNCH((goct_pw_kernel<true, csn_bf16>), grid, dim3(CSN_BLOCK), lds, stream, a);

@@ -148,11 +148,25 @@ __device__ __forceinline__ DwRow dw_load_row(csn_buf rb, int y, int x0, int W, b
   return r;
 }
 
+// (the halo columns unmasked: for callers that mask after a transform anyway)
+template <bool VEC, typename AT = float>
+__device__ __forceinline__ DwRow dw_load_row_raw(csn_buf rb, int y, int x0, int W) {
+  if (!VEC) return dw_load_row<false, AT>(rb, y, x0, W, true, true);
+  DwRow r;
+  constexpr unsigned E = (unsigned)sizeof(AT);
+  const unsigned o = (unsigned)(y * W + x0) * E;
+  const float4 c = csn_bufacc<AT>::ld4(rb, o, 0);
+  r.v[1] = c.x; r.v[2] = c.y; r.v[3] = c.z; r.v[4] = c.w;
+  r.v[0] = csn_bufacc<AT>::ld1(rb, o - E, 0);
+  r.v[5] = csn_bufacc<AT>::ld1(rb, o + 4u * E, 0);
+  return r;
+}
+
 // row of x = PReLU(z * sc + sh) from a row of the producer's raw output z (see DwBranch::in_scale); outside the plane: 0
 template <bool VEC, typename AT>
 __device__ __forceinline__ DwRow dw_load_row_bn(csn_buf rb, int y, int H, int x0, int W, bool has_l, bool has_r, float sc,
                                                 float sh, float al, float* zc = nullptr) {
-  DwRow r = dw_load_row<VEC, AT>(rb, y, x0, W, has_l, has_r);
+  DwRow r = dw_load_row_raw<VEC, AT>(rb, y, x0, W);
   if (zc) { zc[0] = r.v[1]; zc[1] = r.v[2]; zc[2] = r.v[3]; zc[3] = r.v[4]; }   // the raw centre values z
   const bool rowin = y >= 0 && y < H;
 #pragma unroll
@@ -334,31 +348,35 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
     const bool has2 = BNF && br.dy2 != nullptr;
     const csn_buf zb = csn_make_buf_n(act_cast<AT>(BNF ? br.zraw : br.in) + (int64_t)pc * H * W, nb);
     const csn_buf g2b = csn_make_buf_n(act_cast<AT>(has2 ? br.dy2 : br.in) + (int64_t)pc * H * W, nb);
-    float bsc = 0.f, bsh = 0.f, bal = 0.f, bmu = 0.f, bis = 0.f, bm1 = 0.f, bm2 = 0.f, bgi = 0.f;
+    // dz = gi (dbn - m1 - (z - mu) invstd m2),  dbn = dy (bn > 0 ? 1 : alpha)   [bn_bwd_apply_kernel]
+    //    = dy * (bn > 0 ? gi : gi alpha) - (B z + A),   B = gi invstd m2,  A = gi (m1 - mu invstd m2):  five operations per element
+    float bsc = 0.f, bsh = 0.f, bgi = 0.f, bga = 0.f, bA = 0.f, bB = 0.f;
     if (BNF) {
-      bsc = csn_const(br.bn_scale)[c]; bsh = csn_const(br.bn_shift)[c]; bal = csn_const(br.bn_alpha)[c];
-      bmu = csn_const(br.bn_mean)[c]; bis = csn_const(br.bn_invstd)[c];
-      bm1 = csn_const(br.bn_m1m2)[2 * c]; bm2 = csn_const(br.bn_m1m2)[2 * c + 1];
+      bsc = csn_const(br.bn_scale)[c]; bsh = csn_const(br.bn_shift)[c];
+      const float bal = csn_const(br.bn_alpha)[c], bmu = csn_const(br.bn_mean)[c], bis = csn_const(br.bn_invstd)[c];
+      const float bm1 = csn_const(br.bn_m1m2)[2 * c], bm2 = csn_const(br.bn_m1m2)[2 * c + 1];
       bgi = csn_const(br.bn_gamma)[c] * bis;
+      bga = bgi * bal;
+      bB = bgi * (bis * bm2);
+      bA = bgi * (bm1 - bmu * (bis * bm2));
     }
     auto load_g = [&](int y) {
-      DwRow g = dw_load_row<VEC, AT>(gb, y, x0, W, has_l, has_r);
-      if (BNF) {
-        const DwRow z = dw_load_row<VEC, AT>(zb, y, x0, W, has_l, has_r);
-        if (has2) {
-          const DwRow e = dw_load_row<VEC, AT>(g2b, y, x0, W, has_l, has_r);
+      if (!BNF) return dw_load_row<VEC, AT>(gb, y, x0, W, has_l, has_r);
+      DwRow g = dw_load_row_raw<VEC, AT>(gb, y, x0, W);
+      const DwRow z = dw_load_row_raw<VEC, AT>(zb, y, x0, W);
+      if (has2) {
+        const DwRow e = dw_load_row_raw<VEC, AT>(g2b, y, x0, W);
 #pragma unroll
-          for (int i = 0; i < 6; ++i) g.v[i] += e.v[i];
-        }
-        const bool rowin = y >= 0 && y < H;
+        for (int i = 0; i < 6; ++i) g.v[i] += e.v[i];
+      }
+      const bool rowin = y >= 0 && y < H;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          const float bn = z.v[i] * bsc + bsh;
-          const float dbn = bn > 0.f ? g.v[i] : bal * g.v[i];
-          const float dzv = bgi * (dbn - bm1 - (z.v[i] - bmu) * bis * bm2);
-          const bool colin = i == 0 ? has_l : (i == 5 ? has_r : (VEC || x0 + i - 1 < W));
-          g.v[i] = (rowin && colin) ? dzv : 0.f;
-        }
+      for (int i = 0; i < 6; ++i) {
+        const float bn = fmaf(z.v[i], bsc, bsh);
+        const float t = fmaf(bB, z.v[i], bA);
+        const float dzv = fmaf(g.v[i], bn > 0.f ? bgi : bga, -t);
+        const bool colin = i == 0 ? has_l : (i == 5 ? has_r : (VEC || x0 + i - 1 < W));
+        g.v[i] = (rowin && colin) ? dzv : 0.f;
       }
       return g;
     };
@@ -366,16 +384,18 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
     if (XBN) { isc = csn_const(br.in_scale)[c]; ish = csn_const(br.in_shift)[c]; ial = csn_const(br.in_alpha)[c]; }
     float imu = 0.f, iis = 0.f;
     if (XBN) { imu = csn_const(br.in_mean)[c]; iis = csn_const(br.in_invstd)[c]; }
-    float zc1[4] = {0.f, 0.f, 0.f, 0.f}, zc2[4];   // XBN: raw z of the producer at the centre columns of rows y, y + 1
     auto load_x = [&](int y, float* zc) {
       if (XBN) return dw_load_row_bn<VEC, AT>(xb, y, H, x0, W, has_l, has_r, isc, ish, ial, zc);
       return dw_load_row<VEC, AT>(xb, y, x0, W, has_l, has_r);
     };
+    float zc1[4] = {0.f, 0.f, 0.f, 0.f}, zc2[4];   // XBN: raw z of the producer at the centre columns of rows y, y + 1
     DwRow g0 = load_g(y0 - 1);
     DwRow g1 = load_g(y0);
     DwRow u0 = load_x(y0 - 1, nullptr);
     DwRow u1 = load_x(y0, zc1);
     const int yend = min(y0 + br.R, H);
+    // (rotating three register sets through an unrolled-by-three loop instead of copying rows: 11 % fewer VALU instructions per row,
+    // but 158 instead of 98 VGPRs and 2.8x the code -- not taken)
     for (int y = y0; y < yend; ++y) {
       const DwRow g2 = load_g(y + 1);
       const DwRow u2 = load_x(y + 1, zc2);
@@ -386,7 +406,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
         for (int j = 0; j < 4; ++j)
           if (VEC || x0 + j < W) {
             const float z = zc1[j], dy = dxv[j];
-            const float bn = z * isc + ish;
+            const float bn = fmaf(z, isc, ish);
             const float dbn = bn > 0.f ? dy : ial * dy;
             rf[0] += dbn;
             rf[1] = fmaf(dbn, (z - imu) * iis, rf[1]);

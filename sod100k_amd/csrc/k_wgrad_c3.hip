@@ -207,16 +207,17 @@ int csn_wgrad_c3_blocks(const WgArgs& a) {
 int csn_launch_wgrad_c3(const WgArgs& a, void* stream) {
   const size_t lds = (size_t)(W3_TILE + std::max(a.rows16 * W3_DZP, 1024)) * sizeof(float);
 #ifndef CSN_CPU_EMU
-  static bool attr_done = false;
-  if (!attr_done) {
+  static CsnPerDeviceOnce attr_once;
+  const int ast = attr_once.run([&]() {
     const void* fns[2] = {reinterpret_cast<const void*>(&goct_wgrad_c3_kernel<float>),
                           reinterpret_cast<const void*>(&goct_wgrad_c3_kernel<csn_bf16>)};
     for (const void* f : fns) {
       const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return (int)e;
     }
-    attr_done = true;
-  }
+    return 0;
+  });
+  if (ast != 0) return ast;
 #endif
   if (a.a16) CSN_LAUNCH((goct_wgrad_c3_kernel<csn_bf16>), dim3(a.nblk), dim3(CSN_BLOCK), lds, stream, a);
   else CSN_LAUNCH((goct_wgrad_c3_kernel<float>), dim3(a.nblk), dim3(CSN_BLOCK), lds, stream, a);

@@ -575,7 +575,8 @@ def _train_step_vs_fp64(lib, device, manifest, B, size, seed):
     return (num / den) ** 0.5, (ref2 / den) ** 0.5, bad
 
 
-def check_train_step_well_conditioned(lib, device, manifest, B=2, size=64, seeds=(31, 41, 51, 61, 71, 81, 91, 101)):
+def check_train_step_well_conditioned(lib, device, manifest, B=2, size=64, seeds=(31, 41, 51, 61, 71, 81, 91, 101),
+                                      local_seeds=None):
     """One train step on the well-conditioned state, judged against an fp64 run of the oracle with the fp32 ORACLE's own
     distance from that run as the yardstick (57 batch-normalised layers amplify fp32 rounding whatever the conditioning of
     the parameters, so an absolute bound is unreachable for any fp32 implementation).
@@ -588,13 +589,20 @@ def check_train_step_well_conditioned(lib, device, manifest, B=2, size=64, seeds
     with the oracle to 4e-7 on the tensors around it (check_train_units_local, the sharp test).  Hence several seeds and
     the QUIET seeds as the yardstick: on at least three of the eight seeds the kernels must be within 1.5x of the fp32
     oracle's own distance AND have fewer than 3 % of the tensors further from fp64 than twice the fp32 oracle (+1e-4); on
-    every seed the distance stays below 0.1 (an event, not a wrong gradient).  A median would not do: with events on half
+    every seed the distance stays below 0.05 (an event, not a wrong gradient) and every unit passes the unit-local check.  A median would not do: with events on half
     of the seeds it sits between the two modes (round-3 kernels at size 64: sorted ratios 0.34, 0.99, 1.00, 1.13, 1.68, 3.2,
     7.3, 13; with split-K in the 3x3 kernel at size 32: 0.90, 0.99, 1.01, 1.04, 3.7, 5.1, 100, 157)."""
     res = [_train_step_vs_fp64(lib, device, manifest, B, size, s_) for s_ in seeds]
     quiet = sum(1 for r in res if r[0] <= 1.5 * r[1] + 1e-5 and r[2] <= 12)          # 419 gradient tensors
     assert quiet >= min(3, len(res)), f"kernels further from fp64 than the fp32 oracle on almost every seed: {res}"
-    assert max(r[0] for r in res) <= 0.1, res
+    # an event, not a wrong gradient: round-4 kernels at size 64 reach 2.2e-2 on their worst seed (the fp32 oracle 1.8e-2 on its own)
+    assert max(r[0] for r in res) <= 0.05, res
+    # The sharp, deterministic gate on EVERY seed (ADVICE r3: a <10 % error in a rarely taken path -- pwq, virt_cons, the fused
+    # BN apply of dw3x3_bwd -- must not hide behind the "event" allowance above): each unit's forward, dz, dx and parameter
+    # gradients re-computed by the oracle from the tensors the device itself produced around that unit (no amplification through
+    # depth, the oracle following the device's argmax / PReLU branch only inside its 1e-5 band): 2e-5 / 2e-4 relative L2.
+    for s_ in (seeds if local_seeds is None else local_seeds):
+        check_train_units_local(lib, device, manifest, B=B, size=min(size, 32), act_dtype="fp32", state="well", seed=s_)
     rel = sorted(r[0] for r in res)
     rel32 = sorted(r[1] for r in res)
     return 0.5 * (rel[(len(rel) - 1) // 2] + rel[len(rel) // 2]), 0.5 * (rel32[(len(rel32) - 1) // 2] + rel32[len(rel32) // 2])
@@ -848,3 +856,112 @@ def _check_train_units_local(lib, device, manifest, B, size, act_dtype, state, f
     if kink_units:
         worst["kink_elements"] = kink_units
     return worst
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Paths the shipped x2 configuration never takes: the un-pruned training network and the pruned slim one
+# ------------------------------------------------------------------------------------------------------------------
+def random_state(m, seed):
+    """O(1) activations for a freshly built network (its initialisers make every unit's output ~1e2)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = m.state_dict()
+    out = {}
+    for k, v in sd.items():
+        if k.endswith("num_batches_tracked"):
+            out[k] = v.clone()
+        elif k.endswith("running_var"):
+            out[k] = torch.rand(v.shape, generator=g) + 0.5
+        elif k.endswith("running_mean") or k.endswith("bias"):
+            out[k] = 0.1 * torch.randn(v.shape, generator=g)
+        elif "bn" in k and k.endswith("weight"):
+            out[k] = 1.0 + 0.1 * torch.randn(v.shape, generator=g)
+        elif "prelu" in k:
+            out[k] = 0.25 + 0.05 * torch.randn(v.shape, generator=g)
+        else:
+            fan = max(1, int(np.prod(v.shape[1:])))
+            out[k] = torch.randn(v.shape, generator=g) * (0.5 / fan ** 0.5) * (0.01 if "convs" in k or "msconv" in k else 1.0)
+    return out
+
+
+def check_unpruned(lib, device, expand, width, B=2, size=32, seed=4, train=True, act_dtype="fp32"):
+    """basic_split [0.5, 0.5] at `expand` (csnet-L-x2_train.yml:9-18, init_layers csnet.py:414-518): eval forward and one
+    train step (fp64 run of the oracle as the truth, the fp32 oracle's own deviation as the yardstick: random state)."""
+    m = M.build_model(basic_split=[0.5, 0.5], expand=expand, save_path="/tmp")
+    sd = random_state(m, seed)
+    m.load_state_dict(sd)
+    m = m.to(device)
+    if device.type == "cpu":
+        m._lib = lib
+    cfg = O.init_layers(width, [0.5, 0.5])
+    x = torch.from_numpy(I.randn_batch(5, B, size, size))
+    t = torch.from_numpy(I.binary_target(6, B, size, size))
+    m.eval()
+    with torch.no_grad():
+        ref = O.csnet_forward(cfg, {k: v.clone() for k, v in sd.items()}, x)
+    y = m(x.to(device)).cpu()
+    err = (y - ref).abs().max().item()
+    assert err <= 1e-4 * max(1.0, ref.abs().max().item()), err
+    if not train:
+        return err, None, None
+    m.train(); m.set_batchsize(B); m.clear_flops(); m.flops_hook(1.0)
+    if act_dtype == "bf16":
+        m.set_train_act_dtype("bf16")
+    xd = x.to(device)
+    yt, pen = m._train_forward_raw(xd)
+    loss, dy = bce_and_grad(lib, yt, t.to(device))
+    flat = m._train_backward_raw(xd, dy, 3.0 / B)
+    kw = dict(expandflop=1.0, flops_weight=3.0, batchsize=B, lr=0.0, wd=0.0)
+    r32 = O.train_step(cfg, {k: v.clone() for k, v in sd.items()}, x, t, **kw)
+    r64 = O.train_step(cfg, {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()},
+                       x.double(), t.double(), **kw)
+    mine = np.array([e / (n + 1e-12) for e, n in grad_errors(m, flat, r64["grads"]).values()])
+    yard = np.array([float((r32["grads"][k].double() - g).norm() / (g.norm() + 1e-12)) for k, g in r64["grads"].items()])
+    if act_dtype == "bf16":
+        # storage rounding through ~60 normalised layers with random unit-gain weights: O(1e-2) on the scalars; the gradients of
+        # ANY bf16-storage run are O(1) from the fp64 run (measured: the oracle's own bf16 emulation 1.13 median / 1.85 worst,
+        # the kernels 1.09 / 2.01) -- the oracle's emulation is the yardstick, the unit-local checks are the sharp test
+        r16 = O.train_step(cfg, {k: v.clone() for k, v in sd.items()}, x, t, act_dtype="bf16", **kw)
+        yard = np.array([float((r16["grads"][k].double() - g).norm() / (g.norm() + 1e-12)) for k, g in r64["grads"].items()])
+        assert abs(float(loss) - r64["loss_bce"]) <= 3e-2 * max(1.0, abs(r64["loss_bce"]))
+        assert abs(float(pen) / B - r64["penalty"]) <= 3e-2 * max(1.0, abs(r64["penalty"]))
+        assert np.isfinite(mine).all() and np.median(mine) <= 1.5 * np.median(yard) + 0.05 and mine.max() <= 3 * yard.max(), (
+            np.median(mine), np.median(yard), mine.max(), yard.max())
+    else:
+        assert abs(float(loss) - r64["loss_bce"]) <= 1e-5
+        assert abs(float(pen) / B - r64["penalty"]) <= 1e-5 * max(1.0, abs(r64["penalty"]))
+        assert np.median(mine) <= 3 * np.median(yard) and mine.max() <= 3 * yard.max(), (np.median(mine), np.median(yard),
+                                                                                         mine.max(), yard.max())
+    return err, float(np.median(mine)), float(np.median(yard))
+
+
+def check_slim_network(lib, device, manifest, tmp_path, thres=0.01, B=2, H=32, W=48):
+    """The prune-and-finetune result (finetune_model / build_model_with_weight; it has an output branch with ZERO channels)
+    through the kernels: eval forward and a train-mode forward + backward against the oracle."""
+    m = M.build_model(predefine=manifest)
+    m.load_state_dict(O.load_weights(manifest))
+    new_cfg, mask = M.finetune_model(m, save_path=str(tmp_path), base_layer_config=M.load_layer_config(manifest), thres=thres)
+    slim = M.build_model_with_weight(new_cfg, m, mask).eval()
+    sd = {k: v.clone() for k, v in slim.state_dict().items()}
+    slim = slim.to(device)
+    if device.type == "cpu":
+        slim._lib = lib
+    x = torch.from_numpy(I.randn_batch(2, B, H, W))
+    with torch.no_grad():
+        ref = O.csnet_forward(new_cfg, sd, x)
+    y = slim(x.to(device)).cpu()
+    err = (y - ref).abs().max().item()
+    assert err <= 1e-4 * max(1.0, ref.abs().max().item()), err
+    return err
+
+
+def oracle_adam_trajectory(cfg, sd, x, t, steps, lr, wd, eps, batchsize, flops_weight=0.0, act_dtype=None):
+    """BCE of `steps` iterations of train.py:203-216 on FIXED data, by the oracle (Adam state carried along)."""
+    sd = {k: v.clone() for k, v in sd.items()}
+    st = None
+    out = []
+    for _ in range(steps):
+        r = O.train_step(cfg, sd, x, t, expandflop=1.0, flops_weight=flops_weight, batchsize=batchsize, lr=lr, wd=wd, eps=eps,
+                         adam_state=st, use_penalty=flops_weight != 0.0, act_dtype=act_dtype)
+        st = r["adam_state"]
+        out.append(r["loss_bce"])
+    return out

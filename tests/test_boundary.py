@@ -64,7 +64,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(N.LIB_PATH)
     for s in N.EXPORTS:
         assert hasattr(lib, s), s
-    assert lib.csn_abi_version() == 1
+    assert lib.csn_abi_version() == N.ABI_VERSION
 
 
 def test_no_cpu_fallback_and_clear_errors():

@@ -1,0 +1,134 @@
+"""Paths the shipped csnet-L-x2 configuration does not take on its own, on the MI355X:
+the un-pruned training network of csnet-L-x2_train.yml, the pruned slim network (zero-channel branch), the opt-in stream-lane
+modes (real concurrency: a race shows up as run-to-run differences), and an optimisation run whose loss must go down."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import csnet_oracle as O, inputs as I
+
+import parity_cases as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from sod100k_amd import _native as N
+    assert torch.cuda.is_available(), "no ROCm device"
+    return N.load(), torch.device("cuda", 0)
+
+
+def test_gpu_unpruned_expand2_eval_and_train_step(hip):
+    """expand 2.0 / basic_split [0.5, 0.5] (CSNet_training/configs/csnet-L-x2_train.yml:9-18, 788,631 parameters): weight images
+    beyond the LDS budget take the M-group / row-chunk paths the shipped x2 net never touches."""
+    lib, dev = hip
+    err, mine, yard = P.check_unpruned(lib, dev, expand=2.0, width=40, B=2, size=64, seed=4)
+    print(f"unpruned x2: eval max-abs {err:.2e}; gradient median rel err {mine:.2e} (fp32 oracle vs fp64: {yard:.2e})")
+
+
+def test_gpu_unpruned_expand2_train_step_bf16(hip):
+    lib, dev = hip
+    err, mine, yard = P.check_unpruned(lib, dev, expand=2.0, width=40, B=2, size=64, seed=4, act_dtype="bf16")
+    print(f"unpruned x2 bf16 storage: gradient median rel err {mine:.2e}")
+
+
+def test_gpu_unpruned_expand1(hip):
+    lib, dev = hip
+    P.check_unpruned(lib, dev, expand=1.0, width=20, B=2, size=64, seed=0)
+
+
+def test_gpu_slim_network_forward(hip, x2_manifest, tmp_path):
+    """G10's network (prune threshold 0.01: one output branch has zero channels) on the device."""
+    lib, dev = hip
+    err = P.check_slim_network(lib, dev, x2_manifest, tmp_path)
+    print(f"slim network: max-abs {err:.2e}")
+    P.check_slim_network(lib, dev, x2_manifest, tmp_path, B=3, H=224, W=224)
+
+
+def _train_grad(lib, dev, manifest, x, t, B):
+    from sod100k_amd.tools.train import FusedTrainer
+    m, _ = P.make_model(lib, manifest, dev)
+    m.train(); m.set_batchsize(B); m.clear_flops(); m.flops_hook(1.0)
+    tr = FusedTrainer(m, lr=0.0, weight_decay=0.0, flops_weight=3.0, batchsize=B, lib=lib)
+    outs = []
+    for _ in range(20):                       # eager, capture, replays: the parameters do not move (lr 0)
+        loss, pen = tr.step(x, t)
+        outs.append((tr.grad.clone(), float(loss), float(pen)))
+    torch.cuda.synchronize()
+    return outs
+
+
+def test_gpu_overlap2_weight_gradient_lane_is_deterministic(hip, x2_manifest, monkeypatch):
+    """CSN_OPT_OVERLAP = 2 moves every weight-gradient launch of csn_backward to a side stream (the mode ADVICE r2 found a race
+    in): 20 repeated steps must be bit-identical to each other and to the default mode's gradient."""
+    lib, dev = hip
+    B, S = 4, 96
+    x = torch.from_numpy(I.randn_batch(70, B, S, S)).to(dev)
+    t = torch.from_numpy(I.binary_target(71, B, S, S)).to(dev)
+    base = _train_grad(lib, dev, x2_manifest, x, t, B)
+    monkeypatch.setenv("CSN_OVERLAP", "2")
+    lane = _train_grad(lib, dev, x2_manifest, x, t, B)
+    g0 = base[0][0]
+    for k, (g, loss, pen) in enumerate(base):
+        assert torch.equal(g, g0), f"default mode: step {k} differs from step 0"
+    for k, (g, loss, pen) in enumerate(lane):
+        assert torch.equal(g, g0), f"overlap 2: step {k} differs from the default mode ({(g - g0).abs().max().item():.3e})"
+        assert loss == base[0][1] and pen == base[0][2]
+
+
+def test_gpu_slice_lanes_is_deterministic(hip, x2_manifest, monkeypatch):
+    """CSN_SLICE_LANES = 1: two half-batches side by side on the plan's stream lanes; 20 forwards bit-identical to the default."""
+    lib, dev = hip
+    x = torch.randn(16, 3, 224, 224, generator=torch.Generator().manual_seed(3)).to(dev)
+    m, _ = P.make_model(lib, x2_manifest, dev)
+    y0 = m(x).clone()
+    monkeypatch.setenv("CSN_SLICE_LANES", "1")
+    m2, _ = P.make_model(lib, x2_manifest, dev)
+    y = torch.empty_like(y0)
+    eng = m2.engine_for(x)
+    eng.refresh(m2._arena.flat)
+    for k in range(20):
+        y.fill_(float("nan"))
+        eng.forward(x, out=y)
+        assert torch.equal(y, y0), f"slice lanes: forward {k} differs ({(y - y0).abs().max().item():.3e})"
+
+
+@pytest.mark.parametrize("act_dtype", ["fp32", "bf16"])
+def test_gpu_loss_goes_down(hip, x2_manifest, act_dtype):
+    """The reference's training loop on fixed synthetic data, replayed on the device: 40 optimiser steps at lr 1e-3 on 8 pictures
+    (train.py:101-123,203-216: Adam with the two parameter groups, loss = BCE + 3.0 * get_flops(), shipped x2 weights as the start)
+    against golden G11 -- the BCE of every step of the REFERENCE itself (oracle/make_golden_traj.py)."""
+    import json
+    from sod100k_amd.tools.train import FusedTrainer
+    lib, dev = hip
+    g = json.load(open(os.path.join(P.GOLD, "g11_train_trajectory_x2.json")))
+    B, S, steps = g["B"], g["S"], g["steps"]
+    x = torch.from_numpy(I.randn_batch(90, B, S, S))
+    t = (torch.nn.functional.avg_pool2d(x[:, :1], 9, 1, 4) > 0).float()
+    m, sd = P.make_model(lib, x2_manifest, dev)
+    m.train(); m.set_batchsize(B); m.clear_flops(); m.flops_hook(g["expandflop"])
+    tr = FusedTrainer(m, lr=g["lr"], weight_decay=g["weight_decay"], eps=g["eps"], betas=tuple(g["betas"]),
+                      flops_weight=g["flops_weight"], batchsize=B, lib=lib, act_dtype=act_dtype)
+    xd, td = x.to(dev), t.to(dev)
+    mine, pens = [], []
+    for _ in range(steps):
+        loss, pen = tr.step(xd, td)
+        mine.append(float(loss)); pens.append(float(pen))
+    ref = g["bce"]
+    print(f"{act_dtype}: bce {mine[0]:.4f} -> {mine[-1]:.4f}; reference {ref[0]:.4f} -> {ref[-1]:.4f}; "
+          f"max |diff| {max(abs(a - b) for a, b in zip(mine, ref)):.3e}")
+    assert mine[-1] < 0.6 * mine[0], mine
+    assert np.mean(mine[-10:]) < np.mean(mine[10:20]) < np.mean(mine[:10])
+    # Two free-running trajectories are NOT 1e-2 apart step by step: at lr 1e-3 the first updates move the ~1e-6-gamma channels of
+    # the shipped checkpoint across PReLU kinks (the CPU emulation of these very kernels, fp32, is 4.5e-2 from the oracle at step 7
+    # and back within 1.1 % at the end; with bf16 storage 0.13 / 1.5 %; MI355X bf16: 0.10 at step 8).  Hence: the first two steps
+    # (same parameters up to one update) tight, the whole curve loose, the end of the run in between.
+    tol0, tol_curve, tol_end = (2e-3, 0.1, 0.05) if act_dtype == "fp32" else (3e-2, 0.3, 0.2)
+    assert abs(mine[0] - ref[0]) <= tol0 * max(1.0, abs(ref[0])) and abs(pens[0] - g["penalty"][0]) <= 5 * tol0 * max(1.0, g["penalty"][0])
+    assert abs(mine[1] - ref[1]) <= 5 * tol0 * max(1.0, abs(ref[1])), (mine[:2], ref[:2])
+    for k, (a, b) in enumerate(zip(mine, ref)):
+        assert abs(a - b) <= tol_curve * max(1.0, abs(b)), (k, a, b)
+    assert abs(np.mean(mine[-10:]) - np.mean(ref[-10:])) <= tol_end * np.mean(ref[-10:]), (mine[-10:], ref[-10:])

@@ -59,7 +59,10 @@ def main():
         head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     except Exception:
         head = "?"
-    out = {"_source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/unit_table.py, one eval forward, batch 64; "
+    sys.path.insert(0, ROOT)
+    from sod100k_amd import _native as N
+    out = {"_kernel_sources_sha16": N.sources_sha16(),
+           "_source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/unit_table.py, one eval forward, batch 64; "
                       f"calibrated with tools/probes/fetch_cal; tree {head}",
            "_calibration": {"read_bytes_per_counted_byte": {str(k): round(v, 4) for k, v in f_rd.items()},
                             "write_bytes_per_counted_byte": {str(k): round(v, 4) for k, v in f_wr.items()}}}

@@ -74,6 +74,9 @@ def main():
         head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     except Exception:
         head = ""
+    sys.path.insert(0, ROOT)
+    from sod100k_amd import _native as N
+    res["_kernel_sources_sha16"] = N.sources_sha16()
     res["_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --train-steps 3 (batch 256, csnet-L-x2), "
                       "last step of each storage mode between two bce_logits_kernel launches; calibrated with tools/probes/fetch_cal "
                       f"(x{k_rd:.3f} reads, x{k_wr:.3f} writes); tree {head}")
