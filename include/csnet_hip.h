@@ -141,7 +141,7 @@ int32_t csn_plan_num_units(const csn_plan* plan);
 
 /* Debug / parity probes of the train step (valid after csn_plan_enable_training): where an activation's companions live
  * in the workspace.  z: the raw convolution output of the producing unit after csn_forward_train, OVERWRITTEN by the
- * gradient w.r.t. z (dz) in csn_backward; grad[s]: the gradient w.r.t. the activation contributed by its s-th consumer
+ * gradient w.r.t. z (dz) in csn_backward (or dz goes over the activation: dz_offset_bytes); grad[s]: the gradient w.r.t. the activation contributed by its s-th consumer
  * (-1: none).  Elements are bfloat16 when CSN_OPT_TRAIN_BF16 is set (`bf16` = 1), else float. */
 typedef struct csn_train_act_info {
   int64_t act_offset_bytes;     /* the activation itself (-1: the external input; bf16 mode keeps a copy at x16)  */
@@ -150,6 +150,8 @@ typedef struct csn_train_act_info {
   int64_t x16_offset_bytes;     /* bf16 copy of the external input (act 0), -1 otherwise / in fp32 mode            */
   int32_t n_consumers;
   int32_t bf16;
+  int64_t dz_offset_bytes;      /* where csn_backward leaves dz: z_offset_bytes (over z), or act_offset_bytes when the BatchNorm
+                                   backward of that output runs fused with the adjoint upsampling (the activation is dead by then) */
 } csn_train_act_info;
 int csn_plan_train_act_info(const csn_plan* plan, int32_t act_id, csn_train_act_info* out);
 /* Which of the two gradient buffers of its input activation `branch` unit `unit` writes (0 / 1; < 0: none). */

@@ -90,7 +90,8 @@ CSF_MAX_BRANCH = 4
 
 class TrainActInfo(C.Structure):
     _fields_ = [("act_offset_bytes", C.c_int64), ("z_offset_bytes", C.c_int64), ("grad_offset_bytes", C.c_int64 * 2),
-                ("x16_offset_bytes", C.c_int64), ("n_consumers", C.c_int32), ("bf16", C.c_int32)]
+                ("x16_offset_bytes", C.c_int64), ("n_consumers", C.c_int32), ("bf16", C.c_int32),
+                ("dz_offset_bytes", C.c_int64)]
 
 
 class CsfGnOff(C.Structure):

@@ -56,6 +56,8 @@ struct UnitBwd {
   int64_t tmp_off = -1;
   int64_t dwf_w[3] = {-1, -1, -1};           // depthwise: tap-flipped x100 weights (packed)
   int64_t scratch = 0;                       // bytes of unit scratch used
+  int adj_fused[3] = {-1, -1, -1};           // output branch j: index of the f = 2 AdjPlan its BatchNorm-backward apply pass also
+                                             // produces (bn_bwd_apply_adj2_kernel; dz then goes to the branch's activation buffer)
 };
 
 // one DataLaunch per row chunk of `L`; the routing kernel (to_tmp) follows the last chunk only
@@ -259,6 +261,15 @@ int plan_goct_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
     const int st = finish_launch(bl, dl.L);
     if (st != CSN_OK) return st;
   }
+  // the x2 adjoint upsampling of dz_j inside the BatchNorm backward's apply pass of branch j (k_train.hip)
+  for (size_t k = 0; k < ub.adj.size(); ++k) {
+    const AdjPlan& ap = ub.adj[k];
+    const int a = d.out_act[ap.j];
+    if (ap.f != 2 || a <= 0 || P.acts[a].ws_off < 0) continue;
+    const int lvl = base + ap.j;
+    const int Hh = P.H >> lvl, Wh = P.W >> lvl;
+    if (csn_bn_bwd_adj2_ok((int64_t)Hh * Wh, Wh)) ub.adj_fused[ap.j] = (int)k;
+  }
   return CSN_OK;
 }
 
@@ -414,6 +425,13 @@ int run_wgrad(const BwdCtx& b, const WgPlan& w, const PwBind& bd) {
     a.rs[q].ptr = b.c.eo(row_base(w.rows[q]), (int64_t)w.rows[q].c0 * hw);
     a.rs[q].ctot = w.rows[q].ctot; a.rs[q].n = w.rows[q].n;
   }
+  // a 2x2 max-pooled tap slice whose pooled copy exists (c3q_kernel's forward launch read it: u.mp_off, written in csn_forward_train)
+  // is read as a plain tap slice of that copy -- the same values, a quarter of the loads
+  for (int s2 = 0; s2 < a.ps.nsrc; ++s2)
+    if (a.ps.src[s2].mode == PW_POOL2_TAPS && pp.src_kind[s2] == SRC_IN && bd.mp[pp.src_branch[s2]] != nullptr) {
+      a.ps.src[s2].ptr = b.c.eo(bd.mp[pp.src_branch[s2]], (int64_t)pp.src_c0[s2] * hw);
+      a.ps.src[s2].mode = PW_TAPS;
+    }
   a.gpp = (int)((hw + 63) / 64);
   a.ngroups = a.gpp * P.S;
   if (std::getenv("CSN_DEBUG_WGRAD")) {
@@ -454,7 +472,9 @@ int run_wgrad(const BwdCtx& b, const WgPlan& w, const PwBind& bd) {
 }
 
 // skip_apply: reduce + finalise only (the unit's depthwise backward forms dz on load); keep: the arguments, for that kernel
-int run_bn_bwd(const BwdCtx& b, int ui, const UnitPlan& u, int j, bool skip_apply = false, BnBwdArgs* keep = nullptr) {
+// adj2: the apply pass also writes the x2 adjoint-upsampled dz there, and dz itself over the branch's (dead) activation
+int run_bn_bwd(const BwdCtx& b, int ui, const UnitPlan& u, int j, bool skip_apply = false, BnBwdArgs* keep = nullptr,
+               float* adj2 = nullptr) {
   const csn_plan& P = b.c.P;
   const csn_unit_desc& d = u.d;
   const int act = d.out_act[j];
@@ -477,6 +497,7 @@ int run_bn_bwd(const BwdCtx& b, int ui, const UnitPlan& u, int j, bool skip_appl
   a.a16 = b.c.a16 ? 1 : 0;
   a.skip_apply = skip_apply ? 1 : 0;
   a.nslab_in = 0;
+  if (adj2) { a.adj2 = adj2; a.dz_out = b.c.act_y(act); a.W = P.W >> A.lvl; }
   if (!P.virt_cons.empty() && P.virt_cons[act] >= 0) {   // the only consumer's backward kernel has left the partial sums
     const UnitPlan& cu = P.units[P.virt_cons[act]];
     for (int i = 0; i < cu.d.n_in; ++i)
@@ -531,15 +552,25 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
       bool fuse_apply = false;
       if (d.kind == CSN_UNIT_DW && P.bn_bwd_fuse)
         fuse_apply = dw_fused_slabs(P, ub, j, P.acts[d.in_act[j]].lvl, c.lanes, dw_in_virtual(P, ui, j)) > 0;
-      const int st = run_bn_bwd(b, ui, u, j, fuse_apply, &bnargs[j]);
+      // (not with the weight-gradient side lane, CSN_OPT_OVERLAP = 2: the fused pass writes dz over the branch's activation, which
+      // the side lane of the unit AFTER this one may still be reading as its weight-gradient input -- found by
+      // tests/test_gpu_paths.py::test_gpu_overlap2_weight_gradient_lane_is_deterministic on the first graph replay)
+      const int kf = (d.kind == CSN_UNIT_GOCT && !fuse_apply && !c.lanes) ? ub.adj_fused[j] : -1;
+      float* adjp = kf >= 0 ? reinterpret_cast<float*>(scratch + ub.adj[kf].off) : nullptr;
+      const int st = run_bn_bwd(b, ui, u, j, fuse_apply, &bnargs[j], adjp);
       if (st != CSN_OK) return st;
       bn_fused[j] = fuse_apply;
-      bd.dz[j] = reinterpret_cast<const float*>(c.ws + P.tz_off[d.out_act[j]]);
+      bd.dz[j] = kf >= 0 ? c.act_y(d.out_act[j]) : reinterpret_cast<const float*>(c.ws + P.tz_off[d.out_act[j]]);
+      if (kf >= 0) bd.adj[kf] = adjp;
     }
+    bool c3q_fwd = false;   // the train-mode forward ran this 3x3 unit on c3q_kernel: its max-pooled input copies exist (run_unit)
+    if (d.kind == CSN_UNIT_GOCT && d.ksize == 3 && P.c3q && P.tiled3 && !std::getenv("CSN_WGRAD_NO_MP"))
+      for (const PwLaunchPlan& L : u.pwl) c3q_fwd = c3q_fwd || L.c3q;
     for (int i = 0; i < d.n_in; ++i) {
       if (d.cin[i] == 0) continue;
       bd.in[i] = (d.kind == CSN_UNIT_GOCT && d.stride == 2 && !u.std_conv) ? reinterpret_cast<const float*>(c.ws + u.pooled_off[i])
                                                              : c.act_in(d.in_act[i]);
+      if (c3q_fwd && u.mp_off[i] >= 0) bd.mp[i] = reinterpret_cast<const float*>(c.ws + u.mp_off[i]);
     }
   }
   for (int i = 0; i < d.n_in; ++i) {
@@ -641,6 +672,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
   // adjoint-upsampled dz (gOctConv low->high terms)
   for (size_t k = 0; k < ub.adj.size(); ++k) {
     const AdjPlan& ap = ub.adj[k];
+    if (ub.adj_fused[ap.j] == (int)k) continue;   // written by the BatchNorm backward above
     AdjUpArgs ua;
     ua.in = bd.dz[ap.j]; ua.out = reinterpret_cast<float*>(scratch + ap.off);
     ua.planes = S * ap.C; ua.Hl = P.H >> ap.lvl; ua.Wl = P.W >> ap.lvl; ua.f = ap.f;
@@ -873,6 +905,13 @@ int csn_plan_train_act_info(const csn_plan* P, int32_t id, csn_train_act_info* o
   if (!P->train) return CSN_E_STATE;
   out->act_offset_bytes = P->acts[id].ws_off;
   out->z_offset_bytes = P->tz_off[id];
+  out->dz_offset_bytes = P->tz_off[id];
+  {
+    const int pu = id < (int)P->act_prod_unit.size() ? P->act_prod_unit[id] : -1;
+    if (pu >= 0 && P->units[pu].d.kind == CSN_UNIT_GOCT && P->bwd[pu].adj_fused[P->act_prod_branch[id]] >= 0 &&
+        !(P->overlap_bwd && P->overlap))   // (csn_backward: c.lanes -- the side lane keeps dz over z)
+      out->dz_offset_bytes = P->acts[id].ws_off;
+  }
   out->grad_offset_bytes[0] = P->tg_off[id][0];
   out->grad_offset_bytes[1] = P->tg_off[id][1];
   out->x16_offset_bytes = (id == 0 && P->act16) ? P->x16_off : -1;

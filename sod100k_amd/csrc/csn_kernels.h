@@ -336,6 +336,9 @@ int csn_launch_wgrad_c3(const WgArgs& a, void* stream);
 bool csn_wgrad_bf_eligible(const WgArgs& a);                 // k_wgrad_bf.hip: 1x1 passes of the bf16 train step on the bf16 matrix cores
 int csn_wgrad_bf_blocks(const WgArgs& a);
 int csn_launch_wgrad_bf(const WgArgs& a, void* stream);
+bool csn_wgrad_bf3_eligible(const WgArgs& a);                // ... and the 3x3 tap passes (v_mfma_f32_16x16x32_bf16, shifted operands)
+int csn_wgrad_bf3_blocks(const WgArgs& a);
+int csn_launch_wgrad_bf3(const WgArgs& a, void* stream);
 
 // ---------------------------------------------------------------------------------------------
 // train-mode BatchNorm + PReLU + GAP penalty (see k_train.hip)
@@ -420,7 +423,15 @@ struct BnBwdArgs {
   int32_t skip_apply;  // reduce + finalise only: the consumer of dz forms it on load (dw3x3_bwd_kernel, DwBranch::zraw)
   int32_t nslab_in;    // > 0: `partial` already holds that many partials per channel (written by the depthwise backward of the
                        // activation's only consumer, DwBranch::bnred): no reduce pass
+  // round 4: the apply pass also leaves the adjoint of F.interpolate(scale_factor=2, bilinear) of the dz it writes -- the
+  // [S][C][H/2][W/2] tensor the low -> high terms of the unit's weight / input gradients read (csn_backward.inl AdjPlan, f = 2) --
+  // so that adjup2_pair_kernel does not read dz back (null: none; needs W % 8 == 0 and even H, see csn_bn_bwd_adj2_ok)
+  float* adj2 = nullptr;
+  float* dz_out = nullptr;   // adj2 only: dz goes HERE, not over z (a lane reads its neighbours' z / dy: in place would race) -- the
+                             // planner hands over the buffer of the branch's own activation, which is dead at this point of csn_backward
+  int32_t W = 0, pad_ = 0;   // row width of the plane (adj2 only)
 };
+bool csn_bn_bwd_adj2_ok(int64_t HW, int W);
 int csn_launch_bn_bwd(const BnBwdArgs& a, void* stream);
 int csn_launch_bn_bwd_apply(const BnBwdArgs& a, void* stream);   // the apply pass alone (debug: materialise dz for the probes)
 

@@ -112,19 +112,19 @@ __global__ __launch_bounds__(CSN_BLOCK) void msblock_kernel(MsArgs a) {
 // lane; double buffering with R = 4): profiles/r3_notes.md.  Lanes of one (image, dilation): x quads
 // fastest, then the d row residues, then the groups of R d rows; items are WAVES (64 lanes of one image and dilation), all
 // waves of an image on one XCD.
-template <int DC, int R>
+template <int DC, int R, typename AT>
 __device__ __forceinline__ void msr_load(csn_buf rb, const unsigned (&ro)[R + 2], unsigned dl, unsigned dr, unsigned so,
                                          float (&v)[R + 2][12]) {
 #pragma unroll
   for (int r = 0; r < R + 2; ++r) {
     if (DC == 4) {
-      const float4 l = csn_ld4(rb, ro[r] + dl, so), c = csn_ld4(rb, ro[r], so), rr = csn_ld4(rb, ro[r] + dr, so);
+      const float4 l = csn_bufacc<AT>::ld4(rb, ro[r] + dl, so), c = csn_bufacc<AT>::ld4(rb, ro[r], so), rr = csn_bufacc<AT>::ld4(rb, ro[r] + dr, so);
       v[r][0] = l.x; v[r][1] = l.y; v[r][2] = l.z; v[r][3] = l.w;
       v[r][4] = c.x; v[r][5] = c.y; v[r][6] = c.z; v[r][7] = c.w;
       v[r][8] = rr.x; v[r][9] = rr.y; v[r][10] = rr.z; v[r][11] = rr.w;
     } else {
-      const float2 l = csn_ld2(rb, ro[r] + dl, so), rr = csn_ld2(rb, ro[r] + dr, so);
-      const float4 c = csn_ld4(rb, ro[r], so);
+      const float2 l = csn_bufacc<AT>::ld2(rb, ro[r] + dl, so), rr = csn_bufacc<AT>::ld2(rb, ro[r] + dr, so);
+      const float4 c = csn_bufacc<AT>::ld4(rb, ro[r], so);
       v[r][0] = 0.f; v[r][1] = 0.f; v[r][2] = l.x; v[r][3] = l.y;
       v[r][4] = c.x; v[r][5] = c.y; v[r][6] = c.z; v[r][7] = c.w;
       v[r][8] = rr.x; v[r][9] = rr.y; v[r][10] = 0.f; v[r][11] = 0.f;
@@ -148,9 +148,9 @@ __device__ __forceinline__ void msr_fma(const float (&v)[R + 2][12], csn_cfp wc,
   }
 }
 
-template <int NCO, int DC, int R, bool DB>
+template <int NCO, int DC, int R, bool DB, typename AT>
 __device__ __forceinline__ void msr_group(const MsArgs& a, csn_buf rb, const unsigned (&ro)[R + 2], unsigned dl, unsigned dr,
-                                          unsigned cs4, int cinp, csn_cfp wg, float* __restrict__ op, int hw, int rstride, int g,
+                                          unsigned cs4, int cinp, csn_cfp wg, AT* __restrict__ op, int hw, int rstride, int g,
                                           int d, const bool (&st)[R]) {
   float acc[R][NCO][4];
 #pragma unroll
@@ -162,20 +162,20 @@ __device__ __forceinline__ void msr_group(const MsArgs& a, csn_buf rb, const uns
   const int cin = a.cin;
   if (DB) {   // channel c + 1 in flight while channel c is contracted (two register sets)
     float vA[R + 2][12], vB[R + 2][12];
-    msr_load<DC, R>(rb, ro, dl, dr, 0u, vA);
+    msr_load<DC, R, AT>(rb, ro, dl, dr, 0u, vA);
     CSN_SCHED_FENCE();
     for (int ci = 0; ci < cin; ci += 2) {
-      msr_load<DC, R>(rb, ro, dl, dr, (unsigned)min(ci + 1, cin - 1) * cs4, vB);
+      msr_load<DC, R, AT>(rb, ro, dl, dr, (unsigned)min(ci + 1, cin - 1) * cs4, vB);
       CSN_SCHED_FENCE();
       msr_fma<NCO, DC, R>(vA, wg + ci * 72, acc);
-      msr_load<DC, R>(rb, ro, dl, dr, (unsigned)min(ci + 2, cin - 1) * cs4, vA);
+      msr_load<DC, R, AT>(rb, ro, dl, dr, (unsigned)min(ci + 2, cin - 1) * cs4, vA);
       CSN_SCHED_FENCE();
       if (ci + 1 < cin) msr_fma<NCO, DC, R>(vB, wg + (ci + 1) * 72, acc);
     }
   } else {
     for (int ci = 0; ci < cin; ++ci) {
       float v[R + 2][12];
-      msr_load<DC, R>(rb, ro, dl, dr, (unsigned)ci * cs4, v);
+      msr_load<DC, R, AT>(rb, ro, dl, dr, (unsigned)ci * cs4, v);
       msr_fma<NCO, DC, R>(v, wg + ci * 72, acc);
     }
   }
@@ -187,9 +187,9 @@ __device__ __forceinline__ void msr_group(const MsArgs& a, csn_buf rb, const uns
 #pragma unroll
     for (int i = 0; i < R; ++i)
       if (st[i]) {
-        float* q = op + (int64_t)oc * hw + (int64_t)i * rstride;
-        *reinterpret_cast<float4*>(q) = make_float4(csn_epi(acc[i][co][0], sc, shf, al), csn_epi(acc[i][co][1], sc, shf, al),
-                                                    csn_epi(acc[i][co][2], sc, shf, al), csn_epi(acc[i][co][3], sc, shf, al));
+        AT* q = op + (int64_t)oc * hw + (int64_t)i * rstride;
+        act_st4(q, make_float4(csn_epi(acc[i][co][0], sc, shf, al), csn_epi(acc[i][co][1], sc, shf, al),
+                               csn_epi(acc[i][co][2], sc, shf, al), csn_epi(acc[i][co][3], sc, shf, al)));
       }
   }
 }
@@ -200,8 +200,9 @@ __host__ __device__ inline int msr_waves(int H, int QW, int d, int R) {
   return (QW * (((H + span - 1) / span) << d) + 63) >> 6;
 }
 
-template <int R, bool DB>
+template <int R, bool DB, typename AT = float>
 __global__ __launch_bounds__(CSN_BLOCK) void msr_kernel(MsArgs a) {
+  constexpr unsigned E = (unsigned)sizeof(AT);   // (bfloat16: the train-mode forward of the bf16 step, identity epilogue)
   const int H = a.H, W = a.W, QW = W >> 2;
   const int hw = H * W;
   int wmax = 0;
@@ -228,12 +229,12 @@ __global__ __launch_bounds__(CSN_BLOCK) void msr_kernel(MsArgs a) {
   const int y0 = (rest >> d) * span + (rest & (dil - 1));
   const int x0 = 4 * xq;
   const bool valid = y0 < H;   // (rows past the last group: lanes idle)
-  const csn_buf rb = csn_make_buf_n(a.in + (int64_t)b * a.cin * hw, (unsigned)(a.cin * hw) * 4u);
+  const csn_buf rb = csn_make_buf_n(act_cast<AT>(a.in) + (int64_t)b * a.cin * hw, (unsigned)(a.cin * hw) * E);
   unsigned ro[R + 2];
 #pragma unroll
   for (int r = 0; r < R + 2; ++r) {
     const int yy = y0 + (r - 1) * dil;
-    ro[r] = (valid && yy >= 0 && yy < H) ? (unsigned)(yy * W + x0) * 4u : 0x80000000u;
+    ro[r] = (valid && yy >= 0 && yy < H) ? (unsigned)(yy * W + x0) * E : 0x80000000u;
   }
   bool st[R];
 #pragma unroll
@@ -241,20 +242,20 @@ __global__ __launch_bounds__(CSN_BLOCK) void msr_kernel(MsArgs a) {
   // left / right piece: a quad at x0 -+ dil (dil >= 4), else the two columns next to the quad
   const int step = dil >= 4 ? dil : 2, rstep = dil >= 4 ? dil : 4;
   const int rlast = dil >= 4 ? 3 : 1;   // last column of the right piece
-  const unsigned dl = x0 - step >= 0 ? (unsigned)(-step * 4) : 0x40000000u;
-  const unsigned dr = x0 + rstep + rlast < W ? (unsigned)(rstep * 4) : 0x40000000u;
-  float* __restrict__ op = a.out + (int64_t)b * a.cout * hw + (int64_t)(valid ? y0 : 0) * W + x0;
+  const unsigned dl = x0 - step >= 0 ? (unsigned)(-step * (int)E) : 0x40000000u;
+  const unsigned dr = x0 + rstep + rlast < W ? (unsigned)(rstep * (int)E) : 0x40000000u;
+  AT* __restrict__ op = act_cast<AT>(a.out) + (int64_t)b * a.cout * hw + (int64_t)(valid ? y0 : 0) * W + x0;
   const int cinp = (a.cin + 1) & ~1;
   const int ngrp = (nco + 7) >> 3;
   for (int g = 0; g < ngrp; ++g) {
     csn_cfp wg = csn_const(a.w[d]) + (int64_t)g * cinp * 72;
     const int live = min(8, nco - 8 * g);
-#define MSR_ARGS a, rb, ro, dl, dr, (unsigned)hw * 4u, cinp, wg, op, hw, dil * W, g, d, st
+#define MSR_ARGS a, rb, ro, dl, dr, (unsigned)hw * E, cinp, wg, op, hw, dil * W, g, d, st
 #define MSR_CASE(N)                                                                \
   case N:                                                                           \
-    if (d == 0) msr_group<N, 1, R, DB>(MSR_ARGS);                               \
-    else if (d == 1) msr_group<N, 2, R, DB>(MSR_ARGS);                          \
-    else msr_group<N, 4, R, DB>(MSR_ARGS);                                      \
+    if (d == 0) msr_group<N, 1, R, DB, AT>(MSR_ARGS);                           \
+    else if (d == 1) msr_group<N, 2, R, DB, AT>(MSR_ARGS);                      \
+    else msr_group<N, 4, R, DB, AT>(MSR_ARGS);                                  \
     break;
     if (R > 2) {
       switch (live) { MSR_CASE(1) MSR_CASE(2) default: MSR_CASE(3) }
@@ -271,7 +272,8 @@ int csn_launch_ms(const MsArgs& a, void* stream) {
   static const bool rows = !(std::getenv("CSN_MS_ROWS") && std::getenv("CSN_MS_ROWS")[0] == '0');   // 0: one pixel per lane everywhere
   // four pixels per lane (float, rows of whole quads); small maps keep one pixel per lane (28^2 x 64 images is 320 blocks of
   // quads: 42 us against 29 us, profiles/r3_notes.md)
-  if (rows && !a.a16 && (a.W & 3) == 0 && a.H * (a.W >> 2) >= 512) {
+  static const bool rows16 = !(std::getenv("CSN_MS_ROWS16") && std::getenv("CSN_MS_ROWS16")[0] == '0');   // ... also for bfloat16 tensors
+  if (rows && (!a.a16 || rows16) && (a.W & 3) == 0 && a.H * (a.W >> 2) >= 512) {
     int mx = 0;
     for (int d = 0; d < 5; ++d) mx = a.dch[d] > mx ? a.dch[d] : mx;
     // R quads per lane in dilation-strided rows (profiles/r3_notes.md: 94 -> 68 us, 62 -> 57 us)
@@ -281,7 +283,10 @@ int csn_launch_ms(const MsArgs& a, void* stream) {
       if (a.dch[d] > 0) { const int wv = msr_waves(a.H, a.W >> 2, d, R); wmax = wv > wmax ? wv : wmax; }
     const int bpi = (5 * wmax + 3) >> 2;
     const dim3 grid((unsigned)(((a.B + 7) / 8) * bpi * 8));
-    if (R == 4) CSN_LAUNCH((msr_kernel<4, false>), grid, dim3(CSN_BLOCK), 0, stream, a);
+    if (a.a16) {   // (round 4: the train-mode forward of the bf16 step ran the one-pixel-per-lane kernel: 0.92 ms for three launches)
+      if (R == 4) CSN_LAUNCH((msr_kernel<4, false, csn_bf16>), grid, dim3(CSN_BLOCK), 0, stream, a);
+      else CSN_LAUNCH((msr_kernel<2, true, csn_bf16>), grid, dim3(CSN_BLOCK), 0, stream, a);
+    } else if (R == 4) CSN_LAUNCH((msr_kernel<4, false>), grid, dim3(CSN_BLOCK), 0, stream, a);
     else CSN_LAUNCH((msr_kernel<2, true>), grid, dim3(CSN_BLOCK), 0, stream, a);
     return (int)hipGetLastError();
   }

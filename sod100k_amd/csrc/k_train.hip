@@ -298,6 +298,97 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_apply_kernel(BnBwdArgs a) {
   }
 }
 
+// The apply pass of a HIGH output branch of a gOctConv unit, and in the same pass the adjoint of the bilinear x2 upsampling
+// (csnet.py:702-707: y_hi += up(conv(x_lo))) of the dz it writes:  adj[yl][xl] = sum_{yh, xh} w(yh -> yl) w(xh -> xl) dz[yh][xh],
+// w = the forward's own weights (PyTorch align_corners=False: 0.25 / 0.75 towards the two nearest sources, both onto the border
+// source where the index clamps), i.e. per axis  adj[s] = .25 dz[2s - 1] + .75 dz[2s] + .75 dz[2s + 1] + .25 dz[2s + 2]  with the
+// .75 next to a border replaced by 1.  adjup2_pair_kernel computed the same sums from the stored dz (one more pass over the
+// largest gradient tensor of every unit: 2.1 ms of the 49 ms bf16 step); here a lane owns 8 columns of a strip of rows, walks
+// down two rows per step with the two previous row sums in registers, and forms dz for its columns plus one on either side
+// (the neighbours' values are recomputed from dy and z -- the same arithmetic, hence the same value -- not exchanged).
+// grid (C, S), one plane per block; W % 8 == 0, H even.  dz is bit for bit bn_bwd_apply_kernel's; the sums use the values AS
+// STORED (rounded through bfloat16 in that mode), like the two-pass scheme.  dz is NOT written over z (lanes read their neighbours'
+// z and dy): it goes to a.dz_out.
+template <typename AT>
+__global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_apply_adj2_kernel(BnBwdArgs a) {
+  const int c = blockIdx.x, n = blockIdx.y;
+  const int W = a.W, H = (int)(a.HW / W), Wl = W >> 1, Hl = H >> 1;
+  const int64_t base = ((int64_t)n * a.C + c) * a.HW;
+  const float sc = a.scale[c], sh = a.shift[c], al = a.alpha[c], mu = a.mean[c], is = a.invstd[c];
+  const float m1 = a.m1m2[2 * c], m2 = a.m1m2[2 * c + 1];
+  const float gi = a.arena[a.off_weight + c] * is;
+  auto f = [&](float z, float dy) {
+    const float bn = z * sc + sh;
+    const float dbn = bn > 0.f ? dy : al * dy;
+    const float v = gi * (dbn - m1 - (z - mu) * is * m2);
+    return sizeof(AT) == 2 ? csn_bf2f(csn_f2bf(v)) : v;   // the value the consumers of dz will read back
+  };
+  const int LX = W >> 3;                       // lanes per row
+  const int NS = CSN_BLOCK / LX;               // row strips per block
+  const int tid = threadIdx.x;
+  const int lx = tid % LX, st = tid / LX;
+  const int lrows = (Hl + NS - 1) / NS;        // low rows per strip
+  const int yl0 = st * lrows, yl1 = min(Hl, yl0 + lrows);
+  if (st >= NS || yl0 >= yl1) return;
+  const int x0 = lx * 8;
+  const AT* zp = act_cast<AT>(a.z) + base;
+  const AT* ap = act_cast<AT>(a.dyA) + base;
+  const AT* bp = a.dyB ? act_cast<AT>(a.dyB) + base : nullptr;
+  AT* dzp = act_cast<AT>(a.dz_out) + base;
+  AT* op = act_cast<AT>(a.adj2) + ((int64_t)n * a.C + c) * (int64_t)Hl * Wl + (x0 >> 1);
+  const bool has_l = x0 > 0, has_r = x0 + 8 < W;
+  const float wfirst = has_l ? 0.75f : 1.f, wlast = has_r ? 0.75f : 1.f;
+  // dz of row yh for columns x0 - 1 .. x0 + 8 (stored for the lane's own eight when `store`), reduced along x: h[k] = the row's
+  // contribution to low column x0 / 2 + k
+  auto row = [&](int yh, bool store, float (&h)[4]) {
+    if (yh < 0 || yh >= H) { h[0] = h[1] = h[2] = h[3] = 0.f; return; }
+    const int64_t o = (int64_t)yh * W + x0;
+    float4 z0 = act_ld4(zp + o), z1 = act_ld4(zp + o + 4), d0 = act_ld4(ap + o), d1 = act_ld4(ap + o + 4);
+    float zl = has_l ? act_ld(zp + o - 1) : 0.f, zr = has_r ? act_ld(zp + o + 8) : 0.f;
+    float dl = has_l ? act_ld(ap + o - 1) : 0.f, dr = has_r ? act_ld(ap + o + 8) : 0.f;
+    if (bp) {
+      const float4 e0 = act_ld4(bp + o), e1 = act_ld4(bp + o + 4);
+      d0.x += e0.x; d0.y += e0.y; d0.z += e0.z; d0.w += e0.w; d1.x += e1.x; d1.y += e1.y; d1.z += e1.z; d1.w += e1.w;
+      if (has_l) dl += act_ld(bp + o - 1);
+      if (has_r) dr += act_ld(bp + o + 8);
+    }
+    float v[10];
+    v[0] = has_l ? f(zl, dl) : 0.f;
+    v[1] = f(z0.x, d0.x); v[2] = f(z0.y, d0.y); v[3] = f(z0.z, d0.z); v[4] = f(z0.w, d0.w);
+    v[5] = f(z1.x, d1.x); v[6] = f(z1.y, d1.y); v[7] = f(z1.z, d1.z); v[8] = f(z1.w, d1.w);
+    v[9] = has_r ? f(zr, dr) : 0.f;
+    if (store) {
+      act_st4(dzp + o, make_float4(v[1], v[2], v[3], v[4]));
+      act_st4(dzp + o + 4, make_float4(v[5], v[6], v[7], v[8]));
+    }
+    h[0] = 0.25f * v[0] + wfirst * v[1] + 0.75f * v[2] + 0.25f * v[3];
+    h[1] = 0.25f * v[2] + 0.75f * v[3] + 0.75f * v[4] + 0.25f * v[5];
+    h[2] = 0.25f * v[4] + 0.75f * v[5] + 0.75f * v[6] + 0.25f * v[7];
+    h[3] = 0.25f * v[6] + 0.75f * v[7] + wlast * v[8] + 0.25f * v[9];
+  };
+  // rows 2 yl0 - 1 (the strip above owns and stores it: only its sums are needed here) and 2 yl0
+  float hm[4], h0[4], h1[4], h2[4];
+  row(2 * yl0 - 1, false, hm);
+  row(2 * yl0, true, h0);
+  for (int yl = yl0; yl < yl1; ++yl) {
+    row(2 * yl + 1, true, h1);
+    row(2 * yl + 2, yl + 1 < yl1, h2);      // the first row of the next strip is stored by that strip
+    const float wa = yl > 0 ? 0.75f : 1.f, wb = yl + 1 < Hl ? 0.75f : 1.f;
+    float o4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o4[k] = 0.25f * hm[k] + wa * h0[k] + wb * h1[k] + 0.25f * h2[k];
+    act_st4(op + (int64_t)yl * Wl, make_float4(o4[0], o4[1], o4[2], o4[3]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { hm[k] = h1[k]; h0[k] = h2[k]; }
+  }
+}
+
+bool csn_bn_bwd_adj2_ok(int64_t HW, int W) {
+  static const bool off = std::getenv("CSN_ADJ_FUSE") && std::getenv("CSN_ADJ_FUSE")[0] == '0';
+  if (off || W <= 0 || (W & 7) != 0 || HW % W != 0 || W / 8 > CSN_BLOCK) return false;
+  return ((HW / W) & 1) == 0;
+}
+
 // depthwise 3x3 weight gradient: dW[c][t] = 100 * sum_{n,p} dz[n,c,p] * x[n,c,p + off(t)]   (conv2d.py:104)
 // A lane owns QUADS of four consecutive pixels of a row (W % 4 == 0, chunks start on multiples of four): one vector load
 // of dz, three of x (rows y - 1, y, y + 1; rows outside the plane fall out of the bounded buffer range and read as 0) plus
@@ -466,6 +557,61 @@ __global__ __launch_bounds__(CSN_BLOCK) void adjup2_pair_kernel(AdjUpArgs a) {
   }
 }
 
+// f = 4, W % 8 == 0, H % 4 == 0 (CSFHead.fuse / fuse1x1: dz of the 112^2 branch towards the 28^2 one): the generic kernel above gathers
+// an 8 x 8 window per source pixel with scalar loads and recomputes the forward's index arithmetic per tap (0.45 ms per launch for
+// 0.5 GB).  Here a lane owns 8 columns (two source columns) of a strip of rows and walks down them once: per row one 128-bit load
+// plus the pair of columns on either side, the row reduced along x with the 8 constant weights of the x4 adjoint
+// (.125 .375 .625 .875 .875 .625 .375 .125; next to a border the two clamped outputs carry weight 1), and added into the two source
+// rows it belongs to.  grid = planes.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(CSN_BLOCK) void adjup4_rows_kernel(AdjUpArgs a) {
+  const int Hl = a.Hl, Wl = a.Wl, H = Hl * 4, W = Wl * 4;
+  const int64_t pl = blockIdx.x;
+  const TI* ip = act_cast<TI>(a.in) + pl * (int64_t)H * W;
+  TO* op = act_cast<TO>(a.out) + pl * (int64_t)Hl * Wl;
+  const int LX = W >> 3, NS = CSN_BLOCK / LX;
+  const int tid = threadIdx.x, lx = tid % LX, st = tid / LX;
+  const int lrows = (Hl + NS - 1) / NS;
+  const int yl0 = st * lrows, yl1 = min(Hl, yl0 + lrows);
+  if (st >= NS || yl0 >= yl1) return;
+  const int x0 = lx * 8;
+  const bool has_l = x0 > 0, has_r = x0 + 8 < W;
+  const float w8[8] = {0.125f, 0.375f, 0.625f, 0.875f, 0.875f, 0.625f, 0.375f, 0.125f};
+  float wa[8], wb[8];   // weights of columns x0 - 2 .. x0 + 5 towards source column x0 / 4, of x0 + 2 .. x0 + 9 towards x0 / 4 + 1
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { wa[i] = w8[i]; wb[i] = w8[i]; }
+  if (!has_l) { wa[2] = 1.f; wa[3] = 1.f; }    // outputs 0 and 1 clamp onto source column 0
+  if (!has_r) { wb[4] = 1.f; wb[5] = 1.f; }    // outputs W - 2, W - 1 onto the last one
+  auto row = [&](int yh, float& h0, float& h1) {
+    const TI* rp = ip + (int64_t)yh * W + x0;
+    const float4 c0 = act_ld4(rp), c1 = act_ld4(rp + 4);
+    float2 l = make_float2(0.f, 0.f), r = make_float2(0.f, 0.f);
+    if (has_l) l = act_ld2(rp - 2);
+    if (has_r) r = act_ld2(rp + 8);
+    const float v[12] = {l.x, l.y, c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, r.x, r.y};
+    h0 = 0.f; h1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { h0 = fmaf(wa[i], v[i], h0); h1 = fmaf(wb[i], v[4 + i], h1); }
+  };
+  // source row yl receives from the output rows 4 yl - 2 .. 4 yl + 5 with the same weights (clamped rows: weight 1)
+  for (int yl = yl0; yl < yl1; ++yl) {
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int yh = 4 * yl - 2 + i;
+      if (yh < 0 || yh >= H) continue;
+      float wv = w8[i];
+      if (yl == 0 && (i == 2 || i == 3)) wv = 1.f;
+      if (yl == Hl - 1 && (i == 4 || i == 5)) wv = 1.f;
+      float h0, h1;
+      row(yh, h0, h1);
+      a0 = fmaf(wv, h0, a0);
+      a1 = fmaf(wv, h1, a1);
+    }
+    act_st2(op + (int64_t)yl * Wl + (x0 >> 2), make_float2(a0, a1));
+  }
+}
+
 // adjoint of avg_pool2d(2, 2): dx[p] = 0.25 * dxp[p >> 1]
 template <typename AT>
 __global__ __launch_bounds__(CSN_BLOCK) void avgpool2_bwd_kernel(PoolBwdArgs a) {
@@ -611,7 +757,11 @@ int csn_launch_bn_bwd(const BnBwdArgs& a0, void* stream) {
   if (a.nslab_in > 0) a.nslab = a.nslab_in;
   else CSN_LAUNCH_AT(a.a16, bn_bwd_reduce_kernel, dim3(a.nslab, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   CSN_LAUNCH(bn_bwd_finalize_kernel, dim3(a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
-  if (!a.skip_apply) CSN_LAUNCH_AT(a.a16, bn_bwd_apply_kernel, dim3(a.C, a.S), dim3(CSN_BLOCK), 0, stream, a);
+  if (!a.skip_apply) {
+    if (a.adj2 && a.dz_out && a.dz_out != a.z && csn_bn_bwd_adj2_ok(a.HW, a.W)) CSN_LAUNCH_AT(a.a16, bn_bwd_apply_adj2_kernel, dim3(a.C, a.S), dim3(CSN_BLOCK), 0, stream, a);
+    else if (a.adj2) return 1;   // (the caller asks csn_bn_bwd_adj2_ok first)
+    else CSN_LAUNCH_AT(a.a16, bn_bwd_apply_kernel, dim3(a.C, a.S), dim3(CSN_BLOCK), 0, stream, a);
+  }
   return (int)hipGetLastError();
 }
 int csn_launch_gap_tiles(const GapTilesArgs& a, void* stream) {
@@ -635,6 +785,14 @@ int csn_launch_dw_wgrad(const DwWgradArgs& a0, void* stream) {
 }
 // in16 / out16: element type of the source / destination (the logits gradient arrives as float whatever the mode)
 int csn_launch_adjup(const AdjUpArgs& a, void* stream) {
+  static const bool rows4_off = std::getenv("CSN_ADJ4_ROWS") && std::getenv("CSN_ADJ4_ROWS")[0] == '0';
+  if (a.f == 4 && !rows4_off && ((a.Wl * 4) & 7) == 0 && (a.Wl * 4) / 8 <= CSN_BLOCK) {
+    const dim3 grid(a.planes), block(CSN_BLOCK);
+    if (a.in16 && a.out16) CSN_LAUNCH((adjup4_rows_kernel<csn_bf16, csn_bf16>), grid, block, 0, stream, a);
+    else if (a.out16) CSN_LAUNCH((adjup4_rows_kernel<float, csn_bf16>), grid, block, 0, stream, a);
+    else if (!a.in16) CSN_LAUNCH((adjup4_rows_kernel<float, float>), grid, block, 0, stream, a);
+    if (!(a.in16 && !a.out16)) return (int)hipGetLastError();
+  }
   const bool pair = a.f == 2 && (a.Wl & 1) == 0;
   const dim3 grid(grid_for((int64_t)a.planes * a.Hl * (pair ? (a.Wl >> 1) : a.Wl))), block(CSN_BLOCK);
   if (pair) {

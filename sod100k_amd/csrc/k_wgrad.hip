@@ -306,6 +306,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void wgrad_reduce_kernel(WgReduceArgs a)
 static bool wgrad_wave_fits(const WgArgs& a) { return a.k16 <= 64 && a.rows16 <= 48; }
 
 int csn_wgrad_blocks(const WgArgs& a) {
+  if (csn_wgrad_bf3_eligible(a)) return csn_wgrad_bf3_blocks(a);
   if (csn_wgrad_c3_eligible(a)) return csn_wgrad_c3_blocks(a);
   if (csn_wgrad_bf_eligible(a)) return csn_wgrad_bf_blocks(a);
   const int units = wgrad_wave_fits(a) ? (a.ngroups + 3) / 4 : a.ngroups;
@@ -338,6 +339,7 @@ static int launch_wgrad_t(const WgArgs& a, void* stream) {
 
 int csn_launch_wgrad(const WgArgs& a, void* stream) {
   if (a.rows16 > 16 * WG_MAX_NT) return -1;
+  if (csn_wgrad_bf3_eligible(a)) return csn_launch_wgrad_bf3(a, stream);   // bf16 tensors, 3x3 taps: shifted operands (k_wgrad_bf.hip)
   if (csn_wgrad_c3_eligible(a)) return csn_launch_wgrad_c3(a, stream);   // 3x3 tap slices: LDS-tiled (k_wgrad_c3.hip)
   if (csn_wgrad_bf_eligible(a)) return csn_launch_wgrad_bf(a, stream);   // bf16 tensors, 1x1: operands straight from the loads (k_wgrad_bf.hip)
   return a.a16 ? launch_wgrad_t<csn_bf16>(a, stream) : launch_wgrad_t<float>(a, stream);

@@ -283,6 +283,208 @@ __global__ __launch_bounds__(CSN_BLOCK, 2) void wgrad_bf16_kernel(WgBfArgs a_byv
 }
 #endif
 
+// ================================================================================================ 3x3 tap passes
+// dW[row][9 ch + t] = sum_{n, p} dz[row][p] * x[ch][p + off(t)],  t = 3 (dy + 1) + (dx + 1)        (csnet.py:664-726 with k = 3;
+// x = the pass-resolution input: the avg-pooled copy of a stride-2 unit, or the 2x2 max-pooled copy c3q_kernel reads)
+// on v_mfma_f32_16x16x32_bf16 with the same "a load is an operand" mapping: lane l holds A[i = l & 15][8 (l >> 4) .. + 7], four k
+// groups of 8 pixels; with S sub-blocks the 16 rows are (plane i / S, sub-block i % S) and a load instruction covers 16 / S planes
+// x 32 S pixels.  The B operand of tap (dy, dx) is the lane's 8 pixels shifted by dy rows and dx columns: per (channel tile, dy) ONE
+// 128-bit load of the row y + dy plus the dword on either side; dx = -1 / +1 are v_alignbit_b32 of neighbouring dwords
+// (8 bfloat16 shifted by one element), rows / columns outside the plane are masked to zero (the conv's padding).  W % 8 == 0: a
+// lane's 8 pixels lie in one image row.  9 x NTR x NTC accumulator tiles (4 registers each) live over all items of a wave.
+struct WgBf3Args {
+  WgBfSrc rs[3];        // dz rows
+  WgBfSrc cs[3];        // tap channels (pass resolution), source after source
+  int32_t nrs, ncs;
+  int32_t R, C;         // rows; channels of THIS launch = [c_first, c_first + C) of the concatenated sources
+  int32_t c_first;
+  int32_t HW, W, H, B;
+  int32_t slog, L, runs, nitems, nblk;
+  int32_t rows16, k16;
+  float* partial;       // [nblk][rows16][k16], column 9 (c_first + ch) + t
+};
+typedef const CSN_CONST_AS WgBf3Args* WgBf3ArgsP;
+
+#ifdef CSN_CPU_EMU
+template <int NTR, int NTC>
+__global__ void wgrad_bf16_c3_kernel(WgBf3Args a_byval) {
+  const WgBf3Args* a = &a_byval;
+  if (threadIdx.x != 0) return;
+  const int S = 1 << a->slog, PXS = 32 * S, HW = a->HW, W = a->W, H = a->H, R = a->R, C = a->C;
+  std::vector<float> acc((size_t)R * C * 9, 0.f), dz(R);
+  for (int wave = 0; wave < 4; ++wave)
+    for (int it = blockIdx.x * 4 + wave; it < a->nitems; it += a->nblk * 4) {
+      const int b = it / a->runs, run = it - b * a->runs;
+      const int q0 = run * a->L * PXS, q1 = min(HW, q0 + a->L * PXS);
+      for (int p = q0; p < q1; ++p) {
+        const int y = p / W, x = p - y * W;
+        for (int r = 0; r < R; ++r) {
+          const char* base; unsigned is;
+          wgbf_plane(a->rs, a->nrs, r, HW, base, is);
+          dz[r] = csn_bf2f(reinterpret_cast<const unsigned short*>(base)[(int64_t)b * is + p]);
+        }
+        for (int ch = 0; ch < C; ++ch) {
+          const char* base; unsigned is;
+          wgbf_plane(a->cs, a->ncs, a->c_first + ch, HW, base, is);
+          const unsigned short* pl = reinterpret_cast<const unsigned short*>(base) + (int64_t)b * is;
+          for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+            const float v = csn_bf2f(pl[yy * W + xx]);
+            for (int r = 0; r < R; ++r) acc[((size_t)r * C + ch) * 9 + t] = fmaf(dz[r], v, acc[((size_t)r * C + ch) * 9 + t]);
+          }
+        }
+      }
+    }
+  float* out = a->partial + (int64_t)blockIdx.x * a->rows16 * a->k16;
+  for (int r = 0; r < R; ++r)
+    for (int ch = 0; ch < C; ++ch)
+      for (int t = 0; t < 9; ++t) out[(int64_t)r * a->k16 + 9 * (a->c_first + ch) + t] = acc[((size_t)r * C + ch) * 9 + t];
+}
+#else
+typedef float wgb_f4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) unsigned* wgbf_gp1;
+__device__ __forceinline__ unsigned wgbf_ld1(const char* p) { return *(wgbf_gp1)(unsigned long long)p; }
+
+template <int NTR, int NTC>
+__global__ __launch_bounds__(CSN_BLOCK, 2) void wgrad_bf16_c3_kernel(WgBf3Args a_byval) {
+  CSN_DYN_SMEM(float, lds);
+  WgBf3ArgsP a = CSN_KERNARG(WgBf3Args, a_byval);
+  constexpr int NT = NTR + NTC;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int sl = a->slog, S = 1 << sl, PXS = 32 << sl, TP = 16 >> sl;
+  const int HW = a->HW, W = a->W, H = a->H;
+  csn_u2* tabp = reinterpret_cast<csn_u2*>(lds);                 // [NT][64]
+  unsigned* tabs = reinterpret_cast<unsigned*>(lds) + NT * 128;  // [NT][64]
+  for (int e = tid; e < NT * 64; e += CSN_BLOCK) {
+    const int t = e >> 6, l = e & 63;
+    const int pl = (l & 15) >> sl;
+    const char* base;
+    unsigned is;
+    if (t < NTR) wgbf_plane(a->rs, a->nrs, min(t * TP + pl, a->R - 1), HW, base, is);
+    else wgbf_plane(a->cs, a->ncs, a->c_first + min((t - NTR) * TP + pl, a->C - 1), HW, base, is);
+    const unsigned long long bv = (unsigned long long)base;
+    csn_u2 v;
+    v.x = (unsigned)bv; v.y = (unsigned)(bv >> 32);
+    tabp[e] = v;
+    tabs[e] = is;
+  }
+  __syncthreads();
+  const int lpix = ((lane >> 4) << (3 + sl)) + ((lane & (S - 1)) << 3);   // this lane's first pixel inside a set
+  const float rcpW = 1.0f / (float)W;
+  wgb_f4 acc[9][NTR][NTC];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int tr = 0; tr < NTR; ++tr)
+#pragma unroll
+      for (int tc = 0; tc < NTC; ++tc)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][tr][tc][i] = 0.f;
+
+  for (int it = blockIdx.x * 4 + wave; it < a->nitems; it += a->nblk * 4) {
+    const int b = it / a->runs, run = it - b * a->runs;
+    const int q0 = run * a->L * PXS;
+    const int nset = min(a->L, (HW - q0) / PXS);
+    const char* pr[NTR];
+    const char* pc[NTC];
+#pragma unroll
+    for (int t = 0; t < NTR; ++t) {
+      const csn_u2 bp = tabp[t * 64 + lane];
+      const unsigned long long base = ((unsigned long long)bp.y << 32) | bp.x;
+      pr[t] = reinterpret_cast<const char*>(base + 2ull * ((unsigned long long)b * tabs[t * 64 + lane] + (unsigned)(q0 + lpix)));
+    }
+#pragma unroll
+    for (int t = 0; t < NTC; ++t) {
+      const csn_u2 bp = tabp[(NTR + t) * 64 + lane];
+      const unsigned long long base = ((unsigned long long)bp.y << 32) | bp.x;
+      pc[t] = reinterpret_cast<const char*>(base + 2ull * ((unsigned long long)b * tabs[(NTR + t) * 64 + lane]));
+    }
+    for (int s = 0; s < nset; ++s) {
+      const int p = q0 + s * PXS + lpix;
+      int y = (int)((float)p * rcpW);
+      y -= (y * W > p) ? 1 : 0;
+      y += ((y + 1) * W <= p) ? 1 : 0;
+      const int x = p - y * W;
+      const bool has_l = x > 0, has_r = x + 8 < W;
+      csn_u4 A[NTR], V[NTC][3];
+      unsigned Ld[NTC][3], Rd[NTC][3];
+#pragma unroll
+      for (int t = 0; t < NTR; ++t) A[t] = wgbf_ld(pr[t] + s * (PXS * 2));
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int yc = min(max(y + dy - 1, 0), H - 1);          // a row outside the plane: fetched from a valid one, masked below
+        const unsigned o = (unsigned)(yc * W + x) * 2u;
+#pragma unroll
+        for (int t = 0; t < NTC; ++t) {
+          V[t][dy] = wgbf_ld(pc[t] + o);
+          Ld[t][dy] = wgbf_ld1(pc[t] + o - (has_l ? 4u : 0u));
+          Rd[t][dy] = wgbf_ld1(pc[t] + o + (has_r ? 16u : 12u));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);   // every load of the set is in flight before the first contraction
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const unsigned mrow = (y + dy - 1 >= 0 && y + dy - 1 < H) ? 0xffffffffu : 0u;
+        const unsigned ml = has_l ? mrow : 0u, mr = has_r ? mrow : 0u;
+#pragma unroll
+        for (int tc = 0; tc < NTC; ++tc) {
+          csn_u4 c0 = V[tc][dy];
+          c0.x &= mrow; c0.y &= mrow; c0.z &= mrow; c0.w &= mrow;
+          const unsigned l = Ld[tc][dy] & ml, r = Rd[tc][dy] & mr;
+          csn_u4 cm, cp;   // columns x - 1 .. x + 6 and x + 1 .. x + 8
+          cm.x = __builtin_amdgcn_alignbit(c0.x, l, 16); cm.y = __builtin_amdgcn_alignbit(c0.y, c0.x, 16);
+          cm.z = __builtin_amdgcn_alignbit(c0.z, c0.y, 16); cm.w = __builtin_amdgcn_alignbit(c0.w, c0.z, 16);
+          cp.x = __builtin_amdgcn_alignbit(c0.y, c0.x, 16); cp.y = __builtin_amdgcn_alignbit(c0.z, c0.y, 16);
+          cp.z = __builtin_amdgcn_alignbit(c0.w, c0.z, 16); cp.w = __builtin_amdgcn_alignbit(r, c0.w, 16);
+#pragma unroll
+          for (int tr = 0; tr < NTR; ++tr) {
+            const wgb_bf8 av = __builtin_bit_cast(wgb_bf8, A[tr]);
+            acc[3 * dy + 0][tr][tc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(wgb_bf8, cm), acc[3 * dy + 0][tr][tc], 0, 0, 0);
+            acc[3 * dy + 1][tr][tc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(wgb_bf8, c0), acc[3 * dy + 1][tr][tc], 0, 0, 0);
+            acc[3 * dy + 2][tr][tc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(wgb_bf8, cp), acc[3 * dy + 2][tr][tc], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- the four waves' 16 x 16 tiles through LDS, four tiles per round: sum the S diagonal blocks, write the block's partial
+  float* out = a->partial + (int64_t)blockIdx.x * a->rows16 * a->k16;
+  const int j = lane & 15, i0 = (lane >> 4) * 4;
+  const int k16 = a->k16, Rr = a->R, Cc = a->C, cfirst = a->c_first;
+  constexpr int NTILE = 9 * NTR * NTC;
+#pragma unroll
+  for (int r0 = 0; r0 < NTILE; r0 += 4) {
+    __syncthreads();   // (first round: the plane table is no longer read)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int tl = r0 + q;
+      if (tl < NTILE) {
+        const int t9 = tl / (NTR * NTC), tr = (tl / NTC) % NTR, tc = tl % NTC;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) lds[(q * 4 + wave) * 256 + (i0 + reg) * 16 + j] = acc[t9][tr][tc][reg];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int tl = r0 + q;
+      if (tl < NTILE && tid < TP * TP) {
+        const int t9 = tl / (NTR * NTC), tr = (tl / NTC) % NTR, tc = tl % NTC;
+        const int r = tid / TP, c = tid - r * TP;
+        float v = 0.f;
+        for (int w = 0; w < 4; ++w)
+          for (int s = 0; s < S; ++s) v += lds[(q * 4 + w) * 256 + (r * S + s) * 16 + c * S + s];
+        const int row = tr * TP + r, ch = tc * TP + c;
+        if (row < Rr && ch < Cc) out[(int64_t)row * k16 + 9 * (cfirst + ch) + t9] = v;
+      }
+    }
+  }
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------ host side
 namespace {
 struct WgBfCfg { int slog, ntr, ntc, L, runs, nitems, nblk; bool pool; };
@@ -370,4 +572,101 @@ int csn_launch_wgrad_bf(const WgArgs& a, void* stream) {
     case 42: return wgbf_launch_t<4, 2>(q, c.pool, stream);
     default: return -1;
   }
+}
+
+// ---- 3x3 tap passes
+namespace {
+struct WgBf3Cfg { int slog, ntr, ntc, maxch, L, runs, nitems, nblk; };
+
+bool wgbf3_config(const WgArgs& a, WgBf3Cfg* c) {
+  static const bool off = std::getenv("CSN_WGRAD_BF3") && std::getenv("CSN_WGRAD_BF3")[0] == '0';
+  if (off || !a.a16) return false;
+  const PwPass& ps = a.ps;
+  if (ps.nsrc < 1 || ps.nsrc > 3 || a.nrs < 1 || a.nrs > 3) return false;
+  int C = 0;
+  for (int s = 0; s < ps.nsrc; ++s) {
+    if (ps.src[s].mode != PW_TAPS || ps.src[s].dil != 1) return false;
+    C += ps.src[s].C;
+  }
+  const int64_t HW = (int64_t)a.Hr * a.Wr;
+  if ((a.Wr % 8) != 0 || HW % 32 != 0 || HW > (1 << 24) || ps.cin != 9 * C) return false;
+  const int R = ps.nrows;
+  if (R < 1 || C < 1) return false;
+  int best = -1, best_chunks = 1 << 30;
+  for (int sl = 2; sl >= 0; --sl) {
+    const int S = 1 << sl, TP = 16 >> sl;
+    if (HW % (32 * S) != 0) continue;
+    const int ntr = (R + TP - 1) / TP;
+    if (ntr > 4) continue;
+    const int maxch = TP * (ntr <= 2 ? 2 : 1);
+    const int chunks = (C + maxch - 1) / maxch;
+    if (chunks < best_chunks) { best = sl; best_chunks = chunks; }   // (ties: the larger S, i.e. the longer contiguous runs)
+  }
+  if (best < 0) return false;
+  const int S = 1 << best, TP = 16 >> best;
+  c->slog = best; c->ntr = (R + TP - 1) / TP;
+  c->maxch = TP * (c->ntr <= 2 ? 2 : 1);
+  c->ntc = ((C < c->maxch ? C : c->maxch) + TP - 1) / TP;
+  const int64_t sets_img = HW / (32 * S), total = sets_img * a.B;
+  int64_t L = total / (12 * 4 * WG_MAX_BLOCKS);
+  L = L < 1 ? 1 : (L > 16 ? 16 : L);
+  c->L = (int)L;
+  c->runs = (int)((sets_img + L - 1) / L);
+  c->nitems = c->runs * a.B;
+  const int nb = (c->nitems + 3) / 4;
+  c->nblk = nb < WG_MAX_BLOCKS ? nb : WG_MAX_BLOCKS;
+  return true;
+}
+
+template <int NTR, int NTC>
+int wgbf3_launch_t(const WgBf3Args& q, void* stream) {
+  CSN_LAUNCH((wgrad_bf16_c3_kernel<NTR, NTC>), dim3(q.nblk), dim3(CSN_BLOCK), 4 * 1024 * sizeof(float), stream, q);
+  return (int)hipGetLastError();
+}
+}  // namespace
+
+bool csn_wgrad_bf3_eligible(const WgArgs& a) {
+  WgBf3Cfg c;
+  return wgbf3_config(a, &c);
+}
+
+int csn_wgrad_bf3_blocks(const WgArgs& a) {
+  WgBf3Cfg c;
+  return wgbf3_config(a, &c) ? c.nblk : 0;
+}
+
+int csn_launch_wgrad_bf3(const WgArgs& a, void* stream) {
+  WgBf3Cfg c;
+  if (!wgbf3_config(a, &c) || c.nblk != a.nblk) return -1;
+  WgBf3Args q;
+  int Ctot = 0;
+  for (int s = 0; s < 3; ++s) {
+    q.rs[s].ptr = s < a.nrs ? a.rs[s].ptr : nullptr; q.rs[s].ctot = s < a.nrs ? a.rs[s].ctot : 0; q.rs[s].n = s < a.nrs ? a.rs[s].n : 0;
+    q.cs[s].ptr = s < a.ps.nsrc ? a.ps.src[s].ptr : nullptr; q.cs[s].ctot = s < a.ps.nsrc ? a.ps.src[s].Ctot : 0;
+    q.cs[s].n = s < a.ps.nsrc ? a.ps.src[s].C : 0;
+    Ctot += q.cs[s].n;
+  }
+  q.nrs = a.nrs; q.ncs = a.ps.nsrc;
+  q.R = a.ps.nrows;
+  q.HW = a.Hr * a.Wr; q.W = a.Wr; q.H = a.Hr; q.B = a.B;
+  q.slog = c.slog; q.L = c.L; q.runs = c.runs; q.nitems = c.nitems; q.nblk = c.nblk;
+  q.rows16 = a.rows16; q.k16 = a.k16; q.partial = a.partial;
+  const int TP = 16 >> c.slog;
+  for (int c0 = 0; c0 < Ctot; c0 += c.maxch) {   // channel chunks: disjoint columns of the same partial slices
+    q.c_first = c0;
+    q.C = Ctot - c0 < c.maxch ? Ctot - c0 : c.maxch;
+    const int ntc = (q.C + TP - 1) / TP;
+    int st = -1;
+    switch (c.ntr * 10 + ntc) {
+      case 11: st = wgbf3_launch_t<1, 1>(q, stream); break;
+      case 12: st = wgbf3_launch_t<1, 2>(q, stream); break;
+      case 21: st = wgbf3_launch_t<2, 1>(q, stream); break;
+      case 22: st = wgbf3_launch_t<2, 2>(q, stream); break;
+      case 31: st = wgbf3_launch_t<3, 1>(q, stream); break;
+      case 41: st = wgbf3_launch_t<4, 1>(q, stream); break;
+      default: return -1;
+    }
+    if (st != 0) return st;
+  }
+  return 0;
 }

@@ -224,13 +224,12 @@ class Engine:
         return self.workspace[off:off + 4 * n].view(torch.float32).view(shape)
 
     def train_probe(self, act_id: int, what: str) -> torch.Tensor:
-        """float32 copy of a train-step tensor of activation `act_id`: "act", "z" (raw conv output after the forward, dz after
-        the backward), "grad0" / "grad1" (gradient contributed by the first / second consumer)."""
+        """float32 copy of a train-step tensor of activation `act_id`: "act", "z" (raw conv output after the forward), "dz" (after the backward), "grad0" / "grad1" (gradient contributed by the first / second consumer)."""
         ti = N.TrainActInfo()
         N.check(self.lib, self.lib.csn_plan_train_act_info(self.plan, act_id, C.byref(ti)), "csn_plan_train_act_info")
         bf16 = bool(ti.bf16)
         off = {"act": ti.x16_offset_bytes if (act_id == 0 and bf16) else ti.act_offset_bytes, "z": ti.z_offset_bytes,
-               "grad0": ti.grad_offset_bytes[0], "grad1": ti.grad_offset_bytes[1]}[what]
+               "dz": ti.dz_offset_bytes, "grad0": ti.grad_offset_bytes[0], "grad1": ti.grad_offset_bytes[1]}[what]
         if off < 0:
             raise ValueError(f"activation {act_id} has no '{what}' buffer")
         return self._ws_tensor(off, act_id, bf16).to(torch.float32).clone()

@@ -709,7 +709,7 @@ def _check_train_units_local(lib, device, manifest, B, size, act_dtype, state, f
         Z[a] = eng.train_probe(a, "z").cpu()
     loss, dy = bce_and_grad(m._lib or N.load(), y, td)
     flat = m._train_backward_raw(xd, dy, flops_weight / B).cpu()
-    DZ = {a: eng.train_probe(a, "z").cpu() for a in range(1, n_acts)}
+    DZ = {a: eng.train_probe(a, "dz").cpu() for a in range(1, n_acts)}
     G = {}
     for a in range(1, n_acts):
         for s in range(eng.n_consumers(a)):

@@ -18,7 +18,7 @@ static float bf2f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; m
 static unsigned rng = 12345u;
 static float rnd() { rng = rng * 1664525u + 1013904223u; return ((rng >> 8) & 0xffff) / 65536.0f - 0.5f; }
 
-struct Case { const char* name; int nrs; int rn[3]; int rctot[3]; int ncs; int cn[3]; int cctot[3]; int H, W, B; bool pool; bool check; };
+struct Case { const char* name; int nrs; int rn[3]; int rctot[3]; int ncs; int cn[3]; int cctot[3]; int H, W, B; bool pool; bool check; bool taps = false; };
 
 static int run(const Case& c) {
   const int HW = c.H * c.W;
@@ -46,35 +46,39 @@ static int run(const Case& c) {
     hipMemcpy(dc[q], hc[q].data(), hc[q].size() * 2, hipMemcpyHostToDevice);
     const int c0 = c.cctot[q] > c.cn[q] ? 1 : 0;
     a.ps.src[q].ptr = reinterpret_cast<const float*>(dc[q] + (int64_t)c0 * chw); a.ps.src[q].C = c.cn[q]; a.ps.src[q].Ctot = c.cctot[q];
-    a.ps.src[q].mode = c.pool ? PW_POOL2 : PW_OWN; a.ps.src[q].K = c.cn[q];
-    K += c.cn[q];
+    a.ps.src[q].mode = c.taps ? PW_TAPS : (c.pool ? PW_POOL2 : PW_OWN); a.ps.src[q].K = (c.taps ? 9 : 1) * c.cn[q];
+    a.ps.src[q].dil = 1;
+    K += (c.taps ? 9 : 1) * c.cn[q];
   }
   a.ps.nsrc = c.ncs; a.ps.cin = K; a.ps.nrows = R;
   a.Hr = c.H; a.Wr = c.W; a.B = c.B; a.a16 = 1;
   a.rows16 = (R + 15) & ~15; a.k16 = (K + 15) & ~15;
-  if (!csn_wgrad_bf_eligible(a)) { printf("%-34s NOT ELIGIBLE\n", c.name); return 1; }
-  a.nblk = csn_wgrad_bf_blocks(a);
+  if (!(c.taps ? csn_wgrad_bf3_eligible(a) : csn_wgrad_bf_eligible(a))) { printf("%-34s NOT ELIGIBLE\n", c.name); return 1; }
+  a.nblk = c.taps ? csn_wgrad_bf3_blocks(a) : csn_wgrad_bf_blocks(a);
+  auto launch = [&]() { return c.taps ? csn_launch_wgrad_bf3(a, nullptr) : csn_launch_wgrad_bf(a, nullptr); };
   const size_t pf = (size_t)a.nblk * a.rows16 * a.k16;
   hipMalloc(&a.partial, pf * 4);
   hipMemset(a.partial, 0xff, pf * 4);
-  int st = csn_launch_wgrad_bf(a, nullptr);
+  int st = launch();
   hipError_t e = hipDeviceSynchronize();
   if (st != 0 || e != hipSuccess) { printf("%-34s launch failed %d %s\n", c.name, st, hipGetErrorString(e)); return 1; }
   WgBfCfg cfg;
-  wgbf_config(a, &cfg);
+  memset(&cfg, 0, sizeof(cfg));
+  if (c.taps) { WgBf3Cfg c3; wgbf3_config(a, &c3); cfg.slog = c3.slog; cfg.ntr = c3.ntr; cfg.ntc = c3.ntc; cfg.L = c3.L; cfg.nitems = c3.nitems; cfg.nblk = c3.nblk; }
+  else wgbf_config(a, &cfg);
   float ms = 0.f;
   {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int reps = c.check ? 1 : 5;
     hipEventRecord(e0, nullptr);
-    for (int i = 0; i < reps; ++i) csn_launch_wgrad_bf(a, nullptr);
+    for (int i = 0; i < reps; ++i) launch();
     hipEventRecord(e1, nullptr);
     hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
     ms /= reps;
   }
-  const double bytes = 2.0 * c.B * HW * R + 2.0 * c.B * chw * K;
+  const double bytes = 2.0 * c.B * HW * R + 2.0 * c.B * chw * (c.taps ? K / 9 : K);
   int bad = 0;
   double maxerr = 0;
   if (c.check) {
@@ -82,6 +86,32 @@ static int run(const Case& c) {
     hipMemcpy(part.data(), a.partial, pf * 4, hipMemcpyDeviceToHost);
     std::vector<double> ref((size_t)R * K, 0.0), mag((size_t)R * K, 0.0);
     std::vector<float> dzv(R), gv(K);
+    if (c.taps) {
+      const int Cc = K / 9;
+      std::vector<const unsigned short*> cpl(Cc);
+      for (int b = 0; b < c.B; ++b) {
+        int k = 0;
+        for (int q = 0; q < c.ncs; ++q) {
+          const int c0 = c.cctot[q] > c.cn[q] ? 1 : 0;
+          for (int i = 0; i < c.cn[q]; ++i) cpl[k++] = &hc[q][((size_t)b * c.cctot[q] + c0 + i) * HW];
+        }
+        for (int p = 0; p < HW; ++p) {
+          const int y = p / c.W, x = p % c.W;
+          int r = 0;
+          for (int q = 0; q < c.nrs; ++q) {
+            const int c0 = c.rctot[q] > c.rn[q] ? 1 : 0;
+            for (int i = 0; i < c.rn[q]; ++i) dzv[r++] = bf2f(hr[q][((size_t)b * c.rctot[q] + c0 + i) * HW + p]);
+          }
+          for (int ch = 0; ch < Cc; ++ch)
+            for (int t = 0; t < 9; ++t) {
+              const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+              if (yy < 0 || yy >= c.H || xx < 0 || xx >= c.W) continue;
+              const double v = bf2f(cpl[ch][yy * c.W + xx]);
+              for (int i = 0; i < R; ++i) { ref[(size_t)i * K + 9 * ch + t] += dzv[i] * v; mag[(size_t)i * K + 9 * ch + t] += fabs(dzv[i] * v); }
+            }
+        }
+      }
+    } else
     for (int b = 0; b < c.B; ++b)
       for (int p = 0; p < HW; ++p) {
         int r = 0;
@@ -135,6 +165,15 @@ int main() {
       {"pool 11x13 56^2 S4", 1, {11, 0, 0}, {11, 0, 0}, 1, {13, 0, 0}, {13, 0, 0}, 56, 56, 3, true, true},
       {"pool 22x34 56^2 S2", 1, {22, 0, 0}, {22, 0, 0}, 1, {34, 0, 0}, {36, 0, 0}, 56, 56, 2, true, true},
       {"pool 38x(30+21) 24x16 S1", 1, {38, 0, 0}, {38, 0, 0}, 2, {30, 21, 0}, {30, 21, 0}, 24, 16, 2, true, true},
+      {"taps 13x3 112^2 S4", 1, {13, 0, 0}, {13, 0, 0}, 1, {3, 0, 0}, {3, 0, 0}, 112, 112, 2, false, true, true},
+      {"taps 28x18 56^2 S1", 1, {28, 0, 0}, {30, 0, 0}, 1, {18, 0, 0}, {18, 0, 0}, 56, 56, 2, false, true, true},
+      {"taps 21x(12+18) 56^2 2src", 1, {21, 0, 0}, {21, 0, 0}, 2, {12, 18, 0}, {12, 19, 0}, 56, 56, 2, false, true, true},
+      {"taps 23x51 56^2 chunks", 1, {23, 0, 0}, {23, 0, 0}, 1, {51, 0, 0}, {51, 0, 0}, 56, 56, 2, false, true, true},
+      {"taps 10x3 48x40 S4", 1, {10, 0, 0}, {10, 0, 0}, 1, {3, 0, 0}, {3, 0, 0}, 48, 40, 3, false, true, true},
+      {"taps 40x5 16x8 (3,1)", 1, {40, 0, 0}, {40, 0, 0}, 1, {5, 0, 0}, {5, 0, 0}, 16, 8, 2, false, true, true},
+      {"taps 13x3 224^2 B256", 1, {13, 0, 0}, {13, 0, 0}, 1, {3, 0, 0}, {3, 0, 0}, 224, 224, 256, false, false, true},
+      {"taps 28x18 112^2 B256", 1, {28, 0, 0}, {28, 0, 0}, 1, {18, 0, 0}, {18, 0, 0}, 112, 112, 256, false, false, true},
+      {"taps 23x51 56^2 B256", 1, {23, 0, 0}, {23, 0, 0}, 1, {51, 0, 0}, {51, 0, 0}, 56, 56, 256, false, false, true},
       {"own 18x13 224^2 B256", 1, {18, 0, 0}, {18, 0, 0}, 1, {13, 0, 0}, {13, 0, 0}, 224, 224, 256, false, false},
       {"own 29x12 112^2 B256", 2, {18, 11, 0}, {18, 11, 0}, 1, {12, 0, 0}, {12, 0, 0}, 112, 112, 256, false, false},
       {"pool 11x13 112^2 B256", 1, {11, 0, 0}, {11, 0, 0}, 1, {13, 0, 0}, {13, 0, 0}, 112, 112, 256, true, false},

@@ -33,5 +33,6 @@ for name, tab in (("fp32", f32[-1] if f32 else None), ("bf16", b16[-1] if b16 el
     if tab is None:
         continue
     print(f"## {name}: {sum(v[1] for v in tab.values()) / 1e3:.2f} ms of kernel time in one step")
-    for k, v in sorted(tab.items(), key=lambda kv: -kv[1][1])[:32]:
+    top = 32 if len(sys.argv) < 3 else int(sys.argv[2])      # second argument: rows per table (0 = every kernel)
+    for k, v in sorted(tab.items(), key=lambda kv: -kv[1][1])[:top or None]:
         print(f"{v[1] / 1e3:8.2f} ms {v[0]:4d}  {k[:90]}")
