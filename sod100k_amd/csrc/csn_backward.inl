@@ -396,13 +396,27 @@ int plan_cls_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
 }
 
 // ---------------------------------------------------------------------------------------------- execution
+#define CSN_WG_REGIONS 8   // partial-dW regions: that many weight-gradient passes are reduced by ONE wgrad_reduce launch
+struct BwdDefer {          // launches of csn_backward that only feed the optimizer: collected, issued in batches
+  std::vector<WgReduceArgs> wgred;   // pending reductions, one partial region each
+  std::vector<DwFinJob> dwfin;       // depthwise finalise jobs (own partial regions: UnitPlan::dwwg_off), flushed at the end
+  int next_region = 0;
+};
 struct BwdCtx {
   const Ctx& c;
   const float* arena;
   float* grad;
   const float* flop_w;
   float pen_scale;
+  BwdDefer* defer = nullptr;         // null: every reduction right behind its pass (side-lane mode)
 };
+
+int flush_wgred(const BwdCtx& b) {
+  if (!b.defer || b.defer->wgred.empty()) return CSN_OK;
+  LAUNCH_TRY(csn_launch_wgrad_reduce_batch(b.defer->wgred.data(), (int)b.defer->wgred.size(), b.c.stream));
+  b.defer->wgred.clear();
+  return CSN_OK;
+}
 
 float* grad_buf(const Ctx& c, int act, int slot) {
   return reinterpret_cast<float*>(c.ws + c.P.tg_off[act][slot]);
@@ -442,6 +456,7 @@ int run_wgrad(const BwdCtx& b, const WgPlan& w, const PwBind& bd) {
   a.k16 = (pp.K + 15) & ~15;
   a.partial = reinterpret_cast<float*>(b.c.ws + (b.c.side ? P.wg2_off : P.wg_off));
   a.a16 = b.c.a16 ? 1 : 0; a.pad = 0;
+  const bool defer = b.defer != nullptr && !b.c.side;
   // the kernel holds at most 80 output channels (5 MFMA row tiles) per launch: wider passes go in row chunks
   // ... and passes with K <= 64 in chunks of 48 rows, which keeps them on the wave-private kernel
   const int row_chunk = (a.nrs == 1 && a.k16 <= 64 && pp.nrows > 48) ? 48 : WG_MAX_ROWS;
@@ -454,6 +469,10 @@ int run_wgrad(const BwdCtx& b, const WgPlan& w, const PwBind& bd) {
     }
     a.rows16 = (nr + 15) & ~15;
     a.nblk = csn_wgrad_blocks(a);
+    if (defer) {   // this pass's own partial region; the reduction waits for a batch (CSN_WG_REGIONS passes per launch)
+      if ((int)b.defer->wgred.size() >= CSN_WG_REGIONS) { const int fs = flush_wgred(b); if (fs != CSN_OK) return fs; }
+      a.partial = reinterpret_cast<float*>(b.c.ws + P.wg_off) + (int64_t)(b.defer->next_region++ % CSN_WG_REGIONS) * P.wg_region_floats;
+    }
     LAUNCH_TRY(csn_launch_wgrad(a, b.c.stream));
     WgReduceArgs r;
     r.partial = a.partial; r.grad = b.grad;
@@ -466,7 +485,8 @@ int run_wgrad(const BwdCtx& b, const WgPlan& w, const PwBind& bd) {
         r.blk[q].dst = 0; r.blk[q].ld = 0; r.blk[q].ncol = 0; r.blk[q].col = 0; r.blk[q].scale = 0.f; r.blk[q].tk = 0;
       }
     r.nblk = a.nblk; r.nrows = nr; r.K = pp.K; r.rows16 = a.rows16; r.k16 = a.k16;
-    LAUNCH_TRY(csn_launch_wgrad_reduce(r, b.c.stream));
+    if (defer) b.defer->wgred.push_back(r);
+    else LAUNCH_TRY(csn_launch_wgrad_reduce(r, b.c.stream));
   }
   return CSN_OK;
 }
@@ -591,7 +611,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
     cs.stream = P.lane[0];
     cs.side = true;
   }
-  const BwdCtx bs{cs, b.arena, b.grad, b.flop_w, b.pen_scale};
+  const BwdCtx bs{cs, b.arena, b.grad, b.flop_w, b.pen_scale, c.lanes ? nullptr : b.defer};
   if (d.kind == CSN_UNIT_DW) {
     DwArgs a;
     a.nbr = 0; a.B = S; a.a16 = c.a16 ? 1 : 0; a.pad = 0;
@@ -610,6 +630,8 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
       if (fslabs > 0) {
         const Ctx& cf = (virt && cs.side) ? c : cs;   // (a never-stored input pins the unit to this kernel, on the caller's stream)
         if (&cf == &c) w.partial = reinterpret_cast<double*>(c.ws + P.red_off);
+        const bool defer_fin = b.defer != nullptr && &cf == &c && u.dwwg_off[k] >= 0;
+        if (defer_fin) w.partial = reinterpret_cast<double*>(c.ws + u.dwwg_off[k]);   // own region: finalised with all the others
         DwArgs f;
         f.nbr = 1; f.B = S; f.a16 = c.a16 ? 1 : 0; f.pad = 0;
         DwBranch& fb = f.br[0];
@@ -644,7 +666,13 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
         LAUNCH_TRY(csn_launch_dw_bwd(f, cf.stream));
         if (bn_fused[k] && P.debug_dz) LAUNCH_TRY(csn_launch_bn_bwd_apply(bnargs[k], cf.stream));   // probes only: dz over z, afterwards
         w.nslab = fslabs;                                   // partials are there: finalise only
-        LAUNCH_TRY(csn_launch_dw_wgrad(w, cf.stream));
+        if (defer_fin) {
+          DwFinJob fj;
+          fj.partial = w.partial; fj.off_w = w.off_w; fj.C = w.C; fj.nslab = fslabs;
+          b.defer->dwfin.push_back(fj);
+        } else {
+          LAUNCH_TRY(csn_launch_dw_wgrad(w, cf.stream));
+        }
         continue;
       }
       LAUNCH_TRY(csn_launch_dw_wgrad(w, cs.stream));
@@ -881,8 +909,15 @@ static int enable_training_impl(csn_plan* P) {
     }
   P->scratch_bytes = scratch;
   P->scratch_off = bl.alloc_ws(scratch > 0 ? scratch : 256);
-  P->wg_off = bl.alloc_ws(wg_floats * (int64_t)sizeof(float));
+  P->wg_region_floats = wg_floats;
+  P->wg_off = bl.alloc_ws(wg_floats * (int64_t)sizeof(float) * CSN_WG_REGIONS);
   P->wg2_off = bl.alloc_ws(wg_floats * (int64_t)sizeof(float));
+  for (int k = 0; k < nu; ++k) {
+    UnitPlan& u = P->units[k];
+    if (u.d.kind != CSN_UNIT_DW) continue;
+    for (int i = 0; i < u.d.n_in; ++i)
+      if (u.d.cout[i] > 0) u.dwwg_off[i] = bl.alloc_ws((int64_t)u.d.cout[i] * CSN_BN_NSLAB * 9 * sizeof(double));
+  }
   // the packed buffer and the job list grew: re-allocate / re-upload
   if (P->packed) (void)hipFree(P->packed);
   if (P->jobs_dev) (void)hipFree(P->jobs_dev);
@@ -942,7 +977,8 @@ int csn_backward(csn_plan* P, const float* x, const float* dy, void* workspace, 
     c.raw = true;
     c.a16 = P->act16;
     c.lanes = P->overlap_bwd && lanes_ready(P);   // measured: no gain for the train step (106.3 vs 105.5 ms), off by default
-    const BwdCtx b{c, arena, grad, flop_w, pen_scale};
+    BwdDefer defer;
+    const BwdCtx b{c, arena, grad, flop_w, pen_scale, (c.lanes || std::getenv("CSN_BWD_NO_DEFER")) ? nullptr : &defer};
     for (int a : P->orphan_acts)
       HIP_TRY(hipMemsetAsync(c.ws + P->tg_off[a][0], 0, (size_t)P->S * P->acts[a].channels * (P->H >> P->acts[a].lvl) *
                                                            (P->W >> P->acts[a].lvl) * (c.a16 ? 2 : 4), (hipStream_t)s));
@@ -953,6 +989,14 @@ int csn_backward(csn_plan* P, const float* x, const float* dy, void* workspace, 
     if (c.lanes) {       // the weight-gradient lane rejoins the caller's stream
       const int st = lanes_join(c, 1);
       if (st != CSN_OK) return st;
+    }
+    if (b.defer) {
+      const int st = flush_wgred(b);
+      if (st != CSN_OK) return st;
+      if (!defer.dwfin.empty()) {
+        const int fe = csn_launch_dw_wgrad_finalize_batch(defer.dwfin.data(), (int)defer.dwfin.size(), grad, s);
+        if (fe != 0) return (int)CSN_E_HIP;
+      }
     }
     return (int)CSN_OK;
   });

@@ -106,6 +106,11 @@ struct GapTilesArgs {                // gapabs[c][n] = | sum_tiles gapin[c][n * 
   int64_t HW;
 };
 int csn_launch_gap_tiles(const GapTilesArgs& a, void* stream);
+// ... of many (unit, branch) pairs in ONE launch (round 4: 66 launches of ~5 us per train-mode forward): the tables are read only by
+// the penalty kernel at the end of the forward and by the backward pass
+#define CSN_GAP_JOBS 80
+struct GapTilesBatch { GapTilesArgs job[CSN_GAP_JOBS]; int32_t n, pad; };
+int csn_launch_gap_tiles_batch(const GapTilesArgs* jobs, int njobs, void* stream);
 struct DwArgs {
   DwBranch br[3];
   int32_t nbr, B;
@@ -330,6 +335,9 @@ struct WgReduceArgs {
 int csn_launch_wgrad(const WgArgs& a, void* stream);
 int csn_wgrad_blocks(const WgArgs& a);   // partial slices (= blocks) the launch will use (ps, rows16, k16, ngroups set)
 int csn_launch_wgrad_reduce(const WgReduceArgs& a, void* stream);
+#define CSN_WGRED_JOBS 16
+struct WgReduceBatch { WgReduceArgs job[CSN_WGRED_JOBS]; int32_t n, pad; };
+int csn_launch_wgrad_reduce_batch(const WgReduceArgs* jobs, int njobs, void* stream);   // several passes (own partial regions) per launch
 bool csn_wgrad_c3_eligible(const WgArgs& a);                 // k_wgrad_c3.hip: LDS-tiled weight gradient of 3x3 tap passes
 int csn_wgrad_c3_blocks(const WgArgs& a);
 int csn_launch_wgrad_c3(const WgArgs& a, void* stream);
@@ -446,6 +454,11 @@ struct DwWgradArgs {
   int32_t a16;         // dz / x are bfloat16
 };
 int csn_launch_dw_wgrad(const DwWgradArgs& a, void* stream);
+// finalise pass of many depthwise units in one launch (their partials live in per-unit regions: csn_plan dwwg_off)
+#define CSN_DWFIN_JOBS 128
+struct DwFinJob { const double* partial; int64_t off_w; int32_t C, nslab; };
+struct DwFinBatch { DwFinJob job[CSN_DWFIN_JOBS]; float* grad; int32_t n, pad; };
+int csn_launch_dw_wgrad_finalize_batch(const DwFinJob* jobs, int njobs, float* grad, void* stream);
 
 struct AdjUpArgs {
   const float* in;     // [planes][Hl*f][Wl*f]

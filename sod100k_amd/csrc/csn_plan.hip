@@ -127,6 +127,8 @@ struct UnitPlan {
   int64_t gap_off[3] = {-1, -1, -1};
   int64_t gapin_off[3] = {-1, -1, -1};   // depthwise unit, training: per-tile plane sums of an input that is never stored (virt_cons)
   int64_t bnred_off[3] = {-1, -1, -1};   // ... and the BatchNorm-backward sums of its producer, taken by this unit's backward kernel
+  int64_t dwwg_off[3] = {-1, -1, -1};    // depthwise unit, training: its own weight-gradient partials [C][NSLAB][9] (finalised by ONE
+                                         // launch for all units at the end of csn_backward instead of one per unit and branch)
   int in_slot[3] = {-1, -1, -1};
   // GOCT 1x1 with two or three input branches: launches of pw4_kernel (k_pw4.hip); pw4 = 0: the unit does not qualify
   struct Pw4Launch {
@@ -230,7 +232,8 @@ struct csn_plan {
   std::vector<int> orphan_acts;          // outputs without consumer: zero gradient (training)
   int64_t scratch_off = 0, scratch_bytes = 0;   // per-unit backward temporaries (shared by all units)
   int64_t red_off = 0;                          // fp64 partials of the BN / depthwise reductions
-  int64_t wg_off = 0;                           // partial dW slices (k_wgrad.hip)
+  int64_t wg_off = 0;                           // partial dW slices (k_wgrad.hip): CSN_WG_REGIONS regions of wg_region_floats
+  int64_t wg_region_floats = 0;
   int64_t red2_off = 0, wg2_off = 0;            // ... of the weight-gradient side lane (csn_backward)
   std::vector<UnitBwd> bwd;
   ~csn_plan();
@@ -802,6 +805,7 @@ struct Ctx {
   bool side = false;  // backward: this context enqueues on the weight-gradient side lane (own partial buffers)
   bool a16 = false;   // bf16 train mode: every activation tensor in the workspace is bfloat16
   bool dw_stats = false;   // train-mode forward: depthwise units reduce their own BN statistics
+  std::vector<GapTilesArgs>* gap_defer = nullptr;   // train-mode forward: |GAP| table jobs collected for one launch at the end
   const float* sc(const Epi& e) const { return P.packed + (raw ? P.ident.scale : e.scale); }
   const float* sh(const Epi& e) const { return P.packed + (raw ? P.ident.shift : e.shift); }
   const float* al(const Epi& e) const { return P.packed + (raw ? P.ident.alpha : e.alpha); }
@@ -1138,7 +1142,8 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
         GapTilesArgs ga;
         ga.gapin = br.gapin; ga.gapabs = reinterpret_cast<float*>(c.ws + pu.gap_off[P.act_prod_branch[ia]]);
         ga.C = br.C; ga.S = S; ga.tiles = br.tiles_x * br.tiles_y; ga.pad = 0; ga.HW = (int64_t)br.H * br.W;
-        LAUNCH_TRY(csn_launch_gap_tiles(ga, c.stream));
+        if (c.gap_defer) c.gap_defer->push_back(ga);
+        else LAUNCH_TRY(csn_launch_gap_tiles(ga, c.stream));
       }
     } break;
     case CSN_UNIT_GOCT: {
@@ -1873,6 +1878,8 @@ static int forward_train_body(csn_plan* P, const float* x, float* y, void* works
     LAUNCH_TRY(csn_launch_to_bf16(x, c.ws + P->x16_off, nx, stream));
   }
   c.dw_stats = true;
+  std::vector<GapTilesArgs> gap_jobs;    // (read by the penalty kernel below and by csn_backward only)
+  c.gap_defer = &gap_jobs;
   for (int u = 0; u < nu; ++u) {
     const UnitPlan& up = P->units[u];
     const csn_unit_desc& d = up.d;
@@ -1918,6 +1925,7 @@ static int forward_train_body(csn_plan* P, const float* x, float* y, void* works
       }
     }
   }
+  if (!gap_jobs.empty()) LAUNCH_TRY(csn_launch_gap_tiles_batch(gap_jobs.data(), (int)gap_jobs.size(), stream));
   // the Oct_bn_hook penalty of all hooked sub-modules: two launches at the end of the forward (partials live in the first
   // unit's statistics slab, which the backward pass does not read)
   if (!pen_jobs.empty()) {

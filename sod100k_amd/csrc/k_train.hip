@@ -13,6 +13,7 @@
 //   bn_finalize_kernel  per channel: mean / biased var -> folded scale/shift for the apply pass, running-stat
 //                       update in the caller's parameter arena;
 //   bn_apply_gap_kernel y = PReLU(z*scale + shift) in place (float4 stream), per-(n,c) plane sum -> penalty.
+#include <algorithm>
 #include <cstdlib>
 
 #include "csn_kernels.h"
@@ -154,6 +155,17 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_apply_gap_kernel(BnApplyArgs a) 
 // |mean_hw y| per (channel, image) from the per-tile plane sums the consuming depthwise kernel left (its input y was formed on
 // load and never stored, so bn_apply_gap_kernel did not run for it): fixed order over the tiles
 __global__ __launch_bounds__(CSN_BLOCK) void gap_tiles_kernel(GapTilesArgs a) {
+  const int i = blockIdx.x * CSN_BLOCK + threadIdx.x;
+  if (i >= a.C * a.S) return;
+  const int c = i / a.S, n = i - c * a.S;
+  const double* p = a.gapin + (int64_t)c * BN_NSLAB + (int64_t)n * a.tiles;
+  double s = 0.0;
+  for (int t = 0; t < a.tiles; ++t) s += p[t];
+  a.gapabs[i] = (float)fabs(s / (double)a.HW);
+}
+
+__global__ __launch_bounds__(CSN_BLOCK) void gap_tiles_jobs_kernel(GapTilesBatch b) {
+  const GapTilesArgs a = CSN_KERNARG(GapTilesBatch, b)->job[blockIdx.y];
   const int i = blockIdx.x * CSN_BLOCK + threadIdx.x;
   if (i >= a.C * a.S) return;
   const int c = i / a.S, n = i - c * a.S;
@@ -468,6 +480,25 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw_wgrad_finalize_kernel(DwWgradArg
   }
 }
 
+// grid (max C, jobs): the finalise pass of many depthwise units at once (same arithmetic, same order per channel)
+__global__ __launch_bounds__(CSN_BLOCK) void dw_wgrad_finalize_jobs_kernel(DwFinBatch b) {
+  CSN_DYN_SMEM(double, sm);
+  const DwFinJob j = CSN_KERNARG(DwFinBatch, b)->job[blockIdx.y];
+  const int c = blockIdx.x;
+  if (c >= j.C) return;
+  double s[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) s[t] = 0.0;
+  for (int k = threadIdx.x; k < j.nslab; k += CSN_BLOCK)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) s[t] += j.partial[((int64_t)c * BN_NSLAB + k) * 9 + t];
+  bn_block_sum_n<9>(s, sm);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) b.grad[j.off_w + c * 9 + t] = (float)(100.0 * s[t]);
+  }
+}
+
 // adjoint of F.interpolate(scale_factor=f, mode='bilinear', align_corners=False): out[lo] = sum_hi w(hi->lo) in[hi].
 // Source pixel s receives from the outputs o in [f*s - f/2, f*s + f + f/2 - 1] (2f candidates per axis, f = 2 or 4);
 // the weight of each candidate is read off the forward's own index computation (csn_bilin), so the border clamping
@@ -766,6 +797,26 @@ int csn_launch_bn_bwd(const BnBwdArgs& a0, void* stream) {
 }
 int csn_launch_gap_tiles(const GapTilesArgs& a, void* stream) {
   CSN_LAUNCH(gap_tiles_kernel, dim3((a.C * a.S + CSN_BLOCK - 1) / CSN_BLOCK), dim3(CSN_BLOCK), 0, stream, a);
+  return (int)hipGetLastError();
+}
+int csn_launch_gap_tiles_batch(const GapTilesArgs* jobs, int njobs, void* stream) {
+  for (int first = 0; first < njobs; first += CSN_GAP_JOBS) {
+    GapTilesBatch b;
+    b.n = njobs - first < CSN_GAP_JOBS ? njobs - first : CSN_GAP_JOBS; b.pad = 0;
+    int mx = 1;
+    for (int i = 0; i < b.n; ++i) { b.job[i] = jobs[first + i]; mx = std::max(mx, (jobs[first + i].C * jobs[first + i].S + CSN_BLOCK - 1) / CSN_BLOCK); }
+    CSN_LAUNCH(gap_tiles_jobs_kernel, dim3(mx, b.n), dim3(CSN_BLOCK), 0, stream, b);
+  }
+  return (int)hipGetLastError();
+}
+int csn_launch_dw_wgrad_finalize_batch(const DwFinJob* jobs, int njobs, float* grad, void* stream) {
+  for (int first = 0; first < njobs; first += CSN_DWFIN_JOBS) {
+    DwFinBatch b;
+    b.n = njobs - first < CSN_DWFIN_JOBS ? njobs - first : CSN_DWFIN_JOBS; b.pad = 0; b.grad = grad;
+    int mx = 1;
+    for (int i = 0; i < b.n; ++i) { b.job[i] = jobs[first + i]; mx = std::max(mx, (int)jobs[first + i].C); }
+    CSN_LAUNCH(dw_wgrad_finalize_jobs_kernel, dim3(mx, b.n), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, b);
+  }
   return (int)hipGetLastError();
 }
 int csn_launch_bn_bwd_apply(const BnBwdArgs& a, void* stream) {

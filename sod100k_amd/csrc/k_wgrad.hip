@@ -16,6 +16,7 @@
 // so the accumulators D[row][k] (4 VGPRs per 16x16 tile) stay in registers across ALL the groups of the block.
 // Blocks write their partial dW to a scratch buffer; wgrad_reduce_kernel sums the partials in a fixed order
 // (fp64, deterministic) and scatters the columns back to the reference's [Cout][Cin][k][k] weight layout.
+#include <algorithm>
 #include "pw_gather.h"
 
 #define WG_P 68          // panel pitch (floats)
@@ -302,6 +303,35 @@ __global__ __launch_bounds__(CSN_BLOCK) void wgrad_reduce_kernel(WgReduceArgs a)
   a.grad[a.blk[bi].dst + idx] = (float)((double)a.blk[bi].scale * s);
 }
 
+// several passes per launch: grid (max ceil(K / 64), max nrows, jobs) -- the same per-element arithmetic and order as above
+__global__ __launch_bounds__(CSN_BLOCK) void wgrad_reduce_jobs_kernel(WgReduceBatch bt) {
+  CSN_DYN_SMEM(double, sm);
+  const WgReduceArgs a = CSN_KERNARG(WgReduceBatch, bt)->job[blockIdx.z];   // (read in place from the kernarg segment: no scratch copy)
+  if ((int)blockIdx.y >= a.nrows || (int)blockIdx.x * 64 >= a.K) return;   // (block-uniform)
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane, r = blockIdx.y;
+  double s = 0.0;
+  if (k < a.K) {
+    const float* p = a.partial + (int64_t)r * a.k16 + k;
+    const int64_t stride = (int64_t)a.rows16 * a.k16;
+#pragma unroll 8
+    for (int b = grp; b < a.nblk; b += 4) s += (double)p[b * stride];
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (grp != 0 || k >= a.K) return;
+  s = (sm[lane] + sm[64 + lane]) + (sm[128 + lane] + sm[192 + lane]);
+  int bi = -1;
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    if (q < a.nblocks && k >= a.blk[q].col && k < a.blk[q].col + a.blk[q].ncol) bi = q;
+  if (bi < 0) return;
+  const int c = k - a.blk[bi].col, tk = a.blk[bi].tk;
+  const int64_t idx = tk > 0 ? (int64_t)(c / tk) * a.blk[bi].ld + (int64_t)r * tk + (tk - 1 - c % tk)
+                             : (int64_t)r * a.blk[bi].ld + c;
+  a.grad[a.blk[bi].dst + idx] = (float)((double)a.blk[bi].scale * s);
+}
+
 // wave-private variant: 4 groups per block step; returns false when the pass does not fit it
 static bool wgrad_wave_fits(const WgArgs& a) { return a.k16 <= 64 && a.rows16 <= 48; }
 
@@ -343,6 +373,21 @@ int csn_launch_wgrad(const WgArgs& a, void* stream) {
   if (csn_wgrad_c3_eligible(a)) return csn_launch_wgrad_c3(a, stream);   // 3x3 tap slices: LDS-tiled (k_wgrad_c3.hip)
   if (csn_wgrad_bf_eligible(a)) return csn_launch_wgrad_bf(a, stream);   // bf16 tensors, 1x1: operands straight from the loads (k_wgrad_bf.hip)
   return a.a16 ? launch_wgrad_t<csn_bf16>(a, stream) : launch_wgrad_t<float>(a, stream);
+}
+
+int csn_launch_wgrad_reduce_batch(const WgReduceArgs* jobs, int njobs, void* stream) {
+  for (int first = 0; first < njobs; first += CSN_WGRED_JOBS) {
+    WgReduceBatch b;
+    b.n = njobs - first < CSN_WGRED_JOBS ? njobs - first : CSN_WGRED_JOBS; b.pad = 0;
+    int gx = 1, gy = 1;
+    for (int i = 0; i < b.n; ++i) {
+      b.job[i] = jobs[first + i];
+      gx = std::max(gx, (jobs[first + i].K + 63) / 64);
+      gy = std::max(gy, (int)jobs[first + i].nrows);
+    }
+    CSN_LAUNCH(wgrad_reduce_jobs_kernel, dim3(gx, gy, b.n), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, b);
+  }
+  return (int)hipGetLastError();
 }
 
 int csn_launch_wgrad_reduce(const WgReduceArgs& a, void* stream) {

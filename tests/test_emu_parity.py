@@ -194,7 +194,7 @@ def test_bf16_train_plan_has_bf16_sized_workspace(emu_lib, x2_manifest):
     """With bfloat16 storage chosen before the training buffers are laid out, every activation-typed region of the workspace has
     2-byte elements (batch 256: 61 -> 31 GiB); such a plan refuses the fp32 eval forward and a switch back to fp32 storage."""
     from sod100k_amd import _native as N
-    x = torch.zeros(2, 3, 224, 224)   # (plans only: at this size the activations outweigh the fixed-size reduction tables)
+    x = torch.zeros(8, 3, 224, 224)   # (plans only: at this size the activations outweigh the fixed-size reduction tables)
     sizes = {}
     for dt in ("fp32", "bf16"):
         m, _ = P.make_model(emu_lib, x2_manifest, CPU)
@@ -206,8 +206,8 @@ def test_bf16_train_plan_has_bf16_sized_workspace(emu_lib, x2_manifest):
                 eng.forward(x)
             with pytest.raises(RuntimeError):
                 eng.set_option(N.OPT_TRAIN_BF16, 0)
-    # the float / double tables (statistics partials, |GAP| tables, weight-gradient partials: 175 MB whatever the batch) do
-    # not shrink: 0.63 here, 0.54 at batch 8, 0.50 at batch 256
+    # the float / double tables (statistics partials, |GAP| tables, the weight-gradient partial regions: ~0.5 GB whatever the
+    # batch since round 4's per-pass / per-unit regions) do not shrink: 0.57 here, 0.50 at batch 256
     assert sizes["bf16"] < 0.65 * sizes["fp32"], sizes
     print(sizes)
 
