@@ -630,7 +630,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
       if (fslabs > 0) {
         const Ctx& cf = (virt && cs.side) ? c : cs;   // (a never-stored input pins the unit to this kernel, on the caller's stream)
         if (&cf == &c) w.partial = reinterpret_cast<double*>(c.ws + P.red_off);
-        const bool defer_fin = b.defer != nullptr && &cf == &c && u.dwwg_off[k] >= 0;
+        const bool defer_fin = b.defer != nullptr && !cf.side && u.dwwg_off[k] >= 0;
         if (defer_fin) w.partial = reinterpret_cast<double*>(c.ws + u.dwwg_off[k]);   // own region: finalised with all the others
         DwArgs f;
         f.nbr = 1; f.B = S; f.a16 = c.a16 ? 1 : 0; f.pad = 0;
@@ -700,7 +700,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
   // adjoint-upsampled dz (gOctConv low->high terms)
   for (size_t k = 0; k < ub.adj.size(); ++k) {
     const AdjPlan& ap = ub.adj[k];
-    if (ub.adj_fused[ap.j] == (int)k) continue;   // written by the BatchNorm backward above
+    if (bd.adj[k] != nullptr) continue;   // written by the BatchNorm backward above (UnitBwd::adj_fused, not in side-lane mode)
     AdjUpArgs ua;
     ua.in = bd.dz[ap.j]; ua.out = reinterpret_cast<float*>(scratch + ap.off);
     ua.planes = S * ap.C; ua.Hl = P.H >> ap.lvl; ua.Wl = P.W >> ap.lvl; ua.f = ap.f;

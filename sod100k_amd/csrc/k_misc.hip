@@ -162,6 +162,38 @@ __device__ __forceinline__ DwRow dw_load_row_raw(csn_buf rb, int y, int x0, int 
   return r;
 }
 
+// The same row as it comes out of the loads, NOT yet converted: a conversion (bfloat16 -> float is two shifts per dword) is the
+// first use of the loaded registers and makes the wave wait for them, so a row that is to stay IN FLIGHT while the previous one is
+// worked on (dw3x3_bwd_kernel, round 4) is held in this form and converted one loop trip later.
+template <typename AT> struct DwRowRaw;
+template <> struct DwRowRaw<float> { float4 c; float l, r; };
+template <> struct DwRowRaw<csn_bf16> { uint2 c; unsigned short l, r; };
+__device__ __forceinline__ DwRowRaw<float> dw_issue_row(csn_buf rb, int y, int x0, int W, float) {
+  DwRowRaw<float> q;
+  const unsigned o = (unsigned)(y * W + x0) * 4u;   // rows outside the plane: out of the bounded range -> 0
+  q.c = csn_ld4(rb, o, 0); q.l = csn_ld1(rb, o - 4u, 0); q.r = csn_ld1(rb, o + 16u, 0);
+  return q;
+}
+__device__ __forceinline__ DwRowRaw<csn_bf16> dw_issue_row(csn_buf rb, int y, int x0, int W, csn_bf16) {
+  DwRowRaw<csn_bf16> q;
+  const unsigned o = (unsigned)(y * W + x0) * 2u;
+  q.c = csn_ld_u64(rb, o, 0); q.l = csn_ld_u16(rb, o - 2u, 0); q.r = csn_ld_u16(rb, o + 8u, 0);
+  return q;
+}
+__device__ __forceinline__ DwRow dw_row_of(const DwRowRaw<float>& q) {
+  DwRow r;
+  r.v[0] = q.l; r.v[1] = q.c.x; r.v[2] = q.c.y; r.v[3] = q.c.z; r.v[4] = q.c.w; r.v[5] = q.r;
+  return r;
+}
+__device__ __forceinline__ DwRow dw_row_of(const DwRowRaw<csn_bf16>& q) {
+  DwRow r;
+  r.v[0] = csn_bf2f(q.l);
+  r.v[1] = csn_bits_f(q.c.x << 16); r.v[2] = csn_bits_f(q.c.x & 0xffff0000u);
+  r.v[3] = csn_bits_f(q.c.y << 16); r.v[4] = csn_bits_f(q.c.y & 0xffff0000u);
+  r.v[5] = csn_bf2f(q.r);
+  return r;
+}
+
 // row of x = PReLU(z * sc + sh) from a row of the producer's raw output z (see DwBranch::in_scale); outside the plane: 0
 template <bool VEC, typename AT>
 __device__ __forceinline__ DwRow dw_load_row_bn(csn_buf rb, int y, int H, int x0, int W, bool has_l, bool has_r, float sc,
@@ -222,6 +254,10 @@ __device__ __forceinline__ void dw_emit(AT* __restrict__ op, int y, int yend, in
   }
 }
 
+#ifndef DW_FWD_PREFETCH
+#define DW_FWD_PREFETCH 0   // measured (round 4, same lease): 4.06 -> 4.30 ms per bf16 step with the next chunk in flight -- this kernel
+                            // already issues the 12 loads of a four-row chunk back to back; the backward kernel gains (9.70 -> 8.94 ms)
+#endif
 // INBN (train mode, with STATS): the input is formed on load from the producer's raw output and its plane sums are taken
 template <bool VEC, typename AT, bool STATS, bool INBN = false>
 __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
@@ -264,13 +300,47 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
       return r;
     };
 
+    // the row as loaded -> the row the convolution sees (train mode, INBN: PReLU(BN(z)) of the producer's z, zero outside the plane)
+    auto finish_in = [&](DwRow r, int y) {
+      if (INBN) {
+        const bool rowin = y >= 0 && y < H;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const bool colin = i == 0 ? has_l : (i == 5 ? has_r : true);
+          const float v = csn_epi(r.v[i], isc, ish, ial);
+          r.v[i] = (rowin && colin) ? v : 0.f;
+        }
+        if (y >= y0 && y < yend) gsum += (r.v[1] + r.v[2]) + (r.v[3] + r.v[4]);
+        return r;
+      }
+      if (!has_l) r.v[0] = 0.f;
+      if (!has_r) r.v[5] = 0.f;
+      return r;
+    };
     DwRow r0 = load_in(y0 - 1);
     DwRow r1 = load_in(y0);
+    // Round 4 (train-mode kernels, vector path): the four rows of the NEXT chunk are issued before the current chunk is converted and
+    // used -- a whole loop trip in flight instead of being waited for where they are issued
+    constexpr bool PF = VEC && STATS && DW_FWD_PREFETCH;
+    DwRowRaw<AT> q0, q1, q2, q3;
+    if (PF) {
+      q0 = dw_issue_row(rb, y0 + 1, x0, W, AT()); q1 = dw_issue_row(rb, y0 + 2, x0, W, AT());
+      q2 = dw_issue_row(rb, y0 + 3, x0, W, AT()); q3 = dw_issue_row(rb, y0 + 4, x0, W, AT());
+    }
     for (int y = y0; y < yend; y += 4) {
-      const DwRow n0 = load_in(y + 1);
-      const DwRow n1 = load_in(y + 2);
-      const DwRow n2 = load_in(y + 3);
-      const DwRow n3 = load_in(y + 4);
+      DwRow n0, n1, n2, n3;
+      if (PF) {
+        const DwRowRaw<AT> p0 = dw_issue_row(rb, y + 5, x0, W, AT()), p1 = dw_issue_row(rb, y + 6, x0, W, AT());
+        const DwRowRaw<AT> p2 = dw_issue_row(rb, y + 7, x0, W, AT()), p3 = dw_issue_row(rb, y + 8, x0, W, AT());
+#ifndef CSN_CPU_EMU
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        n0 = finish_in(dw_row_of(q0), y + 1); n1 = finish_in(dw_row_of(q1), y + 2);
+        n2 = finish_in(dw_row_of(q2), y + 3); n3 = finish_in(dw_row_of(q3), y + 4);
+        q0 = p0; q1 = p1; q2 = p2; q3 = p3;
+      } else {
+        n0 = load_in(y + 1); n1 = load_in(y + 2); n2 = load_in(y + 3); n3 = load_in(y + 4);
+      }
       dw_emit<VEC, AT, STATS>(op, y, yend, x0, W, w, sc, sh, al, r0, r1, n0, st);
       dw_emit<VEC, AT, STATS>(op, y + 1, yend, x0, W, w, sc, sh, al, r1, n0, n1, st);
       dw_emit<VEC, AT, STATS>(op, y + 2, yend, x0, W, w, sc, sh, al, n0, n1, n2, st);
@@ -309,6 +379,9 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
 // with the channel's (block-uniform) tables, bit for bit bn_bwd_apply_kernel's arithmetic; rows / columns outside the plane
 // are masked to zero AFTER the formula (z = dy = 0 does not give dz = 0).  Saves the write and the re-read of dz (round 3).
 // XBN: the unit's forward input x was never stored: it is formed on load from the producer's raw output (DwBranch::in_scale)
+#ifndef DW_BWD_PREFETCH
+#define DW_BWD_PREFETCH 1   // 0: A/B builds (loads waited for where they are issued, round 3)
+#endif
 template <bool VEC, typename AT, bool BNF, bool XBN = false>
 __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
   CSN_DYN_SMEM(double, sm);
@@ -360,6 +433,28 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
       bB = bgi * (bis * bm2);
       bA = bgi * (bm1 - bmu * (bis * bm2));
     }
+    // dz row from the rows of dy, z (and dy2) as loaded
+    auto finish_g = [&](DwRow g, const DwRow& z, const DwRow& e, int y) {
+      if (!BNF) {
+        if (!has_l) g.v[0] = 0.f;
+        if (!has_r) g.v[5] = 0.f;
+        return g;
+      }
+      if (has2) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) g.v[i] += e.v[i];
+      }
+      const bool rowin = y >= 0 && y < H;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const float bn = fmaf(z.v[i], bsc, bsh);
+        const float t = fmaf(bB, z.v[i], bA);
+        const float dzv = fmaf(g.v[i], bn > 0.f ? bgi : bga, -t);
+        const bool colin = i == 0 ? has_l : (i == 5 ? has_r : (VEC || x0 + i - 1 < W));
+        g.v[i] = (rowin && colin) ? dzv : 0.f;
+      }
+      return g;
+    };
     auto load_g = [&](int y) {
       if (!BNF) return dw_load_row<VEC, AT>(gb, y, x0, W, has_l, has_r);
       DwRow g = dw_load_row_raw<VEC, AT>(gb, y, x0, W);
@@ -388,6 +483,23 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
       if (XBN) return dw_load_row_bn<VEC, AT>(xb, y, H, x0, W, has_l, has_r, isc, ish, ial, zc);
       return dw_load_row<VEC, AT>(xb, y, x0, W, has_l, has_r);
     };
+    // the row of x from the row as loaded (XBN: the producer's z -> PReLU(BN(z)); zc keeps the raw centre values)
+    auto finish_x = [&](DwRow r, int y, float* zc) {
+      if (XBN) {
+        if (zc) { zc[0] = r.v[1]; zc[1] = r.v[2]; zc[2] = r.v[3]; zc[3] = r.v[4]; }
+        const bool rowin = y >= 0 && y < H;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const bool colin = i == 0 ? has_l : (i == 5 ? has_r : true);
+          const float v = csn_epi(r.v[i], isc, ish, ial);
+          r.v[i] = (rowin && colin) ? v : 0.f;
+        }
+        return r;
+      }
+      if (!has_l) r.v[0] = 0.f;
+      if (!has_r) r.v[5] = 0.f;
+      return r;
+    };
     float zc1[4] = {0.f, 0.f, 0.f, 0.f}, zc2[4];   // XBN: raw z of the producer at the centre columns of rows y, y + 1
     DwRow g0 = load_g(y0 - 1);
     DwRow g1 = load_g(y0);
@@ -396,9 +508,36 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
     const int yend = min(y0 + br.R, H);
     // (rotating three register sets through an unrolled-by-three loop instead of copying rows: 11 % fewer VALU instructions per row,
     // but 158 instead of 98 VGPRs and 2.8x the code -- not taken)
+    // Round 4: on the vector path the loads of row y + 2 are issued BEFORE row y + 1 is converted and used, i.e. they are in flight
+    // during a whole loop trip (they used to be waited for right where they were issued: every trip paid a full memory round trip
+    // with only the other waves of the SIMD to cover it).  Rows past the tile / the plane are fetched like any other (zeros past the
+    // plane: bounded resources) and never used.
+    constexpr bool PF = VEC && DW_BWD_PREFETCH;
+    DwRowRaw<AT> rg, rz, re, rx;
+    if (PF) {
+      rg = dw_issue_row(gb, y0 + 1, x0, W, AT());
+      rx = dw_issue_row(xb, y0 + 1, x0, W, AT());
+      if (BNF) rz = dw_issue_row(zb, y0 + 1, x0, W, AT());
+      if (BNF && has2) re = dw_issue_row(g2b, y0 + 1, x0, W, AT());
+    }
     for (int y = y0; y < yend; ++y) {
-      const DwRow g2 = load_g(y + 1);
-      const DwRow u2 = load_x(y + 1, zc2);
+      DwRow g2, u2;
+      if (PF) {
+        const DwRowRaw<AT> ng = dw_issue_row(gb, y + 2, x0, W, AT());
+        const DwRowRaw<AT> nx = dw_issue_row(xb, y + 2, x0, W, AT());
+        DwRowRaw<AT> nz = rz, ne = re;
+        if (BNF) nz = dw_issue_row(zb, y + 2, x0, W, AT());
+        if (BNF && has2) ne = dw_issue_row(g2b, y + 2, x0, W, AT());
+#ifndef CSN_CPU_EMU
+        __builtin_amdgcn_sched_barrier(0);   // the loads above stay above the conversions below
+#endif
+        g2 = finish_g(dw_row_of(rg), BNF ? dw_row_of(rz) : DwRow(), (BNF && has2) ? dw_row_of(re) : DwRow(), y + 1);
+        u2 = finish_x(dw_row_of(rx), y + 1, zc2);
+        rg = ng; rx = nx; rz = nz; re = ne;
+      } else {
+        g2 = load_g(y + 1);
+        u2 = load_x(y + 1, zc2);
+      }
       float dxv[4];
       dw_emit<VEC, AT>(op, y, yend, x0, W, w, 1.f, 0.f, 1.f, g0, g1, g2, nullptr, XBN ? dxv : nullptr);
       if (XBN) {   // the producer's BatchNorm-backward sums (bn_bwd_reduce_kernel's arithmetic): dy = the dx just stored

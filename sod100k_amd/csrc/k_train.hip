@@ -165,14 +165,15 @@ __global__ __launch_bounds__(CSN_BLOCK) void gap_tiles_kernel(GapTilesArgs a) {
 }
 
 __global__ __launch_bounds__(CSN_BLOCK) void gap_tiles_jobs_kernel(GapTilesBatch b) {
-  const GapTilesArgs a = CSN_KERNARG(GapTilesBatch, b)->job[blockIdx.y];
+  const CSN_CONST_AS GapTilesArgs* a = &CSN_KERNARG(GapTilesBatch, b)->job[blockIdx.y];   // (read in place: no scratch copy)
+  const int C = a->C, S = a->S, tiles = a->tiles;
   const int i = blockIdx.x * CSN_BLOCK + threadIdx.x;
-  if (i >= a.C * a.S) return;
-  const int c = i / a.S, n = i - c * a.S;
-  const double* p = a.gapin + (int64_t)c * BN_NSLAB + (int64_t)n * a.tiles;
+  if (i >= C * S) return;
+  const int c = i / S, n = i - c * S;
+  const double* p = a->gapin + (int64_t)c * BN_NSLAB + (int64_t)n * tiles;
   double s = 0.0;
-  for (int t = 0; t < a.tiles; ++t) s += p[t];
-  a.gapabs[i] = (float)fabs(s / (double)a.HW);
+  for (int t = 0; t < tiles; ++t) s += p[t];
+  a->gapabs[i] = (float)fabs(s / (double)a->HW);
 }
 
 // penalty += sum_j 0.5 * w_j * sum_c gamma_c^2 * sum_n |gap_j[c][n]|   (Oct_bn_hook, csnet.py:391-410) over all hooked
@@ -483,19 +484,22 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw_wgrad_finalize_kernel(DwWgradArg
 // grid (max C, jobs): the finalise pass of many depthwise units at once (same arithmetic, same order per channel)
 __global__ __launch_bounds__(CSN_BLOCK) void dw_wgrad_finalize_jobs_kernel(DwFinBatch b) {
   CSN_DYN_SMEM(double, sm);
-  const DwFinJob j = CSN_KERNARG(DwFinBatch, b)->job[blockIdx.y];
-  const int c = blockIdx.x;
-  if (c >= j.C) return;
+  const CSN_CONST_AS DwFinBatch* bp = CSN_KERNARG(DwFinBatch, b);
+  const CSN_CONST_AS DwFinJob* j = &bp->job[blockIdx.y];
+  const int c = blockIdx.x, nslab = j->nslab;
+  if (c >= j->C) return;
+  const double* part = j->partial;
   double s[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) s[t] = 0.0;
-  for (int k = threadIdx.x; k < j.nslab; k += CSN_BLOCK)
+  for (int k = threadIdx.x; k < nslab; k += CSN_BLOCK)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) s[t] += j.partial[((int64_t)c * BN_NSLAB + k) * 9 + t];
+    for (int t = 0; t < 9; ++t) s[t] += part[((int64_t)c * BN_NSLAB + k) * 9 + t];
   bn_block_sum_n<9>(s, sm);
   if (threadIdx.x == 0) {
+    float* g = bp->grad + j->off_w + c * 9;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) b.grad[j.off_w + c * 9 + t] = (float)(100.0 * s[t]);
+    for (int t = 0; t < 9; ++t) g[t] = (float)(100.0 * s[t]);
   }
 }
 

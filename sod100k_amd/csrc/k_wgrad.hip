@@ -306,30 +306,30 @@ __global__ __launch_bounds__(CSN_BLOCK) void wgrad_reduce_kernel(WgReduceArgs a)
 // several passes per launch: grid (max ceil(K / 64), max nrows, jobs) -- the same per-element arithmetic and order as above
 __global__ __launch_bounds__(CSN_BLOCK) void wgrad_reduce_jobs_kernel(WgReduceBatch bt) {
   CSN_DYN_SMEM(double, sm);
-  const WgReduceArgs a = CSN_KERNARG(WgReduceBatch, bt)->job[blockIdx.z];   // (read in place from the kernarg segment: no scratch copy)
-  if ((int)blockIdx.y >= a.nrows || (int)blockIdx.x * 64 >= a.K) return;   // (block-uniform)
+  const CSN_CONST_AS WgReduceArgs* a = &CSN_KERNARG(WgReduceBatch, bt)->job[blockIdx.z];   // (read in place: no scratch copy)
+  const int K = a->K, k16 = a->k16, nblk = a->nblk;
+  if ((int)blockIdx.y >= a->nrows || (int)blockIdx.x * 64 >= K) return;   // (block-uniform)
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + lane, r = blockIdx.y;
   double s = 0.0;
-  if (k < a.K) {
-    const float* p = a.partial + (int64_t)r * a.k16 + k;
-    const int64_t stride = (int64_t)a.rows16 * a.k16;
+  if (k < K) {
+    const float* p = a->partial + (int64_t)r * k16 + k;
+    const int64_t stride = (int64_t)a->rows16 * k16;
 #pragma unroll 8
-    for (int b = grp; b < a.nblk; b += 4) s += (double)p[b * stride];
+    for (int b = grp; b < nblk; b += 4) s += (double)p[b * stride];
   }
   sm[threadIdx.x] = s;
   __syncthreads();
-  if (grp != 0 || k >= a.K) return;
+  if (grp != 0 || k >= K) return;
   s = (sm[lane] + sm[64 + lane]) + (sm[128 + lane] + sm[192 + lane]);
   int bi = -1;
 #pragma unroll
   for (int q = 0; q < 3; ++q)
-    if (q < a.nblocks && k >= a.blk[q].col && k < a.blk[q].col + a.blk[q].ncol) bi = q;
+    if (q < a->nblocks && k >= a->blk[q].col && k < a->blk[q].col + a->blk[q].ncol) bi = q;
   if (bi < 0) return;
-  const int c = k - a.blk[bi].col, tk = a.blk[bi].tk;
-  const int64_t idx = tk > 0 ? (int64_t)(c / tk) * a.blk[bi].ld + (int64_t)r * tk + (tk - 1 - c % tk)
-                             : (int64_t)r * a.blk[bi].ld + c;
-  a.grad[a.blk[bi].dst + idx] = (float)((double)a.blk[bi].scale * s);
+  const int c = k - a->blk[bi].col, tk = a->blk[bi].tk, ld = a->blk[bi].ld;
+  const int64_t idx = tk > 0 ? (int64_t)(c / tk) * ld + (int64_t)r * tk + (tk - 1 - c % tk) : (int64_t)r * ld + c;
+  a->grad[a->blk[bi].dst + idx] = (float)((double)a->blk[bi].scale * s);
 }
 
 // wave-private variant: 4 groups per block step; returns false when the pass does not fit it
