@@ -37,6 +37,10 @@ enum CsnPrepKind {
   // channels co), p0 = source row pitch, p2 = P, p3 = t0 | (k0 << 8):
   //   dst[((k0 + c)*4 + (r & 3))*p2 + t0 + (r >> 2)] = p0f * src0[c*p0 + r]
   CSN_PREP_PW4_T = 13,
+  // transposed, tap-flipped 3x3 block (backward data) -> the image of CSN_PREP_C3Q: n = rows (= the forward's input channels ci),
+  // p1 = gathered channels (= its output channels co), p0 = source row pitch (cin_tot * 9), p2 = P, p3 = t0 | (k0 << 8):
+  //   dst[((k0 + 9*c + t)*4 + (r & 3))*p2 + t0 + (r >> 2)] = p0f * src0[c*p0 + r*9 + (8 - t)]
+  CSN_PREP_C3Q_T = 14,
 };
 struct CsnPrepJob {
   int32_t kind, n, p0, p1, p2, p3;

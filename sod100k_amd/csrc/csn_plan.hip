@@ -375,11 +375,16 @@ int finish_launch(Builder& bl, PwLaunchPlan& L) {
         col += ((C + 15) / 16) * 144;
       }
       if (tail) L.z_c0 = ps.wb[ntap].eye_col0;
-      // ---- c3q_kernel: forward passes (no transposed blocks) on whole tensors at an even resolution ----
-      bool q = (((bl.P.H >> L.lvl) | (bl.P.W >> L.lvl)) & 1) == 0 && ps.out_kind != OUT_DX && ps.out_kind != OUT_TMP;
-      for (int s = 0; s < ntap; ++s)
-        q = q && ps.wb[s].tk == 0 && ps.src_kind[s] == SRC_IN && ps.src_c0[s] == 0 &&
-            (ps.src_ctot[s] == 0 || ps.src_ctot[s] == ps.src_C[s]);
+      // ---- c3q_kernel: forward passes on whole tensors at an even resolution; round 4: also the input-gradient passes (a 3x3
+      // convolution of dz with transposed, tap-flipped weight blocks, CSN_PREP_C3Q_T: plain own-resolution tap slices only) ----
+      const bool grad_pass = ps.out_kind == OUT_DX || ps.out_kind == OUT_TMP;
+      static const bool c3q_bwd_off = std::getenv("CSN_C3Q_BWD") && std::getenv("CSN_C3Q_BWD")[0] == '0';
+      bool q = (((bl.P.H >> L.lvl) | (bl.P.W >> L.lvl)) & 1) == 0 && !(grad_pass && (c3q_bwd_off || tail));
+      for (int s = 0; s < ntap; ++s) {
+        q = q && ps.src_c0[s] == 0 && (ps.src_ctot[s] == 0 || ps.src_ctot[s] == ps.src_C[s]);
+        if (grad_pass) q = q && ps.wb[s].tk == 9 && ps.src_mode[s] == PW_TAPS && (ps.src_kind[s] == SRC_DZ || ps.src_kind[s] == SRC_ADJ);
+        else q = q && ps.wb[s].tk == 0 && ps.src_kind[s] == SRC_IN;
+      }
       if (q) {
         int cap = std::max(1, std::min(bl.P.c3q_cap, csn_c3q_max_tiles()));
         const int nt_tot = (ps.nrows + 3) / 4;
@@ -405,8 +410,12 @@ int finish_launch(Builder& bl, PwLaunchPlan& L) {
             int kb = 0;
             for (int s = 0; s < ntap && nr > 0; ++s) {
               const WBlock& w = ps.wb[s];
-              bl.job(CSN_PREP_C3Q, nr, L.c3q_wimg + g * gimg, w.src + (int64_t)L.c3q_r0[g] * w.ld, -1, -1, -1, w.scale, w.ld,
-                     ps.src_C[s], Pp, 0 | (kb << 8));
+              if (w.tk > 0)   // backward data: row r = input channel, gathered channel = output channel, taps flipped
+                bl.job(CSN_PREP_C3Q_T, nr, L.c3q_wimg + g * gimg, w.src + (int64_t)L.c3q_r0[g] * 9, -1, -1, -1, w.scale, w.ld,
+                       ps.src_C[s], Pp, 0 | (kb << 8));
+              else
+                bl.job(CSN_PREP_C3Q, nr, L.c3q_wimg + g * gimg, w.src + (int64_t)L.c3q_r0[g] * w.ld, -1, -1, -1, w.scale, w.ld,
+                       ps.src_C[s], Pp, 0 | (kb << 8));
               kb += 9 * ps.src_C[s];
             }
           }
@@ -1006,14 +1015,17 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
     for (int s = 0; s < 3; ++s) { q.src[s].ptr = nullptr; q.src[s].C = 0; q.src[s].Ctot = 0; }
     for (int s = 0; s < L.c3q_ntap; ++s) {
       const int br = pp.src_branch[s];
-      q.src[s].ptr = pp.src_mode[s] == PW_POOL2_TAPS ? bd.mp[br] : bd.in[br];
+      q.src[s].ptr = pp.src_kind[s] == SRC_DZ ? bd.dz[br] : pp.src_kind[s] == SRC_ADJ ? bd.adj[br]
+                     : pp.src_mode[s] == PW_POOL2_TAPS ? bd.mp[br] : bd.in[br];
       q.src[s].C = pp.src_C[s]; q.src[s].Ctot = pp.src_C[s];
       ok = ok && q.src[s].ptr != nullptr;
     }
     q.z = L.c3q_z ? bd.z : nullptr; q.z_ctot = L.c3q_z ? pp.src_C[L.c3q_ntap] : 0; q.z_c0 = L.z_c0;
     ok = ok && (!L.c3q_z || q.z != nullptr);
-    float* ob = pp.out_kind == OUT_Z ? bd.zout : bd.act[pp.out_branch];
-    ok = ok && ob != nullptr && (pp.out_kind == OUT_Z || pp.out_kind == OUT_ACT) && !bd.red_w;
+    const bool gradq = pp.out_kind == OUT_DX || pp.out_kind == OUT_TMP;
+    float* ob = pp.out_kind == OUT_Z ? bd.zout : pp.out_kind == OUT_DX ? bd.dx[pp.out_branch] : pp.out_kind == OUT_TMP ? bd.tmp
+                                                                                                : bd.act[pp.out_branch];
+    ok = ok && ob != nullptr && (pp.out_kind == OUT_Z || pp.out_kind == OUT_ACT || gradq) && !bd.red_w;
     if (ok) {
       q.out = ob; q.out_c0 = pp.out_c0; q.out_ctot = pp.out_ctot; q.nrows = pp.nrows;
       q.ep = L.c3q_ep >= 0 ? c.pk(L.c3q_ep) : nullptr;
@@ -1028,7 +1040,7 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
       q.ngroups = L.c3q_ng; q.gimg_floats = L.c3q_gimg; q.nt = L.c3q_nt; q.max_grid = P.pw4_grid;
       q.a16 = c.a16 ? 1 : 0; q.pad_ = 0;
       for (int g = 0; g < PW4_MAX_GROUPS; ++g) { q.grp_r0[g] = L.c3q_r0[g]; q.grp_nt[g] = L.c3q_gnt[g]; }
-      const bool rawq = c.raw || pp.out_kind == OUT_Z;
+      const bool rawq = c.raw || pp.out_kind == OUT_Z || gradq;
       LAUNCH_TRY(csn_launch_c3q(q, rawq ? 1 : 0, c.stream));
       return c.mark("c3q_kernel");
     }

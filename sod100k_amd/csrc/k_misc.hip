@@ -88,6 +88,15 @@ __global__ __launch_bounds__(CSN_BLOCK) void csn_prep_kernel(const CsnPrepJob* _
         dst[((int64_t)(k0 + c) * 4 + (r & 3)) * j.p2 + t0 + (r >> 2)] = j.p0f * arena[j.src0 + (int64_t)r * j.p0 + c];
       }
     } break;
+    case CSN_PREP_C3Q_T: {
+      const int ncol = j.p1 * 9, t0 = j.p3 & 0xff, k0 = j.p3 >> 8;
+      const int tot = j.n * ncol;
+      for (int i = tid; i < tot; i += CSN_BLOCK) {
+        const int r = i / ncol, ct = i - r * ncol;
+        const int c = ct / 9, t = ct - 9 * c;
+        dst[((int64_t)(k0 + ct) * 4 + (r & 3)) * j.p2 + t0 + (r >> 2)] = j.p0f * arena[j.src0 + (int64_t)c * j.p0 + r * 9 + (8 - t)];
+      }
+    } break;
     case CSN_PREP_PW4_T: {
       const int ncol = j.p1, t0 = j.p3 & 0xff, k0 = j.p3 >> 8;
       const int tot = j.n * ncol;
