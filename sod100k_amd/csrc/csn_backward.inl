@@ -493,8 +493,10 @@ int run_wgrad(const BwdCtx& b, const WgPlan& w, const PwBind& bd) {
 
 // skip_apply: reduce + finalise only (the unit's depthwise backward forms dz on load); keep: the arguments, for that kernel
 // adj2: the apply pass also writes the x2 adjoint-upsampled dz there, and dz itself over the branch's (dead) activation
+// steps: 0 = reduce + finalise + apply (one branch on its own); 1 = reduce only, the arguments (with the launcher's cpp / nslab)
+// go to *keep: the caller finalises all branches of the unit in ONE launch and then applies (csn_launch_bn_bwd_apply_step)
 int run_bn_bwd(const BwdCtx& b, int ui, const UnitPlan& u, int j, bool skip_apply = false, BnBwdArgs* keep = nullptr,
-               float* adj2 = nullptr) {
+               float* adj2 = nullptr, int steps = 0) {
   const csn_plan& P = b.c.P;
   const csn_unit_desc& d = u.d;
   const int act = d.out_act[j];
@@ -505,7 +507,8 @@ int run_bn_bwd(const BwdCtx& b, int ui, const UnitPlan& u, int j, bool skip_appl
   a.z = reinterpret_cast<float*>(b.c.ws + P.tz_off[act]);
   a.scale = P.packed + u.out_epi[j].scale; a.shift = P.packed + u.out_epi[j].shift; a.alpha = P.packed + u.out_epi[j].alpha;
   a.mean = P.packed + u.tr_mean[j]; a.invstd = P.packed + u.tr_invstd[j];
-  a.partial = reinterpret_cast<double*>(b.c.ws + P.red_off);
+  // (a third of the table per output branch: the reduce passes of a unit's branches all run before their common finalise launch)
+  a.partial = reinterpret_cast<double*>(b.c.ws + P.red_off) + (int64_t)j * P.red_maxc * CSN_BN_NSLAB * 3;
   a.m1m2 = P.packed + u.tr_m1m2[j];
   a.arena = b.arena; a.grad = b.grad;
   a.gapabs = u.gap_off[j] >= 0 ? reinterpret_cast<const float*>(b.c.ws + u.gap_off[j]) : nullptr;
@@ -526,7 +529,11 @@ int run_bn_bwd(const BwdCtx& b, int ui, const UnitPlan& u, int j, bool skip_appl
         a.nslab_in = dw_stats_slabs(P, A.lvl);
       }
   }
-  LAUNCH_TRY(csn_launch_bn_bwd(a, b.c.stream));
+  if (steps == 1) {
+    LAUNCH_TRY(csn_launch_bn_bwd_reduce(a, b.c.stream));
+  } else {
+    LAUNCH_TRY(csn_launch_bn_bwd(a, b.c.stream));
+  }
   if (keep) *keep = a;
   return CSN_OK;
 }
@@ -577,11 +584,20 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
       // tests/test_gpu_paths.py::test_gpu_overlap2_weight_gradient_lane_is_deterministic on the first graph replay)
       const int kf = (d.kind == CSN_UNIT_GOCT && !fuse_apply && !c.lanes) ? ub.adj_fused[j] : -1;
       float* adjp = kf >= 0 ? reinterpret_cast<float*>(scratch + ub.adj[kf].off) : nullptr;
-      const int st = run_bn_bwd(b, ui, u, j, fuse_apply, &bnargs[j], adjp);
+      const int st = run_bn_bwd(b, ui, u, j, fuse_apply, &bnargs[j], adjp, 1);
       if (st != CSN_OK) return st;
       bn_fused[j] = fuse_apply;
       bd.dz[j] = kf >= 0 ? c.act_y(d.out_act[j]) : reinterpret_cast<const float*>(c.ws + P.tz_off[d.out_act[j]]);
       if (kf >= 0) bd.adj[kf] = adjp;
+    }
+    {   // one finalise launch for the unit's branches, then the apply passes
+      BnBwdArgs fin[CSN_MAX_BRANCH];
+      int nfin = 0;
+      for (int j = 0; j < d.n_out; ++j)
+        if (d.cout[j] > 0) fin[nfin++] = bnargs[j];
+      LAUNCH_TRY(csn_launch_bn_bwd_finalize_n(fin, nfin, c.stream));
+      for (int j = 0; j < d.n_out; ++j)
+        if (d.cout[j] > 0) LAUNCH_TRY(csn_launch_bn_bwd_apply_step(bnargs[j], c.stream));
     }
     bool c3q_fwd = false;   // the train-mode forward ran this 3x3 unit on c3q_kernel: its max-pooled input copies exist (run_unit)
     if (d.kind == CSN_UNIT_GOCT && d.ksize == 3 && P.c3q && P.tiled3 && !std::getenv("CSN_WGRAD_NO_MP"))
@@ -846,6 +862,7 @@ static int enable_training_impl(csn_plan* P) {
       }
   }
   P->x16_off = bl.alloc_ws((int64_t)P->S * P->acts[0].channels * P->H * P->W * 2);   // bf16 copy of the input batch (CSN_OPT_TRAIN_BF16)
+  P->red_maxc = maxc;
   P->red_off = bl.alloc_ws((int64_t)maxc * CSN_BN_NSLAB * 9 * sizeof(double));
   P->red2_off = bl.alloc_ws((int64_t)maxc * CSN_BN_NSLAB * 9 * sizeof(double));   // ... of the weight-gradient side lane
   P->bwd.clear();

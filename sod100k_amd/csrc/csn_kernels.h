@@ -395,6 +395,7 @@ struct BnApplyArgs {
 int csn_launch_bn_stats(const BnStatsArgs& a, void* stream);
 int csn_launch_bn_finalize(const BnFinalizeArgs& a, void* stream);
 int csn_launch_bn_apply(const BnApplyArgs& a, void* stream);
+int csn_launch_bn_finalize_n(const BnFinalizeArgs* jobs, int n, void* stream);   // <= 3 branches of one unit in one launch
 #define CSN_PEN_JOBS 112
 struct BnPenaltyJob {     // one hooked (unit, output branch): its |GAP| table [C][S], gamma offset, branch weight
   const float* gapabs;
@@ -445,6 +446,9 @@ struct BnBwdArgs {
 };
 bool csn_bn_bwd_adj2_ok(int64_t HW, int W);
 int csn_launch_bn_bwd(const BnBwdArgs& a, void* stream);
+int csn_launch_bn_bwd_reduce(BnBwdArgs& a, void* stream);                       // ... or step by step (<= 3 branches share the finalise launch)
+int csn_launch_bn_bwd_finalize_n(const BnBwdArgs* jobs, int n, void* stream);
+int csn_launch_bn_bwd_apply_step(const BnBwdArgs& a, void* stream);
 int csn_launch_bn_bwd_apply(const BnBwdArgs& a, void* stream);   // the apply pass alone (debug: materialise dz for the probes)
 
 struct DwWgradArgs {

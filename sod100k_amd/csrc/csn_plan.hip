@@ -231,7 +231,8 @@ struct csn_plan {
   std::vector<int> act_prod_unit, act_prod_branch;   // per act: producing unit / its output branch
   std::vector<int> orphan_acts;          // outputs without consumer: zero gradient (training)
   int64_t scratch_off = 0, scratch_bytes = 0;   // per-unit backward temporaries (shared by all units)
-  int64_t red_off = 0;                          // fp64 partials of the BN / depthwise reductions
+  int64_t red_off = 0;                          // fp64 partials of the BN / depthwise reductions: [red_maxc][NSLAB][9] doubles
+  int red_maxc = 0;
   int64_t wg_off = 0;                           // partial dW slices (k_wgrad.hip): CSN_WG_REGIONS regions of wg_region_floats
   int64_t wg_region_floats = 0;
   int64_t red2_off = 0, wg2_off = 0;            // ... of the weight-gradient side lane (csn_backward)
@@ -1900,6 +1901,9 @@ static int forward_train_body(csn_plan* P, const float* x, float* y, void* works
     const int st = run_unit(c, up, nullptr);           // raw z of every output branch (no depthwise fusion)
     if (st != CSN_OK) return st;
     if (d.kind == CSN_UNIT_CLS) continue;
+    // statistics of every output branch, then ONE finalise launch for the unit, then the apply passes
+    BnFinalizeArgs fas[CSN_MAX_BRANCH];
+    int fa_of[CSN_MAX_BRANCH] = {-1, -1, -1}, nfa = 0;
     for (int j = 0; j < d.n_out; ++j) {
       if (d.cout[j] == 0) continue;
       const Act& act = P->acts[d.out_act[j]];
@@ -1908,7 +1912,7 @@ static int forward_train_body(csn_plan* P, const float* x, float* y, void* works
       double* part = reinterpret_cast<double*>(c.ws + up.stats_off[j]);
       BnStatsArgs sa; sa.z = z; sa.partial = part; sa.S = P->S; sa.C = d.cout[j]; sa.HW = hw; sa.a16 = c.a16 ? 1 : 0;
       if (!stats_done) LAUNCH_TRY(csn_launch_bn_stats(sa, stream));
-      BnFinalizeArgs fa; fa.partial = part; fa.arena = arena;
+      BnFinalizeArgs& fa = fas[nfa]; fa.partial = part; fa.arena = arena;
       fa.nslab = stats_done ? dw_stats_slabs(*P, act.lvl) : 0;
       fa.scale = P->packed + up.out_epi[j].scale; fa.shift = P->packed + up.out_epi[j].shift;
       fa.off_weight = d.bn[j].weight; fa.off_bias = d.bn[j].bias; fa.off_rmean = d.bn[j].running_mean;
@@ -1916,7 +1920,15 @@ static int forward_train_body(csn_plan* P, const float* x, float* y, void* works
       // backward needs the batch mean / invstd; without training buffers they land in a dummy slot of the tables
       fa.mean = P->packed + (P->train ? up.tr_mean[j] : P->ident.dummy);
       fa.invstd = P->packed + (P->train ? up.tr_invstd[j] : P->ident.dummy);
-      LAUNCH_TRY(csn_launch_bn_finalize(fa, stream));
+      fa_of[j] = nfa++;
+    }
+    LAUNCH_TRY(csn_launch_bn_finalize_n(fas, nfa, stream));
+    for (int j = 0; j < d.n_out; ++j) {
+      if (d.cout[j] == 0) continue;
+      const Act& act = P->acts[d.out_act[j]];
+      const int64_t hw = (int64_t)(P->H >> act.lvl) * (P->W >> act.lvl);
+      float* z = c.act_out(d.out_act[j]);
+      const BnFinalizeArgs& fa = fas[fa_of[j]];
       BnApplyArgs aa; aa.z = z; aa.y = c.act_y(d.out_act[j]);
       aa.gapabs = reinterpret_cast<float*>(c.ws + up.gap_off[j]);
       aa.scale = fa.scale; aa.shift = fa.shift; aa.alpha = P->packed + up.out_epi[j].alpha;

@@ -93,9 +93,9 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_stats_kernel(BnStatsArgs a) {
 }
 
 // one block per channel: the slab partials are summed by the block (fixed order), thread 0 finishes
-__global__ __launch_bounds__(CSN_BLOCK) void bn_finalize_kernel(BnFinalizeArgs a) {
-  CSN_DYN_SMEM(double, sm);
+__device__ __forceinline__ void bn_finalize_body(const BnFinalizeArgs& a, double* sm) {
   const int c = blockIdx.x;
+  if (c >= a.C) return;   // (block-uniform: the multi-job launch is as wide as its widest job)
   double s1 = 0.0, s2 = 0.0;
   for (int k = threadIdx.x; k < a.nslab; k += CSN_BLOCK) {
     s1 += a.partial[((int64_t)c * BN_NSLAB + k) * 2 + 0];
@@ -118,6 +118,17 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_finalize_kernel(BnFinalizeArgs a
   const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
   a.arena[a.off_rmean + c] = 0.9f * a.arena[a.off_rmean + c] + 0.1f * (float)mean;
   a.arena[a.off_rvar + c] = 0.9f * a.arena[a.off_rvar + c] + 0.1f * (float)unbiased;
+}
+__global__ __launch_bounds__(CSN_BLOCK) void bn_finalize_kernel(BnFinalizeArgs a) {
+  CSN_DYN_SMEM(double, sm);
+  bn_finalize_body(a, sm);
+}
+// the output branches of ONE unit in one launch (grid (max C, jobs): ~100 launches of ~5 us less per train-mode forward)
+__global__ __launch_bounds__(CSN_BLOCK) void bn_finalize3_kernel(BnFinalizeArgs a0, BnFinalizeArgs a1, BnFinalizeArgs a2) {
+  CSN_DYN_SMEM(double, sm);
+  if (blockIdx.y == 0) bn_finalize_body(a0, sm);
+  else if (blockIdx.y == 1) bn_finalize_body(a1, sm);
+  else bn_finalize_body(a2, sm);
 }
 
 // grid (C, S): block (c, n) streams one plane: y = PReLU(z*scale + shift) (z is kept for the backward pass), and
@@ -252,9 +263,9 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_reduce_kernel(BnBwdArgs a) {
   }
 }
 
-__global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_finalize_kernel(BnBwdArgs a) {
-  CSN_DYN_SMEM(double, sm);
+__device__ __forceinline__ void bn_bwd_finalize_body(const BnBwdArgs& a, double* sm) {
   const int c = blockIdx.x;
+  if (c >= a.C) return;   // (block-uniform)
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   for (int k = threadIdx.x; k < a.nslab; k += CSN_BLOCK) {
     const double* o = a.partial + ((int64_t)c * BN_NSLAB + k) * 3;
@@ -279,6 +290,16 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_finalize_kernel(BnBwdArgs a)
   a.grad[a.off_weight + c] = (float)dgamma;
   a.grad[a.off_bias + c] = (float)s0;
   a.grad[a.off_prelu + c] = (float)s2;
+}
+__global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_finalize_kernel(BnBwdArgs a) {
+  CSN_DYN_SMEM(double, sm);
+  bn_bwd_finalize_body(a, sm);
+}
+__global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_finalize3_kernel(BnBwdArgs a0, BnBwdArgs a1, BnBwdArgs a2) {
+  CSN_DYN_SMEM(double, sm);
+  if (blockIdx.y == 0) bn_bwd_finalize_body(a0, sm);
+  else if (blockIdx.y == 1) bn_bwd_finalize_body(a1, sm);
+  else bn_bwd_finalize_body(a2, sm);
 }
 
 // grid (C, S): dz written over z (same index, same thread)
@@ -322,6 +343,33 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_apply_kernel(BnBwdArgs a) {
 // grid (C, S), one plane per block; W % 8 == 0, H even.  dz is bit for bit bn_bwd_apply_kernel's; the sums use the values AS
 // STORED (rounded through bfloat16 in that mode), like the two-pass scheme.  dz is NOT written over z (lanes read their neighbours'
 // z and dy): it goes to a.dz_out.
+// eight consecutive elements of a row plus the one on either side, AS LOADED (no conversion: a row that is to stay in flight while
+// the previous one is worked on must not be touched)
+template <typename AT> struct BnRow8;
+template <> struct BnRow8<float> { float4 a, b; float l, r; };
+template <> struct BnRow8<csn_bf16> { uint2 a, b; unsigned short l, r; };
+__device__ __forceinline__ BnRow8<float> bn_row8_ld(const float* p, bool has_l, bool has_r) {
+  BnRow8<float> q;
+  q.a = *reinterpret_cast<const float4*>(p); q.b = *reinterpret_cast<const float4*>(p + 4);
+  q.l = p[has_l ? -1 : 0]; q.r = p[has_r ? 8 : 7];
+  return q;
+}
+__device__ __forceinline__ BnRow8<csn_bf16> bn_row8_ld(const csn_bf16* p, bool has_l, bool has_r) {
+  BnRow8<csn_bf16> q;
+  q.a = *reinterpret_cast<const uint2*>(p); q.b = *reinterpret_cast<const uint2*>(p + 4);
+  q.l = p[has_l ? -1 : 0].u; q.r = p[has_r ? 8 : 7].u;
+  return q;
+}
+__device__ __forceinline__ void bn_row8_f(const BnRow8<float>& q, float (&v)[10]) {
+  v[0] = q.l; v[1] = q.a.x; v[2] = q.a.y; v[3] = q.a.z; v[4] = q.a.w; v[5] = q.b.x; v[6] = q.b.y; v[7] = q.b.z; v[8] = q.b.w; v[9] = q.r;
+}
+__device__ __forceinline__ void bn_row8_f(const BnRow8<csn_bf16>& q, float (&v)[10]) {
+  v[0] = csn_bf2f(q.l);
+  v[1] = csn_bits_f(q.a.x << 16); v[2] = csn_bits_f(q.a.x & 0xffff0000u); v[3] = csn_bits_f(q.a.y << 16); v[4] = csn_bits_f(q.a.y & 0xffff0000u);
+  v[5] = csn_bits_f(q.b.x << 16); v[6] = csn_bits_f(q.b.x & 0xffff0000u); v[7] = csn_bits_f(q.b.y << 16); v[8] = csn_bits_f(q.b.y & 0xffff0000u);
+  v[9] = csn_bf2f(q.r);
+}
+
 template <typename AT>
 __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_apply_adj2_kernel(BnBwdArgs a) {
   const int c = blockIdx.x, n = blockIdx.y;
@@ -344,55 +392,63 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_apply_adj2_kernel(BnBwdArgs 
   const int yl0 = st * lrows, yl1 = min(Hl, yl0 + lrows);
   if (st >= NS || yl0 >= yl1) return;
   const int x0 = lx * 8;
-  const AT* zp = act_cast<AT>(a.z) + base;
-  const AT* ap = act_cast<AT>(a.dyA) + base;
-  const AT* bp = a.dyB ? act_cast<AT>(a.dyB) + base : nullptr;
-  AT* dzp = act_cast<AT>(a.dz_out) + base;
+  const AT* zp = act_cast<AT>(a.z) + base + x0;
+  const AT* ap = act_cast<AT>(a.dyA) + base + x0;
+  const AT* bp = a.dyB ? act_cast<AT>(a.dyB) + base + x0 : nullptr;
+  AT* dzp = act_cast<AT>(a.dz_out) + base + x0;
   AT* op = act_cast<AT>(a.adj2) + ((int64_t)n * a.C + c) * (int64_t)Hl * Wl + (x0 >> 1);
   const bool has_l = x0 > 0, has_r = x0 + 8 < W;
   const float wfirst = has_l ? 0.75f : 1.f, wlast = has_r ? 0.75f : 1.f;
-  // dz of row yh for columns x0 - 1 .. x0 + 8 (stored for the lane's own eight when `store`), reduced along x: h[k] = the row's
-  // contribution to low column x0 / 2 + k
-  auto row = [&](int yh, bool store, float (&h)[4]) {
-    if (yh < 0 || yh >= H) { h[0] = h[1] = h[2] = h[3] = 0.f; return; }
-    const int64_t o = (int64_t)yh * W + x0;
-    float4 z0 = act_ld4(zp + o), z1 = act_ld4(zp + o + 4), d0 = act_ld4(ap + o), d1 = act_ld4(ap + o + 4);
-    float zl = has_l ? act_ld(zp + o - 1) : 0.f, zr = has_r ? act_ld(zp + o + 8) : 0.f;
-    float dl = has_l ? act_ld(ap + o - 1) : 0.f, dr = has_r ? act_ld(ap + o + 8) : 0.f;
-    if (bp) {
-      const float4 e0 = act_ld4(bp + o), e1 = act_ld4(bp + o + 4);
-      d0.x += e0.x; d0.y += e0.y; d0.z += e0.z; d0.w += e0.w; d1.x += e1.x; d1.y += e1.y; d1.z += e1.z; d1.w += e1.w;
-      if (has_l) dl += act_ld(bp + o - 1);
-      if (has_r) dr += act_ld(bp + o + 8);
-    }
-    float v[10];
-    v[0] = has_l ? f(zl, dl) : 0.f;
-    v[1] = f(z0.x, d0.x); v[2] = f(z0.y, d0.y); v[3] = f(z0.z, d0.z); v[4] = f(z0.w, d0.w);
-    v[5] = f(z1.x, d1.x); v[6] = f(z1.y, d1.y); v[7] = f(z1.z, d1.z); v[8] = f(z1.w, d1.w);
-    v[9] = has_r ? f(zr, dr) : 0.f;
-    if (store) {
-      act_st4(dzp + o, make_float4(v[1], v[2], v[3], v[4]));
-      act_st4(dzp + o + 4, make_float4(v[5], v[6], v[7], v[8]));
-    }
-    h[0] = 0.25f * v[0] + wfirst * v[1] + 0.75f * v[2] + 0.25f * v[3];
-    h[1] = 0.25f * v[2] + 0.75f * v[3] + 0.75f * v[4] + 0.25f * v[5];
-    h[2] = 0.25f * v[4] + 0.75f * v[5] + 0.75f * v[6] + 0.25f * v[7];
-    h[3] = 0.25f * v[6] + 0.75f * v[7] + wlast * v[8] + 0.25f * v[9];
-  };
-  // rows 2 yl0 - 1 (the strip above owns and stores it: only its sums are needed here) and 2 yl0
-  float hm[4], h0[4], h1[4], h2[4];
-  row(2 * yl0 - 1, false, hm);
-  row(2 * yl0, true, h0);
-  for (int yl = yl0; yl < yl1; ++yl) {
-    row(2 * yl + 1, true, h1);
-    row(2 * yl + 2, yl + 1 < yl1, h2);      // the first row of the next strip is stored by that strip
-    const float wa = yl > 0 ? 0.75f : 1.f, wb = yl + 1 < Hl ? 0.75f : 1.f;
-    float o4[4];
+  // The strip's output rows r0 .. r1 in one loop (2 yl0 - 1: the strip above owns and stores it, only its sums are needed; 2 yl1: the
+  // strip below's): the loads of row r + 1 are issued BEFORE row r is converted and used (a whole trip in flight), rows outside
+  // the plane are fetched from a clamped row and ignored.
+  const int r0 = 2 * yl0 - 1, r1 = 2 * yl1;
+  auto rowoff = [&](int r) { return (int64_t)min(max(r, 0), H - 1) * W; };
+  BnRow8<AT> qz = bn_row8_ld(zp + rowoff(r0), has_l, has_r), qa = bn_row8_ld(ap + rowoff(r0), has_l, has_r), qb = qz;
+  if (bp) qb = bn_row8_ld(bp + rowoff(r0), has_l, has_r);
+  float h3[4] = {0.f, 0.f, 0.f, 0.f}, h2[4] = {0.f, 0.f, 0.f, 0.f}, h1[4] = {0.f, 0.f, 0.f, 0.f};   // row sums of r - 3, r - 2, r - 1
+  for (int r = r0; r <= r1; ++r) {
+    const int64_t on = rowoff(r + 1);
+    const BnRow8<AT> nz = bn_row8_ld(zp + on, has_l, has_r), na = bn_row8_ld(ap + on, has_l, has_r);
+    BnRow8<AT> nb = nz;
+    if (bp) nb = bn_row8_ld(bp + on, has_l, has_r);
+#ifndef CSN_CPU_EMU
+    __builtin_amdgcn_sched_barrier(0);   // the loads above stay above the conversions below
+#endif
+    float h[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r >= 0 && r < H) {
+      float z[10], d[10], v[10];
+      bn_row8_f(qz, z); bn_row8_f(qa, d);
+      if (bp) {
+        float e[10];
+        bn_row8_f(qb, e);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o4[k] = 0.25f * hm[k] + wa * h0[k] + wb * h1[k] + 0.25f * h2[k];
-    act_st4(op + (int64_t)yl * Wl, make_float4(o4[0], o4[1], o4[2], o4[3]));
+        for (int i = 0; i < 10; ++i) d[i] += e[i];
+      }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { hm[k] = h1[k]; h0[k] = h2[k]; }
+      for (int i = 0; i < 10; ++i) v[i] = f(z[i], d[i]);
+      if (!has_l) v[0] = 0.f;
+      if (!has_r) v[9] = 0.f;
+      if (r >= 2 * yl0 && r < 2 * yl1) {
+        act_st4(dzp + (int64_t)r * W, make_float4(v[1], v[2], v[3], v[4]));
+        act_st4(dzp + (int64_t)r * W + 4, make_float4(v[5], v[6], v[7], v[8]));
+      }
+      h[0] = 0.25f * v[0] + wfirst * v[1] + 0.75f * v[2] + 0.25f * v[3];
+      h[1] = 0.25f * v[2] + 0.75f * v[3] + 0.75f * v[4] + 0.25f * v[5];
+      h[2] = 0.25f * v[4] + 0.75f * v[5] + 0.75f * v[6] + 0.25f * v[7];
+      h[3] = 0.25f * v[6] + 0.75f * v[7] + wlast * v[8] + 0.25f * v[9];
+    }
+    if (((r & 1) == 0) && r >= 2 * yl0 + 2) {   // row 2 yl + 2 closes low row yl: rows 2 yl - 1 .. 2 yl + 2 = h3, h2, h1, h
+      const int yl = (r >> 1) - 1;
+      const float wa = yl > 0 ? 0.75f : 1.f, wb = yl + 1 < Hl ? 0.75f : 1.f;
+      act_st4(op + (int64_t)yl * Wl, make_float4(0.25f * h3[0] + wa * h2[0] + wb * h1[0] + 0.25f * h[0],
+                                                  0.25f * h3[1] + wa * h2[1] + wb * h1[1] + 0.25f * h[1],
+                                                  0.25f * h3[2] + wa * h2[2] + wb * h1[2] + 0.25f * h[2],
+                                                  0.25f * h3[3] + wa * h2[3] + wb * h1[3] + 0.25f * h[3]));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { h3[k] = h2[k]; h2[k] = h1[k]; h1[k] = h[k]; }
+    qz = nz; qa = na; qb = nb;
   }
 }
 
@@ -765,6 +821,19 @@ int csn_launch_bn_finalize(const BnFinalizeArgs& a0, void* stream) {
   CSN_LAUNCH(bn_finalize_kernel, dim3(a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   return (int)hipGetLastError();
 }
+int csn_launch_bn_finalize_n(const BnFinalizeArgs* jobs, int n, void* stream) {
+  if (n <= 0) return 0;
+  BnFinalizeArgs a[3];
+  int mx = 1;
+  for (int i = 0; i < 3; ++i) {
+    a[i] = jobs[i < n ? i : 0];
+    if (a[i].nslab <= 0) a[i].nslab = bn_nslab(a[i].S, bn_cpp(a[i].S, a[i].C, a[i].count / a[i].S));
+    if (i < n) mx = std::max(mx, (int)a[i].C);
+  }
+  if (n == 1) CSN_LAUNCH(bn_finalize_kernel, dim3(a[0].C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a[0]);
+  else CSN_LAUNCH(bn_finalize3_kernel, dim3(mx, n), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a[0], a[1], a[2]);
+  return (int)hipGetLastError();
+}
 int csn_launch_bn_apply(const BnApplyArgs& a, void* stream) {
   CSN_LAUNCH_AT(a.a16, bn_apply_gap_kernel, dim3(a.C, a.S), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
   return (int)hipGetLastError();
@@ -785,6 +854,31 @@ int csn_launch_bn_penalty(const BnPenaltyJob* jobs, int njobs, const float* aren
 
 static inline int grid_for(int64_t n) { return (int)((n + CSN_BLOCK - 1) / CSN_BLOCK < 4096 ? (n + CSN_BLOCK - 1) / CSN_BLOCK : 4096); }
 
+// the three steps of csn_launch_bn_bwd one by one, so that the finalise steps of a unit's branches share a launch:
+// reduce (fills a.cpp / a.nslab) -> csn_launch_bn_bwd_finalize_n -> csn_launch_bn_bwd_apply_step
+int csn_launch_bn_bwd_reduce(BnBwdArgs& a, void* stream) {
+  a.cpp = bn_cpp(a.S, a.C, a.HW);
+  a.nslab = bn_nslab(a.S, a.cpp);
+  if (a.nslab_in > 0) a.nslab = a.nslab_in;
+  else CSN_LAUNCH_AT(a.a16, bn_bwd_reduce_kernel, dim3(a.nslab, a.C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, a);
+  return (int)hipGetLastError();
+}
+int csn_launch_bn_bwd_finalize_n(const BnBwdArgs* jobs, int n, void* stream) {
+  if (n <= 0) return 0;
+  int mx = 1;
+  for (int i = 0; i < n; ++i) mx = std::max(mx, (int)jobs[i].C);
+  if (n == 1) CSN_LAUNCH(bn_bwd_finalize_kernel, dim3(jobs[0].C), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, jobs[0]);
+  else CSN_LAUNCH(bn_bwd_finalize3_kernel, dim3(mx, n), dim3(CSN_BLOCK), CSN_BLOCK * sizeof(double), stream, jobs[0], jobs[1], jobs[n > 2 ? 2 : 0]);
+  return (int)hipGetLastError();
+}
+int csn_launch_bn_bwd_apply_step(const BnBwdArgs& a, void* stream) {
+  if (!a.skip_apply) {
+    if (a.adj2 && a.dz_out && a.dz_out != a.z && csn_bn_bwd_adj2_ok(a.HW, a.W)) CSN_LAUNCH_AT(a.a16, bn_bwd_apply_adj2_kernel, dim3(a.C, a.S), dim3(CSN_BLOCK), 0, stream, a);
+    else if (a.adj2) return 1;   // (the caller asks csn_bn_bwd_adj2_ok first)
+    else CSN_LAUNCH_AT(a.a16, bn_bwd_apply_kernel, dim3(a.C, a.S), dim3(CSN_BLOCK), 0, stream, a);
+  }
+  return (int)hipGetLastError();
+}
 int csn_launch_bn_bwd(const BnBwdArgs& a0, void* stream) {
   BnBwdArgs a = a0;
   a.cpp = bn_cpp(a.S, a.C, a.HW);

@@ -63,7 +63,7 @@ def _train_grad(lib, dev, manifest, x, t, B):
 
 def test_gpu_overlap2_weight_gradient_lane_is_deterministic(hip, x2_manifest, monkeypatch):
     """CSN_OPT_OVERLAP = 2 moves every weight-gradient launch of csn_backward to a side stream (the mode ADVICE r2 found a race
-    in): 20 repeated steps must be bit-identical to each other and to the default mode's gradient."""
+    in): 20 repeated steps must be bit-identical to each other, and equal to the default mode's gradient up to summation order."""
     lib, dev = hip
     B, S = 4, 96
     x = torch.from_numpy(I.randn_batch(70, B, S, S)).to(dev)
@@ -71,12 +71,17 @@ def test_gpu_overlap2_weight_gradient_lane_is_deterministic(hip, x2_manifest, mo
     base = _train_grad(lib, dev, x2_manifest, x, t, B)
     monkeypatch.setenv("CSN_OVERLAP", "2")
     lane = _train_grad(lib, dev, x2_manifest, x, t, B)
-    g0 = base[0][0]
+    g0, l0 = base[0][0], lane[0][0]
     for k, (g, loss, pen) in enumerate(base):
         assert torch.equal(g, g0), f"default mode: step {k} differs from step 0"
+    # the side-lane mode takes other kernels for some passes (the depthwise units' weight gradients on their own kernel, the
+    # adjoint upsampling as its own pass): the same gradient up to fp32 summation order -- and bit-identical from step to step
+    # (a race between the lanes shows up as a run-to-run difference, as it did on the first graph replay in round 4)
     for k, (g, loss, pen) in enumerate(lane):
-        assert torch.equal(g, g0), f"overlap 2: step {k} differs from the default mode ({(g - g0).abs().max().item():.3e})"
-        assert loss == base[0][1] and pen == base[0][2]
+        assert torch.equal(g, l0), f"overlap 2: step {k} differs from step 0 ({(g - l0).abs().max().item():.3e})"
+        assert loss == base[0][1] and abs(pen - base[0][2]) <= 1e-6 * max(1.0, abs(base[0][2]))
+    rel = float((l0 - g0).norm() / g0.norm())
+    assert rel <= 1e-4, f"overlap 2 vs default mode: relative L2 {rel:.3e}"
 
 
 def test_gpu_slice_lanes_is_deterministic(hip, x2_manifest, monkeypatch):
