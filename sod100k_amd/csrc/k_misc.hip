@@ -242,13 +242,29 @@ __device__ __forceinline__ void dw_emit(AT* __restrict__ op, int y, int yend, in
   }
   AT* q = op + (int64_t)y * W + x0;
   if (STATS) {
+    if (sizeof(AT) == 2) {
+      // bfloat16 storage (round 4): the stored values have 8 significant bits, so v * v is exact in fp32 and the sums of the row's
+      // four values / squares are exact or off by one fp32 rounding -- fp32 over the row, fp64 across rows (the per-element fp64
+      // form cost 12 double-rate operations per row of a kernel that is instruction bound)
+      float s = 0.f, q2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (VEC || x0 + j < W) {
-        const double v = (double)(sizeof(AT) == 2 ? csn_bf2f(csn_f2bf(o[j])) : o[j]);
-        st[0] += v;
-        st[1] += v * v;
-      }
+      for (int j = 0; j < 4; ++j)
+        if (VEC || x0 + j < W) {
+          const float v = csn_bf2f(csn_f2bf(o[j]));
+          s += v;
+          q2 = fmaf(v, v, q2);
+        }
+      st[0] += (double)s;
+      st[1] += (double)q2;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (VEC || x0 + j < W) {
+          const double v = (double)o[j];
+          st[0] += v;
+          st[1] += v * v;
+        }
+    }
   }
   if (oret) {   // the values as STORED
 #pragma unroll
@@ -550,6 +566,10 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
       float dxv[4];
       dw_emit<VEC, AT>(op, y, yend, x0, W, w, 1.f, 0.f, 1.f, g0, g1, g2, nullptr, XBN ? dxv : nullptr);
       if (XBN) {   // the producer's BatchNorm-backward sums (bn_bwd_reduce_kernel's arithmetic): dy = the dx just stored
+        // fp32 over the row's four values, fp64 across the rows of the lane (round 4: the sums -- the PReLU slope's gradient above
+        // all -- cancel heavily on the shipped checkpoint; 64 fp32 terms per lane put one tensor at 2.1e-4 of the unit-local bound
+        // 2e-4 on the device)
+        rf[0] = rf[1] = rf[2] = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (VEC || x0 + j < W) {
@@ -560,6 +580,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
             rf[1] = fmaf(dbn, (z - imu) * iis, rf[1]);
             rf[2] = fmaf(bn > 0.f ? 0.f : dy, bn, rf[2]);
           }
+        rs[0] += (double)rf[0]; rs[1] += (double)rf[1]; rs[2] += (double)rf[2];
 #pragma unroll
         for (int j = 0; j < 4; ++j) zc1[j] = zc2[j];
       }
@@ -578,11 +599,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
 #pragma unroll
   for (int t = 0; t < 9; ++t) sv[t] = (double)s[t];
   bn_block_sum_n<9>(sv, sm);
-  if (XBN) {
-#pragma unroll
-    for (int t = 0; t < 3; ++t) rs[t] = (double)rf[t];
-    bn_block_sum_n<3>(rs, sm);
-  }
+  if (XBN) bn_block_sum_n<3>(rs, sm);
   if (tid == 0) {
     const int b = pc / br.C;
     double* o = br.stats + ((int64_t)c * CSN_BN_NSLAB + (int64_t)b * tiles + tile) * 9;

@@ -73,8 +73,13 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_stats_kernel(BnStatsArgs a) {
     if ((a.HW & 3) == 0) {
       for (int i = (r.beg >> 2) + threadIdx.x; i < (r.end >> 2); i += CSN_BLOCK) {
         const float4 v = act_ld4(p + 4 * i);
-        s1 += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
-        s2 += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+        if (sizeof(AT) == 2) {   // bfloat16 values: squares exact in fp32, four-term sums in fp32, fp64 across the quads (round 4)
+          s1 += (double)((v.x + v.y) + (v.z + v.w));
+          s2 += (double)(fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w));
+        } else {
+          s1 += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+          s2 += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+        }
       }
     } else {
       for (int i = r.beg + threadIdx.x; i < r.end; i += CSN_BLOCK) {
@@ -148,7 +153,8 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_apply_gap_kernel(BnApplyArgs a) 
       v.x = csn_epi(v.x, sc, sh, al); v.y = csn_epi(v.y, sc, sh, al);
       v.z = csn_epi(v.z, sc, sh, al); v.w = csn_epi(v.w, sc, sh, al);
       act_st4(q + 4 * i, v);
-      s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+      if (sizeof(AT) == 2) s += (double)((v.x + v.y) + (v.z + v.w));
+      else s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
     }
   } else {
     for (int64_t i = threadIdx.x; i < hw; i += CSN_BLOCK) {
@@ -248,7 +254,20 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_reduce_kernel(BnBwdArgs a) {
       const float4 z = act_ld4(z4 + 4 * i);
       float4 d = act_ld4(a4 + 4 * i);
       if (b4) { const float4 e = act_ld4(b4 + 4 * i); d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
-      acc(z.x, d.x); acc(z.y, d.y); acc(z.z, d.z); acc(z.w, d.w);
+      if (sizeof(AT) == 2) {   // bf16 storage (round 4): fp32 over the quad, fp64 across quads -- 6 instead of ~28 double-rate operations
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+        auto acc4 = [&](float zz, float dy) {
+          const float bn = zz * sc + sh;
+          const float dbn = bn > 0.f ? dy : al * dy;
+          t0 += dbn;
+          t1 = fmaf(dbn, (zz - mu) * is, t1);
+          t2 = fmaf(bn > 0.f ? 0.f : dy, bn, t2);
+        };
+        acc4(z.x, d.x); acc4(z.y, d.y); acc4(z.z, d.z); acc4(z.w, d.w);
+        s0 += (double)t0; s1 += (double)t1; s2 += (double)t2;
+      } else {
+        acc(z.x, d.x); acc(z.y, d.y); acc(z.z, d.z); acc(z.w, d.w);
+      }
     }
   } else {
     for (int i = r.beg + threadIdx.x; i < r.end; i += CSN_BLOCK)
