@@ -756,13 +756,20 @@ def _check_train_units_local(lib, device, manifest, B, size, act_dtype, state, f
         def local(flips):
             """The unit recomputed by the oracle from the device's own inputs / upstream gradients; ``flips``: PReLU elements
             (per BatchNorm call) that take the other branch -- see O.PRELU_FLIP."""
+            # fp32 storage: the reference in fp64 (round 4) -- an fp32 reference has its own summation noise, which on heavily
+            # cancelling sums (a PReLU slope's gradient on the shipped checkpoint: +-1 terms, result 0.03) is as large as the bound
+            # and made the verdict depend on the last bits of the upstream tensors; against fp64 the deviation IS the device's error
+            # (not for the stride-2 units: their max-pool takes avg-pooled values, whose fp64 / fp32 roundings break ties differently
+            # -- a discrete event, 6e-2 on dx of stage4.0 -- so those keep the fp32 reference)
+            s2 = name.endswith(".conv1x1") and name[:-len(".conv1x1")] in blocks and blocks[name[:-len(".conv1x1")]]["stride"] == 2
+            rdt = torch.float32 if (bf16 or s2) else torch.float64
             xs = []
             for i in range(n_in):
                 if u.cin[i] > 0:
-                    xs.append(A[int(u.in_act[i])].clone().requires_grad_(int(u.in_act[i]) > 0))
+                    xs.append(A[int(u.in_act[i])].to(rdt).clone().requires_grad_(int(u.in_act[i]) > 0))
                 else:
                     xs.append(None)
-            loc = {k: v.clone() for k, v in sd.items() if k.startswith(name + ".")}
+            loc = {k: (v.to(rdt) if v.is_floating_point() else v).clone() for k, v in sd.items() if k.startswith(name + ".")}
             for k in pkeys:
                 loc[k].requires_grad_(True)
             O.Z_CAPTURE = []
@@ -799,10 +806,10 @@ def _check_train_units_local(lib, device, manifest, B, size, act_dtype, state, f
                     total = None
                     for q, j in enumerate(outs):
                         if name == "cls_layer":
-                            up = dy.cpu()
+                            up = dy.cpu().to(rdt)
                         else:
                             a = int(u.out_act[j])
-                            up = G[(a, 0)] + (G[(a, 1)] if (a, 1) in G else 0.0)
+                            up = (G[(a, 0)] + (G[(a, 1)] if (a, 1) in G else 0.0)).to(rdt)
                             w = flop_tab[ui * N.MAX_BRANCH + j]
                             if w != 0.0:   # Oct_bn_hook (csnet.py:391-410): 0.5 w sum |mean_hw y| gamma^2, y detached; /batchsize
                                 gam = loc[[k for k in pkeys if k.endswith(f"bns.{j}.weight")][0]]
