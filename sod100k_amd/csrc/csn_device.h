@@ -231,6 +231,30 @@ __device__ __forceinline__ void act_st4(float* p, float4 v) { *reinterpret_cast<
 __device__ __forceinline__ void act_st4(csn_bf16* p, float4 v) {
   *reinterpret_cast<uint2*>(p) = make_uint2(csn_pack_bf2(v.x, v.y), csn_pack_bf2(v.z, v.w));
 }
+// eight consecutive elements (p 16-byte aligned for bfloat16, 32 for float): ONE 128-bit access per lane in the bf16 mode, two
+// in flight for float -- the streaming BatchNorm kernels of the train step (round 4)
+struct csn_f8 { float v[8]; };
+__device__ __forceinline__ csn_f8 act_ld8(const float* p) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  csn_f8 r;
+  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+  return r;
+}
+__device__ __forceinline__ csn_f8 act_ld8(const csn_bf16* p) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p);
+  csn_f8 r;
+  r.v[0] = csn_bits_f(u.x << 16); r.v[1] = csn_bits_f(u.x & 0xffff0000u); r.v[2] = csn_bits_f(u.y << 16); r.v[3] = csn_bits_f(u.y & 0xffff0000u);
+  r.v[4] = csn_bits_f(u.z << 16); r.v[5] = csn_bits_f(u.z & 0xffff0000u); r.v[6] = csn_bits_f(u.w << 16); r.v[7] = csn_bits_f(u.w & 0xffff0000u);
+  return r;
+}
+__device__ __forceinline__ void act_st8(float* p, const csn_f8& r) {
+  *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+__device__ __forceinline__ void act_st8(csn_bf16* p, const csn_f8& r) {
+  *reinterpret_cast<uint4*>(p) = make_uint4(csn_pack_bf2(r.v[0], r.v[1]), csn_pack_bf2(r.v[2], r.v[3]), csn_pack_bf2(r.v[4], r.v[5]),
+                                             csn_pack_bf2(r.v[6], r.v[7]));
+}
 // typed view of an argument-block pointer (the blocks carry `float*` whatever the element type)
 template <typename AT> __device__ __forceinline__ const AT* act_cast(const float* p) { return reinterpret_cast<const AT*>(p); }
 template <typename AT> __device__ __forceinline__ AT* act_cast(float* p) { return reinterpret_cast<AT*>(p); }

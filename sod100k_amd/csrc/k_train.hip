@@ -53,7 +53,7 @@ __device__ __forceinline__ BnRange bn_range(int slab, int cpp, int S, int C, int
   }
   const int n = slab / cpp, ch = slab - n * cpp;
   int per = (int)((hw + cpp - 1) / cpp);
-  per = (per + 3) & ~3;   // chunks start on a float4 boundary
+  per = (per + 7) & ~7;   // chunks start on a multiple of eight elements (128-bit accesses in the bf16 mode)
   r.base = ((int64_t)n * C + c) * hw;
   r.beg = min(ch * per, (int)hw);
   r.end = min(r.beg + per, (int)hw);
@@ -70,7 +70,22 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_stats_kernel(BnStatsArgs a) {
   double s1 = 0.0, s2 = 0.0;
   for (int img = 0; img < r.nimg; ++img) {
     const AT* __restrict__ p = act_cast<AT>(a.z) + r.base + (int64_t)img * a.C * a.HW;
-    if ((a.HW & 3) == 0) {
+    if ((a.HW & 7) == 0) {   // eight elements per lane and trip
+      for (int i = (r.beg >> 3) + threadIdx.x; i < (r.end >> 3); i += CSN_BLOCK) {
+        const csn_f8 v = act_ld8(p + 8 * i);
+        if (sizeof(AT) == 2) {
+          s1 += (double)(((v.v[0] + v.v[1]) + (v.v[2] + v.v[3])) + ((v.v[4] + v.v[5]) + (v.v[6] + v.v[7])));
+          s2 += (double)((fmaf(v.v[0], v.v[0], v.v[1] * v.v[1]) + fmaf(v.v[2], v.v[2], v.v[3] * v.v[3])) +
+                         (fmaf(v.v[4], v.v[4], v.v[5] * v.v[5]) + fmaf(v.v[6], v.v[6], v.v[7] * v.v[7])));
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; k += 4) {
+            s1 += ((double)v.v[k] + (double)v.v[k + 1]) + ((double)v.v[k + 2] + (double)v.v[k + 3]);
+            s2 += ((double)v.v[k] * v.v[k] + (double)v.v[k + 1] * v.v[k + 1]) + ((double)v.v[k + 2] * v.v[k + 2] + (double)v.v[k + 3] * v.v[k + 3]);
+          }
+        }
+      }
+    } else if ((a.HW & 3) == 0) {
       for (int i = (r.beg >> 2) + threadIdx.x; i < (r.end >> 2); i += CSN_BLOCK) {
         const float4 v = act_ld4(p + 4 * i);
         if (sizeof(AT) == 2) {   // bfloat16 values: squares exact in fp32, four-term sums in fp32, fp64 across the quads (round 4)
@@ -147,7 +162,18 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_apply_gap_kernel(BnApplyArgs a) 
   AT* __restrict__ q = act_cast<AT>(a.y) + ((int64_t)n * a.C + c) * hw;
   const float sc = a.scale[c], sh = a.shift[c], al = a.alpha[c];
   double s = 0.0;
-  if ((hw & 3) == 0) {
+  if ((hw & 7) == 0) {
+    for (int64_t i = threadIdx.x; i < (hw >> 3); i += CSN_BLOCK) {
+      csn_f8 v = act_ld8(p + 8 * i);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v.v[k] = csn_epi(v.v[k], sc, sh, al);
+      act_st8(q + 8 * i, v);
+      if (sizeof(AT) == 2) s += (double)(((v.v[0] + v.v[1]) + (v.v[2] + v.v[3])) + ((v.v[4] + v.v[5]) + (v.v[6] + v.v[7])));
+      else
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += (double)v.v[k];
+    }
+  } else if ((hw & 3) == 0) {
     for (int64_t i = threadIdx.x; i < (hw >> 2); i += CSN_BLOCK) {
       float4 v = act_ld4(p + 4 * i);
       v.x = csn_epi(v.x, sc, sh, al); v.y = csn_epi(v.y, sc, sh, al);
@@ -246,7 +272,35 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_reduce_kernel(BnBwdArgs a) {
   for (int img = 0; img < r0.nimg; ++img) {
   BnRange r = r0;
   r.base += (int64_t)img * a.C * a.HW;
-  if ((a.HW & 3) == 0) {   // chunks start on float4 boundaries (bn_range)
+  if ((a.HW & 7) == 0) {   // eight elements per lane and trip: fp32 over the eight, fp64 across (float: per element as below)
+    const AT* z8 = act_cast<AT>(a.z) + r.base;
+    const AT* a8 = act_cast<AT>(a.dyA) + r.base;
+    const AT* b8 = a.dyB ? act_cast<AT>(a.dyB) + r.base : nullptr;
+    for (int i = (r.beg >> 3) + threadIdx.x; i < (r.end >> 3); i += CSN_BLOCK) {
+      const csn_f8 z = act_ld8(z8 + 8 * i);
+      csn_f8 d = act_ld8(a8 + 8 * i);
+      if (b8) {
+        const csn_f8 e = act_ld8(b8 + 8 * i);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d.v[k] += e.v[k];
+      }
+      if (sizeof(AT) == 2) {
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float bn = z.v[k] * sc + sh;
+          const float dbn = bn > 0.f ? d.v[k] : al * d.v[k];
+          t0 += dbn;
+          t1 = fmaf(dbn, (z.v[k] - mu) * is, t1);
+          t2 = fmaf(bn > 0.f ? 0.f : d.v[k], bn, t2);
+        }
+        s0 += (double)t0; s1 += (double)t1; s2 += (double)t2;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc(z.v[k], d.v[k]);
+      }
+    }
+  } else if ((a.HW & 3) == 0) {   // chunks start on float4 boundaries (bn_range)
     const AT* z4 = act_cast<AT>(a.z) + r.base;
     const AT* a4 = act_cast<AT>(a.dyA) + r.base;
     const AT* b4 = a.dyB ? act_cast<AT>(a.dyB) + r.base : nullptr;
@@ -335,7 +389,22 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_apply_kernel(BnBwdArgs a) {
     const float dbn = bn > 0.f ? dy : al * dy;
     return gi * (dbn - m1 - (z - mu) * is * m2);
   };
-  if ((hw & 3) == 0) {
+  if ((hw & 7) == 0) {
+    AT* z8 = act_cast<AT>(a.z) + base;
+    const AT* a8 = act_cast<AT>(a.dyA) + base;
+    const AT* b8 = a.dyB ? act_cast<AT>(a.dyB) + base : nullptr;
+    for (int64_t i = threadIdx.x; i < (hw >> 3); i += CSN_BLOCK) {
+      csn_f8 z = act_ld8(z8 + 8 * i), d = act_ld8(a8 + 8 * i);
+      if (b8) {
+        const csn_f8 e = act_ld8(b8 + 8 * i);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d.v[k] += e.v[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) z.v[k] = f(z.v[k], d.v[k]);
+      act_st8(z8 + 8 * i, z);
+    }
+  } else if ((hw & 3) == 0) {
     AT* z4 = act_cast<AT>(a.z) + base;
     const AT* a4 = act_cast<AT>(a.dyA) + base;
     const AT* b4 = a.dyB ? act_cast<AT>(a.dyB) + base : nullptr;

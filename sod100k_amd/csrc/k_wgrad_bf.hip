@@ -298,6 +298,7 @@ struct WgBf3Args {
   int32_t nrs, ncs;
   int32_t R, C;         // rows; channels of THIS launch = [c_first, c_first + C) of the concatenated sources
   int32_t c_first;
+  int32_t dil;          // dilation of the taps (1: gOctConv 3x3; 2, 4, 8, 16: MSBlock slices, csnet.py:116-149) = the kernel instantiation
   int32_t HW, W, H, B;
   int32_t slog, L, runs, nitems, nblk;
   int32_t rows16, k16;
@@ -306,7 +307,7 @@ struct WgBf3Args {
 typedef const CSN_CONST_AS WgBf3Args* WgBf3ArgsP;
 
 #ifdef CSN_CPU_EMU
-template <int NTR, int NTC>
+template <int NTR, int NTC, int DIL>
 __global__ void wgrad_bf16_c3_kernel(WgBf3Args a_byval) {
   const WgBf3Args* a = &a_byval;
   if (threadIdx.x != 0) return;
@@ -328,7 +329,7 @@ __global__ void wgrad_bf16_c3_kernel(WgBf3Args a_byval) {
           wgbf_plane(a->cs, a->ncs, a->c_first + ch, HW, base, is);
           const unsigned short* pl = reinterpret_cast<const unsigned short*>(base) + (int64_t)b * is;
           for (int t = 0; t < 9; ++t) {
-            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            const int yy = y + (t / 3 - 1) * DIL, xx = x + (t % 3 - 1) * DIL;
             if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
             const float v = csn_bf2f(pl[yy * W + xx]);
             for (int r = 0; r < R; ++r) acc[((size_t)r * C + ch) * 9 + t] = fmaf(dz[r], v, acc[((size_t)r * C + ch) * 9 + t]);
@@ -346,7 +347,14 @@ typedef float wgb_f4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) unsigned* wgbf_gp1;
 __device__ __forceinline__ unsigned wgbf_ld1(const char* p) { return *(wgbf_gp1)(unsigned long long)p; }
 
-template <int NTR, int NTC>
+typedef const __attribute__((address_space(1))) csn_u2* wgbf_gp2;
+__device__ __forceinline__ csn_u2 wgbf_ld2(const char* p) { return *(wgbf_gp2)(unsigned long long)p; }
+
+// the side pieces of a row for dilation DIL: the DIL columns left of x and right of x + 8 (DIL <= 8), or the whole shifted vectors
+// (DIL = 16); element counts 2 (one dword: also DIL = 1), 2, 4, 8, 8
+template <int DIL> struct WgbSide { static constexpr int NDW = DIL <= 2 ? 1 : (DIL == 4 ? 2 : 4); };
+
+template <int NTR, int NTC, int DIL>
 __global__ __launch_bounds__(CSN_BLOCK, 2) void wgrad_bf16_c3_kernel(WgBf3Args a_byval) {
   CSN_DYN_SMEM(float, lds);
   WgBf3ArgsP a = CSN_KERNARG(WgBf3Args, a_byval);
@@ -407,37 +415,58 @@ __global__ __launch_bounds__(CSN_BLOCK, 2) void wgrad_bf16_c3_kernel(WgBf3Args a
       y -= (y * W > p) ? 1 : 0;
       y += ((y + 1) * W <= p) ? 1 : 0;
       const int x = p - y * W;
-      const bool has_l = x > 0, has_r = x + 8 < W;
-      csn_u4 A[NTR], V[NTC][3];
-      unsigned Ld[NTC][3], Rd[NTC][3];
+      // the pieces left / right of the lane's 8 columns are inside the row as a whole or not at all (x, W and DIL >= 8 are
+      // multiples of 8; DIL < 8: the piece ends at x - 1 / starts at x + 8)
+      constexpr int SD = DIL < 8 ? 8 : DIL;                      // column distance of the side vectors' far end
+      const bool has_l = x - SD >= 0, has_r = x + 8 + SD <= W;
+      constexpr int NDW = WgbSide<DIL>::NDW;
+      csn_u4 A[NTR], V[NTC][3], Lv[NTC][3], Rv[NTC][3];         // (Lv / Rv: only the first NDW dwords are loaded and used)
 #pragma unroll
       for (int t = 0; t < NTR; ++t) A[t] = wgbf_ld(pr[t] + s * (PXS * 2));
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
-        const int yc = min(max(y + dy - 1, 0), H - 1);          // a row outside the plane: fetched from a valid one, masked below
+        const int yc = min(max(y + (dy - 1) * DIL, 0), H - 1);   // a row outside the plane: fetched from a valid one, masked below
         const unsigned o = (unsigned)(yc * W + x) * 2u;
+        // left piece: the DIL columns ending at x - 1 (DIL <= 8) or the vector at x - 16; right piece: starting at x + 8 / x + 16
+        const unsigned lo = has_l ? o - (unsigned)(DIL == 1 ? 4 : 2 * DIL) : o;
+        const unsigned ro = has_r ? o + (unsigned)(DIL == 16 ? 32 : 16) : o;
 #pragma unroll
         for (int t = 0; t < NTC; ++t) {
           V[t][dy] = wgbf_ld(pc[t] + o);
-          Ld[t][dy] = wgbf_ld1(pc[t] + o - (has_l ? 4u : 0u));
-          Rd[t][dy] = wgbf_ld1(pc[t] + o + (has_r ? 16u : 12u));
+          if (NDW == 1) { Lv[t][dy].x = wgbf_ld1(pc[t] + lo); Rv[t][dy].x = wgbf_ld1(pc[t] + ro); }
+          else if (NDW == 2) {
+            const csn_u2 l2 = wgbf_ld2(pc[t] + lo), r2 = wgbf_ld2(pc[t] + ro);
+            Lv[t][dy].x = l2.x; Lv[t][dy].y = l2.y; Rv[t][dy].x = r2.x; Rv[t][dy].y = r2.y;
+          } else { Lv[t][dy] = wgbf_ld(pc[t] + lo); Rv[t][dy] = wgbf_ld(pc[t] + ro); }
         }
       }
       __builtin_amdgcn_sched_barrier(0);   // every load of the set is in flight before the first contraction
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
-        const unsigned mrow = (y + dy - 1 >= 0 && y + dy - 1 < H) ? 0xffffffffu : 0u;
+        const int yy = y + (dy - 1) * DIL;
+        const unsigned mrow = (yy >= 0 && yy < H) ? 0xffffffffu : 0u;
         const unsigned ml = has_l ? mrow : 0u, mr = has_r ? mrow : 0u;
 #pragma unroll
         for (int tc = 0; tc < NTC; ++tc) {
           csn_u4 c0 = V[tc][dy];
           c0.x &= mrow; c0.y &= mrow; c0.z &= mrow; c0.w &= mrow;
-          const unsigned l = Ld[tc][dy] & ml, r = Rd[tc][dy] & mr;
-          csn_u4 cm, cp;   // columns x - 1 .. x + 6 and x + 1 .. x + 8
-          cm.x = __builtin_amdgcn_alignbit(c0.x, l, 16); cm.y = __builtin_amdgcn_alignbit(c0.y, c0.x, 16);
-          cm.z = __builtin_amdgcn_alignbit(c0.z, c0.y, 16); cm.w = __builtin_amdgcn_alignbit(c0.w, c0.z, 16);
-          cp.x = __builtin_amdgcn_alignbit(c0.y, c0.x, 16); cp.y = __builtin_amdgcn_alignbit(c0.z, c0.y, 16);
-          cp.z = __builtin_amdgcn_alignbit(c0.w, c0.z, 16); cp.w = __builtin_amdgcn_alignbit(r, c0.w, 16);
+          csn_u4 cm, cp;   // columns x - DIL .. x - DIL + 7 and x + DIL .. x + DIL + 7
+          if (DIL == 1) {
+            const unsigned l = Lv[tc][dy].x & ml, r = Rv[tc][dy].x & mr;
+            cm.x = __builtin_amdgcn_alignbit(c0.x, l, 16); cm.y = __builtin_amdgcn_alignbit(c0.y, c0.x, 16);
+            cm.z = __builtin_amdgcn_alignbit(c0.z, c0.y, 16); cm.w = __builtin_amdgcn_alignbit(c0.w, c0.z, 16);
+            cp.x = __builtin_amdgcn_alignbit(c0.y, c0.x, 16); cp.y = __builtin_amdgcn_alignbit(c0.z, c0.y, 16);
+            cp.z = __builtin_amdgcn_alignbit(c0.w, c0.z, 16); cp.w = __builtin_amdgcn_alignbit(r, c0.w, 16);
+          } else if (DIL == 2) {   // one dword = two columns
+            cm.x = Lv[tc][dy].x & ml; cm.y = c0.x; cm.z = c0.y; cm.w = c0.z;
+            cp.x = c0.y; cp.y = c0.z; cp.z = c0.w; cp.w = Rv[tc][dy].x & mr;
+          } else if (DIL == 4) {
+            cm.x = Lv[tc][dy].x & ml; cm.y = Lv[tc][dy].y & ml; cm.z = c0.x; cm.w = c0.y;
+            cp.x = c0.z; cp.y = c0.w; cp.z = Rv[tc][dy].x & mr; cp.w = Rv[tc][dy].y & mr;
+          } else {                 // 8, 16: whole vectors
+            cm = Lv[tc][dy]; cm.x &= ml; cm.y &= ml; cm.z &= ml; cm.w &= ml;
+            cp = Rv[tc][dy]; cp.x &= mr; cp.y &= mr; cp.z &= mr; cp.w &= mr;
+          }
 #pragma unroll
           for (int tr = 0; tr < NTR; ++tr) {
             const wgb_bf8 av = __builtin_bit_cast(wgb_bf8, A[tr]);
@@ -584,10 +613,15 @@ bool wgbf3_config(const WgArgs& a, WgBf3Cfg* c) {
   const PwPass& ps = a.ps;
   if (ps.nsrc < 1 || ps.nsrc > 3 || a.nrs < 1 || a.nrs > 3) return false;
   int C = 0;
+  bool dilated = false;
   for (int s = 0; s < ps.nsrc; ++s) {
-    if (ps.src[s].mode != PW_TAPS || ps.src[s].dil != 1) return false;
+    const int d = ps.src[s].dil;
+    if (ps.src[s].mode != PW_TAPS || !(d == 1 || d == 2 || d == 4 || d == 8 || d == 16)) return false;
+    dilated = dilated || d != 1;
     C += ps.src[s].C;
   }
+  static const bool ms_off = std::getenv("CSN_WGRAD_BF3_MS") && std::getenv("CSN_WGRAD_BF3_MS")[0] == '0';
+  if (dilated && ms_off) return false;
   const int64_t HW = (int64_t)a.Hr * a.Wr;
   if ((a.Wr % 8) != 0 || HW % 32 != 0 || HW > (1 << 24) || ps.cin != 9 * C) return false;
   const int R = ps.nrows;
@@ -597,15 +631,17 @@ bool wgbf3_config(const WgArgs& a, WgBf3Cfg* c) {
     const int S = 1 << sl, TP = 16 >> sl;
     if (HW % (32 * S) != 0) continue;
     const int ntr = (R + TP - 1) / TP;
-    if (ntr > 4) continue;
-    const int maxch = TP * (ntr <= 2 ? 2 : 1);
-    const int chunks = (C + maxch - 1) / maxch;
+    if (ntr > 4 || (dilated && ntr > 3)) continue;                // (the dilated instantiations: one channel tile, <= 3 row tiles)
+    const int maxch = TP * ((ntr <= 2 && !dilated) ? 2 : 1);
+    int chunks = 0;
+    if (dilated) for (int q = 0; q < ps.nsrc; ++q) chunks += (ps.src[q].C + maxch - 1) / maxch;   // a launch per slice (one dilation)
+    else chunks = (C + maxch - 1) / maxch;
     if (chunks < best_chunks) { best = sl; best_chunks = chunks; }   // (ties: the larger S, i.e. the longer contiguous runs)
   }
   if (best < 0) return false;
   const int S = 1 << best, TP = 16 >> best;
   c->slog = best; c->ntr = (R + TP - 1) / TP;
-  c->maxch = TP * (c->ntr <= 2 ? 2 : 1);
+  c->maxch = TP * ((c->ntr <= 2 && !dilated) ? 2 : 1);
   c->ntc = ((C < c->maxch ? C : c->maxch) + TP - 1) / TP;
   const int64_t sets_img = HW / (32 * S), total = sets_img * a.B;
   int64_t L = total / (12 * 4 * WG_MAX_BLOCKS);
@@ -618,10 +654,19 @@ bool wgbf3_config(const WgArgs& a, WgBf3Cfg* c) {
   return true;
 }
 
-template <int NTR, int NTC>
+template <int NTR, int NTC, int DIL = 1>
 int wgbf3_launch_t(const WgBf3Args& q, void* stream) {
-  CSN_LAUNCH((wgrad_bf16_c3_kernel<NTR, NTC>), dim3(q.nblk), dim3(CSN_BLOCK), 4 * 1024 * sizeof(float), stream, q);
+  CSN_LAUNCH((wgrad_bf16_c3_kernel<NTR, NTC, DIL>), dim3(q.nblk), dim3(CSN_BLOCK), 4 * 1024 * sizeof(float), stream, q);
   return (int)hipGetLastError();
+}
+template <int DIL>
+int wgbf3_launch_dil(int ntr, const WgBf3Args& q, void* stream) {
+  switch (ntr) {
+    case 1: return wgbf3_launch_t<1, 1, DIL>(q, stream);
+    case 2: return wgbf3_launch_t<2, 1, DIL>(q, stream);
+    case 3: return wgbf3_launch_t<3, 1, DIL>(q, stream);
+    default: return -1;
+  }
 }
 }  // namespace
 
@@ -652,6 +697,31 @@ int csn_launch_wgrad_bf3(const WgArgs& a, void* stream) {
   q.slog = c.slog; q.L = c.L; q.runs = c.runs; q.nitems = c.nitems; q.nblk = c.nblk;
   q.rows16 = a.rows16; q.k16 = a.k16; q.partial = a.partial;
   const int TP = 16 >> c.slog;
+  bool dilated = false;
+  for (int s = 0; s < a.ps.nsrc; ++s) dilated = dilated || a.ps.src[s].dil != 1;
+  if (dilated) {   // MSBlock: a launch per slice (its dilation = the instantiation) and channel chunk
+    int cb = 0;
+    for (int s = 0; s < a.ps.nsrc; ++s) {
+      for (int c0 = 0; c0 < a.ps.src[s].C; c0 += c.maxch) {
+        q.c_first = cb + c0;
+        q.C = a.ps.src[s].C - c0 < c.maxch ? a.ps.src[s].C - c0 : c.maxch;
+        q.dil = a.ps.src[s].dil;
+        int st = -1;
+        switch (q.dil) {
+          case 1: st = wgbf3_launch_dil<1>(c.ntr, q, stream); break;
+          case 2: st = wgbf3_launch_dil<2>(c.ntr, q, stream); break;
+          case 4: st = wgbf3_launch_dil<4>(c.ntr, q, stream); break;
+          case 8: st = wgbf3_launch_dil<8>(c.ntr, q, stream); break;
+          case 16: st = wgbf3_launch_dil<16>(c.ntr, q, stream); break;
+          default: return -1;
+        }
+        if (st != 0) return st;
+      }
+      cb += a.ps.src[s].C;
+    }
+    return 0;
+  }
+  q.dil = 1;
   for (int c0 = 0; c0 < Ctot; c0 += c.maxch) {   // channel chunks: disjoint columns of the same partial slices
     q.c_first = c0;
     q.C = Ctot - c0 < c.maxch ? Ctot - c0 : c.maxch;

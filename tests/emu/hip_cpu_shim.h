@@ -34,6 +34,8 @@ struct float2 { float x, y; };
 struct alignas(16) float4 { float x, y, z, w; };
 struct uint2 { unsigned x, y; };
 static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 

@@ -18,7 +18,7 @@ static float bf2f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; m
 static unsigned rng = 12345u;
 static float rnd() { rng = rng * 1664525u + 1013904223u; return ((rng >> 8) & 0xffff) / 65536.0f - 0.5f; }
 
-struct Case { const char* name; int nrs; int rn[3]; int rctot[3]; int ncs; int cn[3]; int cctot[3]; int H, W, B; bool pool; bool check; bool taps = false; };
+struct Case { const char* name; int nrs; int rn[3]; int rctot[3]; int ncs; int cn[3]; int cctot[3]; int H, W, B; bool pool; bool check; bool taps = false; int dils[3] = {1, 1, 1}; };
 
 static int run(const Case& c) {
   const int HW = c.H * c.W;
@@ -47,7 +47,7 @@ static int run(const Case& c) {
     const int c0 = c.cctot[q] > c.cn[q] ? 1 : 0;
     a.ps.src[q].ptr = reinterpret_cast<const float*>(dc[q] + (int64_t)c0 * chw); a.ps.src[q].C = c.cn[q]; a.ps.src[q].Ctot = c.cctot[q];
     a.ps.src[q].mode = c.taps ? PW_TAPS : (c.pool ? PW_POOL2 : PW_OWN); a.ps.src[q].K = (c.taps ? 9 : 1) * c.cn[q];
-    a.ps.src[q].dil = 1;
+    a.ps.src[q].dil = c.dils[q];
     K += (c.taps ? 9 : 1) * c.cn[q];
   }
   a.ps.nsrc = c.ncs; a.ps.cin = K; a.ps.nrows = R;
@@ -91,9 +91,10 @@ static int run(const Case& c) {
       std::vector<const unsigned short*> cpl(Cc);
       for (int b = 0; b < c.B; ++b) {
         int k = 0;
+        std::vector<int> cdil(Cc);
         for (int q = 0; q < c.ncs; ++q) {
           const int c0 = c.cctot[q] > c.cn[q] ? 1 : 0;
-          for (int i = 0; i < c.cn[q]; ++i) cpl[k++] = &hc[q][((size_t)b * c.cctot[q] + c0 + i) * HW];
+          for (int i = 0; i < c.cn[q]; ++i) { cdil[k] = c.dils[q]; cpl[k++] = &hc[q][((size_t)b * c.cctot[q] + c0 + i) * HW]; }
         }
         for (int p = 0; p < HW; ++p) {
           const int y = p / c.W, x = p % c.W;
@@ -104,7 +105,7 @@ static int run(const Case& c) {
           }
           for (int ch = 0; ch < Cc; ++ch)
             for (int t = 0; t < 9; ++t) {
-              const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+              const int yy = y + (t / 3 - 1) * cdil[ch], xx = x + (t % 3 - 1) * cdil[ch];
               if (yy < 0 || yy >= c.H || xx < 0 || xx >= c.W) continue;
               const double v = bf2f(cpl[ch][yy * c.W + xx]);
               for (int i = 0; i < R; ++i) { ref[(size_t)i * K + 9 * ch + t] += dzv[i] * v; mag[(size_t)i * K + 9 * ch + t] += fabs(dzv[i] * v); }
@@ -171,6 +172,12 @@ int main() {
       {"taps 23x51 56^2 chunks", 1, {23, 0, 0}, {23, 0, 0}, 1, {51, 0, 0}, {51, 0, 0}, 56, 56, 2, false, true, true},
       {"taps 10x3 48x40 S4", 1, {10, 0, 0}, {10, 0, 0}, 1, {3, 0, 0}, {3, 0, 0}, 48, 40, 3, false, true, true},
       {"taps 40x5 16x8 (3,1)", 1, {40, 0, 0}, {40, 0, 0}, 1, {5, 0, 0}, {5, 0, 0}, 16, 8, 2, false, true, true},
+      {"ms 17x(2,1,2) dil 1,2,4 56x48", 1, {17, 0, 0}, {17, 0, 0}, 3, {2, 1, 2}, {8, 8, 8}, 56, 48, 2, false, true, true, {1, 2, 4}},
+      {"ms 17x(2,1) dil 8,16 56x48", 1, {17, 0, 0}, {17, 0, 0}, 2, {2, 1, 0}, {8, 8, 0}, 56, 48, 2, false, true, true, {8, 16, 1}},
+      {"ms 38x(6,6,7) dil 2,4,8 56^2", 1, {38, 0, 0}, {38, 0, 0}, 3, {6, 6, 7}, {24, 24, 24}, 56, 56, 2, false, true, true, {2, 4, 8}},
+      {"ms 38x5 dil 16 56^2", 1, {38, 0, 0}, {38, 0, 0}, 1, {5, 0, 0}, {24, 0, 0}, 56, 56, 2, false, true, true, {16, 1, 1}},
+      {"ms 38x(6,6,7) 56^2 B256", 1, {38, 0, 0}, {38, 0, 0}, 3, {6, 6, 7}, {24, 24, 24}, 56, 56, 256, false, false, true, {2, 4, 8}},
+      {"ms 17x(2,1,2) 112^2 B256", 1, {17, 0, 0}, {17, 0, 0}, 3, {2, 1, 2}, {8, 8, 8}, 112, 112, 256, false, false, true, {1, 2, 4}},
       {"taps 13x3 224^2 B256", 1, {13, 0, 0}, {13, 0, 0}, 1, {3, 0, 0}, {3, 0, 0}, 224, 224, 256, false, false, true},
       {"taps 28x18 112^2 B256", 1, {28, 0, 0}, {28, 0, 0}, 1, {18, 0, 0}, {18, 0, 0}, 112, 112, 256, false, false, true},
       {"taps 23x51 56^2 B256", 1, {23, 0, 0}, {23, 0, 0}, 1, {51, 0, 0}, {51, 0, 0}, 56, 56, 256, false, false, true},
