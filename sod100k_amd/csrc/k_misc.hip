@@ -221,7 +221,10 @@ __device__ __forceinline__ DwRow dw_load_row_bn(csn_buf rb, int y, int H, int x0
 
 // STATS: also accumulate sum / sum of squares of the values as STORED (train mode: the raw conv output z whose batch
 // statistics the BatchNorm that follows needs -- saves bn_stats_kernel's pass over z)
-template <bool VEC, typename AT = float, bool STATS = false>
+// IDENT: the epilogue is the identity (train mode: the raw sums are stored, BatchNorm runs on the batch statistics afterwards; the
+// backward kernel's dx) -- skipped instead of evaluated with scale 1 / shift 0 / slope 1 (four instructions per value of kernels
+// whose instruction and memory times add up, round 4)
+template <bool VEC, typename AT = float, bool STATS = false, bool IDENT = false>
 __device__ __forceinline__ void dw_emit(AT* __restrict__ op, int y, int yend, int x0, int W,
                                         const float (&w)[9], float sc, float sh, float al, const DwRow& top,
                                         const DwRow& mid, const DwRow& bot, double* st = nullptr, float* oret = nullptr) {
@@ -238,7 +241,7 @@ __device__ __forceinline__ void dw_emit(AT* __restrict__ op, int y, int yend, in
     acc = fmaf(w[6], bot.v[j], acc);
     acc = fmaf(w[7], bot.v[j + 1], acc);
     acc = fmaf(w[8], bot.v[j + 2], acc);
-    o[j] = csn_epi(acc, sc, sh, al);
+    o[j] = IDENT ? acc : csn_epi(acc, sc, sh, al);
   }
   AT* q = op + (int64_t)y * W + x0;
   if (STATS) {
@@ -366,10 +369,10 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
       } else {
         n0 = load_in(y + 1); n1 = load_in(y + 2); n2 = load_in(y + 3); n3 = load_in(y + 4);
       }
-      dw_emit<VEC, AT, STATS>(op, y, yend, x0, W, w, sc, sh, al, r0, r1, n0, st);
-      dw_emit<VEC, AT, STATS>(op, y + 1, yend, x0, W, w, sc, sh, al, r1, n0, n1, st);
-      dw_emit<VEC, AT, STATS>(op, y + 2, yend, x0, W, w, sc, sh, al, n0, n1, n2, st);
-      dw_emit<VEC, AT, STATS>(op, y + 3, yend, x0, W, w, sc, sh, al, n1, n2, n3, st);
+      dw_emit<VEC, AT, STATS, STATS>(op, y, yend, x0, W, w, sc, sh, al, r0, r1, n0, st);
+      dw_emit<VEC, AT, STATS, STATS>(op, y + 1, yend, x0, W, w, sc, sh, al, r1, n0, n1, st);
+      dw_emit<VEC, AT, STATS, STATS>(op, y + 2, yend, x0, W, w, sc, sh, al, n0, n1, n2, st);
+      dw_emit<VEC, AT, STATS, STATS>(op, y + 3, yend, x0, W, w, sc, sh, al, n1, n2, n3, st);
       r0 = n2;
       r1 = n3;
     }
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
         u2 = load_x(y + 1, zc2);
       }
       float dxv[4];
-      dw_emit<VEC, AT>(op, y, yend, x0, W, w, 1.f, 0.f, 1.f, g0, g1, g2, nullptr, XBN ? dxv : nullptr);
+      dw_emit<VEC, AT, false, true>(op, y, yend, x0, W, w, 1.f, 0.f, 1.f, g0, g1, g2, nullptr, XBN ? dxv : nullptr);
       if (XBN) {   // the producer's BatchNorm-backward sums (bn_bwd_reduce_kernel's arithmetic): dy = the dx just stored
         // fp32 over the row's four values, fp64 across the rows of the lane (round 4: the sums -- the PReLU slope's gradient above
         // all -- cancel heavily on the shipped checkpoint; 64 fp32 terms per lane put one tensor at 2.1e-4 of the unit-local bound

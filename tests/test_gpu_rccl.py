@@ -7,6 +7,14 @@ import sys
 
 import pytest
 
+
+def _free_port():
+    """An ephemeral port of 127.0.0.1 (a fixed one collides on a shared box)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = r"""
@@ -50,7 +58,7 @@ def test_gpu_rccl_one_rank_allreduce(tmp_path):
     script.write_text(WORKER)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-           "--master-port", "29643", str(script), ROOT]
+           "--master-port", str(_free_port()), str(script), ROOT]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "RCCL_OK 1" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
@@ -60,7 +68,7 @@ def test_gpu_bench_under_torchrun_one_rank():
     """``bench.py --gpus 1`` exactly as the driver launches N > 1: a one-rank RCCL group, the train step's all-reduce inside."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_PROTO="LL")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-           "--master-port", "29644", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--train-steps", "2",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--train-steps", "2",
            "--train-batch", "16", "--csf-batch", "0", "--no-cpu-baseline", "--event-steps", "0", "--no-train-bf16"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
