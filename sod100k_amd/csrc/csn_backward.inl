@@ -673,7 +673,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
         fb.pool = nullptr; fb.skip_out = 0; fb.stats = w.partial;
         fb.C = d.cout[k]; fb.H = H; fb.W = W;
         const int fcols = (W + 3) / 4;
-        fb.LX = fcols < 64 ? fcols : 64;
+        fb.LX = dw_lanes_x(fcols);
         fb.NY = CSN_BLOCK / fb.LX;
         fb.tiles_x = (fcols + fb.LX - 1) / fb.LX;
         fb.R = choose_dw_rows(H, fb.NY);
@@ -701,7 +701,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
       br.pool = nullptr; br.skip_out = 0; br.stats = nullptr; br.xin = nullptr;
       br.C = d.cout[k]; br.H = H; br.W = W;
       const int cols = (br.W + 3) / 4;
-      br.LX = cols < 64 ? cols : 64;
+      br.LX = dw_lanes_x(cols);
       br.NY = CSN_BLOCK / br.LX;
       br.tiles_x = (cols + br.LX - 1) / br.LX;
       br.R = choose_dw_rows(br.H, br.NY);

@@ -189,6 +189,7 @@ struct PwArgs {
 // load registers (see k_pw4.hip)
 // ---------------------------------------------------------------------------------------------
 #define PW4_MAX_GROUPS 4
+#define PW4_FLAT_TWL 7     // Pw4Args / C3qArgs::twl >= 7: flat tiles of 64 consecutive (low) pixels / quads, tiles_y = 1
 #define PW4_PITCH(NT4) (((NT4) % 16) == 0 ? (NT4) + 4 : (NT4))   // floats per (channel, row-in-tile) of the weight image
 struct Pw4Group { int32_t r0h, nth, r0l, ntl; };   // M group: first high / low output channel (multiples of 4) and row tiles (of 4 channels)
 struct Pw4Args {

@@ -175,6 +175,7 @@ struct csn_plan {
   bool pw4 = true;        // CSN_OPT_PW4: two-branch 1x1 units on pw4_kernel (k_pw4.hip)
   int pw4_grid = 2048;    // its block cap (CSN_PW4_GRID, experiments)
   int pw4_twl = 6;        // log2 of its widest tile in low pixels: whole rows of up to 64 (CSN_PW4_TWL; 4 = 16 x 4 tiles: 1 % slower)
+  bool pw4_flat = true;       // CSN_PW4_FLAT=0: row-segment tiles everywhere (round 3; A/B)
   bool pw4_no_q = false;      // CSN_PW4_NOQ: CSFHead.fuse's lowest output branch stays on goct_pw_kernel (experiments)
   bool bn_bwd_fuse = true;    // depthwise backward forms dz on load, the BatchNorm backward's apply pass is skipped (CSN_BN_BWD_FUSE=0: off)
   bool bn_fwd_fuse = true;    // activations consumed only by a depthwise unit are formed on load (virt_cons; CSN_BN_FWD_FUSE=0: off)
@@ -833,6 +834,23 @@ struct Ctx {
   }
 };
 
+// Lanes per row of the depthwise kernels' blocks (a lane owns 4 columns; the block's 256 lanes are LX x NY, NY = 256 / LX).  Round 3
+// took LX = min(cols, 64): at 224 columns that is 56 lanes x 4 rows = 224 lanes, half a wave of every block idle, and at widths
+// past 256 a second, mostly empty tile.  Now the LX in [14, 64] with the largest (covered columns) x (lanes used) product: 28 x 9
+// (252 lanes, two tiles per row) at 224, 40 x 6 at 320.  CSN_DW_LX=0: the old rule (A/B).
+int dw_lanes_x(int cols) {
+  static const bool legacy = std::getenv("CSN_DW_LX") && std::getenv("CSN_DW_LX")[0] == '0';
+  if (legacy || cols <= 14) return cols < 64 ? cols : 64;
+  int best = 14;
+  double best_s = -1;
+  for (int LX = 14; LX <= 64 && LX <= cols; ++LX) {   // (no narrower than 14 lanes: row segments of 224 B in fp32, 112 B in bf16)
+    const int tx = (cols + LX - 1) / LX;
+    const double s = (double)cols / ((double)tx * LX) * (double)((CSN_BLOCK / LX) * LX) / CSN_BLOCK;
+    if (s >= best_s - 1e-12) { best_s = s > best_s ? s : best_s; best = LX; }   // ties: the widest
+  }
+  return best;
+}
+
 // rows per lane of the fused depthwise pair: the intermediate tile (NY*R + 2 rows) must stay small in LDS
 int choose_dw2_rows(int H, int NY, int LX, bool even = false, bool quad = false) {
   const int step = quad ? 4 : (even ? 2 : 1);   // even: the pair also writes 2x2 averages; quad: ... and their 2x2 maxima
@@ -869,7 +887,7 @@ int dw_stats_slabs(const csn_plan& P, int lvl) {
   if (std::getenv("CSN_DW_STATS") && std::getenv("CSN_DW_STATS")[0] == '0') return 0;
   const int H = P.H >> lvl, W = P.W >> lvl;
   const int cols = (W + 3) / 4;
-  const int LX = cols < 64 ? cols : 64, NY = CSN_BLOCK / LX;
+  const int LX = dw_lanes_x(cols), NY = CSN_BLOCK / LX;
   const int tiles_x = (cols + LX - 1) / LX;
   const int R = choose_dw_rows(H, NY);
   const int tiles_y = (H + NY * R - 1) / (NY * R);
@@ -1038,6 +1056,9 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
       q.twl = twl;
       q.tiles_x = (Wq + (1 << twl) - 1) >> twl;
       q.tiles_y = (Hq + (64 >> twl) - 1) / (64 >> twl);
+      if (P.pw4_flat && q.tiles_x * q.tiles_y > (Hq * Wq + 63) / 64) {
+        q.twl = PW4_FLAT_TWL; q.tiles_x = (Hq * Wq + 63) / 64; q.tiles_y = 1;
+      }
       q.ngroups = L.c3q_ng; q.gimg_floats = L.c3q_gimg; q.nt = L.c3q_nt; q.max_grid = P.pw4_grid;
       q.a16 = c.a16 ? 1 : 0; q.pad_ = 0;
       for (int g = 0; g < PW4_MAX_GROUPS; ++g) { q.grp_r0[g] = L.c3q_r0[g]; q.grp_nt[g] = L.c3q_gnt[g]; }
@@ -1112,7 +1133,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
         br.pool = nullptr; br.skip_out = 0; br.stats = nullptr; br.xin = nullptr;
         br.C = d.cout[k]; br.H = P.H >> act.lvl; br.W = P.W >> act.lvl;
         const int cols = (br.W + 3) / 4;
-        br.LX = cols < 64 ? cols : 64;
+        br.LX = fused ? (cols < 64 ? cols : 64) : dw_lanes_x(cols);   // (the fused pair keeps whole rows of its intermediate in LDS)
         br.NY = CSN_BLOCK / br.LX;
         br.tiles_x = (cols + br.LX - 1) / br.LX;
         if (fused) {
@@ -1227,6 +1248,9 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
           a.twl = twl;
           a.tiles_x = (a.Wl + (1 << twl) - 1) >> twl;
           a.tiles_y = (a.Hl + (64 >> twl) - 1) / (64 >> twl);
+          if (P.pw4_flat && a.tiles_x * a.tiles_y > (a.Hl * a.Wl + 63) / 64) {   // rows that do not fill their tiles: flat tiles
+            a.twl = PW4_FLAT_TWL; a.tiles_x = (a.Hl * a.Wl + 63) / 64; a.tiles_y = 1;
+          }
           a.ngroups = L.ng; a.gimg_floats = L.gimg; a.nth = L.nth; a.ntl = L.ntl;
           a.max_grid = P.pw4_grid; a.a16 = c.a16 ? 1 : 0;
           for (int g = 0; g < PW4_MAX_GROUPS; ++g) a.grp[g] = L.grp[g];
@@ -1492,6 +1516,7 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   if (const char* v = std::getenv("CSN_PW4_GRID")) { if (std::atoi(v) >= 8) P->pw4_grid = std::atoi(v); }
   if (std::getenv("CSN_PW4_NOSPLIT")) P->pw4_nosplit = true;
   if (std::getenv("CSN_PW4_NOQ")) P->pw4_no_q = true;
+  if (const char* e = std::getenv("CSN_PW4_FLAT")) P->pw4_flat = std::atoi(e) != 0;
   if (std::getenv("CSN_NO_MP_FUSE")) P->no_mp_fuse = true;
   if (const char* v = std::getenv("CSN_C3Q_TWL")) { if (std::atoi(v) >= 2 && std::atoi(v) <= 6) P->c3q_twl = std::atoi(v); }
   if (const char* v = std::getenv("CSN_BN_BWD_FUSE")) P->bn_bwd_fuse = v[0] != '0';

@@ -95,8 +95,17 @@ __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q_kernel(C3qArgs a_byval
   for (int item = xcd * chunk + (int)(blockIdx.x >> 3) * 4 + wave; item < iend; item += nslot) {
     const int tile = item / ng, g = item - tile * ng;
     const int b = tile / tiles_xy, txy = tile - b * tiles_xy;
-    const int ty = txy / a->tiles_x, tx = txy - ty * a->tiles_x;
-    const int yq = (ty << (6 - twl)) + ly, xq = (tx << twl) + lx;
+    int yq, xq;
+    if (twl >= PW4_FLAT_TWL) {   // flat tiles: 64 consecutive quads of the plane (see k_pw4.hip)
+      const int p = txy * 64 + lane;
+      int q = (int)((float)p * (1.0f / (float)Wq));
+      q -= (q * Wq > p) ? 1 : 0;
+      q += ((q + 1) * Wq <= p) ? 1 : 0;
+      yq = q; xq = p - q * Wq;
+    } else {
+      const int ty = txy / a->tiles_x, tx = txy - ty * a->tiles_x;
+      yq = (ty << (6 - twl)) + ly; xq = (tx << twl) + lx;
+    }
     const bool valid = yq < Hq && xq < Wq;
     const int y = min(yq, Hq - 1), x = min(xq, Wq - 1);
     const float* wg = wl_lane + g * a->gimg_floats;

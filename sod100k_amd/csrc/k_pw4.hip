@@ -194,8 +194,20 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
   for (int item = xcd * chunk + (int)(blockIdx.x >> 3) * 4 + wave; item < iend; item += nslot) {
     const int tile = item / ng, g_first = item - tile * ng;
     const int b = tile / tiles_xy, txy = tile - b * tiles_xy;
-    const int ty = txy / a->tiles_x, tx = txy - ty * a->tiles_x;
-    const int y = (ty << (6 - twl)) + ly, x = (tx << twl) + lx;
+    int y, x;
+    if (twl >= PW4_FLAT_TWL) {
+      // flat tiles (round 4): the wave's 64 low pixels are consecutive in the plane's row-major order -- no idle lanes where the
+      // row width is not a multiple of the tile width (112, 56, 28, 14: one lane in eight was idle), 12.5 % fewer items; a wave
+      // then spans a row boundary, which only splits its row segments (every address is per lane anyway)
+      const int p = txy * 64 + lane;
+      int q = (int)((float)p * (1.0f / (float)Wl));
+      q -= (q * Wl > p) ? 1 : 0;
+      q += ((q + 1) * Wl <= p) ? 1 : 0;
+      y = q; x = p - q * Wl;   // p >= Hl * Wl: y >= Hl, invalid
+    } else {
+      const int ty = txy / a->tiles_x, tx = txy - ty * a->tiles_x;
+      y = (ty << (6 - twl)) + ly; x = (tx << twl) + lx;
+    }
     const bool valid = y < Hl && x < Wl;
     const int yc = min(y, Hl - 1), xc = min(x, Wl - 1);
     unsigned ol[9];

@@ -695,8 +695,9 @@ def _check_train_units_local(lib, device, manifest, B, size, act_dtype, state, f
     m._lib = lib if device.type == "cpu" else None
     m.set_train_act_dtype(act_dtype)
     m.train(); m.set_batchsize(B); m.clear_flops(); m.flops_hook(1.0)
-    x = torch.from_numpy(I.randn_batch(seed, B, size, size))
-    t = torch.from_numpy(I.binary_target(seed + 1, B, size, size))
+    hw = size if isinstance(size, tuple) else (size, size)   # (height, width)
+    x = torch.from_numpy(I.randn_batch(seed, B, hw[0], hw[1]))
+    t = torch.from_numpy(I.binary_target(seed + 1, B, hw[0], hw[1]))
     xd, td = x.to(device), t.to(device)
     y, pen = m._train_forward_raw(xd)
     eng = m.engine_for(xd, train=True)

@@ -89,7 +89,9 @@ import pytest
 
 
 @pytest.mark.parametrize("act_dtype,B,size,state", [("fp32", 2, 64, "shipped"), ("fp32", 3, 48, "well"), ("bf16", 2, 64, "shipped"),
-                                                    ("bf16", 3, 48, "well"), ("bf16", 2, 16, "shipped")])
+                                                    ("bf16", 3, 48, "well"), ("bf16", 2, 16, "shipped"),
+                                                    # 224 wide: the depthwise kernels' 28-lane tiles (two per row), flat pw4 / c3q tiles
+                                                    ("fp32", 1, (32, 224), "well"), ("bf16", 1, (32, 224), "shipped")])
 def test_emu_train_units_local(emu_lib, x2_manifest, act_dtype, B, size, state):
     """Every unit's train-mode forward and backward (dz, dx per consumer slot, every parameter gradient) against the oracle
     applied to the tensors the kernels themselves produced around that unit -- no error amplification through depth."""
@@ -251,12 +253,14 @@ def test_emu_backward_with_weight_gradient_side_lane(emu_lib, x2_manifest, monke
 
 
 def test_emu_results_do_not_depend_on_the_tile_geometry(emu_lib, x2_manifest, monkeypatch):
-    """pw4_kernel / c3q_kernel tiles as 16 x 4 blocks (CSN_PW4_TWL = CSN_C3Q_TWL = 4) or as whole rows (6, the default): the same
-    per-pixel arithmetic in the same order -- eval logits, train-mode logits and all gradients are equal bit for bit."""
+    """pw4_kernel / c3q_kernel tiles as 16 x 4 blocks (CSN_PW4_TWL = CSN_C3Q_TWL = 4), as row segments (6 with CSN_PW4_FLAT=0, round 3)
+    or as 64 consecutive pixels of the plane (flat tiles, the default where rows do not fill their tiles): the same per-pixel
+    arithmetic in the same order -- eval logits, train-mode logits and all gradients are equal bit for bit."""
     out = {}
-    for tw in ("4", "6"):
+    for tw, flat in (("4", "0"), ("6", "0"), ("6", "1")):
         monkeypatch.setenv("CSN_PW4_TWL", tw)
         monkeypatch.setenv("CSN_C3Q_TWL", tw)
+        monkeypatch.setenv("CSN_PW4_FLAT", flat)
         m, sd = P.make_model(emu_lib, x2_manifest, CPU)
         x = torch.from_numpy(I.randn_batch(5, 2, 96, 160))
         t = torch.from_numpy(I.binary_target(6, 2, 96, 160))
@@ -264,6 +268,7 @@ def test_emu_results_do_not_depend_on_the_tile_geometry(emu_lib, x2_manifest, mo
         m.train(); m.set_batchsize(2); m.clear_flops(); m.flops_hook(1.0)
         y, pen = m._train_forward_raw(x)
         loss, dy = P.bce_and_grad(emu_lib, y, t)
-        out[tw] = (ye, y.clone(), m._train_backward_raw(x, dy, 1.5).clone())
-    for a, b in zip(out["4"], out["6"]):
-        assert torch.equal(a, b)
+        out[tw + flat] = (ye, y.clone(), m._train_backward_raw(x, dy, 1.5).clone())
+    for k in ("60", "61"):
+        for a, b in zip(out["40"], out[k]):
+            assert torch.equal(a, b), k

@@ -3,7 +3,7 @@
 # -> gpurun_out/$1/{cal,train}_{fetch,write}/ ; tools/pmc_train.py turns them into profiles/<tag>_pmc_train.json
 out=$PWD/gpurun_out/$1; mkdir -p $out
 R=$PWD
-CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --csf-batch 0 --no-latency-b1 --event-steps 0 --profile-iters 1 --train-steps 1"
+CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --csf-batch 0 --no-latency-b1 --event-steps 0 --profile-iters 1 --train-steps 1 --train-net x2"
 cd /tmp && export TMPDIR=/tmp
 ( timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/cal_fetch -o c -- $R/tools/probes/fetch_cal ) > $out/cal_fetch.log 2>&1
 ( timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/cal_write -o c -- $R/tools/probes/fetch_cal ) > $out/cal_write.log 2>&1
