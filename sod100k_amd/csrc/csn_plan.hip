@@ -834,16 +834,17 @@ struct Ctx {
   }
 };
 
-// Lanes per row of the depthwise kernels' blocks (a lane owns 4 columns; the block's 256 lanes are LX x NY, NY = 256 / LX).  Round 3
-// took LX = min(cols, 64): at 224 columns that is 56 lanes x 4 rows = 224 lanes, half a wave of every block idle, and at widths
-// past 256 a second, mostly empty tile.  Now the LX in [14, 64] with the largest (covered columns) x (lanes used) product: 28 x 9
-// (252 lanes, two tiles per row) at 224, 40 x 6 at 320.  CSN_DW_LX=0: the old rule (A/B).
+// Lanes per row of the depthwise kernels' blocks (a lane owns 4 columns; the block's 256 lanes are LX x NY, NY = 256 / LX): whole rows
+// up to 64 lanes (256 columns).  Wider rows: the LX in [14, 64] with the largest (covered columns) x (lanes used) product instead
+// of 64 and a mostly empty last tile (40 x 6 at 320 columns).  Measured at 224 columns (round 4, bf16 step): 28 x 9 lanes in two
+// tiles per row (252 of 256 lanes busy instead of 224) is 0.3-0.4 ms SLOWER than 56 x 4 -- the half-empty fourth wave costs less
+// than the shorter row segments and the extra tile row; CSN_DW_LX=1 applies the search at every width (A/B).
 int dw_lanes_x(int cols) {
-  static const bool legacy = std::getenv("CSN_DW_LX") && std::getenv("CSN_DW_LX")[0] == '0';
-  if (legacy || cols <= 14) return cols < 64 ? cols : 64;
+  static const bool everywhere = std::getenv("CSN_DW_LX") && std::getenv("CSN_DW_LX")[0] == '1';
+  if (cols <= 14 || (cols <= 64 && !everywhere)) return cols;
   int best = 14;
   double best_s = -1;
-  for (int LX = 14; LX <= 64 && LX <= cols; ++LX) {   // (no narrower than 14 lanes: row segments of 224 B in fp32, 112 B in bf16)
+  for (int LX = 14; LX <= 64 && LX <= cols; ++LX) {
     const int tx = (cols + LX - 1) / LX;
     const double s = (double)cols / ((double)tx * LX) * (double)((CSN_BLOCK / LX) * LX) / CSN_BLOCK;
     if (s >= best_s - 1e-12) { best_s = s > best_s ? s : best_s; best = LX; }   // ties: the widest

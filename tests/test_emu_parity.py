@@ -90,8 +90,8 @@ import pytest
 
 @pytest.mark.parametrize("act_dtype,B,size,state", [("fp32", 2, 64, "shipped"), ("fp32", 3, 48, "well"), ("bf16", 2, 64, "shipped"),
                                                     ("bf16", 3, 48, "well"), ("bf16", 2, 16, "shipped"),
-                                                    # 224 wide: the depthwise kernels' 28-lane tiles (two per row), flat pw4 / c3q tiles
-                                                    ("fp32", 1, (32, 224), "well"), ("bf16", 1, (32, 224), "shipped")])
+                                                    # 224 / 320 wide: flat pw4 / c3q tiles, two depthwise tiles per row at 320
+                                                    ("fp32", 1, (32, 224), "well"), ("bf16", 1, (32, 320), "shipped")])
 def test_emu_train_units_local(emu_lib, x2_manifest, act_dtype, B, size, state):
     """Every unit's train-mode forward and backward (dz, dx per consumer slot, every parameter gradient) against the oracle
     applied to the tensors the kernels themselves produced around that unit -- no error amplification through depth."""

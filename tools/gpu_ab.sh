@@ -1,19 +1,19 @@
 #!/bin/bash
-# A/B sweep of the eval forward on the GPU box: one bench.py line per variant into gpurun_out/$1/<tag>.json
-# usage: tools/gpu_ab.sh <outdir-tag> "<TAG ENV=VAL ...>" ...
-out=gpurun_out/$1; shift
-mkdir -p $out
+# A/B bench runs on one lease: tools/gpu_ab.sh <outdir> name[:variant-lib][:ENV=V,...] ...   (variant libs: tools/build_variant.sh)
+O=$PWD/gpurun_out/$1; mkdir -p $O; shift
+B="--no-cpu-baseline --csf-batch 0 --no-latency-b1 --train-net x2"
 for spec in "$@"; do
-  tag=${spec%% *}; envs=${spec#* }; [ "$envs" == "$spec" ] && envs=""
-  env $envs python bench.py --steps 30 --warmup 5 --train-steps 0 --csf-batch 0 --no-cpu-baseline --event-steps 30 \
-      > $out/$tag.json 2> $out/$tag.err || echo "FAILED $tag" >> $out/failed.txt
-  python - "$out/$tag.json" "$tag" <<'PY'
-import json,sys
+  IFS=: read -r name lib envs <<< "$spec"
+  E=(X=1)
+  [ -n "$lib" ] && E+=(SOD100K_HIP_LIB=$PWD/gpurun_variants/lib_$lib.so)
+  [ -n "$envs" ] && E+=(${envs//,/ })
+  ( env "${E[@]}" timeout 400 python bench.py $B ) > $O/bench_$name.json 2> $O/bench_$name.err
+  python - $O/bench_$name.json $name <<'PY'
+import json, sys
 try:
-    d=json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1])
-    pk=d['roofline']['per_kernel']
-    print(f"{sys.argv[2]:28s} {d['value']:9.1f} img/s  {d['ms_per_step']:.3f} ms  " + "  ".join(f"{k.split('_kernel')[0]}={v['ms']:.3f}" for k,v in pk.items()), flush=True)
+    j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[2], "eval %.0f img/s %.4f ms | fp32 %.2f ms | bf16 %.2f ms" % (j["value"], j["ms_per_step"], j["train_step"]["ms_per_step"], j["train_step_bf16"]["ms_per_step"]))
 except Exception as e:
-    print(sys.argv[2], "no result:", e)
+    print(sys.argv[2], "FAILED", e)
 PY
 done
