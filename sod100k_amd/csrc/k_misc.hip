@@ -537,7 +537,8 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
     // (rotating three register sets through an unrolled-by-three loop instead of copying rows: 17 % fewer VALU instructions per row
     // (220 instead of 264), but 182 instead of 102 VGPRs = two waves per SIMD instead of four: 42.1 instead of 40.2 ms per bf16 step,
     // and 42.8 ms bounded to 168 VGPRs; bounding the loop as it is to 96 / 80 VGPRs for five / six waves spills: 41.8 / 63 ms --
-    // round 4, gpurun_out/r4k, r4l.  The kernel is bound by the latency its four waves can cover, not by instruction issue alone.)
+    // round 4, gpurun_out/r4k, r4l.  Two rows of loads in flight instead of one (126 VGPRs, still four waves): 40.1-40.8 instead of
+    // 39.3-39.4 ms, r4m.  Neither fewer instructions at lower occupancy nor more loads in flight at the same occupancy helps.)
     // Round 4: on the vector path the loads of row y + 2 are issued BEFORE row y + 1 is converted and used, i.e. they are in flight
     // during a whole loop trip (they used to be waited for right where they were issued: every trip paid a full memory round trip
     // with only the other waves of the SIMD to cover it).  Rows past the tile / the plane are fetched like any other (zeros past the
