@@ -384,13 +384,13 @@ def main():
                 unpruned = {"what": "un-pruned training network (expand 2.0, basic_split [0.5, 0.5], csnet-L-x2_train.yml:9-18), random init: "
                                     "train-mode forward + BCE + backward + Adam", "batch_per_gpu": UB,
                             "parameters": int(sum(p.numel() for p in um.parameters()))}
-                for dt in ("fp32", "bf16"):
-                    utr = FusedTrainer(um, lr=1e-4, weight_decay=5e-3, flops_weight=3.0, batchsize=UB, act_dtype=dt)
+                for adt in ("fp32", "bf16"):
+                    utr = FusedTrainer(um, lr=1e-4, weight_decay=5e-3, flops_weight=3.0, batchsize=UB, act_dtype=adt)
                     for _ in range(3):
                         utr.step(ux, ut, world_size=world)
                     udt = D.timed_region(lambda: utr.step(ux, ut, world_size=world), max(3, args.train_steps // 2), sync=sync, device=dev)
                     n_ = max(3, args.train_steps // 2)
-                    unpruned[dt] = {"ms_per_step": round(udt / n_ * 1e3, 3), "images_per_sec": round(world * UB * n_ / udt, 1),
+                    unpruned[adt] = {"ms_per_step": round(udt / n_ * 1e3, 3), "images_per_sec": round(world * UB * n_ / udt, 1),
                                     "loss": (round(float(utr.loss), 6) if np.isfinite(float(utr.loss)) else None)}
                     del utr
                     um._engines = {}

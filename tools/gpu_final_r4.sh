@@ -6,7 +6,8 @@
 O=$PWD/gpurun_out/r4; mkdir -p $O; R=$PWD
 bash tools/gpu_pmc_hbm.sh r4z r4 > /dev/null 2>&1; tail -3 gpurun_out/r4z/pmc_hbm.txt
 bash tools/gpu_pmc_train.sh r4z r4 > /dev/null 2>&1; grep "^##" gpurun_out/r4z/pmc_train.txt
-( timeout 1500 python -m pytest tests -m gpu -q --durations=12 2>&1 | tail -40 ) > $O/pytest_gpu.log; tail -6 $O/pytest_gpu.log
+# (the whole GPU suite ran on its own lease right before: gpurun_out/r4/pytest_gpu.log; here only the torchrun / RCCL tests again)
+( timeout 600 python -m pytest tests/test_gpu_rccl.py -m gpu -q 2>&1 | tail -8 ) > $O/pytest_gpu_rccl.log; tail -3 $O/pytest_gpu_rccl.log
 ( timeout 900 python bench.py ) > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.json; echo
 ( timeout 300 python tools/unit_table.py --json $O/unit_table.json ) > $O/unit_table.txt 2>&1; tail -3 $O/unit_table.txt
 cd /tmp && export TMPDIR=/tmp
