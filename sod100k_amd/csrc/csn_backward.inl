@@ -56,6 +56,8 @@ struct UnitBwd {
   int64_t tmp_off = -1;
   int64_t dwf_w[3] = {-1, -1, -1};           // depthwise: tap-flipped x100 weights (packed)
   int64_t scratch = 0;                       // bytes of unit scratch used
+  int64_t msdx_w[5] = {-1, -1, -1, -1, -1};  // MSBlock: CSN_PREP_MSDX weight images of ms_dx_kernel, msdx_ng > 0
+  int msdx_ng = 0;
   int adj_fused[3] = {-1, -1, -1};           // output branch j: index of the f = 2 AdjPlan its BatchNorm-backward apply pass also
                                              // produces (bn_bwd_apply_adj2_kernel; dz then goes to the branch's activation buffer)
 };
@@ -314,6 +316,18 @@ int plan_ms_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
     ub.wg.push_back(wg);
   }
   if (!ub.need_dx[0]) return CSN_OK;
+  // backward data: ms_dx_kernel (one launch, every dz tap loaded once per pixel); CSN_MS_DX=0: the generic tap kernel below
+  static const bool msdx = !(std::getenv("CSN_MS_DX") && std::getenv("CSN_MS_DX")[0] == '0');
+  if (msdx && cin <= 40) {
+    ub.msdx_ng = (cin + 7) / 8;
+    for (int k = 0; k < CSN_NDIL; ++k) {
+      if (d.dil_ch[k] == 0) continue;
+      const int ncop = (d.dil_ch[k] + 1) & ~1;
+      ub.msdx_w[k] = bl.alloc_packed((int64_t)ncop * 9 * ub.msdx_ng * 8);
+      bl.job(CSN_PREP_MSDX, d.dil_ch[k], ub.msdx_w[k], d.w_off[k], -1, -1, -1, 100.0f, cin, 0, ub.msdx_ng * 8, 0);
+    }
+    return CSN_OK;
+  }
   int k = 0;
   bool first = true;
   while (k < CSN_NDIL) {
@@ -740,6 +754,18 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
       HIP_TRY(hipMemsetAsync(bd.dx[i], 0, (size_t)S * d.cin[i] * (P.H >> lvl) * (P.W >> lvl) * (c.a16 ? 2 : 4),
                              (hipStream_t)c.stream));
     }
+  if (ub.msdx_ng > 0) {
+    MsDxArgs ma;
+    ma.dz = bd.dz[0]; ma.dx = bd.dx[0];
+    int base = 0;
+    for (int k = 0; k < CSN_NDIL; ++k) {
+      ma.dch[k] = d.dil_ch[k]; ma.cobase[k] = base; base += d.dil_ch[k];
+      ma.w[k] = d.dil_ch[k] ? c.pk(ub.msdx_w[k]) : nullptr;
+    }
+    ma.cin = d.cin[0]; ma.cout = d.cout[0]; ma.H = P.H >> u.base_lvl; ma.W = P.W >> u.base_lvl; ma.B = S;
+    ma.ng = ub.msdx_ng; ma.a16 = c.a16 ? 1 : 0; ma.pad = 0;
+    LAUNCH_TRY(csn_launch_ms_dx(ma, c.stream));
+  }
   for (const DataLaunch& dl : ub.data) {
     const int st = launch_pw(c, dl.L, bd);
     if (st != CSN_OK) return st;

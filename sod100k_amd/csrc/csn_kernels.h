@@ -41,6 +41,9 @@ enum CsnPrepKind {
   // p1 = gathered channels (= its output channels co), p0 = source row pitch (cin_tot * 9), p2 = P, p3 = t0 | (k0 << 8):
   //   dst[((k0 + 9*c + t)*4 + (r & 3))*p2 + t0 + (r >> 2)] = p0f * src0[c*p0 + r*9 + (8 - t)]
   CSN_PREP_C3Q_T = 14,
+  // MSBlock backward data (ms_dx_kernel): one dilation's [co][ci][3][3] block, tap-flipped, the ci of one (co, tap) contiguous:
+  // n = co count, p0 = cin, p2 = padded ci count:   dst[(co*9 + t)*p2 + ci] = p0f * src0[(co*p0 + ci)*9 + (8 - t)]
+  CSN_PREP_MSDX = 15,
 };
 struct CsnPrepJob {
   int32_t kind, n, p0, p1, p2, p3;
@@ -284,6 +287,18 @@ struct MsArgs {
   int32_t a16, pad;    // bfloat16 activations (per-pixel kernel only)
 };
 
+// MSBlock backward data: dx[ci] = sum over the dilations d, their output channels co and the taps t of dz[co][p + off(t) 2^d] w_d[co][ci][8 - t]
+struct MsDxArgs {
+  const float* dz;     // [B][cout][H][W]: the gradient at the block's pre-activation output (all dilations, concatenated)
+  float* dx;           // [B][cin][H][W]
+  const float* w[5];   // CSN_PREP_MSDX images [dch rounded up to 2][9][ng * 8] (null if the dilation is absent)
+  int32_t dch[5];
+  int32_t cobase[5];
+  int32_t cin, cout, H, W, B;
+  int32_t ng;          // accumulator groups of 8 input channels per lane: ceil(cin / 8) <= 5
+  int32_t a16, pad;
+};
+
 // ---------------------------------------------------------------------------------------------
 // 2x2 average pool of up to 3 tensors; bilinear x2 of one tensor
 // ---------------------------------------------------------------------------------------------
@@ -519,6 +534,7 @@ int csn_launch_pw(const PwArgs& a, int raw, void* stream);
 bool csn_c3_eligible(const PwArgs& a);                        // one pass of 3x3 tap slices (k_goct_c3.hip)
 int csn_launch_c3(const PwArgs& a, int raw, void* stream);   // raw: plain-store instantiation (no BN/PReLU epilogue)
 int csn_launch_ms(const MsArgs& a, void* stream);
+int csn_launch_ms_dx(const MsDxArgs& a, void* stream);
 int csn_launch_pool(const PoolArgs& a, void* stream);
 int csn_launch_maxpool(const PoolArgs& a, void* stream);   // 2x2 max instead of the mean (float)
 int csn_launch_up2(const Up2Args& a, void* stream);

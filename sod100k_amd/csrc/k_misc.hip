@@ -88,6 +88,14 @@ __global__ __launch_bounds__(CSN_BLOCK) void csn_prep_kernel(const CsnPrepJob* _
         dst[((int64_t)(k0 + c) * 4 + (r & 3)) * j.p2 + t0 + (r >> 2)] = j.p0f * arena[j.src0 + (int64_t)r * j.p0 + c];
       }
     } break;
+    case CSN_PREP_MSDX: {
+      const int tot = j.n * j.p0 * 9;
+      for (int i = tid; i < tot; i += CSN_BLOCK) {
+        const int t = i % 9, rc = i / 9;
+        const int ci = rc % j.p0, co = rc / j.p0;
+        dst[((int64_t)co * 9 + t) * j.p2 + ci] = j.p0f * arena[j.src0 + ((int64_t)co * j.p0 + ci) * 9 + (8 - t)];
+      }
+    } break;
     case CSN_PREP_C3Q_T: {
       const int ncol = j.p1 * 9, t0 = j.p3 & 0xff, k0 = j.p3 >> 8;
       const int tot = j.n * ncol;

@@ -267,6 +267,91 @@ __global__ __launch_bounds__(CSN_BLOCK) void msr_kernel(MsArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// ms_dx_kernel: the block's backward data pass (round 4; before: two launches of the generic tap kernel, 0.7 ms for the 112^2 block
+// of a bf16 step).  The adjoint of five dilated convolutions that WRITE disjoint channel slices is one convolution that READS them:
+//   dx[ci][p] = sum_d sum_co sum_t dz[cobase_d + co][p + off(t) 2^d] * 100 w_d[co][ci][8 - t]
+// One lane owns one pixel and ALL its cin <= 40 sums (NG groups of 8 accumulators): every tap of dz is loaded exactly once per pixel
+// -- 9 cout loads against the forward's 45 cin -- and meets 8 NG wave-uniform weights (s_load, CSN_PREP_MSDX image).  Channels in
+// pairs with the 18 tap loads in flight before the first FMA, bounded resource + 9-bit tap mask as in msblock_kernel.
+template <int NG, typename AT>
+__global__ __launch_bounds__(CSN_BLOCK) void ms_dx_kernel(MsDxArgs a) {
+  constexpr unsigned E = (unsigned)sizeof(AT);
+  constexpr int NC = NG * 8;
+  const int H = a.H, W = a.W, hw = H * W;
+  const int ntx = (hw + CSN_BLOCK - 1) / CSN_BLOCK;
+  const int tile = blockIdx.x;
+  if (tile >= ntx * a.B) return;
+  const int b = tile / ntx;
+  const int p0 = (tile - b * ntx) * CSN_BLOCK + threadIdx.x;
+  const bool valid = p0 < hw;
+  const int p = valid ? p0 : hw - 1;
+  const int y = p / W, x = p - y * W;
+  const csn_buf rb = csn_make_buf_n(act_cast<AT>(a.dz) + (int64_t)b * a.cout * hw, (unsigned)(a.cout * hw) * E);
+  const unsigned lo = (unsigned)p * E;
+  const unsigned cs4 = (unsigned)hw * E;
+  float acc[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) acc[i] = 0.f;
+  for (int d = 0; d < 5; ++d) {
+    const int nco = a.dch[d];
+    if (nco == 0) continue;
+    const int dil = 1 << d;
+    const unsigned vm = ms_tap_mask(y, x, H, W, dil);
+    int toff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) toff[t] = ((t / 3 - 1) * W + (t % 3 - 1)) * dil * (int)E;
+    csn_cfp wd = csn_const(a.w[d]);
+    const int ncop = (nco + 1) & ~1;
+    for (int co = 0; co < ncop; co += 2) {
+      float v[2][9];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const unsigned so = (unsigned)(a.cobase[d] + min(co + u, nco - 1)) * cs4;   // pad channel: its weights are zero
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v[u][t] = csn_bufacc<AT>::ld1(rb, lo + (unsigned)toff[t], so);
+      }
+      CSN_SCHED_FENCE();
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        csn_cfp wc = wd + (int64_t)(co + u) * 9 * NC;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const float val = ((vm >> t) & 1u) ? v[u][t] : 0.f;
+#pragma unroll
+          for (int i = 0; i < NC; ++i) acc[i] = fmaf(wc[t * NC + i], val, acc[i]);
+        }
+      }
+    }
+  }
+  if (valid) {
+    AT* __restrict__ op = act_cast<AT>(a.dx) + (int64_t)b * a.cin * hw + p;
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+      if (i < a.cin) act_st(op + (int64_t)i * hw, acc[i]);
+  }
+}
+
+int csn_launch_ms_dx(const MsDxArgs& a, void* stream) {
+  if (a.ng < 1 || a.ng > 5 || a.cin > a.ng * 8) return 1;
+  const int hw = a.H * a.W;
+  const dim3 grid((unsigned)(((hw + CSN_BLOCK - 1) / CSN_BLOCK) * a.B));
+#define MSDX_LAUNCH(G)                                                                                     \
+  do {                                                                                                    \
+    if (a.a16) CSN_LAUNCH((ms_dx_kernel<G, csn_bf16>), grid, dim3(CSN_BLOCK), 0, stream, a);               \
+    else CSN_LAUNCH((ms_dx_kernel<G, float>), grid, dim3(CSN_BLOCK), 0, stream, a);                        \
+  } while (0)
+  switch (a.ng) {
+    case 1: MSDX_LAUNCH(1); break;
+    case 2: MSDX_LAUNCH(2); break;
+    case 3: MSDX_LAUNCH(3); break;
+    case 4: MSDX_LAUNCH(4); break;
+    default: MSDX_LAUNCH(5); break;
+  }
+#undef MSDX_LAUNCH
+  return (int)hipGetLastError();
+}
+
 int csn_launch_ms(const MsArgs& a, void* stream) {
   const int hw = a.H * a.W;
   static const bool rows = !(std::getenv("CSN_MS_ROWS") && std::getenv("CSN_MS_ROWS")[0] == '0');   // 0: one pixel per lane everywhere
