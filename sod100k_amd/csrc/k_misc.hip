@@ -546,7 +546,9 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
     // (220 instead of 264), but 182 instead of 102 VGPRs = two waves per SIMD instead of four: 42.1 instead of 40.2 ms per bf16 step,
     // and 42.8 ms bounded to 168 VGPRs; bounding the loop as it is to 96 / 80 VGPRs for five / six waves spills: 41.8 / 63 ms --
     // round 4, gpurun_out/r4k, r4l.  Two rows of loads in flight instead of one (126 VGPRs, still four waves): 40.1-40.8 instead of
-    // 39.3-39.4 ms, r4m.  Neither fewer instructions at lower occupancy nor more loads in flight at the same occupancy helps.)
+    // 39.3-39.4 ms, r4m.  Neither fewer instructions at lower occupancy nor more loads in flight at the same occupancy helps;
+    // five waves (fp32 row sums + a 96-register bound, one reload per row) measure the same as four, r4s.  By the ISA listing the
+    // loop is 264 VALU instructions per row of four pixels = ~6.5 ms of pure issue time per bf16 step against 9.0 ms measured.)
     // Round 4: on the vector path the loads of row y + 2 are issued BEFORE row y + 1 is converted and used, i.e. they are in flight
     // during a whole loop trip (they used to be waited for right where they were issued: every trip paid a full memory round trip
     // with only the other waves of the SIMD to cover it).  Rows past the tile / the plane are fetched like any other (zeros past the
