@@ -127,6 +127,13 @@ static inline void csn_st_u32(csn_buf b, unsigned voff, unsigned soff, unsigned 
   const unsigned o = voff + soff;
   if (o + 4u <= b.n && o + 4u > o && o >= voff) *reinterpret_cast<unsigned*>(const_cast<char*>(b.p) + o) = v;
 }
+static inline void csn_st_u64(csn_buf b, unsigned voff, unsigned soff, uint2 v) {
+  const unsigned o = voff + soff;
+  if (o + 8u <= b.n && o + 8u > o && o >= voff) {
+    unsigned* q = reinterpret_cast<unsigned*>(const_cast<char*>(b.p) + o);
+    q[0] = v.x; q[1] = v.y;
+  }
+}
 #else
 typedef __amdgpu_buffer_rsrc_t csn_buf;
 typedef unsigned csn_u2 __attribute__((ext_vector_type(2)));
@@ -178,6 +185,11 @@ __device__ __forceinline__ void csn_st_u16(csn_buf b, unsigned voff, unsigned so
 }
 __device__ __forceinline__ void csn_st_u32(csn_buf b, unsigned voff, unsigned soff, unsigned v) {
   __builtin_amdgcn_raw_buffer_store_b32(v, b, voff, soff, 0);
+}
+__device__ __forceinline__ void csn_st_u64(csn_buf b, unsigned voff, unsigned soff, uint2 v) {
+  csn_u2 u;
+  u.x = v.x; u.y = v.y;
+  __builtin_amdgcn_raw_buffer_store_b64(u, b, voff, soff, 0);
 }
 #endif
 
@@ -268,6 +280,7 @@ template <> struct csn_bufacc<float> {
   static __device__ __forceinline__ float4 ld4(csn_buf b, unsigned voff, unsigned soff) { return csn_ld4(b, voff, soff); }
   static __device__ __forceinline__ void st1(csn_buf b, unsigned voff, unsigned soff, float v) { csn_st1(b, voff, soff, v); }
   static __device__ __forceinline__ void st2(csn_buf b, unsigned voff, unsigned soff, float2 v) { csn_st2(b, voff, soff, v); }
+  static __device__ __forceinline__ void st4(csn_buf b, unsigned voff, unsigned soff, float4 v) { csn_st4(b, voff, soff, v); }
 };
 template <> struct csn_bufacc<csn_bf16> {
   static __device__ __forceinline__ float ld1(csn_buf b, unsigned voff, unsigned soff) { return csn_bf2f(csn_ld_u16(b, voff, soff)); }
@@ -281,6 +294,9 @@ template <> struct csn_bufacc<csn_bf16> {
   }
   static __device__ __forceinline__ void st1(csn_buf b, unsigned voff, unsigned soff, float v) { csn_st_u16(b, voff, soff, csn_f2bf(v)); }
   static __device__ __forceinline__ void st2(csn_buf b, unsigned voff, unsigned soff, float2 v) { csn_st_u32(b, voff, soff, csn_pack_bf2(v.x, v.y)); }
+  static __device__ __forceinline__ void st4(csn_buf b, unsigned voff, unsigned soff, float4 v) {   // one 64-bit store
+    csn_st_u64(b, voff, soff, make_uint2(csn_pack_bf2(v.x, v.y), csn_pack_bf2(v.z, v.w)));
+  }
 };
 
 #ifndef CSN_FILL_U

@@ -11,6 +11,8 @@
 // rows of Wt from the LDS image, D = four consecutive output channels of the lane's own element), 128-bit stores.
 // Replaces goct_pw_kernel<true> for these launches (round 3): ~3,000 instructions per 64 elements there, ~25 per channel
 // and 256 elements here; float and bfloat16 storage.  Needs H * W % 4 == 0 (else the launch stays on goct_pw_kernel).
+#include <cstdlib>
+
 #include "pw4_common.h"
 
 #ifndef PWQ_CB
@@ -124,12 +126,171 @@ __global__ __launch_bounds__(CSN_BLOCK, 16 * NT <= 96 ? 3 : 2) void pwq_kernel(P
         for (int i = 0; i < 4; ++i) {
           const unsigned so = (unsigned)(r0 + 4 * tt + i) * cs;
           const float4 o = make_float4(acc[0][tt][i], acc[1][tt][i], acc[2][tt][i], acc[3][tt][i]);
-          if (sizeof(AT) == 4) {
-            csn_st4(ob, sv, so, o);
-          } else {
-            csn_bufacc<AT>::st2(ob, sv, so, make_float2(o.x, o.y));
-            csn_bufacc<AT>::st2(ob, sv + 2u * E, so, make_float2(o.z, o.w));
-          }
+          csn_bufacc<AT>::st4(ob, sv, so, o);   // (bfloat16: one 64-bit store; two 32-bit ones until round 4)
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pwq16_kernel (round 4): the same launches for bfloat16 tensors on v_mfma_f32_4x4x4_16B_bf16.  At batch 256 pwq_kernel<bf16> is
+// bound by the fp32 matrix pipe, not by HBM: one v_mfma_f32_4x4x1 (256 MACs in 2 passes) per loaded value and row tile, 20 x 29
+// rows x channels on the stage-1 passes = the fp32 MFMA peak's worth of time (profiles/r4_notes.md).  The bf16 instruction takes
+// FOUR channels of the lane's element per issue (1024 MACs in the same 2 passes):
+//   B = {dz[c0 .. c0 + 3][p]} -- the lane's element p of four channels, packed from the four 64-bit loads by v_perm_b32
+//       (two per element and channel pair: no conversion to float at all);
+//   A = {Wt[4 t + (lane & 3)][c0 .. c0 + 3]} -- 64 bits of a bfloat16 image of the transposed weights in LDS, built by the block
+//       from the fp32 image (round to nearest even) while it is filled; D as before.
+// The weights of this pass are rounded to bfloat16 (8 bits of mantissa, like its other operand dz; fp32 masters, products exact,
+// fp32 accumulation) -- what torch.autocast(bfloat16) does to a convolution's weight; covered by the bf16 unit-local bound (3e-2 of
+// the oracle's storage emulation).  CSN_PWQ16=0: pwq_kernel<bf16> (fp32 weights, fp32 MFMA).
+typedef short pwq_s4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pwq_perm(unsigned hi, unsigned lo, unsigned sel) {
+#ifdef CSN_CPU_EMU
+  const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+  unsigned r = 0;
+  for (int i = 0; i < 4; ++i) r |= (unsigned)((v >> (8 * ((sel >> (8 * i)) & 7))) & 0xffu) << (8 * i);
+  return r;
+#else
+  return __builtin_amdgcn_perm(hi, lo, sel);
+#endif
+}
+
+// acc[i] += sum_k W[4 t + i][k0 + k] * x[k] for the lane's own element; a = the lane's row of the tile (device) / all four rows (emu)
+struct Pwq16A {
+#ifdef CSN_CPU_EMU
+  uint2 r[4];
+#else
+  uint2 r[1];
+#endif
+};
+__device__ __forceinline__ void pwq16_mfma(const Pwq16A& a, uint2 x, csn_f4& acc) {
+#ifdef CSN_CPU_EMU
+  const unsigned xs[4] = {x.x & 0xffffu, x.x >> 16, x.y & 0xffffu, x.y >> 16};
+  for (int i = 0; i < 4; ++i) {
+    const unsigned ws[4] = {a.r[i].x & 0xffffu, a.r[i].x >> 16, a.r[i].y & 0xffffu, a.r[i].y >> 16};
+    float sum = acc[i];
+    for (int k = 0; k < 4; ++k) sum = fmaf(csn_bf2f((unsigned short)ws[k]), csn_bf2f((unsigned short)xs[k]), sum);
+    acc[i] = sum;
+  }
+#else
+  union { uint2 u; pwq_s4 s; } ca, cb;
+  ca.u = a.r[0]; cb.u = x;
+  acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ca.s, cb.s, acc, 0, 0, 0);
+#endif
+}
+
+template <int NT>
+__global__ __launch_bounds__(CSN_BLOCK, 16 * NT <= 96 ? 3 : 2) void pwq16_kernel(PwqArgs a_byval) {
+  constexpr int NT4 = (NT + 3) & ~3, P = PW4_PITCH(NT4);
+  constexpr unsigned E = 2u;
+  CSN_DYN_SMEM(float, lds);
+  uint2* wl = reinterpret_cast<uint2*>(lds);            // [group][channel group of 4][tile][row in tile]: four bfloat16 each
+  const CSN_CONST_AS PwqArgs* a = CSN_KERNARG(PwqArgs, a_byval);
+  const int tid = threadIdx.x;
+  const int ng = a->ngroups;
+  int kgs[3] = {0, 0, 0}, kg_tot = 0;                    // channel groups per slice (slices are padded to four channels)
+  for (int s = 0; s < a->nsrc; ++s) { kgs[s] = (a->src[s].C + 3) >> 2; kg_tot += kgs[s]; }
+  {   // the bfloat16 image from the fp32 one: W[4 t + i][k] = wimg[g][k][i][t]
+    const int per_g = kg_tot * NT * 4;
+    for (int idx = tid; idx < ng * per_g; idx += CSN_BLOCK) {
+      const int g = idx / per_g, r = idx - g * per_g;
+      const int kg = r / (NT * 4), ti = r - kg * (NT * 4);
+      const int t = ti >> 2, i = ti & 3;
+      int s = 0, lk = kg, krow = 0;
+      while (s < a->nsrc - 1 && lk >= kgs[s]) { lk -= kgs[s]; krow += a->src[s].C; ++s; }
+      const int C = a->src[s].C;
+      float w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 4 * lk + e;
+        w[e] = c < C ? a->wimg[(int64_t)g * a->gimg_floats + ((int64_t)(krow + c) * 4 + i) * P + t] : 0.f;
+      }
+      wl[idx] = make_uint2(csn_pack_bf2(w[0], w[1]), csn_pack_bf2(w[2], w[3]));
+    }
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = pw4_uniform(tid >> 6);
+  const int hw = a->HW, nq = hw >> 2;
+  const unsigned cs = (unsigned)hw * E;
+  const int tiles_img = (nq + 63) >> 6;
+  const int nitems = tiles_img * a->B * ng;
+  const int nslot = (int)(gridDim.x >> 3) * 4;
+  const int chunk = (((nitems + 7) >> 3) + ng - 1) / ng * ng;
+  const int xcd = blockIdx.x & 7;
+  const int iend = min((xcd + 1) * chunk, nitems);
+#ifdef CSN_CPU_EMU
+  const uint2* wl_lane = wl;
+#else
+  const uint2* wl_lane = wl + (lane & 3);
+#endif
+  auto load4 = [&](csn_buf rb, unsigned off, int c0, int C, uint2 (&v)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = csn_ld_u64(rb, off, (unsigned)min(c0 + j, C - 1) * cs);   // pad channels: zero weights
+  };
+  auto contract = [&](const uint2 (&v)[4], const uint2* wk, csn_f4 (&acc)[4][NT]) {
+    // element s of channels c0 .. c0 + 3: the low / high halves of .x (s = 0, 1) and of .y (s = 2, 3)
+    uint2 x[4];
+    x[0] = make_uint2(pwq_perm(v[1].x, v[0].x, 0x05040100u), pwq_perm(v[3].x, v[2].x, 0x05040100u));
+    x[1] = make_uint2(pwq_perm(v[1].x, v[0].x, 0x07060302u), pwq_perm(v[3].x, v[2].x, 0x07060302u));
+    x[2] = make_uint2(pwq_perm(v[1].y, v[0].y, 0x05040100u), pwq_perm(v[3].y, v[2].y, 0x05040100u));
+    x[3] = make_uint2(pwq_perm(v[1].y, v[0].y, 0x07060302u), pwq_perm(v[3].y, v[2].y, 0x07060302u));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      Pwq16A wa;
+#ifdef CSN_CPU_EMU
+      for (int i = 0; i < 4; ++i) wa.r[i] = wk[t * 4 + i];
+#else
+      wa.r[0] = wk[t * 4];
+#endif
+#pragma unroll
+      for (int s = 0; s < 4; ++s) pwq16_mfma(wa, x[s], acc[s][t]);
+    }
+  };
+  for (int item = xcd * chunk + (int)(blockIdx.x >> 3) * 4 + wave; item < iend; item += nslot) {
+    const int tile = item / ng, g = item - tile * ng;
+    const int b = tile / tiles_img, t = tile - b * tiles_img;
+    const int q0 = (t << 6) + lane;
+    const bool valid = q0 < nq;
+    const unsigned off = (unsigned)min(q0, nq - 1) * 4u * E;
+    const uint2* wg = wl_lane + (int64_t)g * kg_tot * NT * 4;
+    csn_f4 acc[4][NT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[s][tt][i] = 0.f;
+    int kg0 = 0;
+    for (int s = 0; s < a->nsrc; ++s) {
+      const int C = a->src[s].C;
+      const csn_buf rb = csn_make_buf_n(reinterpret_cast<const char*>(a->src[s].ptr) + (int64_t)b * a->src[s].Ctot * (int64_t)cs,
+                                        (unsigned)C * cs);
+      // channel group kg is contracted while group kg + 1 is in flight
+      uint2 vC[4], vN[4];
+      load4(rb, off, 0, C, vC);
+      const int n = kgs[s];
+      for (int kg = 0; kg < n; ++kg) {
+        load4(rb, off, 4 * (kg + 1), C, vN);     // (past the last group: the last channel again, never used)
+        PW4_FENCE();
+        contract(vC, wg + (int64_t)(kg0 + kg) * NT * 4, acc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vC[j] = vN[j];
+      }
+      kg0 += n;
+    }
+    const int r0 = a->grp_r0[g], nt = a->grp_nt[g];
+    const csn_buf ob = csn_make_buf_n(reinterpret_cast<char*>(a->out) + (int64_t)b * a->out_ctot * (int64_t)cs, (unsigned)a->nrows * cs);
+    const unsigned sv = valid ? off : 0x80000000u;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+      if (tt < nt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const unsigned so = (unsigned)(r0 + 4 * tt + i) * cs;
+          csn_bufacc<csn_bf16>::st4(ob, sv, so, make_float4(acc[0][tt][i], acc[1][tt][i], acc[2][tt][i], acc[3][tt][i]));
         }
       }
     }
@@ -138,8 +299,8 @@ __global__ __launch_bounds__(CSN_BLOCK, 16 * NT <= 96 ? 3 : 2) void pwq_kernel(P
 
 #define PWQ_INST_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6)
 typedef void (*PwqFn)(PwqArgs);
-struct PwqEntry { int nt; PwqFn fn[2]; };
-#define PWQ_ENTRY(N) {N, {pwq_kernel<N, float>, pwq_kernel<N, csn_bf16>}},
+struct PwqEntry { int nt; PwqFn fn[3]; };
+#define PWQ_ENTRY(N) {N, {pwq_kernel<N, float>, pwq_kernel<N, csn_bf16>, pwq16_kernel<N>}},
 static const PwqEntry g_pwq_table[] = {PWQ_INST_LIST(PWQ_ENTRY)};
 
 int csn_pwq_max_tiles(void) { return 6; }
@@ -154,14 +315,21 @@ int csn_launch_pwq(const PwqArgs& a, void* stream) {
   int nblk = (nitems + 3) / 4;
   if (nblk > a.max_grid) nblk = a.max_grid;
   const dim3 grid((nblk + 7) & ~7);
-  const size_t lds = (size_t)a.ngroups * a.gimg_floats * sizeof(float);
+  static const bool mfma16 = !(std::getenv("CSN_PWQ16") && std::getenv("CSN_PWQ16")[0] == '0');
+  const int fi = a.a16 ? (mfma16 ? 2 : 1) : 0;
+  size_t lds = (size_t)a.ngroups * a.gimg_floats * sizeof(float);
+  if (fi == 2) {   // the bfloat16 image: eight bytes per (channel group of four, tile, row)
+    int kg = 0;
+    for (int s = 0; s < a.nsrc; ++s) kg += (a.src[s].C + 3) >> 2;
+    lds = (size_t)a.ngroups * kg * a.nt * 4 * sizeof(uint2);
+  }
 #ifndef CSN_CPU_EMU
   if (lds > 64 * 1024) {
-    const hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(e->fn[a.a16 ? 1 : 0]),
+    const hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(e->fn[fi]),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (er != hipSuccess) return (int)er;
   }
 #endif
-  CSN_LAUNCH(e->fn[a.a16 ? 1 : 0], grid, dim3(CSN_BLOCK), lds, stream, a);
+  CSN_LAUNCH(e->fn[fi], grid, dim3(CSN_BLOCK), lds, stream, a);
   return (int)hipGetLastError();
 }
