@@ -182,9 +182,12 @@ __device__ __forceinline__ void pwq16_mfma(const Pwq16A& a, uint2 x, csn_f4& acc
 #endif
 }
 
+#ifndef PWQ16_GB
+#define PWQ16_GB 1     // channel groups of four per load batch
+#endif
 template <int NT>
 __global__ __launch_bounds__(CSN_BLOCK, 16 * NT <= 96 ? 3 : 2) void pwq16_kernel(PwqArgs a_byval) {
-  constexpr int NT4 = (NT + 3) & ~3, P = PW4_PITCH(NT4);
+  constexpr int NT4 = (NT + 3) & ~3, P = PW4_PITCH(NT4), GB = PWQ16_GB;
   constexpr unsigned E = 2u;
   CSN_DYN_SMEM(float, lds);
   uint2* wl = reinterpret_cast<uint2*>(lds);            // [group][channel group of 4][tile][row in tile]: four bfloat16 each
@@ -268,16 +271,22 @@ __global__ __launch_bounds__(CSN_BLOCK, 16 * NT <= 96 ? 3 : 2) void pwq16_kernel
       const int C = a->src[s].C;
       const csn_buf rb = csn_make_buf_n(reinterpret_cast<const char*>(a->src[s].ptr) + (int64_t)b * a->src[s].Ctot * (int64_t)cs,
                                         (unsigned)C * cs);
-      // channel group kg is contracted while group kg + 1 is in flight
-      uint2 vC[4], vN[4];
-      load4(rb, off, 0, C, vC);
-      const int n = kgs[s];
-      for (int kg = 0; kg < n; ++kg) {
-        load4(rb, off, 4 * (kg + 1), C, vN);     // (past the last group: the last channel again, never used)
-        PW4_FENCE();
-        contract(vC, wg + (int64_t)(kg0 + kg) * NT * 4, acc);
+      // channel groups kg .. kg + GB - 1 are contracted while the next GB groups are in flight
+      uint2 vC[GB][4], vN[GB][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) vC[j] = vN[j];
+      for (int u = 0; u < GB; ++u) load4(rb, off, 4 * u, C, vC[u]);
+      const int n = kgs[s];
+      for (int kg = 0; kg < n; kg += GB) {
+#pragma unroll
+        for (int u = 0; u < GB; ++u) load4(rb, off, 4 * (kg + GB + u), C, vN[u]);   // (past the last group: the last channel again, never used)
+        PW4_FENCE();
+#pragma unroll
+        for (int u = 0; u < GB; ++u)
+          if (kg + u < n) contract(vC[u], wg + (int64_t)(kg0 + kg + u) * NT * 4, acc);
+#pragma unroll
+        for (int u = 0; u < GB; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) vC[u][j] = vN[u][j];
       }
       kg0 += n;
     }
