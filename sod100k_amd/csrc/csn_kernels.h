@@ -265,7 +265,8 @@ struct C3qArgs {
   int32_t twl, tiles_x, tiles_y;   // tile = 2^twl x 64 / 2^twl quads
   int32_t ngroups, gimg_floats, nt;
   int32_t max_grid;
-  int32_t a16, pad_;    // activation tensors (sources, z, out) are bfloat16: raw launches of the bf16 train mode
+  int32_t a16;          // activation tensors (sources, z, out) are bfloat16: raw launches of the bf16 train mode
+  int32_t mfma16;       // ... on c3q16_kernel (v_mfma_f32_4x4x4_16B_bf16, weights of the pass rounded to bfloat16)
   int32_t grp_r0[PW4_MAX_GROUPS], grp_nt[PW4_MAX_GROUPS];   // first row / row tiles of every M group
 };
 int csn_c3q_max_tiles(void);

@@ -176,6 +176,7 @@ struct csn_plan {
   int pw4_grid = 2048;    // its block cap (CSN_PW4_GRID, experiments)
   int pw4_twl = 6;        // log2 of its widest tile in low pixels: whole rows of up to 64 (CSN_PW4_TWL; 4 = 16 x 4 tiles: 1 % slower)
   bool pw4_flat = true;       // CSN_PW4_FLAT=0: row-segment tiles everywhere (round 3; A/B)
+  int c3q16 = 1;              // CSN_C3Q16: bf16 3x3 launches on c3q16_kernel -- 0 none, 1 input-gradient launches (default), 2 forward launches too (bf16 weights in the forward pass move the whole-step statistics past their test bound: 3.4e-2 vs 3e-2)
   bool pw4_no_q = false;      // CSN_PW4_NOQ: CSFHead.fuse's lowest output branch stays on goct_pw_kernel (experiments)
   bool bn_bwd_fuse = true;    // depthwise backward forms dz on load, the BatchNorm backward's apply pass is skipped (CSN_BN_BWD_FUSE=0: off)
   bool bn_fwd_fuse = true;    // activations consumed only by a depthwise unit are formed on load (virt_cons; CSN_BN_FWD_FUSE=0: off)
@@ -1061,7 +1062,8 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
         q.twl = PW4_FLAT_TWL; q.tiles_x = (Hq * Wq + 63) / 64; q.tiles_y = 1;
       }
       q.ngroups = L.c3q_ng; q.gimg_floats = L.c3q_gimg; q.nt = L.c3q_nt; q.max_grid = P.pw4_grid;
-      q.a16 = c.a16 ? 1 : 0; q.pad_ = 0;
+      q.a16 = c.a16 ? 1 : 0;
+      q.mfma16 = (c.a16 && (gradq ? P.c3q16 >= 1 : P.c3q16 >= 2)) ? 1 : 0;
       for (int g = 0; g < PW4_MAX_GROUPS; ++g) { q.grp_r0[g] = L.c3q_r0[g]; q.grp_nt[g] = L.c3q_gnt[g]; }
       const bool rawq = c.raw || pp.out_kind == OUT_Z || gradq;
       LAUNCH_TRY(csn_launch_c3q(q, rawq ? 1 : 0, c.stream));
@@ -1518,6 +1520,7 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   if (std::getenv("CSN_PW4_NOSPLIT")) P->pw4_nosplit = true;
   if (std::getenv("CSN_PW4_NOQ")) P->pw4_no_q = true;
   if (const char* e = std::getenv("CSN_PW4_FLAT")) P->pw4_flat = std::atoi(e) != 0;
+  if (const char* e = std::getenv("CSN_C3Q16")) P->c3q16 = std::atoi(e);
   if (std::getenv("CSN_NO_MP_FUSE")) P->no_mp_fuse = true;
   if (const char* v = std::getenv("CSN_C3Q_TWL")) { if (std::atoi(v) >= 2 && std::atoi(v) <= 6) P->c3q_twl = std::atoi(v); }
   if (const char* v = std::getenv("CSN_BN_BWD_FUSE")) P->bn_bwd_fuse = v[0] != '0';

@@ -206,12 +206,211 @@ __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q_kernel(C3qArgs a_byval
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// c3q16_kernel (round 4): raw launches with bfloat16 tensors on v_mfma_f32_4x4x4_16B_bf16.  The SQ counters of a bf16 train step put
+// c3q_kernel<bf16> at 64 % of the fp32 matrix pipe (profiles/r4_sq_train_summary.txt): 36 NT v_mfma_f32_4x4x1 per channel.  Here one
+// issue contracts FOUR channels of a window position:
+//   per channel the 4x4 window is 12 dwords AS LOADED (rows x {pixels 2x - 2 | 2x - 1, 2x | 2x + 1, 2x + 2 | 2x + 3}: aligned dwords
+//   instead of a dword + two shorts -- the outer halves are not used); per group of four channels and window position (row, column)
+//   two v_perm_b32 pick that position's half of the four channels' dwords -> the B operand (no conversion to float);
+//   A = {W[4 t + (lane & 3)][channels c0 .. c0 + 3, tap]} from a bfloat16 image the block builds in LDS from the fp32 one.
+// 36 NT matrix instructions and 32 v_perm per FOUR channels (before: 144 NT and 64 conversions).  Weights rounded to bfloat16 for
+// this pass (fp32 masters; see pwq16_kernel).  Epilogue as c3q_kernel<RAW>.
+struct C3q16Raw { unsigned c[4][4], l[4][4], r[4][4]; };   // [channel of the group][window row]
+
+__device__ __forceinline__ void c3q16_load(csn_buf rb, const C3qGeo& g, unsigned cs, int c0, int C, C3q16Raw& w) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned so = (unsigned)min(c0 + j, C - 1) * cs;   // pad channels: zero weights
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      w.c[j][r] = csn_ld_u32(rb, g.row[r], so);
+      w.l[j][r] = csn_ld_u32(rb, g.row[r] + g.dl, so);
+      w.r[j][r] = csn_ld_u32(rb, g.row[r] + g.dr, so);
+    }
+  }
+}
+
+// nine taps of four channels: wk = the group's image [tap][tile][row in tile]
+// window position (row, column) of the four channels of a group: the B operands
+__device__ __forceinline__ void c3q16_pack(const C3q16Raw& w, uint2 (&x)[4][4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    x[r][0] = make_uint2(pw16_perm(w.l[1][r], w.l[0][r], 0x07060302u), pw16_perm(w.l[3][r], w.l[2][r], 0x07060302u));
+    x[r][1] = make_uint2(pw16_perm(w.c[1][r], w.c[0][r], 0x05040100u), pw16_perm(w.c[3][r], w.c[2][r], 0x05040100u));
+    x[r][2] = make_uint2(pw16_perm(w.c[1][r], w.c[0][r], 0x07060302u), pw16_perm(w.c[3][r], w.c[2][r], 0x07060302u));
+    x[r][3] = make_uint2(pw16_perm(w.r[1][r], w.r[0][r], 0x05040100u), pw16_perm(w.r[3][r], w.r[2][r], 0x05040100u));
+  }
+}
+template <int NT>
+__device__ __forceinline__ void c3q16_group(const uint2 (&x)[4][4], const uint2* wk, csn_f4 (&acc)[4][NT]) {
+#pragma unroll
+  for (int t9 = 0; t9 < 9; ++t9) {
+    const int ty = t9 / 3, tx = t9 - 3 * ty;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      Pw16A wa;
+#ifdef CSN_CPU_EMU
+      for (int i = 0; i < 4; ++i) wa.r[i] = wk[(t9 * NT + t) * 4 + i];
+#else
+      wa.r[0] = wk[(t9 * NT + t) * 4];
+#endif
+#pragma unroll
+      for (int s = 0; s < 4; ++s) pw16_mfma(wa, x[(s >> 1) + ty][(s & 1) + tx], acc[s][t]);
+    }
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q16_kernel(C3qArgs a_byval) {
+  typedef csn_bf16 AT;
+  constexpr int NT4 = (NT + 3) & ~3, P = PW4_PITCH(NT4);
+  constexpr unsigned E = 2u;
+  CSN_DYN_SMEM(float, lds);
+  uint2* wl = reinterpret_cast<uint2*>(lds);   // [group][channel group of 4][tap][tile][row in tile]: four bfloat16 each
+  const CSN_CONST_AS C3qArgs* a = CSN_KERNARG(C3qArgs, a_byval);
+  const int tid = threadIdx.x;
+  const int ng = a->ngroups;
+  int kgs[3] = {0, 0, 0}, kg_tot = 0;
+  for (int s = 0; s < a->nsrc; ++s) { kgs[s] = (a->src[s].C + 3) >> 2; kg_tot += kgs[s]; }
+  {   // the bfloat16 image from the fp32 one: W[4 t + i][entry] = wimg[g][entry][i][t], entry = 9 * channel + tap inside the slice
+    const int per_g = kg_tot * 9 * NT * 4;
+    for (int idx = tid; idx < ng * per_g; idx += CSN_BLOCK) {
+      const int g = idx / per_g, r = idx - g * per_g;
+      const int kt = r / (NT * 4), ti = r - kt * (NT * 4);
+      const int kg = kt / 9, t9 = kt - 9 * kg;
+      const int t = ti >> 2, i = ti & 3;
+      int s = 0, lk = kg, krow = 0;
+      while (s < a->nsrc - 1 && lk >= kgs[s]) { lk -= kgs[s]; krow += 9 * a->src[s].C; ++s; }
+      const int C = a->src[s].C;
+      float w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 4 * lk + e;
+        w[e] = c < C ? a->wimg[(int64_t)g * a->gimg_floats + ((int64_t)(krow + 9 * c + t9) * 4 + i) * P + t] : 0.f;
+      }
+      wl[idx] = make_uint2(csn_pack_bf2(w[0], w[1]), csn_pack_bf2(w[2], w[3]));
+    }
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = pw4_uniform(tid >> 6);
+  const int H = a->H, W = a->W, Hq = H >> 1, Wq = W >> 1;
+  const unsigned cs = (unsigned)(H * W) * E;
+  const int twl = a->twl;
+  const int lx = lane & ((1 << twl) - 1), ly = lane >> twl;
+  const int tiles_xy = a->tiles_x * a->tiles_y;
+  const int nitems = tiles_xy * a->B * ng;
+  const int nslot = (int)(gridDim.x >> 3) * 4;
+  const int chunk = (((nitems + 7) >> 3) + ng - 1) / ng * ng;
+  const int xcd = blockIdx.x & 7;
+  const int iend = min((xcd + 1) * chunk, nitems);
+#ifdef CSN_CPU_EMU
+  const uint2* wl_lane = wl;
+#else
+  const uint2* wl_lane = wl + (lane & 3);
+#endif
+  for (int item = xcd * chunk + (int)(blockIdx.x >> 3) * 4 + wave; item < iend; item += nslot) {
+    const int tile = item / ng, g = item - tile * ng;
+    const int b = tile / tiles_xy, txy = tile - b * tiles_xy;
+    int yq, xq;
+    if (twl >= PW4_FLAT_TWL) {
+      const int p = txy * 64 + lane;
+      int q = (int)((float)p * (1.0f / (float)Wq));
+      q -= (q * Wq > p) ? 1 : 0;
+      q += ((q + 1) * Wq <= p) ? 1 : 0;
+      yq = q; xq = p - q * Wq;
+    } else {
+      const int ty = txy / a->tiles_x, tx = txy - ty * a->tiles_x;
+      yq = (ty << (6 - twl)) + ly; xq = (tx << twl) + lx;
+    }
+    const bool valid = yq < Hq && xq < Wq;
+    const int y = min(yq, Hq - 1), x = min(xq, Wq - 1);
+    const uint2* wg = wl_lane + (int64_t)g * kg_tot * 9 * NT * 4;
+
+    csn_f4 acc[4][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[s][t][i] = 0.f;
+
+    const bool has_l = x > 0, has_r = 2 * x + 2 < W;
+    int kg0 = 0;
+    for (int s = 0; s < a->nsrc; ++s) {
+      const int C = a->src[s].C;
+      C3qGeo geo;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int yy = 2 * y - 1 + r;
+        geo.row[r] = (yy >= 0 && yy < H) ? (unsigned)(yy * W + 2 * x) * E : 0x80000000u;
+      }
+      geo.dl = has_l ? 0u - 2u * E : 0x40000000u;   // the dword of pixels 2x - 2 | 2x - 1
+      geo.dr = has_r ? 2u * E : 0x40000000u;        // ... of pixels 2x + 2 | 2x + 3
+      const csn_buf rb = csn_make_buf_n(reinterpret_cast<const char*>(a->src[s].ptr) + (int64_t)b * a->src[s].Ctot * (int64_t)cs,
+                                        (unsigned)a->src[s].Ctot * cs);
+      // group kg is contracted while the loads of group kg + 1 are in flight: the window as loaded (48 registers) is packed into the
+      // operands (32) first, the next group's loads then reuse its registers
+      C3q16Raw w;
+      c3q16_load(rb, geo, cs, 0, C, w);
+      const int n = kgs[s];
+      for (int kg = 0; kg < n; ++kg) {
+        uint2 x[4][4];
+        c3q16_pack(w, x);
+        PW4_FENCE();
+        c3q16_load(rb, geo, cs, 4 * (kg + 1), C, w);   // (past the last group: the last channel again, never used)
+        PW4_FENCE();
+        c3q16_group<NT>(x, wg + (int64_t)(kg0 + kg) * 9 * NT * 4, acc);
+      }
+      kg0 += n;
+    }
+
+    // ---- epilogue: + bilinear_up2(z), raw 32-bit stores of the quad rows (as c3q_kernel<RAW>) ----
+    const int r0 = a->grp_r0[g], nt = a->grp_nt[g];
+    const unsigned o0 = (unsigned)((2 * y) * W + 2 * x) * E, o1 = o0 + (unsigned)W * E;
+    const unsigned sv0 = valid ? o0 : 0x80000000u, sv1 = valid ? o1 : 0x80000000u;
+    const csn_buf ob = csn_make_buf_n(reinterpret_cast<char*>(a->out) + (int64_t)b * a->out_ctot * (int64_t)cs, (unsigned)a->out_ctot * cs);
+    unsigned oz[9];
+    csn_buf zb = ob;
+    const unsigned csz = cs >> 2;
+    if (a->z) {
+      const int yy[3] = {max(y - 1, 0), y, min(y + 1, Hq - 1)};
+      const int xx[3] = {max(x - 1, 0), x, min(x + 1, Wq - 1)};
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) oz[3 * r + c] = (unsigned)(yy[r] * Wq + xx[c]) * E;
+      zb = csn_make_buf_n(reinterpret_cast<const char*>(a->z) + (int64_t)b * a->z_ctot * (int64_t)csz, (unsigned)a->z_ctot * csz);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      if (t < nt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * t + i;
+          float zq[4] = {0.f, 0.f, 0.f, 0.f};
+          if (a->z) {
+            float zv[9];
+            const unsigned zo = (unsigned)min(a->z_c0 + r0 + r, a->z_ctot - 1) * csz;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) zv[k] = csn_bufacc<AT>::ld1(zb, oz[k], zo);
+            pw4_up2_quad(zv, zq);
+          }
+          const unsigned so = (unsigned)(a->out_c0 + r0 + r) * cs;
+          csn_bufacc<AT>::st2(ob, sv0, so, make_float2(acc[0][t][i] + zq[0], acc[1][t][i] + zq[1]));
+          csn_bufacc<AT>::st2(ob, sv1, so, make_float2(acc[2][t][i] + zq[2], acc[3][t][i] + zq[3]));
+        }
+      }
+    }
+  }
+}
+
 // ---- instantiation table -----------------------------------------------------------------------------------------
 #define C3Q_INST_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
 typedef void (*C3qFn)(C3qArgs);
-struct C3qEntry { int nt; C3qFn fn[3]; };   // BN + PReLU / raw / raw with bfloat16 tensors
-#define C3Q_ENTRY(N) {N, {c3q_kernel<N, false>, c3q_kernel<N, true>, c3q_kernel<N, true, csn_bf16>}},
+struct C3qEntry { int nt; C3qFn fn[4]; };   // BN + PReLU / raw / raw with bfloat16 tensors / ... on the bf16 matrix instruction
+#define C3Q_ENTRY(N) {N, {c3q_kernel<N, false>, c3q_kernel<N, true>, c3q_kernel<N, true, csn_bf16>, c3q16_kernel<N>}},
 static const C3qEntry g_c3q_table[] = {C3Q_INST_LIST(C3Q_ENTRY)};
 
 int csn_c3q_max_tiles(void) { return 7; }
@@ -230,7 +429,7 @@ int csn_launch_c3q(const C3qArgs& a, int raw, void* stream) {
   static CsnPerDeviceOnce attr_once;
   const int ast = attr_once.run([&]() {
     for (size_t i = 0; i < sizeof(g_c3q_table) / sizeof(g_c3q_table[0]); ++i)
-      for (int r = 0; r < 3; ++r) {
+      for (int r = 0; r < 4; ++r) {
         const hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(g_c3q_table[i].fn[r]),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (er != hipSuccess) return (int)er;
@@ -240,6 +439,13 @@ int csn_launch_c3q(const C3qArgs& a, int raw, void* stream) {
   if (ast != 0) return ast;
 #endif
   if (a.a16 && !raw) return 1;   // bfloat16 tensors: train-mode (raw) launches only
+  if (a.a16 && a.mfma16) {
+    int kg = 0;
+    for (int s = 0; s < a.nsrc; ++s) kg += (a.src[s].C + 3) >> 2;
+    const size_t lds16 = (size_t)a.ngroups * kg * 9 * a.nt * 4 * sizeof(uint2);
+    CSN_LAUNCH(e->fn[3], grid, dim3(CSN_BLOCK), lds16, stream, a);
+    return (int)hipGetLastError();
+  }
   CSN_LAUNCH(e->fn[raw ? (a.a16 ? 2 : 1) : 0], grid, dim3(CSN_BLOCK), lds, stream, a);
   return (int)hipGetLastError();
 }

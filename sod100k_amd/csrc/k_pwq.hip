@@ -145,43 +145,6 @@ __global__ __launch_bounds__(CSN_BLOCK, 16 * NT <= 96 ? 3 : 2) void pwq_kernel(P
 // The weights of this pass are rounded to bfloat16 (8 bits of mantissa, like its other operand dz; fp32 masters, products exact,
 // fp32 accumulation) -- what torch.autocast(bfloat16) does to a convolution's weight; covered by the bf16 unit-local bound (3e-2 of
 // the oracle's storage emulation).  CSN_PWQ16=0: pwq_kernel<bf16> (fp32 weights, fp32 MFMA).
-typedef short pwq_s4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ unsigned pwq_perm(unsigned hi, unsigned lo, unsigned sel) {
-#ifdef CSN_CPU_EMU
-  const unsigned long long v = ((unsigned long long)hi << 32) | lo;
-  unsigned r = 0;
-  for (int i = 0; i < 4; ++i) r |= (unsigned)((v >> (8 * ((sel >> (8 * i)) & 7))) & 0xffu) << (8 * i);
-  return r;
-#else
-  return __builtin_amdgcn_perm(hi, lo, sel);
-#endif
-}
-
-// acc[i] += sum_k W[4 t + i][k0 + k] * x[k] for the lane's own element; a = the lane's row of the tile (device) / all four rows (emu)
-struct Pwq16A {
-#ifdef CSN_CPU_EMU
-  uint2 r[4];
-#else
-  uint2 r[1];
-#endif
-};
-__device__ __forceinline__ void pwq16_mfma(const Pwq16A& a, uint2 x, csn_f4& acc) {
-#ifdef CSN_CPU_EMU
-  const unsigned xs[4] = {x.x & 0xffffu, x.x >> 16, x.y & 0xffffu, x.y >> 16};
-  for (int i = 0; i < 4; ++i) {
-    const unsigned ws[4] = {a.r[i].x & 0xffffu, a.r[i].x >> 16, a.r[i].y & 0xffffu, a.r[i].y >> 16};
-    float sum = acc[i];
-    for (int k = 0; k < 4; ++k) sum = fmaf(csn_bf2f((unsigned short)ws[k]), csn_bf2f((unsigned short)xs[k]), sum);
-    acc[i] = sum;
-  }
-#else
-  union { uint2 u; pwq_s4 s; } ca, cb;
-  ca.u = a.r[0]; cb.u = x;
-  acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ca.s, cb.s, acc, 0, 0, 0);
-#endif
-}
-
 #ifndef PWQ16_GB
 #define PWQ16_GB 1     // channel groups of four per load batch
 #endif
@@ -236,20 +199,20 @@ __global__ __launch_bounds__(CSN_BLOCK, 16 * NT <= 96 ? 3 : 2) void pwq16_kernel
   auto contract = [&](const uint2 (&v)[4], const uint2* wk, csn_f4 (&acc)[4][NT]) {
     // element s of channels c0 .. c0 + 3: the low / high halves of .x (s = 0, 1) and of .y (s = 2, 3)
     uint2 x[4];
-    x[0] = make_uint2(pwq_perm(v[1].x, v[0].x, 0x05040100u), pwq_perm(v[3].x, v[2].x, 0x05040100u));
-    x[1] = make_uint2(pwq_perm(v[1].x, v[0].x, 0x07060302u), pwq_perm(v[3].x, v[2].x, 0x07060302u));
-    x[2] = make_uint2(pwq_perm(v[1].y, v[0].y, 0x05040100u), pwq_perm(v[3].y, v[2].y, 0x05040100u));
-    x[3] = make_uint2(pwq_perm(v[1].y, v[0].y, 0x07060302u), pwq_perm(v[3].y, v[2].y, 0x07060302u));
+    x[0] = make_uint2(pw16_perm(v[1].x, v[0].x, 0x05040100u), pw16_perm(v[3].x, v[2].x, 0x05040100u));
+    x[1] = make_uint2(pw16_perm(v[1].x, v[0].x, 0x07060302u), pw16_perm(v[3].x, v[2].x, 0x07060302u));
+    x[2] = make_uint2(pw16_perm(v[1].y, v[0].y, 0x05040100u), pw16_perm(v[3].y, v[2].y, 0x05040100u));
+    x[3] = make_uint2(pw16_perm(v[1].y, v[0].y, 0x07060302u), pw16_perm(v[3].y, v[2].y, 0x07060302u));
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      Pwq16A wa;
+      Pw16A wa;
 #ifdef CSN_CPU_EMU
       for (int i = 0; i < 4; ++i) wa.r[i] = wk[t * 4 + i];
 #else
       wa.r[0] = wk[t * 4];
 #endif
 #pragma unroll
-      for (int s = 0; s < 4; ++s) pwq16_mfma(wa, x[s], acc[s][t]);
+      for (int s = 0; s < 4; ++s) pw16_mfma(wa, x[s], acc[s][t]);
     }
   };
   for (int item = xcd * chunk + (int)(blockIdx.x >> 3) * 4 + wave; item < iend; item += nslot) {

@@ -121,6 +121,45 @@ __device__ __forceinline__ void pw4_lo_batch(const float (&v)[LB][9], const floa
   }
 }
 
+// ---- v_mfma_f32_4x4x4_16B_bf16 from packed bfloat16 operands (bf16 train mode: k_pwq.hip pwq16_kernel, k_c3q.hip c3q16_kernel) ----
+typedef short pw16_s4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pw16_perm(unsigned hi, unsigned lo, unsigned sel) {
+#ifdef CSN_CPU_EMU
+  const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+  unsigned r = 0;
+  for (int i = 0; i < 4; ++i) r |= (unsigned)((v >> (8 * ((sel >> (8 * i)) & 7))) & 0xffu) << (8 * i);
+  return r;
+#else
+  return __builtin_amdgcn_perm(hi, lo, sel);
+#endif
+}
+
+// acc[i] += sum_k W[4 t + i][k0 + k] * x[k] for the lane's own element; a = the lane's row of the tile (device) / all four rows (emu)
+struct Pw16A {
+#ifdef CSN_CPU_EMU
+  uint2 r[4];
+#else
+  uint2 r[1];
+#endif
+};
+__device__ __forceinline__ void pw16_mfma(const Pw16A& a, uint2 x, csn_f4& acc) {
+#ifdef CSN_CPU_EMU
+  const unsigned xs[4] = {x.x & 0xffffu, x.x >> 16, x.y & 0xffffu, x.y >> 16};
+  for (int i = 0; i < 4; ++i) {
+    const unsigned ws[4] = {a.r[i].x & 0xffffu, a.r[i].x >> 16, a.r[i].y & 0xffffu, a.r[i].y >> 16};
+    float sum = acc[i];
+    for (int k = 0; k < 4; ++k) sum = fmaf(csn_bf2f((unsigned short)ws[k]), csn_bf2f((unsigned short)xs[k]), sum);
+    acc[i] = sum;
+  }
+#else
+  union { uint2 u; pw16_s4 s; } ca, cb;
+  ca.u = a.r[0]; cb.u = x;
+  acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ca.s, cb.s, acc, 0, 0, 0);
+#endif
+}
+
+
 // y = z * scale + shift;  PReLU as max(y, 0) + alpha * min(y, 0): bit-identical to the select form of csn_epi (one of the
 // two terms is an exact zero) without the v_cmp -> v_cndmask SGPR round trip
 __device__ __forceinline__ float pw4_epi(float z, float sc, float sh, float al) {
