@@ -6,8 +6,6 @@
 O=$PWD/gpurun_out/r4; mkdir -p $O; R=$PWD
 bash tools/gpu_pmc_hbm.sh r4z r4 > /dev/null 2>&1; tail -3 gpurun_out/r4z/pmc_hbm.txt
 bash tools/gpu_pmc_train.sh r4z r4 > /dev/null 2>&1; grep "^##" gpurun_out/r4z/pmc_train.txt
-# (the whole GPU suite ran on its own lease right before: gpurun_out/r4/pytest_gpu.log; here only the torchrun / RCCL tests again)
-( timeout 600 python -m pytest tests/test_gpu_rccl.py -m gpu -q 2>&1 | tail -8 ) > $O/pytest_gpu_rccl.log; tail -3 $O/pytest_gpu_rccl.log
 ( timeout 900 python bench.py ) > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.json; echo
 ( timeout 300 python tools/unit_table.py --json $O/unit_table.json ) > $O/unit_table.txt 2>&1; tail -3 $O/unit_table.txt
 cd /tmp && export TMPDIR=/tmp
@@ -23,3 +21,5 @@ python tools/train_step_breakdown.py $(find $O/trace_train -name "*kernel_trace.
 cp $(find $O/trace_train -name "*kernel_trace.csv" | head -1) $O/train_kernel_trace.csv 2>/dev/null; gzip -f $O/train_kernel_trace.csv
 rm -rf $O/trace_train $O/trace_eval/*/*.db $O/trace_eval_nolanes/*/*.db
 head -12 $O/kernel_stats_eval_nolanes.md; grep -A12 "## bf16" $O/train_step_kernels.md
+# the whole GPU suite on the same tree, last (the collection above does not depend on it)
+( timeout 600 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -30 ) > $O/pytest_gpu.log; tail -4 $O/pytest_gpu.log
