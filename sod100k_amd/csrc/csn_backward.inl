@@ -317,8 +317,7 @@ int plan_ms_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
   }
   if (!ub.need_dx[0]) return CSN_OK;
   // backward data: ms_dx_kernel (one launch, every dz tap loaded once per pixel); CSN_MS_DX=0: the generic tap kernel below
-  static const bool msdx = !(std::getenv("CSN_MS_DX") && std::getenv("CSN_MS_DX")[0] == '0');
-  if (msdx && cin <= 40) {
+  if (P.ms_dx && cin <= 40) {
     ub.msdx_ng = (cin + 7) / 8;
     for (int k = 0; k < CSN_NDIL; ++k) {
       if (d.dil_ch[k] == 0) continue;

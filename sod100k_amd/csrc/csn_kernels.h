@@ -238,6 +238,7 @@ struct PwqArgs {
   int32_t out_ctot, HW, B;
   int32_t ngroups, gimg_floats, nt, max_grid;
   int32_t a16;         // tensors are bfloat16
+  int32_t mfma16;      // ... on pwq16_kernel (v_mfma_f32_4x4x4_16B_bf16, weights of the pass rounded to bfloat16)
   int32_t grp_r0[PW4_MAX_GROUPS], grp_nt[PW4_MAX_GROUPS];
 };
 int csn_pwq_max_tiles(void);

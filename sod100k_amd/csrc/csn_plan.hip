@@ -176,7 +176,9 @@ struct csn_plan {
   int pw4_grid = 2048;    // its block cap (CSN_PW4_GRID, experiments)
   int pw4_twl = 6;        // log2 of its widest tile in low pixels: whole rows of up to 64 (CSN_PW4_TWL; 4 = 16 x 4 tiles: 1 % slower)
   bool pw4_flat = true;       // CSN_PW4_FLAT=0: row-segment tiles everywhere (round 3; A/B)
-  int c3q16 = 1;              // CSN_C3Q16: bf16 3x3 launches on c3q16_kernel -- 0 none, 1 input-gradient launches (default), 2 forward launches too (bf16 weights in the forward pass move the whole-step statistics past their test bound: 3.4e-2 vs 3e-2)
+  bool pwq16 = true;          // CSN_PWQ16=0: 1x1 input-gradient launches of the bf16 step on pwq_kernel<bf16> (fp32 matrix instruction)
+  bool ms_dx = true;          // CSN_MS_DX=0: MSBlock input gradients on the generic tap kernel (two launches) instead of ms_dx_kernel
+  int c3q16 = 1;              // CSN_C3Q16: bf16 3x3 launches on c3q16_kernel -- 0 none, 1 input-gradient launches (default), 2 forward launches too (experiments only: bf16 weights in the forward pass put z of the stride-2 units at 2.9e-3 of the unit-local 2e-3 bound and the whole-step statistics at 3.4e-2 of 3e-2)
   bool pw4_no_q = false;      // CSN_PW4_NOQ: CSFHead.fuse's lowest output branch stays on goct_pw_kernel (experiments)
   bool bn_bwd_fuse = true;    // depthwise backward forms dz on load, the BatchNorm backward's apply pass is skipped (CSN_BN_BWD_FUSE=0: off)
   bool bn_fwd_fuse = true;    // activations consumed only by a depthwise unit are formed on load (virt_cons; CSN_BN_FWD_FUSE=0: off)
@@ -381,7 +383,7 @@ int finish_launch(Builder& bl, PwLaunchPlan& L) {
       // ---- c3q_kernel: forward passes on whole tensors at an even resolution; round 4: also the input-gradient passes (a 3x3
       // convolution of dz with transposed, tap-flipped weight blocks, CSN_PREP_C3Q_T: plain own-resolution tap slices only) ----
       const bool grad_pass = ps.out_kind == OUT_DX || ps.out_kind == OUT_TMP;
-      static const bool c3q_bwd_off = std::getenv("CSN_C3Q_BWD") && std::getenv("CSN_C3Q_BWD")[0] == '0';
+      const bool c3q_bwd_off = std::getenv("CSN_C3Q_BWD") && std::getenv("CSN_C3Q_BWD")[0] == '0';
       bool q = (((bl.P.H >> L.lvl) | (bl.P.W >> L.lvl)) & 1) == 0 && !(grad_pass && (c3q_bwd_off || tail));
       for (int s = 0; s < ntap; ++s) {
         q = q && ps.src_c0[s] == 0 && (ps.src_ctot[s] == 0 || ps.src_ctot[s] == ps.src_C[s]);
@@ -1020,6 +1022,7 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
     q.wimg = c.pk(L.pwq_wimg);
     q.HW = a.H0 * a.W0; q.B = a.B;
     q.ngroups = L.pwq_ng; q.gimg_floats = L.pwq_gimg; q.nt = L.pwq_nt; q.max_grid = P.pw4_grid; q.a16 = c.a16 ? 1 : 0;
+    q.mfma16 = (c.a16 && P.pwq16) ? 1 : 0;
     for (int g = 0; g < PW4_MAX_GROUPS; ++g) { q.grp_r0[g] = L.pwq_r0[g]; q.grp_nt[g] = L.pwq_gnt[g]; }
     bool ok = q.out != nullptr;
     for (int s = 0; s < q.nsrc; ++s) ok = ok && q.src[s].ptr != nullptr;
@@ -1521,6 +1524,8 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   if (std::getenv("CSN_PW4_NOQ")) P->pw4_no_q = true;
   if (const char* e = std::getenv("CSN_PW4_FLAT")) P->pw4_flat = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_C3Q16")) P->c3q16 = std::atoi(e);
+  if (const char* e = std::getenv("CSN_PWQ16")) P->pwq16 = std::atoi(e) != 0;
+  if (const char* e = std::getenv("CSN_MS_DX")) P->ms_dx = std::atoi(e) != 0;
   if (std::getenv("CSN_NO_MP_FUSE")) P->no_mp_fuse = true;
   if (const char* v = std::getenv("CSN_C3Q_TWL")) { if (std::atoi(v) >= 2 && std::atoi(v) <= 6) P->c3q_twl = std::atoi(v); }
   if (const char* v = std::getenv("CSN_BN_BWD_FUSE")) P->bn_bwd_fuse = v[0] != '0';

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 16 * NT <= 96 ? 3 : 2) void pwq_kernel(P
 //       from the fp32 image (round to nearest even) while it is filled; D as before.
 // The weights of this pass are rounded to bfloat16 (8 bits of mantissa, like its other operand dz; fp32 masters, products exact,
 // fp32 accumulation) -- what torch.autocast(bfloat16) does to a convolution's weight; covered by the bf16 unit-local bound (3e-2 of
-// the oracle's storage emulation).  CSN_PWQ16=0: pwq_kernel<bf16> (fp32 weights, fp32 MFMA).
+// the oracle's storage emulation).  CSN_PWQ16=0 (read at plan creation): pwq_kernel<bf16> (fp32 weights, fp32 MFMA).
 #ifndef PWQ16_GB
 #define PWQ16_GB 1     // channel groups of four per load batch
 #endif
@@ -287,8 +287,7 @@ int csn_launch_pwq(const PwqArgs& a, void* stream) {
   int nblk = (nitems + 3) / 4;
   if (nblk > a.max_grid) nblk = a.max_grid;
   const dim3 grid((nblk + 7) & ~7);
-  static const bool mfma16 = !(std::getenv("CSN_PWQ16") && std::getenv("CSN_PWQ16")[0] == '0');
-  const int fi = a.a16 ? (mfma16 ? 2 : 1) : 0;
+  const int fi = a.a16 ? (a.mfma16 ? 2 : 1) : 0;
   size_t lds = (size_t)a.ngroups * a.gimg_floats * sizeof(float);
   if (fi == 2) {   // the bfloat16 image: eight bytes per (channel group of four, tile, row)
     int kg = 0;

@@ -541,7 +541,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_bwd_apply_adj2_kernel(BnBwdArgs 
 }
 
 bool csn_bn_bwd_adj2_ok(int64_t HW, int W) {
-  static const bool off = std::getenv("CSN_ADJ_FUSE") && std::getenv("CSN_ADJ_FUSE")[0] == '0';
+  const bool off = std::getenv("CSN_ADJ_FUSE") && std::getenv("CSN_ADJ_FUSE")[0] == '0';
   if (off || W <= 0 || (W & 7) != 0 || HW % W != 0 || W / 8 > CSN_BLOCK) return false;
   return ((HW / W) & 1) == 0;
 }
@@ -1022,7 +1022,7 @@ int csn_launch_dw_wgrad(const DwWgradArgs& a0, void* stream) {
 }
 // in16 / out16: element type of the source / destination (the logits gradient arrives as float whatever the mode)
 int csn_launch_adjup(const AdjUpArgs& a, void* stream) {
-  static const bool rows4_off = std::getenv("CSN_ADJ4_ROWS") && std::getenv("CSN_ADJ4_ROWS")[0] == '0';
+  const bool rows4_off = std::getenv("CSN_ADJ4_ROWS") && std::getenv("CSN_ADJ4_ROWS")[0] == '0';
   if (a.f == 4 && !rows4_off && ((a.Wl * 4) & 7) == 0 && (a.Wl * 4) / 8 <= CSN_BLOCK) {
     const dim3 grid(a.planes), block(CSN_BLOCK);
     if (a.in16 && a.out16) CSN_LAUNCH((adjup4_rows_kernel<csn_bf16, csn_bf16>), grid, block, 0, stream, a);

@@ -519,7 +519,7 @@ namespace {
 struct WgBfCfg { int slog, ntr, ntc, L, runs, nitems, nblk; bool pool; };
 
 bool wgbf_config(const WgArgs& a, WgBfCfg* c) {
-  static const bool off = std::getenv("CSN_WGRAD_BF") && std::getenv("CSN_WGRAD_BF")[0] == '0';
+  const bool off = std::getenv("CSN_WGRAD_BF") && std::getenv("CSN_WGRAD_BF")[0] == '0';
   if (off || !a.a16) return false;
   const PwPass& ps = a.ps;
   if (ps.nsrc < 1 || ps.nsrc > 3 || a.nrs < 1 || a.nrs > 3) return false;
@@ -608,7 +608,7 @@ namespace {
 struct WgBf3Cfg { int slog, ntr, ntc, maxch, L, runs, nitems, nblk; };
 
 bool wgbf3_config(const WgArgs& a, WgBf3Cfg* c) {
-  static const bool off = std::getenv("CSN_WGRAD_BF3") && std::getenv("CSN_WGRAD_BF3")[0] == '0';
+  const bool off = std::getenv("CSN_WGRAD_BF3") && std::getenv("CSN_WGRAD_BF3")[0] == '0';
   if (off || !a.a16) return false;
   const PwPass& ps = a.ps;
   if (ps.nsrc < 1 || ps.nsrc > 3 || a.nrs < 1 || a.nrs > 3) return false;
@@ -620,7 +620,7 @@ bool wgbf3_config(const WgArgs& a, WgBf3Cfg* c) {
     dilated = dilated || d != 1;
     C += ps.src[s].C;
   }
-  static const bool ms_off = std::getenv("CSN_WGRAD_BF3_MS") && std::getenv("CSN_WGRAD_BF3_MS")[0] == '0';
+  const bool ms_off = std::getenv("CSN_WGRAD_BF3_MS") && std::getenv("CSN_WGRAD_BF3_MS")[0] == '0';
   if (dilated && ms_off) return false;
   const int64_t HW = (int64_t)a.Hr * a.Wr;
   if ((a.Wr % 8) != 0 || HW % 32 != 0 || HW > (1 << 24) || ps.cin != 9 * C) return false;

@@ -119,6 +119,18 @@ def test_emu_train_units_local_fallback_paths(emu_lib, x2_manifest, monkeypatch,
     print(P.check_train_units_local(emu_lib, CPU, x2_manifest, B=2, size=48, act_dtype=act_dtype, state="shipped"))
 
 
+@pytest.mark.parametrize("env", [{"CSN_PWQ16": "0", "CSN_C3Q16": "0", "CSN_MS_DX": "0", "CSN_WGRAD_BF": "0", "CSN_WGRAD_BF3": "0"},
+                                 {"CSN_ADJ_FUSE": "0", "CSN_ADJ4_ROWS": "0", "CSN_C3Q_BWD": "0", "CSN_BWD_NO_DEFER": "1"}])
+def test_emu_bf16_units_local_with_the_round4_kernels_switched(emu_lib, x2_manifest, monkeypatch, env):
+    """The round-4 kernels of the bf16 step behind their switches: (a) all off -- the fp32 matrix instruction for the 1x1 / 3x3 input
+    gradients and the weight gradients, the generic tap kernel for the MSBlock input gradient; (b) apply / adjoint unfused, 3x3 input
+    gradients on the LDS-tiled kernel, no launch batching.  Every unit stays inside the same unit-local bounds.  (CSN_C3Q16=2, the 3x3
+    FORWARD launches with bf16 weights, is NOT certified: z of the stride-2 units lands at 2.9e-3 against the 2e-3 bound.)"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    print(P.check_train_units_local(emu_lib, CPU, x2_manifest, B=2, size=64, act_dtype="bf16", state="shipped"))
+
+
 def test_emu_bf16_trainer_steps_and_eval_afterwards(emu_lib, x2_manifest):
     """FusedTrainer in bf16 storage mode: a few optimizer steps move the parameters, the loss stays finite and close to the
     fp32 trainer's, and the eval-mode forward afterwards is the fp32 path (equal to the oracle on the updated state)."""

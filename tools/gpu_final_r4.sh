@@ -22,4 +22,6 @@ cp $(find $O/trace_train -name "*kernel_trace.csv" | head -1) $O/train_kernel_tr
 rm -rf $O/trace_train $O/trace_eval/*/*.db $O/trace_eval_nolanes/*/*.db
 head -12 $O/kernel_stats_eval_nolanes.md; grep -A12 "## bf16" $O/train_step_kernels.md
 # the whole GPU suite on the same tree, last (the collection above does not depend on it)
-( timeout 600 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -30 ) > $O/pytest_gpu.log; tail -4 $O/pytest_gpu.log
+[ -n "$SKIP_PYTEST" ] || { ( timeout 600 python -m pytest tests -m gpu -q --durations=8 2>&1 | tail -30 ) > $O/pytest_gpu.log; tail -4 $O/pytest_gpu.log; }
+# (SKIP_PYTEST=1: the re-collection after a change that the CPU suite covers; then only the train / path tests that touch it)
+[ -z "$SKIP_PYTEST" ] || { ( timeout 200 python -m pytest tests -m gpu -q -x -k "(units_local and bf16 and 96) or train_step_bf16" 2>&1 | tail -3 ) > $O/pytest_gpu_recheck.log; tail -2 $O/pytest_gpu_recheck.log; }
