@@ -669,8 +669,11 @@ def _rel(a, b):
 
 
 def check_train_units_local(lib, device, manifest, B=2, size=64, act_dtype="bf16", state="shipped", flops_weight=3.0,
-                            tol_fwd=None, tol_bwd=None, seed=51):
-    """Returns the worst relative L2 deviations {z, act, dz, dx, dparam} over all units."""
+                            tol_fwd=None, tol_bwd=None, seed=51, net=None):
+    """Returns the worst relative L2 deviations {z, act, dz, dx, dparam} over all units.  net = (model, layer_config, state_dict):
+    a prebuilt network (e.g. the pruned one) instead of the manifest's."""
+    global _LOCAL_NET
+    _LOCAL_NET = net
     import contextlib
     bf16 = act_dtype == "bf16"
     # the depthwise backward forms dz on load and skips the BatchNorm backward's apply pass; CSN_DEBUG_DZ (read at plan creation)
@@ -682,15 +685,31 @@ def check_train_units_local(lib, device, manifest, B=2, size=64, act_dtype="bf16
         del os.environ["CSN_DEBUG_DZ"]
 
 
+_LOCAL_NET = None
+
+
+def slim_network(manifest, tmp_path, thres=0.01):
+    """(model, layer_config, state_dict) of the prune-and-finetune result of the shipped weights (zero-channel branches / dilations)."""
+    m = M.build_model(predefine=manifest)
+    m.load_state_dict(O.load_weights(manifest))
+    new_cfg, mask = M.finetune_model(m, save_path=str(tmp_path), base_layer_config=M.load_layer_config(manifest), thres=thres)
+    slim = M.build_model_with_weight(new_cfg, m, mask)
+    return slim, new_cfg, {k: v.clone() for k, v in slim.state_dict().items()}
+
+
 def _check_train_units_local(lib, device, manifest, B, size, act_dtype, state, flops_weight, tol_fwd, tol_bwd, seed):
     import contextlib
     bf16 = act_dtype == "bf16"
     # bf16: one rounding of the output (2^-9 rms) + rare flips of rounded inputs; fp32: summation order only
     tol_fwd = tol_fwd if tol_fwd is not None else (2e-3 if bf16 else 2e-5)
     tol_bwd = tol_bwd if tol_bwd is not None else (3e-2 if bf16 else 2e-4)
-    sd = well_conditioned_state(manifest) if state == "well" else O.load_weights(manifest)
-    m = M.build_model(predefine=manifest)
-    m.load_state_dict(sd)
+    if _LOCAL_NET is not None:
+        m, net_cfg, sd = _LOCAL_NET
+    else:
+        sd = well_conditioned_state(manifest) if state == "well" else O.load_weights(manifest)
+        m = M.build_model(predefine=manifest)
+        m.load_state_dict(sd)
+        net_cfg = None
     m = m.to(device)
     m._lib = lib if device.type == "cpu" else None
     m.set_train_act_dtype(act_dtype)
@@ -715,7 +734,7 @@ def _check_train_units_local(lib, device, manifest, B, size, act_dtype, state, f
     for a in range(1, n_acts):
         for s in range(eng.n_consumers(a)):
             G[(a, s)] = eng.train_probe(a, f"grad{s}").cpu()
-    cfg = O.load_layer_config_json(manifest)
+    cfg = net_cfg if net_cfg is not None else O.load_layer_config_json(manifest)
     blocks = {b["name"]: b for b in O.block_table(cfg)}
     cfg3 = cfg[len(blocks):len(blocks) + 3]
     offs = m._arena.offsets
@@ -944,7 +963,7 @@ def check_unpruned(lib, device, expand, width, B=2, size=32, seed=4, train=True,
 
 def check_slim_network(lib, device, manifest, tmp_path, thres=0.01, B=2, H=32, W=48):
     """The prune-and-finetune result (finetune_model / build_model_with_weight; it has an output branch with ZERO channels)
-    through the kernels: eval forward and a train-mode forward + backward against the oracle."""
+    through the kernels: eval forward against the oracle (its train step: check_train_units_local(net=slim_network(...)))."""
     m = M.build_model(predefine=manifest)
     m.load_state_dict(O.load_weights(manifest))
     new_cfg, mask = M.finetune_model(m, save_path=str(tmp_path), base_layer_config=M.load_layer_config(manifest), thres=thres)

@@ -131,6 +131,14 @@ def test_emu_bf16_units_local_with_the_round4_kernels_switched(emu_lib, x2_manif
     print(P.check_train_units_local(emu_lib, CPU, x2_manifest, B=2, size=64, act_dtype="bf16", state="shipped"))
 
 
+@pytest.mark.parametrize("act_dtype", ["fp32", "bf16"])
+def test_emu_train_units_local_on_the_pruned_network(emu_lib, x2_manifest, tmp_path, act_dtype):
+    """The network the reference FINETUNES (finetune_model / build_model_with_weight: branches and dilations with zero channels, odd
+    channel counts): every unit's train-mode forward and backward inside the same unit-local bounds."""
+    net = P.slim_network(x2_manifest, tmp_path)
+    print(P.check_train_units_local(emu_lib, CPU, x2_manifest, B=2, size=64, act_dtype=act_dtype, net=net))
+
+
 def test_emu_bf16_trainer_steps_and_eval_afterwards(emu_lib, x2_manifest):
     """FusedTrainer in bf16 storage mode: a few optimizer steps move the parameters, the loss stays finite and close to the
     fp32 trainer's, and the eval-mode forward afterwards is the fp32 path (equal to the oracle on the updated state)."""

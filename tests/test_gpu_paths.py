@@ -48,6 +48,16 @@ def test_gpu_slim_network_forward(hip, x2_manifest, tmp_path):
     P.check_slim_network(lib, dev, x2_manifest, tmp_path, B=3, H=224, W=224)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("act_dtype", ["fp32", "bf16"])
+def test_gpu_slim_network_train_units_local(hip, x2_manifest, tmp_path, act_dtype):
+    """... and its train step (the reference finetunes exactly this network): every unit's forward and backward on the device inside
+    the unit-local bounds (zero-channel branches / dilations, odd channel counts)."""
+    lib, dev = hip
+    net = P.slim_network(x2_manifest, tmp_path)
+    print(P.check_train_units_local(lib, dev, x2_manifest, B=2, size=96, act_dtype=act_dtype, net=net))
+
+
 def _train_grad(lib, dev, manifest, x, t, B):
     from sod100k_amd.tools.train import FusedTrainer
     m, _ = P.make_model(lib, manifest, dev)
