@@ -292,3 +292,21 @@ def test_emu_results_do_not_depend_on_the_tile_geometry(emu_lib, x2_manifest, mo
     for k in ("60", "61"):
         for a, b in zip(out["40"], out[k]):
             assert torch.equal(a, b), k
+
+
+def test_emu_msblock_input_gradient_kernel_equals_the_generic_tap_kernel(emu_lib, x2_manifest, monkeypatch):
+    """ms_dx_kernel (one launch, every dz tap loaded once) against the two generic tap launches it replaced (CSN_MS_DX=0): the same sums
+    in another order -- all gradients equal to summation-order accuracy in fp32."""
+    out = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("CSN_MS_DX", sw)
+        m, sd = P.make_model(emu_lib, x2_manifest, CPU)
+        x = torch.from_numpy(I.randn_batch(5, 2, 64, 96))
+        t = torch.from_numpy(I.binary_target(6, 2, 64, 96))
+        m.train(); m.set_batchsize(2); m.clear_flops(); m.flops_hook(1.0)
+        y, pen = m._train_forward_raw(x)
+        loss, dy = P.bce_and_grad(emu_lib, y, t)
+        out[sw] = m._train_backward_raw(x, dy, 1.5).clone().double()
+    rel = float((out["1"] - out["0"]).norm() / out["0"].norm())
+    assert 0.0 < rel <= 1e-5, rel   # (> 0: the two runs really took different kernels)
+
