@@ -102,3 +102,19 @@ def test_csfnet_state_dict_matches_reference_manifest():
     d = net.describe_head(net._ensure_arena().offsets)
     assert list(d.cin) == [256, 512, 1024, 2048] and list(d.cmid) == [128, 256, 512, 512]
     assert [list(r) for r in d.ms_split] == [[25, 25, 25, 25, 28], [51, 51, 51, 51, 52], [102, 102, 102, 102, 104]] * 1 + [[102, 102, 102, 102, 104]]
+
+
+def test_flat_tile_index_arithmetic_is_exact_for_every_supported_plane():
+    """pw4 / c3q flat tiles (k_pw4.hip, k_c3q.hip): row = p / W through a float reciprocal and a +-1 correction.  Exact for every
+    plane width up to 2048 and every pixel index up to 2048 x 2048 + 63 (float32 model of the device arithmetic)."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    for W in list(range(1, 130)) + [224, 448, 1000, 1023, 1024, 1025, 2047, 2048]:
+        pmax = min(W * 2048 + 63, (1 << 22) - 1)
+        p = np.unique(np.concatenate([np.arange(0, min(pmax, 70000)), rng.integers(0, pmax + 1, 20000),
+                                      np.arange(max(pmax - 5000, 0), pmax + 1)])).astype(np.int64)
+        inv = np.float32(1.0) / np.float32(W)
+        q = (p.astype(np.float32) * inv).astype(np.int64)
+        q = q - (q * W > p)
+        q = q + ((q + 1) * W <= p)
+        assert np.array_equal(q, p // W), W
