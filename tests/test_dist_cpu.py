@@ -2,6 +2,7 @@
 import os
 import sys
 
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -194,23 +195,26 @@ def test_two_rank_gradient_allreduce_bf16(emu_lib):
     assert torch.equal(acc / 2, torch.from_numpy(res[0][3]))
 
 
-def test_bench_self_spawns_two_ranks(emu_lib):
-    """``python bench.py --gpus 2`` from a bare shell (no torchrun environment) must start its own two ranks, rendezvous on
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_self_spawns_n_ranks(emu_lib, n):
+    """``python bench.py --gpus N`` from a bare shell (no torchrun environment) must start its own N ranks, rendezvous on
     127.0.0.1, time the eval step and the train step WITH the gradient all-reduce, and print one JSON line whose ``nranks``
-    is the size of the communicator.  Here: gloo + the emulated kernels (``--emu-plumbing``; the line is marked invalid)."""
+    is the size of the communicator.  Here: gloo + the emulated kernels (``--emu-plumbing``; the line is marked invalid).
+    N = 8 is the driver's SCALE command for BASELINE config 4 (8 ranks: rank -> device mapping, port handling, MAX-reduced timing
+    and the all-reduce had only ever seen two ranks before round 5; no 8-GPU node has run it)."""
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env["OMP_NUM_THREADS"] = "2"
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--train-steps", "1", "--emu-plumbing"], env=env, capture_output=True, text=True, timeout=900)
+    env["OMP_NUM_THREADS"] = "2" if n == 2 else "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
+                        "--train-steps", "1", "--emu-plumbing"], env=env, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout                      # rank 0 only
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["nranks"] == 2 and out["backend"] == "gloo"
+    assert out["n_gpus"] == n and out["nranks"] == n and out["backend"] == "gloo"
     assert out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
-    assert out["config"]["global_batch"] == 2 * out["config"]["batch_per_gpu"]
+    assert out["config"]["global_batch"] == n * out["config"]["batch_per_gpu"]
     assert out["data"].startswith("INVALID")              # never mistaken for a measurement
     assert out["self_check"]["max_abs_vs_oracle"] <= 1e-4
     assert "all-reduce" in out["train_step"]["what"] and out["train_step"]["steps"] == 1

@@ -35,6 +35,16 @@ def test_gpu_unpruned_expand2_train_step_bf16(hip):
     print(f"unpruned x2 bf16 storage: gradient median rel err {mine:.2e}")
 
 
+@pytest.mark.parametrize("act_dtype", ["fp32", "bf16"])
+def test_gpu_unpruned_expand2_train_units_local(hip, x2_manifest, act_dtype):
+    """Every unit of the un-pruned expand-2 net (40-160 channels per branch: several M groups / row chunks per launch) judged
+    LOCALLY on the device's own tensors, fp32 and bf16 storage -- the sharp gate check_unpruned's whole-step yardstick is not."""
+    lib, dev = hip
+    net = P.unpruned_network(2.0, 40, seed=4)
+    worst = P.check_train_units_local(lib, dev, x2_manifest, B=2, size=64, act_dtype=act_dtype, net=net)
+    print(f"unpruned x2 unit-local [{act_dtype}] worst relative L2 per kind: {worst}")
+
+
 def test_gpu_unpruned_expand1(hip):
     lib, dev = hip
     P.check_unpruned(lib, dev, expand=1.0, width=20, B=2, size=64, seed=0)
@@ -133,15 +143,17 @@ def test_gpu_loss_goes_down(hip, x2_manifest, act_dtype):
         loss, pen = tr.step(xd, td)
         mine.append(float(loss)); pens.append(float(pen))
     ref = g["bce"]
+    end_dev = abs(np.mean(mine[-10:]) - np.mean(ref[-10:])) / np.mean(ref[-10:])
     print(f"{act_dtype}: bce {mine[0]:.4f} -> {mine[-1]:.4f}; reference {ref[0]:.4f} -> {ref[-1]:.4f}; "
-          f"max |diff| {max(abs(a - b) for a, b in zip(mine, ref)):.3e}")
+          f"max |diff| {max(abs(a - b) for a, b in zip(mine, ref)):.3e} (step {int(np.argmax([abs(a - b) for a, b in zip(mine, ref)]))}); "
+          f"first step {abs(mine[0] - ref[0]):.2e}, second {abs(mine[1] - ref[1]):.2e}, mean of the last ten: relative {end_dev:.2e}")
     assert mine[-1] < 0.6 * mine[0], mine
     assert np.mean(mine[-10:]) < np.mean(mine[10:20]) < np.mean(mine[:10])
     # Two free-running trajectories are NOT 1e-2 apart step by step: at lr 1e-3 the first updates move the ~1e-6-gamma channels of
     # the shipped checkpoint across PReLU kinks (the CPU emulation of these very kernels, fp32, is 4.5e-2 from the oracle at step 7
     # and back within 1.1 % at the end; with bf16 storage 0.13 / 1.5 %; MI355X bf16: 0.10 at step 8).  Hence: the first two steps
     # (same parameters up to one update) tight, the whole curve loose, the end of the run in between.
-    tol0, tol_curve, tol_end = (2e-3, 0.1, 0.05) if act_dtype == "fp32" else (3e-2, 0.3, 0.2)
+    tol0, tol_curve, tol_end = (2e-3, 0.1, 0.05) if act_dtype == "fp32" else (3e-2, 0.2, 0.1)
     assert abs(mine[0] - ref[0]) <= tol0 * max(1.0, abs(ref[0])) and abs(pens[0] - g["penalty"][0]) <= 5 * tol0 * max(1.0, g["penalty"][0])
     assert abs(mine[1] - ref[1]) <= 5 * tol0 * max(1.0, abs(ref[1])), (mine[:2], ref[:2])
     for k, (a, b) in enumerate(zip(mine, ref)):

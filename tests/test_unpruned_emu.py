@@ -108,3 +108,14 @@ def test_emu_unpruned_expand2_train_step(emu_lib):
     ref = np.array([float((r32["grads"][k].double() - g).norm() / (g.norm() + 1e-12)) for k, g in r64["grads"].items()])
     assert np.median(mine) <= 3 * np.median(ref) and mine.max() <= 3 * ref.max(), (np.median(mine), np.median(ref),
                                                                                   mine.max(), ref.max())
+
+
+import pytest
+
+
+@pytest.mark.parametrize("act_dtype", ["fp32", "bf16"])
+def test_emu_unpruned_expand2_train_units_local(emu_lib, x2_manifest, act_dtype):
+    """Every unit of the un-pruned expand-2 net judged locally (the GPU twin: tests/test_gpu_paths.py) -- the wide-channel launches
+    (several M groups / row chunks) of the train step, forward and backward."""
+    net = P.unpruned_network(2.0, 40, seed=4)
+    print(P.check_train_units_local(emu_lib, CPU, x2_manifest, B=2, size=32, act_dtype=act_dtype, net=net))
