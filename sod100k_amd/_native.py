@@ -115,22 +115,87 @@ def hipcc_path() -> Optional[str]:
     return None
 
 
+HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result")
+OBJ_DIR = os.path.join(CSRC, "build")      # per-source objects + the key each was compiled under (git-ignored)
+
+
+def _sha(*parts: bytes) -> str:
+    h = hashlib.sha256()
+    for p in parts:
+        h.update(p)
+    return h.hexdigest()[:16]
+
+
+_BUILD_TAG = b"CSN_BUILD_SOURCES_SHA16="
+
+
+def built_sources_sha16(path: Optional[str] = None) -> Optional[str]:
+    """The kernel-source hash a libcsnet_hip.so was BUILT from (the string behind the exported ``csn_build_sources_sha16``), or
+    None when the library is missing / predates the export.  Read from the file's bytes, not through dlopen: a library that is
+    already mapped under this path would be handed back by the loader even after the file has been replaced."""
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        return None
+    with open(path, "rb") as fh:
+        blob = fh.read()
+    i = blob.find(_BUILD_TAG)
+    if i < 0:
+        return None
+    return blob[i + len(_BUILD_TAG):i + len(_BUILD_TAG) + 16].decode("ascii", "replace")
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP sources for gfx950 into ``csrc/libcsnet_hip.so`` (in-tree, not installed)."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith((".h", ".inl"))] + \
-        [os.path.join(os.path.dirname(HERE), "include", h) for h in ("csnet_hip.h", "csf_hip.h")]
-    if not force and os.path.exists(LIB_PATH) and all(
-            os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+    """Compile the HIP sources for gfx950 into ``csrc/libcsnet_hip.so`` (in-tree, not installed).
+
+    Staleness is decided by CONTENT, not by mtimes (a prebuilt library that travels with the tree must not be
+    reused for other sources): the library exports the sha256 of the kernel sources it was built from
+    (``csn_build_sources_sha16``, compared again by ``load()``); a mismatch rebuilds.  Every source is its own hipcc job
+    (parallel), cached under csrc/build/ by the hash of (that source, every header, the flags)."""
+    want = sources_sha16()
+    if not force and built_sources_sha16() == want:
         return LIB_PATH
     hipcc = hipcc_path()
     if hipcc is None:
         raise RuntimeError("hipcc not found: cannot build libcsnet_hip.so")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-result", "-o", LIB_PATH] + srcs
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdr = b""
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".h", ".inl")):
+            hdr += f.encode() + open(os.path.join(CSRC, f), "rb").read()
+    for h in ("csnet_hip.h", "csf_hip.h"):
+        hdr += open(os.path.join(os.path.dirname(HERE), "include", h), "rb").read()
+    flags = " ".join(HIPCC_FLAGS).encode()
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(OBJ_DIR, src[:-4] + ".o")
+        key = _sha(open(os.path.join(CSRC, src), "rb").read(), hdr, flags)
+        keyf = obj + ".key"
+        if not force and os.path.exists(obj) and os.path.exists(keyf) and open(keyf).read() == key:
+            return obj
+        cmd = [hipcc, *HIPCC_FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        with open(keyf, "w") as fh:
+            fh.write(key)
+        return obj
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    # the build id: a host-only translation unit generated here
+    idc = os.path.join(OBJ_DIR, "csn_build_id.cpp")
+    with open(idc, "w") as fh:
+        fh.write('// generated by sod100k_amd/_native.py:build()\n'
+                 f'extern "C" const char* csn_build_sources_sha16(void) {{ return "CSN_BUILD_SOURCES_SHA16={want}" + 24; }}\n')
+    ido = os.path.join(OBJ_DIR, "csn_build_id.o")
+    subprocess.run([hipcc, "-O1", "-fPIC", "-c", idc, "-o", ido], check=True, cwd=CSRC)
+    tmp = LIB_PATH + ".tmp"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", tmp] + objs + [ido]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)
+    os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 
@@ -231,7 +296,7 @@ EXPORTS: Sequence[str] = (
     "csn_forward", "csn_forward_train", "csn_plan_enable_training", "csn_backward", "csn_bce_with_logits",
            "csn_adam_step", "csn_val_mae", "csn_saliency_u8", "csn_normalize_nchw", "csn_resize_normalize_nchw", "csn_saliency_resize_u8", "csn_resize_bilinear", "csn_sal_hist", "csn_forward_profile", "csn_profile_num_kernels", "csn_profile_bracket_us", "csn_profile_kernel", "csn_unit_kernel_name", "csn_unit_algorithmic_bytes",
     "csf_head_create", "csf_head_destroy", "csf_head_workspace_bytes", "csf_head_refresh_params", "csf_head_forward",
-    "csf_head_stage_info", "csf_head_macs", "csf_bn_act")
+    "csf_head_stage_info", "csf_head_macs", "csf_bn_act", "csn_build_sources_sha16")
 
 _lib: Optional[C.CDLL] = None
 
@@ -261,6 +326,19 @@ def load() -> C.CDLL:
         if got != ABI_VERSION:      # before bind(): a stale library fails here, not with an AttributeError on a new symbol
             raise RuntimeError(f"{LIB_PATH}: ABI version {got}, this package needs {ABI_VERSION} -- rebuild "
                                "(python -c 'import __graft_entry__ as g; g.build()')")
+        # ... and the library must have been built from THESE kernel sources (the .so travels with the tree, git-ignored: an
+        # edit without a rebuild would otherwise run stale kernels under fresh host code).  SOD100K_HIP_LIB (A/B variant builds of
+        # the same sources with extra -D flags) is the developer's own responsibility.
+        if not os.environ.get("SOD100K_HIP_LIB"):
+            try:
+                raw.csn_build_sources_sha16.restype = C.c_char_p
+                built = raw.csn_build_sources_sha16().decode()
+            except AttributeError:
+                built = None
+            want = sources_sha16()
+            if built != want:
+                raise RuntimeError(f"{LIB_PATH} was built from kernel sources {built}, the tree holds {want} -- rebuild "
+                                   "(python -c 'import __graft_entry__ as g; g.build()')")
         _lib = bind(raw)
     return _lib
 
