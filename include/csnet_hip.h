@@ -88,6 +88,10 @@ typedef struct csn_act_info {
 typedef struct csn_plan csn_plan;
 
 int csn_abi_version(void);
+/* sha256[:16] over the kernel sources (sod100k_amd/csrc: *.hip, *.h, *.inl) this library was BUILT from.  The host side
+ * (sod100k_amd/_native.py load()) compares it with the sources in the tree and refuses a stale library; bench lines and
+ * counter files carry the same stamp. */
+const char* csn_build_sources_sha16(void);
 const char* csn_strerror(int status);
 /* Text of the last failing HIP call of this thread (empty string if none). */
 const char* csn_last_hip_error(void);
