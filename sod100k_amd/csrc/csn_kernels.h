@@ -224,6 +224,36 @@ bool csn_pw4_pick(int nth, int ntl, int* pnth, int* pntl);
 int csn_launch_pw4(const Pw4Args& a, int raw, void* stream);
 
 // ---------------------------------------------------------------------------------------------
+// one whole ILBlock (1x1 gOctaveCBR -> depthwise pair) per launch, the block's planes in LDS (small maps; see k_ilb.hip)
+// ---------------------------------------------------------------------------------------------
+struct IlbDw {           // the two depthwise units of one branch, tables indexed by channel
+  const float* w9a; const float* sca; const float* sha; const float* ala;   // conv3x3_1: [C][9] (x100 folded), folded BN, PReLU
+  const float* w9b; const float* scb; const float* shb; const float* alb;   // conv3x3_2
+};
+struct IlbArgs {
+  const float* xh;     // [B][CH][2 Hl][2 Wl]   block inputs
+  const float* xl;     // [B][CL][Hl][Wl]
+  float* yh;           // [B][OH][2 Hl][2 Wl]   outputs of conv3x3_2
+  float* yl;           // [B][OL][Hl][Wl]       (unused when OL = 0)
+  const float* wimg;   // [ng][CH + CL][4][P]: pw4_kernel's image (CSN_PREP_PW4) of every group: tiles 0 .. nth-1 high rows, then low rows
+  const float* ep_h;   // conv1x1's {scale, shift, alpha, 0} per high / low output channel, padded to whole groups
+  const float* ep_l;
+  IlbDw dwh, dwl;
+  float* pool_h; float* pool_l;   // 2x2 averages of the outputs for a stride-2 unit that follows (null: none) ...
+  float* mp_h; float* mp_l;       // ... and the 2x2 maxima of those averages (c3q_kernel's high -> low slice)
+  int32_t skip_h, skip_l;         // the full-resolution output has no other reader
+  int32_t CH, CL, OH, OL, Hl, Wl, B;
+  int32_t ng, gimg_floats, nth, ntl;
+  int32_t Rh, Rl;                 // rows per depthwise task (even with pool_*, multiple of 4 with mp_*)
+  int32_t nthreads;
+  int32_t ph, pl, plane_h, plane_l;                               // LDS row pitches / plane sizes (floats), set by csn_ilb_layout
+  int32_t off_h1, off_h2, off_l1, off_l2, off_z, lds_floats;
+};
+size_t csn_ilb_layout(IlbArgs& a);          // fills the layout fields from (CH, CL, Hl, Wl, nth, ntl, Rh, Rl); LDS bytes, 0 = unsupported
+bool csn_ilb_supported(int nth, int ntl);
+int csn_launch_ilb(const IlbArgs& a, void* stream);
+
+// ---------------------------------------------------------------------------------------------
 // plain 1x1 contraction over own-resolution slices, raw output (input-gradient launches; see k_pwq.hip)
 // ---------------------------------------------------------------------------------------------
 struct PwqSrc {

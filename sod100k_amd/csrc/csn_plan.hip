@@ -141,6 +141,12 @@ struct UnitPlan {
   };
   std::vector<Pw4Launch> pw4l;
   int pw4 = 0;
+  // GOCT 1x1 at the head of an ILBlock whose planes fit the LDS: this unit + the fused depthwise pair behind it as ONE launch of
+  // ilb_kernel (k_ilb.hip); on = 0: not eligible
+  struct Ilb {
+    int on = 0, nth = 0, ntl = 0, ng = 0, gimg = 0, Rh = 4, Rl = 4;
+    int64_t wimg = -1, ep[2] = {-1, -1};
+  } ilb;
   int pw4_old_mask = 0;              // output branches that stay on goct_pw_kernel (CSFHead.fuse's lowest branch)
   // MS
   int64_t ms_w[5] = {-1, -1, -1, -1, -1};
@@ -172,6 +178,8 @@ struct csn_plan {
                           // in its own workspace region
   bool c3q = true;        // CSN_OPT_C3Q: eval-mode 3x3 passes on c3q_kernel (k_c3q.hip)
   int c3q_cap = 4;        // its row tiles per M group (CSN_C3Q_NT, experiments)
+  bool ilb = true;        // CSN_OPT_FUSE_ILB / CSN_ILB=0: whole ILBlocks of the small maps on ilb_kernel (k_ilb.hip, round 5)
+  int ilb_nt = 1;         // its row tiles per group and branch (CSN_ILB_NT=2: experiments)
   bool pw4 = true;        // CSN_OPT_PW4: two-branch 1x1 units on pw4_kernel (k_pw4.hip)
   int pw4_grid = 2048;    // its block cap (CSN_PW4_GRID, experiments)
   int pw4_twl = 6;        // log2 of its widest tile in low pixels: whole rows of up to 64 (CSN_PW4_TWL; 4 = 16 x 4 tiles: 1 % slower)
@@ -787,6 +795,78 @@ int plan_cls(Builder& bl, UnitPlan& u) {
   L.passes.push_back(ps);
   u.pwl.push_back(L);
   return finish_launch(bl, u.pwl.back());
+}
+
+// Whole ILBlock on ilb_kernel (k_ilb.hip): unit k is a two-input 1x1 gOctaveCBR whose outputs are read only by the fused depthwise
+// pair (k + 1, k + 2), and the planes of a group of output channels fit the LDS of a CU.  Lays out the per-group weight images
+// (pw4_kernel's [K][4][P] form, uniform groups of nth high + ntl low row tiles) and the epilogue records.
+int plan_ilb(Builder& bl, int k) {
+  csn_plan& P = bl.P;
+  if (k + 2 >= (int)P.units.size()) return CSN_OK;
+  UnitPlan& u = P.units[k];
+  const csn_unit_desc& d = u.d;
+  const UnitPlan& d1 = P.units[k + 1];
+  const UnitPlan& d2 = P.units[k + 2];
+  if (d.kind != CSN_UNIT_GOCT || d.ksize != 1 || d.stride != 1 || u.std_conv || d.n_in != 2 || d.cin[0] <= 0 || d.cin[1] <= 0) return CSN_OK;
+  if (d.n_out < 1 || d.n_out > 2 || d.cout[0] <= 0) return CSN_OK;
+  if (d1.d.kind != CSN_UNIT_DW || d2.d.kind != CSN_UNIT_DW || !d1.fuse_next || d1.d.n_in != d.n_out) return CSN_OK;
+  for (int j = 0; j < d.n_out; ++j) {
+    if (d1.d.cin[j] != d.cout[j]) return CSN_OK;
+    if (d.cout[j] == 0) continue;
+    if (d1.d.in_act[j] != d.out_act[j]) return CSN_OK;
+    for (int q = 0; q < (int)P.units.size(); ++q) {   // nobody but the pair reads the 1x1 unit's outputs
+      if (q == k + 1) continue;
+      for (int s = 0; s < CSN_MAX_BRANCH; ++s)
+        if (s < P.units[q].d.n_in && P.units[q].d.cin[s] > 0 && P.units[q].d.in_act[s] == d.out_act[j]) return CSN_OK;
+    }
+  }
+  const int OH = d.cout[0], OL = d.n_out >= 2 ? d.cout[1] : 0;
+  int cin_tot = d.cin[0] + d.cin[1];
+  const int co_off[2] = {0, OH}, ci_off[2] = {0, d.cin[0]};
+  IlbArgs a = {};
+  a.CH = d.cin[0]; a.CL = d.cin[1]; a.OH = OH; a.OL = OL;
+  a.Hl = P.H >> (u.base_lvl + 1); a.Wl = P.W >> (u.base_lvl + 1); a.B = P.S;
+  a.Rh = 4; a.Rl = 4;
+  a.nth = P.ilb_nt; a.ntl = OL > 0 ? P.ilb_nt : 0;
+  if (!csn_ilb_supported(a.nth, a.ntl)) return CSN_OK;
+  size_t lds = csn_ilb_layout(a);
+  if ((lds == 0 || lds > 160 * 1024) && a.nth > 1) {   // the planes of a narrower group
+    a.nth = 1; a.ntl = OL > 0 ? 1 : 0;
+    lds = csn_ilb_layout(a);
+  }
+  if (lds == 0 || lds > 160 * 1024) return CSN_OK;
+  const int th = (OH + 3) / 4, tl = (OL + 3) / 4;
+  const int ng = std::max((th + a.nth - 1) / a.nth, a.ntl > 0 ? (tl + a.ntl - 1) / a.ntl : 0);
+  const int NT4 = (a.nth + a.ntl + 3) & ~3, Pp = PW4_PITCH(NT4);
+  UnitPlan::Ilb& I = u.ilb;
+  I.nth = a.nth; I.ntl = a.ntl; I.ng = ng; I.gimg = a.gimg_floats; I.Rh = a.Rh; I.Rl = a.Rl;
+  I.wimg = bl.alloc_packed((int64_t)ng * I.gimg);
+  for (int g = 0; g < ng; ++g) {
+    const int64_t img = I.wimg + (int64_t)g * I.gimg;
+    const int r0h = 4 * a.nth * g, r0l = 4 * a.ntl * g;
+    const int nrh = std::max(0, std::min(4 * a.nth, OH - r0h)), nrl = a.ntl > 0 ? std::max(0, std::min(4 * a.ntl, OL - r0l)) : 0;
+    int k0 = 0;
+    for (int i = 0; i < 2; ++i) {   // gathered channels: branch 0 (high), branch 1 (low)
+      if (nrh > 0)
+        bl.job(CSN_PREP_PW4, nrh, img, d.w_off[0] + (int64_t)(co_off[0] + r0h) * cin_tot + ci_off[i], -1, -1, -1, 1.f, cin_tot, d.cin[i],
+               Pp, 0 | (k0 << 8));
+      if (nrl > 0)
+        bl.job(CSN_PREP_PW4, nrl, img, d.w_off[0] + (int64_t)(co_off[1] + r0l) * cin_tot + ci_off[i], -1, -1, -1, 1.f, cin_tot, d.cin[i],
+               Pp, a.nth | (k0 << 8));
+      k0 += d.cin[i];
+    }
+  }
+  for (int q = 0; q < 2; ++q) {
+    const int C = q == 0 ? OH : OL;
+    if (C <= 0) continue;
+    const int rows = 4 * ng * (q == 0 ? a.nth : a.ntl) + 4;
+    I.ep[q] = bl.alloc_packed((int64_t)rows * 4);
+    bl.job(CSN_PREP_BN_SCALE, C, I.ep[q], d.bn[q].weight, d.bn[q].running_var, -1, -1, 1.f, 0, 0, 4, 0);
+    bl.job(CSN_PREP_BN_SHIFT, C, I.ep[q], d.bn[q].weight, d.bn[q].running_var, d.bn[q].bias, d.bn[q].running_mean, 1.f, 0, 0, 4, 1);
+    bl.job(CSN_PREP_COPY, C, I.ep[q], d.bn[q].prelu, -1, -1, -1, 1.f, 0, 0, 4, 2);
+  }
+  I.on = 1;
+  return CSN_OK;
 }
 
 // ------------------------------------------------------------------------------------ execution
@@ -1406,6 +1486,46 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
   return CSN_OK;
 }
 
+// units k, k + 1, k + 2 (1x1 gOctaveCBR + depthwise pair) as one launch of ilb_kernel (eval forward)
+int run_ilb(const Ctx& c, int k) {
+  const csn_plan& P = c.P;
+  const UnitPlan& u = P.units[k];
+  const UnitPlan& d1 = P.units[k + 1];
+  const UnitPlan& d2 = P.units[k + 2];
+  const csn_unit_desc& d = u.d;
+  const UnitPlan::Ilb& I = u.ilb;
+  IlbArgs a = {};
+  a.CH = d.cin[0]; a.CL = d.cin[1]; a.OH = d.cout[0]; a.OL = d.n_out >= 2 ? d.cout[1] : 0;
+  a.Hl = P.H >> (u.base_lvl + 1); a.Wl = P.W >> (u.base_lvl + 1); a.B = P.S;
+  a.nth = I.nth; a.ntl = I.ntl; a.ng = I.ng; a.Rh = I.Rh; a.Rl = I.Rl;
+  if (csn_ilb_layout(a) == 0 || a.gimg_floats != I.gimg) return CSN_E_STATE;
+  a.xh = c.act_in(d.in_act[0]); a.xl = c.act_in(d.in_act[1]);
+  a.yh = c.act_out(d2.d.out_act[0]);
+  a.yl = a.OL > 0 ? c.act_out(d2.d.out_act[1]) : nullptr;
+  a.wimg = c.pk(I.wimg);
+  a.ep_h = c.pk(I.ep[0]);
+  a.ep_l = I.ep[1] >= 0 ? c.pk(I.ep[1]) : nullptr;
+  for (int j = 0; j < 2; ++j) {
+    if (j == 1 && a.OL == 0) break;
+    IlbDw& w = j == 0 ? a.dwh : a.dwl;
+    w.w9a = c.pk(d1.dw_w[j]); w.sca = c.pk(d1.dw_epi[j].scale); w.sha = c.pk(d1.dw_epi[j].shift); w.ala = c.pk(d1.dw_epi[j].alpha);
+    w.w9b = c.pk(d2.dw_w[j]); w.scb = c.pk(d2.dw_epi[j].scale); w.shb = c.pk(d2.dw_epi[j].shift); w.alb = c.pk(d2.dw_epi[j].alpha);
+    const int Wj = P.W >> (u.base_lvl + j);
+    if (d1.pool_unit >= 0 && (Wj % 4) == 0) {   // the stride-2 unit that follows reads the 2x2 averages (+ their 2x2 maxima)
+      float* pool = reinterpret_cast<float*>(c.ws + P.units[d1.pool_unit].pooled_off[j]);
+      float* mp = dw_pair_writes_mp(P, d1, j) ? reinterpret_cast<float*>(c.ws + P.units[d1.pool_unit].mp_off[j]) : nullptr;
+      if (j == 0) { a.pool_h = pool; a.mp_h = mp; a.skip_h = d1.pool_skip[j]; }
+      else { a.pool_l = pool; a.mp_l = mp; a.skip_l = d1.pool_skip[j]; }
+    }
+  }
+  LAUNCH_TRY(csn_launch_ilb(a, c.stream));
+  return c.mark("ilb_kernel");
+}
+
+// ... which needs what the stride-2 consumer's planning expects of the pair in front of it
+bool ilb_active(const csn_plan& P, int k) {
+  return P.ilb && P.fuse_dw && k >= 0 && k + 2 < (int)P.units.size() && P.units[k].ilb.on;
+}
 
 }  // namespace
 
@@ -1523,6 +1643,8 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   if (std::getenv("CSN_PW4_NOSPLIT")) P->pw4_nosplit = true;
   if (std::getenv("CSN_PW4_NOQ")) P->pw4_no_q = true;
   if (const char* e = std::getenv("CSN_PW4_FLAT")) P->pw4_flat = std::atoi(e) != 0;
+  if (const char* e = std::getenv("CSN_ILB")) P->ilb = std::atoi(e) != 0;
+  if (const char* e = std::getenv("CSN_ILB_NT")) P->ilb_nt = std::atoi(e) == 2 ? 2 : 1;
   if (const char* e = std::getenv("CSN_C3Q16")) P->c3q16 = std::atoi(e);
   if (const char* e = std::getenv("CSN_PWQ16")) P->pwq16 = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_MS_DX")) P->ms_dx = std::atoi(e) != 0;
@@ -1623,6 +1745,10 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
       P->units[k].pool_skip[i] = only ? 1 : 0;
     }
   }
+  for (int k = 0; k + 2 < n_units; ++k) {   // whole ILBlocks of the small maps on ilb_kernel
+    const int st = plan_ilb(bl, k);
+    if (st != CSN_OK) { delete P; return st; }
+  }
   // cls fusion: a single-output, single-launch 1x1 unit whose only reader is the cls_layer that follows it
   for (int k = 0; k + 1 < n_units; ++k) {
     const csn_unit_desc& a = P->units[k].d;
@@ -1697,7 +1823,7 @@ int csn_plan_set_option(csn_plan* P, int32_t option, int32_t value) {
     case CSN_OPT_PW4: P->pw4 = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_C3Q: P->c3q = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_SLICE_LANES: P->slice_lanes = value != 0; drop_graph(P); return CSN_OK;
-    case CSN_OPT_FUSE_ILB: return CSN_OK;   // retired (round 3): accepted and ignored
+    case CSN_OPT_FUSE_ILB: P->ilb = value != 0; drop_graph(P); return CSN_OK;   // (round 5: ilb_kernel, k_ilb.hip)
     case CSN_OPT_OVERLAP: P->overlap = value != 0; P->overlap_bwd = value == 2; drop_graph(P); return CSN_OK;
     case CSN_OPT_TRAIN_BF16:
       if (P->act_half && value == 0) { g_hip_err = "the workspace of this plan is laid out for bfloat16 tensors"; return CSN_E_STATE; }
@@ -1820,6 +1946,13 @@ static int forward_body(csn_plan* P, const float* x, float* y, void* workspace, 
             u += m - 1;
             continue;
           }
+        }
+        if (ilb_active(*P, u)) {   // the whole ILBlock (1x1 unit + depthwise pair) as one launch
+          const int st = run_ilb(c, u);
+          if (st != CSN_OK) { P->profiling = false; return st; }
+          if (prof) unit_of_tag.resize(P->tags.size(), u);
+          u += 2;
+          continue;
         }
         const bool fuse = u + 1 < nu && ((P->fuse_dw && P->units[u].fuse_next) || (P->fuse_cls && P->units[u].fuse_cls));
         const size_t t0 = P->tags.size();
@@ -1996,6 +2129,7 @@ static int forward_train_body(csn_plan* P, const float* x, float* y, void* works
 
 const char* csn_unit_kernel_name(const csn_plan* P, int32_t u) {
   if (!P || u < 0 || u >= (int)P->units.size()) return "";
+  if (ilb_active(*P, u) || (u >= 1 && ilb_active(*P, u - 1)) || (u >= 2 && ilb_active(*P, u - 2))) return "ilb_kernel";
   if (P->fuse_dw && P->units[u].d.kind == CSN_UNIT_DW) {
     if (P->units[u].fuse_next || (u > 0 && P->units[u - 1].fuse_next)) return "dw3x3x2_bn_prelu_kernel";
   }

@@ -1,0 +1,394 @@
+// k_ilb.hip -- one whole ILBlock (conv1x1 -> conv3x3_1 -> conv3x3_2, CSNet/model/csnet.py:17-76) in ONE launch, for the small maps
+// (stages 3-4 of csnet-L-x2 at 224 x 224: 56^2 / 28^2 / 14^2 planes).  Round 5.
+//
+// Reference semantics: ILBlock.forward (csnet.py:72-76) = gOctaveCBR with 1x1 kernels (664-726, 778-792: y_h = W_hh x_h +
+// bilinear_up2(W_hl x_l), y_l = W_ll x_l + W_lh max_pool2(x_h), then per-branch BN + PReLU) followed by two
+// SimplifiedGOctConvBR (795-851: depthwise 3x3, padding 1, x100 weights (conv2d.py:104), BN, PReLU per branch).
+//
+// Why: on these maps the three units were two launches of 13-23 us each whatever their size (profiles/r4_unit_table.md: 20 units =
+// 40 launches = 0.46 ms for 11 % of the forward's bytes) -- latency chains, not bandwidth.  Round 2's whole-ILBlock kernel (lane =
+// pixel with every channel in registers) lost because the depthwise stages need wave-uniform weights per CHANNEL; its conclusion
+// was "fusion has to keep the per-channel-block structure of the depthwise pair, i.e. transposition through LDS".  This is that:
+//   * work item = (image, group of 4 NTH high + 4 NTL low OUTPUT channels).  The rows of a 1x1 convolution are independent, and
+//     the depthwise units are per channel, so an item needs ALL input channels of its image (small, L2 / Infinity Cache resident)
+//     but no halo and no recomputation: the group's whole planes live in LDS from the contraction to the last store.
+//   * phase 1 (contraction, k_pw4.hip's scheme): lane = one low pixel + its 2x2 high quad, v_mfma_f32_4x4x1 with the loaded value
+//     as the B operand.  The low -> high term is evaluated in the REFERENCE's order, conv at low resolution then interpolate
+//     (csnet.py:702-707): z = W_hl x_l costs NTH matrix instructions per low channel instead of nine loads and a dozen vector
+//     instructions per low INPUT channel and item; z goes through LDS and its bilinear x2 is added per OUTPUT channel.
+//   * BN + PReLU on the accumulators, rows of four channels to their LDS planes [channel][H + 2][W + 4] (zero frame = the
+//     depthwise convolutions' padding; the four zero columns in front of a row double as the right frame of the row above).
+//   * phases 2, 3 (depthwise pair, k_misc.hip dw3x3x2's arithmetic): a lane owns a strip of four columns x R rows of ONE channel,
+//     rolling three-row window read from LDS (one 128-bit + two 32-bit reads per row), conv3x3_1 -> second LDS plane, conv3x3_2
+//     -> HBM (+ the 2x2 averages / their 2x2 maxima for a stride-2 unit that follows, as dw3x3x2 delivers them).
+// HBM traffic = block inputs (once per group, from L2) + block outputs: the two intermediate tensors never leave the CU.
+#include "pw4_common.h"
+
+namespace {
+
+// contract `n` (<= LB) low-branch channels: the centre value -> z rows (the high rows of the weight image, at LOW resolution)
+// and -> low rows
+template <int NTH, int NTL, int LB, int P, bool GUARD>
+__device__ __forceinline__ void ilb_lo_batch(const float (&v)[LB], const float* wk, int n, csn_f4 (&accz)[NTH], csn_f4 (&accl)[NTL > 0 ? NTL : 1]) {
+  constexpr int NT4 = (NTH + NTL + 3) & ~3;
+#pragma unroll
+  for (int j = 0; j < LB; ++j) {
+    if (GUARD && j >= n) break;
+    Pw4A<NT4> a;
+    pw4_load_a<NT4, P>(wk + j * 4 * P, a);
+#pragma unroll
+    for (int t = 0; t < NTH; ++t) pw4_mfma<NT4>(a, t, v[j], accz[t]);
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) pw4_mfma<NT4>(a, NTH + t, v[j], accl[t]);
+  }
+}
+
+template <int LB>
+__device__ __forceinline__ void ilb_load_lo(csn_buf rb, unsigned o, unsigned cs, int k0, int C, float (&v)[LB]) {
+#pragma unroll
+  for (int j = 0; j < LB; ++j) v[j] = csn_ld1(rb, o, (unsigned)min(k0 + j, C - 1) * cs);
+}
+
+struct IlbRow { float v[6]; };   // [0] = x0 - 1, [1..4] = x0 .. x0 + 3, [5] = x0 + 4
+
+__device__ __forceinline__ IlbRow ilb_ld_row(const float* p) {   // p = column x0 of the row inside an LDS plane (16-byte aligned)
+  IlbRow r;
+  const float4 c = *reinterpret_cast<const float4*>(p);
+  r.v[0] = p[-1]; r.v[1] = c.x; r.v[2] = c.y; r.v[3] = c.z; r.v[4] = c.w; r.v[5] = p[4];
+  return r;
+}
+
+__device__ __forceinline__ void ilb_dw4(const float (&w)[9], const IlbRow& top, const IlbRow& mid, const IlbRow& bot, float sc, float sh,
+                                        float al, float (&o)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {   // dw_emit's chain (k_misc.hip): bit-identical to the unit kernels on identical inputs
+    float acc = w[0] * top.v[j];
+    acc = fmaf(w[1], top.v[j + 1], acc);
+    acc = fmaf(w[2], top.v[j + 2], acc);
+    acc = fmaf(w[3], mid.v[j], acc);
+    acc = fmaf(w[4], mid.v[j + 1], acc);
+    acc = fmaf(w[5], mid.v[j + 2], acc);
+    acc = fmaf(w[6], bot.v[j], acc);
+    acc = fmaf(w[7], bot.v[j + 1], acc);
+    acc = fmaf(w[8], bot.v[j + 2], acc);
+    o[j] = csn_epi(acc, sc, sh, al);
+  }
+}
+
+// one depthwise unit over the group's planes of one branch: tasks (channel, row chunk, strip) of `nch` channels.
+// LAST = false: LDS plane `src` -> LDS plane `dst`;  LAST = true: -> HBM (+ pooled copies)
+template <bool LAST>
+__device__ __forceinline__ void ilb_dw_branch(int task, const float* src, float* dst, int plane, int pitch, int H, int W, int R, int nstrip,
+                                              int nrc, csn_cfp w9, csn_cfp scp, csn_cfp shp, csn_cfp alp, int c0, float* __restrict__ out,
+                                              float* __restrict__ pool, float* __restrict__ pmax, int skip_out) {
+  const int c = task / (nstrip * nrc), rem = task - c * (nstrip * nrc);
+  const int rc = rem / nstrip, s = rem - rc * nstrip;
+  const int x0 = 4 * s, y0 = rc * R;
+  float w[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) w[i] = w9[(c0 + c) * 9 + i];
+  const float sc = scp[c0 + c], sh = shp[c0 + c], al = alp[c0 + c];
+  const float* base = src + c * plane + 4 + x0;   // column x0 of plane row 0 (= image row -1)
+  IlbRow top = ilb_ld_row(base + y0 * pitch), mid = ilb_ld_row(base + (y0 + 1) * pitch);
+  const bool full = x0 + 4 <= W;
+  float mx = 0.f, e0 = 0.f, e1 = 0.f;
+  for (int q = 0; q < R; ++q) {
+    const int y = y0 + q;
+    if (y >= H) break;
+    const IlbRow bot = ilb_ld_row(base + (y + 2) * pitch);
+    float o[4];
+    ilb_dw4(w, top, mid, bot, sc, sh, al, o);
+    if (!LAST) {
+      float* d = dst + c * plane + (y + 1) * pitch + 4 + x0;
+      if (full) {
+        *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {   // the columns past W stay zero: they are the second unit's padding
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (x0 + j < W) d[j] = o[j];
+      }
+    } else {
+      float* g = out + (int64_t)c * H * W + (int64_t)y * W + x0;
+      if (pool) {   // avg_pool2d(2, 2) of the block's output (csnet.py:679-680 of the stride-2 unit that follows) and the 2x2
+                    // maximum of those averages, in dw3x3x2_bn_prelu_kernel's summation order (W % 4 == 0, R % 2 / % 4 == 0)
+        if ((q & 1) == 0) {
+          e0 = o[0] + o[1];
+          e1 = o[2] + o[3];
+        } else {
+          float2 pv;
+          pv.x = (e0 + o[0] + o[1]) * 0.25f;
+          pv.y = (e1 + o[2] + o[3]) * 0.25f;
+          *reinterpret_cast<float2*>(pool + (int64_t)c * (H >> 1) * (W >> 1) + (int64_t)(y >> 1) * (W >> 1) + (x0 >> 1)) = pv;
+          if (pmax) {
+            if ((q & 3) == 1) mx = fmaxf(pv.x, pv.y);
+            else pmax[(int64_t)c * (H >> 2) * (W >> 2) + (int64_t)(y >> 2) * (W >> 2) + (x0 >> 2)] = fmaxf(mx, fmaxf(pv.x, pv.y));
+          }
+        }
+      }
+      if (!skip_out) {
+        if (full && (W & 3) == 0) {
+          *reinterpret_cast<float4*>(g) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (x0 + j < W) g[j] = o[j];
+        }
+      }
+    }
+    top = mid;
+    mid = bot;
+  }
+}
+
+}  // namespace
+
+template <int NTH, int NTL>
+__global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
+  constexpr int NT4 = (NTH + NTL + 3) & ~3, P = PW4_PITCH(NT4);
+  constexpr int HB = 4, LB = 8;
+  CSN_DYN_SMEM(float, lds);
+  const CSN_CONST_AS IlbArgs* a = CSN_KERNARG(IlbArgs, a_byval);
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  // items in XCD-aware order: XCD x = blockIdx.x & 7 takes the images [x * ipx, (x + 1) * ipx) with all their groups, so that the
+  // groups of an image (which read the same inputs) share one L2
+  const int ng = a->ng;
+  const int ipx = (a->B + 7) >> 3;
+  const int xcd = blockIdx.x & 7, idx = (int)(blockIdx.x >> 3);
+  const int b = xcd * ipx + idx / ng, g = idx % ng;
+  if (idx >= ipx * ng || b >= a->B) return;
+  const int CH = a->CH, CL = a->CL, OH = a->OH, OL = a->OL, Hl = a->Hl, Wl = a->Wl, Hh = 2 * Hl, Wh = 2 * Wl;
+  const int HWl = Hl * Wl;
+  const int ph = a->ph, pl = a->pl, plane_h = a->plane_h, plane_l = a->plane_l;
+  float* H1 = lds + a->off_h1;
+  float* H2 = lds + a->off_h2;
+  float* L1 = lds + a->off_l1;
+  float* L2 = lds + a->off_l2;
+  float* Z = lds + a->off_z;
+  const int r0h = 4 * NTH * g, r0l = 4 * NTL * g;                       // first high / low output channel of the group
+  const int nch_h = max(0, min(4 * NTH, OH - r0h)), nch_l = NTL > 0 ? max(0, min(4 * NTL, OL - r0l)) : 0;
+
+  // ---- phase 0: the group's weight image; zero frame (whole planes: the interiors are overwritten below) ----
+  {
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(a->wimg + (int64_t)g * a->gimg_floats);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    for (int i = tid; i < (a->gimg_floats >> 2); i += nthr) dst[i] = src[i];
+    float4* zp = reinterpret_cast<float4*>(lds + a->off_h1);
+    const int nz4 = (a->off_z - a->off_h1) >> 2;
+    for (int i = tid; i < nz4; i += nthr) zp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+
+  // ---- phase 1: contraction.  Wave w owns the 64 consecutive low pixels [64 w, 64 w + 64) of the plane (flat tiles, k_pw4.hip);
+  // the launcher provides a wave per tile, so the accumulators survive the barrier the z exchange needs ----
+  const int lane = tid & 63, wave = pw4_uniform(tid >> 6);
+  const int pix = wave * 64 + lane;
+  const bool tile_on = wave * 64 < HWl;
+  const bool valid = pix < HWl;
+  const int pc = min(pix, HWl - 1);
+  const int y = pc / Wl, x = pc - y * Wl;
+  csn_f4 acch[4][NTH], accz[NTH], accl[NTL > 0 ? NTL : 1];
+#pragma unroll
+  for (int t = 0; t < NTH; ++t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      accz[t][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acch[s][t][i] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < (NTL > 0 ? NTL : 1); ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accl[t][i] = 0.f;
+  if (tile_on) {
+#ifdef CSN_CPU_EMU
+    const float* wg = lds;
+#else
+    const float* wg = lds + (lane & 3) * P;
+#endif
+    const unsigned csl = (unsigned)HWl * 4u, csh = csl * 4u;
+    const unsigned oh0 = (unsigned)((2 * y) * Wh + 2 * x) * 4u, oh1 = oh0 + (unsigned)Wh * 4u, olc = (unsigned)pc * 4u;
+    const csn_buf rbh = csn_make_buf_n(reinterpret_cast<const char*>(a->xh) + (int64_t)b * CH * (int64_t)csh, (unsigned)CH * csh);
+    const csn_buf rbl = csn_make_buf_n(reinterpret_cast<const char*>(a->xl) + (int64_t)b * CL * (int64_t)csl, (unsigned)CL * csl);
+    // high channels: quad -> high rows, 2x2 maximum -> low rows (pw4_hi_batch); batch k0 contracted while k0 + HB is in flight
+    float2 hA[HB][2], hB[HB][2];
+    float lA[LB], lB[LB];
+    pw4_load_hi<HB>(rbh, oh0, oh1, csh, 0, CH, hA);
+    PW4_FENCE();
+    const int nfh = (CH - 1) / HB;
+    int k0 = 0;
+    for (int p = 0; p < (nfh >> 1); ++p) {
+      pw4_load_hi<HB>(rbh, oh0, oh1, csh, k0 + HB, CH, hB);
+      PW4_FENCE();
+      pw4_hi_batch<NTH, NTL, HB, P, false>(hA, wg + k0 * 4 * P, HB, acch, accl);
+      pw4_load_hi<HB>(rbh, oh0, oh1, csh, k0 + 2 * HB, CH, hA);
+      PW4_FENCE();
+      pw4_hi_batch<NTH, NTL, HB, P, false>(hB, wg + (k0 + HB) * 4 * P, HB, acch, accl);
+      k0 += 2 * HB;
+    }
+    if (nfh & 1) {
+      pw4_load_hi<HB>(rbh, oh0, oh1, csh, k0 + HB, CH, hB);
+      PW4_FENCE();
+      pw4_hi_batch<NTH, NTL, HB, P, false>(hA, wg + k0 * 4 * P, HB, acch, accl);
+      k0 += HB;
+#pragma unroll
+      for (int j = 0; j < HB; ++j) { hA[j][0] = hB[j][0]; hA[j][1] = hB[j][1]; }
+    }
+    ilb_load_lo<LB>(rbl, olc, csl, 0, CL, lA);
+    PW4_FENCE();
+    pw4_hi_batch<NTH, NTL, HB, P, true>(hA, wg + k0 * 4 * P, CH - k0, acch, accl);
+    // low channels: the centre value -> z rows and low rows
+    const float* wgl = wg + CH * 4 * P;
+    const int nfl = (CL - 1) / LB;
+    int c0 = 0;
+    for (int p = 0; p < (nfl >> 1); ++p) {
+      ilb_load_lo<LB>(rbl, olc, csl, c0 + LB, CL, lB);
+      PW4_FENCE();
+      ilb_lo_batch<NTH, NTL, LB, P, false>(lA, wgl + c0 * 4 * P, LB, accz, accl);
+      ilb_load_lo<LB>(rbl, olc, csl, c0 + 2 * LB, CL, lA);
+      PW4_FENCE();
+      ilb_lo_batch<NTH, NTL, LB, P, false>(lB, wgl + (c0 + LB) * 4 * P, LB, accz, accl);
+      c0 += 2 * LB;
+    }
+    if (nfl & 1) {
+      ilb_load_lo<LB>(rbl, olc, csl, c0 + LB, CL, lB);
+      PW4_FENCE();
+      ilb_lo_batch<NTH, NTL, LB, P, false>(lA, wgl + c0 * 4 * P, LB, accz, accl);
+      c0 += LB;
+#pragma unroll
+      for (int j = 0; j < LB; ++j) lA[j] = lB[j];
+    }
+    ilb_lo_batch<NTH, NTL, LB, P, true>(lA, wgl + c0 * 4 * P, CL - c0, accz, accl);
+    if (valid) {   // z = W_hl x_l at the low resolution, one plane per high row of the group
+#pragma unroll
+      for (int t = 0; t < NTH; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Z[(4 * t + i) * HWl + pix] = accz[t][i];
+    }
+  }
+  __syncthreads();
+  if (tile_on && valid) {
+    // y_h = W_hh x_h + bilinear_up2(z) (csnet.py:702-707,720-722: the branches are summed in input order), then BN + PReLU
+    int zo[9];
+    {
+      const int yy[3] = {max(y - 1, 0), y, min(y + 1, Hl - 1)};
+      const int xx[3] = {max(x - 1, 0), x, min(x + 1, Wl - 1)};
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) zo[3 * r + c] = yy[r] * Wl + xx[c];
+    }
+    csn_cfp eph = csn_const(a->ep_h) + 4 * r0h;
+    float* h1 = H1 + (2 * y + 1) * ph + 4 + 2 * x;
+#pragma unroll
+    for (int t = 0; t < NTH; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * t + i;
+        if (r < nch_h) {
+          float v[9], q[4];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) v[k] = Z[r * HWl + zo[k]];
+          pw4_up2_quad(v, q);
+          float o[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) o[s] = pw4_epi(acch[s][t][i] + q[s], eph[4 * r], eph[4 * r + 1], eph[4 * r + 2]);
+          *reinterpret_cast<float2*>(h1 + r * plane_h) = make_float2(o[0], o[1]);
+          *reinterpret_cast<float2*>(h1 + r * plane_h + ph) = make_float2(o[2], o[3]);
+        }
+      }
+    if (NTL > 0) {
+      csn_cfp epl = csn_const(a->ep_l) + 4 * r0l;
+      float* l1 = L1 + (y + 1) * pl + 4 + x;
+#pragma unroll
+      for (int t = 0; t < NTL; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * t + i;
+          if (r < nch_l) l1[r * plane_l] = pw4_epi(accl[t][i], epl[4 * r], epl[4 * r + 1], epl[4 * r + 2]);
+        }
+    }
+  }
+  __syncthreads();
+
+  // ---- phases 2, 3: the depthwise pair, tasks = (channel, row chunk, strip of four columns), high planes then low planes ----
+  const int nsh = (Wh + 3) >> 2, nrh = (Hh + a->Rh - 1) / a->Rh, nsl = (Wl + 3) >> 2, nrl = (Hl + a->Rl - 1) / a->Rl;
+  const int th = nch_h * nsh * nrh, tl = nch_l * nsl * nrl;
+  for (int task = tid; task < th + tl; task += nthr) {
+    if (task < th)
+      ilb_dw_branch<false>(task, H1, H2, plane_h, ph, Hh, Wh, a->Rh, nsh, nrh, csn_const(a->dwh.w9a), csn_const(a->dwh.sca),
+                           csn_const(a->dwh.sha), csn_const(a->dwh.ala), r0h, nullptr, nullptr, nullptr, 0);
+    else
+      ilb_dw_branch<false>(task - th, L1, L2, plane_l, pl, Hl, Wl, a->Rl, nsl, nrl, csn_const(a->dwl.w9a), csn_const(a->dwl.sca),
+                           csn_const(a->dwl.sha), csn_const(a->dwl.ala), r0l, nullptr, nullptr, nullptr, 0);
+  }
+  __syncthreads();
+  for (int task = tid; task < th + tl; task += nthr) {
+    if (task < th) {
+      const int64_t o = ((int64_t)b * OH + r0h);
+      ilb_dw_branch<true>(task, H2, nullptr, plane_h, ph, Hh, Wh, a->Rh, nsh, nrh, csn_const(a->dwh.w9b), csn_const(a->dwh.scb),
+                          csn_const(a->dwh.shb), csn_const(a->dwh.alb), r0h, a->yh + o * Hh * Wh,
+                          a->pool_h ? a->pool_h + o * (Hh >> 1) * (Wh >> 1) : nullptr,
+                          a->mp_h ? a->mp_h + o * (Hh >> 2) * (Wh >> 2) : nullptr, a->skip_h);
+    } else {
+      const int64_t o = ((int64_t)b * OL + r0l);
+      ilb_dw_branch<true>(task - th, L2, nullptr, plane_l, pl, Hl, Wl, a->Rl, nsl, nrl, csn_const(a->dwl.w9b), csn_const(a->dwl.scb),
+                          csn_const(a->dwl.shb), csn_const(a->dwl.alb), r0l, a->yl + o * Hl * Wl,
+                          a->pool_l ? a->pool_l + o * (Hl >> 1) * (Wl >> 1) : nullptr,
+                          a->mp_l ? a->mp_l + o * (Hl >> 2) * (Wl >> 2) : nullptr, a->skip_l);
+    }
+  }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------------------
+typedef void (*IlbFn)(IlbArgs);
+struct IlbEntry { int nth, ntl; IlbFn fn; };
+static const IlbEntry g_ilb_table[] = {{1, 1, ilb_kernel<1, 1>}, {1, 0, ilb_kernel<1, 0>}, {2, 2, ilb_kernel<2, 2>}, {2, 0, ilb_kernel<2, 0>}};
+
+// LDS layout of an item for (nth, ntl) row tiles per group; returns the bytes, 0 when the geometry is not supported
+size_t csn_ilb_layout(IlbArgs& a) {
+  const int Hh = 2 * a.Hl, Wh = 2 * a.Wl;
+  const int NT4 = (a.nth + a.ntl + 3) & ~3, P = PW4_PITCH(NT4);
+  a.gimg_floats = (a.CH + a.CL) * 4 * P;
+  a.ph = ((Wh + 3) & ~3) + 4; a.pl = ((a.Wl + 3) & ~3) + 4;
+  a.plane_h = (Hh + 2) * a.ph + 4; a.plane_l = (a.Hl + 2) * a.pl + 4;   // + 4: the right frame of the last row
+  int off = a.gimg_floats;
+  a.off_h1 = off; off += 4 * a.nth * a.plane_h;
+  a.off_h2 = off; off += 4 * a.nth * a.plane_h;
+  a.off_l1 = off; off += 4 * a.ntl * a.plane_l;
+  a.off_l2 = off; off += 4 * a.ntl * a.plane_l;
+  a.off_z = off; off += 4 * a.nth * a.Hl * a.Wl;
+  a.lds_floats = off;
+  // a wave per tile of 64 low pixels (the accumulators live across the z barrier); one task per lane where the block allows
+  const int tiles = (a.Hl * a.Wl + 63) / 64;
+  if (tiles > 16) return 0;
+  const int tasks = 4 * a.nth * ((Wh + 3) / 4) * ((Hh + a.Rh - 1) / a.Rh) + 4 * a.ntl * ((a.Wl + 3) / 4) * ((a.Hl + a.Rl - 1) / a.Rl);
+  int nthr = std::max(64 * tiles, std::min(1024, (tasks + 63) & ~63));
+  a.nthreads = nthr;
+  return (size_t)off * sizeof(float);
+}
+
+bool csn_ilb_supported(int nth, int ntl) {
+  for (const IlbEntry& e : g_ilb_table)
+    if (e.nth == nth && e.ntl == ntl) return true;
+  return false;
+}
+
+int csn_launch_ilb(const IlbArgs& a, void* stream) {
+  const IlbEntry* e = nullptr;
+  for (const IlbEntry& t : g_ilb_table)
+    if (t.nth == a.nth && t.ntl == a.ntl) e = &t;
+  if (!e) return -1;
+  const size_t lds = (size_t)a.lds_floats * sizeof(float);
+  if (lds > 160 * 1024) return -1;
+#ifndef CSN_CPU_EMU
+  if (lds > 64 * 1024) {
+    const hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(e->fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (er != hipSuccess) return (int)er;
+  }
+#endif
+  const int ipx = (a.B + 7) >> 3;
+  const dim3 grid(8 * ipx * a.ng);
+  CSN_LAUNCH(e->fn, grid, dim3(a.nthreads), lds, stream, a);
+  return (int)hipGetLastError();
+}

@@ -82,6 +82,50 @@ def check_unit_probes(lib, device, manifest):
     return worst
 
 
+def check_ilb_vs_unit_kernels(lib, device, manifest, B, H, W, seed=3, min_blocks=1, env=None):
+    """Whole-ILBlock launches (k_ilb.hip, round 5) against the unit kernels they replace (CSN_ILB=0, read at plan creation): every
+    block output (conv3x3_2) to UNIT_TOL relative, the logits of both to the oracle.  Returns (fused units, worst block deviation,
+    logit deviation from the oracle)."""
+    x = torch.from_numpy(I.randn_batch(seed, B, H, W))
+    saved = {k: os.environ.get(k) for k in ["CSN_ILB"] + list(env or {})}
+    try:
+        os.environ.update(env or {})
+        os.environ["CSN_ILB"] = "1"
+        m1, sd = make_model(lib, manifest, device)
+        y1 = m1(x.to(device)).cpu()
+        e1 = m1.engine_for(x.to(device))
+        names = [e1.lib.csn_unit_kernel_name(e1.plan, u).decode() for u in range(e1.n_units)]
+        os.environ["CSN_ILB"] = "0"
+        m0, _ = make_model(lib, manifest, device)
+        y0 = m0(x.to(device)).cpu()
+        e0 = m0.engine_for(x.to(device))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    nfused = sum(n == "ilb_kernel" for n in names)
+    assert nfused >= 3 * min_blocks and nfused % 3 == 0, (nfused, names)
+    units, acts, unames = m1.describe(m1._arena.offsets)
+    worst = 0.0
+    for u, name in zip(units, unames):
+        if not name.endswith(".conv3x3_2"):
+            continue
+        for j in range(N.MAX_BRANCH):
+            a = u.out_act[j]
+            if a < 0:
+                continue
+            g1, g0 = e1.activation(a).cpu(), e0.activation(a).cpu()
+            err = float((g1 - g0).abs().max()) / max(1.0, float(g0.abs().max()))
+            assert err <= UNIT_TOL, f"{name} branch {j}: ilb_kernel vs unit kernels {err:.3e}"
+            worst = max(worst, err)
+    ref = oracle_forward(manifest, sd, x)
+    err_o = float((y1 - ref).abs().max())
+    assert err_o <= TOL and float((y0 - ref).abs().max()) <= TOL, err_o
+    return nfused, worst, err_o
+
+
 def check_vs_oracle(lib, device, manifest, x, sub_batch=0, tol=TOL):
     m, sd = make_model(lib, manifest, device, sub_batch=sub_batch)
     y = m(x.to(device)).cpu()

@@ -9,7 +9,7 @@ name=$1; files=$2; shift; shift
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 mkdir -p "$ROOT/gpurun_variants" /tmp/csn_obj
 cd "$ROOT/sod100k_amd/csrc"
-SRCS="csn_plan.hip k_misc.hip k_goct_pw.hip k_ms.hip k_train.hip k_wgrad.hip k_wgrad_c3.hip k_wgrad_bf.hip k_goct_c3.hip k_csf.hip k_pw4.hip k_c3q.hip k_pwq.hip"
+SRCS="csn_plan.hip k_misc.hip k_goct_pw.hip k_ms.hip k_train.hip k_wgrad.hip k_wgrad_c3.hip k_wgrad_bf.hip k_goct_c3.hip k_csf.hip k_pw4.hip k_c3q.hip k_pwq.hip k_ilb.hip"
 CC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 objs=""
 for s in $SRCS; do
