@@ -44,6 +44,9 @@ enum CsnPrepKind {
   // MSBlock backward data (ms_dx_kernel): one dilation's [co][ci][3][3] block, tap-flipped, the ci of one (co, tap) contiguous:
   // n = co count, p0 = cin, p2 = padded ci count:   dst[(co*9 + t)*p2 + ci] = p0f * src0[(co*p0 + ci)*9 + (8 - t)]
   CSN_PREP_MSDX = 15,
+  // depthwise weights with the eval-mode BatchNorm scale folded in (dw_core.h): n = channels, src0 = w [C][9], src1 = gamma, src2 = running_var,
+  // p2 = record pitch, p3 = column offset:   dst[c*p2 + p3 + t] = p0f * src0[c*9 + t] * (gamma[c] / sqrt(var[c] + eps))
+  CSN_PREP_DWREC = 16,
 };
 struct CsnPrepJob {
   int32_t kind, n, p0, p1, p2, p3;
@@ -226,10 +229,6 @@ int csn_launch_pw4(const Pw4Args& a, int raw, void* stream);
 // ---------------------------------------------------------------------------------------------
 // one whole ILBlock (1x1 gOctaveCBR -> depthwise pair) per launch, the block's planes in LDS (small maps; see k_ilb.hip)
 // ---------------------------------------------------------------------------------------------
-struct IlbDw {           // the two depthwise units of one branch, tables indexed by channel
-  const float* w9a; const float* sca; const float* sha; const float* ala;   // conv3x3_1: [C][9] (x100 folded), folded BN, PReLU
-  const float* w9b; const float* scb; const float* shb; const float* alb;   // conv3x3_2
-};
 struct IlbArgs {
   const float* xh;     // [B][CH][2 Hl][2 Wl]   block inputs
   const float* xl;     // [B][CL][Hl][Wl]
@@ -238,7 +237,8 @@ struct IlbArgs {
   const float* wimg;   // [ng][CH + CL][4][P]: pw4_kernel's image (CSN_PREP_PW4) of every group: tiles 0 .. nth-1 high rows, then low rows
   const float* ep_h;   // conv1x1's {scale, shift, alpha, 0} per high / low output channel, padded to whole groups
   const float* ep_l;
-  IlbDw dwh, dwl;
+  const float* dwrec_h;  // depthwise records per high / low channel, 2 x 12 floats: {w'[9] (x100 and the BN scale folded), shift, alpha, 0} of
+  const float* dwrec_l;  // conv3x3_1, then of conv3x3_2 (dw_core.h); padded to whole groups
   float* pool_h; float* pool_l;   // 2x2 averages of the outputs for a stride-2 unit that follows (null: none) ...
   float* mp_h; float* mp_l;       // ... and the 2x2 maxima of those averages (c3q_kernel's high -> low slice)
   int32_t skip_h, skip_l;         // the full-resolution output has no other reader
@@ -247,7 +247,7 @@ struct IlbArgs {
   int32_t Rh, Rl;                 // rows per depthwise task (even with pool_*, multiple of 4 with mp_*)
   int32_t nthreads;
   int32_t ph, pl, plane_h, plane_l;                               // LDS row pitches / plane sizes (floats), set by csn_ilb_layout
-  int32_t off_h1, off_h2, off_l1, off_l2, off_z, lds_floats;
+  int32_t off_h1, off_h2, off_l1, off_l2, off_z, off_par, lds_floats;
 };
 size_t csn_ilb_layout(IlbArgs& a);          // fills the layout fields from (CH, CL, Hl, Wl, nth, ntl, Rh, Rl); LDS bytes, 0 = unsupported
 bool csn_ilb_supported(int nth, int ntl);

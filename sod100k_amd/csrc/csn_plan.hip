@@ -146,6 +146,7 @@ struct UnitPlan {
   struct Ilb {
     int on = 0, nth = 0, ntl = 0, ng = 0, gimg = 0, Rh = 4, Rl = 4;
     int64_t wimg = -1, ep[2] = {-1, -1};
+    int64_t dwrec[2] = {-1, -1};   // per channel {w9[9] x100, scale, shift, alpha} of conv3x3_1 and of conv3x3_2 (24 floats)
   } ilb;
   int pw4_old_mask = 0;              // output branches that stay on goct_pw_kernel (CSFHead.fuse's lowest branch)
   // MS
@@ -864,6 +865,15 @@ int plan_ilb(Builder& bl, int k) {
     bl.job(CSN_PREP_BN_SCALE, C, I.ep[q], d.bn[q].weight, d.bn[q].running_var, -1, -1, 1.f, 0, 0, 4, 0);
     bl.job(CSN_PREP_BN_SHIFT, C, I.ep[q], d.bn[q].weight, d.bn[q].running_var, d.bn[q].bias, d.bn[q].running_mean, 1.f, 0, 0, 4, 1);
     bl.job(CSN_PREP_COPY, C, I.ep[q], d.bn[q].prelu, -1, -1, -1, 1.f, 0, 0, 4, 2);
+    // the depthwise pair's parameters of the branch as one record per channel (staged in LDS with the weight image)
+    I.dwrec[q] = bl.alloc_packed((int64_t)rows * 24);
+    for (int h = 0; h < 2; ++h) {
+      const csn_unit_desc& w = h == 0 ? d1.d : d2.d;
+      const int o = 12 * h;
+      bl.job(CSN_PREP_DWREC, C, I.dwrec[q], w.w_off[q], w.bn[q].weight, w.bn[q].running_var, -1, 100.0f, 0, 0, 24, o);   // conv2d.py:104
+      bl.job(CSN_PREP_BN_SHIFT, C, I.dwrec[q], w.bn[q].weight, w.bn[q].running_var, w.bn[q].bias, w.bn[q].running_mean, 1.f, 0, 0, 24, o + 9);
+      bl.job(CSN_PREP_COPY, C, I.dwrec[q], w.bn[q].prelu, -1, -1, -1, 1.f, 0, 0, 24, o + 10);
+    }
   }
   I.on = 1;
   return CSN_OK;
@@ -1504,12 +1514,11 @@ int run_ilb(const Ctx& c, int k) {
   a.yl = a.OL > 0 ? c.act_out(d2.d.out_act[1]) : nullptr;
   a.wimg = c.pk(I.wimg);
   a.ep_h = c.pk(I.ep[0]);
-  a.ep_l = I.ep[1] >= 0 ? c.pk(I.ep[1]) : nullptr;
+  a.ep_l = I.ep[1] >= 0 ? c.pk(I.ep[1]) : a.ep_h;
+  a.dwrec_h = c.pk(I.dwrec[0]);
+  a.dwrec_l = I.dwrec[1] >= 0 ? c.pk(I.dwrec[1]) : a.dwrec_h;
   for (int j = 0; j < 2; ++j) {
     if (j == 1 && a.OL == 0) break;
-    IlbDw& w = j == 0 ? a.dwh : a.dwl;
-    w.w9a = c.pk(d1.dw_w[j]); w.sca = c.pk(d1.dw_epi[j].scale); w.sha = c.pk(d1.dw_epi[j].shift); w.ala = c.pk(d1.dw_epi[j].alpha);
-    w.w9b = c.pk(d2.dw_w[j]); w.scb = c.pk(d2.dw_epi[j].scale); w.shb = c.pk(d2.dw_epi[j].shift); w.alb = c.pk(d2.dw_epi[j].alpha);
     const int Wj = P.W >> (u.base_lvl + j);
     if (d1.pool_unit >= 0 && (Wj % 4) == 0) {   // the stride-2 unit that follows reads the 2x2 averages (+ their 2x2 maxima)
       float* pool = reinterpret_cast<float*>(c.ws + P.units[d1.pool_unit].pooled_off[j]);

@@ -23,6 +23,15 @@
 //     -> HBM (+ the 2x2 averages / their 2x2 maxima for a stride-2 unit that follows, as dw3x3x2 delivers them).
 // HBM traffic = block inputs (once per group, from L2) + block outputs: the two intermediate tensors never leave the CU.
 #include "pw4_common.h"
+#include "dw_core.h"
+
+// tools/probes/ilb_bench.hip (-DILB_TIMING): wall-clock stamps (100 MHz) of block phases, thread 0 of every block
+#ifdef ILB_TIMING
+__device__ unsigned long long* g_ilb_stamps = nullptr;
+#define ILB_STAMP(i) do { if (threadIdx.x == 0 && g_ilb_stamps) g_ilb_stamps[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define ILB_STAMP(i)
+#endif
 
 namespace {
 
@@ -49,66 +58,33 @@ __device__ __forceinline__ void ilb_load_lo(csn_buf rb, unsigned o, unsigned cs,
   for (int j = 0; j < LB; ++j) v[j] = csn_ld1(rb, o, (unsigned)min(k0 + j, C - 1) * cs);
 }
 
-struct IlbRow { float v[6]; };   // [0] = x0 - 1, [1..4] = x0 .. x0 + 3, [5] = x0 + 4
-
-__device__ __forceinline__ IlbRow ilb_ld_row(const float* p) {   // p = column x0 of the row inside an LDS plane (16-byte aligned)
-  IlbRow r;
-  const float4 c = *reinterpret_cast<const float4*>(p);
-  r.v[0] = p[-1]; r.v[1] = c.x; r.v[2] = c.y; r.v[3] = c.z; r.v[4] = c.w; r.v[5] = p[4];
-  return r;
-}
-
-__device__ __forceinline__ void ilb_dw4(const float (&w)[9], const IlbRow& top, const IlbRow& mid, const IlbRow& bot, float sc, float sh,
-                                        float al, float (&o)[4]) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {   // dw_emit's chain (k_misc.hip): bit-identical to the unit kernels on identical inputs
-    float acc = w[0] * top.v[j];
-    acc = fmaf(w[1], top.v[j + 1], acc);
-    acc = fmaf(w[2], top.v[j + 2], acc);
-    acc = fmaf(w[3], mid.v[j], acc);
-    acc = fmaf(w[4], mid.v[j + 1], acc);
-    acc = fmaf(w[5], mid.v[j + 2], acc);
-    acc = fmaf(w[6], bot.v[j], acc);
-    acc = fmaf(w[7], bot.v[j + 1], acc);
-    acc = fmaf(w[8], bot.v[j + 2], acc);
-    o[j] = csn_epi(acc, sc, sh, al);
-  }
-}
-
-// one depthwise unit over the group's planes of one branch: tasks (channel, row chunk, strip) of `nch` channels.
-// LAST = false: LDS plane `src` -> LDS plane `dst`;  LAST = true: -> HBM (+ pooled copies)
+// one depthwise unit over the group's planes of one branch: task = (channel, row chunk, strip of four columns) of `nch` channels.
+// LAST = false: LDS plane `src` -> LDS plane `dst`;  LAST = true: -> HBM (+ pooled copies).  dw_core.h's row core.
 template <bool LAST>
-__device__ __forceinline__ void ilb_dw_branch(int task, const float* src, float* dst, int plane, int pitch, int H, int W, int R, int nstrip,
-                                              int nrc, csn_cfp w9, csn_cfp scp, csn_cfp shp, csn_cfp alp, int c0, float* __restrict__ out,
-                                              float* __restrict__ pool, float* __restrict__ pmax, int skip_out) {
-  const int c = task / (nstrip * nrc), rem = task - c * (nstrip * nrc);
-  const int rc = rem / nstrip, s = rem - rc * nstrip;
-  const int x0 = 4 * s, y0 = rc * R;
-  float w[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) w[i] = w9[(c0 + c) * 9 + i];
-  const float sc = scp[c0 + c], sh = shp[c0 + c], al = alp[c0 + c];
-  const float* base = src + c * plane + 4 + x0;   // column x0 of plane row 0 (= image row -1)
-  IlbRow top = ilb_ld_row(base + y0 * pitch), mid = ilb_ld_row(base + (y0 + 1) * pitch);
+__device__ __forceinline__ void ilb_dw_rows(const DwPar& par, const float* base, float* drow, int pitch, int y0, int H, int W, int R, int x0,
+                                            float* __restrict__ g, float* __restrict__ pool, float* __restrict__ pmax, int skip_out) {
+  DwRow2 top = dw_row2_lds4(base + y0 * pitch), mid = dw_row2_lds4(base + (y0 + 1) * pitch);
   const bool full = x0 + 4 <= W;
   float mx = 0.f, e0 = 0.f, e1 = 0.f;
   for (int q = 0; q < R; ++q) {
     const int y = y0 + q;
     if (y >= H) break;
-    const IlbRow bot = ilb_ld_row(base + (y + 2) * pitch);
-    float o[4];
-    ilb_dw4(w, top, mid, bot, sc, sh, al, o);
+    const DwRow2 bot = dw_row2_lds4(base + (y + 2) * pitch);
+    csn_v2 o01, o23;
+    dw_conv4(par, top, mid, bot, o01, o23);
+    o01 = dw_prelu2(o01, par.al, par.lim);
+    o23 = dw_prelu2(o23, par.al, par.lim);
+    const float o[4] = {o01[0], o01[1], o23[0], o23[1]};
     if (!LAST) {
-      float* d = dst + c * plane + (y + 1) * pitch + 4 + x0;
+      float* d = drow + (y + 1) * pitch;
       if (full) {
-        *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(__builtin_assume_aligned(d, 16)) = make_float4(o[0], o[1], o[2], o[3]);
       } else {   // the columns past W stay zero: they are the second unit's padding
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (x0 + j < W) d[j] = o[j];
       }
     } else {
-      float* g = out + (int64_t)c * H * W + (int64_t)y * W + x0;
       if (pool) {   // avg_pool2d(2, 2) of the block's output (csnet.py:679-680 of the stride-2 unit that follows) and the 2x2
                     // maximum of those averages, in dw3x3x2_bn_prelu_kernel's summation order (W % 4 == 0, R % 2 / % 4 == 0)
         if ((q & 1) == 0) {
@@ -118,20 +94,21 @@ __device__ __forceinline__ void ilb_dw_branch(int task, const float* src, float*
           float2 pv;
           pv.x = (e0 + o[0] + o[1]) * 0.25f;
           pv.y = (e1 + o[2] + o[3]) * 0.25f;
-          *reinterpret_cast<float2*>(pool + (int64_t)c * (H >> 1) * (W >> 1) + (int64_t)(y >> 1) * (W >> 1) + (x0 >> 1)) = pv;
+          *reinterpret_cast<float2*>(pool + (y >> 1) * (W >> 1) + (x0 >> 1)) = pv;
           if (pmax) {
             if ((q & 3) == 1) mx = fmaxf(pv.x, pv.y);
-            else pmax[(int64_t)c * (H >> 2) * (W >> 2) + (int64_t)(y >> 2) * (W >> 2) + (x0 >> 2)] = fmaxf(mx, fmaxf(pv.x, pv.y));
+            else pmax[(y >> 2) * (W >> 2) + (x0 >> 2)] = fmaxf(mx, fmaxf(pv.x, pv.y));
           }
         }
       }
       if (!skip_out) {
+        float* gp = g + y * W + x0;
         if (full && (W & 3) == 0) {
-          *reinterpret_cast<float4*>(g) = make_float4(o[0], o[1], o[2], o[3]);
+          *reinterpret_cast<float4*>(gp) = make_float4(o[0], o[1], o[2], o[3]);
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            if (x0 + j < W) g[j] = o[j];
+            if (x0 + j < W) gp[j] = o[j];
         }
       }
     }
@@ -140,12 +117,29 @@ __device__ __forceinline__ void ilb_dw_branch(int task, const float* src, float*
   }
 }
 
+template <bool LAST>
+__device__ __forceinline__ void ilb_dw_branch(int task, const float* src, float* dst, int plane, int pitch, int H, int W, int R, int nstrip,
+                                              int nrc, const float* rec, float* __restrict__ out, float* __restrict__ pool,
+                                              float* __restrict__ pmax, int skip_out) {
+  const int c = task / (nstrip * nrc), rem = task - c * (nstrip * nrc);
+  const int rc = rem / nstrip, s = rem - rc * nstrip;
+  const int x0 = 4 * s, y0 = rc * R;
+  // the channel's record in LDS: conv3x3_1's {w'[9], shift, alpha, .}, then conv3x3_2's (IlbArgs::dwrec_*, CSN_PREP_DWREC)
+  const DwPar par = dw_par_load(rec + c * (2 * DWREC_FLOATS) + (LAST ? DWREC_FLOATS : 0));
+  const float* base = src + c * plane + 3 + x0;   // column x0 - 1 of plane row 0 (= image row -1)
+  float* drow = LAST ? nullptr : dst + c * plane + 4 + x0;
+  float* g = LAST ? out + c * H * W : nullptr;
+  float* pl = (LAST && pool) ? pool + c * (H >> 1) * (W >> 1) : nullptr;
+  float* pm = (LAST && pmax) ? pmax + c * (H >> 2) * (W >> 2) : nullptr;
+  ilb_dw_rows<LAST>(par, base, drow, pitch, y0, H, W, R, x0, g, pl, pm, skip_out);
+}
+
 }  // namespace
 
 template <int NTH, int NTL>
 __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
   constexpr int NT4 = (NTH + NTL + 3) & ~3, P = PW4_PITCH(NT4);
-  constexpr int HB = 4, LB = 8;
+  constexpr int HB = NTH == 1 ? 8 : 4, LB = NTH == 1 ? 16 : 8;   // channels per load batch (two batches in flight)
   CSN_DYN_SMEM(float, lds);
   const CSN_CONST_AS IlbArgs* a = CSN_KERNARG(IlbArgs, a_byval);
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -167,25 +161,60 @@ __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
   const int r0h = 4 * NTH * g, r0l = 4 * NTL * g;                       // first high / low output channel of the group
   const int nch_h = max(0, min(4 * NTH, OH - r0h)), nch_l = NTL > 0 ? max(0, min(4 * NTL, OL - r0l)) : 0;
 
-  // ---- phase 0: the group's weight image; zero frame (whole planes: the interiors are overwritten below) ----
-  {
-    const float4* __restrict__ src = reinterpret_cast<const float4*>(a->wimg + (int64_t)g * a->gimg_floats);
-    float4* dst = reinterpret_cast<float4*>(lds);
-    for (int i = tid; i < (a->gimg_floats >> 2); i += nthr) dst[i] = src[i];
-    float4* zp = reinterpret_cast<float4*>(lds + a->off_h1);
-    const int nz4 = (a->off_z - a->off_h1) >> 2;
-    for (int i = tid; i < nz4; i += nthr) zp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  __syncthreads();
-
-  // ---- phase 1: contraction.  Wave w owns the 64 consecutive low pixels [64 w, 64 w + 64) of the plane (flat tiles, k_pw4.hip);
-  // the launcher provides a wave per tile, so the accumulators survive the barrier the z exchange needs ----
+  // ---- lane geometry of the contraction.  Wave w owns the 64 consecutive low pixels [64 w, 64 w + 64) of the plane (flat tiles,
+  // k_pw4.hip); the launcher provides a wave per tile, so the accumulators survive the barrier the z exchange needs ----
+  ILB_STAMP(0);
   const int lane = tid & 63, wave = pw4_uniform(tid >> 6);
   const int pix = wave * 64 + lane;
   const bool tile_on = wave * 64 < HWl;
   const bool valid = pix < HWl;
   const int pc = min(pix, HWl - 1);
   const int y = pc / Wl, x = pc - y * Wl;
+  const unsigned csl = (unsigned)HWl * 4u, csh = csl * 4u;
+  const unsigned oh0 = (unsigned)((2 * y) * Wh + 2 * x) * 4u, oh1 = oh0 + (unsigned)Wh * 4u, olc = (unsigned)pc * 4u;
+  const csn_buf rbh = csn_make_buf_n(reinterpret_cast<const char*>(a->xh) + (int64_t)b * CH * (int64_t)csh, (unsigned)CH * csh);
+  const csn_buf rbl = csn_make_buf_n(reinterpret_cast<const char*>(a->xl) + (int64_t)b * CL * (int64_t)csl, (unsigned)CL * csl);
+  // the first two batches of activation loads are issued BEFORE the weights are staged: an item is one latency chain
+  // (weights -> loads -> contraction -> planes -> depthwise pair -> stores), every round trip taken off it counts
+  float2 hA[HB][2], hB[HB][2];
+  float lA[LB], lB[LB];
+  const int nfh = (CH - 1) / HB;   // full batches in front of the last one
+  if (tile_on) {
+    pw4_load_hi<HB>(rbh, oh0, oh1, csh, 0, CH, hA);
+    if (nfh >= 1) pw4_load_hi<HB>(rbh, oh0, oh1, csh, HB, CH, hB);
+  }
+  PW4_FENCE();
+
+  // ---- phase 0: the group's weight image, epilogue records and depthwise records -> LDS; zero frame (whole planes: the interiors
+  // are overwritten below) ----
+  {
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(a->wimg + (int64_t)g * a->gimg_floats);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    for (int i = tid; i < (a->gimg_floats >> 2); i += nthr) dst[i] = src[i];
+    // records of the group's channels: [4 NTH] x {scale, shift, alpha, 0} (conv1x1, high), [4 NTL] x the same (low),
+    // [4 NTH] x 24 depthwise (high), [4 NTL] x 24 (low).  The tables are padded to whole groups.
+    float4* par = reinterpret_cast<float4*>(lds + a->off_par);
+    const int n_eh = 4 * NTH, n_el = 4 * NTL, n_dh = 24 * NTH, n_dl = 24 * NTL;
+    for (int i = tid; i < n_eh + n_el + n_dh + n_dl; i += nthr) {
+      const float4* q;
+      if (i < n_eh) q = reinterpret_cast<const float4*>(a->ep_h + 4 * r0h) + i;
+      else if (i < n_eh + n_el) q = reinterpret_cast<const float4*>(a->ep_l + 4 * r0l) + (i - n_eh);
+      else if (i < n_eh + n_el + n_dh) q = reinterpret_cast<const float4*>(a->dwrec_h + 24 * r0h) + (i - n_eh - n_el);
+      else q = reinterpret_cast<const float4*>(a->dwrec_l + 24 * r0l) + (i - n_eh - n_el - n_dh);
+      par[i] = *q;
+    }
+    float4* zp = reinterpret_cast<float4*>(lds + a->off_h1);
+    const int nz4 = (a->off_z - a->off_h1) >> 2;
+    for (int i = tid; i < nz4; i += nthr) zp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  ILB_STAMP(1);
+  const float* par_eh = lds + a->off_par;
+  const float* par_el = par_eh + 16 * NTH;
+  const float* par_dh = par_el + 16 * NTL;
+  const float* par_dl = par_dh + 96 * NTH;
+
+  // ---- phase 1: contraction ----
   csn_f4 acch[4][NTH], accz[NTH], accl[NTL > 0 ? NTL : 1];
 #pragma unroll
   for (int t = 0; t < NTH; ++t) {
@@ -206,53 +235,42 @@ __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
 #else
     const float* wg = lds + (lane & 3) * P;
 #endif
-    const unsigned csl = (unsigned)HWl * 4u, csh = csl * 4u;
-    const unsigned oh0 = (unsigned)((2 * y) * Wh + 2 * x) * 4u, oh1 = oh0 + (unsigned)Wh * 4u, olc = (unsigned)pc * 4u;
-    const csn_buf rbh = csn_make_buf_n(reinterpret_cast<const char*>(a->xh) + (int64_t)b * CH * (int64_t)csh, (unsigned)CH * csh);
-    const csn_buf rbl = csn_make_buf_n(reinterpret_cast<const char*>(a->xl) + (int64_t)b * CL * (int64_t)csl, (unsigned)CL * csl);
-    // high channels: quad -> high rows, 2x2 maximum -> low rows (pw4_hi_batch); batch k0 contracted while k0 + HB is in flight
-    float2 hA[HB][2], hB[HB][2];
-    float lA[LB], lB[LB];
-    pw4_load_hi<HB>(rbh, oh0, oh1, csh, 0, CH, hA);
-    PW4_FENCE();
-    const int nfh = (CH - 1) / HB;
+    // high channels: quad -> high rows, 2x2 maximum -> low rows (pw4_hi_batch); two batches in flight: A and B hold batches
+    // k0 and k0 + HB on entry of every trip
     int k0 = 0;
     for (int p = 0; p < (nfh >> 1); ++p) {
-      pw4_load_hi<HB>(rbh, oh0, oh1, csh, k0 + HB, CH, hB);
-      PW4_FENCE();
       pw4_hi_batch<NTH, NTL, HB, P, false>(hA, wg + k0 * 4 * P, HB, acch, accl);
       pw4_load_hi<HB>(rbh, oh0, oh1, csh, k0 + 2 * HB, CH, hA);
       PW4_FENCE();
       pw4_hi_batch<NTH, NTL, HB, P, false>(hB, wg + (k0 + HB) * 4 * P, HB, acch, accl);
+      if (k0 + 3 * HB < CH) pw4_load_hi<HB>(rbh, oh0, oh1, csh, k0 + 3 * HB, CH, hB);
+      PW4_FENCE();
       k0 += 2 * HB;
     }
-    if (nfh & 1) {
-      pw4_load_hi<HB>(rbh, oh0, oh1, csh, k0 + HB, CH, hB);
-      PW4_FENCE();
+    if (nfh & 1) {   // A = full batch k0, B = the last (partial) batch
       pw4_hi_batch<NTH, NTL, HB, P, false>(hA, wg + k0 * 4 * P, HB, acch, accl);
       k0 += HB;
 #pragma unroll
       for (int j = 0; j < HB; ++j) { hA[j][0] = hB[j][0]; hA[j][1] = hB[j][1]; }
     }
-    ilb_load_lo<LB>(rbl, olc, csl, 0, CL, lA);
+    const int nfl = (CL - 1) / LB;
+    ilb_load_lo<LB>(rbl, olc, csl, 0, CL, lA);   // the low channels' first two batches fly during the last high batch
+    if (nfl >= 1) ilb_load_lo<LB>(rbl, olc, csl, LB, CL, lB);
     PW4_FENCE();
     pw4_hi_batch<NTH, NTL, HB, P, true>(hA, wg + k0 * 4 * P, CH - k0, acch, accl);
-    // low channels: the centre value -> z rows and low rows
+    // low channels: the centre value -> z rows and low rows, same scheme
     const float* wgl = wg + CH * 4 * P;
-    const int nfl = (CL - 1) / LB;
     int c0 = 0;
     for (int p = 0; p < (nfl >> 1); ++p) {
-      ilb_load_lo<LB>(rbl, olc, csl, c0 + LB, CL, lB);
-      PW4_FENCE();
       ilb_lo_batch<NTH, NTL, LB, P, false>(lA, wgl + c0 * 4 * P, LB, accz, accl);
       ilb_load_lo<LB>(rbl, olc, csl, c0 + 2 * LB, CL, lA);
       PW4_FENCE();
       ilb_lo_batch<NTH, NTL, LB, P, false>(lB, wgl + (c0 + LB) * 4 * P, LB, accz, accl);
+      if (c0 + 3 * LB < CL) ilb_load_lo<LB>(rbl, olc, csl, c0 + 3 * LB, CL, lB);
+      PW4_FENCE();
       c0 += 2 * LB;
     }
     if (nfl & 1) {
-      ilb_load_lo<LB>(rbl, olc, csl, c0 + LB, CL, lB);
-      PW4_FENCE();
       ilb_lo_batch<NTH, NTL, LB, P, false>(lA, wgl + c0 * 4 * P, LB, accz, accl);
       c0 += LB;
 #pragma unroll
@@ -267,6 +285,7 @@ __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
     }
   }
   __syncthreads();
+  ILB_STAMP(2);
   if (tile_on && valid) {
     // y_h = W_hh x_h + bilinear_up2(z) (csnet.py:702-707,720-722: the branches are summed in input order), then BN + PReLU
     int zo[9];
@@ -278,7 +297,7 @@ __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) zo[3 * r + c] = yy[r] * Wl + xx[c];
     }
-    csn_cfp eph = csn_const(a->ep_h) + 4 * r0h;
+    const float* eph = par_eh;
     float* h1 = H1 + (2 * y + 1) * ph + 4 + 2 * x;
 #pragma unroll
     for (int t = 0; t < NTH; ++t)
@@ -298,7 +317,7 @@ __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
         }
       }
     if (NTL > 0) {
-      csn_cfp epl = csn_const(a->ep_l) + 4 * r0l;
+      const float* epl = par_el;
       float* l1 = L1 + (y + 1) * pl + 4 + x;
 #pragma unroll
       for (int t = 0; t < NTL; ++t)
@@ -310,34 +329,34 @@ __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
     }
   }
   __syncthreads();
+  ILB_STAMP(3);
 
   // ---- phases 2, 3: the depthwise pair, tasks = (channel, row chunk, strip of four columns), high planes then low planes ----
   const int nsh = (Wh + 3) >> 2, nrh = (Hh + a->Rh - 1) / a->Rh, nsl = (Wl + 3) >> 2, nrl = (Hl + a->Rl - 1) / a->Rl;
   const int th = nch_h * nsh * nrh, tl = nch_l * nsl * nrl;
   for (int task = tid; task < th + tl; task += nthr) {
-    if (task < th)
-      ilb_dw_branch<false>(task, H1, H2, plane_h, ph, Hh, Wh, a->Rh, nsh, nrh, csn_const(a->dwh.w9a), csn_const(a->dwh.sca),
-                           csn_const(a->dwh.sha), csn_const(a->dwh.ala), r0h, nullptr, nullptr, nullptr, 0);
-    else
-      ilb_dw_branch<false>(task - th, L1, L2, plane_l, pl, Hl, Wl, a->Rl, nsl, nrl, csn_const(a->dwl.w9a), csn_const(a->dwl.sca),
-                           csn_const(a->dwl.sha), csn_const(a->dwl.ala), r0l, nullptr, nullptr, nullptr, 0);
+    if (task < th) ilb_dw_branch<false>(task, H1, H2, plane_h, ph, Hh, Wh, a->Rh, nsh, nrh, par_dh, nullptr, nullptr, nullptr, 0);
+    else ilb_dw_branch<false>(task - th, L1, L2, plane_l, pl, Hl, Wl, a->Rl, nsl, nrl, par_dl, nullptr, nullptr, nullptr, 0);
   }
   __syncthreads();
+  ILB_STAMP(4);
   for (int task = tid; task < th + tl; task += nthr) {
     if (task < th) {
       const int64_t o = ((int64_t)b * OH + r0h);
-      ilb_dw_branch<true>(task, H2, nullptr, plane_h, ph, Hh, Wh, a->Rh, nsh, nrh, csn_const(a->dwh.w9b), csn_const(a->dwh.scb),
-                          csn_const(a->dwh.shb), csn_const(a->dwh.alb), r0h, a->yh + o * Hh * Wh,
+      ilb_dw_branch<true>(task, H2, nullptr, plane_h, ph, Hh, Wh, a->Rh, nsh, nrh, par_dh, a->yh + o * Hh * Wh,
                           a->pool_h ? a->pool_h + o * (Hh >> 1) * (Wh >> 1) : nullptr,
                           a->mp_h ? a->mp_h + o * (Hh >> 2) * (Wh >> 2) : nullptr, a->skip_h);
     } else {
       const int64_t o = ((int64_t)b * OL + r0l);
-      ilb_dw_branch<true>(task - th, L2, nullptr, plane_l, pl, Hl, Wl, a->Rl, nsl, nrl, csn_const(a->dwl.w9b), csn_const(a->dwl.scb),
-                          csn_const(a->dwl.shb), csn_const(a->dwl.alb), r0l, a->yl + o * Hl * Wl,
+      ilb_dw_branch<true>(task - th, L2, nullptr, plane_l, pl, Hl, Wl, a->Rl, nsl, nrl, par_dl, a->yl + o * Hl * Wl,
                           a->pool_l ? a->pool_l + o * (Hl >> 1) * (Wl >> 1) : nullptr,
                           a->mp_l ? a->mp_l + o * (Hl >> 2) * (Wl >> 2) : nullptr, a->skip_l);
     }
   }
+#ifdef ILB_TIMING
+  __syncthreads();
+#endif
+  ILB_STAMP(5);
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------------
@@ -358,6 +377,7 @@ size_t csn_ilb_layout(IlbArgs& a) {
   a.off_l1 = off; off += 4 * a.ntl * a.plane_l;
   a.off_l2 = off; off += 4 * a.ntl * a.plane_l;
   a.off_z = off; off += 4 * a.nth * a.Hl * a.Wl;
+  a.off_par = off; off += (a.nth + a.ntl) * (16 + 96);   // epilogue records + depthwise records of the group's channels
   a.lds_floats = off;
   // a wave per tile of 64 low pixels (the accumulators live across the z barrier); one task per lane where the block allows
   const int tiles = (a.Hl * a.Wl + 63) / 64;

@@ -113,6 +113,13 @@ __global__ __launch_bounds__(CSN_BLOCK) void csn_prep_kernel(const CsnPrepJob* _
         dst[((int64_t)(k0 + c) * 4 + (r & 3)) * j.p2 + t0 + (r >> 2)] = j.p0f * arena[j.src0 + (int64_t)c * j.p0 + r];
       }
     } break;
+    case CSN_PREP_DWREC:
+      for (int i = tid; i < j.n * 9; i += CSN_BLOCK) {
+        const int c = i / 9, t = i - 9 * c;
+        const float sc = arena[j.src1 + c] / sqrtf(arena[j.src2 + c] + eps);
+        dst[(int64_t)c * j.p2 + j.p3 + t] = (j.p0f * arena[j.src0 + i]) * sc;
+      }
+      break;
     case CSN_PREP_PW4: {
       const int ncol = j.p1, t0 = j.p3 & 0xff, k0 = j.p3 >> 8;
       const int tot = j.n * ncol;

@@ -116,6 +116,11 @@ def check_ilb_vs_unit_kernels(lib, device, manifest, B, H, W, seed=3, min_blocks
             a = u.out_act[j]
             if a < 0:
                 continue
+            # a block output read ONLY by the stride-2 unit behind it is never stored at full resolution (that unit reads the 2x2
+            # averages the block delivers: pool_skip): nothing to compare -- the blocks downstream cover it
+            readers = [v for v in units if any(v.in_act[i] == a and v.cin[i] > 0 for i in range(int(v.n_in)))]
+            if readers and all(v.kind == N.UNIT_GOCT and v.stride == 2 for v in readers):
+                continue
             g1, g0 = e1.activation(a).cpu(), e0.activation(a).cpu()
             err = float((g1 - g0).abs().max()) / max(1.0, float(g0.abs().max()))
             assert err <= UNIT_TOL, f"{name} branch {j}: ilb_kernel vs unit kernels {err:.3e}"
