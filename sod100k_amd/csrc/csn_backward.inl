@@ -643,7 +643,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
   const BwdCtx bs{cs, b.arena, b.grad, b.flop_w, b.pen_scale, c.lanes ? nullptr : b.defer};
   if (d.kind == CSN_UNIT_DW) {
     DwArgs a;
-    a.nbr = 0; a.B = S; a.a16 = c.a16 ? 1 : 0; a.pad = 0;
+    a.nbr = 0; a.B = S; a.a16 = c.a16 ? 1 : 0; a.nthreads = 0;
     int blk = 0;
     for (int k = 0; k < d.n_in; ++k) {
       if (d.cout[k] == 0) continue;
@@ -662,7 +662,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
         const bool defer_fin = b.defer != nullptr && !cf.side && u.dwwg_off[k] >= 0;
         if (defer_fin) w.partial = reinterpret_cast<double*>(c.ws + u.dwwg_off[k]);   // own region: finalised with all the others
         DwArgs f;
-        f.nbr = 1; f.B = S; f.a16 = c.a16 ? 1 : 0; f.pad = 0;
+        f.nbr = 1; f.B = S; f.a16 = c.a16 ? 1 : 0; f.nthreads = 0;
         DwBranch& fb = f.br[0];
         fb.in = bd.dz[k]; fb.out = bd.dx[k]; fb.xin = bd.in[k];
         if (virt) {   // x = PReLU(BN(z of the producer)) on load

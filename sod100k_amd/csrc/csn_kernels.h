@@ -69,6 +69,8 @@ struct DwBranch {
   const float* scale_b;
   const float* shift_b;
   const float* alpha_b;
+  const float* rec = nullptr;   // dw3x3x2_fast_kernel (round 5, dw_core.h): per channel 2 x 12 floats {w'[9] (x100 and the BN scale
+                                // folded), shift, alpha, 0} of the pair's first unit, then of its second; null: the round-1 kernel
   const float* xin;      // dw3x3_bwd_kernel: the unit's forward input x (stats then holds the weight-gradient partials [C][NSLAB][9])
   double* stats;         // single-unit kernel, train mode: BN statistics partials [C][CSN_BN_NSLAB][2] of the stored output,
                          // one per (image, tile): slab = b * tiles_x * tiles_y + tile (null: none)
@@ -81,6 +83,7 @@ struct DwBranch {
   int32_t LX, NY, R;          // lanes per row (4 px each), lane rows per block, rows per lane
   int32_t tiles_x, tiles_y;   // tiles per plane
   int32_t blk_end;            // exclusive prefix sum of blocks over branches
+  uint32_t m_tiles_y = 0, m_C = 0, m_LX = 0;   // dw3x3x2_fast_kernel: ceil(2^32 / d) of the three divisors (0: d = 1), set by its launcher
   // dw3x3_bwd_kernel with the BatchNorm backward's apply pass fused in (zraw non-null): `in` is then the gradient w.r.t. the
   // unit's OUTPUT y from its first consumer, dy2 the second consumer's (null: none), zraw the saved raw conv output, and
   //   dz = gamma * invstd * (dbn - m1 - (z - mean) * invstd * m2),  dbn = (z * scale + shift > 0 ? 1 : alpha) * (dy + dy2)
@@ -124,7 +127,8 @@ int csn_launch_gap_tiles_batch(const GapTilesArgs* jobs, int njobs, void* stream
 struct DwArgs {
   DwBranch br[3];
   int32_t nbr, B;
-  int32_t a16, pad;   // bfloat16 activations (single-unit kernel only; the fused pair is an eval-mode kernel)
+  int32_t a16;        // bfloat16 activations (single-unit kernel only; the fused pair is an eval-mode kernel)
+  int32_t nthreads;   // (unused)
 };
 
 // ---------------------------------------------------------------------------------------------

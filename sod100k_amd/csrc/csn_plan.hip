@@ -112,6 +112,7 @@ struct UnitPlan {
   int64_t dw_w[3] = {-1, -1, -1};
   Epi dw_epi[3];
   int fuse_next = 0;   // DW: the next unit is the second depthwise unit of the same ILBlock
+  int64_t dw2rec[3] = {-1, -1, -1};   // ... and the pair's folded per-channel records (dw3x3x2_fast_kernel, dw_core.h), per branch
   int fuse_cls = 0;    // GOCT: the next unit is the cls_layer and nobody else reads this unit's output
   int std_conv = 0;    // GOCT 1 -> 1: Conv2dX100 (x100 weights, real stride 2)
   int c3 = 0;          // GOCT 3x3: every launch of the unit qualifies for the LDS-tiled kernel (profile attribution)
@@ -179,6 +180,7 @@ struct csn_plan {
                           // in its own workspace region
   bool c3q = true;        // CSN_OPT_C3Q: eval-mode 3x3 passes on c3q_kernel (k_c3q.hip)
   int c3q_cap = 4;        // its row tiles per M group (CSN_C3Q_NT, experiments)
+  bool dw_fast = true;    // CSN_DW_FAST=0: the fused depthwise pair on the round-1 kernel instead of dw3x3x2_fast_kernel (A/B)
   bool ilb = true;        // CSN_OPT_FUSE_ILB / CSN_ILB=0: whole ILBlocks of the small maps on ilb_kernel (k_ilb.hip, round 5)
   int ilb_nt = 1;         // its row tiles per group and branch (CSN_ILB_NT=2: experiments)
   bool pw4 = true;        // CSN_OPT_PW4: two-branch 1x1 units on pw4_kernel (k_pw4.hip)
@@ -1204,7 +1206,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
     case CSN_UNIT_DW: {
       DwArgs a;
       const bool fused = next != nullptr;
-      a.nbr = 0; a.B = S; a.a16 = c.a16 ? 1 : 0; a.pad = 0;
+      a.nbr = 0; a.B = S; a.a16 = c.a16 ? 1 : 0; a.nthreads = 0;
       if (fused && c.a16) return CSN_E_UNSUPPORTED;   // the fused pair is an eval-mode (float) kernel
       int blk = 0;
       for (int k = 0; k < d.n_in; ++k) {
@@ -1233,6 +1235,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
         br.NY = CSN_BLOCK / br.LX;
         br.tiles_x = (cols + br.LX - 1) / br.LX;
         if (fused) {
+          if (P.dw_fast && !c.raw && u.dw2rec[k] >= 0 && (br.W % 4) == 0) br.rec = c.pk(u.dw2rec[k]);
           br.w9b = c.pk(next->dw_w[k]);
           br.scale_b = c.pk(next->dw_epi[k].scale); br.shift_b = c.pk(next->dw_epi[k].shift);
           br.alpha_b = c.pk(next->dw_epi[k].alpha);
@@ -1243,7 +1246,8 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
             br.skip_out = u.pool_skip[k];
             if (mp) br.pool_mp = reinterpret_cast<float*>(c.ws + P.units[u.pool_unit].mp_off[k]);
           }
-          br.R = choose_dw2_rows(br.H, br.NY, br.LX, pool, mp);
+          // (the fast kernel walks its rows in trips of four: R % 4 == 0, which the pooled outputs' 4 x 4 blocks ask for anyway)
+          br.R = choose_dw2_rows(br.H, br.NY, br.LX, pool, mp || br.rec != nullptr);
         } else {
           br.R = choose_dw_rows(br.H, br.NY);
         }
@@ -1653,6 +1657,7 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   if (std::getenv("CSN_PW4_NOQ")) P->pw4_no_q = true;
   if (const char* e = std::getenv("CSN_PW4_FLAT")) P->pw4_flat = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_ILB")) P->ilb = std::atoi(e) != 0;
+  if (const char* e = std::getenv("CSN_DW_FAST")) P->dw_fast = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_ILB_NT")) P->ilb_nt = std::atoi(e) == 2 ? 2 : 1;
   if (const char* e = std::getenv("CSN_C3Q16")) P->c3q16 = std::atoi(e);
   if (const char* e = std::getenv("CSN_PWQ16")) P->pwq16 = std::atoi(e) != 0;
@@ -1726,7 +1731,23 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
           if (P->units[q].d.in_act[s] == a.out_act[i] && s < P->units[q].d.n_in && P->units[q].d.cin[s] > 0) ok = false;
       }
     }
-    if (ok) { P->units[k].fuse_next = 1; ++k; }
+    if (ok) {
+      P->units[k].fuse_next = 1;
+      for (int i = 0; i < a.n_in; ++i) {   // {w' = 100 w gamma / sqrt(var + eps), shift, alpha} records of both units (dw_core.h)
+        if (a.cout[i] == 0) continue;
+        const int C = a.cout[i];
+        const int64_t rec = bl.alloc_packed((int64_t)C * 24 + 8);
+        P->units[k].dw2rec[i] = rec;
+        for (int h = 0; h < 2; ++h) {
+          const csn_unit_desc& w = h == 0 ? a : b;
+          const int o = 12 * h;
+          bl.job(CSN_PREP_DWREC, C, rec, w.w_off[i], w.bn[i].weight, w.bn[i].running_var, -1, 100.0f, 0, 0, 24, o);   // conv2d.py:104
+          bl.job(CSN_PREP_BN_SHIFT, C, rec, w.bn[i].weight, w.bn[i].running_var, w.bn[i].bias, w.bn[i].running_mean, 1.f, 0, 0, 24, o + 9);
+          bl.job(CSN_PREP_COPY, C, rec, w.bn[i].prelu, -1, -1, -1, 1.f, 0, 0, 24, o + 10);
+        }
+      }
+      ++k;
+    }
   }
   // pooled outputs: a fused depthwise pair directly followed by the stride-2 unit that consumes all its branches
   for (int k = 0; k + 2 < n_units; ++k) {

@@ -38,7 +38,8 @@ __device__ __forceinline__ csn_v2 csn_mul2(float w, csn_v2 x) { const csn_v2 ww 
 // per-channel record of one depthwise unit (CSN_PREP_DWREC + strided BN_SHIFT / COPY jobs): {w'[9], shift, alpha, 0}
 #define DWREC_FLOATS 12
 struct DwPar { float w[9], sh, al, lim; };   // lim = +inf when alpha <= 1, else -inf (dw_prelu2)
-__device__ __forceinline__ DwPar dw_par_load(const float* rec) {
+template <typename PTR>   // const float* (LDS, per lane) or csn_cfp (packed buffer through the scalar cache, block-uniform channel)
+__device__ __forceinline__ DwPar dw_par_load(PTR rec) {
   DwPar p;
 #pragma unroll
   for (int i = 0; i < 9; ++i) p.w[i] = rec[i];
@@ -104,4 +105,15 @@ __device__ __forceinline__ float dw_med3(float a, float b, float c) {
 __device__ __forceinline__ csn_v2 dw_prelu2(csn_v2 y, float al, float lim) {
   const csn_v2 t = csn_mul2(al, y);
   return csn_mk2(dw_med3(y[0], t[0], lim), dw_med3(y[1], t[1], lim));
+}
+
+// four outputs -> an LDS row position that is 16-byte aligned
+__device__ __forceinline__ void dw_st4_lds(float* p, csn_v2 o01, csn_v2 o23) {
+#ifdef CSN_CPU_EMU
+  p[0] = o01[0]; p[1] = o01[1]; p[2] = o23[0]; p[3] = o23[1];
+#else
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const v4 v = {o01[0], o01[1], o23[0], o23[1]};
+  *reinterpret_cast<v4*>(__builtin_assume_aligned(p, 16)) = v;
+#endif
 }

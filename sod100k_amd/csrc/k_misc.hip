@@ -7,6 +7,7 @@
 //   bilinear         F.interpolate(size=x.size()[2:], 'bilinear', align_corners=False)  csnet.py:382-385
 #include "csn_kernels.h"
 #include "csn_reduce.h"
+#include "dw_core.h"
 
 // ------------------------------------------------------------------------------------------ prep
 __global__ __launch_bounds__(CSN_BLOCK) void csn_prep_kernel(const CsnPrepJob* __restrict__ jobs,
@@ -815,10 +816,181 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3x2_bn_prelu_kernel(DwArgs a) {
   }
 }
 
+// Round 5: the same pair on dw_core.h's row core.  The kernel above spends ~13 vector instructions per output pixel and unit (ISA:
+// 18 packed FMAs per row of four pixels, but also a BN multiply-add, multiply + compare + select for PReLU, per-element masks and
+// pair-building moves) and is bound by exactly that (profiles/r4_notes.md: 83 % VALU utilisation; tools/probes/issue_probe2: every
+// instruction pays its own issue slot on this part).  Here: BN scale folded into the nine weights and the shift as the accumulator's
+// initial value (the per-channel records DwBranch::rec, CSN_PREP_DWREC), PReLU as one packed multiply + one v_med3 per value, rows held
+// as the five overlapping pairs a packed FMA takes, masks as 0 / 1 factors per ROW.  Same block / lane geometry and LDS layout.
+// Needs W % 4 == 0 (every CSNet resolution: H, W multiples of 16).
+// n / d for n * d < 2^32 with the host's m = ceil(2^32 / d) (csn_div_magic): one multiply-high instead of ~25 instructions
+__device__ __forceinline__ unsigned dw_div(unsigned n, unsigned m) {   // m = 0: d = 1
+#ifdef CSN_CPU_EMU
+  return m ? (unsigned)(((unsigned long long)n * m) >> 32) : n;
+#else
+  return m ? __umulhi(n, m) : n;
+#endif
+}
+
+// a row of the intermediate + the zero frame next to it
+__device__ __forceinline__ void dw2f_put(float* d, bool has_l, bool has_r, csn_v2 o01, csn_v2 o23) {
+  dw_st4_lds(d, o01, o23);
+  if (!has_l) d[-1] = 0.f;
+  if (!has_r) d[4] = 0.f;
+}
+__device__ __forceinline__ void dw2f_row(const DwPar& pa, float* d, int yy, int H, bool has_l, bool has_r, const DwRow2& t, const DwRow2& m,
+                                         const DwRow2& b) {
+  if (yy >= 0 && yy < H) {
+    csn_v2 o01, o23;
+    dw_conv4(pa, t, m, b, o01, o23);
+    dw2f_put(d, has_l, has_r, dw_prelu2(o01, pa.al, pa.lim), dw_prelu2(o23, pa.al, pa.lim));
+  } else {
+    dw2f_put(d, has_l, has_r, csn_mk2(0.f, 0.f), csn_mk2(0.f, 0.f));
+  }
+}
+
+__global__ __launch_bounds__(CSN_BLOCK) void dw3x3x2_fast_kernel(DwArgs a_byval) {
+  CSN_DYN_SMEM(float, lds);
+  const CSN_CONST_AS DwArgs* a = CSN_KERNARG(DwArgs, a_byval);
+  int bid = blockIdx.x;
+  int k = 0;
+  if (a->nbr > 1 && bid >= a->br[0].blk_end) k = 1;
+  if (a->nbr > 2 && bid >= a->br[1].blk_end) k = 2;
+  const CSN_CONST_AS DwBranch* br = &a->br[k];
+  if (k > 0) bid -= a->br[k - 1].blk_end;
+  // block -> (plane, row tile), thread -> (lane row, strip): the divisors are launch constants, the host passes their reciprocals
+  const int pc = (int)dw_div((unsigned)bid, br->m_tiles_y);   // b*C + c
+  const int ty = bid - pc * br->tiles_y;
+  const int c = pc - (int)dw_div((unsigned)pc, br->m_C) * br->C;
+  const int tid = threadIdx.x;
+  const int ly = (int)dw_div((unsigned)tid, br->m_LX), lx = tid - ly * br->LX;
+  const int H = br->H, W = br->W, R = br->R, NY = br->NY;   // R % 4 == 0 (launcher)
+  const int pitch = br->LX * 4 + 8;          // [4 pad | LX*4 pixels | 4 pad], rows 16-byte aligned
+  const int x0 = lx * 4;
+  const int yb = ty * NY * R;                // first output row of the block
+  const bool active = ly < NY;
+  const csn_buf rb = csn_make_buf_n(br->in + (int64_t)pc * H * W, (unsigned)(H * W) * 4u);
+  csn_cfp rec = csn_const(br->rec) + c * (2 * DWREC_FLOATS);
+  const bool has_l = x0 > 0, has_r = x0 + 4 < W;
+  const float ml = has_l ? 1.f : 0.f, mr = has_r ? 1.f : 0.f;
+  const unsigned W4 = (unsigned)W * 4u;
+  // a row from HBM as loaded (one 128-bit load + the two halo columns through ONE byte offset, of column x0 - 1, and immediates);
+  // rows above / below the plane fall out of the bounded resource (zeros)
+  struct Raw { float4 c; float l, r; };
+  auto issue = [&](unsigned ro) {
+    Raw q;
+#ifdef DW_KO_HALO   // knock-out build (wrong results): what do the two halo-column loads cost?
+    q.l = 0.f; q.r = 0.f;
+#else
+    q.l = csn_ld1(rb, ro, 0);
+    q.r = csn_ld1(rb, ro + 20u, 0);
+#endif
+    q.c = csn_ld4(rb, ro + 4u, 0);
+    return q;
+  };
+  auto fin = [&](const Raw& q) { return dw_row2_regs(q.l * ml, q.c.x, q.c.y, q.c.z, q.c.w, q.r * mr); };
+  // ---- phase 1: intermediate rows [yb - 1, yb + NY*R] -> LDS row index (y - yb + 1); rows outside the image are ZERO (the second
+  // conv pads its input, it does not see the first conv's response to padding).  Lane row ly owns rows [ly R, ly R + R) in trips of
+  // four; the block's two halo rows (-1 and NY R) are one extra row for the first / last lane row -- round 4's loop gave those
+  // lanes R + 1 rows, i.e. a whole extra trip of four for every wave that holds one of them ----
+  if (active) {
+    const DwPar pa = dw_par_load(rec);
+    const int y0 = yb + ly * R;                                  // first own image row
+    float* lrow = lds + (ly * R + 1) * pitch + 4 + x0;           // its LDS position
+    unsigned ro = (unsigned)((y0 - 1) * W + x0) * 4u - 4u;       // image row y0 - 1, column x0 - 1
+    const int Rm = y0 > H ? 0 : R;                               // (lane rows past the image's zero row H: nothing of theirs is read)
+    // the halo row of the first / last lane row: its own three-row window (two of the rows are loaded again below: L1 hits)
+    const bool first = ly == 0, last = ly == NY - 1;
+    if (first || last) {
+      const int yh = first ? yb - 1 : yb + NY * R;
+      const unsigned rh = (unsigned)((yh - 1) * W + x0) * 4u - 4u;
+      const Raw h0 = issue(rh), h1 = issue(rh + W4), h2 = issue(rh + 2u * W4);
+      dw2f_row(pa, lds + (yh - yb + 1) * pitch + 4 + x0, yh, H, has_l, has_r, fin(h0), fin(h1), fin(h2));
+      if (first && last) {   // (one lane row per block: both halo rows)
+        const unsigned rg = (unsigned)((yb + R - 1) * W + x0) * 4u - 4u;
+        const Raw g0 = issue(rg), g1 = issue(rg + W4), g2 = issue(rg + 2u * W4);
+        dw2f_row(pa, lds + (R + 1) * pitch + 4 + x0, yb + R, H, has_l, has_r, fin(g0), fin(g1), fin(g2));
+      }
+    }
+    const Raw a0 = issue(ro), a1 = issue(ro + W4);
+    ro += 2u * W4;
+    DwRow2 r0 = fin(a0), r1 = fin(a1);
+    for (int r = 0; r < Rm; r += 4) {
+      const Raw p0 = issue(ro), p1 = issue(ro + W4), p2 = issue(ro + 2u * W4), p3 = issue(ro + 3u * W4);
+      ro += 4u * W4;
+      const DwRow2 tp[6] = {r0, r1, fin(p0), fin(p1), fin(p2), fin(p3)};
+      if (y0 + r + 4 <= H) {   // (y0 >= 0 always: the trip is inside the image -- no per-row tests)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          csn_v2 o01, o23;
+          dw_conv4(pa, tp[q], tp[q + 1], tp[q + 2], o01, o23);
+          dw2f_put(lrow + q * pitch, has_l, has_r, dw_prelu2(o01, pa.al, pa.lim), dw_prelu2(o23, pa.al, pa.lim));
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dw2f_row(pa, lrow + q * pitch, y0 + r + q, H, has_l, has_r, tp[q], tp[q + 1], tp[q + 2]);
+      }
+      lrow += 4 * pitch;
+      r0 = tp[4];
+      r1 = tp[5];
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: second depthwise unit from LDS, four rows per trip (no register rotation inside a trip) ----
+  if (active) {
+    const DwPar pb = dw_par_load(rec + DWREC_FLOATS);
+    const int rs = ly * R;
+    const float* lp = lds + 3 + x0 + rs * pitch;   // column x0 - 1 of the LDS row of image row yb + rs - 1
+    DwRow2 r0 = dw_row2_lds4(lp), r1 = dw_row2_lds4(lp + pitch);
+    lp += 2 * pitch;
+    float* __restrict__ pp = br->pool ? br->pool + (int64_t)pc * (H >> 1) * (W >> 1) + (x0 >> 1) : nullptr;
+    float* __restrict__ pm = br->pool_mp ? br->pool_mp + (int64_t)pc * (H >> 2) * (W >> 2) + (x0 >> 2) : nullptr;
+    const int y0 = yb + rs;
+    const int nrow = min(R, H - y0);   // rows of this lane inside the image (<= 0: none)
+    float* __restrict__ q4 = br->out + (int64_t)pc * H * W + (int64_t)y0 * W + x0;
+    const bool skip = br->skip_out != 0;
+    for (int q = 0; q < nrow; q += 4) {
+      DwRow2 tp[6];
+      tp[0] = r0; tp[1] = r1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tp[2 + i] = dw_row2_lds4(lp + i * pitch);   // (rows past the tile's last: unused)
+      lp += 4 * pitch;
+      csn_v2 o[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        dw_conv4(pb, tp[i], tp[i + 1], tp[i + 2], o[i][0], o[i][1]);
+        o[i][0] = dw_prelu2(o[i][0], pb.al, pb.lim);
+        o[i][1] = dw_prelu2(o[i][1], pb.al, pb.lim);
+      }
+      if (!skip) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (q + i < nrow) *reinterpret_cast<float4*>(q4 + (q + i) * W) = make_float4(o[i][0][0], o[i][0][1], o[i][1][0], o[i][1][1]);
+      }
+      if (pp) {   // avg_pool2d(2, 2) of the output, same summation order as avgpool2_kernel; R even: rows q, q + 1 are a pair
+        float2 pv[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          pv[h].x = ((o[2 * h][0][0] + o[2 * h][0][1]) + o[2 * h + 1][0][0] + o[2 * h + 1][0][1]) * 0.25f;
+          pv[h].y = ((o[2 * h][1][0] + o[2 * h][1][1]) + o[2 * h + 1][1][0] + o[2 * h + 1][1][1]) * 0.25f;
+          if (q + 2 * h + 1 < nrow) *reinterpret_cast<float2*>(pp + (int64_t)((y0 + q) / 2 + h) * (W >> 1)) = pv[h];
+        }
+        // the lane's 4 x 4 block holds one 2x2 window of the averages (same values, max is order-free); H % 4 == 0
+        if (pm && q + 3 < nrow) pm[(int64_t)((y0 + q) >> 2) * (W >> 2)] = fmaxf(fmaxf(pv[0].x, pv[0].y), fmaxf(pv[1].x, pv[1].y));
+      }
+      r0 = tp[4];
+      r1 = tp[5];
+    }
+  }
+}
+
+static unsigned csn_div_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }   // dw_div
+
 size_t csn_dw2_lds_bytes(const DwArgs& a) {
   size_t m = 0;
   for (int k = 0; k < a.nbr; ++k) {
-    const size_t n = (size_t)(a.br[k].NY * a.br[k].R + 2) * (a.br[k].LX * 4 + 8) * sizeof(float);
+    // (+ 3 rows: dw3x3x2_fast_kernel's second phase reads its window four rows at a time, past the last row it uses)
+    const size_t n = (size_t)(a.br[k].NY * a.br[k].R + 2 + 3) * (a.br[k].LX * 4 + 8) * sizeof(float);
     if (n > m) m = n;
   }
   return m;
@@ -830,7 +1002,18 @@ int csn_launch_dw2(const DwArgs& a, void* stream) {
   bool vec = true;
   for (int k = 0; k < a.nbr; ++k) vec = vec && (a.br[k].W % 4 == 0);
   const size_t lds = csn_dw2_lds_bytes(a);
-  if (vec) {
+  bool fast = vec;   // every branch carries the folded per-channel records (dw_core.h)
+  for (int k = 0; k < a.nbr; ++k) fast = fast && a.br[k].rec != nullptr;
+  for (int k = 0; k < a.nbr; ++k) fast = fast && (a.br[k].R % 4) == 0 && a.br[k].tiles_x == 1;
+  if (fast) {
+    DwArgs f = a;
+    for (int k = 0; k < f.nbr; ++k) {
+      f.br[k].m_tiles_y = csn_div_magic((unsigned)f.br[k].tiles_y);
+      f.br[k].m_C = csn_div_magic((unsigned)f.br[k].C);
+      f.br[k].m_LX = csn_div_magic((unsigned)f.br[k].LX);
+    }
+    CSN_LAUNCH(dw3x3x2_fast_kernel, dim3(nblk), dim3(CSN_BLOCK), lds, stream, f);
+  } else if (vec) {
     CSN_LAUNCH((dw3x3x2_bn_prelu_kernel<true>), dim3(nblk), dim3(CSN_BLOCK), lds, stream, a);
   } else {
     CSN_LAUNCH((dw3x3x2_bn_prelu_kernel<false>), dim3(nblk), dim3(CSN_BLOCK), lds, stream, a);
