@@ -183,6 +183,7 @@ struct csn_plan {
   bool dw_fast = true;    // CSN_DW_FAST=0: the fused depthwise pair on the round-1 kernel instead of dw3x3x2_fast_kernel (A/B)
   bool ilb = true;        // CSN_OPT_FUSE_ILB / CSN_ILB=0: whole ILBlocks of the small maps on ilb_kernel (k_ilb.hip, round 5)
   int ilb_nt = 1;         // its row tiles per group and branch (CSN_ILB_NT=2: experiments)
+  int ilb_maxpix = 256;   // ... only where the low plane has at most this many pixels (CSN_ILB_MAXPIX)
   bool pw4 = true;        // CSN_OPT_PW4: two-branch 1x1 units on pw4_kernel (k_pw4.hip)
   int pw4_grid = 2048;    // its block cap (CSN_PW4_GRID, experiments)
   int pw4_twl = 6;        // log2 of its widest tile in low pixels: whole rows of up to 64 (CSN_PW4_TWL; 4 = 16 x 4 tiles: 1 % slower)
@@ -832,6 +833,11 @@ int plan_ilb(Builder& bl, int k) {
   a.Rh = 4; a.Rl = 4;
   a.nth = P.ilb_nt; a.ntl = OL > 0 ? P.ilb_nt : 0;
   if (!csn_ilb_supported(a.nth, a.ntl)) return CSN_OK;
+  // Measured (round 5, tools/probes/ilb_bench.hip): every group of an image re-reads ALL of the image's input channels, and on the
+  // 56^2 / 28^2 maps of stage 3 (7-10 groups, 370 KB of input per group, one 155 KB block per CU) the launch is bound by those
+  // re-reads: 45-50 us against 35-40 us for pw4_kernel + the depthwise pair.  Stage 4 (28^2 / 14^2: 18-24 us against 29-37 us) and
+  // smaller planes win.  CSN_ILB_MAXPIX overrides the low-plane pixel limit.
+  if (a.Hl * a.Wl > P.ilb_maxpix) return CSN_OK;
   size_t lds = csn_ilb_layout(a);
   if ((lds == 0 || lds > 160 * 1024) && a.nth > 1) {   // the planes of a narrower group
     a.nth = 1; a.ntl = OL > 0 ? 1 : 0;
@@ -1659,6 +1665,7 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   if (const char* e = std::getenv("CSN_ILB")) P->ilb = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_DW_FAST")) P->dw_fast = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_ILB_NT")) P->ilb_nt = std::atoi(e) == 2 ? 2 : 1;
+  if (const char* e = std::getenv("CSN_ILB_MAXPIX")) { if (std::atoi(e) > 0) P->ilb_maxpix = std::atoi(e); }
   if (const char* e = std::getenv("CSN_C3Q16")) P->c3q16 = std::atoi(e);
   if (const char* e = std::getenv("CSN_PWQ16")) P->pwq16 = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_MS_DX")) P->ms_dx = std::atoi(e) != 0;

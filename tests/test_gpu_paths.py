@@ -161,16 +161,18 @@ def test_gpu_loss_goes_down(hip, x2_manifest, act_dtype):
     assert abs(np.mean(mine[-10:]) - np.mean(ref[-10:])) <= tol_end * np.mean(ref[-10:]), (mine[-10:], ref[-10:])
 
 
-@pytest.mark.parametrize("shape,min_blocks", [((2, 224, 224), 8), ((3, 64, 64), 8), ((2, 96, 160), 8), ((64, 224, 224), 8)])
-def test_gpu_ilb_matches_unit_kernels(hip, x2_manifest, shape, min_blocks):
+@pytest.mark.parametrize("shape,min_blocks,maxpix", [((2, 224, 224), 8, 1024), ((3, 64, 64), 8, 1024), ((2, 96, 160), 8, 1024),
+                                                      ((64, 224, 224), 3, None)])
+def test_gpu_ilb_matches_unit_kernels(hip, x2_manifest, shape, min_blocks, maxpix):
     """Whole-ILBlock launches (k_ilb.hip, round 5) on the device: every block output against the unit kernels they replace
     (CSN_ILB=0), the logits of both against the oracle; batch 64 = the bench's own plan."""
     lib, dev = hip
-    n, worst, err = P.check_ilb_vs_unit_kernels(lib, dev, x2_manifest, *shape, min_blocks=min_blocks)
+    n, worst, err = P.check_ilb_vs_unit_kernels(lib, dev, x2_manifest, *shape, min_blocks=min_blocks,
+                                                env={"CSN_ILB_MAXPIX": str(maxpix)} if maxpix else None)
     print(f"{shape}: {n} units on ilb_kernel, worst block deviation {worst:.2e}, logits vs oracle {err:.2e}")
 
 
 def test_gpu_ilb_x1_and_two_tile_groups(hip, x1_manifest, x2_manifest):
     lib, dev = hip
-    print("x1:", P.check_ilb_vs_unit_kernels(lib, dev, x1_manifest, 2, 224, 224, min_blocks=4))
-    print("nt 2:", P.check_ilb_vs_unit_kernels(lib, dev, x2_manifest, 2, 64, 64, env={"CSN_ILB_NT": "2"}))
+    print("x1:", P.check_ilb_vs_unit_kernels(lib, dev, x1_manifest, 2, 224, 224, min_blocks=4, env={"CSN_ILB_MAXPIX": "1024"}))
+    print("nt 2:", P.check_ilb_vs_unit_kernels(lib, dev, x2_manifest, 2, 64, 64, env={"CSN_ILB_NT": "2", "CSN_ILB_MAXPIX": "1024"}))
