@@ -151,7 +151,8 @@ def main():
     ap.add_argument("--train-net", default="x2+unpruned", choices=["x2", "x2+unpruned", "unpruned"],
                     help="networks of the train-step points: the shipped csnet-L-x2 (BASELINE config 3) and / or the UN-PRUNED expand 2.0, "
                          "basic_split [0.5, 0.5] net the reference's training recipe starts from (csnet-L-x2_train.yml:9-18), batch 64")
-    ap.add_argument("--unpruned-batch", type=int, default=64)
+    ap.add_argument("--unpruned-batch", type=int, default=256,
+                    help="images per GPU of the un-pruned net's bf16 point (BASELINE config 3's batch); its fp32 point stays at 64")
     ap.add_argument("--no-latency-b1", action="store_true", help="skip the batch-1 latency loop (\"latency_b1\"): kernel traces of the "
                     "headline workload then hold batch-64 launches only")
     ap.add_argument("--event-steps", type=int, default=50,
@@ -377,22 +378,29 @@ def main():
                     um = M.build_model(basic_split=[0.5, 0.5], expand=2.0, save_path="/tmp")
                 um = um.to(dev).train()
                 um.flops_hook(1.0)
-                UB = args.unpruned_batch
-                um.set_batchsize(UB)
-                ux = torch.randn(UB, 3, S, S, generator=g).to(dev)
-                ut = (torch.rand(UB, 1, S, S, generator=g) > 0.5).float().to(dev)
                 unpruned = {"what": "un-pruned training network (expand 2.0, basic_split [0.5, 0.5], csnet-L-x2_train.yml:9-18), random init: "
-                                    "train-mode forward + BCE + backward + Adam", "batch_per_gpu": UB,
+                                    "train-mode forward + BCE + backward + Adam; bf16 storage at config 3's batch, fp32 at 64",
                             "parameters": int(sum(p.numel() for p in um.parameters()))}
-                for adt in ("fp32", "bf16"):
+                u_alg = train_algorithmic_bytes(um) // 4       # (3 in + 7 out) activation ELEMENTS per image, SURVEY 8(d)
+                for adt, UB in (("fp32", min(64, args.unpruned_batch)), ("bf16", args.unpruned_batch)):
+                    esz = 2 if adt == "bf16" else 4
+                    um.set_batchsize(UB)
+                    ux = torch.randn(UB, 3, S, S, generator=g).to(dev)
+                    ut = (torch.rand(UB, 1, S, S, generator=g) > 0.5).float().to(dev)
                     utr = FusedTrainer(um, lr=1e-4, weight_decay=5e-3, flops_weight=3.0, batchsize=UB, act_dtype=adt)
                     for _ in range(3):
                         utr.step(ux, ut, world_size=world)
-                    udt = D.timed_region(lambda: utr.step(ux, ut, world_size=world), max(3, args.train_steps // 2), sync=sync, device=dev)
                     n_ = max(3, args.train_steps // 2)
+                    udt = D.timed_region(lambda: utr.step(ux, ut, world_size=world), n_, sync=sync, device=dev)
+                    u_bw = u_alg * esz * UB / (udt / n_) / 1e9
                     unpruned[adt] = {"ms_per_step": round(udt / n_ * 1e3, 3), "images_per_sec": round(world * UB * n_ / udt, 1),
-                                    "loss": (round(float(utr.loss), 6) if np.isfinite(float(utr.loss)) else None)}
-                    del utr
+                                     "batch_per_gpu": UB,
+                                     "loss": (round(float(utr.loss), 6) if np.isfinite(float(utr.loss)) else None),
+                                     "roofline": {"bound": "hbm", "achieved": round(u_bw, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                  "frac": round(u_bw / HBM_PEAK_GBS, 4), "bytes_per_step": int(u_alg * esz * UB),
+                                                  "traffic": None,
+                                                  "what": f"algorithmic (3*in + 7*out) x {esz} B per unit of THIS net (SURVEY 8(d)) / whole-step time"}}
+                    del utr, ux, ut
                     um._engines = {}
                     torch.cuda.empty_cache()
                 del um

@@ -986,7 +986,8 @@ int csn_plan_train_act_info(const csn_plan* P, int32_t id, csn_train_act_info* o
   {
     const int pu = id < (int)P->act_prod_unit.size() ? P->act_prod_unit[id] : -1;
     if (pu >= 0 && P->units[pu].d.kind == CSN_UNIT_GOCT && P->bwd[pu].adj_fused[P->act_prod_branch[id]] >= 0 &&
-        !(P->overlap_bwd && P->overlap))   // (csn_backward: c.lanes -- the side lane keeps dz over z)
+        !P->last_bwd_lanes)   // the decision the last csn_backward actually took (side lane: dz stays over z) -- ADVICE r4: asking the
+                              // options again disagreed with it whenever the lanes could not be created (always so on the emulator)
       out->dz_offset_bytes = P->acts[id].ws_off;
   }
   out->grad_offset_bytes[0] = P->tg_off[id][0];
@@ -1018,7 +1019,8 @@ int csn_backward(csn_plan* P, const float* x, const float* dy, void* workspace, 
     Ctx c{*P, x, nullptr, static_cast<char*>(workspace), s};
     c.raw = true;
     c.a16 = P->act16;
-    c.lanes = P->overlap_bwd && lanes_ready(P);   // measured: no gain for the train step (106.3 vs 105.5 ms), off by default
+    c.lanes = P->overlap_bwd && lanes_ready(P);
+    P->last_bwd_lanes = c.lanes;   // measured: no gain for the train step (106.3 vs 105.5 ms), off by default
     BwdDefer defer;
     const BwdCtx b{c, arena, grad, flop_w, pen_scale, (c.lanes || std::getenv("CSN_BWD_NO_DEFER")) ? nullptr : &defer};
     for (int a : P->orphan_acts)

@@ -3,6 +3,7 @@
 // include/csnet_hip.h.  No torch types; the caller owns every tensor.
 #include <array>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -200,6 +201,8 @@ struct csn_plan {
   int c3q_twl = 6;        // ... of c3q_kernel's tile in output quads (CSN_C3Q_TWL)
   bool pw4_nosplit = false;   // CSN_PW4_NOSPLIT: no extra M groups on small maps (experiments)
   bool overlap_bwd = false;   // CSN_OPT_OVERLAP value 2: also the weight-gradient side lane of csn_backward
+  bool last_bwd_lanes = false;   // ... and whether the last csn_backward really ran with it (csn_plan_train_act_info reports from this)
+  int device = 0;             // ordinal of the device the plan's streams / events / packed buffer live on (csn_plan_destroy)
   bool overlap = true;    // CSN_OPT_OVERLAP: independent launches of a unit (and the MSBlocks) on parallel stream lanes
   hipStream_t lane[2] = {nullptr, nullptr};      // auxiliary lanes (lane 0 = the caller's stream)
   hipEvent_t lane_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1666,7 +1669,12 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   if (const char* e = std::getenv("CSN_DW_FAST")) P->dw_fast = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_ILB_NT")) P->ilb_nt = std::atoi(e) == 2 ? 2 : 1;
   if (const char* e = std::getenv("CSN_ILB_MAXPIX")) { if (std::atoi(e) > 0) P->ilb_maxpix = std::atoi(e); }
-  if (const char* e = std::getenv("CSN_C3Q16")) P->c3q16 = std::atoi(e);
+  if (const char* e = std::getenv("CSN_C3Q16")) {   // 0 / 1; 2 (bf16 weights in the FORWARD 3x3 launches: beyond the certified unit-local bound,
+    const int v = std::atoi(e);                      // profiles/r4_notes.md) only together with CSN_EXPERIMENTS=1, and it says so
+    const bool exp = std::getenv("CSN_EXPERIMENTS") && std::getenv("CSN_EXPERIMENTS")[0] == '1';
+    P->c3q16 = v <= 0 ? 0 : (v >= 2 && exp ? 2 : 1);
+    if (v >= 2) std::fprintf(stderr, "csnet_hip: CSN_C3Q16=%d -> %d%s\n", v, P->c3q16, exp ? " (experiment: forward 3x3 launches with bf16 weights)" : " (set CSN_EXPERIMENTS=1 for 2)");
+  }
   if (const char* e = std::getenv("CSN_PWQ16")) P->pwq16 = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_MS_DX")) P->ms_dx = std::atoi(e) != 0;
   if (std::getenv("CSN_NO_MP_FUSE")) P->no_mp_fuse = true;
@@ -1819,6 +1827,9 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
           }
   }
   if (csn_kernels_init() != 0) { delete P; return CSN_E_HIP; }
+#ifndef CSN_CPU_EMU
+  (void)hipGetDevice(&P->device);
+#endif
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&P->packed), (size_t)(P->packed_floats + 4) * sizeof(float));
   if (e != hipSuccess) { delete P; hip_fail(e, "hipMalloc(packed)"); return CSN_E_NOMEM; }
   e = hipMemsetAsync(P->packed, 0, (size_t)(P->packed_floats + 4) * sizeof(float), nullptr);
@@ -1836,7 +1847,17 @@ void csn_plan_destroy(csn_plan* P) {
   // callers enqueue asynchronously: the plan's last forward may still be running on the caller's stream and on the lanes when an
   // LRU eviction (sod100k_amd/model/csnet.py engine_for) drops it -- graphs, lane streams, events and the packed weights must
   // outlive that work.  Not legal (and not needed: nothing of this plan can be in flight) while a stream is capturing.
-  (void)hipDeviceSynchronize();
+  // (1) wait on the plan's OWN device, not on whatever device is current (a multi-GPU process evicting a plan of
+  // another GPU); (2) never from inside a stream capture of this thread: hipDeviceSynchronize() would invalidate the user's
+  // capture, and nothing of this plan can be in flight on a capturing stream that has not been launched yet.
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  if (cur != P->device) (void)hipSetDevice(P->device);
+  hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(nullptr, &cst) != hipSuccess || cst != hipStreamCaptureStatusNone;
+  if (capturing) (void)hipGetLastError();   // (the legacy stream cannot be queried during a global-mode capture: that IS the answer)
+  if (!capturing) (void)hipDeviceSynchronize();
+  if (cur != P->device) (void)hipSetDevice(cur);
 #endif
   for (hipEvent_t ev : P->ev) (void)hipEventDestroy(ev);
 #ifndef CSN_CPU_EMU
