@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CSN_ABI_VERSION 2   /* 2 (round 4): csn_profile_bracket_us, options 8-10, CSN_OPT_FUSE_ILB retired */
+#define CSN_ABI_VERSION 3   /* 2 (round 4): csn_profile_bracket_us, options 8-10; 3 (round 5): csn_build_sources_sha16, CSN_OPT_FUSE_ILB live again */
 #define CSN_MAX_BRANCH 3
 #define CSN_NDIL 5
 
@@ -112,8 +112,10 @@ void csn_plan_destroy(csn_plan* plan);
  * feeds it (CSFHead.fuse1x1), whose 79-channel output is then never written; 0 = separate launches (probes).
  * CSN_OPT_TILED3 [1]: 3x3 gOctConv passes run as an LDS-tiled implicit GEMM (goct_c3_kernel); 0 = per-pixel tap
  * gathers in goct_pw_kernel (same arithmetic up to the summation order inside a k step).
- * CSN_OPT_FUSE_ILB: retired in round 3 (the register-resident whole-ILBlock kernel of round 2 measured slower than the unit
- * kernels -- profiles/r2_notes.md -- and the unit kernels have since been replaced); the value is accepted and ignored.
+ * CSN_OPT_FUSE_ILB [1]: (round 5) an ILBlock whose first unit is a 1x1 gOctaveCBR with two input branches and whose low plane
+ * has at most 256 pixels (stage 4 at 224 x 224) runs as ONE launch of ilb_kernel (k_ilb.hip: contraction -> the group's planes in
+ * LDS -> depthwise pair): its two intermediate tensors are then never written.  0 = the unit kernels (probes).  Needs
+ * CSN_OPT_FUSE_DW.  (Rounds 3-4 accepted and ignored the option: round 2's register-resident kernel had been retired.)
  * CSN_OPT_OVERLAP [1]: launches that do not depend on each other -- {z -> high pass} || {low pass} of a 3x3 unit, the
  * per-branch launches of CSFHead.fuse, the three MSBlocks -- are enqueued on parallel stream lanes (fork / join by events on
  * the caller's stream; parallel branches of the hipGraph); 0 = one stream, strictly in order; 2 = additionally all

@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("SOD100K_HIP_LIB") or os.path.join(CSRC, "libcsnet_hip.so")
 SOURCES = ("csn_plan.hip", "k_misc.hip", "k_goct_pw.hip", "k_ms.hip", "k_train.hip", "k_wgrad.hip", "k_wgrad_c3.hip", "k_wgrad_bf.hip", "k_goct_c3.hip", "k_csf.hip", "k_pw4.hip", "k_c3q.hip", "k_pwq.hip", "k_ilb.hip")
 
-ABI_VERSION = 2       # include/csnet_hip.h CSN_ABI_VERSION: checked BEFORE the entry points are bound (a stale .so lacks the new ones)
+ABI_VERSION = 3       # include/csnet_hip.h CSN_ABI_VERSION: checked BEFORE the entry points are bound (a stale .so lacks the new ones)
 
 
 def sources_sha16() -> str:

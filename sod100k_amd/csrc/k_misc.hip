@@ -219,6 +219,24 @@ __device__ __forceinline__ DwRow dw_row_of(const DwRowRaw<csn_bf16>& q) {
   return r;
 }
 
+// x = PReLU(z * sc + sh) of a loaded row of six values, zero outside the plane -- the lean form (round 5, from dw_core.h's findings:
+// the bf16 train step's depthwise kernels ARE bound by their vector instructions).  Bit for bit csn_epi's values: PReLU as
+// v_med3(y, alpha y, +-inf) (= max for alpha <= 1, min above) instead of compare + select; a row outside the plane loads zeros, and
+// with scale = shift = 0 for that row y = 0 without a mask per element; only the two halo columns are masked.  ~16 instead of ~32
+// vector instructions per row.
+__device__ __forceinline__ DwRow dw_bn_row(DwRow r, bool rowin, bool has_l, bool has_r, float sc, float sh, float al) {
+  const float scr = rowin ? sc : 0.f, shr = rowin ? sh : 0.f;
+  const float lim = al <= 1.f ? __builtin_inff() : -__builtin_inff();
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const float y = fmaf(r.v[i], scr, shr);
+    r.v[i] = dw_med3(y, al * y, lim);
+  }
+  if (!has_l) r.v[0] = 0.f;
+  if (!has_r) r.v[5] = 0.f;
+  return r;
+}
+
 // row of x = PReLU(z * sc + sh) from a row of the producer's raw output z (see DwBranch::in_scale); outside the plane: 0
 template <bool VEC, typename AT>
 __device__ __forceinline__ DwRow dw_load_row_bn(csn_buf rb, int y, int H, int x0, int W, bool has_l, bool has_r, float sc,
@@ -226,6 +244,7 @@ __device__ __forceinline__ DwRow dw_load_row_bn(csn_buf rb, int y, int H, int x0
   DwRow r = dw_load_row_raw<VEC, AT>(rb, y, x0, W);
   if (zc) { zc[0] = r.v[1]; zc[1] = r.v[2]; zc[2] = r.v[3]; zc[3] = r.v[4]; }   // the raw centre values z
   const bool rowin = y >= 0 && y < H;
+  if (VEC) return dw_bn_row(r, rowin, has_l, has_r, sc, sh, al);
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const bool colin = i == 0 ? has_l : (i == 5 ? has_r : (VEC || x0 + i - 1 < W));
@@ -347,13 +366,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
     // the row as loaded -> the row the convolution sees (train mode, INBN: PReLU(BN(z)) of the producer's z, zero outside the plane)
     auto finish_in = [&](DwRow r, int y) {
       if (INBN) {
-        const bool rowin = y >= 0 && y < H;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          const bool colin = i == 0 ? has_l : (i == 5 ? has_r : true);
-          const float v = csn_epi(r.v[i], isc, ish, ial);
-          r.v[i] = (rowin && colin) ? v : 0.f;
-        }
+        r = dw_bn_row(r, y >= 0 && y < H, has_l, has_r, isc, ish, ial);
         if (y >= y0 && y < yend) gsum += (r.v[1] + r.v[2]) + (r.v[3] + r.v[4]);
         return r;
       }
@@ -489,6 +502,18 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
         for (int i = 0; i < 6; ++i) g.v[i] += e.v[i];
       }
       const bool rowin = y >= 0 && y < H;
+      if (VEC) {   // a row outside the plane loads dy = z = 0: with A = 0 for that row dz = 0 without a mask per element (round 5)
+        const float bAr = rowin ? bA : 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const float bn = fmaf(z.v[i], bsc, bsh);
+          const float t = fmaf(bB, z.v[i], bAr);
+          g.v[i] = fmaf(g.v[i], bn > 0.f ? bgi : bga, -t);
+        }
+        if (!has_l) g.v[0] = 0.f;
+        if (!has_r) g.v[5] = 0.f;
+        return g;
+      }
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         const float bn = fmaf(z.v[i], bsc, bsh);
@@ -531,14 +556,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
     auto finish_x = [&](DwRow r, int y, float* zc) {
       if (XBN) {
         if (zc) { zc[0] = r.v[1]; zc[1] = r.v[2]; zc[2] = r.v[3]; zc[3] = r.v[4]; }
-        const bool rowin = y >= 0 && y < H;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          const bool colin = i == 0 ? has_l : (i == 5 ? has_r : true);
-          const float v = csn_epi(r.v[i], isc, ish, ial);
-          r.v[i] = (rowin && colin) ? v : 0.f;
-        }
-        return r;
+        return dw_bn_row(r, y >= 0 && y < H, has_l, has_r, isc, ish, ial);
       }
       if (!has_l) r.v[0] = 0.f;
       if (!has_r) r.v[5] = 0.f;
