@@ -22,7 +22,7 @@ ABI_VERSION = 3       # include/csnet_hip.h CSN_ABI_VERSION: checked BEFORE the 
 
 
 def sources_sha16() -> str:
-    """sha256[:16] over the kernel sources (csrc/*.hip, *.h, *.inl): stamps counter files / bench lines with the tree they belong to
+    """sha256[:16] over the kernel sources (csrc/*.hip, *.h, *.inl, include/*.h): stamps counter files / bench lines with the tree they belong to
     (the GPU box has no .git)."""
     h = hashlib.sha256()
     for f in sorted(os.listdir(CSRC)):
@@ -30,6 +30,10 @@ def sources_sha16() -> str:
             h.update(f.encode())
             with open(os.path.join(CSRC, f), "rb") as fh:
                 h.update(fh.read())
+    for f in ("csnet_hip.h", "csf_hip.h"):        # the public headers are compiled in too (ABI version, argument structs)
+        h.update(f.encode())
+        with open(os.path.join(os.path.dirname(HERE), "include", f), "rb") as fh:
+            h.update(fh.read())
     return h.hexdigest()[:16]
 
 
