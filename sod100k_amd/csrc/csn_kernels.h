@@ -252,6 +252,8 @@ struct IlbArgs {
   int32_t nthreads;
   int32_t ph, pl, plane_h, plane_l;                               // LDS row pitches / plane sizes (floats), set by csn_ilb_layout
   int32_t off_h1, off_h2, off_l1, off_l2, off_z, off_par, lds_floats;
+  int32_t nsh, nrh, nsl, nrl;                                      // strips per row / row chunks per plane of the depthwise tasks
+  uint32_t m_hsr, m_hs, m_lsr, m_ls;                               // ... and ceil(2^32 / d) of nsh nrh, nsh, nsl nrl, nsl (0: d = 1)
 };
 size_t csn_ilb_layout(IlbArgs& a);          // fills the layout fields from (CH, CL, Hl, Wl, nth, ntl, Rh, Rl); LDS bytes, 0 = unsupported
 bool csn_ilb_supported(int nth, int ntl);

@@ -183,7 +183,7 @@ struct csn_plan {
   int c3q_cap = 4;        // its row tiles per M group (CSN_C3Q_NT, experiments)
   bool dw_fast = true;    // CSN_DW_FAST=0: the fused depthwise pair on the round-1 kernel instead of dw3x3x2_fast_kernel (A/B)
   bool ilb = true;        // CSN_OPT_FUSE_ILB / CSN_ILB=0: whole ILBlocks of the small maps on ilb_kernel (k_ilb.hip, round 5)
-  int ilb_nt = 1;         // its row tiles per group and branch (CSN_ILB_NT=2: experiments)
+  int ilb_nt = 0;         // its row tiles per group and branch: 0 = chosen per block (plan_ilb), CSN_ILB_NT=1|2 forces (experiments)
   int ilb_maxpix = 256;   // ... only where the low plane has at most this many pixels (CSN_ILB_MAXPIX)
   bool pw4 = true;        // CSN_OPT_PW4: two-branch 1x1 units on pw4_kernel (k_pw4.hip)
   int pw4_grid = 2048;    // its block cap (CSN_PW4_GRID, experiments)
@@ -835,6 +835,28 @@ int plan_ilb(Builder& bl, int k) {
   a.Hl = P.H >> (u.base_lvl + 1); a.Wl = P.W >> (u.base_lvl + 1); a.B = P.S;
   a.Rh = 4; a.Rl = 4;
   a.nth = P.ilb_nt; a.ntl = OL > 0 ? P.ilb_nt : 0;
+  if (P.ilb_nt == 0) {
+    // Row tiles per group and branch: the fewest rounds of blocks over the 256 CUs (a block is one latency chain: loads -> contraction
+    // -> planes -> depthwise pair -> stores), then the fewest groups (every group re-reads the image's inputs).  Measured on the
+    // harness (profiles/r5_notes.md): stage 4.2 with 11 groups of (1, 1) starts its blocks in two waves (28.9 us), stage 4.3 with
+    // (2, 0) 22.4 instead of 26.6 us.
+    const int th_ = (OH + 3) / 4, tl_ = (OL + 3) / 4;
+    int64_t best = -1;
+    for (int nh = 1; nh <= 2; ++nh)
+      for (int nl = (OL > 0 ? 1 : 0); nl <= (OL > 0 ? 2 : 0); ++nl) {
+        if (!csn_ilb_supported(nh, nl)) continue;
+        IlbArgs t = a;
+        t.nth = nh; t.ntl = nl;
+        const size_t l = csn_ilb_layout(t);
+        if (l == 0 || l > 160 * 1024) continue;
+        const int g = std::max((th_ + nh - 1) / nh, nl > 0 ? (tl_ + nl - 1) / nl : 0);
+        const int64_t slots = 256 * (int64_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / l, 2048 / (size_t)t.nthreads));
+        const int64_t rounds = ((int64_t)P.S * g + slots - 1) / slots;
+        const int64_t cost = rounds * 1000 + g;
+        if (best < 0 || cost < best) { best = cost; a.nth = nh; a.ntl = nl; }
+      }
+    if (best < 0) return CSN_OK;
+  }
   if (!csn_ilb_supported(a.nth, a.ntl)) return CSN_OK;
   // Measured (round 5, tools/probes/ilb_bench.hip): every group of an image re-reads ALL of the image's input channels, and on the
   // 56^2 / 28^2 maps of stage 3 (7-10 groups, 370 KB of input per group, one 155 KB block per CU) the launch is bound by those
@@ -1667,7 +1689,7 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   if (const char* e = std::getenv("CSN_PW4_FLAT")) P->pw4_flat = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_ILB")) P->ilb = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_DW_FAST")) P->dw_fast = std::atoi(e) != 0;
-  if (const char* e = std::getenv("CSN_ILB_NT")) P->ilb_nt = std::atoi(e) == 2 ? 2 : 1;
+  if (const char* e = std::getenv("CSN_ILB_NT")) P->ilb_nt = std::atoi(e) == 2 ? 2 : (std::atoi(e) == 1 ? 1 : 0);
   if (const char* e = std::getenv("CSN_ILB_MAXPIX")) { if (std::atoi(e) > 0) P->ilb_maxpix = std::atoi(e); }
   if (const char* e = std::getenv("CSN_C3Q16")) {   // 0 / 1; 2 (bf16 weights in the FORWARD 3x3 launches: beyond the certified unit-local bound,
     const int v = std::atoi(e);                      // profiles/r4_notes.md) only together with CSN_EXPERIMENTS=1, and it says so

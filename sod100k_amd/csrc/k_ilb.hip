@@ -58,6 +58,14 @@ __device__ __forceinline__ void ilb_load_lo(csn_buf rb, unsigned o, unsigned cs,
   for (int j = 0; j < LB; ++j) v[j] = csn_ld1(rb, o, (unsigned)min(k0 + j, C - 1) * cs);
 }
 
+__device__ __forceinline__ unsigned ilb_div(unsigned n, unsigned m) {   // n / d for n * d < 2^32, m = ceil(2^32 / d) or 0 (d = 1)
+#ifdef CSN_CPU_EMU
+  return m ? (unsigned)(((unsigned long long)n * m) >> 32) : n;
+#else
+  return m ? __umulhi(n, m) : n;
+#endif
+}
+
 // one depthwise unit over the group's planes of one branch: task = (channel, row chunk, strip of four columns) of `nch` channels.
 // LAST = false: LDS plane `src` -> LDS plane `dst`;  LAST = true: -> HBM (+ pooled copies).  dw_core.h's row core.
 template <bool LAST>
@@ -119,10 +127,11 @@ __device__ __forceinline__ void ilb_dw_rows(const DwPar& par, const float* base,
 
 template <bool LAST>
 __device__ __forceinline__ void ilb_dw_branch(int task, const float* src, float* dst, int plane, int pitch, int H, int W, int R, int nstrip,
-                                              int nrc, const float* rec, float* __restrict__ out, float* __restrict__ pool,
-                                              float* __restrict__ pmax, int skip_out) {
-  const int c = task / (nstrip * nrc), rem = task - c * (nstrip * nrc);
-  const int rc = rem / nstrip, s = rem - rc * nstrip;
+                                              int nrc, unsigned m_sr, unsigned m_s, const float* rec, float* __restrict__ out,
+                                              float* __restrict__ pool, float* __restrict__ pmax, int skip_out) {
+  // (the divisors are launch constants: the host passes ceil(2^32 / d), 0 for d = 1 -- one multiply-high per division)
+  const int c = (int)ilb_div((unsigned)task, m_sr), rem = task - c * (nstrip * nrc);
+  const int rc = (int)ilb_div((unsigned)rem, m_s), s = rem - rc * nstrip;
   const int x0 = 4 * s, y0 = rc * R;
   // the channel's record in LDS: conv3x3_1's {w'[9], shift, alpha, .}, then conv3x3_2's (IlbArgs::dwrec_*, CSN_PREP_DWREC)
   const DwPar par = dw_par_load(rec + c * (2 * DWREC_FLOATS) + (LAST ? DWREC_FLOATS : 0));
@@ -332,26 +341,26 @@ __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
   ILB_STAMP(3);
 
   // ---- phases 2, 3: the depthwise pair, tasks = (channel, row chunk, strip of four columns), high planes then low planes ----
-  const int nsh = (Wh + 3) >> 2, nrh = (Hh + a->Rh - 1) / a->Rh, nsl = (Wl + 3) >> 2, nrl = (Hl + a->Rl - 1) / a->Rl;
+  const int nsh = a->nsh, nrh = a->nrh, nsl = a->nsl, nrl = a->nrl;
   const int th = nch_h * nsh * nrh, tl = nch_l * nsl * nrl;
   for (int task = tid; task < th + tl; task += nthr) {
-    if (task < th) ilb_dw_branch<false>(task, H1, H2, plane_h, ph, Hh, Wh, a->Rh, nsh, nrh, par_dh, nullptr, nullptr, nullptr, 0);
-    else ilb_dw_branch<false>(task - th, L1, L2, plane_l, pl, Hl, Wl, a->Rl, nsl, nrl, par_dl, nullptr, nullptr, nullptr, 0);
+    const bool hi = task < th;
+    ilb_dw_branch<false>(hi ? task : task - th, hi ? H1 : L1, hi ? H2 : L2, hi ? plane_h : plane_l, hi ? ph : pl, hi ? Hh : Hl, hi ? Wh : Wl,
+                         hi ? a->Rh : a->Rl, hi ? nsh : nsl, hi ? nrh : nrl, hi ? a->m_hsr : a->m_lsr, hi ? a->m_hs : a->m_ls,
+                         hi ? par_dh : par_dl, nullptr, nullptr, nullptr, 0);
   }
   __syncthreads();
   ILB_STAMP(4);
   for (int task = tid; task < th + tl; task += nthr) {
-    if (task < th) {
-      const int64_t o = ((int64_t)b * OH + r0h);
-      ilb_dw_branch<true>(task, H2, nullptr, plane_h, ph, Hh, Wh, a->Rh, nsh, nrh, par_dh, a->yh + o * Hh * Wh,
-                          a->pool_h ? a->pool_h + o * (Hh >> 1) * (Wh >> 1) : nullptr,
-                          a->mp_h ? a->mp_h + o * (Hh >> 2) * (Wh >> 2) : nullptr, a->skip_h);
-    } else {
-      const int64_t o = ((int64_t)b * OL + r0l);
-      ilb_dw_branch<true>(task - th, L2, nullptr, plane_l, pl, Hl, Wl, a->Rl, nsl, nrl, par_dl, a->yl + o * Hl * Wl,
-                          a->pool_l ? a->pool_l + o * (Hl >> 1) * (Wl >> 1) : nullptr,
-                          a->mp_l ? a->mp_l + o * (Hl >> 2) * (Wl >> 2) : nullptr, a->skip_l);
-    }
+    const bool hi = task < th;
+    const int Hb = hi ? Hh : Hl, Wb = hi ? Wh : Wl;
+    const int64_t o = hi ? ((int64_t)b * OH + r0h) : ((int64_t)b * OL + r0l);
+    float* pool = hi ? a->pool_h : a->pool_l;
+    float* pmx = hi ? a->mp_h : a->mp_l;
+    ilb_dw_branch<true>(hi ? task : task - th, hi ? H2 : L2, nullptr, hi ? plane_h : plane_l, hi ? ph : pl, Hb, Wb, hi ? a->Rh : a->Rl,
+                        hi ? nsh : nsl, hi ? nrh : nrl, hi ? a->m_hsr : a->m_lsr, hi ? a->m_hs : a->m_ls, hi ? par_dh : par_dl,
+                        (hi ? a->yh : a->yl) + o * Hb * Wb, pool ? pool + o * (Hb >> 1) * (Wb >> 1) : nullptr,
+                        pmx ? pmx + o * (Hb >> 2) * (Wb >> 2) : nullptr, hi ? a->skip_h : a->skip_l);
   }
 #ifdef ILB_TIMING
   __syncthreads();
@@ -362,7 +371,8 @@ __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
 // ---- host side -----------------------------------------------------------------------------------------------------------------
 typedef void (*IlbFn)(IlbArgs);
 struct IlbEntry { int nth, ntl; IlbFn fn; };
-static const IlbEntry g_ilb_table[] = {{1, 1, ilb_kernel<1, 1>}, {1, 0, ilb_kernel<1, 0>}, {2, 2, ilb_kernel<2, 2>}, {2, 0, ilb_kernel<2, 0>}};
+static const IlbEntry g_ilb_table[] = {{1, 1, ilb_kernel<1, 1>}, {1, 0, ilb_kernel<1, 0>}, {2, 2, ilb_kernel<2, 2>}, {2, 0, ilb_kernel<2, 0>},
+                                       {1, 2, ilb_kernel<1, 2>}, {2, 1, ilb_kernel<2, 1>}};
 
 // LDS layout of an item for (nth, ntl) row tiles per group; returns the bytes, 0 when the geometry is not supported
 size_t csn_ilb_layout(IlbArgs& a) {
@@ -377,6 +387,10 @@ size_t csn_ilb_layout(IlbArgs& a) {
   a.off_l1 = off; off += 4 * a.ntl * a.plane_l;
   a.off_l2 = off; off += 4 * a.ntl * a.plane_l;
   a.off_z = off; off += 4 * a.nth * a.Hl * a.Wl;
+  a.nsh = (Wh + 3) / 4; a.nrh = (Hh + a.Rh - 1) / a.Rh; a.nsl = (a.Wl + 3) / 4; a.nrl = (a.Hl + a.Rl - 1) / a.Rl;
+  auto magic = [](unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); };
+  a.m_hsr = magic((unsigned)(a.nsh * a.nrh)); a.m_hs = magic((unsigned)a.nsh);
+  a.m_lsr = magic((unsigned)(a.nsl * a.nrl)); a.m_ls = magic((unsigned)a.nsl);
   a.off_par = off; off += (a.nth + a.ntl) * (16 + 96);   // epilogue records + depthwise records of the group's channels
   a.lds_floats = off;
   // a wave per tile of 64 low pixels (the accumulators live across the z barrier); one task per lane where the block allows
