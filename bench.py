@@ -300,7 +300,7 @@ def main():
                                             # the fused depthwise pair implements TWO units per launch: its algorithmic
                                             # bytes count both units' (in + out), the kernel physically moves half of that
                                             **({"moved_GBps": round(0.5 * v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
-                                               if k == "dw3x3x2_bn_prelu_kernel" and v["bytes"] else {}))
+                                               if k in ("dw3x3x2_bn_prelu_kernel", "dw3x3x2_fast_kernel") and v["bytes"] else {}))
                                     for k, v in agg.items() if "ms" in v})
 
     sub_b = eng_sub(eng, B)

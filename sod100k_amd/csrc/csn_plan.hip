@@ -1297,7 +1297,8 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
       }
       if (fused) LAUNCH_TRY(csn_launch_dw2(a, c.stream));
       else LAUNCH_TRY(csn_launch_dw(a, c.stream));
-      { const int ms_ = c.mark(fused ? "dw3x3x2_bn_prelu_kernel" : "dw3x3_bn_prelu_kernel"); if (ms_ != CSN_OK) return ms_; }
+      { const int ms_ = c.mark(fused ? (a.br[0].rec ? "dw3x3x2_fast_kernel" : "dw3x3x2_bn_prelu_kernel") : "dw3x3_bn_prelu_kernel");
+        if (ms_ != CSN_OK) return ms_; }
       for (int q = 0, k = 0; k < d.n_in; ++k) {   // |mean_hw y| tables of the producers whose y was formed on load here
         if (d.cout[k] == 0) continue;
         const DwBranch& br = a.br[q++];
@@ -2211,7 +2212,13 @@ const char* csn_unit_kernel_name(const csn_plan* P, int32_t u) {
   if (!P || u < 0 || u >= (int)P->units.size()) return "";
   if (ilb_active(*P, u) || (u >= 1 && ilb_active(*P, u - 1)) || (u >= 2 && ilb_active(*P, u - 2))) return "ilb_kernel";
   if (P->fuse_dw && P->units[u].d.kind == CSN_UNIT_DW) {
-    if (P->units[u].fuse_next || (u > 0 && P->units[u - 1].fuse_next)) return "dw3x3x2_bn_prelu_kernel";
+    if (P->units[u].fuse_next || (u > 0 && P->units[u - 1].fuse_next)) {
+      const UnitPlan& first = P->units[u].fuse_next ? P->units[u] : P->units[u - 1];
+      bool fast = P->dw_fast;   // (run_unit: every branch carries the folded records and its width is a multiple of four)
+      for (int k = 0; k < first.d.n_in; ++k)
+        if (first.d.cout[k] > 0 && (first.dw2rec[k] < 0 || ((P->W >> P->acts[first.d.in_act[k]].lvl) % 4) != 0)) fast = false;
+      return fast ? "dw3x3x2_fast_kernel" : "dw3x3x2_bn_prelu_kernel";
+    }
   }
   if (P->tiled3 && P->units[u].c3) {
     bool q = P->c3q;
