@@ -248,6 +248,8 @@ struct IlbArgs {
   int32_t skip_h, skip_l;         // the full-resolution output has no other reader
   int32_t CH, CL, OH, OL, Hl, Wl, B;
   int32_t ng, gimg_floats, nth, ntl;
+  int32_t k3;                     // 3x3 stride-2 entry block: xh = the block input's 2x2 average, xl = its 2x2 maximum (CL = CH), image
+                                  // [ng][9 CH][4][P] (CSN_PREP_C3Q)
   int32_t Rh, Rl;                 // rows per depthwise task (even with pool_*, multiple of 4 with mp_*)
   int32_t nthreads;
   int32_t ph, pl, plane_h, plane_l;                               // LDS row pitches / plane sizes (floats), set by csn_ilb_layout

@@ -147,6 +147,7 @@ struct UnitPlan {
   // ilb_kernel (k_ilb.hip); on = 0: not eligible
   struct Ilb {
     int on = 0, nth = 0, ntl = 0, ng = 0, gimg = 0, Rh = 4, Rl = 4;
+    int k3 = 0;   // the 3x3 stride-2 entry block of a stage (one input branch; its 2x2 averages / maxima come from the pair in front)
     int64_t wimg = -1, ep[2] = {-1, -1};
     int64_t dwrec[2] = {-1, -1};   // per channel {w9[9] x100, scale, shift, alpha} of conv3x3_1 and of conv3x3_2 (24 floats)
   } ilb;
@@ -807,6 +808,8 @@ int plan_cls(Builder& bl, UnitPlan& u) {
 // Whole ILBlock on ilb_kernel (k_ilb.hip): unit k is a two-input 1x1 gOctaveCBR whose outputs are read only by the fused depthwise
 // pair (k + 1, k + 2), and the planes of a group of output channels fit the LDS of a CU.  Lays out the per-group weight images
 // (pw4_kernel's [K][4][P] form, uniform groups of nth high + ntl low row tiles) and the epilogue records.
+bool dw_pair_writes_mp(const csn_plan& P, const UnitPlan& pair, int k);
+
 int plan_ilb(Builder& bl, int k) {
   csn_plan& P = bl.P;
   if (k + 2 >= (int)P.units.size()) return CSN_OK;
@@ -814,8 +817,12 @@ int plan_ilb(Builder& bl, int k) {
   const csn_unit_desc& d = u.d;
   const UnitPlan& d1 = P.units[k + 1];
   const UnitPlan& d2 = P.units[k + 2];
-  if (d.kind != CSN_UNIT_GOCT || d.ksize != 1 || d.stride != 1 || u.std_conv || d.n_in != 2 || d.cin[0] <= 0 || d.cin[1] <= 0) return CSN_OK;
-  if (d.n_out < 1 || d.n_out > 2 || d.cout[0] <= 0) return CSN_OK;
+  if (d.kind != CSN_UNIT_GOCT || u.std_conv || d.n_out < 1 || d.n_out > 2 || d.cout[0] <= 0) return CSN_OK;
+  const bool one = d.ksize == 1 && d.stride == 1 && d.n_in == 2 && d.cin[0] > 0 && d.cin[1] > 0;
+  // the stride-2 entry block: 3x3, ONE input branch whose 2x2 averages AND their 2x2 maxima the depthwise pair in front delivers
+  const bool k3 = d.ksize == 3 && d.stride == 2 && d.n_in == 1 && d.cin[0] > 0 && d.n_out == 2 && d.cout[1] > 0 && u.pooled_by_producer &&
+                  u.mp_producer >= 0 && u.mp_off[0] >= 0 && dw_pair_writes_mp(P, P.units[u.mp_producer], 0);
+  if (!one && !k3) return CSN_OK;
   if (d1.d.kind != CSN_UNIT_DW || d2.d.kind != CSN_UNIT_DW || !d1.fuse_next || d1.d.n_in != d.n_out) return CSN_OK;
   for (int j = 0; j < d.n_out; ++j) {
     if (d1.d.cin[j] != d.cout[j]) return CSN_OK;
@@ -828,10 +835,11 @@ int plan_ilb(Builder& bl, int k) {
     }
   }
   const int OH = d.cout[0], OL = d.n_out >= 2 ? d.cout[1] : 0;
-  int cin_tot = d.cin[0] + d.cin[1];
+  int cin_tot = k3 ? d.cin[0] : d.cin[0] + d.cin[1];
   const int co_off[2] = {0, OH}, ci_off[2] = {0, d.cin[0]};
   IlbArgs a = {};
-  a.CH = d.cin[0]; a.CL = d.cin[1]; a.OH = OH; a.OL = OL;
+  a.k3 = k3 ? 1 : 0;
+  a.CH = d.cin[0]; a.CL = k3 ? d.cin[0] : d.cin[1]; a.OH = OH; a.OL = OL;
   a.Hl = P.H >> (u.base_lvl + 1); a.Wl = P.W >> (u.base_lvl + 1); a.B = P.S;
   a.Rh = 4; a.Rl = 4;
   a.nth = P.ilb_nt; a.ntl = OL > 0 ? P.ilb_nt : 0;
@@ -842,7 +850,7 @@ int plan_ilb(Builder& bl, int k) {
     // (2, 0) 22.4 instead of 26.6 us.
     const int th_ = (OH + 3) / 4, tl_ = (OL + 3) / 4;
     int64_t best = -1;
-    for (int nh = 1; nh <= 2; ++nh)
+    for (int nh = 1; nh <= (k3 ? 1 : 2); ++nh)   // (the 3x3 form with eight high channels per group spills: 112-160 B of scratch per lane)
       for (int nl = (OL > 0 ? 1 : 0); nl <= (OL > 0 ? 2 : 0); ++nl) {
         if (!csn_ilb_supported(nh, nl)) continue;
         IlbArgs t = a;
@@ -850,7 +858,9 @@ int plan_ilb(Builder& bl, int k) {
         const size_t l = csn_ilb_layout(t);
         if (l == 0 || l > 160 * 1024) continue;
         const int g = std::max((th_ + nh - 1) / nh, nl > 0 ? (tl_ + nl - 1) / nl : 0);
-        const int64_t slots = 256 * (int64_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / l, 2048 / (size_t)t.nthreads));
+        // blocks per CU: by LDS and by registers (launch bound 1024 = at most 128 VGPRs: 16 waves per CU)
+        const size_t wblk = (size_t)(t.nthreads + 63) / 64;
+        const int64_t slots = 256 * (int64_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / l, 16 / wblk));
         const int64_t rounds = ((int64_t)P.S * g + slots - 1) / slots;
         const int64_t cost = rounds * 1000 + g;
         if (best < 0 || cost < best) { best = cost; a.nth = nh; a.ntl = nl; }
@@ -873,12 +883,20 @@ int plan_ilb(Builder& bl, int k) {
   const int ng = std::max((th + a.nth - 1) / a.nth, a.ntl > 0 ? (tl + a.ntl - 1) / a.ntl : 0);
   const int NT4 = (a.nth + a.ntl + 3) & ~3, Pp = PW4_PITCH(NT4);
   UnitPlan::Ilb& I = u.ilb;
-  I.nth = a.nth; I.ntl = a.ntl; I.ng = ng; I.gimg = a.gimg_floats; I.Rh = a.Rh; I.Rl = a.Rl;
+  I.nth = a.nth; I.ntl = a.ntl; I.ng = ng; I.gimg = a.gimg_floats; I.Rh = a.Rh; I.Rl = a.Rl; I.k3 = a.k3;
   I.wimg = bl.alloc_packed((int64_t)ng * I.gimg);
   for (int g = 0; g < ng; ++g) {
     const int64_t img = I.wimg + (int64_t)g * I.gimg;
     const int r0h = 4 * a.nth * g, r0l = 4 * a.ntl * g;
     const int nrh = std::max(0, std::min(4 * a.nth, OH - r0h)), nrl = a.ntl > 0 ? std::max(0, std::min(4 * a.ntl, OL - r0l)) : 0;
+    if (k3) {   // [9 C][4][P]: gathered entry 9 c + tap (CSN_PREP_C3Q), high rows in tiles 0 .., low rows behind them
+      const int ld9 = cin_tot * 9;
+      if (nrh > 0)
+        bl.job(CSN_PREP_C3Q, nrh, img, d.w_off[0] + (int64_t)(co_off[0] + r0h) * ld9, -1, -1, -1, 1.f, ld9, d.cin[0], Pp, 0 | (0 << 8));
+      if (nrl > 0)
+        bl.job(CSN_PREP_C3Q, nrl, img, d.w_off[0] + (int64_t)(co_off[1] + r0l) * ld9, -1, -1, -1, 1.f, ld9, d.cin[0], Pp, a.nth | (0 << 8));
+      continue;
+    }
     int k0 = 0;
     for (int i = 0; i < 2; ++i) {   // gathered channels: branch 0 (high), branch 1 (low)
       if (nrh > 0)
@@ -1541,11 +1559,17 @@ int run_ilb(const Ctx& c, int k) {
   const csn_unit_desc& d = u.d;
   const UnitPlan::Ilb& I = u.ilb;
   IlbArgs a = {};
-  a.CH = d.cin[0]; a.CL = d.cin[1]; a.OH = d.cout[0]; a.OL = d.n_out >= 2 ? d.cout[1] : 0;
+  a.k3 = I.k3;
+  a.CH = d.cin[0]; a.CL = I.k3 ? d.cin[0] : d.cin[1]; a.OH = d.cout[0]; a.OL = d.n_out >= 2 ? d.cout[1] : 0;
   a.Hl = P.H >> (u.base_lvl + 1); a.Wl = P.W >> (u.base_lvl + 1); a.B = P.S;
   a.nth = I.nth; a.ntl = I.ntl; a.ng = I.ng; a.Rh = I.Rh; a.Rl = I.Rl;
   if (csn_ilb_layout(a) == 0 || a.gimg_floats != I.gimg) return CSN_E_STATE;
-  a.xh = c.act_in(d.in_act[0]); a.xl = c.act_in(d.in_act[1]);
+  if (I.k3) {   // the 2x2 averages of the block's input and their 2x2 maxima, written by the depthwise pair (or ilb launch) in front
+    a.xh = reinterpret_cast<const float*>(c.ws + u.pooled_off[0]);
+    a.xl = reinterpret_cast<const float*>(c.ws + u.mp_off[0]);
+  } else {
+    a.xh = c.act_in(d.in_act[0]); a.xl = c.act_in(d.in_act[1]);
+  }
   a.yh = c.act_out(d2.d.out_act[0]);
   a.yl = a.OL > 0 ? c.act_out(d2.d.out_act[1]) : nullptr;
   a.wimg = c.pk(I.wimg);
@@ -1569,7 +1593,9 @@ int run_ilb(const Ctx& c, int k) {
 
 // ... which needs what the stride-2 consumer's planning expects of the pair in front of it
 bool ilb_active(const csn_plan& P, int k) {
-  return P.ilb && P.fuse_dw && k >= 0 && k + 2 < (int)P.units.size() && P.units[k].ilb.on;
+  if (!(P.ilb && P.fuse_dw && k >= 0 && k + 2 < (int)P.units.size() && P.units[k].ilb.on)) return false;
+  const UnitPlan& u = P.units[k];   // the 3x3 entry form reads the max-pooled copy the pair in front writes (options may have changed)
+  return !u.ilb.k3 || (u.mp_producer >= 0 && dw_pair_writes_mp(P, P.units[u.mp_producer], 0));
 }
 
 }  // namespace

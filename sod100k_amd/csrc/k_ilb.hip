@@ -145,7 +145,13 @@ __device__ __forceinline__ void ilb_dw_branch(int task, const float* src, float*
 
 }  // namespace
 
-template <int NTH, int NTL>
+// K3 (round 5): the stride-2 ENTRY block of a stage -- gOctaveCBR with 3x3 kernels on ONE input branch (csnet.py:33-40, 679-680,
+// 708-717): y_h = conv3x3(x), y_l = conv3x3(max_pool2(x)), x = the 2x2 average of the block's input, delivered with its 2x2 maximum
+// by the depthwise pair in front (xh / xl of the argument block, the SAME CH channels at two resolutions).  The contraction is
+// k_c3q.hip's: per channel the 4x4 window around the lane's quad (zero padding = out-of-range offsets of a bounded resource) and the
+// 3x3 window around its low pixel, nine taps x (4 NTH + NTL) matrix instructions; no low -> high term.  Everything behind the
+// contraction (planes in LDS, depthwise pair) is the 1x1 form's.
+template <int NTH, int NTL, bool K3 = false>
 __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
   constexpr int NT4 = (NTH + NTL + 3) & ~3, P = PW4_PITCH(NT4);
   constexpr int HB = NTH == 1 ? 8 : 4, LB = NTH == 1 ? 16 : 8;   // channels per load batch (two batches in flight)
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
   float2 hA[HB][2], hB[HB][2];
   float lA[LB], lB[LB];
   const int nfh = (CH - 1) / HB;   // full batches in front of the last one
-  if (tile_on) {
+  if (tile_on && !K3) {
     pw4_load_hi<HB>(rbh, oh0, oh1, csh, 0, CH, hA);
     if (nfh >= 1) pw4_load_hi<HB>(rbh, oh0, oh1, csh, HB, CH, hB);
   }
@@ -238,7 +244,72 @@ __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
   for (int t = 0; t < (NTL > 0 ? NTL : 1); ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) accl[t][i] = 0.f;
-  if (tile_on) {
+  if (tile_on && K3) {
+#ifdef CSN_CPU_EMU
+    const float* wg = lds;
+#else
+    const float* wg = lds + (lane & 3) * P;
+#endif
+    // window geometry: rows 2y - 1 .. 2y + 2 of the high plane at column 2x (64-bit centre pairs), left / right edge columns; the 3x3
+    // neighbourhood of (y, x) in the low plane; anything outside a plane gets an out-of-range offset (= the zero padding)
+    unsigned rowh[4], ol9[9];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int yy = 2 * y - 1 + r;
+      rowh[r] = (yy >= 0 && yy < Hh) ? (unsigned)(yy * Wh + 2 * x) * 4u : 0x80000000u;
+    }
+    const unsigned dl = x > 0 ? 0u - 4u : 0x40000000u, dr = 2 * x + 2 < Wh ? 8u : 0x40000000u;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int yy = y - 1 + r, xx = x - 1 + c;
+        ol9[3 * r + c] = (yy >= 0 && yy < Hl && xx >= 0 && xx < Wl) ? (unsigned)(yy * Wl + xx) * 4u : 0x80000000u;
+      }
+    auto load_win = [&](int c, float (&v)[16], float (&u)[9]) {
+      const unsigned sh_ = (unsigned)min(c, CH - 1) * csh, sl_ = (unsigned)min(c, CH - 1) * csl;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float2 cc = csn_ld2(rbh, rowh[r], sh_);
+        v[4 * r + 1] = cc.x; v[4 * r + 2] = cc.y;
+        v[4 * r] = csn_ld1(rbh, rowh[r] + dl, sh_);
+        v[4 * r + 3] = csn_ld1(rbh, rowh[r] + dr, sh_);
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) u[t] = csn_ld1(rbl, ol9[t], sl_);
+    };
+    auto contract = [&](const float (&v)[16], const float (&u)[9], const float* wk) {
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) {
+        const int ty = t9 / 3, tx = t9 - 3 * ty;
+        Pw4A<NT4> aw;
+        pw4_load_a<NT4, P>(wk + t9 * 4 * P, aw);
+#pragma unroll
+        for (int t = 0; t < NTH; ++t)
+#pragma unroll
+          for (int sq = 0; sq < 4; ++sq) pw4_mfma<NT4>(aw, t, v[4 * ((sq >> 1) + ty) + (sq & 1) + tx], acch[sq][t]);
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) pw4_mfma<NT4>(aw, NTH + t, u[t9], accl[t]);
+      }
+    };
+    // channel c + 1 is in flight while channel c is contracted.  (Measured, stage 4.0, batch 64: the launch is bound by the NUMBER of
+    // vector-memory instructions -- 21 gathers per channel and wave against 9 (4 NTH + NTL) matrix instructions, ten waves per CU --
+    // not by their latency: a third register set in flight (which needs > 128 registers = one block per CU) made it slower,
+    // 51 -> 56 us; profiles/r5_notes.md.)
+    float vA[16], uA[9], vB[16], uB[9];
+    load_win(0, vA, uA);
+    PW4_FENCE();
+    for (int c = 0; c < CH; c += 2) {
+      load_win(c + 1, vB, uB);
+      PW4_FENCE();
+      contract(vA, uA, wg + 9 * c * 4 * P);
+      if (c + 1 >= CH) break;
+      load_win(c + 2, vA, uA);
+      PW4_FENCE();
+      contract(vB, uB, wg + 9 * (c + 1) * 4 * P);
+    }
+  }
+  if (tile_on && !K3) {
 #ifdef CSN_CPU_EMU
     const float* wg = lds;
 #else
@@ -314,10 +385,12 @@ __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
       for (int i = 0; i < 4; ++i) {
         const int r = 4 * t + i;
         if (r < nch_h) {
-          float v[9], q[4];
+          float v[9], q[4] = {0.f, 0.f, 0.f, 0.f};
+          if (!K3) {
 #pragma unroll
-          for (int k = 0; k < 9; ++k) v[k] = Z[r * HWl + zo[k]];
-          pw4_up2_quad(v, q);
+            for (int k = 0; k < 9; ++k) v[k] = Z[r * HWl + zo[k]];
+            pw4_up2_quad(v, q);
+          }
           float o[4];
 #pragma unroll
           for (int s = 0; s < 4; ++s) o[s] = pw4_epi(acch[s][t][i] + q[s], eph[4 * r], eph[4 * r + 1], eph[4 * r + 2]);
@@ -370,15 +443,15 @@ __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
 
 // ---- host side -----------------------------------------------------------------------------------------------------------------
 typedef void (*IlbFn)(IlbArgs);
-struct IlbEntry { int nth, ntl; IlbFn fn; };
-static const IlbEntry g_ilb_table[] = {{1, 1, ilb_kernel<1, 1>}, {1, 0, ilb_kernel<1, 0>}, {2, 2, ilb_kernel<2, 2>}, {2, 0, ilb_kernel<2, 0>},
-                                       {1, 2, ilb_kernel<1, 2>}, {2, 1, ilb_kernel<2, 1>}};
+struct IlbEntry { int nth, ntl; IlbFn fn; IlbFn fn3; };   // 1x1 block / 3x3 stride-2 entry block
+#define ILB_ENTRY(H, L) {H, L, ilb_kernel<H, L, false>, ilb_kernel<H, L, true>}
+static const IlbEntry g_ilb_table[] = {ILB_ENTRY(1, 1), ILB_ENTRY(1, 0), ILB_ENTRY(2, 2), ILB_ENTRY(2, 0), ILB_ENTRY(1, 2), ILB_ENTRY(2, 1)};
 
 // LDS layout of an item for (nth, ntl) row tiles per group; returns the bytes, 0 when the geometry is not supported
 size_t csn_ilb_layout(IlbArgs& a) {
   const int Hh = 2 * a.Hl, Wh = 2 * a.Wl;
   const int NT4 = (a.nth + a.ntl + 3) & ~3, P = PW4_PITCH(NT4);
-  a.gimg_floats = (a.CH + a.CL) * 4 * P;
+  a.gimg_floats = (a.k3 ? 9 * a.CH : a.CH + a.CL) * 4 * P;
   a.ph = ((Wh + 3) & ~3) + 4; a.pl = ((a.Wl + 3) & ~3) + 4;
   a.plane_h = (Hh + 2) * a.ph + 4; a.plane_l = (a.Hl + 2) * a.pl + 4;   // + 4: the right frame of the last row
   int off = a.gimg_floats;
@@ -417,12 +490,14 @@ int csn_launch_ilb(const IlbArgs& a, void* stream) {
   if (lds > 160 * 1024) return -1;
 #ifndef CSN_CPU_EMU
   if (lds > 64 * 1024) {
-    const hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(e->fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(a.k3 ? e->fn3 : e->fn),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (er != hipSuccess) return (int)er;
   }
 #endif
   const int ipx = (a.B + 7) >> 3;
   const dim3 grid(8 * ipx * a.ng);
-  CSN_LAUNCH(e->fn, grid, dim3(a.nthreads), lds, stream, a);
+  if (a.k3) CSN_LAUNCH(e->fn3, grid, dim3(a.nthreads), lds, stream, a);
+  else CSN_LAUNCH(e->fn, grid, dim3(a.nthreads), lds, stream, a);
   return (int)hipGetLastError();
 }

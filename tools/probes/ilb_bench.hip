@@ -15,16 +15,17 @@ static float* dalloc(size_t n, float v) {
   return p;
 }
 
-static void run(const char* name, int B, int CH, int CL, int OH, int OL, int Hl, int nt) {
+static void run(const char* name, int B, int CH, int CL, int OH, int OL, int Hl, int nt, int k3 = 0, int ntl = -1) {
   IlbArgs a = {};
-  a.CH = CH; a.CL = CL; a.OH = OH; a.OL = OL; a.Hl = Hl; a.Wl = Hl; a.B = B; a.Rh = 4; a.Rl = 4;
-  a.nth = nt; a.ntl = OL > 0 ? nt : 0;
+  a.CH = CH; a.CL = k3 ? CH : CL; a.OH = OH; a.OL = OL; a.Hl = Hl; a.Wl = Hl; a.B = B; a.Rh = 4; a.Rl = 4;
+  a.k3 = k3;
+  a.nth = nt; a.ntl = ntl >= 0 ? ntl : (OL > 0 ? nt : 0);
   const size_t lds = csn_ilb_layout(a);
   if (lds == 0 || lds > 160 * 1024) { printf("%s: does not fit (%zu B)\n", name, lds); return; }
   const int th = (OH + 3) / 4, tl = (OL + 3) / 4;
   a.ng = std::max((th + a.nth - 1) / a.nth, a.ntl ? (tl + a.ntl - 1) / a.ntl : 0);
   const size_t HWl = (size_t)Hl * Hl;
-  a.xh = dalloc((size_t)B * CH * 4 * HWl, 1.f); a.xl = dalloc((size_t)B * CL * HWl, 1.f);
+  a.xh = dalloc((size_t)B * CH * 4 * HWl, 1.f); a.xl = dalloc((size_t)B * a.CL * HWl, 1.f);
   a.yh = dalloc((size_t)B * OH * 4 * HWl, 0.f); a.yl = OL ? dalloc((size_t)B * OL * HWl, 0.f) : nullptr;
   a.wimg = dalloc((size_t)a.ng * a.gimg_floats, 0.1f);
   a.ep_h = dalloc((size_t)(4 * a.ng * a.nth + 4) * 4, 1.f); a.ep_l = dalloc((size_t)(4 * a.ng * std::max(a.ntl, 1) + 4) * 4, 1.f);
@@ -84,6 +85,8 @@ int main(int argc, char** argv) {
   run("stage4.1", 64, 18, 31, 31, 27, 14, 1);
   run("stage4.2", 64, 31, 27, 26, 44, 14, 1);
   run("stage4.3", 64, 26, 44, 64, 0, 14, 1);
+  run("stage4.0 3x3 (1,1)", 64, 38, 0, 18, 31, 14, 1, 1, 1);
+  run("stage4.0 3x3 (1,2)", 64, 38, 0, 18, 31, 14, 1, 1, 2);
   run("stage4.1/2", 64, 18, 31, 31, 27, 14, 2);
   run("stage4.3/2", 64, 26, 44, 64, 0, 14, 2);
   return 0;
