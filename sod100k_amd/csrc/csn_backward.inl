@@ -643,7 +643,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
   const BwdCtx bs{cs, b.arena, b.grad, b.flop_w, b.pen_scale, c.lanes ? nullptr : b.defer};
   if (d.kind == CSN_UNIT_DW) {
     DwArgs a;
-    a.nbr = 0; a.B = S; a.a16 = c.a16 ? 1 : 0; a.nthreads = 0;
+    a.nbr = 0; a.B = S; a.a16 = c.a16 ? 1 : 0; a.variant = 0;
     int blk = 0;
     for (int k = 0; k < d.n_in; ++k) {
       if (d.cout[k] == 0) continue;
@@ -662,7 +662,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
         const bool defer_fin = b.defer != nullptr && !cf.side && u.dwwg_off[k] >= 0;
         if (defer_fin) w.partial = reinterpret_cast<double*>(c.ws + u.dwwg_off[k]);   // own region: finalised with all the others
         DwArgs f;
-        f.nbr = 1; f.B = S; f.a16 = c.a16 ? 1 : 0; f.nthreads = 0;
+        f.nbr = 1; f.B = S; f.a16 = c.a16 ? 1 : 0; f.variant = P.dwb_fast ? (P.dw_xl ? 2 : 1) : 0;
         DwBranch& fb = f.br[0];
         fb.in = bd.dz[k]; fb.out = bd.dx[k]; fb.xin = bd.in[k];
         if (virt) {   // x = PReLU(BN(z of the producer)) on load
@@ -686,7 +686,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
         fb.pool = nullptr; fb.skip_out = 0; fb.stats = w.partial;
         fb.C = d.cout[k]; fb.H = H; fb.W = W;
         const int fcols = (W + 3) / 4;
-        fb.LX = dw_lanes_x(fcols);
+        fb.LX = dw_lanes_x(fcols, P.dw_xl);
         fb.NY = CSN_BLOCK / fb.LX;
         fb.tiles_x = (fcols + fb.LX - 1) / fb.LX;
         fb.R = choose_dw_rows(H, fb.NY);
@@ -714,7 +714,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
       br.pool = nullptr; br.skip_out = 0; br.stats = nullptr; br.xin = nullptr;
       br.C = d.cout[k]; br.H = H; br.W = W;
       const int cols = (br.W + 3) / 4;
-      br.LX = dw_lanes_x(cols);
+      br.LX = dw_lanes_x(cols, P.dw_xl);
       br.NY = CSN_BLOCK / br.LX;
       br.tiles_x = (cols + br.LX - 1) / br.LX;
       br.R = choose_dw_rows(br.H, br.NY);

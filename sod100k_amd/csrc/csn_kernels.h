@@ -128,7 +128,7 @@ struct DwArgs {
   DwBranch br[3];
   int32_t nbr, B;
   int32_t a16;        // bfloat16 activations (single-unit kernel only; the fused pair is an eval-mode kernel)
-  int32_t nthreads;   // (unused)
+  int32_t variant;    // csn_launch_dw_bwd: 1 = the packed-pair form of the fully fused backward (dw3x3_bwd_x_kernel); else 0
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -183,6 +183,8 @@ struct csn_plan {
   bool c3q = true;        // CSN_OPT_C3Q: eval-mode 3x3 passes on c3q_kernel (k_c3q.hip)
   int c3q_cap = 4;        // its row tiles per M group (CSN_C3Q_NT, experiments)
   bool dw_fast = true;    // CSN_DW_FAST=0: the fused depthwise pair on the round-1 kernel instead of dw3x3x2_fast_kernel (A/B)
+  int dwb_fast = 1;       // CSN_DWB_FAST=0: the fully fused depthwise backward on the round-4 loop instead of dw3x3_bwd_x_kernel (A/B)
+  bool dw_xl = true;      // CSN_DW_XL=0: train-mode depthwise launches in the round-4 geometry, halo columns loaded (see dw_lanes_x)
   bool ilb = true;        // CSN_OPT_FUSE_ILB / CSN_ILB=0: whole ILBlocks of the small maps on ilb_kernel (k_ilb.hip, round 5)
   int ilb_nt = 0;         // its row tiles per group and branch: 0 = chosen per block (plan_ilb), CSN_ILB_NT=1|2 forces (experiments)
   int ilb_maxpix = 256;   // ... only where the low plane has at most this many pixels (CSN_ILB_MAXPIX)
@@ -983,7 +985,14 @@ struct Ctx {
 // of 64 and a mostly empty last tile (40 x 6 at 320 columns).  Measured at 224 columns (round 4, bf16 step): 28 x 9 lanes in two
 // tiles per row (252 of 256 lanes busy instead of 224) is 0.3-0.4 ms SLOWER than 56 x 4 -- the half-empty fourth wave costs less
 // than the shorter row segments and the extra tile row; CSN_DW_LX=1 applies the search at every width (A/B).
-int dw_lanes_x(int cols) {
+// pow2 (csn_plan::dw_xl, train-mode launches): a plane that fits one tile in x gets a power-of-two group of lanes per row, so that
+// every row of lanes sits inside ONE wave and the kernels take their halo columns from the neighbouring lanes (dwx_row_of, k_misc.hip)
+int dw_lanes_x(int cols, bool pow2 = false) {
+  if (pow2 && cols <= 64) {
+    int g = 1;
+    while (g < cols) g <<= 1;
+    return g;
+  }
   static const bool everywhere = std::getenv("CSN_DW_LX") && std::getenv("CSN_DW_LX")[0] == '1';
   if (cols <= 14 || (cols <= 64 && !everywhere)) return cols;
   int best = 14;
@@ -1032,7 +1041,7 @@ int dw_stats_slabs(const csn_plan& P, int lvl) {
   if (std::getenv("CSN_DW_STATS") && std::getenv("CSN_DW_STATS")[0] == '0') return 0;
   const int H = P.H >> lvl, W = P.W >> lvl;
   const int cols = (W + 3) / 4;
-  const int LX = dw_lanes_x(cols), NY = CSN_BLOCK / LX;
+  const int LX = dw_lanes_x(cols, P.dw_xl), NY = CSN_BLOCK / LX;
   const int tiles_x = (cols + LX - 1) / LX;
   const int R = choose_dw_rows(H, NY);
   const int tiles_y = (H + NY * R - 1) / (NY * R);
@@ -1255,7 +1264,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
     case CSN_UNIT_DW: {
       DwArgs a;
       const bool fused = next != nullptr;
-      a.nbr = 0; a.B = S; a.a16 = c.a16 ? 1 : 0; a.nthreads = 0;
+      a.nbr = 0; a.B = S; a.a16 = c.a16 ? 1 : 0; a.variant = (P.dw_xl && P.train) ? 2 : 0;
       if (fused && c.a16) return CSN_E_UNSUPPORTED;   // the fused pair is an eval-mode (float) kernel
       int blk = 0;
       for (int k = 0; k < d.n_in; ++k) {
@@ -1280,7 +1289,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
         br.pool = nullptr; br.skip_out = 0; br.stats = nullptr; br.xin = nullptr;
         br.C = d.cout[k]; br.H = P.H >> act.lvl; br.W = P.W >> act.lvl;
         const int cols = (br.W + 3) / 4;
-        br.LX = fused ? (cols < 64 ? cols : 64) : dw_lanes_x(cols);   // (the fused pair keeps whole rows of its intermediate in LDS)
+        br.LX = fused ? (cols < 64 ? cols : 64) : dw_lanes_x(cols, P.dw_xl && P.train);   // (the fused pair keeps whole rows of its intermediate in LDS)
         br.NY = CSN_BLOCK / br.LX;
         br.tiles_x = (cols + br.LX - 1) / br.LX;
         if (fused) {
@@ -1716,6 +1725,8 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   if (const char* e = std::getenv("CSN_PW4_FLAT")) P->pw4_flat = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_ILB")) P->ilb = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_DW_FAST")) P->dw_fast = std::atoi(e) != 0;
+  if (const char* e = std::getenv("CSN_DWB_FAST")) P->dwb_fast = std::atoi(e) != 0 ? 1 : 0;
+  if (const char* e = std::getenv("CSN_DW_XL")) P->dw_xl = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_ILB_NT")) P->ilb_nt = std::atoi(e) == 2 ? 2 : (std::atoi(e) == 1 ? 1 : 0);
   if (const char* e = std::getenv("CSN_ILB_MAXPIX")) { if (std::atoi(e) > 0) P->ilb_maxpix = std::atoi(e); }
   if (const char* e = std::getenv("CSN_C3Q16")) {   // 0 / 1; 2 (bf16 weights in the FORWARD 3x3 launches: beyond the certified unit-local bound,

@@ -25,6 +25,7 @@ struct csn_v2 {
 __device__ __forceinline__ csn_v2 csn_mk2(float a, float b) { csn_v2 r; r.v[0] = a; r.v[1] = b; return r; }
 __device__ __forceinline__ csn_v2 csn_fma2(float w, csn_v2 x, csn_v2 c) { return csn_mk2(fmaf(w, x[0], c[0]), fmaf(w, x[1], c[1])); }
 __device__ __forceinline__ csn_v2 csn_mul2(float w, csn_v2 x) { return csn_mk2(w * x[0], w * x[1]); }
+__device__ __forceinline__ csn_v2 csn_fmav2(csn_v2 a, csn_v2 b, csn_v2 c) { return csn_mk2(fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])); }
 #else
 typedef float csn_v2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ csn_v2 csn_mk2(float a, float b) { csn_v2 r = {a, b}; return r; }
@@ -33,6 +34,7 @@ __device__ __forceinline__ csn_v2 csn_fma2(float w, csn_v2 x, csn_v2 c) {   // v
   return __builtin_elementwise_fma(ww, x, c);
 }
 __device__ __forceinline__ csn_v2 csn_mul2(float w, csn_v2 x) { const csn_v2 ww = {w, w}; return ww * x; }
+__device__ __forceinline__ csn_v2 csn_fmav2(csn_v2 a, csn_v2 b, csn_v2 c) { return __builtin_elementwise_fma(a, b, c); }   // pair x pair + pair
 #endif
 
 // per-channel record of one depthwise unit (CSN_PREP_DWREC + strided BN_SHIFT / COPY jobs): {w'[9], shift, alpha, 0}

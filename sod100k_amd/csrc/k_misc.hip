@@ -219,6 +219,31 @@ __device__ __forceinline__ DwRow dw_row_of(const DwRowRaw<csn_bf16>& q) {
   return r;
 }
 
+// Halo columns without loads (round 5).  Measured on the bf16 step (lease r5z): this kernel with all of its arithmetic removed is
+// 10 % faster, with its eight 16-bit halo loads per trip removed (of twelve loads) 20 % -- it is bound by the NUMBER of vector-memory
+// instructions, not by bytes or arithmetic.  When a row of lanes sits inside one wave (launch geometry: lanes per row = a power of two
+// <= 64, one tile per row) the value left / right of a lane's four columns is the neighbouring lane's last / first own value: one DPP
+// move (wave_shr:1 / wave_shl:1) on the loaded register instead of a load.  Lanes at a row's ends read a lane of another row or an
+// idle lane: those are the positions has_l / has_r mask to zero anyway.  (The CPU emulator runs lanes one after the other: it loads.)
+#ifndef CSN_CPU_EMU
+__device__ __forceinline__ unsigned csn_from_lane_below(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ unsigned csn_from_lane_above(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
+#endif
+// a row as loaded and converted, the halo columns from the neighbouring lanes (no masks: the callers mask or transform anyway)
+template <typename AT>
+__device__ __forceinline__ DwRow dw_load_row_xl(csn_buf rb, int y, int x0, int W) {
+#ifndef CSN_CPU_EMU
+  DwRow r;
+  const float4 c = csn_bufacc<AT>::ld4(rb, (unsigned)(y * W + x0) * (unsigned)sizeof(AT), 0);
+  r.v[1] = c.x; r.v[2] = c.y; r.v[3] = c.z; r.v[4] = c.w;
+  r.v[0] = csn_bits_f(csn_from_lane_below(__float_as_uint(c.w)));
+  r.v[5] = csn_bits_f(csn_from_lane_above(__float_as_uint(c.x)));
+  return r;
+#else
+  return dw_load_row_raw<true, AT>(rb, y, x0, W);
+#endif
+}
+
 // x = PReLU(z * sc + sh) of a loaded row of six values, zero outside the plane -- the lean form (round 5, from dw_core.h's findings:
 // the bf16 train step's depthwise kernels ARE bound by their vector instructions).  Bit for bit csn_epi's values: PReLU as
 // v_med3(y, alpha y, +-inf) (= max for alpha <= 1, min above) instead of compare + select; a row outside the plane loads zeros, and
@@ -322,7 +347,8 @@ __device__ __forceinline__ void dw_emit(AT* __restrict__ op, int y, int yend, in
                             // already issues the 12 loads of a four-row chunk back to back; the backward kernel gains (9.70 -> 8.94 ms)
 #endif
 // INBN (train mode, with STATS): the input is formed on load from the producer's raw output and its plane sums are taken
-template <bool VEC, typename AT, bool STATS, bool INBN = false>
+// XL: halo columns from the neighbouring lanes (see csn_from_lane_below; launches whose rows of lanes sit inside one wave)
+template <bool VEC, typename AT, bool STATS, bool INBN = false, bool XL = false>
 __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
   CSN_DYN_SMEM(double, sm);   // STATS only
   int bid = blockIdx.x;
@@ -357,6 +383,17 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bn_prelu_kernel(DwArgs a) {
     if (INBN) { isc = csn_const(br.in_scale)[c]; ish = csn_const(br.in_shift)[c]; ial = csn_const(br.in_alpha)[c]; }
     float gsum = 0.f;   // <= 16 rows x 4 values per lane: fp32, then fp64 across the block
     auto load_in = [&](int y) {
+      if (XL) {
+        DwRow r = dw_load_row_xl<AT>(rb, y, x0, W);
+        if (INBN) {
+          r = dw_bn_row(r, y >= 0 && y < H, has_l, has_r, isc, ish, ial);
+          if (y >= y0 && y < yend) gsum += (r.v[1] + r.v[2]) + (r.v[3] + r.v[4]);
+        } else {
+          if (!has_l) r.v[0] = 0.f;
+          if (!has_r) r.v[5] = 0.f;
+        }
+        return r;
+      }
       if (!INBN) return dw_load_row<VEC, AT>(rb, y, x0, W, has_l, has_r);
       const DwRow r = dw_load_row_bn<VEC, AT>(rb, y, H, x0, W, has_l, has_r, isc, ish, ial);
       if (y >= y0 && y < yend) gsum += (r.v[1] + r.v[2]) + (r.v[3] + r.v[4]);   // (columns past W are zero)
@@ -654,6 +691,290 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
   }
 }
 
+// ---- the fully fused form of the kernel above (BNF + XBN, whole four-pixel lanes) on packed pairs (round 5) ----
+// The bf16 train step spends a quarter of its time here (60 launches) and the kernel is bound by its vector instructions (85 %
+// issue utilisation at 3.3 TB/s, profiles/r4_notes.md): of the 264 per row of four pixels above, 74 are register moves (two
+// three-row windows of six values shifted down every row, pairs re-formed for the packed FMAs).  Here
+//   * dx is accumulated in SCATTER form: a row of dz, when it arrives, adds its top / middle / bottom tap rows to the outputs
+//     of the rows below / at / above it (two pair accumulators per open output row: the roll is the FMA's destination), in the
+//     same order of operations per output as the gather form: dx is bit-identical;
+//   * the weight gradient pairs the arriving row of x with the CENTRE pairs of three rows of dz (2 pairs per row kept instead of
+//     a three-row window of x), summed as even / odd columns per tap (18 packed FMAs) and added at the end;
+//   * dx of row r is final when dz of row r + 1 has arrived -- the same trip x of row r is formed in, whose pre-activation values
+//     the producer's BatchNorm-backward sums need: nothing is carried for them.
+template <bool XL>
+__device__ __forceinline__ DwRowRaw<float> dwx_issue(csn_buf rb, int y, int x0, int W, float tag) {
+#ifndef CSN_CPU_EMU
+  if (XL) {
+    DwRowRaw<float> q;
+    q.c = csn_ld4(rb, (unsigned)(y * W + x0) * 4u, 0); q.l = q.r = 0.f;
+    return q;
+  }
+#endif
+  return dw_issue_row(rb, y, x0, W, tag);
+}
+template <bool XL>
+__device__ __forceinline__ DwRowRaw<csn_bf16> dwx_issue(csn_buf rb, int y, int x0, int W, csn_bf16 tag) {
+#ifndef CSN_CPU_EMU
+  if (XL) {
+    DwRowRaw<csn_bf16> q;
+    q.c = csn_ld_u64(rb, (unsigned)(y * W + x0) * 2u, 0); q.l = q.r = 0;
+    return q;
+  }
+#endif
+  return dw_issue_row(rb, y, x0, W, tag);
+}
+template <bool XL>
+__device__ __forceinline__ DwRow dwx_row_of(const DwRowRaw<float>& q) {
+  DwRow r = dw_row_of(q);
+#ifndef CSN_CPU_EMU
+  if (XL) {
+    r.v[0] = csn_bits_f(csn_from_lane_below(__float_as_uint(q.c.w)));
+    r.v[5] = csn_bits_f(csn_from_lane_above(__float_as_uint(q.c.x)));
+  }
+#endif
+  return r;
+}
+template <bool XL>
+__device__ __forceinline__ DwRow dwx_row_of(const DwRowRaw<csn_bf16>& q) {
+#ifndef CSN_CPU_EMU
+  if (XL) {
+    DwRow r;
+    r.v[0] = csn_bits_f(csn_from_lane_below(q.c.y) & 0xffff0000u);   // the neighbour's fourth value = high half of its second dword
+    r.v[1] = csn_bits_f(q.c.x << 16); r.v[2] = csn_bits_f(q.c.x & 0xffff0000u);
+    r.v[3] = csn_bits_f(q.c.y << 16); r.v[4] = csn_bits_f(q.c.y & 0xffff0000u);
+    r.v[5] = csn_bits_f(csn_from_lane_above(q.c.x) << 16);           // ... first value = low half of its first dword
+    return r;
+  }
+#endif
+  return dw_row_of(q);
+}
+// dy + dy2 of one row as loaded
+template <bool XL, typename AT>
+__device__ __forceinline__ DwRow dwx_dy_row(const DwRowRaw<AT>& qg, const DwRowRaw<AT>& qe, bool has2) {
+  DwRow g = dwx_row_of<XL>(qg);
+  if (has2) {
+    const DwRow e = dwx_row_of<XL>(qe);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) g.v[i] += e.v[i];
+  }
+  return g;
+}
+// dz of one row from dy (+ dy2) and z; rows / columns outside the plane -> 0
+__device__ __forceinline__ DwRow2 dwx_dz_row(DwRow g, const DwRow& z, bool has_l, bool has_r, float bsc, float bsh, float bgi, float bga,
+                                             float bB, float bAr) {   // g: dy (+ dy2); bAr: A of the row, 0 for a row outside the
+                                                                      // plane (it loads dy = z = 0: dz = 0)
+#pragma unroll
+  for (int i = 0; i < 6; i += 2) {
+    const csn_v2 z2 = csn_mk2(z.v[i], z.v[i + 1]);
+    const csn_v2 bn = csn_fma2(bsc, z2, csn_mk2(bsh, bsh));
+    const csn_v2 t = csn_fma2(bB, z2, csn_mk2(bAr, bAr));
+    const csn_v2 sl = csn_mk2(bn[0] > 0.f ? bgi : bga, bn[1] > 0.f ? bgi : bga);
+    const csn_v2 d = csn_fmav2(csn_mk2(g.v[i], g.v[i + 1]), sl, csn_mk2(-t[0], -t[1]));
+    g.v[i] = d[0]; g.v[i + 1] = d[1];
+  }
+  if (!has_l) g.v[0] = 0.f;
+  if (!has_r) g.v[5] = 0.f;
+  return dw_row2_regs(g.v[0], g.v[1], g.v[2], g.v[3], g.v[4], g.v[5]);
+}
+
+// x = PReLU(z isc + ish) of one row of the producer's raw output; pre[4]: z isc + ish of the lane's four own columns
+__device__ __forceinline__ DwRow2 dwx_x_row(const DwRow& zraw, bool has_l, bool has_r, float sc, float sh, float ial, float ilim,
+                                            float (&pre)[4]) {   // sc = sh = 0 for a row outside the plane
+  float v[6];
+#pragma unroll
+  for (int i = 0; i < 6; i += 2) {
+    const csn_v2 y = csn_fma2(sc, csn_mk2(zraw.v[i], zraw.v[i + 1]), csn_mk2(sh, sh));
+    const csn_v2 x = dw_prelu2(y, ial, ilim);
+    v[i] = x[0]; v[i + 1] = x[1];
+    if (i == 0) pre[0] = y[1];
+    if (i == 2) { pre[1] = y[0]; pre[2] = y[1]; }
+    if (i == 4) pre[3] = y[0];
+  }
+  if (!has_l) v[0] = 0.f;
+  if (!has_r) v[5] = 0.f;
+  return dw_row2_regs(v[0], v[1], v[2], v[3], v[4], v[5]);
+}
+
+// the nine weight-gradient taps' even / odd column sums: centre pairs (g1,g2) (g3,g4) of one row of dz x one row of x, tap row ty
+__device__ __forceinline__ void dwx_wgrad(csn_v2 gb, csn_v2 gd, const DwRow2& u, csn_v2 (&s2)[9], int ty) {
+  s2[3 * ty] = csn_fmav2(gb, u.a, s2[3 * ty]);         s2[3 * ty] = csn_fmav2(gd, u.c, s2[3 * ty]);
+  s2[3 * ty + 1] = csn_fmav2(gb, u.b, s2[3 * ty + 1]); s2[3 * ty + 1] = csn_fmav2(gd, u.d, s2[3 * ty + 1]);
+  s2[3 * ty + 2] = csn_fmav2(gb, u.c, s2[3 * ty + 2]); s2[3 * ty + 2] = csn_fmav2(gd, u.e, s2[3 * ty + 2]);
+}
+
+// four outputs -> memory; d01 / d23: the values as stored (bfloat16: rounded once, packed, and unpacked again)
+__device__ __forceinline__ void dwx_store4(float* q, csn_v2 o01, csn_v2 o23, csn_v2& d01, csn_v2& d23) {
+  act_st4(q, make_float4(o01[0], o01[1], o23[0], o23[1]));
+  d01 = o01; d23 = o23;
+}
+__device__ __forceinline__ void dwx_store4(csn_bf16* q, csn_v2 o01, csn_v2 o23, csn_v2& d01, csn_v2& d23) {
+  const unsigned lo = csn_pack_bf2(o01[0], o01[1]), hi = csn_pack_bf2(o23[0], o23[1]);
+  *reinterpret_cast<uint2*>(q) = make_uint2(lo, hi);
+  d01 = csn_mk2(csn_bits_f(lo << 16), csn_bits_f(lo & 0xffff0000u));
+  d23 = csn_mk2(csn_bits_f(hi << 16), csn_bits_f(hi & 0xffff0000u));
+}
+
+// XL: the halo columns come from the neighbouring LANES (see dwx_row_x) -- launches whose rows sit inside one wave (csn_launch_dw_bwd)
+template <typename AT, bool XL>
+__global__ __launch_bounds__(CSN_BLOCK, sizeof(AT) == 2 ? 4 : 3) void dw3x3_bwd_x_kernel(DwArgs a) {
+  CSN_DYN_SMEM(double, sm);
+  int bid = blockIdx.x;
+  int kb = 0;
+  if (a.nbr > 1 && bid >= a.br[0].blk_end) kb = 1;
+  if (a.nbr > 2 && bid >= a.br[1].blk_end) kb = 2;
+  const DwBranch br = a.br[kb];
+  if (kb > 0) bid -= a.br[kb - 1].blk_end;
+  const int tiles = br.tiles_x * br.tiles_y;
+  const int tile = bid % tiles;
+  const int pc = bid / tiles;  // b*C + c
+  const int c = pc % br.C;
+  const int tx = tile % br.tiles_x, ty = tile / br.tiles_x;
+  const int tid = threadIdx.x;
+  const int lx = tid % br.LX, ly = tid / br.LX;
+  const int H = br.H, W = br.W;
+  const int x0 = (tx * br.LX + lx) * 4;
+  const int y0 = (ty * br.NY + ly) * br.R;
+  const bool active = ly < br.NY && x0 < W && y0 < H;
+  csn_v2 s2[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) s2[t] = csn_mk2(0.f, 0.f);
+  double rs[3] = {0.0, 0.0, 0.0};
+  if (active) {
+    const unsigned nb = (unsigned)(H * W) * (unsigned)sizeof(AT);
+    const csn_buf gb = csn_make_buf_n(act_cast<AT>(br.in) + (int64_t)pc * H * W, nb);      // dy of the first consumer
+    const csn_buf xb = csn_make_buf_n(act_cast<AT>(br.xin) + (int64_t)pc * H * W, nb);     // the producer's raw output
+    const csn_buf zb = csn_make_buf_n(act_cast<AT>(br.zraw) + (int64_t)pc * H * W, nb);    // the unit's own raw output
+    const bool has2 = br.dy2 != nullptr;
+    const csn_buf eb = csn_make_buf_n(act_cast<AT>(has2 ? br.dy2 : br.in) + (int64_t)pc * H * W, nb);
+    AT* __restrict__ op = act_cast<AT>(br.out) + (int64_t)pc * H * W;
+    float w[9];
+    csn_cfp w9 = csn_const(br.w9);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) w[i] = w9[c * 9 + i];
+    // the unit's own BatchNorm backward (see finish_g above) ...
+    const float bsc = csn_const(br.bn_scale)[c], bsh = csn_const(br.bn_shift)[c];
+    const float bal = csn_const(br.bn_alpha)[c], bmu = csn_const(br.bn_mean)[c], bis = csn_const(br.bn_invstd)[c];
+    const float bm1 = csn_const(br.bn_m1m2)[2 * c], bm2 = csn_const(br.bn_m1m2)[2 * c + 1];
+    const float bgi = csn_const(br.bn_gamma)[c] * bis, bga = bgi * bal, bB = bgi * (bis * bm2), bA = bgi * (bm1 - bmu * (bis * bm2));
+    // ... and the producer's BatchNorm + PReLU (x = PReLU(z isc + ish)); (z - mean) invstd = z iis + imi
+    const float isc = csn_const(br.in_scale)[c], ish = csn_const(br.in_shift)[c], ial = csn_const(br.in_alpha)[c];
+    const float ilim = ial <= 1.f ? __builtin_inff() : -__builtin_inff();
+    const float iis = csn_const(br.in_invstd)[c], imi = -(csn_const(br.in_mean)[c] * iis);
+    const bool has_l = x0 > 0, has_r = x0 + 4 < W;
+    const int yend = min(y0 + br.R, H);
+    const AT tag = AT();
+    // rows y0 - 1, y0 of dz and row y0 - 1 of x; the first trip's rows (dz y0 + 1, x y0) are issued before those are used
+    DwRowRaw<AT> pg0 = dwx_issue<XL>(gb, y0 - 1, x0, W, tag), pz0 = dwx_issue<XL>(zb, y0 - 1, x0, W, tag), pe0 = pg0;
+    DwRowRaw<AT> pg1 = dwx_issue<XL>(gb, y0, x0, W, tag), pz1 = dwx_issue<XL>(zb, y0, x0, W, tag), pe1 = pg1;
+    if (has2) { pe0 = dwx_issue<XL>(eb, y0 - 1, x0, W, tag); pe1 = dwx_issue<XL>(eb, y0, x0, W, tag); }
+    const DwRowRaw<AT> px0 = dwx_issue<XL>(xb, y0 - 1, x0, W, tag);
+    DwRowRaw<AT> rg = dwx_issue<XL>(gb, y0 + 1, x0, W, tag), rz = dwx_issue<XL>(zb, y0 + 1, x0, W, tag), re = rg;
+    if (has2) re = dwx_issue<XL>(eb, y0 + 1, x0, W, tag);
+    DwRowRaw<AT> rx = dwx_issue<XL>(xb, y0, x0, W, tag);
+#ifndef CSN_CPU_EMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    csn_v2 a1_01, a1_23, a2_01, a2_23;    // open outputs: row r (top + middle taps so far), row r + 1 (top taps)
+    csn_v2 gpb, gpd, gcb, gcd;            // centre pairs of dz rows r - 1 (zero when not the lane's own) and r
+    {
+      const DwRow2 g = dwx_dz_row(dwx_dy_row<XL>(pg0, pe0, has2), dwx_row_of<XL>(pz0), has_l, has_r, bsc, bsh, bgi, bga, bB, y0 > 0 ? bA : 0.f);
+      a1_01 = csn_mul2(w[0], g.a);        a1_23 = csn_mul2(w[0], g.c);
+      a1_01 = csn_fma2(w[1], g.b, a1_01); a1_23 = csn_fma2(w[1], g.d, a1_23);
+      a1_01 = csn_fma2(w[2], g.c, a1_01); a1_23 = csn_fma2(w[2], g.e, a1_23);
+    }
+    {
+      const DwRow2 g = dwx_dz_row(dwx_dy_row<XL>(pg1, pe1, has2), dwx_row_of<XL>(pz1), has_l, has_r, bsc, bsh, bgi, bga, bB, bA);
+      a1_01 = csn_fma2(w[3], g.a, a1_01); a1_23 = csn_fma2(w[3], g.c, a1_23);
+      a1_01 = csn_fma2(w[4], g.b, a1_01); a1_23 = csn_fma2(w[4], g.d, a1_23);
+      a1_01 = csn_fma2(w[5], g.c, a1_01); a1_23 = csn_fma2(w[5], g.e, a1_23);
+      a2_01 = csn_mul2(w[0], g.a);        a2_23 = csn_mul2(w[0], g.c);
+      a2_01 = csn_fma2(w[1], g.b, a2_01); a2_23 = csn_fma2(w[1], g.d, a2_23);
+      a2_01 = csn_fma2(w[2], g.c, a2_01); a2_23 = csn_fma2(w[2], g.e, a2_23);
+      gcb = g.b; gcd = g.d;
+      gpb = csn_mk2(0.f, 0.f); gpd = gpb;
+    }
+    {
+      float pre[4];
+      const DwRow2 u = dwx_x_row(dwx_row_of<XL>(px0), has_l, has_r, y0 > 0 ? isc : 0.f, y0 > 0 ? ish : 0.f, ial, ilim, pre);
+      dwx_wgrad(gcb, gcd, u, s2, 0);   // x row y0 - 1 is the top tap row of output row y0
+    }
+    // One trip = one output row.  The rows loaded during a trip are consumed by the next one: a trip first converts the load
+    // registers (its only use of them), then issues the next trip's loads INTO THE SAME registers, then does its arithmetic with
+    // those loads in flight -- no second register set and no copies (16 of ~200 vector instructions per trip with copies; the loop
+    // unrolled by two with two sets swapping roles needs 137 registers).
+#ifndef CSN_CPU_EMU
+#define DWX_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define DWX_FENCE()
+#endif
+#define DWX_TRIP(r, G, Z, E, X, AHEAD)                                                                                          \
+  {                                                                                                                             \
+    const DwRow fg = dwx_dy_row<XL>(G, E, has2), fz = dwx_row_of<XL>(Z), zr = dwx_row_of<XL>(X);                                              \
+    DWX_FENCE();   /* conversions above, a later trip's loads between the fences, arithmetic below */                           \
+    G = dwx_issue<XL>(gb, (r) + 1 + AHEAD, x0, W, tag); Z = dwx_issue<XL>(zb, (r) + 1 + AHEAD, x0, W, tag);                       \
+    if (has2) E = dwx_issue<XL>(eb, (r) + 1 + AHEAD, x0, W, tag);                                                                \
+    X = dwx_issue<XL>(xb, (r) + AHEAD, x0, W, tag);                                                                              \
+    DWX_FENCE();                                                                                                                \
+    const DwRow2 g = dwx_dz_row(fg, fz, has_l, has_r, bsc, bsh, bgi, bga, bB, (r) + 1 < H ? bA : 0.f);                                                     \
+    /* dx of row r is complete with the bottom taps; rows r + 1, r + 2 stay open */                                             \
+    csn_v2 o01 = csn_fma2(w[6], g.a, a1_01), o23 = csn_fma2(w[6], g.c, a1_23);                                              \
+    o01 = csn_fma2(w[7], g.b, o01); o23 = csn_fma2(w[7], g.d, o23);                                                         \
+    o01 = csn_fma2(w[8], g.c, o01); o23 = csn_fma2(w[8], g.e, o23);                                                         \
+    a1_01 = csn_fma2(w[3], g.a, a2_01); a1_23 = csn_fma2(w[3], g.c, a2_23);                                                 \
+    a1_01 = csn_fma2(w[4], g.b, a1_01); a1_23 = csn_fma2(w[4], g.d, a1_23);                                                 \
+    a1_01 = csn_fma2(w[5], g.c, a1_01); a1_23 = csn_fma2(w[5], g.e, a1_23);                                                 \
+    a2_01 = csn_mul2(w[0], g.a);        a2_23 = csn_mul2(w[0], g.c);                                                        \
+    a2_01 = csn_fma2(w[1], g.b, a2_01); a2_23 = csn_fma2(w[1], g.d, a2_23);                                                 \
+    a2_01 = csn_fma2(w[2], g.c, a2_01); a2_23 = csn_fma2(w[2], g.e, a2_23);                                                 \
+    csn_v2 d01, d23;   /* the values as stored */                                                                               \
+    dwx_store4(op + (int64_t)(r) * W + x0, o01, o23, d01, d23);                                                                 \
+    const bool own_n = (r) + 1 < yend;   /* dz row r + 1 is one of the lane's own output rows */                                 \
+    const csn_v2 gnb = csn_mk2(own_n ? g.b[0] : 0.f, own_n ? g.b[1] : 0.f), gnd = csn_mk2(own_n ? g.d[0] : 0.f, own_n ? g.d[1] : 0.f); \
+    float pre[4];                                                                                                               \
+    const DwRow2 u = dwx_x_row(zr, has_l, has_r, isc, ish, ial, ilim, pre);                                                               \
+    dwx_wgrad(gnb, gnd, u, s2, 0);                                                                                              \
+    dwx_wgrad(gcb, gcd, u, s2, 1);                                                                                              \
+    dwx_wgrad(gpb, gpd, u, s2, 2);                                                                                              \
+    /* the producer's BatchNorm-backward sums (bn_bwd_reduce_kernel): dy = the dx just stored; fp32 over the row's four values  \
+       (as even / odd pairs), fp64 across the rows of the lane (see the kernel above) */                                        \
+    const csn_v2 p01 = csn_mk2(pre[0], pre[1]), p23 = csn_mk2(pre[2], pre[3]);                                                  \
+    const csn_v2 e01 = csn_mul2(ial, d01), e23 = csn_mul2(ial, d23);                                                        \
+    const csn_v2 b01 = csn_mk2(p01[0] > 0.f ? d01[0] : e01[0], p01[1] > 0.f ? d01[1] : e01[1]);                                 \
+    const csn_v2 b23 = csn_mk2(p23[0] > 0.f ? d23[0] : e23[0], p23[1] > 0.f ? d23[1] : e23[1]);                                 \
+    const csn_v2 h01 = csn_fma2(iis, csn_mk2(zr.v[1], zr.v[2]), csn_mk2(imi, imi));                                       \
+    const csn_v2 h23 = csn_fma2(iis, csn_mk2(zr.v[3], zr.v[4]), csn_mk2(imi, imi));                                       \
+    const csn_v2 n01 = csn_mk2(fminf(p01[0], 0.f), fminf(p01[1], 0.f)), n23 = csn_mk2(fminf(p23[0], 0.f), fminf(p23[1], 0.f));   \
+    const csn_v2 q0 = csn_mk2(b01[0] + b23[0], b01[1] + b23[1]);                                                                \
+    const csn_v2 q1 = csn_fmav2(b23, h23, csn_fmav2(b01, h01, csn_mk2(0.f, 0.f)));                                              \
+    const csn_v2 q2 = csn_fmav2(d23, n23, csn_fmav2(d01, n01, csn_mk2(0.f, 0.f)));                                              \
+    rs[0] += (double)(q0[0] + q0[1]); rs[1] += (double)(q1[0] + q1[1]); rs[2] += (double)(q2[0] + q2[1]);                       \
+    gpb = gcb; gpd = gcd; gcb = gnb; gcd = gnd;                                                                                 \
+  }
+    for (int r = y0; r < yend; ++r) DWX_TRIP(r, rg, rz, re, rx, 1)
+#undef DWX_TRIP
+#undef DWX_FENCE
+    {   // x row yend: the bottom tap row of output row yend - 1 (whose centre pairs the roll left in gpb / gpd)
+      float pre[4];
+      const DwRow2 u = dwx_x_row(dwx_row_of<XL>(rx), has_l, has_r, yend < H ? isc : 0.f, yend < H ? ish : 0.f, ial, ilim, pre);
+      dwx_wgrad(gpb, gpd, u, s2, 2);
+    }
+  }
+  double sv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) sv[t] = (double)s2[t][0] + (double)s2[t][1];
+  bn_block_sum_n<9>(sv, sm);
+  bn_block_sum_n<3>(rs, sm);
+  if (tid == 0) {
+    const int b = pc / br.C;
+    double* o = br.stats + ((int64_t)c * CSN_BN_NSLAB + (int64_t)b * tiles + tile) * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) o[t] = sv[t];
+    double* q = br.bnred + ((int64_t)c * CSN_BN_NSLAB + (int64_t)b * tiles + tile) * 3;
+    q[0] = rs[0]; q[1] = rs[1]; q[2] = rs[2];
+  }
+}
+
 int csn_launch_dw_bwd(const DwArgs& a, void* stream) {
   const int nblk = a.br[a.nbr - 1].blk_end;
   if (nblk <= 0) return 0;
@@ -664,6 +985,16 @@ int csn_launch_dw_bwd(const DwArgs& a, void* stream) {
   for (int k = 1; k < a.nbr; ++k)
     if ((a.br[k].zraw != nullptr) != bnf || (a.br[k].in_scale != nullptr) != xbn) return 1;
   if (xbn && !bnf) return 1;   // (the planner only skips an activation when its consumer runs the fully fused backward)
+  if (xbn && vec && a.variant >= 1) {
+    // halo columns from the neighbouring lanes: every row of lanes inside one wave, the whole plane width in one tile
+    bool xl = a.variant == 2;
+    for (int k = 0; k < a.nbr; ++k) xl = xl && a.br[k].tiles_x == 1 && a.br[k].LX <= 64 && (a.br[k].LX & (a.br[k].LX - 1)) == 0;
+    if (a.a16 && xl) CSN_LAUNCH((dw3x3_bwd_x_kernel<csn_bf16, true>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);
+    else if (a.a16) CSN_LAUNCH((dw3x3_bwd_x_kernel<csn_bf16, false>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);
+    else if (xl) CSN_LAUNCH((dw3x3_bwd_x_kernel<float, true>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);
+    else CSN_LAUNCH((dw3x3_bwd_x_kernel<float, false>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);
+    return (int)hipGetLastError();
+  }
 #define DWB_LAUNCH(V, T)                                                                                         \
   do {                                                                                                          \
     if (xbn) CSN_LAUNCH((dw3x3_bwd_kernel<V, T, true, true>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);     \
@@ -1052,6 +1383,16 @@ int csn_launch_dw(const DwArgs& a, void* stream) {
   for (int k = 0; k < a.nbr; ++k)
     if (!inbn && a.br[k].in_scale != nullptr) return 1;
   if (inbn && !stats) return 1;
+  // train-mode launches in the power-of-two geometry (csn_plan::dw_xl -> DwArgs::variant 2): halo columns from the neighbouring lanes
+  bool xl = a.variant == 2 && vec && stats;
+  for (int k = 0; k < a.nbr; ++k) xl = xl && a.br[k].tiles_x == 1 && a.br[k].LX <= 64 && (a.br[k].LX & (a.br[k].LX - 1)) == 0;
+  if (xl) {
+    if (a.a16 && inbn) CSN_LAUNCH((dw3x3_bn_prelu_kernel<true, csn_bf16, true, true, true>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);
+    else if (a.a16) CSN_LAUNCH((dw3x3_bn_prelu_kernel<true, csn_bf16, true, false, true>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);
+    else if (inbn) CSN_LAUNCH((dw3x3_bn_prelu_kernel<true, float, true, true, true>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);
+    else CSN_LAUNCH((dw3x3_bn_prelu_kernel<true, float, true, false, true>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);
+    return (int)hipGetLastError();
+  }
 #define DW_LAUNCH(V, T)                                                                                              \
   do {                                                                                                               \
     if (inbn) CSN_LAUNCH((dw3x3_bn_prelu_kernel<V, T, true, true>), dim3(nblk), dim3(CSN_BLOCK), sml, stream, a);    \

@@ -737,6 +737,40 @@ def check_train_units_local(lib, device, manifest, B=2, size=64, act_dtype="bf16
 _LOCAL_NET = None
 
 
+def train_backward_probes(lib, device, manifest, B, size, act_dtype, env, seed=51, state="shipped", flops_weight=3.0):
+    """One train-mode forward + backward with the switches of ``env`` set while the plan is created; returns the flat gradient and
+    every stored input gradient {(activation, consumer slot): tensor} -- for A/B checks between two forms of one kernel."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        sd = well_conditioned_state(manifest) if state == "well" else O.load_weights(manifest)
+        m = M.build_model(predefine=manifest)
+        m.load_state_dict(sd)
+        m = m.to(device)
+        m._lib = lib if device.type == "cpu" else None
+        m.set_train_act_dtype(act_dtype)
+        m.train(); m.set_batchsize(B); m.clear_flops(); m.flops_hook(1.0)
+        hw = size if isinstance(size, tuple) else (size, size)
+        xd = torch.from_numpy(I.randn_batch(seed, B, hw[0], hw[1])).to(device)
+        td = torch.from_numpy(I.binary_target(seed + 1, B, hw[0], hw[1])).to(device)
+        y, pen = m._train_forward_raw(xd)
+        eng = m.engine_for(xd, train=True)
+        units, acts, names = m.describe(m._arena.offsets)
+        loss, dy = bce_and_grad(m._lib or N.load(), y, td)
+        flat = m._train_backward_raw(xd, dy, flops_weight / B).cpu()
+        G = {}
+        for a in range(1, len(acts)):
+            for s_ in range(eng.n_consumers(a)):
+                G[(a, s_)] = eng.train_probe(a, f"grad{s_}").cpu()
+        return flat, G
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
 def slim_network(manifest, tmp_path, thres=0.01):
     """(model, layer_config, state_dict) of the prune-and-finetune result of the shipped weights (zero-channel branches / dilations)."""
     m = M.build_model(predefine=manifest)

@@ -1,33 +1,31 @@
-// dpp_probe.hip -- hardware check of the cross-lane primitives the fused ILBlock kernel relies on (gfx950):
-// DPP wave_shr:1 / wave_shl:1 (full-wave shifts by one lane, zero fill), v_pk_fma_f32 with a broadcast scalar.
-// Build: hipcc --offload-arch=gfx950 -O3 tools/probes/dpp_probe.hip -o tools/probes/dpp_probe ; run on the GPU box.
+// dpp_probe.hip -- which lane does a wave_shr:1 / wave_shl:1 DPP move read on gfx950?  (k_misc.hip csn_from_lane_below / _above take the
+// depthwise kernels' halo columns from the neighbouring lanes with them.)  Expected: below[i] = i - 1 (lane 0: 0 by bound_ctrl),
+// above[i] = i + 1 (lane 63: 0); with the upper half of the wave switched off, lane 31's "above" must not be lane 32's stale value
+// used for anything (it is masked by the kernels) -- printed for the record.
+// build: hipcc --offload-arch=gfx950 -O3 -o dpp_probe dpp_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
-__global__ void k(float* o) {
-  const int l = threadIdx.x;
-  const float v = (float)(l + 1);
-  const int shr = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true);   // wave_shr:1
-  const int shl = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true);   // wave_shl:1
-  const int rshr = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true);  // row_shr:1
-  o[l] = __int_as_float(shr);
-  o[64 + l] = __int_as_float(shl);
-  o[128 + l] = __int_as_float(rshr);
+__global__ void k(unsigned* o, int half) {
+  const unsigned v = 100 + threadIdx.x;
+  unsigned b = 7777, a = 7777;
+  if (!half || threadIdx.x < 32) {
+    b = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
+    a = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
+  }
+  o[threadIdx.x] = b; o[64 + threadIdx.x] = a;
 }
 int main() {
-  float* d; float h[192];
+  unsigned* d; unsigned h[128];
   hipMalloc(&d, sizeof(h));
-  hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d);
-  hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
-  int bad = 0;
-  for (int l = 0; l < 64; ++l) {
-    const float e_shr = l == 0 ? 0.f : (float)l;          // lane l receives lane l-1
-    const float e_shl = l == 63 ? 0.f : (float)(l + 2);   // lane l receives lane l+1
-    const float e_r = (l & 15) == 0 ? 0.f : (float)l;
-    if (h[l] != e_shr || h[64 + l] != e_shl || h[128 + l] != e_r) {
-      ++bad;
-      printf("lane %d: wave_shr %g (want %g) wave_shl %g (want %g) row_shr %g (want %g)\n", l, h[l], e_shr, h[64 + l], e_shl, h[128 + l], e_r);
-    }
+  for (int half = 0; half < 2; ++half) {
+    hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d, half);
+    hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    int okb = 0, oka = 0;
+    const int n = half ? 32 : 64;
+    for (int i = 1; i < n; ++i) okb += h[i] == 100u + i - 1;
+    for (int i = 0; i < n - 1; ++i) oka += h[64 + i] == 100u + i + 1;
+    printf("%s: from_lane_below correct on %d of %d lanes (lane 0 reads %u); from_lane_above correct on %d of %d (lane %d reads %u)\n",
+           half ? "lower half of the wave active" : "whole wave active", okb, n - 1, h[0], oka, n - 1, n - 1, h[64 + n - 1]);
   }
-  printf("dpp_probe: %s\n", bad ? "MISMATCH" : "OK wave_shr:1 = from lane-1, wave_shl:1 = from lane+1, zero fill");
-  return bad != 0;
+  return 0;
 }
