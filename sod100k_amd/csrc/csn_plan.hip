@@ -1289,11 +1289,13 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
         br.pool = nullptr; br.skip_out = 0; br.stats = nullptr; br.xin = nullptr;
         br.C = d.cout[k]; br.H = P.H >> act.lvl; br.W = P.W >> act.lvl;
         const int cols = (br.W + 3) / 4;
-        br.LX = fused ? (cols < 64 ? cols : 64) : dw_lanes_x(cols, P.dw_xl && P.train);   // (the fused pair keeps whole rows of its intermediate in LDS)
+        // (the fused pair keeps whole rows of its intermediate in LDS; on the fast kernel a row of lanes is a power-of-two group)
+        const bool fastk = fused && P.dw_fast && !c.raw && u.dw2rec[k] >= 0 && (br.W % 4) == 0;
+        br.LX = fused ? (cols < 64 ? ((fastk && P.dw_xl) ? dw_lanes_x(cols, true) : cols) : 64) : dw_lanes_x(cols, P.dw_xl && P.train);
         br.NY = CSN_BLOCK / br.LX;
         br.tiles_x = (cols + br.LX - 1) / br.LX;
         if (fused) {
-          if (P.dw_fast && !c.raw && u.dw2rec[k] >= 0 && (br.W % 4) == 0) br.rec = c.pk(u.dw2rec[k]);
+          if (fastk) br.rec = c.pk(u.dw2rec[k]);
           br.w9b = c.pk(next->dw_w[k]);
           br.scale_b = c.pk(next->dw_epi[k].scale); br.shift_b = c.pk(next->dw_epi[k].shift);
           br.alpha_b = c.pk(next->dw_epi[k].alpha);
@@ -1305,7 +1307,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
             if (mp) br.pool_mp = reinterpret_cast<float*>(c.ws + P.units[u.pool_unit].mp_off[k]);
           }
           // (the fast kernel walks its rows in trips of four: R % 4 == 0, which the pooled outputs' 4 x 4 blocks ask for anyway)
-          br.R = choose_dw2_rows(br.H, br.NY, br.LX, pool, mp || br.rec != nullptr);
+          br.R = choose_dw2_rows(br.H, br.NY, fastk ? cols : br.LX, pool, mp || br.rec != nullptr);
         } else {
           br.R = choose_dw_rows(br.H, br.NY);
         }

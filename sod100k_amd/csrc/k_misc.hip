@@ -1198,6 +1198,11 @@ __device__ __forceinline__ void dw2f_row(const DwPar& pa, float* d, int yy, int 
   }
 }
 
+// XL: LX is a power of two >= the plane's strips (idle lanes at the end of every row of lanes), so that a row of lanes sits inside one
+// wave and the two halo columns of a loaded row are the neighbouring lanes' registers (csn_from_lane_below / _above: one DPP move each
+// instead of a load -- the knock-out build without the halo loads measured -12 % on this kernel, it is bound by the number of
+// vector-memory instructions like the train-mode kernels).
+template <bool XL>
 __global__ __launch_bounds__(CSN_BLOCK) void dw3x3x2_fast_kernel(DwArgs a_byval) {
   CSN_DYN_SMEM(float, lds);
   const CSN_CONST_AS DwArgs* a = CSN_KERNARG(DwArgs, a_byval);
@@ -1214,10 +1219,10 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3x2_fast_kernel(DwArgs a_byval)
   const int tid = threadIdx.x;
   const int ly = (int)dw_div((unsigned)tid, br->m_LX), lx = tid - ly * br->LX;
   const int H = br->H, W = br->W, R = br->R, NY = br->NY;   // R % 4 == 0 (launcher)
-  const int pitch = br->LX * 4 + 8;          // [4 pad | LX*4 pixels | 4 pad], rows 16-byte aligned
+  const int pitch = W + 8;                   // [4 pad | W pixels | 4 pad], rows 16-byte aligned (W % 4 == 0)
   const int x0 = lx * 4;
   const int yb = ty * NY * R;                // first output row of the block
-  const bool active = ly < NY;
+  const bool active = ly < NY && x0 < W;
   const csn_buf rb = csn_make_buf_n(br->in + (int64_t)pc * H * W, (unsigned)(H * W) * 4u);
   csn_cfp rec = csn_const(br->rec) + c * (2 * DWREC_FLOATS);
   const bool has_l = x0 > 0, has_r = x0 + 4 < W;
@@ -1228,16 +1233,23 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3x2_fast_kernel(DwArgs a_byval)
   struct Raw { float4 c; float l, r; };
   auto issue = [&](unsigned ro) {
     Raw q;
-#ifdef DW_KO_HALO   // knock-out build (wrong results): what do the two halo-column loads cost?
-    q.l = 0.f; q.r = 0.f;
-#else
+    q.c = csn_ld4(rb, ro + 4u, 0);
+#ifndef CSN_CPU_EMU
+    if (XL) { q.l = q.r = 0.f; return q; }
+#endif
     q.l = csn_ld1(rb, ro, 0);
     q.r = csn_ld1(rb, ro + 20u, 0);
-#endif
-    q.c = csn_ld4(rb, ro + 4u, 0);
     return q;
   };
-  auto fin = [&](const Raw& q) { return dw_row2_regs(q.l * ml, q.c.x, q.c.y, q.c.z, q.c.w, q.r * mr); };
+  auto fin = [&](const Raw& q) {
+#ifndef CSN_CPU_EMU
+    if (XL) {
+      const float l = csn_bits_f(csn_from_lane_below(__float_as_uint(q.c.w))), r = csn_bits_f(csn_from_lane_above(__float_as_uint(q.c.x)));
+      return dw_row2_regs(l * ml, q.c.x, q.c.y, q.c.z, q.c.w, r * mr);
+    }
+#endif
+    return dw_row2_regs(q.l * ml, q.c.x, q.c.y, q.c.z, q.c.w, q.r * mr);
+  };
   // ---- phase 1: intermediate rows [yb - 1, yb + NY*R] -> LDS row index (y - yb + 1); rows outside the image are ZERO (the second
   // conv pads its input, it does not see the first conv's response to padding).  Lane row ly owns rows [ly R, ly R + R) in trips of
   // four; the block's two halo rows (-1 and NY R) are one extra row for the first / last lane row -- round 4's loop gave those
@@ -1339,7 +1351,8 @@ size_t csn_dw2_lds_bytes(const DwArgs& a) {
   size_t m = 0;
   for (int k = 0; k < a.nbr; ++k) {
     // (+ 3 rows: dw3x3x2_fast_kernel's second phase reads its window four rows at a time, past the last row it uses)
-    const size_t n = (size_t)(a.br[k].NY * a.br[k].R + 2 + 3) * (a.br[k].LX * 4 + 8) * sizeof(float);
+    // (row pitch: LX strips of four in dw3x3x2_bn_prelu_kernel, the plane's width in the fast kernel -- LX may be rounded up there)
+    const size_t n = (size_t)(a.br[k].NY * a.br[k].R + 2 + 3) * (std::max(a.br[k].LX * 4, a.br[k].W) + 8) * sizeof(float);
     if (n > m) m = n;
   }
   return m;
@@ -1361,7 +1374,10 @@ int csn_launch_dw2(const DwArgs& a, void* stream) {
       f.br[k].m_C = csn_div_magic((unsigned)f.br[k].C);
       f.br[k].m_LX = csn_div_magic((unsigned)f.br[k].LX);
     }
-    CSN_LAUNCH(dw3x3x2_fast_kernel, dim3(nblk), dim3(CSN_BLOCK), lds, stream, f);
+    bool xl = true;   // rows of lanes inside one wave
+    for (int k = 0; k < f.nbr; ++k) xl = xl && f.br[k].LX <= 64 && (f.br[k].LX & (f.br[k].LX - 1)) == 0;
+    if (xl) CSN_LAUNCH(dw3x3x2_fast_kernel<true>, dim3(nblk), dim3(CSN_BLOCK), lds, stream, f);
+    else CSN_LAUNCH(dw3x3x2_fast_kernel<false>, dim3(nblk), dim3(CSN_BLOCK), lds, stream, f);
   } else if (vec) {
     CSN_LAUNCH((dw3x3x2_bn_prelu_kernel<true>), dim3(nblk), dim3(CSN_BLOCK), lds, stream, a);
   } else {
