@@ -131,6 +131,30 @@ def check_ilb_vs_unit_kernels(lib, device, manifest, B, H, W, seed=3, min_blocks
     return nfused, worst, err_o
 
 
+def check_lane_exchange_vs_loaded_halos(lib, device, manifest, B, H, W, seed=5):
+    """Eval forward with the depthwise kernels' halo columns taken from the neighbouring lanes (CSN_DW_XL=1, the default: power-of-two
+    lane groups per row, DPP moves) against the round-4 geometry with loaded halo columns (CSN_DW_XL=0; both read at plan creation).
+    The arithmetic per output pixel is the same and no value depends on the tiling: the logits are BIT-IDENTICAL."""
+    x = torch.from_numpy(I.randn_batch(seed, B, H, W))
+    saved = os.environ.get("CSN_DW_XL")
+    ys = {}
+    try:
+        for v in ("1", "0"):
+            os.environ["CSN_DW_XL"] = v
+            m, sd = make_model(lib, manifest, device)
+            ys[v] = m(x.to(device)).cpu()
+    finally:
+        if saved is None:
+            os.environ.pop("CSN_DW_XL", None)
+        else:
+            os.environ["CSN_DW_XL"] = saved
+    assert torch.equal(ys["1"], ys["0"]), float((ys["1"] - ys["0"]).abs().max())
+    ref = oracle_forward(manifest, sd, x)
+    err = float((ys["1"] - ref).abs().max())
+    assert err <= TOL, err
+    return err
+
+
 def check_vs_oracle(lib, device, manifest, x, sub_batch=0, tol=TOL):
     m, sd = make_model(lib, manifest, device, sub_batch=sub_batch)
     y = m(x.to(device)).cpu()

@@ -176,3 +176,27 @@ def test_gpu_ilb_x1_and_two_tile_groups(hip, x1_manifest, x2_manifest):
     lib, dev = hip
     print("x1:", P.check_ilb_vs_unit_kernels(lib, dev, x1_manifest, 2, 224, 224, min_blocks=4, env={"CSN_ILB_MAXPIX": "1024"}))
     print("nt 2:", P.check_ilb_vs_unit_kernels(lib, dev, x2_manifest, 2, 64, 64, env={"CSN_ILB_NT": "2", "CSN_ILB_MAXPIX": "1024"}))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 224, 224), (3, 64, 64), (2, 96, 160), (1, 256, 256)])
+def test_gpu_lane_exchange_equals_loaded_halos_eval(hip, x2_manifest, shape):
+    """Round 5: the depthwise pair's halo columns from the neighbouring lanes (one DPP move each, rows of lanes as power-of-two groups
+    inside a wave) -- bit-identical logits to the kernel that loads them, and inside the oracle bound.  256 x 256: 64 strips per row,
+    no idle lane in a group (the last lane's right neighbour is the first lane of the next ROW: masked)."""
+    lib, dev = hip
+    print(shape, "logits vs oracle %.2e, bit-identical to CSN_DW_XL=0" % P.check_lane_exchange_vs_loaded_halos(lib, dev, x2_manifest, *shape))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("act_dtype,size", [("fp32", 96), ("bf16", 224)])
+def test_gpu_lane_exchange_equals_loaded_halos_train(hip, x2_manifest, act_dtype, size):
+    """... and in the train step: the lane geometry changes the tiling of the partial sums (statistics, weight gradients), not any
+    pixel's arithmetic: gradients agree to rounding (fp32) / to bf16 rounding flips."""
+    lib, dev = hip
+    f1, g1 = P.train_backward_probes(lib, dev, x2_manifest, 2, size, act_dtype, {"CSN_DW_XL": "1"})
+    f0, g0 = P.train_backward_probes(lib, dev, x2_manifest, 2, size, act_dtype, {"CSN_DW_XL": "0"})
+    worst = max(float((g1[k].double() - g0[k].double()).norm() / (g0[k].double().norm() + 1e-30)) for k in g1)
+    rel = float((f1.double() - f0.double()).norm() / f0.double().norm())
+    print(f"{act_dtype} {size}: worst stored input gradient {worst:.2e}, flat gradient {rel:.2e}")
+    assert worst < (2e-2 if act_dtype == "bf16" else 5e-6) and rel < (2e-2 if act_dtype == "bf16" else 5e-6)

@@ -12,6 +12,8 @@ bash tools/gpu_pmc_train.sh ${RND}z $RND > /dev/null 2>&1; grep "^##" gpurun_out
 ( timeout 300 python tools/unit_table.py --json $O/unit_table.json ) > $O/unit_table.txt 2>&1; tail -1 $O/unit_table.txt
 ( timeout 120 tools/probes/issue_probe2 ) > $O/issue_probe2.txt 2>&1
 ( timeout 120 tools/probes/ilb_bench ) > $O/ilb_bench.txt 2>&1
+( timeout 60 tools/probes/dpp_probe ) > $O/dpp_probe.txt 2>&1
+( timeout 60 tools/probes/bufrange_probe ) > $O/bufrange_probe.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/trace_eval $O/trace_eval_nolanes $O/trace_train $O/trace_unpruned
 EV="--train-steps 0 --csf-batch 0 --no-cpu-baseline --no-latency-b1"

@@ -10,8 +10,10 @@ run() { name=$1; shift
 }
 run a SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY
 run b SQ_WAVES SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU
+if [ -n "$PMC_EVAL_ALL" ]; then   # (the memory-side passes: mid-round only, profiles/r5_pmc_eval_mid_round.txt)
 run c SQ_WAVES TA_BUSY TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLED_BY_TC_CYCLES TA_BUFFER_TOTAL_CYCLES
 run d SQ_WAVES TCP_PENDING_STALL_CYCLES TCP_GATE_EN1 TCP_LFIFO_STALL_CYCLES TCP_TCC_READ_REQ
+fi
 run e SQ_WAVES SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT
 cd $R
 python - $out <<'PY' | tee $out/pmc_eval.txt
