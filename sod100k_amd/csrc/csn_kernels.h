@@ -306,6 +306,8 @@ struct C3qArgs {
   int32_t max_grid;
   int32_t a16;          // activation tensors (sources, z, out) are bfloat16: raw launches of the bf16 train mode
   int32_t mfma16;       // ... on c3q16_kernel (v_mfma_f32_4x4x4_16B_bf16, weights of the pass rounded to bfloat16)
+  int32_t hl;           // float tensors, flat tiles: 62 quads per tile in lanes 1 .. 62, lanes 0 / 63 load their neighbours' halo
+                        // (tiles_x = ceil(quads / 62)); edge columns by lane exchange (k_c3q.hip C3qWin)
   int32_t grp_r0[PW4_MAX_GROUPS], grp_nt[PW4_MAX_GROUPS];   // first row / row tiles of every M group
 };
 int csn_c3q_max_tiles(void);

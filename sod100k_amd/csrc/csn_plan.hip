@@ -201,6 +201,7 @@ struct csn_plan {
   bool debug_dz = false;      // CSN_DEBUG_DZ (tests): the skipped passes (y of virt_cons activations, dz below) still run for the probes
   // CSN_DEBUG_DZ: ... and the apply pass still runs AFTER that kernel, so that the probes see dz (tests)
   bool no_mp_fuse = false;    // CSN_NO_MP_FUSE: the max-pooled copies of c3q_kernel always come from pool2_kernel (experiments)
+  bool c3q_hl = true;     // CSN_C3Q_HL=0: c3q_kernel's float launches on 64-quad tiles with loaded edge columns (round 3) instead of halo lanes
   int c3q_twl = 6;        // ... of c3q_kernel's tile in output quads (CSN_C3Q_TWL)
   bool pw4_nosplit = false;   // CSN_PW4_NOSPLIT: no extra M groups on small maps (experiments)
   bool overlap_bwd = false;   // CSN_OPT_OVERLAP value 2: also the weight-gradient side lane of csn_backward
@@ -1217,6 +1218,8 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
       q.ngroups = L.c3q_ng; q.gimg_floats = L.c3q_gimg; q.nt = L.c3q_nt; q.max_grid = P.pw4_grid;
       q.a16 = c.a16 ? 1 : 0;
       q.mfma16 = (c.a16 && (gradq ? P.c3q16 >= 1 : P.c3q16 >= 2)) ? 1 : 0;
+      q.hl = (P.c3q_hl && !c.a16) ? 1 : 0;
+      if (q.hl) { q.twl = PW4_FLAT_TWL; q.tiles_x = (Hq * Wq + 61) / 62; q.tiles_y = 1; }
       for (int g = 0; g < PW4_MAX_GROUPS; ++g) { q.grp_r0[g] = L.c3q_r0[g]; q.grp_nt[g] = L.c3q_gnt[g]; }
       const bool rawq = c.raw || pp.out_kind == OUT_Z || gradq;
       LAUNCH_TRY(csn_launch_c3q(q, rawq ? 1 : 0, c.stream));
@@ -1740,6 +1743,7 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   if (const char* e = std::getenv("CSN_PWQ16")) P->pwq16 = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_MS_DX")) P->ms_dx = std::atoi(e) != 0;
   if (std::getenv("CSN_NO_MP_FUSE")) P->no_mp_fuse = true;
+  if (const char* v = std::getenv("CSN_C3Q_HL")) P->c3q_hl = std::atoi(v) != 0;
   if (const char* v = std::getenv("CSN_C3Q_TWL")) { if (std::atoi(v) >= 2 && std::atoi(v) <= 6) P->c3q_twl = std::atoi(v); }
   if (const char* v = std::getenv("CSN_BN_BWD_FUSE")) P->bn_bwd_fuse = v[0] != '0';
   if (const char* v = std::getenv("CSN_DEBUG_DZ")) P->debug_dz = v[0] != '0';

@@ -47,6 +47,42 @@ __device__ __forceinline__ void c3q_load_own(csn_buf rb, const C3qGeo& g, unsign
   }
 }
 
+// HL, halo lanes (round 5): a knock-out build without the eight edge loads of a window ran 11 % faster (the load side is bound by the
+// number of vector-memory instructions, profiles/r5_notes.md).  A flat tile is then 62 consecutive quads in lanes 1 .. 62; lane 0 /
+// lane 63 hold the quad in front of / behind them and only LOAD (nothing of theirs is stored).  Every working lane's left / right
+// edge column is its neighbour lane's centre pair (one DPP move on the loaded register, k_misc.hip csn_from_lane_below / _above); no
+// lane needs a fallback load.  Quads in the plane's first / last column take zeros (the padding) instead of the neighbour's value.
+// The four centre pairs are what stays in flight (8 registers per channel instead of 16); the window is completed when it is used.
+struct C3qWin {
+  float2 c[4];
+#ifdef CSN_CPU_EMU
+  float l[4], r[4];   // (the emulator's lanes run one after the other: it loads the edges)
+#endif
+};
+__device__ __forceinline__ void c3q_issue_hl(csn_buf rb, const C3qGeo& g, unsigned so, C3qWin& w) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    w.c[r] = csn_ld2(rb, g.row[r], so);
+#ifdef CSN_CPU_EMU
+    w.l[r] = csn_ld1(rb, g.row[r] + g.dl, so);
+    w.r[r] = csn_ld1(rb, g.row[r] + g.dr, so);
+#endif
+  }
+}
+__device__ __forceinline__ void c3q_finish_hl(const C3qWin& w, bool has_l, bool has_r, float (&v)[16]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    v[4 * r + 1] = w.c[r].x; v[4 * r + 2] = w.c[r].y;
+#ifdef CSN_CPU_EMU
+    v[4 * r] = w.l[r]; v[4 * r + 3] = w.r[r];
+#else
+    const float l = csn_bits_f((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(w.c[r].y), 0x138, 0xf, 0xf, true));
+    const float rr = csn_bits_f((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(w.c[r].x), 0x130, 0xf, 0xf, true));
+    v[4 * r] = has_l ? l : 0.f; v[4 * r + 3] = has_r ? rr : 0.f;
+#endif
+  }
+}
+
 // nine taps of one channel: wk = image rows of (channel, tap 0) (each [4][P] floats)
 template <int NT, int P>
 __device__ __forceinline__ void c3q_channel(const float (&v)[16], const float* wk, csn_f4 (&acc)[4][NT]) {
@@ -66,7 +102,7 @@ __device__ __forceinline__ void c3q_channel(const float (&v)[16], const float* w
 }  // namespace
 
 // AT: element type of the activation tensors (float; csn_bf16 = the bf16 train mode's storage, RAW launches only)
-template <int NT, bool RAW, typename AT = float>
+template <int NT, bool RAW, typename AT = float, bool HL = false>
 __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q_kernel(C3qArgs a_byval) {
   constexpr int NT4 = (NT + 3) & ~3, P = PW4_PITCH(NT4);
   constexpr unsigned E = (unsigned)sizeof(AT);
@@ -96,7 +132,15 @@ __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q_kernel(C3qArgs a_byval
     const int tile = item / ng, g = item - tile * ng;
     const int b = tile / tiles_xy, txy = tile - b * tiles_xy;
     int yq, xq;
-    if (twl >= PW4_FLAT_TWL) {   // flat tiles: 64 consecutive quads of the plane (see k_pw4.hip)
+    bool work = true;   // HL: lanes 0 and 63 only load
+    if (HL) {             // flat tiles of 62 quads in lanes 1 .. 62 (the launcher passes flat tiles only)
+      const int p = max(txy * 62 + lane - 1, 0);
+      int q = (int)((float)p * (1.0f / (float)Wq));
+      q -= (q * Wq > p) ? 1 : 0;
+      q += ((q + 1) * Wq <= p) ? 1 : 0;
+      yq = q; xq = p - q * Wq;
+      work = lane >= 1 && lane <= 62;
+    } else if (twl >= PW4_FLAT_TWL) {   // flat tiles: 64 consecutive quads of the plane (see k_pw4.hip)
       const int p = txy * 64 + lane;
       int q = (int)((float)p * (1.0f / (float)Wq));
       q -= (q * Wq > p) ? 1 : 0;
@@ -106,7 +150,7 @@ __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q_kernel(C3qArgs a_byval
       const int ty = txy / a->tiles_x, tx = txy - ty * a->tiles_x;
       yq = (ty << (6 - twl)) + ly; xq = (tx << twl) + lx;
     }
-    const bool valid = yq < Hq && xq < Wq;
+    const bool valid = work && yq < Hq && xq < Wq;
     const int y = min(yq, Hq - 1), x = min(xq, Wq - 1);
     const float* wg = wl_lane + g * a->gimg_floats;
 
@@ -132,6 +176,29 @@ __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q_kernel(C3qArgs a_byval
       geo.dr = has_r ? 2u * E : 0x40000000u;
       const csn_buf rb = csn_make_buf_n(reinterpret_cast<const char*>(a->src[s].ptr) + (int64_t)b * a->src[s].Ctot * (int64_t)cs,
                                         (unsigned)a->src[s].Ctot * cs);
+      if (HL) {   // the centre pairs of channel c + 1 in flight while channel c is completed (lane exchange) and contracted
+        C3qWin wA, wB;
+        float v[16];
+        c3q_issue_hl(rb, geo, 0u, wA);
+        PW4_FENCE();
+        int c = 0;
+        for (; c + 1 < C; c += 2) {
+          c3q_issue_hl(rb, geo, (unsigned)(c + 1) * cs, wB);
+          PW4_FENCE();
+          c3q_finish_hl(wA, has_l, has_r, v);
+          c3q_channel<NT, P>(v, wg + (krow + 9 * c) * 4 * P, acc);
+          c3q_issue_hl(rb, geo, (unsigned)min(c + 2, C - 1) * cs, wA);
+          PW4_FENCE();
+          c3q_finish_hl(wB, has_l, has_r, v);
+          c3q_channel<NT, P>(v, wg + (krow + 9 * (c + 1)) * 4 * P, acc);
+        }
+        if (c < C) {
+          c3q_finish_hl(wA, has_l, has_r, v);
+          c3q_channel<NT, P>(v, wg + (krow + 9 * c) * 4 * P, acc);
+        }
+        krow += 9 * C;
+        continue;
+      }
       // channel c is contracted while channel c + 1 is in flight: two register sets, channels walked in pairs
       float vA[16], vB[16];
       c3q_load_own<AT>(rb, geo, 0u, vA);
@@ -409,8 +476,10 @@ __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q16_kernel(C3qArgs a_byv
 #define C3Q_INST_LIST(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
 typedef void (*C3qFn)(C3qArgs);
-struct C3qEntry { int nt; C3qFn fn[4]; };   // BN + PReLU / raw / raw with bfloat16 tensors / ... on the bf16 matrix instruction
-#define C3Q_ENTRY(N) {N, {c3q_kernel<N, false>, c3q_kernel<N, true>, c3q_kernel<N, true, csn_bf16>, c3q16_kernel<N>}},
+struct C3qEntry { int nt; C3qFn fn[6]; };   // BN + PReLU / raw / raw with bfloat16 tensors / ... on the bf16 matrix instruction /
+                                            // the first two on halo-lane tiles (C3qArgs::hl)
+#define C3Q_ENTRY(N) {N, {c3q_kernel<N, false>, c3q_kernel<N, true>, c3q_kernel<N, true, csn_bf16>, c3q16_kernel<N>, \
+                          c3q_kernel<N, false, float, true>, c3q_kernel<N, true, float, true>}},
 static const C3qEntry g_c3q_table[] = {C3Q_INST_LIST(C3Q_ENTRY)};
 
 int csn_c3q_max_tiles(void) { return 7; }
@@ -429,7 +498,7 @@ int csn_launch_c3q(const C3qArgs& a, int raw, void* stream) {
   static CsnPerDeviceOnce attr_once;
   const int ast = attr_once.run([&]() {
     for (size_t i = 0; i < sizeof(g_c3q_table) / sizeof(g_c3q_table[0]); ++i)
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < 6; ++r) {
         const hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(g_c3q_table[i].fn[r]),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (er != hipSuccess) return (int)er;
@@ -444,6 +513,11 @@ int csn_launch_c3q(const C3qArgs& a, int raw, void* stream) {
     for (int s = 0; s < a.nsrc; ++s) kg += (a.src[s].C + 3) >> 2;
     const size_t lds16 = (size_t)a.ngroups * kg * 9 * a.nt * 4 * sizeof(uint2);
     CSN_LAUNCH(e->fn[3], grid, dim3(CSN_BLOCK), lds16, stream, a);
+    return (int)hipGetLastError();
+  }
+  if (a.hl) {
+    if (a.a16 || a.twl < PW4_FLAT_TWL) return 1;   // halo-lane tiles: float tensors, flat tiles of 62 quads (the planner's choice)
+    CSN_LAUNCH(e->fn[raw ? 5 : 4], grid, dim3(CSN_BLOCK), lds, stream, a);
     return (int)hipGetLastError();
   }
   CSN_LAUNCH(e->fn[raw ? (a.a16 ? 2 : 1) : 0], grid, dim3(CSN_BLOCK), lds, stream, a);
