@@ -180,10 +180,13 @@ __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
   // k_pw4.hip); the launcher provides a wave per tile, so the accumulators survive the barrier the z exchange needs ----
   ILB_STAMP(0);
   const int lane = tid & 63, wave = pw4_uniform(tid >> 6);
-  const int pix = wave * 64 + lane;
-  const bool tile_on = wave * 64 < HWl;
-  const bool valid = pix < HWl;
-  const int pc = min(pix, HWl - 1);
+  // K3: halo-lane tiles (k_c3q.hip C3qWin): 62 pixels per wave in lanes 1 .. 62, lanes 0 / 63 hold the pixel in front of / behind them
+  // and only load -- every window's edge columns are the neighbouring lanes' centre values, no gathers for them
+  constexpr int TP = K3 ? 62 : 64;
+  const int pix = K3 ? wave * 62 + lane - 1 : wave * 64 + lane;
+  const bool tile_on = wave * TP < HWl;
+  const bool valid = pix < HWl && (!K3 || (lane >= 1 && lane <= 62));
+  const int pc = min(max(pix, 0), HWl - 1);
   const int y = pc / Wl, x = pc - y * Wl;
   const unsigned csl = (unsigned)HWl * 4u, csh = csl * 4u;
   const unsigned oh0 = (unsigned)((2 * y) * Wh + 2 * x) * 4u, oh1 = oh0 + (unsigned)Wh * 4u, olc = (unsigned)pc * 4u;
@@ -266,17 +269,56 @@ __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
         const int yy = y - 1 + r, xx = x - 1 + c;
         ol9[3 * r + c] = (yy >= 0 && yy < Hl && xx >= 0 && xx < Wl) ? (unsigned)(yy * Wl + xx) * 4u : 0x80000000u;
       }
-    auto load_win = [&](int c, float (&v)[16], float (&u)[9]) {
+    // the centre pairs of the four high rows and the centre column of the three low rows: what is loaded (7 loads per channel; the
+    // gather form took 21) and what stays in flight (11 registers instead of 25)
+    struct Win { float2 c[4]; float m[3];
+#ifdef CSN_CPU_EMU
+      float l[4], r[4], ml[3], mr[3];   // (the emulator's lanes run one after the other: it loads the edges)
+#endif
+    };
+    const bool has_l = x > 0, has_r = x < Wl - 1;
+    auto issue_win = [&](int c, Win& w) {
       const unsigned sh_ = (unsigned)min(c, CH - 1) * csh, sl_ = (unsigned)min(c, CH - 1) * csl;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float2 cc = csn_ld2(rbh, rowh[r], sh_);
-        v[4 * r + 1] = cc.x; v[4 * r + 2] = cc.y;
-        v[4 * r] = csn_ld1(rbh, rowh[r] + dl, sh_);
-        v[4 * r + 3] = csn_ld1(rbh, rowh[r] + dr, sh_);
+        w.c[r] = csn_ld2(rbh, rowh[r], sh_);
+#ifdef CSN_CPU_EMU
+        w.l[r] = csn_ld1(rbh, rowh[r] + dl, sh_);
+        w.r[r] = csn_ld1(rbh, rowh[r] + dr, sh_);
+#endif
       }
 #pragma unroll
-      for (int t = 0; t < 9; ++t) u[t] = csn_ld1(rbl, ol9[t], sl_);
+      for (int r = 0; r < 3; ++r) {
+        w.m[r] = csn_ld1(rbl, ol9[3 * r + 1], sl_);
+#ifdef CSN_CPU_EMU
+        w.ml[r] = csn_ld1(rbl, ol9[3 * r], sl_);
+        w.mr[r] = csn_ld1(rbl, ol9[3 * r + 2], sl_);
+#endif
+      }
+    };
+    auto finish_win = [&](const Win& w, float (&v)[16], float (&u)[9]) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[4 * r + 1] = w.c[r].x; v[4 * r + 2] = w.c[r].y;
+#ifdef CSN_CPU_EMU
+        v[4 * r] = w.l[r]; v[4 * r + 3] = w.r[r];
+#else
+        const float l = csn_bits_f((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(w.c[r].y), 0x138, 0xf, 0xf, true));
+        const float rr = csn_bits_f((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(w.c[r].x), 0x130, 0xf, 0xf, true));
+        v[4 * r] = has_l ? l : 0.f; v[4 * r + 3] = has_r ? rr : 0.f;
+#endif
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        u[3 * r + 1] = w.m[r];
+#ifdef CSN_CPU_EMU
+        u[3 * r] = w.ml[r]; u[3 * r + 2] = w.mr[r];
+#else
+        const float l = csn_bits_f((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(w.m[r]), 0x138, 0xf, 0xf, true));
+        const float rr = csn_bits_f((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(w.m[r]), 0x130, 0xf, 0xf, true));
+        u[3 * r] = has_l ? l : 0.f; u[3 * r + 2] = has_r ? rr : 0.f;
+#endif
+      }
     };
     auto contract = [&](const float (&v)[16], const float (&u)[9], const float* wk) {
 #pragma unroll
@@ -292,21 +334,23 @@ __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
         for (int t = 0; t < NTL; ++t) pw4_mfma<NT4>(aw, NTH + t, u[t9], accl[t]);
       }
     };
-    // channel c + 1 is in flight while channel c is contracted.  (Measured, stage 4.0, batch 64: the launch is bound by the NUMBER of
-    // vector-memory instructions -- 21 gathers per channel and wave against 9 (4 NTH + NTL) matrix instructions, ten waves per CU --
-    // not by their latency: a third register set in flight (which needs > 128 registers = one block per CU) made it slower,
-    // 51 -> 56 us; profiles/r5_notes.md.)
-    float vA[16], uA[9], vB[16], uB[9];
-    load_win(0, vA, uA);
+    // channel c + 1 is in flight while channel c is completed (lane exchange) and contracted.  (The gather form -- 21 loads per
+    // channel and wave against 9 (4 NTH + NTL) matrix instructions -- was bound by the NUMBER of its loads, not their latency: a
+    // third register set in flight made it slower, 51 -> 56 us per launch at stage 4.0; profiles/r5_notes.md.)
+    Win wA, wB;
+    float v[16], u[9];
+    issue_win(0, wA);
     PW4_FENCE();
     for (int c = 0; c < CH; c += 2) {
-      load_win(c + 1, vB, uB);
+      issue_win(c + 1, wB);
       PW4_FENCE();
-      contract(vA, uA, wg + 9 * c * 4 * P);
+      finish_win(wA, v, u);
+      contract(v, u, wg + 9 * c * 4 * P);
       if (c + 1 >= CH) break;
-      load_win(c + 2, vA, uA);
+      issue_win(c + 2, wA);
       PW4_FENCE();
-      contract(vB, uB, wg + 9 * (c + 1) * 4 * P);
+      finish_win(wB, v, u);
+      contract(v, u, wg + 9 * (c + 1) * 4 * P);
     }
   }
   if (tile_on && !K3) {
@@ -467,7 +511,7 @@ size_t csn_ilb_layout(IlbArgs& a) {
   a.off_par = off; off += (a.nth + a.ntl) * (16 + 96);   // epilogue records + depthwise records of the group's channels
   a.lds_floats = off;
   // a wave per tile of 64 low pixels (the accumulators live across the z barrier); one task per lane where the block allows
-  const int tiles = (a.Hl * a.Wl + 63) / 64;
+  const int tiles = a.k3 ? (a.Hl * a.Wl + 61) / 62 : (a.Hl * a.Wl + 63) / 64;   // (K3: halo-lane tiles of 62 pixels)
   if (tiles > 16) return 0;
   const int tasks = 4 * a.nth * ((Wh + 3) / 4) * ((Hh + a.Rh - 1) / a.Rh) + 4 * a.ntl * ((a.Wl + 3) / 4) * ((a.Hl + a.Rl - 1) / a.Rl);
   int nthr = std::max(64 * tiles, std::min(1024, (tasks + 63) & ~63));
