@@ -136,18 +136,21 @@ def check_lane_exchange_vs_loaded_halos(lib, device, manifest, B, H, W, seed=5):
     lane groups per row, DPP moves) against the round-4 geometry with loaded halo columns (CSN_DW_XL=0; both read at plan creation).
     The arithmetic per output pixel is the same and no value depends on the tiling: the logits are BIT-IDENTICAL."""
     x = torch.from_numpy(I.randn_batch(seed, B, H, W))
-    saved = os.environ.get("CSN_DW_XL")
+    keys = ("CSN_DW_XL", "CSN_C3Q_HL")   # ... and c3q_kernel's halo-lane tiles against its 64-quad tiles with loaded edge columns
+    saved = {k: os.environ.get(k) for k in keys}
     ys = {}
     try:
         for v in ("1", "0"):
-            os.environ["CSN_DW_XL"] = v
+            for k in keys:
+                os.environ[k] = v
             m, sd = make_model(lib, manifest, device)
             ys[v] = m(x.to(device)).cpu()
     finally:
-        if saved is None:
-            os.environ.pop("CSN_DW_XL", None)
-        else:
-            os.environ["CSN_DW_XL"] = saved
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     assert torch.equal(ys["1"], ys["0"]), float((ys["1"] - ys["0"]).abs().max())
     ref = oracle_forward(manifest, sd, x)
     err = float((ys["1"] - ref).abs().max())

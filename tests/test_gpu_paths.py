@@ -182,7 +182,8 @@ def test_gpu_ilb_x1_and_two_tile_groups(hip, x1_manifest, x2_manifest):
 @pytest.mark.parametrize("shape", [(2, 224, 224), (3, 64, 64), (2, 96, 160), (1, 256, 256)])
 def test_gpu_lane_exchange_equals_loaded_halos_eval(hip, x2_manifest, shape):
     """Round 5: the depthwise pair's halo columns from the neighbouring lanes (one DPP move each, rows of lanes as power-of-two groups
-    inside a wave) -- bit-identical logits to the kernel that loads them, and inside the oracle bound.  256 x 256: 64 strips per row,
+    inside a wave) and c3q_kernel's window edge columns on halo-lane tiles (62 quads per wave, lanes 0 / 63 only load) -- bit-identical
+    logits to the kernels that load them (CSN_DW_XL=0, CSN_C3Q_HL=0), and inside the oracle bound.  256 x 256: 64 strips per row,
     no idle lane in a group (the last lane's right neighbour is the first lane of the next ROW: masked)."""
     lib, dev = hip
     print(shape, "logits vs oracle %.2e, bit-identical to CSN_DW_XL=0" % P.check_lane_exchange_vs_loaded_halos(lib, dev, x2_manifest, *shape))
