@@ -204,7 +204,6 @@ struct csn_plan {
   bool c3q_hl = true;     // CSN_C3Q_HL=0: c3q_kernel's float launches on 64-quad tiles with loaded edge columns (round 3) instead of halo lanes
   int c3q_twl = 6;        // ... of c3q_kernel's tile in output quads (CSN_C3Q_TWL)
   bool pw4_nosplit = false;   // CSN_PW4_NOSPLIT: no extra M groups on small maps (experiments)
-  int pw4_items = 1536;       // CSN_PW4_ITEMS: pw4_kernel's M groups are split until a launch has this many items (1.5 per SIMD)
   bool overlap_bwd = false;   // CSN_OPT_OVERLAP value 2: also the weight-gradient side lane of csn_backward
   bool last_bwd_lanes = false;   // ... and whether the last csn_backward really ran with it (csn_plan_train_act_info reports from this)
   int device = 0;             // ordinal of the device the plan's streams / events / packed buffer live on (csn_plan_destroy)
@@ -654,7 +653,7 @@ int plan_pw4_launch(Builder& bl, UnitPlan& u, const int* ci_off, const int* co_o
   const int64_t tiles = (int64_t)bl.P.S * ((Hl_ * Wl_ + 63) / 64);
   int gmin = 1;
   if (!bl.P.pw4_nosplit)
-    while (gmin < PW4_MAX_GROUPS && tiles * gmin < bl.P.pw4_items && gmin < std::max(nth_tot, ntl_tot)) ++gmin;
+    while (gmin < PW4_MAX_GROUPS && tiles * gmin < 1536 && gmin < std::max(nth_tot, ntl_tot)) ++gmin;
   const int budget = (lo_out < 0 && use_x2) ? 164 : (lo_out < 0 ? 116 : 100);
   int ng = 0, pn = 0, pl = 0;
   for (int g = gmin; g <= PW4_MAX_GROUPS; ++g) {
@@ -1727,7 +1726,6 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   P->S = (sub_batch <= 0 || sub_batch > B) ? B : sub_batch;
   if (const char* v = std::getenv("CSN_PW4_GRID")) { if (std::atoi(v) >= 8) P->pw4_grid = std::atoi(v); }
   if (std::getenv("CSN_PW4_NOSPLIT")) P->pw4_nosplit = true;
-  if (const char* v = std::getenv("CSN_PW4_ITEMS")) { if (std::atoi(v) >= 64) P->pw4_items = std::atoi(v); }
   if (std::getenv("CSN_PW4_NOQ")) P->pw4_no_q = true;
   if (const char* e = std::getenv("CSN_PW4_FLAT")) P->pw4_flat = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_ILB")) P->ilb = std::atoi(e) != 0;
