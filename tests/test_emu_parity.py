@@ -98,6 +98,14 @@ def test_emu_train_units_local(emu_lib, x2_manifest, act_dtype, B, size, state):
     print(P.check_train_units_local(emu_lib, CPU, x2_manifest, B=B, size=size, act_dtype=act_dtype, state=state))
 
 
+@pytest.mark.parametrize("act_dtype", ["fp32", "bf16"])
+def test_emu_train_units_local_badly_centred_channels(emu_lib, x2_manifest, act_dtype):
+    """the fused depthwise backward forms dz = g sel - (B z + A) with the batch mean folded into A; on channels whose raw
+    output has |mean| ~ 10 standard deviations (as far as zero padding lets a depthwise output go) B z and A cancel to ~10 % of their size.
+    Every unit stays inside the unit-local bounds (measured: dz 3e-7 in fp32)."""
+    print(P.check_train_units_local(emu_lib, CPU, x2_manifest, B=2, size=48, act_dtype=act_dtype, state="offcentre"))
+
+
 @pytest.mark.parametrize("act_dtype,ipp", [("fp32", 2), ("bf16", 3)])
 def test_emu_train_units_local_multi_image_slabs(emu_lib, x2_manifest, monkeypatch, act_dtype, ipp):
     """The BN / depthwise reductions hand several whole planes to one block when the batch is large (batch 256: 5-20 images

@@ -195,7 +195,9 @@ def test_gpu_resizes(hip):
 
 
 @pytest.mark.parametrize("act_dtype,B,size,state", [("fp32", 4, 96, "shipped"), ("fp32", 2, 224, "well"), ("bf16", 4, 96, "shipped"),
-                                                    ("bf16", 2, 224, "shipped"), ("bf16", 3, 48, "well"), ("bf16", 2, 16, "shipped")])
+                                                    ("bf16", 2, 224, "shipped"), ("bf16", 3, 48, "well"), ("bf16", 2, 16, "shipped"),
+                                                    # badly centred depthwise channels (|mean| ~ 10 sigma): parity_cases.off_centre_state
+                                                    ("fp32", 2, 96, "offcentre"), ("bf16", 2, 96, "offcentre")])
 def test_gpu_train_units_local(hip, x2_manifest, act_dtype, B, size, state):
     """Every unit's train-mode forward and backward (z, activation, dz, dx per consumer slot, every parameter gradient)
     against the oracle applied to the tensors the kernels themselves produced around that unit: no amplification through
