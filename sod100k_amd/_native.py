@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 # SOD100K_HIP_LIB: developer override (A/B builds of the same sources, e.g. the knock-out variants of profiles/r1_notes.md)
 LIB_PATH = os.environ.get("SOD100K_HIP_LIB") or os.path.join(CSRC, "libcsnet_hip.so")
-SOURCES = ("csn_plan.hip", "k_misc.hip", "k_goct_pw.hip", "k_ms.hip", "k_train.hip", "k_wgrad.hip", "k_wgrad_c3.hip", "k_wgrad_bf.hip", "k_goct_c3.hip", "k_csf.hip", "k_pw4.hip", "k_c3q.hip", "k_pwq.hip", "k_ilb.hip")
+SOURCES = ("csn_plan.hip", "k_misc.hip", "k_goct_pw.hip", "k_ms.hip", "k_train.hip", "k_wgrad.hip", "k_wgrad_c3.hip", "k_wgrad_bf.hip", "k_goct_c3.hip", "k_csf.hip", "k_pw4.hip", "k_c3q.hip", "k_pwq.hip", "k_ilb.hip", "k_head.hip")
 
 ABI_VERSION = 3       # include/csnet_hip.h CSN_ABI_VERSION: checked BEFORE the entry points are bound (a stale .so lacks the new ones)
 

@@ -278,6 +278,16 @@ template <> struct csn_bufacc<float> {
   static __device__ __forceinline__ float ld1(csn_buf b, unsigned voff, unsigned soff) { return csn_ld1(b, voff, soff); }
   static __device__ __forceinline__ float2 ld2(csn_buf b, unsigned voff, unsigned soff) { return csn_ld2(b, voff, soff); }
   static __device__ __forceinline__ float4 ld4(csn_buf b, unsigned voff, unsigned soff) { return csn_ld4(b, voff, soff); }
+  // raw forms: what a load leaves in the registers / its float value.  Kernels that keep a batch of loads in flight across a
+  // scheduling fence hold the RAW registers and convert where the values are used (round 6: with ld1 / ld2 the bfloat16
+  // conversion sat in front of the fence and every batch waited for its own loads -- pw4_kernel<bf16> at 0.21 of the HBM peak)
+  typedef float r1; typedef float2 r2; typedef float4 r4;
+  static __device__ __forceinline__ r1 ldr1(csn_buf b, unsigned voff, unsigned soff) { return csn_ld1(b, voff, soff); }
+  static __device__ __forceinline__ r2 ldr2(csn_buf b, unsigned voff, unsigned soff) { return csn_ld2(b, voff, soff); }
+  static __device__ __forceinline__ r4 ldr4(csn_buf b, unsigned voff, unsigned soff) { return csn_ld4(b, voff, soff); }
+  static __device__ __forceinline__ float cv1(r1 v) { return v; }
+  static __device__ __forceinline__ float2 cv2(r2 v) { return v; }
+  static __device__ __forceinline__ float4 cv4(r4 v) { return v; }
   static __device__ __forceinline__ void st1(csn_buf b, unsigned voff, unsigned soff, float v) { csn_st1(b, voff, soff, v); }
   static __device__ __forceinline__ void st2(csn_buf b, unsigned voff, unsigned soff, float2 v) { csn_st2(b, voff, soff, v); }
   static __device__ __forceinline__ void st4(csn_buf b, unsigned voff, unsigned soff, float4 v) { csn_st4(b, voff, soff, v); }
@@ -290,6 +300,15 @@ template <> struct csn_bufacc<csn_bf16> {
   }
   static __device__ __forceinline__ float4 ld4(csn_buf b, unsigned voff, unsigned soff) {
     const uint2 u = csn_ld_u64(b, voff, soff);
+    return make_float4(csn_bits_f(u.x << 16), csn_bits_f(u.x & 0xffff0000u), csn_bits_f(u.y << 16), csn_bits_f(u.y & 0xffff0000u));
+  }
+  typedef unsigned r1; typedef unsigned r2; typedef uint2 r4;
+  static __device__ __forceinline__ r1 ldr1(csn_buf b, unsigned voff, unsigned soff) { return (unsigned)csn_ld_u16(b, voff, soff); }
+  static __device__ __forceinline__ r2 ldr2(csn_buf b, unsigned voff, unsigned soff) { return csn_ld_u32(b, voff, soff); }
+  static __device__ __forceinline__ r4 ldr4(csn_buf b, unsigned voff, unsigned soff) { return csn_ld_u64(b, voff, soff); }
+  static __device__ __forceinline__ float cv1(r1 u) { return csn_bits_f(u << 16); }
+  static __device__ __forceinline__ float2 cv2(r2 u) { return make_float2(csn_bits_f(u << 16), csn_bits_f(u & 0xffff0000u)); }
+  static __device__ __forceinline__ float4 cv4(r4 u) {
     return make_float4(csn_bits_f(u.x << 16), csn_bits_f(u.x & 0xffff0000u), csn_bits_f(u.y << 16), csn_bits_f(u.y & 0xffff0000u));
   }
   static __device__ __forceinline__ void st1(csn_buf b, unsigned voff, unsigned soff, float v) { csn_st_u16(b, voff, soff, csn_f2bf(v)); }

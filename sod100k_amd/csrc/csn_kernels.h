@@ -231,6 +231,33 @@ bool csn_pw4_pick(int nth, int ntl, int* pnth, int* pntl);
 int csn_launch_pw4(const Pw4Args& a, int raw, void* stream);
 
 // ---------------------------------------------------------------------------------------------
+// high output of a three-branch 1x1 unit, the low -> high terms as low-resolution products through LDS (k_head.hip, round 6)
+// ---------------------------------------------------------------------------------------------
+#define HZ_MAX_GROUPS 8
+struct HzArgs {
+  const float* xh;     // [B][CH][2 H1][2 W1]
+  const float* x1;     // [B][C1][H1][W1]
+  const float* x2;     // [B][C2][H1 / 2][W1 / 2]
+  float* yh;           // [B][OH][2 H1][2 W1]   (rows stored)
+  float* part;         // row reduction (red_w): [ngroups][B][2 H1][2 W1], group g's sum of red_w[r] * PReLU(BN(y_r)) over its rows
+  const float* red_w;  // cls_layer weights per output row (null: rows are stored)
+  const float* wimg;   // [ngroups][CH + C1 + C2][4][P]: pw4_kernel's image (CSN_PREP_PW4), group g = rows [4 nth g, 4 nth (g + 1))
+  const float* ep_h;   // {scale, shift, alpha, 0} per output channel, padded to whole groups
+  int32_t CH, C1, C2, OH;
+  int32_t H1, W1, B;   // H1, W1 even
+  int32_t RB;          // rows of x2 per band (4 RB output rows per item)
+  int32_t ngroups, nth;
+  int32_t hb, nw;      // instantiation: x_0 channels per load batch (2 | 4), waves per block (4 | 8 | 16)
+  // set by csn_hz_layout:
+  int32_t gimg_floats, nbands;
+  int32_t pitch1, plane1, pitch2, plane2;   // LDS planes of z_1 / z_2 (floats): [4 nth][2 RB + 2][W1 + 2], [4 nth][RB + 2][W1 / 2 + 2]
+  int32_t off_z1, off_z2;
+};
+size_t csn_hz_layout(HzArgs& a);   // LDS bytes of an item, 0 = unsupported geometry
+bool csn_hz_supported(int nth);
+int csn_launch_hz(const HzArgs& a, void* stream);
+
+// ---------------------------------------------------------------------------------------------
 // one whole ILBlock (1x1 gOctaveCBR -> depthwise pair) per launch, the block's planes in LDS (small maps; see k_ilb.hip)
 // ---------------------------------------------------------------------------------------------
 struct IlbArgs {
@@ -358,6 +385,10 @@ struct Up2Args {
   float* out;       // [planes][H][W]  (always float: the caller's logits)
   int32_t planes, H, W;
   int32_t in16;     // `in` is bfloat16
+  // `in` is a sum of partial planes (hz_kernel's row reduction, k_head.hip): value = bias[0] + sum_k in[k * part_stride + .]
+  int32_t nparts = 1;
+  int64_t part_stride = 0;
+  const float* bias = nullptr;
 };
 
 // ---------------------------------------------------------------------------------------------

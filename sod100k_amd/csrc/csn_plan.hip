@@ -152,6 +152,8 @@ struct UnitPlan {
     int64_t dwrec[2] = {-1, -1};   // per channel {w9[9] x100, scale, shift, alpha} of conv3x3_1 and of conv3x3_2 (24 floats)
   } ilb;
   int pw4_old_mask = 0;              // output branches that stay on goct_pw_kernel (CSFHead.fuse's lowest branch)
+  // GOCT 1x1 with three input branches: the HIGH output on hz_kernel (k_head.hip; eval mode) instead of pw4l[0]; on = 0: not eligible
+  struct Hz { int on = 0, nth = 0, ng = 0, gimg = 0, RB = 2, hb = 2, nw = 4; int64_t wimg = -1, ep = -1; } hz;
   // MS
   int64_t ms_w[5] = {-1, -1, -1, -1, -1};
   Epi ms_epi;
@@ -189,6 +191,11 @@ struct csn_plan {
   int ilb_nt = 0;         // its row tiles per group and branch: 0 = chosen per block (plan_ilb), CSN_ILB_NT=1|2 forces (experiments)
   int ilb_maxpix = 256;   // ... only where the low plane has at most this many pixels (CSN_ILB_MAXPIX)
   bool pw4 = true;        // CSN_OPT_PW4: two-branch 1x1 units on pw4_kernel (k_pw4.hip)
+  bool hz = true;         // CSN_HZ=0: the high output of the three-branch 1x1 units stays on pw4_kernel (A/B; k_head.hip)
+  // its geometry, [0] for a unit with several outputs (CSFHead.fuse), [1] for a single-output unit (fuse1x1); the environment
+  // variables take "a" or "a,b" (experiments): row tiles per M group (0: chosen by plan_hz; CSN_HZ_NT), rows of the lowest input per
+  // band (CSN_HZ_RB), x_0 channels per load batch (CSN_HZ_HB), waves per block (CSN_HZ_NW)
+  int hz_nt[2] = {0, 0}, hz_rb[2] = {2, 2}, hz_hb[2] = {2, 2}, hz_nw[2] = {4, 4};
   int pw4_grid = 2048;    // its block cap (CSN_PW4_GRID, experiments)
   int pw4_twl = 6;        // log2 of its widest tile in low pixels: whole rows of up to 64 (CSN_PW4_TWL; 4 = 16 x 4 tiles: 1 % slower)
   bool pw4_flat = true;       // CSN_PW4_FLAT=0: row-segment tiles everywhere (round 3; A/B)
@@ -707,6 +714,46 @@ int plan_pw4_launch(Builder& bl, UnitPlan& u, const int* ci_off, const int* co_o
   return 0;
 }
 
+// High output of a three-branch 1x1 unit on hz_kernel (k_head.hip): uniform M groups of `nth` row tiles, weight image
+// [group][K][4][P] in pw4_kernel's form (gathered channels: branch 0, 1, 2), epilogue records padded to whole groups.
+void plan_hz(Builder& bl, UnitPlan& u, const int* ci_off, const int* co_off, int cin_tot) {
+  const csn_unit_desc& d = u.d;
+  if (d.n_in != 3 || d.cin[0] <= 0 || d.cin[1] <= 0 || d.cin[2] <= 0 || d.cout[0] <= 0) return;
+  const int H0 = bl.P.H >> u.base_lvl, W0 = bl.P.W >> u.base_lvl;
+  if ((H0 % 4) != 0 || (W0 % 4) != 0) return;
+  const int tiles = (d.cout[0] + 3) / 4;
+  // row tiles per group: as few groups as the register budget allows (<= 5 tiles = 80 accumulators); a group re-reads x_0
+  const int ki = d.n_out == 1 ? 1 : 0;
+  int nth = bl.P.hz_nt[ki] > 0 ? bl.P.hz_nt[ki] : std::min(5, tiles);
+  if (bl.P.hz_nt[ki] == 0 && tiles > 5) nth = (tiles + ((tiles + 4) / 5) - 1) / ((tiles + 4) / 5);   // even groups
+  const int ng = (tiles + nth - 1) / nth;
+  if (ng > HZ_MAX_GROUPS || !csn_hz_supported(nth)) return;
+  HzArgs a;
+  a.CH = d.cin[0]; a.C1 = d.cin[1]; a.C2 = d.cin[2]; a.OH = d.cout[0]; a.H1 = H0 >> 1; a.W1 = W0 >> 1; a.B = 1;
+  a.nth = nth; a.ngroups = ng; a.RB = bl.P.hz_rb[ki]; a.hb = bl.P.hz_hb[ki]; a.nw = bl.P.hz_nw[ki];
+  const size_t lds = csn_hz_layout(a);
+  if (lds == 0 || lds > 160 * 1024) return;
+  const int NT4 = (nth + 3) & ~3, Pp = PW4_PITCH(NT4);
+  UnitPlan::Hz& h = u.hz;
+  h.nth = nth; h.ng = ng; h.gimg = a.gimg_floats; h.RB = a.RB; h.hb = a.hb; h.nw = a.nw;
+  h.wimg = bl.alloc_packed((int64_t)ng * h.gimg);
+  for (int g = 0; g < ng; ++g) {
+    const int r0 = 4 * nth * g, nr = std::min(4 * nth, d.cout[0] - r0);
+    int k0 = 0;
+    for (int i = 0; i < 3; ++i) {
+      bl.job(CSN_PREP_PW4, nr, h.wimg + (int64_t)g * h.gimg, d.w_off[0] + (int64_t)(co_off[0] + r0) * cin_tot + ci_off[i], -1, -1, -1, 1.f,
+             cin_tot, d.cin[i], Pp, 0 | (k0 << 8));
+      k0 += d.cin[i];
+    }
+  }
+  const int rows = 4 * ng * nth + 4;
+  h.ep = bl.alloc_packed((int64_t)rows * 4);
+  bl.job(CSN_PREP_BN_SCALE, d.cout[0], h.ep, d.bn[0].weight, d.bn[0].running_var, -1, -1, 1.f, 0, 0, 4, 0);
+  bl.job(CSN_PREP_BN_SHIFT, d.cout[0], h.ep, d.bn[0].weight, d.bn[0].running_var, d.bn[0].bias, d.bn[0].running_mean, 1.f, 0, 0, 4, 1);
+  bl.job(CSN_PREP_COPY, d.cout[0], h.ep, d.bn[0].prelu, -1, -1, -1, 1.f, 0, 0, 4, 2);
+  h.on = 1;
+}
+
 int plan_pw4(Builder& bl, UnitPlan& u, const int* ci_off, const int* co_off, int cin_tot) {
   const csn_unit_desc& d = u.d;
   if (d.ksize != 1 || d.stride != 1 || u.std_conv || d.n_in < 2 || d.cin[0] <= 0 || d.cin[1] <= 0 || d.cout[0] <= 0) return CSN_OK;
@@ -736,6 +783,7 @@ int plan_pw4(Builder& bl, UnitPlan& u, const int* ci_off, const int* co_off, int
   }
   if (!ok) { u.pw4l.clear(); u.pw4_old_mask = 0; return CSN_OK; }
   u.pw4 = 1;
+  if (d.n_in == 3) plan_hz(bl, u, ci_off, co_off, cin_tot);
   return CSN_OK;
 }
 
@@ -791,7 +839,7 @@ int plan_cls(Builder& bl, UnitPlan& u) {
   const Act& ai = P.acts[d.in_act[0]];
   if (ai.channels != d.cin[0] || ai.lvl != 1) FAIL(CSN_E_INVALID, "cls: input must be at H/2");  // csnet.py:380-385
   u.base_lvl = 1;
-  u.logits_off = bl.alloc_act(1, 1);
+  u.logits_off = bl.alloc_act(HZ_MAX_GROUPS, 1);   // (hz_kernel's row reduction leaves one partial plane per M group, k_head.hip)
   PwLaunchPlan L;
   L.lvl = 1;
   PwPassPlan ps;
@@ -1384,12 +1432,31 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
         }
         const int nl = (int)u.pw4l.size() + (int)old.size();
         const bool fork = c.lanes && nl >= 2 && nl <= 3;
+        const bool use_hz = P.hz && u.hz.on && !c.raw && !c.a16 && d.stride == 1;
         if (fork) { const int st0 = lanes_fork(c, nl - 1); if (st0 != CSN_OK) return st0; }
         int lane = 0;
         for (const UnitPlan::Pw4Launch& L : u.pw4l) {
           Ctx cl = c;
           if (fork && lane > 0) cl.stream = c.P.lane[lane - 1];
           ++lane;
+          if (use_hz && L.hi_out == 0 && L.lo_out < 0) {   // the high output of a three-branch unit: hz_kernel (k_head.hip)
+            HzArgs h;
+            h.xh = xin[0]; h.x1 = xin[1]; h.x2 = xin[2];
+            h.yh = c.act_out(d.out_act[0]); h.part = nullptr; h.red_w = nullptr;
+            if (cls_next) {   // cls_layer rides in the epilogue: per-group partial sums, added up (+ bias) by the final upsample
+              const PwLaunchPlan& CL = next->pwl[0];
+              h.red_w = c.pk(CL.wimg + CL.passes[0].w_off);
+              h.part = reinterpret_cast<float*>(c.ws + next->logits_off);
+            }
+            h.wimg = c.pk(u.hz.wimg); h.ep_h = c.pk(u.hz.ep);
+            h.CH = d.cin[0]; h.C1 = d.cin[1]; h.C2 = d.cin[2]; h.OH = d.cout[0];
+            h.H1 = P.H >> (u.base_lvl + 1); h.W1 = P.W >> (u.base_lvl + 1); h.B = S;
+            h.RB = u.hz.RB; h.ngroups = u.hz.ng; h.nth = u.hz.nth; h.hb = u.hz.hb; h.nw = u.hz.nw;
+            if (csn_hz_layout(h) == 0) return CSN_E_INVALID;
+            LAUNCH_TRY(csn_launch_hz(h, cl.stream));
+            { const int ms_ = cl.mark("hz_kernel"); if (ms_ != CSN_OK) return ms_; }
+            continue;
+          }
           Pw4Args a;
           a.xh = xin[L.bh]; a.xl = xin[L.bl]; a.x2 = L.use_x2 ? xin[L.bl + 1] : nullptr; a.xq = L.bq >= 0 ? xin[L.bq] : nullptr;
           a.yh = L.hi_out >= 0 ? c.act_out(d.out_act[L.hi_out]) : nullptr;
@@ -1406,6 +1473,9 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
           a.ep_l = L.ep[1] >= 0 ? c.pk(L.ep[1]) : nullptr;
           a.CH = d.cin[L.bh]; a.CL = d.cin[L.bl]; a.C2 = L.use_x2 ? d.cin[L.bl + 1] : 0; a.CQ = L.bq >= 0 ? d.cin[L.bq] : 0;
           a.OH = L.hi_out >= 0 ? d.cout[L.hi_out] : 0; a.OL = L.lo_out >= 0 ? d.cout[L.lo_out] : 0;
+#ifdef CSN_KO_HEAD_NOLOW   // knock-out build (tools/README.md): the high-only three-branch launches without their low / third inputs
+          if (L.use_x2 && L.lo_out < 0) { a.CL = 1; a.C2 = 1; }
+#endif
           a.Hl = P.H >> (u.base_lvl + L.bl); a.Wl = P.W >> (u.base_lvl + L.bl); a.B = S;
           int twl = 0;
           while (twl < P.pw4_twl && (1 << twl) < a.Wl) ++twl;
@@ -1438,6 +1508,10 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
         if (cls_next) {
           Up2Args ua;
           ua.in = reinterpret_cast<const float*>(c.ws + next->logits_off); ua.out = c.y; ua.planes = S; ua.H = P.H; ua.W = P.W; ua.in16 = 0;
+          if (use_hz) {   // hz_kernel left one partial plane per M group: the upsample adds them up and the cls_layer bias
+            ua.nparts = u.hz.ng; ua.part_stride = (int64_t)S * (P.H >> 1) * (P.W >> 1);
+            ua.bias = c.pk(next->pwl[0].passes[0].epi.shift);
+          }
           LAUNCH_TRY(csn_launch_up2(ua, c.stream));
           { const int ms_ = c.mark("bilinear_up2_kernel"); if (ms_ != CSN_OK) return ms_; }
         }
@@ -1726,6 +1800,19 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   P->S = (sub_batch <= 0 || sub_batch > B) ? B : sub_batch;
   if (const char* v = std::getenv("CSN_PW4_GRID")) { if (std::atoi(v) >= 8) P->pw4_grid = std::atoi(v); }
   if (std::getenv("CSN_PW4_NOSPLIT")) P->pw4_nosplit = true;
+  if (const char* e = std::getenv("CSN_HZ")) P->hz = std::atoi(e) != 0;
+  {
+    auto pair = [](const char* name, int (&dst)[2], int lo, int hi) {
+      const char* e = std::getenv(name);
+      if (!e) return;
+      const int a0 = std::atoi(e);
+      const char* c = std::strchr(e, ',');
+      const int a1 = c ? std::atoi(c + 1) : a0;
+      if (a0 >= lo && a0 <= hi) dst[0] = a0;
+      if (a1 >= lo && a1 <= hi) dst[1] = a1;
+    };
+    pair("CSN_HZ_NT", P->hz_nt, 1, 5); pair("CSN_HZ_RB", P->hz_rb, 1, 14); pair("CSN_HZ_HB", P->hz_hb, 2, 4); pair("CSN_HZ_NW", P->hz_nw, 4, 16);
+  }
   if (std::getenv("CSN_PW4_NOQ")) P->pw4_no_q = true;
   if (const char* e = std::getenv("CSN_PW4_FLAT")) P->pw4_flat = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_ILB")) P->ilb = std::atoi(e) != 0;
@@ -2268,6 +2355,9 @@ const char* csn_unit_kernel_name(const csn_plan* P, int32_t u) {
     for (const PwLaunchPlan& L : P->units[u].pwl) q = q && L.c3q;
     return q ? "c3q_kernel" : "goct_c3_kernel";
   }
+  if (P->pw4 && P->hz && P->units[u].pw4 && P->units[u].hz.on &&
+      !(P->fuse_cls && P->units[u].fuse_cls && !(P->units[u].pw4l.size() == 1 && P->units[u].pw4l[0].lo_out < 0)))
+    return "hz_kernel";
   if (P->pw4 && P->units[u].pw4 &&
       !(P->fuse_cls && P->units[u].fuse_cls && !(P->units[u].pw4l.size() == 1 && P->units[u].pw4l[0].lo_out < 0)))
     return "pw4_kernel";

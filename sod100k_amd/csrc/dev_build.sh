@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 cd "$OUT"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-result \
   -Rpass-analysis=kernel-resource-usage -save-temps -I"$HERE" \
-  -o "$HERE/libcsnet_hip.so" "$HERE/csn_plan.hip" "$HERE/k_misc.hip" "$HERE/k_goct_pw.hip" "$HERE/k_ms.hip" "$HERE/k_train.hip" "$HERE/k_wgrad.hip" "$HERE/k_goct_c3.hip" "$HERE/k_csf.hip" "$HERE/k_wgrad_c3.hip" "$HERE/k_wgrad_bf.hip" "$HERE/k_pw4.hip" "$HERE/k_c3q.hip" "$HERE/k_pwq.hip" "$HERE/k_ilb.hip" \
+  -o "$HERE/libcsnet_hip.so" "$HERE/csn_plan.hip" "$HERE/k_misc.hip" "$HERE/k_goct_pw.hip" "$HERE/k_ms.hip" "$HERE/k_train.hip" "$HERE/k_wgrad.hip" "$HERE/k_goct_c3.hip" "$HERE/k_csf.hip" "$HERE/k_wgrad_c3.hip" "$HERE/k_wgrad_bf.hip" "$HERE/k_pw4.hip" "$HERE/k_c3q.hip" "$HERE/k_pwq.hip" "$HERE/k_ilb.hip" "$HERE/k_head.hip" \
   > "$OUT/build.log" 2>&1 || { cat "$OUT/build.log" | grep -E "error" -A3 | head -40; exit 1; }
 python3 - "$OUT/build.log" <<'PY'
 import re, sys

@@ -35,15 +35,27 @@ struct C3qGeo {        // per item, per lane
   unsigned dl, dr;     // add to a row offset for the left (column 2x - 1) / right (column 2x + 2) edge; out of range when outside
 };
 
-// 4x4 window of one channel at the pass resolution
+// 4x4 window of one channel at the pass resolution, as loaded (raw registers: the conversion of a bfloat16 window happens where the
+// window is contracted, behind the scheduling fence -- csn_device.h)
+template <typename AT> struct C3qRaw {
+  typename csn_bufacc<AT>::r2 c[4];
+  typename csn_bufacc<AT>::r1 l[4], r[4];
+};
 template <typename AT>
-__device__ __forceinline__ void c3q_load_own(csn_buf rb, const C3qGeo& g, unsigned so, float (&v)[16]) {
+__device__ __forceinline__ void c3q_load_own(csn_buf rb, const C3qGeo& g, unsigned so, C3qRaw<AT>& w) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const float2 c = csn_bufacc<AT>::ld2(rb, g.row[r], so);
-    v[4 * r + 1] = c.x; v[4 * r + 2] = c.y;
-    v[4 * r] = csn_bufacc<AT>::ld1(rb, g.row[r] + g.dl, so);
-    v[4 * r + 3] = csn_bufacc<AT>::ld1(rb, g.row[r] + g.dr, so);
+    w.c[r] = csn_bufacc<AT>::ldr2(rb, g.row[r], so);
+    w.l[r] = csn_bufacc<AT>::ldr1(rb, g.row[r] + g.dl, so);
+    w.r[r] = csn_bufacc<AT>::ldr1(rb, g.row[r] + g.dr, so);
+  }
+}
+template <typename AT>
+__device__ __forceinline__ void c3q_finish_own(const C3qRaw<AT>& w, float (&v)[16]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float2 c = csn_bufacc<AT>::cv2(w.c[r]);
+    v[4 * r] = csn_bufacc<AT>::cv1(w.l[r]); v[4 * r + 1] = c.x; v[4 * r + 2] = c.y; v[4 * r + 3] = csn_bufacc<AT>::cv1(w.r[r]);
   }
 }
 
@@ -200,29 +212,33 @@ __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q_kernel(C3qArgs a_byval
         continue;
       }
       // channel c is contracted while channel c + 1 is in flight: two register sets, channels walked in pairs
-      float vA[16], vB[16];
-      c3q_load_own<AT>(rb, geo, 0u, vA);
+      C3qRaw<AT> wA, wB;
+      float v[16];
+      c3q_load_own<AT>(rb, geo, 0u, wA);
       PW4_FENCE();
       const int nf = C - 1;
       int c = 0;
       for (int p = 0; p < (nf >> 1); ++p) {
-        c3q_load_own<AT>(rb, geo, (unsigned)(c + 1) * cs, vB);
+        c3q_load_own<AT>(rb, geo, (unsigned)(c + 1) * cs, wB);
         PW4_FENCE();
-        c3q_channel<NT, P>(vA, wg + (krow + 9 * c) * 4 * P, acc);
-        c3q_load_own<AT>(rb, geo, (unsigned)(c + 2) * cs, vA);
+        c3q_finish_own<AT>(wA, v);
+        c3q_channel<NT, P>(v, wg + (krow + 9 * c) * 4 * P, acc);
+        c3q_load_own<AT>(rb, geo, (unsigned)(c + 2) * cs, wA);
         PW4_FENCE();
-        c3q_channel<NT, P>(vB, wg + (krow + 9 * (c + 1)) * 4 * P, acc);
+        c3q_finish_own<AT>(wB, v);
+        c3q_channel<NT, P>(v, wg + (krow + 9 * (c + 1)) * 4 * P, acc);
         c += 2;
       }
       if (nf & 1) {
-        c3q_load_own<AT>(rb, geo, (unsigned)(c + 1) * cs, vB);
+        c3q_load_own<AT>(rb, geo, (unsigned)(c + 1) * cs, wB);
         PW4_FENCE();
-        c3q_channel<NT, P>(vA, wg + (krow + 9 * c) * 4 * P, acc);
+        c3q_finish_own<AT>(wA, v);
+        c3q_channel<NT, P>(v, wg + (krow + 9 * c) * 4 * P, acc);
         ++c;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) vA[i] = vB[i];
+        wA = wB;
       }
-      c3q_channel<NT, P>(vA, wg + (krow + 9 * c) * 4 * P, acc);
+      c3q_finish_own<AT>(wA, v);
+      c3q_channel<NT, P>(v, wg + (krow + 9 * c) * 4 * P, acc);
       krow += 9 * C;
     }
 

@@ -1233,6 +1233,9 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3x2_fast_kernel(DwArgs a_byval)
   struct Raw { float4 c; float l, r; };
   auto issue = [&](unsigned ro) {
     Raw q;
+#ifdef CSN_KO_DW2_NOLOAD   // knock-out build (tools/README.md): the pair without its HBM reads (= a fused block's traffic; wrong results)
+    q.c = make_float4(1.f, 2.f, 3.f, csn_bits_f(ro)); q.l = q.r = 0.f; return q;
+#endif
     q.c = csn_ld4(rb, ro + 4u, 0);
 #ifndef CSN_CPU_EMU
     if (XL) { q.l = q.r = 0.f; return q; }
@@ -1502,8 +1505,17 @@ __global__ __launch_bounds__(CSN_BLOCK) void bilinear_up2_kernel(Up2Args a) {
   csn_bilin(y, 0.5f, Hi, y0, y1, ly);
   csn_bilin(x, 0.5f, Wi, x0, x1, lx);
   const TI* __restrict__ p = act_cast<TI>(a.in) + (int64_t)plane * Hi * Wi;
-  const float v0 = (1.f - lx) * act_ld(p + y0 * Wi + x0) + lx * act_ld(p + y0 * Wi + x1);
-  const float v1 = (1.f - lx) * act_ld(p + y1 * Wi + x0) + lx * act_ld(p + y1 * Wi + x1);
+  float t00 = act_ld(p + y0 * Wi + x0), t01 = act_ld(p + y0 * Wi + x1), t10 = act_ld(p + y1 * Wi + x0), t11 = act_ld(p + y1 * Wi + x1);
+  if (a.nparts > 1 || a.bias) {   // the taps are sums of partial planes (+ the cls_layer bias), added up in plane order
+    for (int k = 1; k < a.nparts; ++k) {
+      const TI* __restrict__ pk = p + (int64_t)k * a.part_stride;
+      t00 += act_ld(pk + y0 * Wi + x0); t01 += act_ld(pk + y0 * Wi + x1); t10 += act_ld(pk + y1 * Wi + x0); t11 += act_ld(pk + y1 * Wi + x1);
+    }
+    const float bv = a.bias ? a.bias[0] : 0.f;
+    t00 += bv; t01 += bv; t10 += bv; t11 += bv;
+  }
+  const float v0 = (1.f - lx) * t00 + lx * t01;
+  const float v1 = (1.f - lx) * t10 + lx * t11;
   a.out[idx] = (1.f - ly) * v0 + ly * v1;
 }
 

@@ -42,6 +42,12 @@
 #ifndef PW4_OCC
 #define PW4_OCC 2   // blocks per CU the register allocation aims at
 #endif
+// accumulator registers up to which a form is compiled for three waves per SIMD (168 registers).  bfloat16 tensors: the raw
+// register sets AND their converted values are live in a batch -- the (5, 3) / (4, 6) forms spilled 136-192 bytes per lane at 168
+#ifndef PW4_ACC3_BF
+#define PW4_ACC3_BF 84
+#endif
+#define PW4_ACC3(AT) (sizeof(AT) == 2 ? PW4_ACC3_BF : 92)
 
 
 
@@ -87,23 +93,27 @@ __device__ __forceinline__ void pw4_x2_geo(int y, int x, int H2, int W2, unsigne
 }
 
 template <int N, int XB, typename AT = float>
-__device__ __forceinline__ void pw4_load_x2(csn_buf rb, const Pw4X2& g, unsigned cs, int c0, int C, float (&v)[XB][N]) {
+__device__ __forceinline__ void pw4_load_x2(csn_buf rb, const Pw4X2& g, unsigned cs, int c0, int C,
+                                            typename csn_bufacc<AT>::r1 (&v)[XB][N]) {
 #pragma unroll
   for (int j = 0; j < XB; ++j) {
     const unsigned so = (unsigned)min(c0 + j, C - 1) * cs;
 #pragma unroll
-    for (int t = 0; t < N; ++t) v[j][t] = csn_bufacc<AT>::ld1(rb, g.o[t], so);
+    for (int t = 0; t < N; ++t) v[j][t] = csn_bufacc<AT>::ldr1(rb, g.o[t], so);
   }
 }
 
 // one channel of the third input: NTL = 0 -> quad values by separable three-tap interpolation -> high rows;
 // NTH = 0 -> one value -> low rows
-template <int NTH, int NTL, int P, int N>
-__device__ __forceinline__ void pw4_x2_channel(const float (&v)[N], const Pw4X2& g, const float* wk,
+template <int NTH, int NTL, int P, int N, typename AT = float>
+__device__ __forceinline__ void pw4_x2_channel(const typename csn_bufacc<AT>::r1 (&raw)[N], const Pw4X2& g, const float* wk,
                                                csn_f4 (&acch)[4][NTH > 0 ? NTH : 1], csn_f4 (&accl)[NTL > 0 ? NTL : 1]) {
   constexpr int NT4 = (NTH + NTL + 3) & ~3;
   Pw4A<NT4> a;
   pw4_load_a<NT4, P>(wk, a);
+  float v[N];
+#pragma unroll
+  for (int t = 0; t < N; ++t) v[t] = csn_bufacc<AT>::cv1(raw[t]);
   if (NTH > 0) {
     float h[2][3];
 #pragma unroll
@@ -131,19 +141,23 @@ __device__ __forceinline__ void pw4_x2_channel(const float (&v)[N], const Pw4X2&
 // fourth input (low-only form): 4x4 max-pool of a tensor at four times the resolution of branch l; o = byte offset of
 // (4 y, 4 x) inside a channel plane (16-byte aligned: W is a multiple of 4 there), ws = its row pitch in bytes
 template <int QB, typename AT>
-__device__ __forceinline__ void pw4_load_xq(csn_buf rb, unsigned o, unsigned ws, unsigned cs, int c0, int C, float4 (&v)[QB][4]) {
+__device__ __forceinline__ void pw4_load_xq(csn_buf rb, unsigned o, unsigned ws, unsigned cs, int c0, int C,
+                                            typename csn_bufacc<AT>::r4 (&v)[QB][4]) {
 #pragma unroll
   for (int j = 0; j < QB; ++j) {
     const unsigned so = (unsigned)min(c0 + j, C - 1) * cs;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[j][r] = csn_bufacc<AT>::ld4(rb, o + (unsigned)r * ws, so);
+    for (int r = 0; r < 4; ++r) v[j][r] = csn_bufacc<AT>::ldr4(rb, o + (unsigned)r * ws, so);
   }
 }
-template <int NTL, int P>
-__device__ __forceinline__ void pw4_xq_channel(const float4 (&v)[4], const float* wk, csn_f4 (&accl)[NTL > 0 ? NTL : 1]) {
+template <int NTL, int P, typename AT = float>
+__device__ __forceinline__ void pw4_xq_channel(const typename csn_bufacc<AT>::r4 (&raw)[4], const float* wk, csn_f4 (&accl)[NTL > 0 ? NTL : 1]) {
   constexpr int NT4 = (NTL + 3) & ~3;
   Pw4A<NT4> a;
   pw4_load_a<NT4, P>(wk, a);
+  float4 v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = csn_bufacc<AT>::cv4(raw[r]);
   float m = fmaxf(fmaxf(v[0].x, v[0].y), fmaxf(v[0].z, v[0].w));
 #pragma unroll
   for (int r = 1; r < 4; ++r) m = fmaxf(m, fmaxf(fmaxf(v[r].x, v[r].y), fmaxf(v[r].z, v[r].w)));
@@ -156,7 +170,7 @@ __device__ __forceinline__ void pw4_xq_channel(const float4 (&v)[4], const float
 // MODE 0: BN + PReLU epilogue, rows stored; 1 (RAW): plain sums stored; 2 (RED): BN + PReLU, rows reduced with red_w
 // AT: element type of the activation tensors (float; csn_bf16 = the bf16 train mode's storage, RAW only)
 template <int NTH, int NTL, int MODE, typename AT = float>
-__global__ __launch_bounds__(CSN_BLOCK, (16 * NTH + 4 * NTL <= 92 && !(NTL == 0 && NTH >= 5) && PW4_OCC < 3) ? 3 : PW4_OCC)
+__global__ __launch_bounds__(CSN_BLOCK, (16 * NTH + 4 * NTL <= PW4_ACC3(AT) && !(NTL == 0 && NTH >= 5) && PW4_OCC < 3) ? 3 : PW4_OCC)
 void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulators leave room (the high-only forms carry the
                                      // third input's staging registers: two waves from five row tiles on)
   constexpr bool RAW = MODE == 1, RED = MODE == 2;
@@ -229,7 +243,11 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
     Pw4X2 g2;
     if (C2 > 0) pw4_x2_geo<NTL == 0>(yc, xc, Hl >> 1, Wl >> 1, E, g2);
     float red[4] = {0.f, 0.f, 0.f, 0.f};
+#ifdef CSN_KO_PW4_NOSTORE   // knock-out build: every store out of range (the instructions stay, their bytes go; wrong results)
+    const unsigned sv0 = 0x80000000u, sv1 = 0x80000000u;
+#else
     const unsigned sv0 = valid ? oh0 : 0x80000000u, sv1 = valid ? oh1 : 0x80000000u;
+#endif
     const int g_last = gloop ? a->ngroups : g_first + 1;
     for (int g = g_first; g < g_last; ++g) {
     const float* wg = wl_lane + g * a->gimg_floats;
@@ -249,8 +267,9 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
     // ---- high-branch channels: batch k0 is contracted while batch k0 + HB is in flight.  Two register sets; the full
     // batches are walked in pairs so that no set is copied inside the loop, and the last (possibly partial) batch always
     // ends up in set A ----
-    float2 hA[HB][2], hB[HB][2];
-    float lA[LB][9], lB[LB][9];
+    typedef csn_bufacc<AT> ACC;   // register sets hold the loads raw (converted where they are contracted)
+    typename ACC::r2 hA[HB][2], hB[HB][2];
+    typename ACC::r1 lA[LB][9], lB[LB][9];
     pw4_load_hi<HB, AT>(rbh, oh0, oh1, csh, 0, CH, hA);
       PW4_FENCE();
     const int nfh = (CH - 1) / HB;   // full batches in front of the last one
@@ -258,23 +277,23 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
     for (int p = 0; p < (nfh >> 1); ++p) {
       pw4_load_hi<HB, AT>(rbh, oh0, oh1, csh, k0 + HB, CH, hB);
       PW4_FENCE();
-      pw4_hi_batch<NTH, NTL, HB, P, false>(hA, wg + k0 * 4 * P, HB, acch, accl);
+      pw4_hi_batch<NTH, NTL, HB, P, false, AT>(hA, wg + k0 * 4 * P, HB, acch, accl);
       pw4_load_hi<HB, AT>(rbh, oh0, oh1, csh, k0 + 2 * HB, CH, hA);
       PW4_FENCE();
-      pw4_hi_batch<NTH, NTL, HB, P, false>(hB, wg + (k0 + HB) * 4 * P, HB, acch, accl);
+      pw4_hi_batch<NTH, NTL, HB, P, false, AT>(hB, wg + (k0 + HB) * 4 * P, HB, acch, accl);
       k0 += 2 * HB;
     }
     if (nfh & 1) {
       pw4_load_hi<HB, AT>(rbh, oh0, oh1, csh, k0 + HB, CH, hB);
       PW4_FENCE();
-      pw4_hi_batch<NTH, NTL, HB, P, false>(hA, wg + k0 * 4 * P, HB, acch, accl);
+      pw4_hi_batch<NTH, NTL, HB, P, false, AT>(hA, wg + k0 * 4 * P, HB, acch, accl);
       k0 += HB;
 #pragma unroll
       for (int j = 0; j < HB; ++j) { hA[j][0] = hB[j][0]; hA[j][1] = hB[j][1]; }
     }
     pw4_load_lo<LB, AT>(rbl, ol, csl, 0, CL, lA);
       PW4_FENCE();
-    pw4_hi_batch<NTH, NTL, HB, P, true>(hA, wg + k0 * 4 * P, CH - k0, acch, accl);
+    pw4_hi_batch<NTH, NTL, HB, P, true, AT>(hA, wg + k0 * 4 * P, CH - k0, acch, accl);
     // ---- low-branch channels, same scheme ----
     const float* wgl = wg + CH * 4 * P;
     const int nfl = (CL - 1) / LB;
@@ -282,27 +301,27 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
     for (int p = 0; p < (nfl >> 1); ++p) {
       pw4_load_lo<LB, AT>(rbl, ol, csl, c0 + LB, CL, lB);
       PW4_FENCE();
-      pw4_lo_batch<NTH, NTL, LB, P, false>(lA, wgl + c0 * 4 * P, LB, acch, accl);
+      pw4_lo_batch<NTH, NTL, LB, P, false, AT>(lA, wgl + c0 * 4 * P, LB, acch, accl);
       pw4_load_lo<LB, AT>(rbl, ol, csl, c0 + 2 * LB, CL, lA);
       PW4_FENCE();
-      pw4_lo_batch<NTH, NTL, LB, P, false>(lB, wgl + (c0 + LB) * 4 * P, LB, acch, accl);
+      pw4_lo_batch<NTH, NTL, LB, P, false, AT>(lB, wgl + (c0 + LB) * 4 * P, LB, acch, accl);
       c0 += 2 * LB;
     }
     if (nfl & 1) {
       pw4_load_lo<LB, AT>(rbl, ol, csl, c0 + LB, CL, lB);
       PW4_FENCE();
-      pw4_lo_batch<NTH, NTL, LB, P, false>(lA, wgl + c0 * 4 * P, LB, acch, accl);
+      pw4_lo_batch<NTH, NTL, LB, P, false, AT>(lA, wgl + c0 * 4 * P, LB, acch, accl);
       c0 += LB;
 #pragma unroll
       for (int j = 0; j < LB; ++j)
 #pragma unroll
         for (int t = 0; t < 9; ++t) lA[j][t] = lB[j][t];
     }
-    pw4_lo_batch<NTH, NTL, LB, P, true>(lA, wgl + c0 * 4 * P, CL - c0, acch, accl);
+    pw4_lo_batch<NTH, NTL, LB, P, true, AT>(lA, wgl + c0 * 4 * P, CL - c0, acch, accl);
     // ---- third input (single-output forms only), XB channels per step, the next step in flight ----
     if ((NTH == 0 || NTL == 0) && C2 > 0) {
       const float* wg2 = wgl + CL * 4 * P;
-      float xA[XB][NX2], xB[XB][NX2];
+      typename ACC::r1 xA[XB][NX2], xB[XB][NX2];
       pw4_load_x2<NX2, XB, AT>(rb2, g2, cs2, 0, C2, xA);
       PW4_FENCE();
       const int nf2 = (C2 - 1) / XB;
@@ -311,18 +330,18 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
         pw4_load_x2<NX2, XB, AT>(rb2, g2, cs2, c + XB, C2, xB);
         PW4_FENCE();
 #pragma unroll
-        for (int j = 0; j < XB; ++j) pw4_x2_channel<NTH, NTL, P, NX2>(xA[j], g2, wg2 + (c + j) * 4 * P, acch, accl);
+        for (int j = 0; j < XB; ++j) pw4_x2_channel<NTH, NTL, P, NX2, AT>(xA[j], g2, wg2 + (c + j) * 4 * P, acch, accl);
         pw4_load_x2<NX2, XB, AT>(rb2, g2, cs2, c + 2 * XB, C2, xA);
         PW4_FENCE();
 #pragma unroll
-        for (int j = 0; j < XB; ++j) pw4_x2_channel<NTH, NTL, P, NX2>(xB[j], g2, wg2 + (c + XB + j) * 4 * P, acch, accl);
+        for (int j = 0; j < XB; ++j) pw4_x2_channel<NTH, NTL, P, NX2, AT>(xB[j], g2, wg2 + (c + XB + j) * 4 * P, acch, accl);
         c += 2 * XB;
       }
       if (nf2 & 1) {
         pw4_load_x2<NX2, XB, AT>(rb2, g2, cs2, c + XB, C2, xB);
         PW4_FENCE();
 #pragma unroll
-        for (int j = 0; j < XB; ++j) pw4_x2_channel<NTH, NTL, P, NX2>(xA[j], g2, wg2 + (c + j) * 4 * P, acch, accl);
+        for (int j = 0; j < XB; ++j) pw4_x2_channel<NTH, NTL, P, NX2, AT>(xA[j], g2, wg2 + (c + j) * 4 * P, acch, accl);
         c += XB;
 #pragma unroll
         for (int j = 0; j < XB; ++j)
@@ -331,7 +350,7 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
       }
 #pragma unroll
       for (int j = 0; j < XB; ++j)
-        if (c + j < C2) pw4_x2_channel<NTH, NTL, P, NX2>(xA[j], g2, wg2 + (c + j) * 4 * P, acch, accl);
+        if (c + j < C2) pw4_x2_channel<NTH, NTL, P, NX2, AT>(xA[j], g2, wg2 + (c + j) * 4 * P, acch, accl);
     }
 
     // ---- fourth input (low-only form): 4x4 max-pool of xq, two channels per step ----
@@ -342,7 +361,7 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
       const csn_buf rbq = csn_make_buf_n(reinterpret_cast<const char*>(a->xq) + (int64_t)b * CQ * (int64_t)csq, (unsigned)CQ * csq);
       const unsigned oq = (unsigned)((4 * yc) * (4 * Wl) + 4 * xc) * E;
       const float* wgq = wgl + (CL + C2) * 4 * P;
-      float4 qA[QB][4], qB[QB][4];
+      typename ACC::r4 qA[QB][4], qB[QB][4];
       pw4_load_xq<QB, AT>(rbq, oq, wsq, csq, 0, CQ, qA);
       PW4_FENCE();
       const int nfq = (CQ - 1) / QB;
@@ -351,18 +370,18 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
         pw4_load_xq<QB, AT>(rbq, oq, wsq, csq, c + QB, CQ, qB);
         PW4_FENCE();
 #pragma unroll
-        for (int j = 0; j < QB; ++j) pw4_xq_channel<NTL, P>(qA[j], wgq + (c + j) * 4 * P, accl);
+        for (int j = 0; j < QB; ++j) pw4_xq_channel<NTL, P, AT>(qA[j], wgq + (c + j) * 4 * P, accl);
         pw4_load_xq<QB, AT>(rbq, oq, wsq, csq, c + 2 * QB, CQ, qA);
         PW4_FENCE();
 #pragma unroll
-        for (int j = 0; j < QB; ++j) pw4_xq_channel<NTL, P>(qB[j], wgq + (c + QB + j) * 4 * P, accl);
+        for (int j = 0; j < QB; ++j) pw4_xq_channel<NTL, P, AT>(qB[j], wgq + (c + QB + j) * 4 * P, accl);
         c += 2 * QB;
       }
       if (nfq & 1) {
         pw4_load_xq<QB, AT>(rbq, oq, wsq, csq, c + QB, CQ, qB);
         PW4_FENCE();
 #pragma unroll
-        for (int j = 0; j < QB; ++j) pw4_xq_channel<NTL, P>(qA[j], wgq + (c + j) * 4 * P, accl);
+        for (int j = 0; j < QB; ++j) pw4_xq_channel<NTL, P, AT>(qA[j], wgq + (c + j) * 4 * P, accl);
         c += QB;
 #pragma unroll
         for (int j = 0; j < QB; ++j)
@@ -371,7 +390,7 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
       }
 #pragma unroll
       for (int j = 0; j < QB; ++j)
-        if (c + j < CQ) pw4_xq_channel<NTL, P>(qA[j], wgq + (c + j) * 4 * P, accl);
+        if (c + j < CQ) pw4_xq_channel<NTL, P, AT>(qA[j], wgq + (c + j) * 4 * P, accl);
     }
 
     // ---- epilogue: folded BN + PReLU, the accumulators are the store registers.  Row tiles past the group's list (an
@@ -407,7 +426,11 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
       const int r0 = a->grp[g].r0l, nt = a->grp[g].ntl;
       const csn_buf ob = csn_make_buf_n(reinterpret_cast<char*>(a->yl) + (int64_t)b * a->OL * (int64_t)csl, (unsigned)a->OL * csl);
       csn_cfp ep = csn_const(a->ep_l) + 4 * r0;
+#ifdef CSN_KO_PW4_NOSTORE
+      const unsigned sv = 0x80000000u;
+#else
       const unsigned sv = valid ? ol[4] : 0x80000000u;
+#endif
 #pragma unroll
       for (int t = 0; t < NTL; ++t) {
         if (t < nt) {

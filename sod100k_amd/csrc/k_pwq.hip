@@ -22,20 +22,21 @@
 namespace {
 
 template <typename AT, int CB>
-__device__ __forceinline__ void pwq_load(csn_buf rb, unsigned off, unsigned cs, int c0, int C, float4 (&v)[CB]) {
+__device__ __forceinline__ void pwq_load(csn_buf rb, unsigned off, unsigned cs, int c0, int C, typename csn_bufacc<AT>::r4 (&v)[CB]) {
 #pragma unroll
-  for (int j = 0; j < CB; ++j) v[j] = csn_bufacc<AT>::ld4(rb, off, (unsigned)min(c0 + j, C - 1) * cs);
+  for (int j = 0; j < CB; ++j) v[j] = csn_bufacc<AT>::ldr4(rb, off, (unsigned)min(c0 + j, C - 1) * cs);   // raw: converted in pwq_batch
 }
 
-template <int NT, int P, int CB, bool GUARD>
-__device__ __forceinline__ void pwq_batch(const float4 (&v)[CB], const float* wk, int n, csn_f4 (&acc)[4][NT]) {
+template <int NT, int P, int CB, bool GUARD, typename AT = float>
+__device__ __forceinline__ void pwq_batch(const typename csn_bufacc<AT>::r4 (&raw)[CB], const float* wk, int n, csn_f4 (&acc)[4][NT]) {
   constexpr int NT4 = (NT + 3) & ~3;
 #pragma unroll
   for (int j = 0; j < CB; ++j) {
     if (GUARD && j >= n) break;
     Pw4A<NT4> a;
     pw4_load_a<NT4, P>(wk + j * 4 * P, a);
-    const float q[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+    const float4 v = csn_bufacc<AT>::cv4(raw[j]);
+    const float q[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 16 * NT <= 96 ? 3 : 2) void pwq_kernel(P
                                         (unsigned)C * cs);
       // batch c0 is contracted while batch c0 + CB is in flight (two register sets, batches walked in pairs, the last --
       // possibly partial -- batch ends up in set A)
-      float4 vA[CB], vB[CB];
+      typename csn_bufacc<AT>::r4 vA[CB], vB[CB];
       pwq_load<AT, CB>(rb, off, cs, 0, C, vA);
       PW4_FENCE();
       const int nf = (C - 1) / CB;
@@ -98,21 +99,21 @@ __global__ __launch_bounds__(CSN_BLOCK, 16 * NT <= 96 ? 3 : 2) void pwq_kernel(P
       for (int p = 0; p < (nf >> 1); ++p) {
         pwq_load<AT, CB>(rb, off, cs, c0 + CB, C, vB);
         PW4_FENCE();
-        pwq_batch<NT, P, CB, false>(vA, wg + (krow + c0) * 4 * P, CB, acc);
+        pwq_batch<NT, P, CB, false, AT>(vA, wg + (krow + c0) * 4 * P, CB, acc);
         pwq_load<AT, CB>(rb, off, cs, c0 + 2 * CB, C, vA);
         PW4_FENCE();
-        pwq_batch<NT, P, CB, false>(vB, wg + (krow + c0 + CB) * 4 * P, CB, acc);
+        pwq_batch<NT, P, CB, false, AT>(vB, wg + (krow + c0 + CB) * 4 * P, CB, acc);
         c0 += 2 * CB;
       }
       if (nf & 1) {
         pwq_load<AT, CB>(rb, off, cs, c0 + CB, C, vB);
         PW4_FENCE();
-        pwq_batch<NT, P, CB, false>(vA, wg + (krow + c0) * 4 * P, CB, acc);
+        pwq_batch<NT, P, CB, false, AT>(vA, wg + (krow + c0) * 4 * P, CB, acc);
         c0 += CB;
 #pragma unroll
         for (int j = 0; j < CB; ++j) vA[j] = vB[j];
       }
-      pwq_batch<NT, P, CB, true>(vA, wg + (krow + c0) * 4 * P, C - c0, acc);
+      pwq_batch<NT, P, CB, true, AT>(vA, wg + (krow + c0) * 4 * P, C - c0, acc);
       krow += C;
     }
     // ---- raw stores: rows past the group's tile list are skipped, rows past the last channel fall out of the resource ----

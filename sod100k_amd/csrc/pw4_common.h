@@ -36,23 +36,27 @@ __device__ __forceinline__ void pw4_mfma(const Pw4A<NT4>& a, int t, float x, csn
 #endif
 }
 
+// (the register sets hold the loads RAW -- csn_bufacc<AT>::r1 / r2 -- and the batches convert where they use them: a conversion in
+// front of PW4_FENCE would make every batch wait for its own loads, csn_device.h)
 template <int HB, typename AT = float>
-__device__ __forceinline__ void pw4_load_hi(csn_buf rb, unsigned o0, unsigned o1, unsigned cs, int k0, int C, float2 (&v)[HB][2]) {
+__device__ __forceinline__ void pw4_load_hi(csn_buf rb, unsigned o0, unsigned o1, unsigned cs, int k0, int C,
+                                            typename csn_bufacc<AT>::r2 (&v)[HB][2]) {
 #pragma unroll
   for (int j = 0; j < HB; ++j) {
     const unsigned so = (unsigned)min(k0 + j, C - 1) * cs;
-    v[j][0] = csn_bufacc<AT>::ld2(rb, o0, so);
-    v[j][1] = csn_bufacc<AT>::ld2(rb, o1, so);
+    v[j][0] = csn_bufacc<AT>::ldr2(rb, o0, so);
+    v[j][1] = csn_bufacc<AT>::ldr2(rb, o1, so);
   }
 }
 
 template <int LB, typename AT = float>
-__device__ __forceinline__ void pw4_load_lo(csn_buf rb, const unsigned (&o)[9], unsigned cs, int k0, int C, float (&v)[LB][9]) {
+__device__ __forceinline__ void pw4_load_lo(csn_buf rb, const unsigned (&o)[9], unsigned cs, int k0, int C,
+                                            typename csn_bufacc<AT>::r1 (&v)[LB][9]) {
 #pragma unroll
   for (int j = 0; j < LB; ++j) {
     const unsigned so = (unsigned)min(k0 + j, C - 1) * cs;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) v[j][t] = csn_bufacc<AT>::ld1(rb, o[t], so);
+    for (int t = 0; t < 9; ++t) v[j][t] = csn_bufacc<AT>::ldr1(rb, o[t], so);
   }
 }
 
@@ -74,16 +78,17 @@ __device__ __forceinline__ void pw4_up2_quad(const float (&v)[9], float (&q)[4])
 }
 
 // contract `n` (<= HB, exact when !GUARD) high-branch channels: quad pixels -> high rows, their 2x2 maximum -> low rows
-template <int NTH, int NTL, int HB, int P, bool GUARD>
-__device__ __forceinline__ void pw4_hi_batch(const float2 (&v)[HB][2], const float* wk, int n, csn_f4 (&acch)[4][NTH > 0 ? NTH : 1],
-                                             csn_f4 (&accl)[NTL > 0 ? NTL : 1]) {
+template <int NTH, int NTL, int HB, int P, bool GUARD, typename AT = float>
+__device__ __forceinline__ void pw4_hi_batch(const typename csn_bufacc<AT>::r2 (&v)[HB][2], const float* wk, int n,
+                                             csn_f4 (&acch)[4][NTH > 0 ? NTH : 1], csn_f4 (&accl)[NTL > 0 ? NTL : 1]) {
   constexpr int NT4 = (NTH + NTL + 3) & ~3;
 #pragma unroll
   for (int j = 0; j < HB; ++j) {
     if (GUARD && j >= n) break;
     Pw4A<NT4> a;
     pw4_load_a<NT4, P>(wk + j * 4 * P, a);
-    const float q[4] = {v[j][0].x, v[j][0].y, v[j][1].x, v[j][1].y};
+    const float2 r0 = csn_bufacc<AT>::cv2(v[j][0]), r1 = csn_bufacc<AT>::cv2(v[j][1]);
+    const float q[4] = {r0.x, r0.y, r1.x, r1.y};
 #pragma unroll
     for (int t = 0; t < NTH; ++t)
 #pragma unroll
@@ -101,23 +106,25 @@ __device__ __forceinline__ void pw4_hi_batch(const float2 (&v)[HB][2], const flo
 // column and 0.25 on the row above (dy = 0) or below (dy = 1), the column left (dx = 0) or right (dx = 1):
 // upsample_bilinear2d, align_corners=False, scale 2 -- at the borders the clamped neighbour IS the centre, which gives
 // PyTorch's clamped source index (area_pixel_compute_source_index) to within one rounding.
-template <int NTH, int NTL, int LB, int P, bool GUARD>
-__device__ __forceinline__ void pw4_lo_batch(const float (&v)[LB][9], const float* wk, int n, csn_f4 (&acch)[4][NTH > 0 ? NTH : 1],
-                                             csn_f4 (&accl)[NTL > 0 ? NTL : 1]) {
+template <int NTH, int NTL, int LB, int P, bool GUARD, typename AT = float>
+__device__ __forceinline__ void pw4_lo_batch(const typename csn_bufacc<AT>::r1 (&v)[LB][9], const float* wk, int n,
+                                             csn_f4 (&acch)[4][NTH > 0 ? NTH : 1], csn_f4 (&accl)[NTL > 0 ? NTL : 1]) {
   constexpr int NT4 = (NTH + NTL + 3) & ~3;
 #pragma unroll
   for (int j = 0; j < LB; ++j) {
     if (GUARD && j >= n) break;
     Pw4A<NT4> a;
     pw4_load_a<NT4, P>(wk + j * 4 * P, a);
-    float q[4];
-    pw4_up2_quad(v[j], q);
+    float f[9], q[4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) f[t] = csn_bufacc<AT>::cv1(v[j][t]);
+    if (NTH > 0) pw4_up2_quad(f, q);
 #pragma unroll
     for (int t = 0; t < NTH; ++t)
 #pragma unroll
       for (int s = 0; s < 4; ++s) pw4_mfma<NT4>(a, t, q[s], acch[s][t]);
 #pragma unroll
-    for (int t = 0; t < NTL; ++t) pw4_mfma<NT4>(a, NTH + t, v[j][4], accl[t]);
+    for (int t = 0; t < NTL; ++t) pw4_mfma<NT4>(a, NTH + t, f[4], accl[t]);
   }
 }
 
