@@ -193,9 +193,10 @@ struct csn_plan {
   bool pw4 = true;        // CSN_OPT_PW4: two-branch 1x1 units on pw4_kernel (k_pw4.hip)
   bool hz = true;         // CSN_HZ=0: the high output of the three-branch 1x1 units stays on pw4_kernel (A/B; k_head.hip)
   // its geometry, [0] for a unit with several outputs (CSFHead.fuse), [1] for a single-output unit (fuse1x1); the environment
-  // variables take "a" or "a,b" (experiments): row tiles per M group (0: chosen by plan_hz; CSN_HZ_NT), rows of the lowest input per
+  // variables take "a" or "a/b" (experiments): row tiles per M group (0: chosen by plan_hz; CSN_HZ_NT), rows of the lowest input per
   // band (CSN_HZ_RB), x_0 channels per load batch (CSN_HZ_HB), waves per block (CSN_HZ_NW)
-  int hz_nt[2] = {0, 0}, hz_rb[2] = {2, 2}, hz_hb[2] = {2, 2}, hz_nw[2] = {4, 4};
+  // (defaults from the sweep of profiles/r6_notes.md: fuse 4-row bands on 4 waves; fuse1x1 groups of 4 tiles, 4-row bands, 8 waves)
+  int hz_nt[2] = {0, 4}, hz_rb[2] = {4, 4}, hz_hb[2] = {2, 2}, hz_nw[2] = {4, 8};
   int pw4_grid = 2048;    // its block cap (CSN_PW4_GRID, experiments)
   int pw4_twl = 6;        // log2 of its widest tile in low pixels: whole rows of up to 64 (CSN_PW4_TWL; 4 = 16 x 4 tiles: 1 % slower)
   bool pw4_flat = true;       // CSN_PW4_FLAT=0: row-segment tiles everywhere (round 3; A/B)
@@ -724,8 +725,9 @@ void plan_hz(Builder& bl, UnitPlan& u, const int* ci_off, const int* co_off, int
   const int tiles = (d.cout[0] + 3) / 4;
   // row tiles per group: as few groups as the register budget allows (<= 5 tiles = 80 accumulators); a group re-reads x_0
   const int ki = d.n_out == 1 ? 1 : 0;
-  int nth = bl.P.hz_nt[ki] > 0 ? bl.P.hz_nt[ki] : std::min(5, tiles);
-  if (bl.P.hz_nt[ki] == 0 && tiles > 5) nth = (tiles + ((tiles + 4) / 5) - 1) / ((tiles + 4) / 5);   // even groups
+  int nth = std::min(bl.P.hz_nt[ki], tiles);
+  if (nth <= 0 || (tiles + nth - 1) / nth > HZ_MAX_GROUPS)   // chosen here: <= 5 tiles per group, groups of equal size
+    nth = tiles <= 5 ? tiles : (tiles + ((tiles + 4) / 5) - 1) / ((tiles + 4) / 5);
   const int ng = (tiles + nth - 1) / nth;
   if (ng > HZ_MAX_GROUPS || !csn_hz_supported(nth)) return;
   HzArgs a;
@@ -1806,7 +1808,7 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
       const char* e = std::getenv(name);
       if (!e) return;
       const int a0 = std::atoi(e);
-      const char* c = std::strchr(e, ',');
+      const char* c = std::strchr(e, '/');
       const int a1 = c ? std::atoi(c + 1) : a0;
       if (a0 >= lo && a0 <= hi) dst[0] = a0;
       if (a1 >= lo && a1 <= hi) dst[1] = a1;

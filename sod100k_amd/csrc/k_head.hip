@@ -24,7 +24,9 @@
 #include "pw4_common.h"
 #include "dw_core.h"
 
+#ifndef HZ_ZB
 #define HZ_ZB 8    // x_1 / x_2 channels per load batch of phase A (one dword each); two batches in flight
+#endif
 
 // knock-out builds (tools/README.md; results wrong, timings valid): HZ_KO_NOA = no phase A, HZ_KO_NOMAIN = no contraction over x_0,
 // HZ_KO_NOEPI = no interpolation in the epilogue
@@ -135,6 +137,8 @@ __device__ __forceinline__ void hz_zrun(const HzZTask& z, const HzZLane& l, cons
   // ... row (the image's last row can also be the bottom halo row of the band in front of the last: no row behind it in the plane)
   // (likewise the image's first row can be the TOP halo row of the second band when a band is one row: nothing in front of it)
   const int dr = (l.row == 0 && z.base < 0) ? -z.pitch : ((l.row == z.Hs - 1 && l.row - z.base < z.rows - 1) ? z.pitch : 0);
+  // (every value goes to its own column and to the frame column -- the same address when the lane has none: no branch; the frame
+  // rows are rare and block-uniform per tile row)
 #pragma unroll
   for (int t = 0; t < NTH; ++t)
 #pragma unroll
@@ -143,10 +147,10 @@ __device__ __forceinline__ void hz_zrun(const HzZTask& z, const HzZLane& l, cons
         float* e = d + (4 * t + i) * z.plane;
         const float v = acc[t][i];
         e[0] = v;
-        if (dc) e[dc] = v;
+        e[dc] = v;
         if (dr) {
           e[dr] = v;
-          if (dc) e[dr + dc] = v;
+          e[dr + dc] = v;
         }
       }
     }

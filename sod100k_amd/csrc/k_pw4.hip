@@ -36,6 +36,10 @@
 #ifndef PW4_HB
 #define PW4_HB 2    // high-branch channels per load batch (2 x 64-bit loads each; measured: 2 beats 4 and 8, profiles/r3_notes.md)
 #endif
+#ifndef PW4_HB_BF
+#define PW4_HB_BF 4  // ... with bfloat16 tensors: a channel is two dword loads, so four channels put the float form's bytes in flight
+                     // (round 6, same lease: bf16 train step 35.10 -> 34.54 ms)
+#endif
 #ifndef PW4_LB
 #define PW4_LB 2    // low-branch channels per load batch (9 dword loads each)
 #endif
@@ -177,7 +181,8 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
   constexpr unsigned E = (unsigned)sizeof(AT);
   // load batches: the low-only form contracts ~2 MFMAs per loaded value and has few accumulators -- its batches are deep
   // (every batch is one exposed memory round trip per item)
-  constexpr int HB = NTH == 0 ? 8 : PW4_HB, LB = NTH == 0 ? 8 : PW4_LB;
+  // (bfloat16: the deeper high batches for the two-output forms only -- the high-only forms, which also stage the third input, spill with them)
+  constexpr int HB = NTH == 0 ? 8 : ((E == 2 && NTL > 0) ? PW4_HB_BF : PW4_HB), LB = NTH == 0 ? 8 : PW4_LB;
   constexpr int NT4 = (NTH + NTL + 3) & ~3, P = PW4_PITCH(NT4);
   CSN_DYN_SMEM(float, lds);
   const CSN_CONST_AS Pw4Args* a = CSN_KERNARG(Pw4Args, a_byval);

@@ -131,6 +131,54 @@ def check_ilb_vs_unit_kernels(lib, device, manifest, B, H, W, seed=3, min_blocks
     return nfused, worst, err_o
 
 
+def check_hz_vs_pw4(lib, device, manifest, B, H, W, seed=7, env=None, fuse_cls=True):
+    """hz_kernel (k_head.hip, round 6: the high output of CSFHead.fuse / fuse1x1 with the low -> high terms convolved at the LOW
+    resolution, interpolated per output channel from LDS -- the reference's own order, csnet.py:702-707) against pw4_kernel's
+    high-only form (CSN_HZ=0: interpolated INPUTS contracted at the output resolution): the outputs of both units to UNIT_TOL
+    relative, the logits of both routes to the oracle.  `env`: geometry switches of the kernel (band rows, tiles per group,
+    waves per block).  Returns (launches on hz_kernel, worst unit deviation, logit deviation from the oracle)."""
+    x = torch.from_numpy(I.randn_batch(seed, B, H, W))
+    saved = {k: os.environ.get(k) for k in ["CSN_HZ"] + list(env or {})}
+    try:
+        os.environ.update(env or {})
+        out = {}
+        for hz in ("1", "0"):
+            os.environ["CSN_HZ"] = hz
+            m, sd = make_model(lib, manifest, device)
+            xd = x.to(device)
+            eng = m.engine_for(xd)
+            if not fuse_cls:
+                eng.set_option(N.OPT_FUSE_CLS, 0)      # fuse1x1's 79 channels are stored (rows-stored form of the kernel)
+            y = m(xd).cpu()
+            eng.profile(xd, iters=1)
+            census = {k: v[1] for k, v in eng.kernel_stats().items()}
+            out[hz] = (m, eng, y, census)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    m1, e1, y1, c1 = out["1"]
+    m0, e0, y0, c0 = out["0"]
+    nhz = c1.get("hz_kernel", 0)
+    assert nhz == 2 and c0.get("hz_kernel", 0) == 0 and c0["pw4_kernel"] == c1["pw4_kernel"] + 2, (c1, c0)
+    units, acts, unames = m1.describe(m1._arena.offsets)
+    worst = 0.0
+    for u, name in zip(units, unames):
+        if name not in ("oct_fuse.fuse", "oct_fuse.fuse1x1") or (name == "oct_fuse.fuse1x1" and fuse_cls):
+            continue
+        a = u.out_act[0]
+        g1, g0 = e1.activation(a).cpu(), e0.activation(a).cpu()
+        err = float((g1 - g0).abs().max()) / max(1.0, float(g0.abs().max()))
+        assert err <= UNIT_TOL, f"{name}: hz_kernel vs pw4_kernel {err:.3e}"
+        worst = max(worst, err)
+    ref = oracle_forward(manifest, sd, x)
+    err_o = float((y1 - ref).abs().max())
+    assert err_o <= TOL and float((y0 - ref).abs().max()) <= TOL, err_o
+    return nhz, worst, err_o
+
+
 def check_lane_exchange_vs_loaded_halos(lib, device, manifest, B, H, W, seed=5):
     """Eval forward with the depthwise kernels' halo columns taken from the neighbouring lanes (CSN_DW_XL=1, the default: power-of-two
     lane groups per row, DPP moves) against the round-4 geometry with loaded halo columns (CSN_DW_XL=0; both read at plan creation).

@@ -201,3 +201,16 @@ def test_gpu_lane_exchange_equals_loaded_halos_train(hip, x2_manifest, act_dtype
     rel = float((f1.double() - f0.double()).norm() / f0.double().norm())
     print(f"{act_dtype} {size}: worst stored input gradient {worst:.2e}, flat gradient {rel:.2e}")
     assert worst < (2e-2 if act_dtype == "bf16" else 5e-6) and rel < (2e-2 if act_dtype == "bf16" else 5e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,env,fuse_cls", [((2, 224, 224), None, True), ((3, 224, 224), None, False),
+                                                ((2, 96, 160), {"CSN_HZ_RB": "3", "CSN_HZ_NT": "3/5", "CSN_HZ_HB": "4"}, False),
+                                                ((3, 16, 16), {"CSN_HZ_RB": "1", "CSN_HZ_NW": "16"}, True)])
+def test_gpu_hz_matches_pw4_and_oracle(hip, x2_manifest, shape, env, fuse_cls):
+    """Round 6: hz_kernel (k_head.hip; the high output of CSFHead.fuse / fuse1x1 with the low -> high terms as low-resolution products
+    through LDS, csnet.py:702-707) on the device against pw4_kernel's high-only form (CSN_HZ=0) and the oracle; the last two cases
+    walk other band heights / M groups / block sizes than the product's."""
+    lib, dev = hip
+    n, worst, err = P.check_hz_vs_pw4(lib, dev, x2_manifest, *shape, env=env, fuse_cls=fuse_cls)
+    print(f"{shape} {env}: {n} launches on hz_kernel, worst unit deviation {worst:.2e}, logits vs oracle {err:.2e}")
