@@ -129,6 +129,28 @@ def train_algorithmic_bytes(model):
     return 4 * (3 * tin + 7 * tout)
 
 
+def measured_copy_peak(dev, gib=1.0, iters=10):
+    """Device-to-device copy bandwidth on this board, GB/s of (read + written) bytes: the achievable HBM figure next to the spec."""
+    try:
+        n = int(gib * 2 ** 30) // 4
+        a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+        b = torch.empty_like(a)
+        for _ in range(3):
+            b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / iters
+        del a, b
+        torch.cuda.empty_cache()
+        return round(2 * n * 4 / (ms * 1e-3) / 1e9, 1)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -281,8 +303,28 @@ def main():
                 traffic = None
         total_alg = sum(nbytes)
         total_ms = sum(v["ms"] for v in agg.values() if "ms" in v)
+        # bytes a fused launch group really moves where that is less than its units' algorithmic sum: a whole ILBlock
+        # on ilb_kernel = three consecutive units, block input + block output only: (in1 + out1) + (in3 + out3) - (in2 + out2)
+        moved = {}
+        ilb_units = [i for i, n in enumerate(names) if n == "ilb_kernel"]
+        for i in ilb_units[::3]:
+            if i + 2 < len(nbytes) and names[i + 1] == names[i + 2] == "ilb_kernel":
+                moved["ilb_kernel"] = moved.get("ilb_kernel", 0) + nbytes[i] + nbytes[i + 2] - nbytes[i + 1]
+        # counter bytes of the WHOLE forward (every kernel family of the committed counter pass) next to the algorithmic figure
+        counter_total = None
+        try:
+            if os.path.exists(pmc):
+                pj_all = json.load(open(pmc))
+                counter_total = int(sum(v.get("hbm_bytes_per_forward", 0) for k, v in pj_all.items() if isinstance(v, dict) and not k.startswith("_")))
+        except Exception:
+            counter_total = None
+        peak_meas = measured_copy_peak(dev)
         roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_src,
+                        frac=round(achieved / HBM_PEAK_GBS, 4),
+                        # the on-box figure next to the 8 TB/s spec -- a device-to-device copy of 1 GiB in this process
+                        # (read + written bytes / time); what a pure streaming kernel reaches on this board
+                        peak_measured=peak_meas, frac_of_measured=(round(achieved / peak_meas, 4) if peak_meas else None),
+                        traffic=traffic, traffic_source=traffic_src,
                         # the counter file was collected on exactly these kernel sources (sha256 over csrc/): else it is a stale number
                         traffic_from_this_tree=bool(traffic_tree_ok), kernel_sources_sha16=N_SRC_SHA,
                         bytes_per_launch=int(bytes_per_launch), us_per_launch=round(us_per_launch, 2),
@@ -293,14 +335,19 @@ def main():
                         frac_raw=round(bytes_per_launch / ((us_per_launch + bracket_us) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                         whole_step=dict(algorithmic_bytes=int(total_alg), events_ms=round(total_ms, 3),
                                         achieved=round(total_alg / (total_ms * 1e-3) / 1e9, 1),
-                                        frac=round(total_alg / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
+                                        frac=round(total_alg / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                        # the bytes the counters saw for one forward (profiles/pmc_latest.json, all families) / the same time
+                                        counter_bytes=counter_total,
+                                        counter_frac=(round(counter_total / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if counter_total else None),
+                                        counter_from_this_tree=bool(traffic_tree_ok)),
                         per_kernel={k: dict(ms=round(v["ms"], 3), launches=v["launches"],
                                             us_per_launch=round(v["ms"] * 1e3 / v["launches"], 2),
                                             alg_GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None,
                                             # the fused depthwise pair implements TWO units per launch: its algorithmic
                                             # bytes count both units' (in + out), the kernel physically moves half of that
                                             **({"moved_GBps": round(0.5 * v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
-                                               if k in ("dw3x3x2_bn_prelu_kernel", "dw3x3x2_fast_kernel") and v["bytes"] else {}))
+                                               if k in ("dw3x3x2_bn_prelu_kernel", "dw3x3x2_fast_kernel") and v["bytes"] else {}),
+                                            **({"moved_GBps": round(moved[k] / (v["ms"] * 1e-3) / 1e9, 1)} if k in moved else {}))
                                     for k, v in agg.items() if "ms" in v})
 
     sub_b = eng_sub(eng, B)

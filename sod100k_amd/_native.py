@@ -162,6 +162,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if hipcc is None:
         raise RuntimeError("hipcc not found: cannot build libcsnet_hip.so")
     os.makedirs(OBJ_DIR, exist_ok=True)
+    # one builder at a time (ranks of a torchrun job, pytest workers): the objects, their keys and the link step share paths
+    import fcntl
+    with open(os.path.join(OBJ_DIR, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and built_sources_sha16() == want:     # another process built it while this one waited
+                return LIB_PATH
+            return _build_locked(hipcc, want, force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(hipcc: str, want: str, force: bool, verbose: bool) -> str:
     hdr = b""
     for f in sorted(os.listdir(CSRC)):
         if f.endswith((".h", ".inl")):
@@ -176,31 +189,41 @@ def build(force: bool = False, verbose: bool = False) -> str:
         keyf = obj + ".key"
         if not force and os.path.exists(obj) and os.path.exists(keyf) and open(keyf).read() == key:
             return obj
+        if os.path.exists(keyf):
+            os.remove(keyf)                       # the key never describes an object that is being rewritten
         cmd = [hipcc, *HIPCC_FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True, cwd=CSRC)
-        with open(keyf, "w") as fh:
+        with open(keyf + ".tmp", "w") as fh:
             fh.write(key)
+        os.replace(keyf + ".tmp", keyf)
         return obj
 
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    # the build id: a host-only translation unit generated here
-    idc = os.path.join(OBJ_DIR, "csn_build_id.cpp")
-    with open(idc, "w") as fh:
-        fh.write('// generated by sod100k_amd/_native.py:build()\n'
-                 f'extern "C" const char* csn_build_sources_sha16(void) {{ return "CSN_BUILD_SOURCES_SHA16={want}" + 24; }}\n')
-    ido = os.path.join(OBJ_DIR, "csn_build_id.o")
-    subprocess.run([hipcc, "-O1", "-fPIC", "-c", idc, "-o", ido], check=True, cwd=CSRC)
-    tmp = LIB_PATH + ".tmp"
+    ido = write_build_id_object(hipcc, want, OBJ_DIR)
+    tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", tmp] + objs + [ido]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)
     os.replace(tmp, LIB_PATH)
     return LIB_PATH
+
+
+def write_build_id_object(hipcc: str, want: str, out_dir: str) -> str:
+    """The build id (``csn_build_sources_sha16``, include/csnet_hip.h) as its own host-only translation unit, generated here:
+    compiled as plain C++ (no device pass, no default offload arch).  ``csrc/dev_build.sh`` links the same unit."""
+    idc = os.path.join(out_dir, "csn_build_id.cpp")
+    with open(idc, "w") as fh:
+        fh.write('// generated by sod100k_amd/_native.py\n'
+                 f'static const char csn_build_id[] = "CSN_BUILD_SOURCES_SHA16={want}";\n'
+                 'extern "C" const char* csn_build_sources_sha16(void) { return &csn_build_id[24]; }\n')
+    ido = os.path.join(out_dir, "csn_build_id.o")
+    subprocess.run([hipcc, "-x", "c++", "-O1", "-fPIC", "-c", idc, "-o", ido], check=True)
+    return ido
 
 
 def bind(lib: C.CDLL) -> C.CDLL:

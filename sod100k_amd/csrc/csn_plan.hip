@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <algorithm>
 #include <new>
 #include <string>
@@ -1309,6 +1310,19 @@ int lanes_join(const Ctx& c, int n) {
   return CSN_OK;
 }
 
+// The fused depthwise pair runs on dw3x3x2_fast_kernel when EVERY branch qualifies (folded records, width a multiple of four, one
+// tile of lanes per row: csn_launch_dw2's own predicate) -- decided once per pair, for the launch geometry, the profile tag and
+// csn_unit_kernel_name alike (a mixed pair ran the round-1 kernel under the fast kernel's name and lane geometry)
+bool dw_pair_fast(const csn_plan& P, const UnitPlan& first) {
+  if (!P.dw_fast) return false;
+  for (int k = 0; k < first.d.n_in; ++k) {
+    if (first.d.cout[k] == 0) continue;
+    const int W = P.W >> P.acts[first.d.in_act[k]].lvl;
+    if (first.dw2rec[k] < 0 || (W % 4) != 0 || W > 256) return false;
+  }
+  return true;
+}
+
 int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
   const csn_plan& P = c.P;
   const csn_unit_desc& d = u.d;
@@ -1320,6 +1334,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
       a.nbr = 0; a.B = S; a.a16 = c.a16 ? 1 : 0; a.variant = (P.dw_xl && P.train) ? 2 : 0;
       if (fused && c.a16) return CSN_E_UNSUPPORTED;   // the fused pair is an eval-mode (float) kernel
       int blk = 0;
+      const bool pair_fast = fused && !c.raw && dw_pair_fast(P, u);
       for (int k = 0; k < d.n_in; ++k) {
         if (d.cout[k] == 0) continue;
         DwBranch& br = a.br[a.nbr++];
@@ -1343,7 +1358,7 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
         br.C = d.cout[k]; br.H = P.H >> act.lvl; br.W = P.W >> act.lvl;
         const int cols = (br.W + 3) / 4;
         // (the fused pair keeps whole rows of its intermediate in LDS; on the fast kernel a row of lanes is a power-of-two group)
-        const bool fastk = fused && P.dw_fast && !c.raw && u.dw2rec[k] >= 0 && (br.W % 4) == 0;
+        const bool fastk = pair_fast;
         br.LX = fused ? (cols < 64 ? ((fastk && P.dw_xl) ? dw_lanes_x(cols, true) : cols) : 64) : dw_lanes_x(cols, P.dw_xl && P.train);
         br.NY = CSN_BLOCK / br.LX;
         br.tiles_x = (cols + br.LX - 1) / br.LX;
@@ -1773,6 +1788,16 @@ static bool lanes_ready(csn_plan* P) {
 
 #include "csn_backward.inl"   // backward planning + sequencing (shares the plan's private types)
 
+#ifndef CSN_CPU_EMU
+// device buffers of plans destroyed while a stream capture was in progress (csn_plan_destroy)
+static std::mutex g_pending_mu;
+static std::vector<void*> g_pending_free;
+static void drain_pending_frees_locked() {
+  for (void* p : g_pending_free) (void)hipFree(p);
+  g_pending_free.clear();
+}
+#endif
+
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" {
 
@@ -1798,6 +1823,15 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   if (H <= 0 || W <= 0 || (H % 16) != 0 || (W % 16) != 0) return CSN_E_INVALID;
   csn_plan* P = new (std::nothrow) csn_plan();
   if (!P) return CSN_E_NOMEM;
+#ifndef CSN_CPU_EMU
+  {   // buffers of plans that were destroyed inside a stream capture
+    hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(nullptr, &cst) != hipSuccess || cst != hipStreamCaptureStatusNone;
+    if (capturing) (void)hipGetLastError();
+    std::lock_guard<std::mutex> g(g_pending_mu);
+    if (!capturing) drain_pending_frees_locked();
+  }
+#endif
   P->B = B; P->H = H; P->W = W;
   P->S = (sub_batch <= 0 || sub_batch > B) ? B : sub_batch;
   if (const char* v = std::getenv("CSN_PW4_GRID")) { if (std::atoi(v) >= 8) P->pw4_grid = std::atoi(v); }
@@ -2011,7 +2045,14 @@ void csn_plan_destroy(csn_plan* P) {
   hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
   const bool capturing = hipStreamIsCapturing(nullptr, &cst) != hipSuccess || cst != hipStreamCaptureStatusNone;
   if (capturing) (void)hipGetLastError();   // (the legacy stream cannot be queried during a global-mode capture: that IS the answer)
-  if (!capturing) (void)hipDeviceSynchronize();
+  if (!capturing) {
+    (void)hipDeviceSynchronize();
+  } else {
+    // the plan's own streams are not the capturing one -- work enqueued on them BEFORE the capture began may still run
+    for (int k = 0; k < 2; ++k) if (P->lane[k]) (void)hipStreamSynchronize(P->lane[k]);
+    if (P->cap_stream) (void)hipStreamSynchronize(P->cap_stream);
+    (void)hipGetLastError();
+  }
   if (cur != P->device) (void)hipSetDevice(cur);
 #endif
   for (hipEvent_t ev : P->ev) (void)hipEventDestroy(ev);
@@ -2020,9 +2061,18 @@ void csn_plan_destroy(csn_plan* P) {
   if (P->cap_stream) (void)hipStreamDestroy(P->cap_stream);
   for (int k = 0; k < 2; ++k) if (P->lane[k]) (void)hipStreamDestroy(P->lane[k]);
   for (int k = 0; k < 6; ++k) if (P->lane_ev[k]) (void)hipEventDestroy(P->lane_ev[k]);
-#endif
+  // hipFree is not legal during a global-mode capture (it would fail or invalidate the capture): the buffers wait on a list that
+  // the next call outside a capture drains (csn_plan_create / csn_plan_destroy)
+  {
+    std::lock_guard<std::mutex> g(g_pending_mu);
+    if (P->packed) g_pending_free.push_back(P->packed);
+    if (P->jobs_dev) g_pending_free.push_back(P->jobs_dev);
+    if (!capturing) drain_pending_frees_locked();
+  }
+#else
   if (P->packed) (void)hipFree(P->packed);
   if (P->jobs_dev) (void)hipFree(P->jobs_dev);
+#endif
   delete P;
 }
 
@@ -2346,10 +2396,7 @@ const char* csn_unit_kernel_name(const csn_plan* P, int32_t u) {
   if (P->fuse_dw && P->units[u].d.kind == CSN_UNIT_DW) {
     if (P->units[u].fuse_next || (u > 0 && P->units[u - 1].fuse_next)) {
       const UnitPlan& first = P->units[u].fuse_next ? P->units[u] : P->units[u - 1];
-      bool fast = P->dw_fast;   // (run_unit: every branch carries the folded records and its width is a multiple of four)
-      for (int k = 0; k < first.d.n_in; ++k)
-        if (first.d.cout[k] > 0 && (first.dw2rec[k] < 0 || ((P->W >> P->acts[first.d.in_act[k]].lvl) % 4) != 0)) fast = false;
-      return fast ? "dw3x3x2_fast_kernel" : "dw3x3x2_bn_prelu_kernel";
+      return dw_pair_fast(*P, first) ? "dw3x3x2_fast_kernel" : "dw3x3x2_bn_prelu_kernel";
     }
   }
   if (P->tiled3 && P->units[u].c3) {

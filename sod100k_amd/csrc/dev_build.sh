@@ -6,9 +6,11 @@ HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="${OUT:-/tmp/csn_build}"
 mkdir -p "$OUT"
 cd "$OUT"
+# the build id the loader checks (csn_build_sources_sha16, include/csnet_hip.h): the unit sod100k_amd/_native.py generates
+python3 -c "import sys; sys.path.insert(0, '$HERE/../..'); from sod100k_amd import _native as N; N.write_build_id_object(N.hipcc_path(), N.sources_sha16(), '$OUT')"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-result \
   -Rpass-analysis=kernel-resource-usage -save-temps -I"$HERE" \
-  -o "$HERE/libcsnet_hip.so" "$HERE/csn_plan.hip" "$HERE/k_misc.hip" "$HERE/k_goct_pw.hip" "$HERE/k_ms.hip" "$HERE/k_train.hip" "$HERE/k_wgrad.hip" "$HERE/k_goct_c3.hip" "$HERE/k_csf.hip" "$HERE/k_wgrad_c3.hip" "$HERE/k_wgrad_bf.hip" "$HERE/k_pw4.hip" "$HERE/k_c3q.hip" "$HERE/k_pwq.hip" "$HERE/k_ilb.hip" "$HERE/k_head.hip" \
+  -o "$HERE/libcsnet_hip.so" "$HERE/csn_plan.hip" "$HERE/k_misc.hip" "$HERE/k_goct_pw.hip" "$HERE/k_ms.hip" "$HERE/k_train.hip" "$HERE/k_wgrad.hip" "$HERE/k_goct_c3.hip" "$HERE/k_csf.hip" "$HERE/k_wgrad_c3.hip" "$HERE/k_wgrad_bf.hip" "$HERE/k_pw4.hip" "$HERE/k_c3q.hip" "$HERE/k_pwq.hip" "$HERE/k_ilb.hip" "$HERE/k_head.hip" "$OUT/csn_build_id.o" \
   > "$OUT/build.log" 2>&1 || { cat "$OUT/build.log" | grep -E "error" -A3 | head -40; exit 1; }
 python3 - "$OUT/build.log" <<'PY'
 import re, sys

@@ -533,10 +533,13 @@ int csn_launch_ilb(const IlbArgs& a, void* stream) {
   const size_t lds = (size_t)a.lds_floats * sizeof(float);
   if (lds > 160 * 1024) return -1;
 #ifndef CSN_CPU_EMU
-  if (lds > 64 * 1024) {
-    const hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(a.k3 ? e->fn3 : e->fn),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (er != hipSuccess) return (int)er;
+  if (lds > 64 * 1024) {   // once per device and function (it was issued on every launch -- host time on a latency chain)
+    static CsnPerDeviceOnce once[sizeof(g_ilb_table) / sizeof(g_ilb_table[0])][2];
+    const int st = once[e - g_ilb_table][a.k3 ? 1 : 0].run([&]() {
+      return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(a.k3 ? e->fn3 : e->fn),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (st != 0) return st;
   }
 #endif
   const int ipx = (a.B + 7) >> 3;

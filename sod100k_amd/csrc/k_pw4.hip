@@ -498,10 +498,12 @@ int csn_launch_pw4(const Pw4Args& a, int raw, void* stream) {
   const dim3 grid((nblk + 7) & ~7);
   const size_t lds = (size_t)a.ngroups * a.gimg_floats * sizeof(float);
 #ifndef CSN_CPU_EMU
-  if (lds > 64 * 1024) {
-    const hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(e->fn[mode]),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (er != hipSuccess) return (int)er;
+  if (lds > 64 * 1024) {   // once per device and function
+    static CsnPerDeviceOnce once[sizeof(g_pw4_table) / sizeof(g_pw4_table[0])][4];
+    const int st = once[e - g_pw4_table][mode].run([&]() {
+      return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(e->fn[mode]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (st != 0) return st;
   }
 #endif
   CSN_LAUNCH(e->fn[mode], grid, dim3(CSN_BLOCK), lds, stream, a);

@@ -594,6 +594,11 @@ class _CSNetTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, x, *params):
+        if x.requires_grad:
+            # csn_backward (include/csnet_hip.h) has no input-gradient output: the first unit's dx is never formed (none of the
+            # reference's callers asks for it: train.py:203-216 feeds plain image batches).  Refuse rather than hand back None.
+            raise RuntimeError("CSNet (HIP): gradients with respect to the input are not provided by csn_backward; "
+                               "pass the image batch with requires_grad=False")
         y, pen = model._train_forward_raw(x, with_backward=True)
         ctx.model, ctx.x = model, x
         # backward reads z / activations / BN statistics of THIS forward from the plan's workspace: remember which
