@@ -199,6 +199,7 @@ struct PwArgs {
 // load registers (see k_pw4.hip)
 // ---------------------------------------------------------------------------------------------
 #define PW4_MAX_GROUPS 4
+#define PWQ_MAX_GROUPS 8   // pwq_kernel / pwq16_kernel: input gradients of the un-pruned net's 80 .. 160-channel branches (round 6)
 #define PW4_FLAT_TWL 7     // Pw4Args / C3qArgs::twl >= 7: flat tiles of 64 consecutive (low) pixels / quads, tiles_y = 1
 #define PW4_PITCH(NT4) (((NT4) % 16) == 0 ? (NT4) + 4 : (NT4))   // floats per (channel, row-in-tile) of the weight image
 struct Pw4Group { int32_t r0h, nth, r0l, ntl; };   // M group: first high / low output channel (multiples of 4) and row tiles (of 4 channels)
@@ -304,7 +305,7 @@ struct PwqArgs {
   int32_t ngroups, gimg_floats, nt, max_grid;
   int32_t a16;         // tensors are bfloat16
   int32_t mfma16;      // ... on pwq16_kernel (v_mfma_f32_4x4x4_16B_bf16, weights of the pass rounded to bfloat16)
-  int32_t grp_r0[PW4_MAX_GROUPS], grp_nt[PW4_MAX_GROUPS];
+  int32_t grp_r0[PWQ_MAX_GROUPS], grp_nt[PWQ_MAX_GROUPS];
 };
 int csn_pwq_max_tiles(void);
 int csn_launch_pwq(const PwqArgs& a, void* stream);

@@ -97,7 +97,7 @@ struct PwLaunchPlan {
   int64_t c3q_wimg = -1, c3q_ep = -1;
   // pwq_kernel's plan (k_pwq.hip): one pass of own-resolution slices, raw output (input-gradient launches); 0: not eligible
   int pwq = 0, pwq_nt = 0, pwq_ng = 0, pwq_gimg = 0;
-  int pwq_r0[PW4_MAX_GROUPS] = {0, 0, 0, 0}, pwq_gnt[PW4_MAX_GROUPS] = {0, 0, 0, 0};
+  int pwq_r0[PWQ_MAX_GROUPS] = {}, pwq_gnt[PWQ_MAX_GROUPS] = {};
   int64_t pwq_wimg = -1;
 };
 
@@ -315,6 +315,13 @@ bool bn_ok(const csn_bn_off& b) {
   return b.weight >= 0 && b.bias >= 0 && b.running_mean >= 0 && b.running_var >= 0 && b.prelu >= 0;
 }
 
+// M groups a pwq launch may have (CSN_PWQ_GROUPS: 4 = round 5's limit, A/B; the un-pruned net's 80 .. 160-row input gradients need 5 .. 7)
+static int pwq_max_groups() {
+  const char* e = std::getenv("CSN_PWQ_GROUPS");
+  const int v = e ? std::atoi(e) : PWQ_MAX_GROUPS;
+  return v >= 1 && v <= PWQ_MAX_GROUPS ? v : PWQ_MAX_GROUPS;
+}
+
 // Lay out the weight image of a launch (rows padded to 16, pitch K4 + 2 floats) and emit the packing jobs.
 int finish_launch(Builder& bl, PwLaunchPlan& L) {
   int img = 0;
@@ -348,7 +355,7 @@ int finish_launch(Builder& bl, PwLaunchPlan& L) {
     for (int s = 0; s < ps.nsrc; ++s) q = q && ps.src_mode[s] == PW_OWN && !ps.wb[s].eye && ps.wb[s].tk <= 1;
     const int nt_tot = (ps.nrows + 3) / 4;
     const int ng = (nt_tot + csn_pwq_max_tiles() - 1) / csn_pwq_max_tiles();
-    if (q && ng >= 1 && ng <= PW4_MAX_GROUPS) {
+    if (q && ng >= 1 && ng <= pwq_max_groups()) {
       const int nt = (nt_tot + ng - 1) / ng;
       const int Pp = PW4_PITCH((nt + 3) & ~3);
       const int64_t gimg = (int64_t)ps.K * 4 * Pp;
@@ -1225,7 +1232,7 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
     q.HW = a.H0 * a.W0; q.B = a.B;
     q.ngroups = L.pwq_ng; q.gimg_floats = L.pwq_gimg; q.nt = L.pwq_nt; q.max_grid = P.pw4_grid; q.a16 = c.a16 ? 1 : 0;
     q.mfma16 = (c.a16 && P.pwq16) ? 1 : 0;
-    for (int g = 0; g < PW4_MAX_GROUPS; ++g) { q.grp_r0[g] = L.pwq_r0[g]; q.grp_nt[g] = L.pwq_gnt[g]; }
+    for (int g = 0; g < PWQ_MAX_GROUPS; ++g) { q.grp_r0[g] = L.pwq_r0[g]; q.grp_nt[g] = L.pwq_gnt[g]; }
     bool ok = q.out != nullptr;
     for (int s = 0; s < q.nsrc; ++s) ok = ok && q.src[s].ptr != nullptr;
     if (ok) {

@@ -459,9 +459,15 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
 }
 
 // ---- instantiation table -----------------------------------------------------------------------------------------
+// (5, 5), round 6: the un-pruned expand-2 net's 80 + 80 -> 80 + 80 units (four M groups; without it they fell back to goct_pw_kernel)
+#ifdef PW4_NO55
+#define PW4_X55(X)
+#else
+#define PW4_X55(X) X(5, 5)
+#endif
 #define PW4_INST_LIST(X) \
   X(3, 3) X(3, 4) X(4, 3) X(4, 4) X(5, 3) X(4, 6) X(4, 0) X(5, 0) X(6, 0) X(2, 2) X(3, 0) X(2, 0) X(1, 1) X(5, 2) X(2, 5) \
-  X(1, 0) X(0, 1) X(0, 2) X(0, 3) X(0, 4) X(0, 5) X(0, 6) X(0, 8) X(0, 10) X(8, 0) X(10, 0) X(7, 0) X(2, 3) X(3, 2) X(2, 1) X(1, 2) X(1, 3) X(2, 4)
+  PW4_X55(X) X(1, 0) X(0, 1) X(0, 2) X(0, 3) X(0, 4) X(0, 5) X(0, 6) X(0, 8) X(0, 10) X(8, 0) X(10, 0) X(7, 0) X(2, 3) X(3, 2) X(2, 1) X(1, 2) X(1, 3) X(2, 4)
 
 typedef void (*Pw4Fn)(Pw4Args);
 struct Pw4Entry { int nth, ntl; Pw4Fn fn[4]; };   // BN + PReLU / raw / row reduction / raw with bfloat16 tensors

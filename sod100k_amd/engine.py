@@ -96,6 +96,7 @@ class Engine:
         self.lib = lib
         self.B, self.H, self.W = B, H, W
         self.sub_batch = sub_batch
+        self.slice_lanes = bool(slice_lanes) and 0 < sub_batch < B   # batch slices side by side on the plan's stream lanes
         self.device = device
         self.unit_names = list(unit_names) if unit_names is not None else [str(i) for i in range(len(units))]
         ua = (N.UnitDesc * len(units))(*units)

@@ -457,7 +457,7 @@ class CSNet(nn.Module):
             self._engines = {}
         return self._arena
 
-    def engine_for(self, x: torch.Tensor, train: bool = False) -> Engine:
+    def engine_for(self, x: torch.Tensor, train: bool = False, slice_lanes: Optional[bool] = None) -> Engine:
         arena = self._ensure_arena()
         if x.device != arena.flat.device:
             raise RuntimeError(f"input on {x.device} but model parameters on {arena.flat.device}")
@@ -468,7 +468,15 @@ class CSNet(nn.Module):
                                    "move the model and the input to the GPU (`model.cuda()`, `x.cuda()`).")
             lib = N.load()
         bf16 = bool(train) and getattr(self, "_train_act_dtype", "fp32") == "bf16"
-        key = (tuple(x.shape), x.device, bool(train), bf16)
+        # Eval batches of 32 images and more run as two half-batches side by side on the plan's stream lanes (CSN_OPT_SLICE_LANES):
+        # one half's launch tails and small-map launches overlap the other half's work.  Bit-identical results; round 6, same
+        # lease: 30.4K -> 31.3K img/s at batch 64 (three slices 31.0K, four 25.3K).  CSN_SLICE_LANES=0 / slice_lanes=False: whole
+        # batch on one stream (what the per-kernel profiles of bench.py are taken on); CSN_SLICE_LANES=1: from batch 2 on.
+        env = os.environ.get("CSN_SLICE_LANES")
+        if slice_lanes is None:
+            slice_lanes = env == "1" or (env != "0" and x.shape[0] >= 32 and not self._sub_batch)
+        lanes = bool(slice_lanes) and not train and x.is_cuda and x.shape[0] >= 2
+        key = (tuple(x.shape), x.device, bool(train), bf16, lanes)
         eng = self._engines.get(key)
         if eng is not None:
             self._engines[key] = self._engines.pop(key)      # most recently used last
@@ -483,10 +491,6 @@ class CSNet(nn.Module):
                 raise ValueError("CSNet needs H and W to be multiples of 16 (cf. test.py:80-85)")
             units, acts, names = self.describe(arena.offsets)
             sub_batch = 0 if train else self._sub_batch
-            # opt-in (CSN_SLICE_LANES=1): a large eval batch as two half-batches side by side on the plan's stream lanes
-            # (CSN_OPT_SLICE_LANES; bit-identical results, +2.4 % at batch 64 on MI355X, profiles/r3_notes.md).  Off by
-            # default: overlapping launches make per-kernel durations in a trace incomparable with the serial profile.
-            lanes = os.environ.get("CSN_SLICE_LANES") == "1" and not train and x.is_cuda and B >= 2
             if lanes and sub_batch == 0:
                 sub_batch = (B + 1) // 2
             # (bf16: the option goes in before the training buffers are laid out, so that every activation-typed region of the

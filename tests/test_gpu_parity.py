@@ -82,6 +82,13 @@ def test_gpu_full_size_properties(hip, x2_manifest):
     for sb in (16, 24):
         m2, _ = P.make_model(lib, x2_manifest, dev, sub_batch=sb)
         assert torch.equal(m2(xd), y)
+    # ... nor does the default schedule of this batch size (round 6: two half-batches side by side on the plan's stream lanes)
+    # against the whole batch on one stream
+    assert m.engine_for(xd).slice_lanes and m.engine_for(xd).sub_batch == 32
+    e1 = m.engine_for(xd, slice_lanes=False)
+    assert not e1.slice_lanes
+    e1.refresh(m._arena.flat)
+    assert torch.equal(e1.forward(xd), y)
     # oracle on 4 images of the batch
     idx = [0, 17, 40, 63]
     ref = P.oracle_forward(x2_manifest, sd, x[idx])

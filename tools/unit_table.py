@@ -47,6 +47,13 @@ def main():
     torch.cuda.synchronize()
     ts = sorted(a.elapsed_time(b) for a, b in evs)
     med = statistics.median(ts)
+    # per-unit times: the same kernels launched once per whole batch on one stream (at batch >= 32 the product's default plan runs
+    # two half-batch slices side by side on two stream lanes: the replay median above is that plan's)
+    if getattr(eng, "slice_lanes", False):
+        eng = model.engine_for(x, slice_lanes=False)
+        eng.refresh(model._arena.flat)
+        for _ in range(3):
+            eng.forward(x, out=y)
     ms, names, nbytes = eng.profile(x, iters=args.iters)
     ks = eng.kernel_stats()
     rows = []
