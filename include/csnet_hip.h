@@ -229,6 +229,10 @@ int csn_resize_bilinear(const float* in, float* out, int32_t planes, int32_t Hi,
 int csn_sal_hist(const uint8_t* sal, const uint8_t* gt, int64_t npix, int32_t n_images, uint64_t* hist, uint64_t* abs_sum,
                  void* stream);
 
+/* Measurement helper (no counterpart in the reference): dst[0 .. n) = src[0 .. n) floats, n a multiple of 4, as a plain streaming
+ * kernel.  bench.py times it for `roofline.peak_measured`, the on-box HBM figure next to the 8 TB/s spec. */
+int csn_stream_copy(const float* src, float* dst, int64_t n, void* stream);
+
 /* The validation loop of the training caller (CSNet_training/train.py:262-276) for ONE picture: sigmoid of the
  * hi x wi logits -> F.interpolate(size=(h, w), bilinear, align_corners=False) -> (x * 255).int() / 255 ->
  * mean |. - target| over the h x w target (float, the picture's own size).  ADDS the mean to *mae (caller zeroes). */

@@ -280,6 +280,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.csn_resize_bilinear.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int32] * 5 + [C.c_void_p]
     lib.csn_val_mae.restype = C.c_int
     lib.csn_val_mae.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.csn_stream_copy.restype = C.c_int
+    lib.csn_stream_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.csn_sal_hist.restype = C.c_int
     lib.csn_sal_hist.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.csn_forward_profile.restype = C.c_int
@@ -321,7 +323,7 @@ EXPORTS: Sequence[str] = (
     "csn_abi_version", "csn_strerror", "csn_last_hip_error", "csn_plan_create", "csn_plan_destroy",
     "csn_plan_set_option", "csn_plan_workspace_bytes", "csn_plan_act_info", "csn_plan_train_act_info", "csn_plan_unit_in_slot", "csn_plan_num_units", "csn_plan_refresh_params",
     "csn_forward", "csn_forward_train", "csn_plan_enable_training", "csn_backward", "csn_bce_with_logits",
-           "csn_adam_step", "csn_val_mae", "csn_saliency_u8", "csn_normalize_nchw", "csn_resize_normalize_nchw", "csn_saliency_resize_u8", "csn_resize_bilinear", "csn_sal_hist", "csn_forward_profile", "csn_profile_num_kernels", "csn_profile_bracket_us", "csn_profile_kernel", "csn_unit_kernel_name", "csn_unit_algorithmic_bytes",
+           "csn_adam_step", "csn_val_mae", "csn_saliency_u8", "csn_normalize_nchw", "csn_resize_normalize_nchw", "csn_saliency_resize_u8", "csn_resize_bilinear", "csn_sal_hist", "csn_stream_copy", "csn_forward_profile", "csn_profile_num_kernels", "csn_profile_bracket_us", "csn_profile_kernel", "csn_unit_kernel_name", "csn_unit_algorithmic_bytes",
     "csf_head_create", "csf_head_destroy", "csf_head_workspace_bytes", "csf_head_refresh_params", "csf_head_forward",
     "csf_head_stage_info", "csf_head_macs", "csf_bn_act", "csn_build_sources_sha16")
 

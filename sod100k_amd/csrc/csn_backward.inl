@@ -461,11 +461,6 @@ int run_wgrad(const BwdCtx& b, const WgPlan& w, const PwBind& bd) {
     }
   a.gpp = (int)((hw + 63) / 64);
   a.ngroups = a.gpp * P.S;
-  if (std::getenv("CSN_DEBUG_WGRAD")) {
-    std::fprintf(stderr, "wgrad: %dx%d rows %d K %d src", a.Hr, a.Wr, pp.nrows, pp.K);
-    for (int q = 0; q < pp.nsrc; ++q) std::fprintf(stderr, " (mode %d C %d dil %d)", pp.src_mode[q], pp.src_C[q], pp.src_dil[q]);
-    std::fprintf(stderr, " rowsrc %d\n", a.nrs);
-  }
   a.k16 = (pp.K + 15) & ~15;
   a.partial = reinterpret_cast<float*>(b.c.ws + (b.c.side ? P.wg2_off : P.wg_off));
   a.a16 = b.c.a16 ? 1 : 0; a.pad = 0;
@@ -613,7 +608,7 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
         if (d.cout[j] > 0) LAUNCH_TRY(csn_launch_bn_bwd_apply_step(bnargs[j], c.stream));
     }
     bool c3q_fwd = false;   // the train-mode forward ran this 3x3 unit on c3q_kernel: its max-pooled input copies exist (run_unit)
-    if (d.kind == CSN_UNIT_GOCT && d.ksize == 3 && P.c3q && P.tiled3 && !std::getenv("CSN_WGRAD_NO_MP"))
+    if (d.kind == CSN_UNIT_GOCT && d.ksize == 3 && P.c3q && P.tiled3)
       for (const PwLaunchPlan& L : u.pwl) c3q_fwd = c3q_fwd || L.c3q;
     for (int i = 0; i < d.n_in; ++i) {
       if (d.cin[i] == 0) continue;
@@ -1094,6 +1089,12 @@ int csn_sal_hist(const uint8_t* sal, const uint8_t* gt, int64_t npix, int32_t n_
   if (!sal || !gt || !hist || !abs_sum || npix <= 0 || n_images <= 0) return CSN_E_INVALID;
   LAUNCH_TRY(csn_launch_sal_hist(sal, gt, npix, n_images, reinterpret_cast<unsigned long long*>(hist),
                                  reinterpret_cast<unsigned long long*>(abs_sum), stream));
+  return CSN_OK;
+}
+
+int csn_stream_copy(const float* src, float* dst, int64_t n, void* stream) {
+  if (!src || !dst || n <= 0 || (n & 3) != 0) return CSN_E_INVALID;
+  LAUNCH_TRY(csn_launch_stream_copy(src, dst, n, stream));
   return CSN_OK;
 }
 

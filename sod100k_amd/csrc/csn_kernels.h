@@ -590,6 +590,7 @@ struct AdamArgs {
 };
 int csn_launch_adam(const AdamArgs& a, void* stream);
 int csn_launch_saliency_u8(const float* y, unsigned char* o, int64_t n, void* stream);
+int csn_launch_stream_copy(const float* src, float* dst, int64_t n, void* stream);
 int csn_launch_sal_hist(const unsigned char* sal, const unsigned char* gt, int64_t npix, int n_images,
                         unsigned long long* hist, unsigned long long* abs_sum, void* stream);
 int csn_launch_normalize_nchw(const float* hwc, float* chw, int64_t B, int64_t HW, void* stream);

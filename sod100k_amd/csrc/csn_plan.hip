@@ -184,8 +184,8 @@ struct csn_plan {
   int slice_lanes = 0;    // CSN_OPT_SLICE_LANES: batch slices (sub_batch < B) run concurrently on the plan's stream lanes, each
                           // in its own workspace region
   bool c3q = true;        // CSN_OPT_C3Q: eval-mode 3x3 passes on c3q_kernel (k_c3q.hip)
-  int c3q_cap = 4;        // its row tiles per M group (CSN_C3Q_NT, experiments)
-  bool dw_fast = true;    // CSN_DW_FAST=0: the fused depthwise pair on the round-1 kernel instead of dw3x3x2_fast_kernel (A/B)
+  int c3q_cap = 4;        // its row tiles per M group
+  bool dw_fast = true;    // the fused depthwise pair on dw3x3x2_fast_kernel where every branch qualifies (dw_pair_fast)
   int dwb_fast = 1;       // CSN_DWB_FAST=0: the fully fused depthwise backward on the round-4 loop instead of dw3x3_bwd_x_kernel (A/B)
   bool dw_xl = true;      // CSN_DW_XL=0: train-mode depthwise launches in the round-4 geometry, halo columns loaded (see dw_lanes_x)
   bool ilb = true;        // CSN_OPT_FUSE_ILB / CSN_ILB=0: whole ILBlocks of the small maps on ilb_kernel (k_ilb.hip, round 5)
@@ -198,21 +198,22 @@ struct csn_plan {
   // band (CSN_HZ_RB), x_0 channels per load batch (CSN_HZ_HB), waves per block (CSN_HZ_NW)
   // (defaults from the sweep of profiles/r6_notes.md: fuse 4-row bands on 4 waves; fuse1x1 groups of 4 tiles, 4-row bands, 8 waves)
   int hz_nt[2] = {0, 4}, hz_rb[2] = {4, 4}, hz_hb[2] = {2, 2}, hz_nw[2] = {4, 8};
-  int pw4_grid = 2048;    // its block cap (CSN_PW4_GRID, experiments)
+  int pw4_grid = 2048;    // its block cap
   int pw4_twl = 6;        // log2 of its widest tile in low pixels: whole rows of up to 64 (CSN_PW4_TWL; 4 = 16 x 4 tiles: 1 % slower)
   bool pw4_flat = true;       // CSN_PW4_FLAT=0: row-segment tiles everywhere (round 3; A/B)
   bool pwq16 = true;          // CSN_PWQ16=0: 1x1 input-gradient launches of the bf16 step on pwq_kernel<bf16> (fp32 matrix instruction)
   bool ms_dx = true;          // CSN_MS_DX=0: MSBlock input gradients on the generic tap kernel (two launches) instead of ms_dx_kernel
-  int c3q16 = 1;              // CSN_C3Q16: bf16 3x3 launches on c3q16_kernel -- 0 none, 1 input-gradient launches (default), 2 forward launches too (experiments only: bf16 weights in the forward pass put z of the stride-2 units at 2.9e-3 of the unit-local 2e-3 bound and the whole-step statistics at 3.4e-2 of 3e-2)
+  int c3q16 = 1;              // CSN_C3Q16=0: the bf16 step's 3x3 INPUT-GRADIENT launches on c3q_kernel<bf16> instead of c3q16_kernel (the
+                              // forward launches always keep fp32 weights: bf16 weights there put z of the stride-2 units past the unit-local bound)
   bool pw4_no_q = false;      // CSN_PW4_NOQ: CSFHead.fuse's lowest output branch stays on goct_pw_kernel (experiments)
   bool bn_bwd_fuse = true;    // depthwise backward forms dz on load, the BatchNorm backward's apply pass is skipped (CSN_BN_BWD_FUSE=0: off)
-  bool bn_fwd_fuse = true;    // activations consumed only by a depthwise unit are formed on load (virt_cons; CSN_BN_FWD_FUSE=0: off)
+  bool bn_fwd_fuse = true;    // activations consumed only by a depthwise unit are formed on load (virt_cons)
   bool debug_dz = false;      // CSN_DEBUG_DZ (tests): the skipped passes (y of virt_cons activations, dz below) still run for the probes
   // CSN_DEBUG_DZ: ... and the apply pass still runs AFTER that kernel, so that the probes see dz (tests)
   bool no_mp_fuse = false;    // CSN_NO_MP_FUSE: the max-pooled copies of c3q_kernel always come from pool2_kernel (experiments)
   bool c3q_hl = true;     // CSN_C3Q_HL=0: c3q_kernel's float launches on 64-quad tiles with loaded edge columns (round 3) instead of halo lanes
   int c3q_twl = 6;        // ... of c3q_kernel's tile in output quads (CSN_C3Q_TWL)
-  bool pw4_nosplit = false;   // CSN_PW4_NOSPLIT: no extra M groups on small maps (experiments)
+  bool pw4_nosplit = false;   // (no extra M groups on small maps: off)
   bool overlap_bwd = false;   // CSN_OPT_OVERLAP value 2: also the weight-gradient side lane of csn_backward
   bool last_bwd_lanes = false;   // ... and whether the last csn_backward really ran with it (csn_plan_train_act_info reports from this)
   int device = 0;             // ordinal of the device the plan's streams / events / packed buffer live on (csn_plan_destroy)
@@ -315,12 +316,8 @@ bool bn_ok(const csn_bn_off& b) {
   return b.weight >= 0 && b.bias >= 0 && b.running_mean >= 0 && b.running_var >= 0 && b.prelu >= 0;
 }
 
-// M groups a pwq launch may have (CSN_PWQ_GROUPS: 4 = round 5's limit, A/B; the un-pruned net's 80 .. 160-row input gradients need 5 .. 7)
-static int pwq_max_groups() {
-  const char* e = std::getenv("CSN_PWQ_GROUPS");
-  const int v = e ? std::atoi(e) : PWQ_MAX_GROUPS;
-  return v >= 1 && v <= PWQ_MAX_GROUPS ? v : PWQ_MAX_GROUPS;
-}
+// M groups a pwq launch may have (round 5: 4; the un-pruned net's 80 .. 160-row input gradients need 5 .. 7)
+static int pwq_max_groups() { return PWQ_MAX_GROUPS; }
 
 // Lay out the weight image of a launch (rows padded to 16, pitch K4 + 2 floats) and emit the packing jobs.
 int finish_launch(Builder& bl, PwLaunchPlan& L) {
@@ -1043,7 +1040,7 @@ struct Ctx {
 // up to 64 lanes (256 columns).  Wider rows: the LX in [14, 64] with the largest (covered columns) x (lanes used) product instead
 // of 64 and a mostly empty last tile (40 x 6 at 320 columns).  Measured at 224 columns (round 4, bf16 step): 28 x 9 lanes in two
 // tiles per row (252 of 256 lanes busy instead of 224) is 0.3-0.4 ms SLOWER than 56 x 4 -- the half-empty fourth wave costs less
-// than the shorter row segments and the extra tile row; CSN_DW_LX=1 applies the search at every width (A/B).
+// than the shorter row segments and the extra tile row (the search stays off for rows of up to 64 lanes).
 // pow2 (csn_plan::dw_xl, train-mode launches): a plane that fits one tile in x gets a power-of-two group of lanes per row, so that
 // every row of lanes sits inside ONE wave and the kernels take their halo columns from the neighbouring lanes (dwx_row_of, k_misc.hip)
 int dw_lanes_x(int cols, bool pow2 = false) {
@@ -1052,8 +1049,7 @@ int dw_lanes_x(int cols, bool pow2 = false) {
     while (g < cols) g <<= 1;
     return g;
   }
-  static const bool everywhere = std::getenv("CSN_DW_LX") && std::getenv("CSN_DW_LX")[0] == '1';
-  if (cols <= 14 || (cols <= 64 && !everywhere)) return cols;
+  if (cols <= 64) return cols;
   int best = 14;
   double best_s = -1;
   for (int LX = 14; LX <= 64 && LX <= cols; ++LX) {
@@ -1275,7 +1271,7 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
       }
       q.ngroups = L.c3q_ng; q.gimg_floats = L.c3q_gimg; q.nt = L.c3q_nt; q.max_grid = P.pw4_grid;
       q.a16 = c.a16 ? 1 : 0;
-      q.mfma16 = (c.a16 && (gradq ? P.c3q16 >= 1 : P.c3q16 >= 2)) ? 1 : 0;
+      q.mfma16 = (c.a16 && gradq && P.c3q16 >= 1) ? 1 : 0;   // (forward launches keep fp32 weights: c3q_kernel<bf16>)
       q.hl = (P.c3q_hl && !c.a16) ? 1 : 0;
       if (q.hl) { q.twl = PW4_FLAT_TWL; q.tiles_x = (Hq * Wq + 61) / 62; q.tiles_y = 1; }
       for (int g = 0; g < PW4_MAX_GROUPS; ++g) { q.grp_r0[g] = L.c3q_r0[g]; q.grp_nt[g] = L.c3q_gnt[g]; }
@@ -1841,8 +1837,7 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
 #endif
   P->B = B; P->H = H; P->W = W;
   P->S = (sub_batch <= 0 || sub_batch > B) ? B : sub_batch;
-  if (const char* v = std::getenv("CSN_PW4_GRID")) { if (std::atoi(v) >= 8) P->pw4_grid = std::atoi(v); }
-  if (std::getenv("CSN_PW4_NOSPLIT")) P->pw4_nosplit = true;
+
   if (const char* e = std::getenv("CSN_HZ")) P->hz = std::atoi(e) != 0;
   {
     auto pair = [](const char* name, int (&dst)[2], int lo, int hi) {
@@ -1859,17 +1854,13 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   if (std::getenv("CSN_PW4_NOQ")) P->pw4_no_q = true;
   if (const char* e = std::getenv("CSN_PW4_FLAT")) P->pw4_flat = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_ILB")) P->ilb = std::atoi(e) != 0;
-  if (const char* e = std::getenv("CSN_DW_FAST")) P->dw_fast = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_DWB_FAST")) P->dwb_fast = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("CSN_DW_XL")) P->dw_xl = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_ILB_NT")) P->ilb_nt = std::atoi(e) == 2 ? 2 : (std::atoi(e) == 1 ? 1 : 0);
   if (const char* e = std::getenv("CSN_ILB_MAXPIX")) { if (std::atoi(e) > 0) P->ilb_maxpix = std::atoi(e); }
-  if (const char* e = std::getenv("CSN_C3Q16")) {   // 0 / 1; 2 (bf16 weights in the FORWARD 3x3 launches: beyond the certified unit-local bound,
-    const int v = std::atoi(e);                      // profiles/r4_notes.md) only together with CSN_EXPERIMENTS=1, and it says so
-    const bool exp = std::getenv("CSN_EXPERIMENTS") && std::getenv("CSN_EXPERIMENTS")[0] == '1';
-    P->c3q16 = v <= 0 ? 0 : (v >= 2 && exp ? 2 : 1);
-    if (v >= 2) std::fprintf(stderr, "csnet_hip: CSN_C3Q16=%d -> %d%s\n", v, P->c3q16, exp ? " (experiment: forward 3x3 launches with bf16 weights)" : " (set CSN_EXPERIMENTS=1 for 2)");
-  }
+  // (0 / 1.  Round 4's value 2 -- bf16 weights in the FORWARD 3x3 launches -- sat beyond the certified unit-local bound
+  // (profiles/r4_notes.md) and went with its CSN_EXPERIMENTS gate in round 6)
+  if (const char* e = std::getenv("CSN_C3Q16")) P->c3q16 = std::atoi(e) <= 0 ? 0 : 1;
   if (const char* e = std::getenv("CSN_PWQ16")) P->pwq16 = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_MS_DX")) P->ms_dx = std::atoi(e) != 0;
   if (std::getenv("CSN_NO_MP_FUSE")) P->no_mp_fuse = true;
@@ -1877,8 +1868,7 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   if (const char* v = std::getenv("CSN_C3Q_TWL")) { if (std::atoi(v) >= 2 && std::atoi(v) <= 6) P->c3q_twl = std::atoi(v); }
   if (const char* v = std::getenv("CSN_BN_BWD_FUSE")) P->bn_bwd_fuse = v[0] != '0';
   if (const char* v = std::getenv("CSN_DEBUG_DZ")) P->debug_dz = v[0] != '0';
-  if (const char* v = std::getenv("CSN_BN_FWD_FUSE")) P->bn_fwd_fuse = v[0] != '0';
-  if (const char* v = std::getenv("CSN_C3Q_NT")) { if (std::atoi(v) >= 1) P->c3q_cap = std::atoi(v); }
+
   if (const char* v = std::getenv("CSN_PW4_TWL")) { if (std::atoi(v) >= 2 && std::atoi(v) <= 6) P->pw4_twl = std::atoi(v); }
   Builder bl(*P);
   P->acts.resize(n_acts);

@@ -1665,6 +1665,28 @@ __global__ __launch_bounds__(CSN_BLOCK) void sal_hist_kernel(const unsigned char
   if (threadIdx.x == 0) atomicAdd(&abs_sum[img], (unsigned long long)lh[512]);
 }
 
+// A plain streaming copy (128-bit loads / stores, 16 elements in flight per lane): bench.py's on-box bandwidth figure next to the
+// 8 TB/s spec (`roofline.peak_measured`) -- what a pure HBM-bound kernel of this library's kind reaches on the board.
+__global__ __launch_bounds__(CSN_BLOCK) void stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
+  const int64_t stride = (int64_t)gridDim.x * CSN_BLOCK;
+  int64_t i = (int64_t)blockIdx.x * CSN_BLOCK + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n4; i += stride) dst[i] = src[i];
+}
+
+int csn_launch_stream_copy(const float* src, float* dst, int64_t n, void* stream) {
+  const int64_t n4 = n >> 2;
+  if (n4 <= 0) return 0;
+  int64_t nb = (n4 + CSN_BLOCK * 4 - 1) / (CSN_BLOCK * 4);
+  if (nb > 256 * 32) nb = 256 * 32;
+  CSN_LAUNCH(stream_copy_kernel, dim3((unsigned)nb), dim3(CSN_BLOCK), 0, stream, reinterpret_cast<const float4*>(src),
+             reinterpret_cast<float4*>(dst), n4);
+  return (int)hipGetLastError();
+}
+
 int csn_launch_sal_hist(const unsigned char* sal, const unsigned char* gt, int64_t npix, int n_images,
                         unsigned long long* hist, unsigned long long* abs_sum, void* stream) {
   int64_t nb = (npix + CSN_BLOCK * 16 - 1) / (CSN_BLOCK * 16);

@@ -354,11 +354,13 @@ int csn_launch_ms_dx(const MsDxArgs& a, void* stream) {
 
 int csn_launch_ms(const MsArgs& a, void* stream) {
   const int hw = a.H * a.W;
-  static const bool rows = !(std::getenv("CSN_MS_ROWS") && std::getenv("CSN_MS_ROWS")[0] == '0');   // 0: one pixel per lane everywhere
-  // four pixels per lane (float, rows of whole quads); small maps keep one pixel per lane (28^2 x 64 images is 320 blocks of
-  // quads: 42 us against 29 us, profiles/r3_notes.md)
-  static const bool rows16 = !(std::getenv("CSN_MS_ROWS16") && std::getenv("CSN_MS_ROWS16")[0] == '0');   // ... also for bfloat16 tensors
-  if (rows && (!a.a16 || rows16) && (a.W & 3) == 0 && a.H * (a.W >> 2) >= 512) {
+  // four pixels per lane (rows of whole quads, float and bfloat16 tensors); small maps keep one pixel per lane (28^2 x 64 images is
+  // 320 blocks of quads: 42 us against 29 us, profiles/r3_notes.md).
+  // Round 6, measured and NOT kept (profiles/r6_notes.md): the block from an LDS band (band + 16 halo rows of one channel staged per
+  // step, double buffered; a lane owns pixel pairs and all dilations; packed FMAs; weights through LDS): 102 / 152 / 104 us for the
+  // three blocks against 73 / 62 / 27 here -- 45 tap reads per pixel pair and channel make it LDS-bandwidth bound (1.8 us per channel
+  // and band on the 112^2 map) on top of a barrier per channel with one block per CU.
+  if ((a.W & 3) == 0 && a.H * (a.W >> 2) >= 512) {
     int mx = 0;
     for (int d = 0; d < 5; ++d) mx = a.dch[d] > mx ? a.dch[d] : mx;
     // R quads per lane in dilation-strided rows (profiles/r3_notes.md: 94 -> 68 us, 62 -> 57 us)

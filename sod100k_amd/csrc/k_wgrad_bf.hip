@@ -620,8 +620,6 @@ bool wgbf3_config(const WgArgs& a, WgBf3Cfg* c) {
     dilated = dilated || d != 1;
     C += ps.src[s].C;
   }
-  const bool ms_off = std::getenv("CSN_WGRAD_BF3_MS") && std::getenv("CSN_WGRAD_BF3_MS")[0] == '0';
-  if (dilated && ms_off) return false;
   const int64_t HW = (int64_t)a.Hr * a.Wr;
   if ((a.Wr % 8) != 0 || HW % 32 != 0 || HW > (1 << 24) || ps.cin != 9 * C) return false;
   const int R = ps.nrows;
