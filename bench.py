@@ -468,6 +468,10 @@ def main():
                                     "train-mode forward + BCE + backward + Adam; bf16 storage at config 3's batch, fp32 at 64",
                             "parameters": int(sum(p.numel() for p in um.parameters()))}
                 u_alg = train_algorithmic_bytes(um) // 4       # (3 in + 7 out) activation ELEMENTS per image, SURVEY 8(d)
+                try:
+                    u_traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_train_unpruned_latest.json")))
+                except Exception:
+                    u_traffic = {}
                 for adt, UB in (("fp32", min(64, args.unpruned_batch)), ("bf16", args.unpruned_batch)):
                     esz = 2 if adt == "bf16" else 4
                     um.set_batchsize(UB)
@@ -484,8 +488,14 @@ def main():
                                      "loss": (round(float(utr.loss), 6) if np.isfinite(float(utr.loss)) else None),
                                      "roofline": {"bound": "hbm", "achieved": round(u_bw, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                   "frac": round(u_bw / HBM_PEAK_GBS, 4), "bytes_per_step": int(u_alg * esz * UB),
-                                                  "traffic": None,
-                                                  "what": f"algorithmic (3*in + 7*out) x {esz} B per unit of THIS net (SURVEY 8(d)) / whole-step time"}}
+                                                  "traffic": u_traffic.get(adt, {}).get("hbm_bytes_per_step") if UB == (64 if adt == "fp32" else 256) else None,
+                                                  "traffic_source": u_traffic.get("_source"),
+                                                  "traffic_from_this_tree": u_traffic.get("_kernel_sources_sha16") == N_SRC_SHA,
+                                                  "dominant_kernels": ({k: round((v["read_bytes"] + v["write_bytes"]) / 1e9, 2)
+                                                                        for k, v in list(u_traffic.get(adt, {}).get("by_kernel", {}).items())[:4]}
+                                                                       or None),
+                                                  "what": f"algorithmic (3*in + 7*out) x {esz} B per unit of THIS net (SURVEY 8(d)) / whole-step time; "
+                                                          "traffic / dominant_kernels (GB per step): the committed counter pass"}}
                     del utr, ux, ut
                     um._engines = {}
                     torch.cuda.empty_cache()

@@ -3,7 +3,7 @@
 # forward -> gpurun_out/$1/pmc_eval.txt.  Counters only (no tracing), separate runs per pass.
 out=$PWD/gpurun_out/$1; mkdir -p $out
 R=$PWD
-CMD="python $R/bench.py --steps 2 --warmup 1 --train-steps 0 --csf-batch 0 --no-cpu-baseline --no-latency-b1 --event-steps 0 --profile-iters 1"
+CMD="env CSN_SLICE_LANES=0 python $R/bench.py --steps 2 --warmup 1 --train-steps 0 --csf-batch 0 --no-cpu-baseline --no-latency-b1 --event-steps 0 --profile-iters 1"
 cd /tmp && export TMPDIR=/tmp
 run() { name=$1; shift
   ( timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $out/pe_$name -o $name -- $CMD ) > $out/pe_$name.log 2>&1

@@ -36,7 +36,7 @@ def main():
     print("calibration: bytes per FETCH_SIZE KiB-unit x1024:", {k: round(v, 3) for k, v in f_rd.items()},
           " WRITE_SIZE:", {k: round(v, 3) for k, v in f_wr.items()})
     # dominant access width of every kernel family (bytes per lane of the loads / stores that carry the traffic)
-    width = {"pw4_kernel": (8, 8), "c3q_kernel": (8, 8), "dw3x3x2_bn_prelu_kernel": (16, 16), "dw3x3x2_fast_kernel": (16, 16), "ilb_kernel": (8, 16), "msr_kernel": (16, 16),
+    width = {"pw4_kernel": (8, 8), "c3q_kernel": (8, 8), "dw3x3x2_bn_prelu_kernel": (16, 16), "dw3x3x2_fast_kernel": (16, 16), "ilb_kernel": (8, 16), "hz_kernel": (8, 8), "msr_kernel": (16, 16),
              "msblock_kernel": (4, 4), "goct_pw_kernel": (4, 4), "goct_c3_kernel": (4, 4), "pool2_kernel": (16, 8),
              "bilinear_up2_kernel": (4, 4)}
 

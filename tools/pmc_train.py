@@ -3,7 +3,7 @@
 `bench.py --train-steps N` (steps are delimited by bce_logits_kernel launches, as in tools/train_step_breakdown.py),
 calibrated on tools/probes/fetch_cal like tools/pmc_hbm.py.
 
-usage: tools/pmc_train.py <dir> <tag>
+usage: tools/pmc_train.py <dir> <tag> [x2 | unpruned]
 <dir> holds cal_fetch/ cal_write/ train_fetch/ train_write/ (tools/gpu_pmc_train.sh).  Writes profiles/<tag>_pmc_train.json."""
 import collections
 import csv
@@ -36,6 +36,8 @@ def steps(seq):
 
 def main():
     src, tag = sys.argv[1], sys.argv[2]
+    net = sys.argv[3] if len(sys.argv) > 3 else "x2"
+    sfx = "" if net == "x2" else "_" + net
     GiB = float(1 << 30)
     cf = [v for n, v in dispatches(os.path.join(src, "cal_fetch"), "FETCH_SIZE") if "stream_kernel" in n or "stride2" in n]
     cw = [v for n, v in dispatches(os.path.join(src, "cal_write"), "WRITE_SIZE") if "stream_kernel" in n or "stride2" in n]
@@ -77,12 +79,13 @@ def main():
     sys.path.insert(0, ROOT)
     from sod100k_amd import _native as N
     res["_kernel_sources_sha16"] = N.sources_sha16()
-    res["_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --train-steps 3 (batch 256, csnet-L-x2), "
+    res["_source"] = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --train-net {net} (x2: csnet-L-x2 at batch 256; "
+                      "unpruned: the expand-2 training net, fp32 at batch 64, bf16 at 256), "
                       "last step of each storage mode between two bce_logits_kernel launches; calibrated with tools/probes/fetch_cal "
                       f"(x{k_rd:.3f} reads, x{k_wr:.3f} writes); tree {head}")
-    out = os.path.join(ROOT, "profiles", f"{tag}_pmc_train.json")
+    out = os.path.join(ROOT, "profiles", f"{tag}_pmc_train{sfx}.json")
     json.dump(res, open(out, "w"), indent=1)
-    json.dump(res, open(os.path.join(ROOT, "profiles", "pmc_train_latest.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(ROOT, "profiles", f"pmc_train{sfx}_latest.json"), "w"), indent=1)
     print("wrote", out)
 
 
