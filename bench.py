@@ -617,7 +617,7 @@ def csf_point(dev, batch, steps):
             "value": round(batch / (ms_all * 1e-3), 1), "unit": "images/sec", "ms_per_step": round(ms_all, 3),
             "ms_head_hip": round(ms_head, 3), "ms_backbone_miopen": round(ms_all - ms_head, 3),
             "head_roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
-                              "frac": round(tf / peak, 4), "kernel": "csf_gemm_kernel (+ combine / GroupNorm passes)",
+                              "frac": round(tf / peak, 4), "kernel": "csf_gemm3_kernel: fp32 operands as three bfloat16 parts on v_mfma_f32_32x32x16_bf16 (+ combine / GroupNorm passes)",
                               "flops_per_step": int(2 * eng.macs)}}
 
 

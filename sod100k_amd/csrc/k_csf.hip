@@ -23,6 +23,8 @@
 //   csf_cls_kernel        fuse1x1's GroupNorm + PReLU applied on the fly + cls_layer (1x1 + bias) (csf_res2net.py:253)
 //   csf_resize_kernel     F.interpolate(size, bilinear, align_corners=False) (csf_res2net.py:254)
 //   csf_prep_kernel       weight images
+#include <cstdlib>
+
 #include "csf_kernels.h"
 #include "pw_gather.h"   // csn_f4
 
@@ -184,10 +186,250 @@ __global__ __launch_bounds__(256) void csf_gemm_kernel(CsfGemmArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// csf_gemm3_kernel (round 6): the same implicit GEMM on the bf16 matrix instruction, fp32 operands split THREE ways.
+// The head is matrix-bound (K = 128 .. 3840) and v_mfma_f32_16x16x4_f32 tops out at 157 TFLOP/s, one sixteenth of the bf16 rate.
+// An fp32 number is exactly the sum of three bfloat16 numbers (its 24 mantissa bits cut into 8 + 8 + 8 by truncation:
+// x = x1 + x2 + x3), products of bfloat16 pairs are exact in fp32, and
+//     a b = a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a3 b1 + a2 b2) + O(2^-24 |a b|)
+// so SIX v_mfma_f32_32x32x16_bf16 issues (fp32 accumulation) reproduce the fp32 product to within the rounding of the fp32
+// instruction itself -- 6 / 16 of its matrix time.  The split costs vector work (4 operations per element, paid once per gathered
+// B element and reused by all the block's rows); it and the matrix work of a SIMD add (profiles/r5_notes.md), hence 128-row blocks.
+// Same block tile, gather, K order, split-K and launch order as csf_gemm_kernel; A is split on the way into LDS from the same
+// fp32 weight image.  LDS per buffer: A [3][2][BM][8] + B [3][2][256][8] bfloat16 (k-group-major: a lane's 16-byte operand reads
+// of a 32-row / 32-pixel tile are contiguous: no bank conflicts).
+#ifdef CSN_CPU_EMU
+struct csf_f16 {
+  float v[16];
+  float& operator[](int i) { return v[i]; }
+  float operator[](int i) const { return v[i]; }
+};
+#else
+typedef __bf16 csf_bf8 __attribute__((ext_vector_type(8)));
+typedef float csf_f16 __attribute__((ext_vector_type(16)));
+
+// three truncation parts of x as the upper halves of three floats (x == f(h) + f(m) + f(l) exactly)
+__device__ __forceinline__ void csf_split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+  const unsigned xb = __float_as_uint(x);
+  h = xb & 0xffff0000u;
+  const float r1 = x - __uint_as_float(h);
+  m = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(m);
+  l = __float_as_uint(r2);
+}
+// bfloat16 pair (element 0 in the low half) from the upper halves of two floats
+__device__ __forceinline__ unsigned csf_pack2(unsigned lo_elem, unsigned hi_elem) {
+  return __builtin_amdgcn_perm(hi_elem, lo_elem, 0x07060302u);   // bytes {lo[2], lo[3], hi[2], hi[3]}: one v_perm_b32
+}
+#endif
+
+template <int MT>   // BM = 16 MT rows per block: 64 (MT = 4) or 128 (MT = 8)
+__global__ __launch_bounds__(256) void csf_gemm3_kernel(CsfGemmArgs a) {
+  constexpr int BM = 16 * MT, TR = BM / 32;
+  constexpr int ASZ = 3 * 2 * BM * 4, BSZ = 3 * 2 * CSF_BN * 4;   // dwords per buffer (8 bfloat16 = 4 dwords per (part, k group, row))
+  CSN_DYN_SMEM(unsigned, lds);
+  unsigned* As = lds;                 // [2][3][2][BM][4]
+  unsigned* Bs = lds + 2 * ASZ;       // [2][3][2][256][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  const int per = gridDim.x >> 3;
+  const int lb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (lb >= a.total_tiles) return;
+  int sp = 0;
+#pragma unroll
+  for (int q = 1; q < CSF_MAX_SUB; ++q)
+    if (q < a.nsub && lb >= a.sub[q].tile0) sp = q;
+  const float* Aimg = a.sub[sp].A;
+  float* outp = a.sub[sp].out;
+  const int M = a.sub[sp].M, dil = a.sub[sp].dil, nmt = a.sub[sp].n_mtiles;
+  const int local = lb - a.sub[sp].tile0;
+  const int mt = local % nmt, rest = local / nmt;
+  const int ks = rest % a.ksplit, nt = rest / a.ksplit;
+  const int m0 = mt * BM;
+
+  const int p = nt * CSF_BN + tid;
+  const int pc = p < a.Ntot ? p : a.Ntot - 1;
+  const int n = pc / a.HWo, pix = pc - n * a.HWo;
+  const int oy = pix / a.Wo, ox = pix - oy * a.Wo;
+
+  csf_f16 acc[TR][2];
+#pragma unroll
+  for (int i = 0; i < TR; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nps = a.taps ? 9 : a.nseg;
+  const int nchunks = a.Kp / CSF_KC;
+  const int c0 = ks * a.chunks_per_split;
+  const int c1 = min(nchunks, c0 + a.chunks_per_split);
+  // A: thread -> (row, 8 consecutive k): BM * 2 threads carry the chunk (the weight image is padded to whole block tiles)
+  const bool a_ld = tid < BM * 2;
+  const float* ap = Aimg + (size_t)(m0 + (tid >> 1)) * a.Kp + (tid & 1) * 8;
+
+  int ps = 0, cc = c0, si = 0;
+  if (a.taps) {
+    ps = c0 / a.seg[0].chunks;
+    cc = c0 - ps * a.seg[0].chunks;
+  } else {
+    while (ps + 1 < nps && cc >= a.seg[ps].chunks) cc -= a.seg[ps++].chunks;
+  }
+  CsfGather g;
+  csf_seg_setup(a, ps, dil, n, oy, ox, g, si);
+  csn_buf buf = csn_make_buf_n(a.seg[si].src, a.seg[si].bytes);
+
+  csn_f4 ra0 = csn_f4{0.f, 0.f, 0.f, 0.f}, ra1 = csn_f4{0.f, 0.f, 0.f, 0.f};
+  float rb[CSF_KC];
+
+  auto fetch = [&](int kc) {
+    if (a_ld) {
+      ra0 = *reinterpret_cast<const csn_f4*>(ap + (size_t)kc * CSF_KC);
+      ra1 = *reinterpret_cast<const csn_f4*>(ap + (size_t)kc * CSF_KC + 4);
+    }
+    const CsfSeg& s = a.seg[si];
+    const unsigned cb = (unsigned)(cc * CSF_KC) * (unsigned)s.cstride * 4u;
+    const unsigned cs = (unsigned)s.cstride * 4u;
+#pragma unroll
+    for (int r = 0; r < CSF_KC; ++r) rb[r] = csn_ld1(buf, g.o00, cb + r * cs);
+    if (++cc == a.seg[si].chunks) {
+      cc = 0;
+      if (++ps < nps) {
+        csf_seg_setup(a, ps, dil, n, oy, ox, g, si);
+        buf = csn_make_buf_n(a.seg[si].src, a.seg[si].bytes);
+      }
+    }
+  };
+
+  if (c0 < c1) fetch(c0);
+  for (int kc = c0; kc < c1; ++kc) {
+    unsigned* Ab = As + ((kc - c0) & 1) * ASZ;
+    unsigned* Bb = Bs + ((kc - c0) & 1) * BSZ;
+#ifdef CSN_CPU_EMU
+    // functional stand-in (the matrix instruction's lane map cannot run on fibers): the chunk as plain floats, row-major
+    float* Af = reinterpret_cast<float*>(Ab);   // [BM][16] needs BM * 16 <= ASZ: 16 BM <= 24 BM
+    float* Bf = reinterpret_cast<float*>(Bb);   // [256][16]
+    if (a_ld) {
+      const int row = tid >> 1, k8 = (tid & 1) * 8;
+      for (int e = 0; e < 4; ++e) { Af[row * 16 + k8 + e] = ra0[e]; Af[row * 16 + k8 + 4 + e] = ra1[e]; }
+    }
+    for (int r = 0; r < CSF_KC; ++r) Bf[tid * 16 + r] = rb[r];
+    __syncthreads();
+    if (kc + 1 < c1) fetch(kc + 1);
+    {
+      const int j32 = lane & 31, ih = (lane >> 5) * 4;
+      for (int i = 0; i < TR; ++i)
+        for (int j = 0; j < 2; ++j)
+          for (int e = 0; e < 16; ++e) {
+            const int row = i * 32 + (e & 3) + 8 * (e >> 2) + ih, col = wave * 64 + j * 32 + j32;
+            float v = acc[i][j][e];
+            for (int u = 0; u < 16; ++u) v = fmaf(Af[row * 16 + u], Bf[col * 16 + u], v);
+            acc[i][j][e] = v;
+          }
+    }
+    __syncthreads();
+#else
+    // ---- split and stage: part q, k group h (k = 8 h .. 8 h + 7), row / pixel r: four dwords at ((q * 2 + h) * R + r) * 4
+    if (a_ld) {
+      const int row = tid >> 1, hh = tid & 1;
+      unsigned h[8], m[8], l[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { csf_split3(ra0[e], h[e], m[e], l[e]); csf_split3(ra1[e], h[4 + e], m[4 + e], l[4 + e]); }
+      csn_u4 q0, q1, q2;
+      q0.x = csf_pack2(h[0], h[1]); q0.y = csf_pack2(h[2], h[3]); q0.z = csf_pack2(h[4], h[5]); q0.w = csf_pack2(h[6], h[7]);
+      q1.x = csf_pack2(m[0], m[1]); q1.y = csf_pack2(m[2], m[3]); q1.z = csf_pack2(m[4], m[5]); q1.w = csf_pack2(m[6], m[7]);
+      q2.x = csf_pack2(l[0], l[1]); q2.y = csf_pack2(l[2], l[3]); q2.z = csf_pack2(l[4], l[5]); q2.w = csf_pack2(l[6], l[7]);
+      *reinterpret_cast<csn_u4*>(Ab + ((0 * 2 + hh) * BM + row) * 4) = q0;
+      *reinterpret_cast<csn_u4*>(Ab + ((1 * 2 + hh) * BM + row) * 4) = q1;
+      *reinterpret_cast<csn_u4*>(Ab + ((2 * 2 + hh) * BM + row) * 4) = q2;
+    }
+    {
+      unsigned h[16], m[16], l[16];
+#pragma unroll
+      for (int r = 0; r < CSF_KC; ++r) csf_split3(rb[r], h[r], m[r], l[r]);
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        csn_u4 q0, q1, q2;
+        q0.x = csf_pack2(h[8 * hh + 0], h[8 * hh + 1]); q0.y = csf_pack2(h[8 * hh + 2], h[8 * hh + 3]);
+        q0.z = csf_pack2(h[8 * hh + 4], h[8 * hh + 5]); q0.w = csf_pack2(h[8 * hh + 6], h[8 * hh + 7]);
+        q1.x = csf_pack2(m[8 * hh + 0], m[8 * hh + 1]); q1.y = csf_pack2(m[8 * hh + 2], m[8 * hh + 3]);
+        q1.z = csf_pack2(m[8 * hh + 4], m[8 * hh + 5]); q1.w = csf_pack2(m[8 * hh + 6], m[8 * hh + 7]);
+        q2.x = csf_pack2(l[8 * hh + 0], l[8 * hh + 1]); q2.y = csf_pack2(l[8 * hh + 2], l[8 * hh + 3]);
+        q2.z = csf_pack2(l[8 * hh + 4], l[8 * hh + 5]); q2.w = csf_pack2(l[8 * hh + 6], l[8 * hh + 7]);
+        *reinterpret_cast<csn_u4*>(Bb + ((0 * 2 + hh) * CSF_BN + tid) * 4) = q0;
+        *reinterpret_cast<csn_u4*>(Bb + ((1 * 2 + hh) * CSF_BN + tid) * 4) = q1;
+        *reinterpret_cast<csn_u4*>(Bb + ((2 * 2 + hh) * CSF_BN + tid) * 4) = q2;
+      }
+    }
+    __syncthreads();
+    if (kc + 1 < c1) fetch(kc + 1);
+    {
+      // lane l: A row (l & 31) of a 32-row tile, B pixel (l & 31) of a 32-pixel tile, k group l >> 5
+      const int r32 = lane & 31, hh = lane >> 5;
+      csn_u4 av[3][TR], bv[3][2];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int i = 0; i < TR; ++i) av[q][i] = *reinterpret_cast<const csn_u4*>(Ab + ((q * 2 + hh) * BM + i * 32 + r32) * 4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[q][j] = *reinterpret_cast<const csn_u4*>(Bb + ((q * 2 + hh) * CSF_BN + wave * 64 + j * 32 + r32) * 4);
+      }
+#define CSF_MMA(QA, QB)                                                                                                        \
+  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(csf_bf8, av[QA][i]), __builtin_bit_cast(csf_bf8, bv[QB][j]), \
+                                                      acc[i][j], 0, 0, 0)
+#pragma unroll
+      for (int i = 0; i < TR; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {   // smallest terms first
+          CSF_MMA(1, 1); CSF_MMA(2, 0); CSF_MMA(0, 2); CSF_MMA(1, 0); CSF_MMA(0, 1); CSF_MMA(0, 0);
+        }
+#undef CSF_MMA
+    }
+#endif
+  }
+
+  // D layout of the 32 x 32 tile: register e of a lane = row (e & 3) + 8 (e >> 2) + 4 (lane >> 5), column lane & 31
+  outp += (size_t)ks * a.split_stride;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = nt * CSF_BN + wave * 64 + j * 32 + (lane & 31);
+    if (q >= a.Ntot) continue;
+    const int qn = q / a.HWo, qp = q - qn * a.HWo;
+    float* o = outp + (size_t)qn * a.out_nstride + qp;
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (m < M) o[(size_t)m * a.HWo] = acc[i][j][e];
+      }
+  }
+}
+
 int csf_launch_gemm(const CsfGemmArgs& a, int mt, void* stream) {
   const int tiles = a.total_tiles;
   if (tiles <= 0) return 0;
   const int grid = (tiles + 7) / 8 * 8;
+  // fp32 operands as three bfloat16 parts on the bf16 matrix instruction (csf_gemm3_kernel); CSF_GEMM_F32=1: the fp32 instruction (A/B)
+  static const bool f32 = getenv("CSF_GEMM_F32") && getenv("CSF_GEMM_F32")[0] == '1';
+  if (!f32 && (mt == 2 || mt == 4 || mt == 8)) {
+    const size_t lds = (size_t)2 * (3 * 2 * 16 * mt * 4 + 3 * 2 * CSF_BN * 4) * sizeof(unsigned);
+    if (mt == 8) {
+#ifndef CSN_CPU_EMU
+      static CsnPerDeviceOnce once;
+      const int st = once.run([&]() {
+        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(csf_gemm3_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      });
+      if (st != 0) return st;
+#endif
+      CSN_LAUNCH(csf_gemm3_kernel<8>, dim3(grid), dim3(256), lds, stream, a);
+    } else if (mt == 4) {
+      CSN_LAUNCH(csf_gemm3_kernel<4>, dim3(grid), dim3(256), lds, stream, a);
+    } else {
+      CSN_LAUNCH(csf_gemm3_kernel<2>, dim3(grid), dim3(256), lds, stream, a);
+    }
+    return (int)hipGetLastError();
+  }
   if (mt == 4) {
     const size_t lds = (size_t)2 * CSF_KC * (64 + 16 + CSF_BP) * sizeof(float);
     CSN_LAUNCH(csf_gemm_kernel<4>, dim3(grid), dim3(256), lds, stream, a);
