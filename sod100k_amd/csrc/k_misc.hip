@@ -1667,12 +1667,38 @@ __global__ __launch_bounds__(CSN_BLOCK) void sal_hist_kernel(const unsigned char
 
 // A plain streaming copy (128-bit loads / stores, 16 elements in flight per lane): bench.py's on-box bandwidth figure next to the
 // 8 TB/s spec (`roofline.peak_measured`) -- what a pure HBM-bound kernel of this library's kind reaches on the board.
+// (measured, round 6, GB/s of read + written bytes for 1 GiB: ONE 128-bit access per lane on an uncapped grid 6,259; grid-stride
+// forms with 2 / 4 / 8 accesses in flight per lane on 1K ... 64K blocks 5,110 ... 5,205, non-temporal accesses 5,150 ... 5,180;
+// torch's copy_ 4,760)
+#ifndef CSN_COPY_U
+#define CSN_COPY_U 1        // 128-bit accesses in flight per lane
+#endif
+#ifndef CSN_COPY_BLOCKS
+#define CSN_COPY_BLOCKS (1 << 22)
+#endif
 __global__ __launch_bounds__(CSN_BLOCK) void stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
   const int64_t stride = (int64_t)gridDim.x * CSN_BLOCK;
   int64_t i = (int64_t)blockIdx.x * CSN_BLOCK + threadIdx.x;
-  for (; i + 3 * stride < n4; i += 4 * stride) {
-    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  for (; i + (CSN_COPY_U - 1) * stride < n4; i += CSN_COPY_U * stride) {
+    float4 v[CSN_COPY_U];
+#pragma unroll
+    for (int k = 0; k < CSN_COPY_U; ++k) {
+#ifdef CSN_COPY_NT
+      v[k].x = __builtin_nontemporal_load(&src[i + k * stride].x); v[k].y = __builtin_nontemporal_load(&src[i + k * stride].y);
+      v[k].z = __builtin_nontemporal_load(&src[i + k * stride].z); v[k].w = __builtin_nontemporal_load(&src[i + k * stride].w);
+#else
+      v[k] = src[i + k * stride];
+#endif
+    }
+#pragma unroll
+    for (int k = 0; k < CSN_COPY_U; ++k) {
+#ifdef CSN_COPY_NT
+      __builtin_nontemporal_store(v[k].x, &dst[i + k * stride].x); __builtin_nontemporal_store(v[k].y, &dst[i + k * stride].y);
+      __builtin_nontemporal_store(v[k].z, &dst[i + k * stride].z); __builtin_nontemporal_store(v[k].w, &dst[i + k * stride].w);
+#else
+      dst[i + k * stride] = v[k];
+#endif
+    }
   }
   for (; i < n4; i += stride) dst[i] = src[i];
 }
@@ -1680,8 +1706,8 @@ __global__ __launch_bounds__(CSN_BLOCK) void stream_copy_kernel(const float4* __
 int csn_launch_stream_copy(const float* src, float* dst, int64_t n, void* stream) {
   const int64_t n4 = n >> 2;
   if (n4 <= 0) return 0;
-  int64_t nb = (n4 + CSN_BLOCK * 4 - 1) / (CSN_BLOCK * 4);
-  if (nb > 256 * 32) nb = 256 * 32;
+  int64_t nb = (n4 + CSN_BLOCK * CSN_COPY_U - 1) / (CSN_BLOCK * CSN_COPY_U);
+  if (nb > CSN_COPY_BLOCKS) nb = CSN_COPY_BLOCKS;
   CSN_LAUNCH(stream_copy_kernel, dim3((unsigned)nb), dim3(CSN_BLOCK), 0, stream, reinterpret_cast<const float4*>(src),
              reinterpret_cast<float4*>(dst), n4);
   return (int)hipGetLastError();
