@@ -198,7 +198,10 @@ struct csn_plan {
   // band (CSN_HZ_RB), x_0 channels per load batch (CSN_HZ_HB), waves per block (CSN_HZ_NW)
   // (defaults from the sweep of profiles/r6_notes.md: fuse 4-row bands on 4 waves; fuse1x1 groups of 4 tiles, 4-row bands, 8 waves)
   int hz_nt[2] = {0, 4}, hz_rb[2] = {4, 4}, hz_hb[2] = {2, 2}, hz_nw[2] = {4, 8};
-  int pw4_grid = 2048;    // its block cap
+#ifndef CSN_PW4_GRID_CAP
+#define CSN_PW4_GRID_CAP 2048
+#endif
+  int pw4_grid = CSN_PW4_GRID_CAP;    // its block cap (persistent blocks walk the items beyond it)
   int pw4_twl = 6;        // log2 of its widest tile in low pixels: whole rows of up to 64 (CSN_PW4_TWL; 4 = 16 x 4 tiles: 1 % slower)
   bool pw4_flat = true;       // CSN_PW4_FLAT=0: row-segment tiles everywhere (round 3; A/B)
   bool pwq16 = true;          // CSN_PWQ16=0: 1x1 input-gradient launches of the bf16 step on pwq_kernel<bf16> (fp32 matrix instruction)
