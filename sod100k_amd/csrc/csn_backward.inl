@@ -317,7 +317,7 @@ int plan_ms_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
   }
   if (!ub.need_dx[0]) return CSN_OK;
   // backward data: ms_dx_kernel (one launch, every dz tap loaded once per pixel); CSN_MS_DX=0: the generic tap kernel below
-  if (P.ms_dx && cin <= 40) {
+  if (P.ms_dx && cin <= 56) {   // (round 6: up to seven groups of eight sums -- the un-pruned x2 net's 53-channel MSBlocks)
     ub.msdx_ng = (cin + 7) / 8;
     for (int k = 0; k < CSN_NDIL; ++k) {
       if (d.dil_ch[k] == 0) continue;

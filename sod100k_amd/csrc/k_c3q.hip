@@ -74,6 +74,10 @@ struct C3qWin {
 __device__ __forceinline__ void c3q_issue_hl(csn_buf rb, const C3qGeo& g, unsigned so, C3qWin& w) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
+#ifdef C3Q_KO_NOLOAD   // knock-out build (tools/README.md): no window loads (wrong results, valid timing)
+    w.c[r] = make_float2(csn_bits_f(g.row[r]), csn_bits_f(so));
+    continue;
+#endif
     w.c[r] = csn_ld2(rb, g.row[r], so);
 #ifdef CSN_CPU_EMU
     w.l[r] = csn_ld1(rb, g.row[r] + g.dl, so);
@@ -88,9 +92,13 @@ __device__ __forceinline__ void c3q_finish_hl(const C3qWin& w, bool has_l, bool 
 #ifdef CSN_CPU_EMU
     v[4 * r] = w.l[r]; v[4 * r + 3] = w.r[r];
 #else
+#ifdef C3Q_KO_NODPP    // knock-out build: the window's edge columns without the lane exchange and the masks
+    v[4 * r] = w.c[r].y; v[4 * r + 3] = w.c[r].x;
+#else
     const float l = csn_bits_f((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(w.c[r].y), 0x138, 0xf, 0xf, true));
     const float rr = csn_bits_f((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(w.c[r].x), 0x130, 0xf, 0xf, true));
     v[4 * r] = has_l ? l : 0.f; v[4 * r + 3] = has_r ? rr : 0.f;
+#endif
 #endif
   }
 }

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void msr_kernel(MsArgs a) {
 // ms_dx_kernel: the block's backward data pass (round 4; before: two launches of the generic tap kernel, 0.7 ms for the 112^2 block
 // of a bf16 step).  The adjoint of five dilated convolutions that WRITE disjoint channel slices is one convolution that READS them:
 //   dx[ci][p] = sum_d sum_co sum_t dz[cobase_d + co][p + off(t) 2^d] * 100 w_d[co][ci][8 - t]
-// One lane owns one pixel and ALL its cin <= 40 sums (NG groups of 8 accumulators): every tap of dz is loaded exactly once per pixel
+// One lane owns one pixel and ALL its cin <= 56 sums (NG groups of 8 accumulators): every tap of dz is loaded exactly once per pixel
 // -- 9 cout loads against the forward's 45 cin -- and meets 8 NG wave-uniform weights (s_load, CSN_PREP_MSDX image).  Channels in
 // pairs with the 18 tap loads in flight before the first FMA, bounded resource + 9-bit tap mask as in msblock_kernel.
 template <int NG, typename AT>
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void ms_dx_kernel(MsDxArgs a) {
 }
 
 int csn_launch_ms_dx(const MsDxArgs& a, void* stream) {
-  if (a.ng < 1 || a.ng > 5 || a.cin > a.ng * 8) return 1;
+  if (a.ng < 1 || a.ng > 7 || a.cin > a.ng * 8) return 1;
   const int hw = a.H * a.W;
   const dim3 grid((unsigned)(((hw + CSN_BLOCK - 1) / CSN_BLOCK) * a.B));
 #define MSDX_LAUNCH(G)                                                                                     \
@@ -346,7 +346,9 @@ int csn_launch_ms_dx(const MsDxArgs& a, void* stream) {
     case 2: MSDX_LAUNCH(2); break;
     case 3: MSDX_LAUNCH(3); break;
     case 4: MSDX_LAUNCH(4); break;
-    default: MSDX_LAUNCH(5); break;
+    case 5: MSDX_LAUNCH(5); break;
+    case 6: MSDX_LAUNCH(6); break;
+    default: MSDX_LAUNCH(7); break;
   }
 #undef MSDX_LAUNCH
   return (int)hipGetLastError();
