@@ -70,9 +70,8 @@ CsfGeom csf_geom(int nsub, const int* M, int nseg, const int* segC, int taps, in
   // 112 / 128-row variants were measured: fewer re-gathers of B, but 2 blocks per CU -- no faster (profiles/r1_notes.md)
   g.mt = maxM >= 48 ? 4 : 2;
   // round 6, csf_gemm3_kernel (fp32 operands as three bfloat16 parts): the split of a gathered B element is vector work that every
-  // row of the block shares -- 128-row blocks where M fills them (CSF_MT8=0: off, A/B)
-  static const bool mt8 = !(getenv("CSF_MT8") && getenv("CSF_MT8")[0] == '0') && !(getenv("CSF_GEMM_F32") && getenv("CSF_GEMM_F32")[0] == '1');
-  if (mt8 && maxM >= 112) g.mt = 8;
+  // row of the block shares -- 128-row blocks where M fills them (same lease: head 6.72 -> 6.57 ms)
+  if (!csf_gemm_f32() && maxM >= 112) g.mt = 8;
   g.BM = 16 * g.mt;
   g.n_ntiles = (Ntot + CSF_BN - 1) / CSF_BN;
   for (int i = 0; i < nsub; ++i) {

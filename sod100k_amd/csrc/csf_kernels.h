@@ -128,7 +128,8 @@ struct CsfBnActArgs {    // x = act(x * scale[c] + shift[c] (+ res)), scale / sh
   int chunks;            // blocks per (image, channel) plane
 };
 int csf_launch_bn_act(const CsfBnActArgs& a, int planes, void* stream);
-int csf_launch_gemm(const CsfGemmArgs& a, int mt, void* stream);     // mt: 16-row tiles per block (2 or 4)
+bool csf_gemm_f32();                                                  // CSF_GEMM_F32=1 (A/B switch)
+int csf_launch_gemm(const CsfGemmArgs& a, int mt, void* stream);     // mt: 16-row tiles per block (2, 4 or 8)
 int csf_launch_combine(const CsfCombArgs& a, void* stream);
 int csf_launch_gn_finalize(const CsfGnFinArgs& a, void* stream);
 int csf_launch_apply(const CsfApplyArgs& a, void* stream);

@@ -1287,15 +1287,6 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
     LAUNCH_TRY(csn_launch_c3(a, all_raw ? 1 : 0, c.stream));
     return c.mark("goct_c3_kernel");
   }
-  if (std::getenv("CSN_DEBUG_FALLBACK")) {
-    std::fprintf(stderr, "goct_pw: lvl %d npass %d raw %d pwq %d |", L.lvl, (int)L.passes.size(), (int)all_raw, L.pwq);
-    for (const PwPassPlan& pp : L.passes) {
-      std::fprintf(stderr, " pass r=%d rows=%d K=%d out_kind=%d nsrc=%d [", pp.r, pp.nrows, pp.K, (int)pp.out_kind, pp.nsrc);
-      for (int q = 0; q < pp.nsrc; ++q) std::fprintf(stderr, "(mode %d C %d kind %d)", pp.src_mode[q], pp.src_C[q], (int)pp.src_kind[q]);
-      std::fprintf(stderr, "]");
-    }
-    std::fprintf(stderr, "\n");
-  }
   LAUNCH_TRY(csn_launch_pw(a, all_raw ? 1 : 0, c.stream));
   return c.mark("goct_pw_kernel");
 }

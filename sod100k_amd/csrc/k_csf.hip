@@ -406,13 +406,17 @@ __global__ __launch_bounds__(256) void csf_gemm3_kernel(CsfGemmArgs a) {
   }
 }
 
+bool csf_gemm_f32() {   // CSF_GEMM_F32=1: the GEMMs on the fp32 matrix instruction (csf_gemm_kernel; A/B against csf_gemm3_kernel)
+  static const bool f32 = getenv("CSF_GEMM_F32") && getenv("CSF_GEMM_F32")[0] == '1';
+  return f32;
+}
+
 int csf_launch_gemm(const CsfGemmArgs& a, int mt, void* stream) {
   const int tiles = a.total_tiles;
   if (tiles <= 0) return 0;
   const int grid = (tiles + 7) / 8 * 8;
   // fp32 operands as three bfloat16 parts on the bf16 matrix instruction (csf_gemm3_kernel); CSF_GEMM_F32=1: the fp32 instruction (A/B)
-  static const bool f32 = getenv("CSF_GEMM_F32") && getenv("CSF_GEMM_F32")[0] == '1';
-  if (!f32 && (mt == 2 || mt == 4 || mt == 8)) {
+  if (!csf_gemm_f32() && (mt == 2 || mt == 4 || mt == 8)) {
     const size_t lds = (size_t)2 * (3 * 2 * 16 * mt * 4 + 3 * 2 * CSF_BN * 4) * sizeof(unsigned);
     if (mt == 8) {
 #ifndef CSN_CPU_EMU
