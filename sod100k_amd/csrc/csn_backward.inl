@@ -467,34 +467,86 @@ int run_wgrad(const BwdCtx& b, const WgPlan& w, const PwBind& bd) {
   const bool defer = b.defer != nullptr && !b.c.side;
   // the kernel holds at most 80 output channels (5 MFMA row tiles) per launch: wider passes go in row chunks
   // ... and passes with K <= 64 in chunks of 48 rows, which keeps them on the wave-private kernel
-  const int row_chunk = (a.nrs == 1 && a.k16 <= 64 && pp.nrows > 48) ? 48 : WG_MAX_ROWS;
+  int row_chunk = (a.nrs == 1 && a.k16 <= 64 && pp.nrows > 48) ? 48 : WG_MAX_ROWS;
+  // Column pieces (round 6).  bf16 storage, 1x1 passes beyond wgrad_bf16_kernel's 4 x 4-tile limit (the un-pruned x2 net: 80 .. 160 rows
+  // against 160 gathered channels) fell back to the generic kernel -- 13.6 of 87 ms per step.  The columns of dW are independent dot
+  // products: such a pass goes in row chunks of 64 and pieces of <= 128 channels of ONE source, each a launch of the bf16 kernel with its
+  // own partial region; the reduction takes the part of every weight block that the piece covers.
+  struct Piece { int s, c0, n, k0; };
+  std::vector<Piece> pieces;
+  {
+    bool own = true, pool = true, flat = true;
+    for (int s2 = 0; s2 < a.ps.nsrc; ++s2) {
+      own = own && a.ps.src[s2].mode == PW_OWN;
+      pool = pool && a.ps.src[s2].mode == PW_POOL2;
+    }
+    for (size_t q = 0; q < w.blocks.size() && q < 3; ++q) flat = flat && w.blocks[q].tk == 0;
+    WgArgs t = a;
+    t.ps.nrows = std::min(pp.nrows, row_chunk); t.rows16 = (t.ps.nrows + 15) & ~15;
+    if (a.a16 && (own || pool) && flat && w.blocks.size() <= 3 && !csn_wgrad_bf_eligible(t)) {
+      // (several row sources -- the regrouped passes, <= 80 rows -- cannot go in row chunks: narrower pieces instead.  The kernel
+      // takes at most 4 x 4 tiles of 32 rows / channels and 8 tiles in all)
+      const int rc = a.nrs == 1 ? 64 : std::min(pp.nrows, row_chunk);
+      const int ntr = (rc + 31) / 32;
+      const int pw = 32 * std::max(1, std::min(4, 8 / ntr));
+      int k0 = 0;
+      for (int s2 = 0; s2 < a.ps.nsrc; ++s2) {
+        for (int c0 = 0; c0 < a.ps.src[s2].C; c0 += pw) pieces.push_back(Piece{s2, c0, std::min(pw, a.ps.src[s2].C - c0), k0 + c0});
+        k0 += a.ps.src[s2].C;
+      }
+      WgArgs t2 = a;   // would a piece be taken?  (geometry limits of the bf16 kernel: HW % 16, pooled widths ...)
+      t2.ps.nrows = std::min(pp.nrows, rc); t2.rows16 = (t2.ps.nrows + 15) & ~15;
+      t2.ps.nsrc = 1; t2.ps.src[0] = a.ps.src[pieces[0].s]; t2.ps.src[0].C = t2.ps.src[0].K = pieces[0].n;
+      t2.ps.cin = pieces[0].n; t2.ps.cin4 = (pieces[0].n + 3) & ~3; t2.k16 = (pieces[0].n + 15) & ~15;
+      if (csn_wgrad_bf_eligible(t2)) row_chunk = a.nrs == 1 ? 64 : row_chunk;
+      else pieces.clear();
+    }
+  }
+  if (pieces.empty()) pieces.push_back(Piece{-1, 0, pp.K, 0});   // the whole pass
   for (int r0 = 0; r0 < pp.nrows; r0 += row_chunk) {
     const int nr = std::min(row_chunk, pp.nrows - r0);
-    a.ps.nrows = nr;
-    if (a.nrs == 1) {   // row chunks of a single source
-      a.rs[0].ptr = b.c.eo(row_base(w.rows[0]), (int64_t)(w.rows[0].c0 + r0) * hw);
-      a.rs[0].n = nr;
-    }
-    a.rows16 = (nr + 15) & ~15;
-    a.nblk = csn_wgrad_blocks(a);
-    if (defer) {   // this pass's own partial region; the reduction waits for a batch (CSN_WG_REGIONS passes per launch)
-      if ((int)b.defer->wgred.size() >= CSN_WG_REGIONS) { const int fs = flush_wgred(b); if (fs != CSN_OK) return fs; }
-      a.partial = reinterpret_cast<float*>(b.c.ws + P.wg_off) + (int64_t)(b.defer->next_region++ % CSN_WG_REGIONS) * P.wg_region_floats;
-    }
-    LAUNCH_TRY(csn_launch_wgrad(a, b.c.stream));
-    WgReduceArgs r;
-    r.partial = a.partial; r.grad = b.grad;
-    r.nblocks = (int)w.blocks.size();
-    for (int q = 0; q < 3; ++q)
-      if (q < r.nblocks) {
-        r.blk[q] = w.blocks[q];
-        r.blk[q].dst += (int64_t)r0 * (r.blk[q].tk > 0 ? r.blk[q].tk : r.blk[q].ld);
-      } else {
-        r.blk[q].dst = 0; r.blk[q].ld = 0; r.blk[q].ncol = 0; r.blk[q].col = 0; r.blk[q].scale = 0.f; r.blk[q].tk = 0;
+    for (const Piece& pc : pieces) {
+      WgArgs q = a;
+      q.ps.nrows = nr;
+      if (q.nrs == 1) {   // row chunks of a single source
+        q.rs[0].ptr = b.c.eo(row_base(w.rows[0]), (int64_t)(w.rows[0].c0 + r0) * hw);
+        q.rs[0].n = nr;
       }
-    r.nblk = a.nblk; r.nrows = nr; r.K = pp.K; r.rows16 = a.rows16; r.k16 = a.k16;
-    if (defer) b.defer->wgred.push_back(r);
-    else LAUNCH_TRY(csn_launch_wgrad_reduce(r, b.c.stream));
+      if (pc.s >= 0) {
+        const PwSrc& src = a.ps.src[pc.s];
+        q.ps.nsrc = 1;
+        q.ps.src[0] = src;
+        q.ps.src[0].ptr = b.c.eo(src.ptr, (int64_t)pc.c0 * (src.mode == PW_POOL2 ? 4 * hw : hw));
+        q.ps.src[0].C = q.ps.src[0].K = pc.n;
+        q.ps.cin = pc.n; q.ps.cin4 = (pc.n + 3) & ~3;
+        q.k16 = (pc.n + 15) & ~15;
+      }
+      q.rows16 = (nr + 15) & ~15;
+      q.nblk = csn_wgrad_blocks(q);
+      if (defer) {   // this pass's own partial region; the reduction waits for a batch (CSN_WG_REGIONS passes per launch)
+        if ((int)b.defer->wgred.size() >= CSN_WG_REGIONS) { const int fs = flush_wgred(b); if (fs != CSN_OK) return fs; }
+        q.partial = reinterpret_cast<float*>(b.c.ws + P.wg_off) + (int64_t)(b.defer->next_region++ % CSN_WG_REGIONS) * P.wg_region_floats;
+      }
+      LAUNCH_TRY(csn_launch_wgrad(q, b.c.stream));
+      WgReduceArgs r;
+      r.partial = q.partial; r.grad = b.grad;
+      r.nblocks = 0;
+      for (int k = 0; k < 3; ++k) { r.blk[k].dst = 0; r.blk[k].ld = 0; r.blk[k].ncol = 0; r.blk[k].col = 0; r.blk[k].scale = 0.f; r.blk[k].tk = 0; }
+      for (size_t k = 0; k < w.blocks.size() && k < 3; ++k) {
+        WgBlock bk = w.blocks[k];
+        bk.dst += (int64_t)r0 * (bk.tk > 0 ? bk.tk : bk.ld);
+        if (pc.s >= 0) {   // the columns [pc.k0, pc.k0 + pc.n) of the pass that fall into this block
+          const int lo = std::max(bk.col, pc.k0), hi = std::min(bk.col + bk.ncol, pc.k0 + pc.n);
+          if (hi <= lo) continue;
+          bk.dst += lo - bk.col; bk.col = lo - pc.k0; bk.ncol = hi - lo;
+        }
+        r.blk[r.nblocks++] = bk;
+      }
+      if (r.nblocks == 0) continue;
+      r.nblk = q.nblk; r.nrows = nr; r.K = pc.s >= 0 ? pc.n : pp.K; r.rows16 = q.rows16; r.k16 = q.k16;
+      if (defer) b.defer->wgred.push_back(r);
+      else LAUNCH_TRY(csn_launch_wgrad_reduce(r, b.c.stream));
+    }
   }
   return CSN_OK;
 }
