@@ -5,6 +5,14 @@
 // feed v_fmac as SGPR operands; only activations travel through VGPRs / LDS.
 #pragma once
 
+// CSN_CPU_EMU (tests/emu: the same sources compiled by g++, TEST INFRASTRUCTURE) comes in two modes.  Default: the lanes of a wave
+// are independent sequential fibers and every cross-lane operand -- another lane's row of an MFMA A operand, a halo column by DPP --
+// is replaced by a functional stand-in (CSN_EMU_SEQ: checks index arithmetic).  `make LANES=1` (CSN_EMU_LANES): the DEVICE paths
+// are compiled and the cross-lane instructions execute lane-exactly through hip_cpu_shim.h's wave rendezvous (checks lane maps).
+#if defined(CSN_CPU_EMU) && !defined(CSN_EMU_LANES)
+#define CSN_EMU_SEQ 1
+#endif
+
 #ifdef CSN_CPU_EMU
 #include "hip_cpu_shim.h"
 #define CSN_LAUNCH(kern, grid, block, smem, stream, ...) \
@@ -134,6 +142,8 @@ static inline void csn_st_u64(csn_buf b, unsigned voff, unsigned soff, uint2 v) 
     q[0] = v.x; q[1] = v.y;
   }
 }
+typedef uint2 csn_u2;
+typedef uint4 csn_u4;
 #else
 typedef __amdgpu_buffer_rsrc_t csn_buf;
 typedef unsigned csn_u2 __attribute__((ext_vector_type(2)));
@@ -219,6 +229,117 @@ __device__ __forceinline__ unsigned short csn_f2bf(float f) {
 #endif
 }
 __device__ __forceinline__ float csn_bf2f(unsigned short h) { return csn_bits_f((unsigned)h << 16); }
+__device__ __forceinline__ unsigned csn_f_bits(float f) {
+#ifdef CSN_CPU_EMU
+  unsigned u; __builtin_memcpy(&u, &f, 4); return u;
+#else
+  return __float_as_uint(f);
+#endif
+}
+
+// ---- cross-lane instructions (device: the builtins; CSN_EMU_LANES: the shim's lane-exact forms; CSN_EMU_SEQ: not available --
+// the call sites carry their stand-ins) ----
+#ifdef CSN_CPU_EMU
+struct csn_f4 {
+  float v[4];
+  float& operator[](int i) { return v[i]; }
+  float operator[](int i) const { return v[i]; }
+};
+struct csn_f16v {
+  float v[16];
+  float& operator[](int i) { return v[i]; }
+  float operator[](int i) const { return v[i]; }
+};
+#else
+typedef float csn_f4 __attribute__((ext_vector_type(4)));
+typedef float csn_f16v __attribute__((ext_vector_type(16)));
+#endif
+#ifndef CSN_EMU_SEQ
+// the value of the lane below / above (v_mov_b32_dpp wave_shr:1 / wave_shl:1, bound_ctrl:0 -> 0 where there is no such lane)
+__device__ __forceinline__ unsigned csn_from_lane_below(unsigned v) {
+#ifdef CSN_EMU_LANES
+  return csn_emu::lanes_dpp_wave_shr1(v);
+#else
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
+#endif
+}
+__device__ __forceinline__ unsigned csn_from_lane_above(unsigned v) {
+#ifdef CSN_EMU_LANES
+  return csn_emu::lanes_dpp_wave_shl1(v);
+#else
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
+#endif
+}
+__device__ __forceinline__ int csn_readfirstlane(int v) {
+#ifdef CSN_EMU_LANES
+  return (int)csn_emu::lanes_readfirstlane((unsigned)v);
+#else
+  return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+// acc[i] += A[i] * b: A[i] = the `a` of lane (lane & ~3) + i, b the lane's own (v_mfma_f32_4x4x1_16b_f32)
+__device__ __forceinline__ csn_f4 csn_mfma_4x4x1(float a, float b, csn_f4 acc) {
+#ifdef CSN_EMU_LANES
+  csn_emu::lanes_mfma_f32_4x4x1(a, b, acc.v);
+  return acc;
+#else
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc, 0, 0, 0);
+#endif
+}
+// ... with four bfloat16 k values per lane (a, b: four bfloat16 in two dwords; v_mfma_f32_4x4x4_16b_bf16)
+__device__ __forceinline__ csn_f4 csn_mfma_4x4x4_bf16(uint2 a, uint2 b, csn_f4 acc) {
+#ifdef CSN_EMU_LANES
+  csn_emu::lanes_mfma_f32_4x4x4_bf16(&a, &b, acc.v);
+  return acc;
+#else
+  typedef short s4 __attribute__((ext_vector_type(4)));
+  union { uint2 u; s4 s; } ca, cb;
+  ca.u = a; cb.u = b;
+  return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ca.s, cb.s, acc, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ csn_f4 csn_mfma_16x16x4(float a, float b, csn_f4 acc) {
+#ifdef CSN_EMU_LANES
+  csn_emu::lanes_mfma_f32_16x16x4_f32(a, b, acc.v);
+  return acc;
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+#endif
+}
+// the 8-pixel bfloat16 forms (a, b: eight bfloat16 in four dwords)
+__device__ __forceinline__ csn_f16v csn_mfma_32x32x16_bf16(csn_u4 a, csn_u4 b, csn_f16v acc) {
+#ifdef CSN_EMU_LANES
+  csn_emu::lanes_mfma_f32_32x32x16_bf16(&a, &b, acc.v);
+  return acc;
+#else
+  typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), acc, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ csn_f4 csn_mfma_16x16x32_bf16(csn_u4 a, csn_u4 b, csn_f4 acc) {
+#ifdef CSN_EMU_LANES
+  csn_emu::lanes_mfma_f32_16x16x32_bf16(&a, &b, acc.v);
+  return acc;
+#else
+  typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), acc, 0, 0, 0);
+#endif
+}
+#endif  // !CSN_EMU_SEQ
+// v_alignbit_b32: the low dword of ({hi, lo} >> sh)
+__device__ __forceinline__ unsigned csn_alignbit(unsigned hi, unsigned lo, unsigned sh) {
+#ifdef CSN_CPU_EMU
+  return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (sh & 31));
+#else
+  return __builtin_amdgcn_alignbit(hi, lo, sh);
+#endif
+}
+// loads above stay above, arithmetic below stays below
+#ifdef CSN_CPU_EMU
+#define CSN_SCHED_FENCE()
+#else
+#define CSN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 // two consecutive elements packed in a dword (element 0 in the low half)
 __device__ __forceinline__ unsigned csn_pack_bf2(float a, float b) { return (unsigned)csn_f2bf(a) | ((unsigned)csn_f2bf(b) << 16); }
 

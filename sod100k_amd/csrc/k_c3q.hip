@@ -67,7 +67,7 @@ __device__ __forceinline__ void c3q_finish_own(const C3qRaw<AT>& w, float (&v)[1
 // The four centre pairs are what stays in flight (8 registers per channel instead of 16); the window is completed when it is used.
 struct C3qWin {
   float2 c[4];
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
   float l[4], r[4];   // (the emulator's lanes run one after the other: it loads the edges)
 #endif
 };
@@ -79,7 +79,7 @@ __device__ __forceinline__ void c3q_issue_hl(csn_buf rb, const C3qGeo& g, unsign
     continue;
 #endif
     w.c[r] = csn_ld2(rb, g.row[r], so);
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
     w.l[r] = csn_ld1(rb, g.row[r] + g.dl, so);
     w.r[r] = csn_ld1(rb, g.row[r] + g.dr, so);
 #endif
@@ -89,14 +89,14 @@ __device__ __forceinline__ void c3q_finish_hl(const C3qWin& w, bool has_l, bool 
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     v[4 * r + 1] = w.c[r].x; v[4 * r + 2] = w.c[r].y;
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
     v[4 * r] = w.l[r]; v[4 * r + 3] = w.r[r];
 #else
 #ifdef C3Q_KO_NODPP    // knock-out build: the window's edge columns without the lane exchange and the masks
     v[4 * r] = w.c[r].y; v[4 * r + 3] = w.c[r].x;
 #else
-    const float l = csn_bits_f((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(w.c[r].y), 0x138, 0xf, 0xf, true));
-    const float rr = csn_bits_f((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(w.c[r].x), 0x130, 0xf, 0xf, true));
+    const float l = csn_bits_f(csn_from_lane_below(csn_f_bits(w.c[r].y)));
+    const float rr = csn_bits_f(csn_from_lane_above(csn_f_bits(w.c[r].x)));
     v[4 * r] = has_l ? l : 0.f; v[4 * r + 3] = has_r ? rr : 0.f;
 #endif
 #endif
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q_kernel(C3qArgs a_byval
   const int chunk = (((nitems + 7) >> 3) + ng - 1) / ng * ng;
   const int xcd = blockIdx.x & 7;
   const int iend = min((xcd + 1) * chunk, nitems);
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
   const float* wl_lane = lds;
 #else
   const float* wl_lane = lds + (lane & 3) * P;
@@ -341,7 +341,7 @@ __device__ __forceinline__ void c3q16_group(const uint2 (&x)[4][4], const uint2*
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       Pw16A wa;
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
       for (int i = 0; i < 4; ++i) wa.r[i] = wk[(t9 * NT + t) * 4 + i];
 #else
       wa.r[0] = wk[(t9 * NT + t) * 4];
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q16_kernel(C3qArgs a_byv
   const int chunk = (((nitems + 7) >> 3) + ng - 1) / ng * ng;
   const int xcd = blockIdx.x & 7;
   const int iend = min((xcd + 1) * chunk, nitems);
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
   const uint2* wl_lane = wl;
 #else
   const uint2* wl_lane = wl + (lane & 3);

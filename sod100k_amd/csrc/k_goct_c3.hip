@@ -39,7 +39,7 @@ struct C3Chunk {   // chunk id -> slice, first channel
 // column (pitch wp), tb = &tile[lane >> 4][2 wave][lane & 15].
 template <bool TWO>
 __device__ __forceinline__ void c3_contract(csn_f4 (&acc)[2][4], const float* wt, int wp, const float* tb, int ng) {
-#ifndef CSN_CPU_EMU
+#ifndef CSN_EMU_SEQ
   for (int g = 0; g < ng; ++g) {
     const float* wg = wt + 4 * g;
     const float* tg = tb + 4 * g * C3_PLANE;
@@ -51,15 +51,15 @@ __device__ __forceinline__ void c3_contract(csn_f4 (&acc)[2][4], const float* wt
 #pragma unroll
       for (int sg = 0; sg < 4; ++sg) {
         const float bv = tg[((sg >> 1) + dy) * C3_TP + 16 * (sg & 1) + dx];
-        acc[0][sg] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc[0][sg], 0, 0, 0);
-        if (TWO) acc[1][sg] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc[1][sg], 0, 0, 0);
+        acc[0][sg] = csn_mfma_16x16x4(a0, bv, acc[0][sg]);
+        if (TWO) acc[1][sg] = csn_mfma_16x16x4(a1, bv, acc[1][sg]);
       }
     }
   }
 #endif
 }
 
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
 // D[row][px] += sum_k W[row][k] x[k][px] in the kernel's k order; this lane holds rows (lane >> 4) * 4 + i of pixel lane & 15
 static inline void c3_contract_emu(csn_f4 (&acc)[2][4], const float* w0, int wp, const float* tile, int wave, int lane,
                                    int ng, bool two) {
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 3) void goct_c3_kernel(PwArgs a_byval) {
         }
         const int ng = (nc + 3) >> 2;
         const float* w0 = WCH ? wch : lds + (int64_t)row0 * w3s + ci * C3_KC;
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
         c3_contract_emu(acc, w0, wp, tile, wave, lane, ng, two);
 #else
         const float* wt = w0 + pxi * wp + kq;

@@ -30,7 +30,7 @@
 // acc[i] += sum_{u<4} W[row0 + (lane>>4)*4 + i][k0 + u] * x[k0 + u][16 s + (lane&15)]
 // wt = &W[row0][k0] in the LDS weight image (row pitch `stride`), xs = &x[k0][16 s] in the wave's panel.
 __device__ __forceinline__ void pw_mfma16(const float* wt, int stride, const float* xs, int lane, csn_f4& acc) {
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
   const int col = lane & 15;
   for (int i = 0; i < 4; ++i) {
     const int row = (lane >> 4) * 4 + i;
@@ -41,7 +41,7 @@ __device__ __forceinline__ void pw_mfma16(const float* wt, int stride, const flo
 #else
   const float av = wt[(lane & 15) * stride + (lane >> 4)];
   const float bv = xs[(lane >> 4) * PW_XP + (lane & 15)];
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+  acc = csn_mfma_16x16x4(av, bv, acc);
 #endif
 }
 

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64 * NW, HZ_MINBLK(NTH, NW)) void hz_kernel(HzArgs 
   const int base1 = 2 * RB * band - 1, base2 = RB * band - 1;   // image row of band row 0 of the z planes
   const int r0 = 4 * NTH * g;                        // first output channel of the group
   const int nr = max(0, min(4 * NTH, a->OH - r0));   // ... and its channel count
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
   const float* wl = lds;
 #else
   const float* wl = lds + (lane & 3) * P;

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) accl[t][i] = 0.f;
   if (tile_on && K3) {
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
     const float* wg = lds;
 #else
     const float* wg = lds + (lane & 3) * P;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
     // the centre pairs of the four high rows and the centre column of the three low rows: what is loaded (7 loads per channel; the
     // gather form took 21) and what stays in flight (11 registers instead of 25)
     struct Win { float2 c[4]; float m[3];
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
       float l[4], r[4], ml[3], mr[3];   // (the emulator's lanes run one after the other: it loads the edges)
 #endif
     };
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         w.c[r] = csn_ld2(rbh, rowh[r], sh_);
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
         w.l[r] = csn_ld1(rbh, rowh[r] + dl, sh_);
         w.r[r] = csn_ld1(rbh, rowh[r] + dr, sh_);
 #endif
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         w.m[r] = csn_ld1(rbl, ol9[3 * r + 1], sl_);
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
         w.ml[r] = csn_ld1(rbl, ol9[3 * r], sl_);
         w.mr[r] = csn_ld1(rbl, ol9[3 * r + 2], sl_);
 #endif
@@ -300,22 +300,22 @@ __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         v[4 * r + 1] = w.c[r].x; v[4 * r + 2] = w.c[r].y;
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
         v[4 * r] = w.l[r]; v[4 * r + 3] = w.r[r];
 #else
-        const float l = csn_bits_f((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(w.c[r].y), 0x138, 0xf, 0xf, true));
-        const float rr = csn_bits_f((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(w.c[r].x), 0x130, 0xf, 0xf, true));
+        const float l = csn_bits_f(csn_from_lane_below(csn_f_bits(w.c[r].y)));
+        const float rr = csn_bits_f(csn_from_lane_above(csn_f_bits(w.c[r].x)));
         v[4 * r] = has_l ? l : 0.f; v[4 * r + 3] = has_r ? rr : 0.f;
 #endif
       }
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         u[3 * r + 1] = w.m[r];
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
         u[3 * r] = w.ml[r]; u[3 * r + 2] = w.mr[r];
 #else
-        const float l = csn_bits_f((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(w.m[r]), 0x138, 0xf, 0xf, true));
-        const float rr = csn_bits_f((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(w.m[r]), 0x130, 0xf, 0xf, true));
+        const float l = csn_bits_f(csn_from_lane_below(csn_f_bits(w.m[r])));
+        const float rr = csn_bits_f(csn_from_lane_above(csn_f_bits(w.m[r])));
         u[3 * r] = has_l ? l : 0.f; u[3 * r + 2] = has_r ? rr : 0.f;
 #endif
       }
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(1024) void ilb_kernel(IlbArgs a_byval) {
     }
   }
   if (tile_on && !K3) {
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
     const float* wg = lds;
 #else
     const float* wg = lds + (lane & 3) * P;

@@ -225,19 +225,16 @@ __device__ __forceinline__ DwRow dw_row_of(const DwRowRaw<csn_bf16>& q) {
 // <= 64, one tile per row) the value left / right of a lane's four columns is the neighbouring lane's last / first own value: one DPP
 // move (wave_shr:1 / wave_shl:1) on the loaded register instead of a load.  Lanes at a row's ends read a lane of another row or an
 // idle lane: those are the positions has_l / has_r mask to zero anyway.  (The CPU emulator runs lanes one after the other: it loads.)
-#ifndef CSN_CPU_EMU
-__device__ __forceinline__ unsigned csn_from_lane_below(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
-__device__ __forceinline__ unsigned csn_from_lane_above(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
-#endif
+// (csn_from_lane_below / _above: csn_device.h)
 // a row as loaded and converted, the halo columns from the neighbouring lanes (no masks: the callers mask or transform anyway)
 template <typename AT>
 __device__ __forceinline__ DwRow dw_load_row_xl(csn_buf rb, int y, int x0, int W) {
-#ifndef CSN_CPU_EMU
+#ifndef CSN_EMU_SEQ
   DwRow r;
   const float4 c = csn_bufacc<AT>::ld4(rb, (unsigned)(y * W + x0) * (unsigned)sizeof(AT), 0);
   r.v[1] = c.x; r.v[2] = c.y; r.v[3] = c.z; r.v[4] = c.w;
-  r.v[0] = csn_bits_f(csn_from_lane_below(__float_as_uint(c.w)));
-  r.v[5] = csn_bits_f(csn_from_lane_above(__float_as_uint(c.x)));
+  r.v[0] = csn_bits_f(csn_from_lane_below(csn_f_bits(c.w)));
+  r.v[5] = csn_bits_f(csn_from_lane_above(csn_f_bits(c.x)));
   return r;
 #else
   return dw_load_row_raw<true, AT>(rb, y, x0, W);
@@ -704,7 +701,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3_bwd_kernel(DwArgs a) {
 //     the producer's BatchNorm-backward sums need: nothing is carried for them.
 template <bool XL>
 __device__ __forceinline__ DwRowRaw<float> dwx_issue(csn_buf rb, int y, int x0, int W, float tag) {
-#ifndef CSN_CPU_EMU
+#ifndef CSN_EMU_SEQ
   if (XL) {
     DwRowRaw<float> q;
     q.c = csn_ld4(rb, (unsigned)(y * W + x0) * 4u, 0); q.l = q.r = 0.f;
@@ -715,7 +712,7 @@ __device__ __forceinline__ DwRowRaw<float> dwx_issue(csn_buf rb, int y, int x0, 
 }
 template <bool XL>
 __device__ __forceinline__ DwRowRaw<csn_bf16> dwx_issue(csn_buf rb, int y, int x0, int W, csn_bf16 tag) {
-#ifndef CSN_CPU_EMU
+#ifndef CSN_EMU_SEQ
   if (XL) {
     DwRowRaw<csn_bf16> q;
     q.c = csn_ld_u64(rb, (unsigned)(y * W + x0) * 2u, 0); q.l = q.r = 0;
@@ -727,17 +724,17 @@ __device__ __forceinline__ DwRowRaw<csn_bf16> dwx_issue(csn_buf rb, int y, int x
 template <bool XL>
 __device__ __forceinline__ DwRow dwx_row_of(const DwRowRaw<float>& q) {
   DwRow r = dw_row_of(q);
-#ifndef CSN_CPU_EMU
+#ifndef CSN_EMU_SEQ
   if (XL) {
-    r.v[0] = csn_bits_f(csn_from_lane_below(__float_as_uint(q.c.w)));
-    r.v[5] = csn_bits_f(csn_from_lane_above(__float_as_uint(q.c.x)));
+    r.v[0] = csn_bits_f(csn_from_lane_below(csn_f_bits(q.c.w)));
+    r.v[5] = csn_bits_f(csn_from_lane_above(csn_f_bits(q.c.x)));
   }
 #endif
   return r;
 }
 template <bool XL>
 __device__ __forceinline__ DwRow dwx_row_of(const DwRowRaw<csn_bf16>& q) {
-#ifndef CSN_CPU_EMU
+#ifndef CSN_EMU_SEQ
   if (XL) {
     DwRow r;
     r.v[0] = csn_bits_f(csn_from_lane_below(q.c.y) & 0xffff0000u);   // the neighbour's fourth value = high half of its second dword
@@ -1237,7 +1234,7 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3x2_fast_kernel(DwArgs a_byval)
     q.c = make_float4(1.f, 2.f, 3.f, csn_bits_f(ro)); q.l = q.r = 0.f; return q;
 #endif
     q.c = csn_ld4(rb, ro + 4u, 0);
-#ifndef CSN_CPU_EMU
+#ifndef CSN_EMU_SEQ
     if (XL) { q.l = q.r = 0.f; return q; }
 #endif
     q.l = csn_ld1(rb, ro, 0);
@@ -1245,9 +1242,9 @@ __global__ __launch_bounds__(CSN_BLOCK) void dw3x3x2_fast_kernel(DwArgs a_byval)
     return q;
   };
   auto fin = [&](const Raw& q) {
-#ifndef CSN_CPU_EMU
+#ifndef CSN_EMU_SEQ
     if (XL) {
-      const float l = csn_bits_f(csn_from_lane_below(__float_as_uint(q.c.w))), r = csn_bits_f(csn_from_lane_above(__float_as_uint(q.c.x)));
+      const float l = csn_bits_f(csn_from_lane_below(csn_f_bits(q.c.w))), r = csn_bits_f(csn_from_lane_above(csn_f_bits(q.c.x)));
       return dw_row2_regs(l * ml, q.c.x, q.c.y, q.c.z, q.c.w, r * mr);
     }
 #endif

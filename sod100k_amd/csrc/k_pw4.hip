@@ -205,7 +205,7 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
   const int chunk = (((nitems + 7) >> 3) + ng - 1) / ng * ng;   // whole tiles per XCD
   const int xcd = blockIdx.x & 7;
   const int iend = min((xcd + 1) * chunk, nitems);
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
   const float* wl_lane = lds;
 #else
   const float* wl_lane = lds + (lane & 3) * P;

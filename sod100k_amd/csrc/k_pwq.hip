@@ -65,7 +65,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 16 * NT <= 96 ? 3 : 2) void pwq_kernel(P
   const int chunk = (((nitems + 7) >> 3) + ng - 1) / ng * ng;
   const int xcd = blockIdx.x & 7;
   const int iend = min((xcd + 1) * chunk, nitems);
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
   const float* wl_lane = lds;
 #else
   const float* wl_lane = lds + (lane & 3) * P;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 16 * NT <= 96 ? 3 : 2) void pwq16_kernel
   const int chunk = (((nitems + 7) >> 3) + ng - 1) / ng * ng;
   const int xcd = blockIdx.x & 7;
   const int iend = min((xcd + 1) * chunk, nitems);
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
   const uint2* wl_lane = wl;
 #else
   const uint2* wl_lane = wl + (lane & 3);
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 16 * NT <= 96 ? 3 : 2) void pwq16_kernel
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       Pw16A wa;
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
       for (int i = 0; i < 4; ++i) wa.r[i] = wk[t * 4 + i];
 #else
       wa.r[0] = wk[t * 4];

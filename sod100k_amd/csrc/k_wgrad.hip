@@ -26,7 +26,7 @@ typedef const CSN_CONST_AS WgArgs* WgArgsP;
 
 template <int NT>
 __device__ __forceinline__ void wg_mma(const float* dzp, const float* xp, int lane, csn_f4 (&acc)[NT]) {
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
   const int j = lane & 15;
   for (int s = 0; s < 16; ++s)
     for (int t = 0; t < NT; ++t)
@@ -44,7 +44,7 @@ __device__ __forceinline__ void wg_mma(const float* dzp, const float* xp, int la
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const float av = dzp[16 * t * WG_P + o + 4 * s];
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
+      acc[t] = csn_mfma_16x16x4(av, bv, acc[t]);
     }
   }
 #endif

@@ -47,10 +47,7 @@ struct WgBfArgs {
   float* partial;
 };
 
-#ifndef CSN_CPU_EMU
-typedef __bf16 wgb_bf8 __attribute__((ext_vector_type(8)));
-typedef float wgb_f16 __attribute__((ext_vector_type(16)));
-#endif
+typedef csn_f16v wgb_f16;
 
 typedef const CSN_CONST_AS WgBfArgs* WgBfArgsP;
 
@@ -64,8 +61,8 @@ __device__ __forceinline__ void wgbf_plane(const CSN_CONST_AS WgBfSrc* src, int 
   istride = (unsigned)((int64_t)src[q].ctot * hw);
 }
 
-#ifdef CSN_CPU_EMU
-// Functional stand-in (the MFMA lane maps cannot run on fibers): the same items per wave, the same partial layout.
+#ifdef CSN_EMU_SEQ
+// Functional stand-in (the lane maps themselves run under `make LANES=1`, csn_device.h): the same items per wave, the same partial layout.
 template <int NTR, int NTC, bool POOL>
 __global__ void wgrad_bf16_kernel(WgBfArgs a_byval) {
   const WgBfArgs* a = &a_byval;
@@ -105,16 +102,20 @@ __global__ void wgrad_bf16_kernel(WgBfArgs a_byval) {
 }
 #else
 // (a pointer rebuilt from integers has no address space: say "global", or the loads are flat_load and count on lgkmcnt too)
+#ifdef CSN_CPU_EMU
+__device__ __forceinline__ csn_u4 wgbf_ld(const char* p) { return *reinterpret_cast<const csn_u4*>(p); }
+#else
 typedef const __attribute__((address_space(1))) csn_u4* wgbf_gp;
 __device__ __forceinline__ csn_u4 wgbf_ld(const char* p) { return *(wgbf_gp)(unsigned long long)p; }
+#endif
 
 // 2x2 max-pool of two rows of 16 bfloat16 values -> 8 bfloat16 values (dword d of a row = the horizontal pair of output d)
 __device__ __forceinline__ unsigned wgbf_pool_pair(unsigned u0a, unsigned u1a, unsigned u0b, unsigned u1b) {
-  const float a = fmaxf(fmaxf(__uint_as_float(u0a << 16), __uint_as_float(u0a & 0xffff0000u)),
-                        fmaxf(__uint_as_float(u1a << 16), __uint_as_float(u1a & 0xffff0000u)));
-  const float b = fmaxf(fmaxf(__uint_as_float(u0b << 16), __uint_as_float(u0b & 0xffff0000u)),
-                        fmaxf(__uint_as_float(u1b << 16), __uint_as_float(u1b & 0xffff0000u)));
-  return (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u);
+  const float a = fmaxf(fmaxf(csn_bits_f(u0a << 16), csn_bits_f(u0a & 0xffff0000u)),
+                        fmaxf(csn_bits_f(u1a << 16), csn_bits_f(u1a & 0xffff0000u)));
+  const float b = fmaxf(fmaxf(csn_bits_f(u0b << 16), csn_bits_f(u0b & 0xffff0000u)),
+                        fmaxf(csn_bits_f(u1b << 16), csn_bits_f(u1b & 0xffff0000u)));
+  return (csn_f_bits(a) >> 16) | (csn_f_bits(b) & 0xffff0000u);
 }
 __device__ __forceinline__ csn_u4 wgbf_pool(const csn_u4 (&r)[4]) {   // r[0], r[1]: row 2y (16 px); r[2], r[3]: row 2y + 1
   csn_u4 o;
@@ -131,8 +132,7 @@ __device__ __forceinline__ void wgbf_mma(const csn_u4 (&A)[NTR], const csn_u4 (&
   for (int tr = 0; tr < NTR; ++tr)
 #pragma unroll
     for (int tc = 0; tc < NTC; ++tc)
-      acc[tr][tc] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wgb_bf8, A[tr]), __builtin_bit_cast(wgb_bf8, Bv[tc]),
-                                                            acc[tr][tc], 0, 0, 0);
+      acc[tr][tc] = csn_mfma_32x32x16_bf16(A[tr], Bv[tc], acc[tr][tc]);
 }
 
 template <int NTR, int NTC, bool POOL>
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 2) void wgrad_bf16_kernel(WgBfArgs a_byv
   WgBfArgsP a = CSN_KERNARG(WgBfArgs, a_byval);
   constexpr int NT = NTR + NTC;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = csn_readfirstlane(tid >> 6);
   const int sl = a->slog, S = 1 << sl, PXS = 16 << sl, TP = 32 >> sl;
   const int HW = a->HW, W = a->W;
   // ---- per-(tile, lane) plane table: base pointer of image 0 and image stride
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 2) void wgrad_bf16_kernel(WgBfArgs a_byv
 #pragma unroll
           for (int t = 0; t < NTC; ++t) Bv[u][t] = wgbf_ld(pc[t] + o);
         }
-        __builtin_amdgcn_sched_barrier(0);   // every load of the trip is in flight before the first contraction
+        CSN_SCHED_FENCE();   // every load of the trip is in flight before the first contraction
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           if (u > 0) {
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 2) void wgrad_bf16_kernel(WgBfArgs a_byv
             raw[u][t][2] = wgbf_ld(pc[t] + o + rowb); raw[u][t][3] = wgbf_ld(pc[t] + o + rowb + 16);
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        CSN_SCHED_FENCE();
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           csn_u4 Bc[NTC];
@@ -306,7 +306,7 @@ struct WgBf3Args {
 };
 typedef const CSN_CONST_AS WgBf3Args* WgBf3ArgsP;
 
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
 template <int NTR, int NTC, int DIL>
 __global__ void wgrad_bf16_c3_kernel(WgBf3Args a_byval) {
   const WgBf3Args* a = &a_byval;
@@ -343,12 +343,17 @@ __global__ void wgrad_bf16_c3_kernel(WgBf3Args a_byval) {
       for (int t = 0; t < 9; ++t) out[(int64_t)r * a->k16 + 9 * (a->c_first + ch) + t] = acc[((size_t)r * C + ch) * 9 + t];
 }
 #else
-typedef float wgb_f4 __attribute__((ext_vector_type(4)));
+typedef csn_f4 wgb_f4;
+#ifdef CSN_CPU_EMU
+__device__ __forceinline__ unsigned wgbf_ld1(const char* p) { return *reinterpret_cast<const unsigned*>(p); }
+__device__ __forceinline__ csn_u2 wgbf_ld2(const char* p) { return *reinterpret_cast<const csn_u2*>(p); }
+#else
 typedef const __attribute__((address_space(1))) unsigned* wgbf_gp1;
 __device__ __forceinline__ unsigned wgbf_ld1(const char* p) { return *(wgbf_gp1)(unsigned long long)p; }
 
 typedef const __attribute__((address_space(1))) csn_u2* wgbf_gp2;
 __device__ __forceinline__ csn_u2 wgbf_ld2(const char* p) { return *(wgbf_gp2)(unsigned long long)p; }
+#endif
 
 // the side pieces of a row for dilation DIL: the DIL columns left of x and right of x + 8 (DIL <= 8), or the whole shifted vectors
 // (DIL = 16); element counts 2 (one dword: also DIL = 1), 2, 4, 8, 8
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 2) void wgrad_bf16_c3_kernel(WgBf3Args a
   WgBf3ArgsP a = CSN_KERNARG(WgBf3Args, a_byval);
   constexpr int NT = NTR + NTC;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = csn_readfirstlane(tid >> 6);
   const int sl = a->slog, S = 1 << sl, PXS = 32 << sl, TP = 16 >> sl;
   const int HW = a->HW, W = a->W, H = a->H;
   csn_u2* tabp = reinterpret_cast<csn_u2*>(lds);                 // [NT][64]
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 2) void wgrad_bf16_c3_kernel(WgBf3Args a
           } else { Lv[t][dy] = wgbf_ld(pc[t] + lo); Rv[t][dy] = wgbf_ld(pc[t] + ro); }
         }
       }
-      __builtin_amdgcn_sched_barrier(0);   // every load of the set is in flight before the first contraction
+      CSN_SCHED_FENCE();   // every load of the set is in flight before the first contraction
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
         const int yy = y + (dy - 1) * DIL;
@@ -453,10 +458,10 @@ __global__ __launch_bounds__(CSN_BLOCK, 2) void wgrad_bf16_c3_kernel(WgBf3Args a
           csn_u4 cm, cp;   // columns x - DIL .. x - DIL + 7 and x + DIL .. x + DIL + 7
           if (DIL == 1) {
             const unsigned l = Lv[tc][dy].x & ml, r = Rv[tc][dy].x & mr;
-            cm.x = __builtin_amdgcn_alignbit(c0.x, l, 16); cm.y = __builtin_amdgcn_alignbit(c0.y, c0.x, 16);
-            cm.z = __builtin_amdgcn_alignbit(c0.z, c0.y, 16); cm.w = __builtin_amdgcn_alignbit(c0.w, c0.z, 16);
-            cp.x = __builtin_amdgcn_alignbit(c0.y, c0.x, 16); cp.y = __builtin_amdgcn_alignbit(c0.z, c0.y, 16);
-            cp.z = __builtin_amdgcn_alignbit(c0.w, c0.z, 16); cp.w = __builtin_amdgcn_alignbit(r, c0.w, 16);
+            cm.x = csn_alignbit(c0.x, l, 16); cm.y = csn_alignbit(c0.y, c0.x, 16);
+            cm.z = csn_alignbit(c0.z, c0.y, 16); cm.w = csn_alignbit(c0.w, c0.z, 16);
+            cp.x = csn_alignbit(c0.y, c0.x, 16); cp.y = csn_alignbit(c0.z, c0.y, 16);
+            cp.z = csn_alignbit(c0.w, c0.z, 16); cp.w = csn_alignbit(r, c0.w, 16);
           } else if (DIL == 2) {   // one dword = two columns
             cm.x = Lv[tc][dy].x & ml; cm.y = c0.x; cm.z = c0.y; cm.w = c0.z;
             cp.x = c0.y; cp.y = c0.z; cp.z = c0.w; cp.w = Rv[tc][dy].x & mr;
@@ -469,10 +474,9 @@ __global__ __launch_bounds__(CSN_BLOCK, 2) void wgrad_bf16_c3_kernel(WgBf3Args a
           }
 #pragma unroll
           for (int tr = 0; tr < NTR; ++tr) {
-            const wgb_bf8 av = __builtin_bit_cast(wgb_bf8, A[tr]);
-            acc[3 * dy + 0][tr][tc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(wgb_bf8, cm), acc[3 * dy + 0][tr][tc], 0, 0, 0);
-            acc[3 * dy + 1][tr][tc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(wgb_bf8, c0), acc[3 * dy + 1][tr][tc], 0, 0, 0);
-            acc[3 * dy + 2][tr][tc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(wgb_bf8, cp), acc[3 * dy + 2][tr][tc], 0, 0, 0);
+            acc[3 * dy + 0][tr][tc] = csn_mfma_16x16x32_bf16(A[tr], cm, acc[3 * dy + 0][tr][tc]);
+            acc[3 * dy + 1][tr][tc] = csn_mfma_16x16x32_bf16(A[tr], c0, acc[3 * dy + 1][tr][tc]);
+            acc[3 * dy + 2][tr][tc] = csn_mfma_16x16x32_bf16(A[tr], cp, acc[3 * dy + 2][tr][tc]);
           }
         }
       }

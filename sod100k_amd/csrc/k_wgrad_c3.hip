@@ -130,7 +130,7 @@ __global__ __launch_bounds__(CSN_BLOCK, 2) void goct_wgrad_c3_kernel(WgArgs a_by
         }
         __syncthreads();
         // ---- contract over the wave's 64 pixels (tile rows 2 wave, 2 wave + 1), four at a time
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
         for (int sx = 0; sx < 16; ++sx)
           for (int t = 0; t < (two ? 2 : 1); ++t)
             for (int tp = 0; tp < 9; ++tp) {
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(CSN_BLOCK, 2) void goct_wgrad_c3_kernel(WgArgs a_by
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) {
               const float bv = bs[(tp / 3) * W3_TP + (tp % 3)];
-              acc[0][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc[0][tp], 0, 0, 0);
-              if (two) acc[1][tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc[1][tp], 0, 0, 0);
+              acc[0][tp] = csn_mfma_16x16x4(a0, bv, acc[0][tp]);
+              if (two) acc[1][tp] = csn_mfma_16x16x4(a1, bv, acc[1][tp]);
             }
           }
         }

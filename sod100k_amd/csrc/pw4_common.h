@@ -6,7 +6,7 @@
 namespace {
 
 template <int NT4> struct Pw4A {
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
   csn_f4 r[4][NT4 / 4];   // all four rows of every tile (lanes are sequential fibers: no cross-lane operand)
 #else
   csn_f4 r[1][NT4 / 4];   // this lane's row (lane & 3) of every tile
@@ -16,7 +16,7 @@ template <int NT4> struct Pw4A {
 // A operands of one input channel: wk = image row of the channel ([4][P] floats), already offset by (lane & 3) * P on the device
 template <int NT4, int P>
 __device__ __forceinline__ void pw4_load_a(const float* wk, Pw4A<NT4>& a) {
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
   for (int i = 0; i < 4; ++i)
     for (int u = 0; u < NT4 / 4; ++u)
       for (int e = 0; e < 4; ++e) a.r[i][u][e] = wk[i * P + 4 * u + e];
@@ -29,10 +29,10 @@ __device__ __forceinline__ void pw4_load_a(const float* wk, Pw4A<NT4>& a) {
 // acc[i] += W[4 t + i][k] * x   for the lane's own pixel
 template <int NT4>
 __device__ __forceinline__ void pw4_mfma(const Pw4A<NT4>& a, int t, float x, csn_f4& acc) {
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
   for (int i = 0; i < 4; ++i) acc[i] = fmaf(a.r[i][t >> 2][t & 3], x, acc[i]);
 #else
-  acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a.r[0][t >> 2][t & 3], x, acc, 0, 0, 0);
+  acc = csn_mfma_4x4x1(a.r[0][t >> 2][t & 3], x, acc);
 #endif
 }
 
@@ -129,7 +129,6 @@ __device__ __forceinline__ void pw4_lo_batch(const typename csn_bufacc<AT>::r1 (
 }
 
 // ---- v_mfma_f32_4x4x4_16B_bf16 from packed bfloat16 operands (bf16 train mode: k_pwq.hip pwq16_kernel, k_c3q.hip c3q16_kernel) ----
-typedef short pw16_s4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned pw16_perm(unsigned hi, unsigned lo, unsigned sel) {
 #ifdef CSN_CPU_EMU
@@ -144,14 +143,14 @@ __device__ __forceinline__ unsigned pw16_perm(unsigned hi, unsigned lo, unsigned
 
 // acc[i] += sum_k W[4 t + i][k0 + k] * x[k] for the lane's own element; a = the lane's row of the tile (device) / all four rows (emu)
 struct Pw16A {
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
   uint2 r[4];
 #else
   uint2 r[1];
 #endif
 };
 __device__ __forceinline__ void pw16_mfma(const Pw16A& a, uint2 x, csn_f4& acc) {
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
   const unsigned xs[4] = {x.x & 0xffffu, x.x >> 16, x.y & 0xffffu, x.y >> 16};
   for (int i = 0; i < 4; ++i) {
     const unsigned ws[4] = {a.r[i].x & 0xffffu, a.r[i].x >> 16, a.r[i].y & 0xffffu, a.r[i].y >> 16};
@@ -160,9 +159,7 @@ __device__ __forceinline__ void pw16_mfma(const Pw16A& a, uint2 x, csn_f4& acc) 
     acc[i] = sum;
   }
 #else
-  union { uint2 u; pw16_s4 s; } ca, cb;
-  ca.u = a.r[0]; cb.u = x;
-  acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ca.s, cb.s, acc, 0, 0, 0);
+  acc = csn_mfma_4x4x4_bf16(a.r[0], x, acc);
 #endif
 }
 
@@ -183,10 +180,10 @@ __device__ __forceinline__ float pw4_epi(float z, float sc, float sh, float al) 
 #endif
 
 __device__ __forceinline__ int pw4_uniform(int v) {
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
   return v;
 #else
-  return __builtin_amdgcn_readfirstlane(v);
+  return csn_readfirstlane(v);
 #endif
 }
 

@@ -3,16 +3,12 @@
 #pragma once
 #include "csn_kernels.h"
 
-#ifdef CSN_CPU_EMU
-struct csn_f4 {
-  float v[4];
-  float& operator[](int i) { return v[i]; }
-  float operator[](int i) const { return v[i]; }
-};
+#if defined(CSN_EMU_SEQ)
 // lanes of a wave run as sequential fibers: make LDS hand-offs inside a wave visible
 #define CSN_WAVE_SYNC() __syncthreads()
+#elif defined(CSN_EMU_LANES)
+#define CSN_WAVE_SYNC() csn_emu::lanes_wave_sync()
 #else
-typedef float csn_f4 __attribute__((ext_vector_type(4)));
 // a wave executes in lockstep and its LDS operations retire in order: only stop the compiler from
 // moving LDS accesses across the hand-off
 #define CSN_WAVE_SYNC() __builtin_amdgcn_wave_barrier()

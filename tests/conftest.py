@@ -32,6 +32,23 @@ def emu_lib():
 
 
 @pytest.fixture(scope="session")
+def emu_lanes_lib():
+    """The emulator's lane-exact mode (tests/emu `make LANES=1`): the kernels' DEVICE paths, with every cross-lane instruction
+    (MFMA lane maps, DPP moves, readfirstlane) executed as a rendezvous of the wave's 64 fibers (hip_cpu_shim.h).  Returns
+    (bound library, raw CDLL) -- the raw handle exposes csn_emu_lane_ops(kind), the count of executed cross-lane instructions."""
+    from sod100k_amd import _native as N
+    emu_dir = os.path.join(ROOT, "tests", "emu")
+    try:
+        subprocess.run(["make", "-C", emu_dir, "LANES=1", "-j8"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    except (OSError, subprocess.CalledProcessError) as e:
+        pytest.skip(f"cannot build the lane-exact CPU emulation of the kernels: {e}")
+    raw = ctypes.CDLL(os.path.join(emu_dir, "libcsnet_emu_lanes.so"))
+    raw.csn_emu_lane_ops.restype = ctypes.c_ulonglong
+    raw.csn_emu_lane_ops.argtypes = [ctypes.c_int]
+    return N.bind(raw), raw
+
+
+@pytest.fixture(scope="session")
 def x2_manifest():
     return os.path.join(DATA, "csnet-L-x2.json")
 
