@@ -277,6 +277,17 @@ __device__ __forceinline__ int csn_readfirstlane(int v) {
   return __builtin_amdgcn_readfirstlane(v);
 #endif
 }
+// the value of lane (lane ^ x)
+__device__ __forceinline__ double csn_shfl_xor(double v, int x) {
+#ifdef CSN_EMU_LANES
+  unsigned long long u; __builtin_memcpy(&u, &v, 8);
+  u = csn_emu::lanes_shfl_xor64(u, x);
+  __builtin_memcpy(&v, &u, 8);
+  return v;
+#else
+  return __shfl_xor(v, x, 64);
+#endif
+}
 // acc[i] += A[i] * b: A[i] = the `a` of lane (lane & ~3) + i, b the lane's own (v_mfma_f32_4x4x1_16b_f32)
 __device__ __forceinline__ csn_f4 csn_mfma_4x4x1(float a, float b, csn_f4 acc) {
 #ifdef CSN_EMU_LANES

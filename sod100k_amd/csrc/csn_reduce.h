@@ -5,7 +5,7 @@
 
 __device__ __forceinline__ double bn_block_sum(double v, double* sm) {
   const int tid = threadIdx.x;
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
   // same summation tree as the device version (butterfly per 64 lanes, then the four wave sums), but evaluated by
   // ONE fiber between two barriers: a barrier costs the emulator 256 context switches
   sm[tid] = v;
@@ -27,7 +27,7 @@ __device__ __forceinline__ double bn_block_sum(double v, double* sm) {
   return r;
 #else
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);   // butterfly inside the wave, fixed order
+  for (int o = 32; o > 0; o >>= 1) v += csn_shfl_xor(v, o);   // butterfly inside the wave, fixed order
   if ((tid & 63) == 0) sm[tid >> 6] = v;
   __syncthreads();
   const double r = (sm[0] + sm[1]) + (sm[2] + sm[3]);
@@ -39,14 +39,14 @@ __device__ __forceinline__ double bn_block_sum(double v, double* sm) {
 // N sums at once: the same summation tree per value as bn_block_sum, one pair of barriers for all of them
 template <int N>
 __device__ __forceinline__ void bn_block_sum_n(double (&v)[N], double* sm) {
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
   for (int t = 0; t < N; ++t) v[t] = bn_block_sum(v[t], sm);
 #else
   const int tid = threadIdx.x;
 #pragma unroll
   for (int t = 0; t < N; ++t) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v[t] += __shfl_xor(v[t], o, 64);
+    for (int o = 32; o > 0; o >>= 1) v[t] += csn_shfl_xor(v[t], o);
   }
   if ((tid & 63) == 0) {
 #pragma unroll

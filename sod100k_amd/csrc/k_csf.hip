@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void csf_gemm_kernel(CsfGemmArgs a) {
     const float* bw = Bb + wave * 64;
 #pragma unroll
     for (int kk = 0; kk < CSF_KC / 4; ++kk) {
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
       const int col = lane & 15;
       for (int i = 0; i < MT; ++i)
         for (int j = 0; j < 4; ++j)
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void csf_gemm_kernel(CsfGemmArgs a) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = csn_mfma_16x16x4(av[i], bv[j], acc[i][j]);
 #endif
     }
   }
@@ -198,28 +198,24 @@ __global__ __launch_bounds__(256) void csf_gemm_kernel(CsfGemmArgs a) {
 // Same block tile, gather, K order, split-K and launch order as csf_gemm_kernel; A is split on the way into LDS from the same
 // fp32 weight image.  LDS per buffer: A [3][2][BM][8] + B [3][2][256][8] bfloat16 (k-group-major: a lane's 16-byte operand reads
 // of a 32-row / 32-pixel tile are contiguous: no bank conflicts).
-#ifdef CSN_CPU_EMU
-struct csf_f16 {
-  float v[16];
-  float& operator[](int i) { return v[i]; }
-  float operator[](int i) const { return v[i]; }
-};
-#else
-typedef __bf16 csf_bf8 __attribute__((ext_vector_type(8)));
-typedef float csf_f16 __attribute__((ext_vector_type(16)));
-
+typedef csn_f16v csf_f16;
+#ifndef CSN_EMU_SEQ
 // three truncation parts of x as the upper halves of three floats (x == f(h) + f(m) + f(l) exactly)
 __device__ __forceinline__ void csf_split3(float x, unsigned& h, unsigned& m, unsigned& l) {
-  const unsigned xb = __float_as_uint(x);
+  const unsigned xb = csn_f_bits(x);
   h = xb & 0xffff0000u;
-  const float r1 = x - __uint_as_float(h);
-  m = __float_as_uint(r1) & 0xffff0000u;
-  const float r2 = r1 - __uint_as_float(m);
-  l = __float_as_uint(r2);
+  const float r1 = x - csn_bits_f(h);
+  m = csn_f_bits(r1) & 0xffff0000u;
+  const float r2 = r1 - csn_bits_f(m);
+  l = csn_f_bits(r2);
 }
 // bfloat16 pair (element 0 in the low half) from the upper halves of two floats
 __device__ __forceinline__ unsigned csf_pack2(unsigned lo_elem, unsigned hi_elem) {
+#ifdef CSN_CPU_EMU
+  return (lo_elem >> 16) | (hi_elem & 0xffff0000u);
+#else
   return __builtin_amdgcn_perm(hi_elem, lo_elem, 0x07060302u);   // bytes {lo[2], lo[3], hi[2], hi[3]}: one v_perm_b32
+#endif
 }
 #endif
 
@@ -305,8 +301,8 @@ __global__ __launch_bounds__(256) void csf_gemm3_kernel(CsfGemmArgs a) {
   for (int kc = c0; kc < c1; ++kc) {
     unsigned* Ab = As + ((kc - c0) & 1) * ASZ;
     unsigned* Bb = Bs + ((kc - c0) & 1) * BSZ;
-#ifdef CSN_CPU_EMU
-    // functional stand-in (the matrix instruction's lane map cannot run on fibers): the chunk as plain floats, row-major
+#ifdef CSN_EMU_SEQ
+    // functional stand-in (the lane map itself runs under `make LANES=1`, csn_device.h): the chunk as plain floats, row-major
     float* Af = reinterpret_cast<float*>(Ab);   // [BM][16] needs BM * 16 <= ASZ: 16 BM <= 24 BM
     float* Bf = reinterpret_cast<float*>(Bb);   // [256][16]
     if (a_ld) {
@@ -375,8 +371,7 @@ __global__ __launch_bounds__(256) void csf_gemm3_kernel(CsfGemmArgs a) {
         for (int j = 0; j < 2; ++j) bv[q][j] = *reinterpret_cast<const csn_u4*>(Bb + ((q * 2 + hh) * CSF_BN + wave * 64 + j * 32 + r32) * 4);
       }
 #define CSF_MMA(QA, QB)                                                                                                        \
-  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(csf_bf8, av[QA][i]), __builtin_bit_cast(csf_bf8, bv[QB][j]), \
-                                                      acc[i][j], 0, 0, 0)
+  acc[i][j] = csn_mfma_32x32x16_bf16(av[QA][i], bv[QB][j], acc[i][j])
 #pragma unroll
       for (int i = 0; i < TR; ++i)
 #pragma unroll
@@ -456,7 +451,7 @@ int csf_launch_gemm(const CsfGemmArgs& a, int mt, void* stream) {
 // log2(256)-step LDS tree: the tree's barriers were a quarter of a block's life)
 __device__ __forceinline__ double csf_block_sum(double v, double* sm) {
   const int tid = threadIdx.x;
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
   sm[tid] = v;
   __syncthreads();
   for (int s = CSN_BLOCK / 2; s > 0; s >>= 1) {
@@ -468,7 +463,7 @@ __device__ __forceinline__ double csf_block_sum(double v, double* sm) {
   return r;
 #else
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  for (int o = 32; o > 0; o >>= 1) v += csn_shfl_xor(v, o);
   if ((tid & 63) == 0) sm[tid >> 6] = v;
   __syncthreads();
   const double r = (sm[0] + sm[1]) + (sm[2] + sm[3]);

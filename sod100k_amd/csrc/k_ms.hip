@@ -14,11 +14,6 @@
 
 #include "csn_kernels.h"
 
-#ifdef CSN_CPU_EMU
-#define CSN_SCHED_FENCE()
-#else
-#define CSN_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
 
 __device__ __forceinline__ unsigned ms_tap_mask(int y, int x, int H, int W, int dil) {
   unsigned vm = 0;
@@ -213,10 +208,10 @@ __global__ __launch_bounds__(CSN_BLOCK) void msr_kernel(MsArgs a) {
   const int slot = blockIdx.x >> 3;
   const int b = (slot / bpi) * 8 + (int)(blockIdx.x & 7);
   if (b >= a.B) return;
-#ifdef CSN_CPU_EMU
+#ifdef CSN_EMU_SEQ
   const int wave = (int)threadIdx.x >> 6;
 #else
-  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wave = csn_readfirstlane((int)threadIdx.x >> 6);
 #endif
   const int w = (slot % bpi) * 4 + wave;
   const int d = w / wmax, wv = w - d * wmax;

@@ -31,9 +31,15 @@ extern "C" int csn_emu_lane_probe(int kind, const unsigned char* a, const unsign
       case 6: if (!masked || ub) r = csn_emu::lanes_dpp_wave_shr1(ua); break;
       case 7: if (!masked || ub) r = csn_emu::lanes_dpp_wave_shl1(ua); break;
       case 8: if (!masked || ub) r = csn_emu::lanes_readfirstlane(ua); break;
+      case 10: {   // 64-bit shuffle: a = the value (two dwords), b = the xor mask
+        unsigned long long v; std::memcpy(&v, la, 8);
+        v = csn_emu::lanes_shfl_xor64(v, (int)(ub & 63));
+        std::memcpy(&d[0], &v, 8);
+        break;
+      }
       default: bad = 1;
     }
-    if ((kind & 15) >= 6) std::memcpy(&d[0], &r, 4);
+    if ((kind & 15) >= 6 && (kind & 15) <= 8) std::memcpy(&d[0], &r, 4);
     for (int i = 0; i < 16; ++i) acc_out[16 * lane + i] = d[i];
   });
   return bad;

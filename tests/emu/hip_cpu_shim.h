@@ -103,6 +103,7 @@ void lanes_mfma_f32_16x16x32_bf16(const void* a8, const void* b8, float* d4);
 unsigned lanes_dpp_wave_shr1(unsigned v);   // lane i <- lane i - 1 (row_shr across the wave, bound_ctrl: 0 where there is no source)
 unsigned lanes_dpp_wave_shl1(unsigned v);   // lane i <- lane i + 1
 unsigned lanes_readfirstlane(unsigned v);
+unsigned long long lanes_shfl_xor64(unsigned long long v, int x);   // the 64-bit value of lane (lane ^ x): __shfl_xor(v, x, 64)
 void lanes_wave_sync();
 #endif
 }  // namespace csn_emu
@@ -381,6 +382,13 @@ __attribute__((noinline)) unsigned lanes_readfirstlane(unsigned v) {
   unsigned r; std::memcpy(&r, x.tab + 64 * __builtin_ctzll(x.mask), 4);
   return r;
 }
+__attribute__((noinline)) unsigned long long lanes_shfl_xor64(unsigned long long v, int xr) {
+  const unsigned lane = cur_thread() & 63, srcl = (lane ^ (unsigned)xr) & 63;
+  const Xchg x = wave_xchg(10, __builtin_return_address(0), &v, 8, false);
+  if (!((x.mask >> srcl) & 1ull)) lanes_fail("__shfl_xor from a lane that does not execute it");
+  unsigned long long r; std::memcpy(&r, x.tab + 64 * srcl, 8);
+  return r;
+}
 __attribute__((noinline)) void lanes_wave_sync() { (void)wave_xchg(9, __builtin_return_address(0), nullptr, 0, false); }
 #endif
 
@@ -501,7 +509,7 @@ void launch_named(const char* name, dim3 grid, dim3 block, size_t smem_bytes, co
 }  // namespace csn_emu
 #ifdef CSN_EMU_LANES
 // tests: the number of cross-lane instructions executed so far (kind: 1 mfma 4x4x1, 2 4x4x4 bf16, 3 16x16x4, 4 32x32x16 bf16,
-// 5 16x16x32 bf16, 6 / 7 DPP wave_shr / wave_shl, 8 readfirstlane, 9 wave sync); proof that the lane-exact paths ran
+// 5 16x16x32 bf16, 6 / 7 DPP wave_shr / wave_shl, 8 readfirstlane, 9 wave sync, 10 shuffle-xor); proof that the lane-exact paths ran
 extern "C" unsigned long long csn_emu_lane_ops(int kind) { return csn_emu::g_lane_ops[kind & 15]; }
 #endif
 #endif  // CSN_EMU_IMPL

@@ -48,8 +48,11 @@ __global__ __launch_bounds__(64) void lane_probe_kernel(int kind, const u4* a, c
     if (!masked || lb.x) r = (unsigned)__builtin_amdgcn_update_dpp(0, (int)la.x, 0x130, 0xf, 0xf, true);
   } else if (k == 8) {
     if (!masked || lb.x) r = (unsigned)__builtin_amdgcn_readfirstlane((int)la.x);
+  } else if (k == 10) {
+    const double v = __shfl_xor(__hiloint2double((int)la.y, (int)la.x), (int)(lb.x & 63), 64);
+    d[0] = __uint_as_float((unsigned)__double2loint(v)); d[1] = __uint_as_float((unsigned)__double2hiint(v));
   }
-  if (k >= 6) d[0] = __uint_as_float(r);
+  if (k >= 6 && k <= 8) d[0] = __uint_as_float(r);
   for (int i = 0; i < 16; ++i) acc_out[16 * lane + i] = d[i];
 }
 

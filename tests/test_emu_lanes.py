@@ -9,7 +9,7 @@ tests/test_gpu_lane_ops.py (the real instructions next to the shim's, bit for bi
 Instruction kinds counted by csn_emu_lane_ops: 1 v_mfma_f32_4x4x1 (pw4 / c3q / pwq / hz / ilb), 2 v_mfma_f32_4x4x4_bf16 (pwq16 /
 c3q16), 3 v_mfma_f32_16x16x4_f32 (generic contraction and weight-gradient kernels), 4 v_mfma_f32_32x32x16_bf16
 (wgrad_bf16_kernel), 5 v_mfma_f32_16x16x32_bf16 (wgrad_bf16_c3_kernel), 6 / 7 DPP wave_shr:1 / wave_shl:1 (c3q, ilb, the depthwise
-kernels), 8 readfirstlane."""
+kernels), 8 readfirstlane, 10 __shfl_xor (the fp64 block sums of csn_reduce.h)."""
 import torch
 
 from oracle import inputs as I
@@ -20,7 +20,7 @@ CPU = torch.device("cpu")
 
 
 def _ops(raw):
-    return [raw.csn_emu_lane_ops(k) for k in range(10)]
+    return [raw.csn_emu_lane_ops(k) for k in range(11)]
 
 
 def _ran(raw, before, kinds):
@@ -72,7 +72,7 @@ def test_lanes_train_step_fp32(emu_lanes_lib, x2_manifest):
     b = _ops(raw)
     P.check_train_forward(lib, CPU, x2_manifest, B=3, size=48)
     P.check_train_step(lib, CPU, x2_manifest)
-    print(_ran(raw, b, (1, 3, 6, 7)))
+    print(_ran(raw, b, (1, 3, 6, 7, 10)))
 
 
 def test_lanes_train_step_bf16(emu_lanes_lib, x2_manifest):
@@ -116,3 +116,25 @@ def test_lanes_instruction_definitions(emu_lanes_lib):
     assert np.array_equal(res(16 + 6, rb), shr)       # a masked-off source lane reads as 0 (bound_ctrl); masked-off lanes keep their value
     assert np.array_equal(res(16 + 7, rb), shl)
     assert np.array_equal(res(16 + 8, rb), np.where(on, v[np.argmax(on)], v).astype(np.uint32))
+    v64 = rng.integers(1, 2 ** 62, size=64).astype(np.uint64)
+    ra = np.zeros((64, 16), np.uint8); ra[:, :8] = v64.view(np.uint8).reshape(64, 8)
+    for x in (1, 32, 21):
+        rb = np.zeros((64, 16), np.uint8); rb[:, 0] = x
+        got = np.ascontiguousarray(L.probe(fn, 10, ra, rb, zero)[:, :2]).view(np.uint64)[:, 0]
+        assert np.array_equal(got, v64[np.arange(64) ^ x])
+
+
+def test_lanes_csf_head(emu_lanes_lib, monkeypatch):
+    """CSF+Res2Net head: csf_gemm3_kernel's real path -- the three-way bfloat16 split of the fp32 operands and six
+    v_mfma_f32_32x32x16_bf16 per product -- against the oracle with the GPU test's bounds."""
+    from oracle import csf_oracle as CO
+    import csf_cases as K
+    lib, raw = emu_lanes_lib
+    b = _ops(raw)
+    net, sd = K.build_csfnet("cpu", lib)
+    feats = CO.synthetic_features(3, 2, [(12, 16), (6, 8), (3, 4), (2, 2)])
+    y, ref, errs = K.head_errors(net, sd, feats, (48, 64))
+    assert errs["logits"] <= 1e-4, errs
+    assert max(v for k, v in errs.items() if k.startswith(("fuse.", "ms."))) <= 2e-4, errs
+    assert errs["hip_vs_fp64"] <= 3 * errs["oracle_vs_fp64"] + 2e-5, errs
+    print(errs, _ran(raw, b, (4,)))

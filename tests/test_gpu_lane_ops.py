@@ -68,3 +68,16 @@ def test_gpu_lane_moves(gpu_probe, emu_probe):
             hw = L.probe(gpu_probe, k, ra, rb, zero)[:, 0].copy().view(np.uint32)
             emu = L.probe(emu_probe, k, ra, rb, zero)[:, 0].copy().view(np.uint32)
             assert np.array_equal(hw, emu), (L.KINDS[kind], "masked" if i else "all lanes")
+
+
+def test_gpu_shuffle_xor(gpu_probe, emu_probe):
+    """__shfl_xor of a 64-bit value (the fp64 butterflies of csn_reduce.h)"""
+    rng = np.random.default_rng(9)
+    v = rng.integers(1, 2 ** 62, size=64).astype(np.uint64)
+    ra = np.zeros((64, 16), np.uint8); ra[:, :8] = v.view(np.uint8).reshape(64, 8)
+    zero = np.zeros((64, 16), np.float32)
+    for x in (1, 2, 4, 8, 16, 32, 5, 63):
+        rb = np.zeros((64, 16), np.uint8); rb[:, 0] = x
+        hw = np.ascontiguousarray(L.probe(gpu_probe, 10, ra, rb, zero)[:, :2]).view(np.uint64)[:, 0]
+        emu = np.ascontiguousarray(L.probe(emu_probe, 10, ra, rb, zero)[:, :2]).view(np.uint64)[:, 0]
+        assert np.array_equal(hw, emu) and np.array_equal(emu, v[np.arange(64) ^ x]), x
