@@ -122,8 +122,9 @@ int plan_goct_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
   // so no weight-gradient launch gathers bilinear taps (4 loads per channel and pixel at the finest resolution) and the
   // pass at resolution r is  [adj(dz_0); ..; adj(dz_{r-1}); dz_r] x x_r  (rows = consecutive rows of W, columns = block r)
   // plus  dz_r x [pool(x_0); ..; pool(x_{r-1})]  for the high -> low blocks.
-  bool regroup = d.ksize == 1 && !u.std_conv && (d.n_in > 1 || d.n_out > 1) && std::getenv("CSN_WGRAD_REGROUP") == nullptr;
-  for (int j = 0; j < d.n_out; ++j) regroup = regroup && d.cout[j] <= WG_MAX_ROWS;
+  // (an output branch wider than a launch holds -- the un-pruned x2 net's 132 / 144-channel heads -- is a pass of its own with ONE row
+  // source, which run_wgrad takes in row chunks; until round 6 such units kept the forward-shaped passes with bilinear gathers)
+  const bool regroup = d.ksize == 1 && !u.std_conv && (d.n_in > 1 || d.n_out > 1) && std::getenv("CSN_WGRAD_REGROUP") == nullptr;
   if (regroup) {
     for (int r = 0; r < d.n_in; ++r) {
       if (d.cin[r] == 0) continue;
@@ -468,6 +469,15 @@ int run_wgrad(const BwdCtx& b, const WgPlan& w, const PwBind& bd) {
   // the kernel holds at most 80 output channels (5 MFMA row tiles) per launch: wider passes go in row chunks
   // ... and passes with K <= 64 in chunks of 48 rows, which keeps them on the wave-private kernel
   int row_chunk = (a.nrs == 1 && a.k16 <= 64 && pp.nrows > 48) ? 48 : WG_MAX_ROWS;
+  // bf16 storage, dilated tap passes (MSBlock): wgrad_bf16_c3_kernel's dilated forms hold three row tiles -- the un-pruned net's
+  // 53-channel blocks go in chunks of 48 rows instead of falling back to the generic kernel
+  if (a.a16 && a.nrs == 1 && pp.nrows > 48) {
+    WgArgs t = a;
+    t.ps.nrows = std::min(pp.nrows, row_chunk); t.rows16 = (t.ps.nrows + 15) & ~15;
+    WgArgs t48 = a;
+    t48.ps.nrows = 48; t48.rows16 = 48;
+    if (!csn_wgrad_bf3_eligible(t) && csn_wgrad_bf3_eligible(t48)) row_chunk = 48;
+  }
   // Column pieces (round 6).  bf16 storage, 1x1 passes beyond wgrad_bf16_kernel's 4 x 4-tile limit (the un-pruned x2 net: 80 .. 160 rows
   // against 160 gathered channels) fell back to the generic kernel -- 13.6 of 87 ms per step.  The columns of dW are independent dot
   // products: such a pass goes in row chunks of 64 and pieces of <= 128 channels of ONE source, each a launch of the bf16 kernel with its
@@ -486,7 +496,7 @@ int run_wgrad(const BwdCtx& b, const WgPlan& w, const PwBind& bd) {
     if (a.a16 && (own || pool) && flat && w.blocks.size() <= 3 && !csn_wgrad_bf_eligible(t)) {
       // (several row sources -- the regrouped passes, <= 80 rows -- cannot go in row chunks: narrower pieces instead.  The kernel
       // takes at most 4 x 4 tiles of 32 rows / channels and 8 tiles in all)
-      const int rc = a.nrs == 1 ? 64 : std::min(pp.nrows, row_chunk);
+      const int rc = a.nrs == 1 ? 64 : std::min(pp.nrows, row_chunk);   // (96- and 128-row chunks measured: no difference)
       const int ntr = (rc + 31) / 32;
       const int pw = 32 * std::max(1, std::min(4, 8 / ntr));
       int k0 = 0;
@@ -498,7 +508,7 @@ int run_wgrad(const BwdCtx& b, const WgPlan& w, const PwBind& bd) {
       t2.ps.nrows = std::min(pp.nrows, rc); t2.rows16 = (t2.ps.nrows + 15) & ~15;
       t2.ps.nsrc = 1; t2.ps.src[0] = a.ps.src[pieces[0].s]; t2.ps.src[0].C = t2.ps.src[0].K = pieces[0].n;
       t2.ps.cin = pieces[0].n; t2.ps.cin4 = (pieces[0].n + 3) & ~3; t2.k16 = (pieces[0].n + 15) & ~15;
-      if (csn_wgrad_bf_eligible(t2)) row_chunk = a.nrs == 1 ? 64 : row_chunk;
+      if (csn_wgrad_bf_eligible(t2)) row_chunk = a.nrs == 1 ? rc : row_chunk;
       else pieces.clear();
     }
   }
@@ -958,7 +968,7 @@ static int enable_training_impl(csn_plan* P) {
     scratch = std::max(scratch, ub.scratch);
     for (const WgPlan& w : ub.wg) {
       const PwPassPlan& pp = w.L.passes[0];
-      const int rows = std::min(pp.nrows, WG_MAX_ROWS);
+      const int rows = std::min(pp.nrows, 128);   // (a launch's row chunk: <= 80 on the generic kernels, <= 128 on wgrad_bf16_kernel)
       wg_floats = std::max(wg_floats, (int64_t)WG_MAX_BLOCKS * ((rows + 15) & ~15) * ((pp.K + 15) & ~15));
     }
   }

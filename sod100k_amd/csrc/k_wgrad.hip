@@ -368,10 +368,10 @@ static int launch_wgrad_t(const WgArgs& a, void* stream) {
 }
 
 int csn_launch_wgrad(const WgArgs& a, void* stream) {
-  if (a.rows16 > 16 * WG_MAX_NT) return -1;
   if (csn_wgrad_bf3_eligible(a)) return csn_launch_wgrad_bf3(a, stream);   // bf16 tensors, 3x3 taps: shifted operands (k_wgrad_bf.hip)
   if (csn_wgrad_c3_eligible(a)) return csn_launch_wgrad_c3(a, stream);   // 3x3 tap slices: LDS-tiled (k_wgrad_c3.hip)
   if (csn_wgrad_bf_eligible(a)) return csn_launch_wgrad_bf(a, stream);   // bf16 tensors, 1x1: operands straight from the loads (k_wgrad_bf.hip)
+  if (a.rows16 > 16 * WG_MAX_NT) return -1;   // (the generic kernels: five row tiles; the bf16 forms above have their own limits)
   return a.a16 ? launch_wgrad_t<csn_bf16>(a, stream) : launch_wgrad_t<float>(a, stream);
 }
 
