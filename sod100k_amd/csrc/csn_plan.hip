@@ -190,7 +190,10 @@ struct csn_plan {
   bool dw_xl = true;      // CSN_DW_XL=0: train-mode depthwise launches in the round-4 geometry, halo columns loaded (see dw_lanes_x)
   bool ilb = true;        // CSN_OPT_FUSE_ILB / CSN_ILB=0: whole ILBlocks of the small maps on ilb_kernel (k_ilb.hip, round 5)
   int ilb_nt = 0;         // its row tiles per group and branch: 0 = chosen per block (plan_ilb), CSN_ILB_NT=1|2 forces (experiments)
-  int ilb_maxpix = 256;   // ... only where the low plane has at most this many pixels (CSN_ILB_MAXPIX)
+  int ilb_maxpix = 784;   // ... only where the low plane has at most this many pixels (CSN_ILB_MAXPIX).  Round 6: 256 -> 784 (the 56^2 / 28^2
+                          // blocks too): slower launch by launch (below), but with the batch in two slices on two stream lanes -- the
+                          // default for 32 images and more -- these latency chains run next to the other slice's bandwidth-bound
+                          // launches: 30,899 -> 31,008 img/s (three A/B pairs on one box), batch 1: 0.614 -> 0.599 ms
   bool pw4 = true;        // CSN_OPT_PW4: two-branch 1x1 units on pw4_kernel (k_pw4.hip)
   bool hz = true;         // CSN_HZ=0: the high output of the three-branch 1x1 units stays on pw4_kernel (A/B; k_head.hip)
   // its geometry, [0] for a unit with several outputs (CSFHead.fuse), [1] for a single-output unit (fuse1x1); the environment
@@ -932,7 +935,8 @@ int plan_ilb(Builder& bl, int k) {
   // Measured (round 5, tools/probes/ilb_bench.hip): every group of an image re-reads ALL of the image's input channels, and on the
   // 56^2 / 28^2 maps of stage 3 (7-10 groups, 370 KB of input per group, one 155 KB block per CU) the launch is bound by those
   // re-reads: 45-50 us against 35-40 us for pw4_kernel + the depthwise pair.  Stage 4 (28^2 / 14^2: 18-24 us against 29-37 us) and
-  // smaller planes win.  CSN_ILB_MAXPIX overrides the low-plane pixel limit.
+  // smaller planes win on their own; under the two-lane slice schedule stage 3 wins as well (ilb_maxpix above).  CSN_ILB_MAXPIX
+  // overrides the low-plane pixel limit.
   if (a.Hl * a.Wl > P.ilb_maxpix) return CSN_OK;
   size_t lds = csn_ilb_layout(a);
   if ((lds == 0 || lds > 160 * 1024) && a.nth > 1) {   // the planes of a narrower group
