@@ -30,6 +30,11 @@ struct DataLaunch {
   bool to_tmp = false;
   int pool_f = 0;     // to_tmp: max-pool factor of the routing kernel that follows
   int lvl_lo = 0;     // to_tmp: level of the temporary
+  // round 6 (`route`): the branch's ONE pooled term (factor 2) is contracted into the temporary FIRST (to_tmp chunks with route set: no
+  // routing kernel behind them) and the direct launch's chunks route it in their epilogue (PwqArgs::route_x); a direct chunk that
+  // cannot (not on pwq_kernel, width not a multiple of 4, CSN_POOL_ROUTE=0) leaves it to the routing kernel after the LAST direct chunk
+  bool route = false;
+  bool route_last = false;
 };
 
 struct WgRowSrc {     // `n` consecutive channels, starting at c0, of the tensor (kind, idx) with ctot channels
@@ -70,6 +75,7 @@ void push_data(UnitBwd& ub, const PwLaunchPlan& L, const DataLaunch& proto) {
     DataLaunch dl = proto;
     dl.L = parts[k];
     dl.to_tmp = proto.to_tmp && k + 1 == parts.size();
+    dl.route_last = proto.route && !proto.to_tmp && k + 1 == parts.size();
     ub.data.push_back(dl);
   }
 }
@@ -232,11 +238,19 @@ int plan_goct_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
       ps.wb.push_back(w);
       ps.K += d.cout[j] * kk;
     }
-    if (ps.nsrc > 0) {
+    // one pooled term with factor 2 behind a direct launch of a 1x1 unit: temporary first, routed by the direct launch (DataLaunch::route)
+    int npool = 0, jpool = -1;
+    for (int j = i + 1; j < d.n_out; ++j)
+      if (d.cout[j] > 0) { ++npool; jpool = j; }
+    const bool route = P.pool_route && ps.nsrc > 0 && npool == 1 && jpool == i + 1 && mode == PW_OWN;
+    auto push_direct = [&]() {
       L.passes.push_back(ps);
       DataLaunch dl;
-      dl.i = i;
+      dl.i = i; dl.route = route; dl.pool_f = 2; dl.lvl_lo = base + i + 1;
       push_data(ub, L, dl);
+    };
+    if (ps.nsrc > 0) {
+      if (!route) push_direct();
     } else {
       ub.zero_dx[i] = true;
     }
@@ -254,10 +268,11 @@ int plan_goct_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
       pq.K = d.cout[j] * kk;
       Lp.passes.push_back(pq);
       DataLaunch dl;
-      dl.i = i; dl.to_tmp = true; dl.pool_f = 1 << (j - i); dl.lvl_lo = base + j;
+      dl.i = i; dl.to_tmp = true; dl.pool_f = 1 << (j - i); dl.lvl_lo = base + j; dl.route = route;
       push_data(ub, Lp, dl);
       tmp_bytes = std::max(tmp_bytes, bl.act_bytes(d.cin[i], base + j));
     }
+    if (route) push_direct();
   }
   if (tmp_bytes > 0) ub.tmp_off = bw_alloc(ub, tmp_bytes);
   for (DataLaunch& dl : ub.data) {
@@ -822,10 +837,26 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
     ma.ng = ub.msdx_ng; ma.a16 = c.a16 ? 1 : 0; ma.pad = 0;
     LAUNCH_TRY(csn_launch_ms_dx(ma, c.stream));
   }
+  // DataLaunch::route: the direct chunks of a branch route the pooled term themselves where ALL of them run on pwq_kernel over rows
+  // of a multiple of four elements (decided per branch: a mixed set would leave rows unrouted or route them twice)
+  bool fuse_br[CSN_MAX_BRANCH] = {false, false, false};
+  for (int i = 0; i < d.n_in; ++i) {
+    int n = 0;
+    bool ok = P.pw4 && bd.in[i] != nullptr && bd.tmp != nullptr;
+    for (const DataLaunch& dl : ub.data)
+      if (dl.i == i && dl.route && !dl.to_tmp) {
+        ++n;
+        ok = ok && dl.L.pwq && dl.L.passes.size() == 1 && ((P.W >> dl.L.lvl) & 3) == 0 && ((P.H >> dl.L.lvl) & 1) == 0;
+      }
+    fuse_br[i] = ok && n > 0;
+  }
   for (const DataLaunch& dl : ub.data) {
-    const int st = launch_pw(c, dl.L, bd);
+    const bool fuse = dl.route && !dl.to_tmp && fuse_br[dl.i];
+    PwBind bq = bd;
+    if (fuse) { bq.route_x = bd.in[dl.i]; bq.route_t = bd.tmp; }
+    const int st = launch_pw(c, dl.L, bq);
     if (st != CSN_OK) return st;
-    if (dl.to_tmp) {
+    if ((dl.to_tmp && !dl.route) || (dl.route_last && !fuse)) {
       PoolBwdArgs pa;
       pa.x = bd.in[dl.i]; pa.t = bd.tmp; pa.dx = bd.dx[dl.i];
       pa.planes = S * d.cin[dl.i]; pa.Hl = P.H >> dl.lvl_lo; pa.Wl = P.W >> dl.lvl_lo; pa.f = dl.pool_f; pa.a16 = c.a16 ? 1 : 0;

@@ -306,6 +306,12 @@ struct PwqArgs {
   int32_t a16;         // tensors are bfloat16
   int32_t mfma16;      // ... on pwq16_kernel (v_mfma_f32_4x4x4_16B_bf16, weights of the pass rounded to bfloat16)
   int32_t grp_r0[PWQ_MAX_GROUPS], grp_nt[PWQ_MAX_GROUPS];
+  // round 6: the adjoint of a 2x2 max-pool routed in the epilogue (x_i was max-pooled into a lower output branch: the gradient
+  // W_ji^T dz_j at the LOW resolution is added to the window's first maximum while the rows are still in the accumulators --
+  // maxpool2_bwd_add_pair_kernel's read-modify-write pass over dx is gone).  Needs route_W % 4 == 0 and an even height.
+  const float* route_x = nullptr;   // the pooled tensor [B][out_ctot][HW], from the launch's first row on (null: no routing)
+  const float* route_t = nullptr;   // the low-resolution gradient [B][out_ctot][HW / 4], same rows
+  int32_t route_W = 0;              // row width at the pass resolution
 };
 int csn_pwq_max_tiles(void);
 int csn_launch_pwq(const PwqArgs& a, void* stream);

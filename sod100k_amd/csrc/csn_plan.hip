@@ -208,6 +208,8 @@ struct csn_plan {
   int pw4_twl = 6;        // log2 of its widest tile in low pixels: whole rows of up to 64 (CSN_PW4_TWL; 4 = 16 x 4 tiles: 1 % slower)
   bool pw4_flat = true;       // CSN_PW4_FLAT=0: row-segment tiles everywhere (round 3; A/B)
   bool pwq16 = true;          // CSN_PWQ16=0: 1x1 input-gradient launches of the bf16 step on pwq_kernel<bf16> (fp32 matrix instruction)
+  bool pool_route = true;     // CSN_POOL_ROUTE=0: the 2x2 max-pool adjoint of the 1x1 units as its own read-modify-write pass over dx
+                              // (maxpool2_bwd_add_pair_kernel) instead of pwq_kernel's epilogue (round 6; bit-identical in fp32, tests flip it)
   bool ms_dx = true;          // CSN_MS_DX=0: MSBlock input gradients on the generic tap kernel (two launches) instead of ms_dx_kernel
   int c3q16 = 1;              // CSN_C3Q16=0: the bf16 step's 3x3 INPUT-GRADIENT launches on c3q_kernel<bf16> instead of c3q16_kernel (the
                               // forward launches always keep fp32 weights: bf16 weights there put z of the stride-2 units past the unit-local bound)
@@ -1146,6 +1148,8 @@ struct PwBind {
   float* tmp = nullptr;                                // OUT_TMP
   const float* red_w = nullptr;                        // fused cls_layer: weights / bias, result -> `logits`
   const float* red_b = nullptr;
+  const float* route_x = nullptr;                      // OUT_DX launch on pwq_kernel: the max-pool adjoint routed in its epilogue --
+  const float* route_t = nullptr;                      // the pooled input branch / the low-resolution gradient (PwqArgs::route_x)
 };
 
 // kernel-side descriptor of one pass: source slices (resolved pointers), weight rows, output, epilogue
@@ -1238,11 +1242,19 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
     for (int g = 0; g < PWQ_MAX_GROUPS; ++g) { q.grp_r0[g] = L.pwq_r0[g]; q.grp_nt[g] = L.pwq_gnt[g]; }
     bool ok = q.out != nullptr;
     for (int s = 0; s < q.nsrc; ++s) ok = ok && q.src[s].ptr != nullptr;
+    if (bd.route_x) {   // (the caller has checked pwq_route_ok for this launch)
+      const PwPassPlan& pp = L.passes[0];
+      q.route_x = c.eo(bd.route_x, (int64_t)pp.out_c0 * q.HW);
+      q.route_t = c.eo(bd.route_t, (int64_t)pp.out_c0 * (q.HW >> 2));
+      q.route_W = a.W0;
+      if (!ok) { g_hip_err = "launch_pw: routed max-pool adjoint without its pwq launch"; return CSN_E_STATE; }
+    }
     if (ok) {
       LAUNCH_TRY(csn_launch_pwq(q, c.stream));
       return c.mark("pwq_kernel");
     }
   }
+  if (bd.route_x) { g_hip_err = "launch_pw: routed max-pool adjoint on a launch that is not pwq_kernel's"; return CSN_E_STATE; }
   if (P.c3q && P.tiled3 && L.c3q && (!c.a16 || c.raw)) {   // 3x3 forward pass: lane = output quad, operands from the load registers
     const PwPassPlan& pp = L.passes[0];
     bool ok = true;
@@ -1860,6 +1872,7 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   }
   if (std::getenv("CSN_PW4_NOQ")) P->pw4_no_q = true;
   if (const char* e = std::getenv("CSN_PW4_FLAT")) P->pw4_flat = std::atoi(e) != 0;
+  if (const char* e = std::getenv("CSN_POOL_ROUTE")) P->pool_route = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_ILB")) P->ilb = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_DWB_FAST")) P->dwb_fast = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("CSN_DW_XL")) P->dw_xl = std::atoi(e) != 0;

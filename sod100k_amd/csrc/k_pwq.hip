@@ -44,6 +44,63 @@ __device__ __forceinline__ void pwq_batch(const typename csn_bufacc<AT>::r4 (&ra
   }
 }
 
+// ---- the adjoint of a 2x2 max-pool routed in the epilogue (PwqArgs::route_x / route_t, round 6) ----
+// The lane's four elements are columns x .. x + 3 of row y of the plane (x % 4 == 0): the own halves of the windows (y >> 1, x >> 1)
+// and (y >> 1, (x >> 1) + 1).  Per output channel it reads its four values of the pooled tensor, the four of the window's other
+// row and the two low-resolution gradients, and adds a gradient where the window's FIRST maximum (row-major scan, `v > best ||
+// v != v` -- max_pool2d's rule, as maxpool2_bwd_add_pair_kernel) is one of its own elements.
+struct PwqRouteGeo {
+  unsigned off_n, off_t;   // byte offsets inside a channel plane: the other row's four elements / the gradient pair
+  bool odd;                // the own row is the window's second row
+};
+template <typename AT>
+__device__ __forceinline__ PwqRouteGeo pwq_route_geo(int e0, int W) {
+  constexpr unsigned E = (unsigned)sizeof(AT);
+  PwqRouteGeo g;
+  const int y = e0 / W, x = e0 - y * W;
+  g.odd = (y & 1) != 0;
+  g.off_n = (unsigned)(e0 + (g.odd ? -W : W)) * E;
+  g.off_t = (unsigned)((y >> 1) * (W >> 1) + (x >> 1)) * E;
+  return g;
+}
+__device__ __forceinline__ void pwq_route_window(float& d0, float& d1, float a0, float a1, float b0, float b1, float t, bool odd) {
+  const float w0 = odd ? b0 : a0, w1 = odd ? b1 : a1, w2 = odd ? a0 : b0, w3 = odd ? a1 : b1;   // scan order: top row first
+  float best = w0; int bi = 0;
+  if (w1 > best || w1 != w1) { best = w1; bi = 1; }
+  if (w2 > best || w2 != w2) { best = w2; bi = 2; }
+  if (w3 > best || w3 != w3) { best = w3; bi = 3; }
+  const int own = bi - (odd ? 2 : 0);
+  if (own == 0) d0 += t;
+  if (own == 1) d1 += t;
+}
+// one row tile (four output channels) of a lane: loads first, then the four routings, then the stores
+template <typename AT>
+__device__ __forceinline__ void pwq_store_tile(csn_buf ob, csn_buf xb, csn_buf tb, unsigned sv, unsigned off, const PwqRouteGeo& rg,
+                                               bool route, int row0, unsigned cs, const csn_f4 (&acc)[4]) {
+  typename csn_bufacc<AT>::r4 xo[4], xn[4];
+  typename csn_bufacc<AT>::r2 tv[4];
+  if (route) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned so = (unsigned)(row0 + i) * cs;
+      xo[i] = csn_bufacc<AT>::ldr4(xb, off, so);
+      xn[i] = csn_bufacc<AT>::ldr4(xb, rg.off_n, so);
+      tv[i] = csn_bufacc<AT>::ldr2(tb, rg.off_t, so >> 2);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float4 o = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+    if (route) {
+      const float4 a = csn_bufacc<AT>::cv4(xo[i]), n = csn_bufacc<AT>::cv4(xn[i]);
+      const float2 t = csn_bufacc<AT>::cv2(tv[i]);
+      pwq_route_window(o.x, o.y, a.x, a.y, n.x, n.y, t.x, rg.odd);
+      pwq_route_window(o.z, o.w, a.z, a.w, n.z, n.w, t.y, rg.odd);
+    }
+    csn_bufacc<AT>::st4(ob, sv, (unsigned)(row0 + i) * cs, o);   // (bfloat16: one 64-bit store)
+  }
+}
+
 }  // namespace
 
 template <int NT, typename AT>
@@ -120,15 +177,19 @@ __global__ __launch_bounds__(CSN_BLOCK, 16 * NT <= 96 ? 3 : 2) void pwq_kernel(P
     const int r0 = a->grp_r0[g], nt = a->grp_nt[g];
     const csn_buf ob = csn_make_buf_n(reinterpret_cast<char*>(a->out) + (int64_t)b * a->out_ctot * (int64_t)cs, (unsigned)a->nrows * cs);
     const unsigned sv = valid ? off : 0x80000000u;
+    const bool route = a->route_x != nullptr;   // (uniform)
+    PwqRouteGeo rg{0u, 0u, false};
+    csn_buf xb = ob, tb = ob;
+    if (route) {
+      rg = pwq_route_geo<AT>(min(q0, nq - 1) * 4, a->route_W);
+      xb = csn_make_buf_n(reinterpret_cast<const char*>(a->route_x) + (int64_t)b * a->out_ctot * (int64_t)cs, (unsigned)a->nrows * cs);
+      tb = csn_make_buf_n(reinterpret_cast<const char*>(a->route_t) + (int64_t)b * a->out_ctot * (int64_t)(cs >> 2), (unsigned)a->nrows * (cs >> 2));
+    }
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
       if (tt < nt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const unsigned so = (unsigned)(r0 + 4 * tt + i) * cs;
-          const float4 o = make_float4(acc[0][tt][i], acc[1][tt][i], acc[2][tt][i], acc[3][tt][i]);
-          csn_bufacc<AT>::st4(ob, sv, so, o);   // (bfloat16: one 64-bit store; two 32-bit ones until round 4)
-        }
+        const csn_f4 at[4] = {acc[0][tt], acc[1][tt], acc[2][tt], acc[3][tt]};
+        pwq_store_tile<AT>(ob, xb, tb, sv, off, rg, route, r0 + 4 * tt, cs, at);
       }
     }
   }
@@ -257,14 +318,19 @@ __global__ __launch_bounds__(CSN_BLOCK, 16 * NT <= 96 ? 3 : 2) void pwq16_kernel
     const int r0 = a->grp_r0[g], nt = a->grp_nt[g];
     const csn_buf ob = csn_make_buf_n(reinterpret_cast<char*>(a->out) + (int64_t)b * a->out_ctot * (int64_t)cs, (unsigned)a->nrows * cs);
     const unsigned sv = valid ? off : 0x80000000u;
+    const bool route = a->route_x != nullptr;   // (uniform)
+    PwqRouteGeo rg{0u, 0u, false};
+    csn_buf xb = ob, tb = ob;
+    if (route) {
+      rg = pwq_route_geo<csn_bf16>(min(q0, nq - 1) * 4, a->route_W);
+      xb = csn_make_buf_n(reinterpret_cast<const char*>(a->route_x) + (int64_t)b * a->out_ctot * (int64_t)cs, (unsigned)a->nrows * cs);
+      tb = csn_make_buf_n(reinterpret_cast<const char*>(a->route_t) + (int64_t)b * a->out_ctot * (int64_t)(cs >> 2), (unsigned)a->nrows * (cs >> 2));
+    }
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
       if (tt < nt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const unsigned so = (unsigned)(r0 + 4 * tt + i) * cs;
-          csn_bufacc<csn_bf16>::st4(ob, sv, so, make_float4(acc[0][tt][i], acc[1][tt][i], acc[2][tt][i], acc[3][tt][i]));
-        }
+        const csn_f4 at[4] = {acc[0][tt], acc[1][tt], acc[2][tt], acc[3][tt]};
+        pwq_store_tile<csn_bf16>(ob, xb, tb, sv, off, rg, route, r0 + 4 * tt, cs, at);
       }
     }
   }

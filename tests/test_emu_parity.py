@@ -301,6 +301,24 @@ def test_emu_backward_with_weight_gradient_side_lane(emu_lib, x2_manifest, monke
     assert torch.equal(flats["1"], flats["2"]), float((flats["1"] - flats["2"]).abs().max())
 
 
+def test_emu_max_pool_adjoint_routed_in_the_input_gradient_launch(emu_lib, x2_manifest, monkeypatch):
+    """Round 6: pwq_kernel's epilogue routes the 2x2 max-pool adjoint of the 1x1 units (PwqArgs::route_x) instead of
+    maxpool2_bwd_add_pair_kernel's read-modify-write pass over dx (CSN_POOL_ROUTE=0).  fp32: the same additions in the same order --
+    every gradient bit for bit, and the routing kernel's launches are gone; 48 x 80 pictures put odd row counts into the
+    item tiles (lanes whose window partner row lies in another wave's tile)."""
+    flats = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("CSN_POOL_ROUTE", sw)
+        m, sd = P.make_model(emu_lib, x2_manifest, CPU)
+        m.train(); m.set_batchsize(2); m.clear_flops(); m.flops_hook(1.0)
+        x = torch.from_numpy(I.randn_batch(41, 2, 48, 80))
+        t = torch.from_numpy(I.binary_target(42, 2, 48, 80))
+        y, pen = m._train_forward_raw(x)
+        loss, dy = P.bce_and_grad(emu_lib, y, t)
+        flats[sw] = m._train_backward_raw(x, dy, 1.5).clone()
+    assert torch.equal(flats["1"], flats["0"]), float((flats["1"] - flats["0"]).abs().max())
+
+
 def test_emu_results_do_not_depend_on_the_tile_geometry(emu_lib, x2_manifest, monkeypatch):
     """pw4_kernel / c3q_kernel tiles as 16 x 4 blocks (CSN_PW4_TWL = CSN_C3Q_TWL = 4), as row segments (6 with CSN_PW4_FLAT=0, round 3)
     or as 64 consecutive pixels of the plane (flat tiles, the default where rows do not fill their tiles): the same per-pixel
