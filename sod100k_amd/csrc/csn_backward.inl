@@ -1037,6 +1037,28 @@ static int enable_training_impl(csn_plan* P) {
         u.bnred_off[i] = bl.alloc_ws((int64_t)u.d.cout[i] * CSN_BN_NSLAB * 3 * sizeof(double));
       }
     }
+  // bf16 mode: the 1x1 units on pw4_kernel leave their outputs' statistics partials themselves (Pw4Args::stats_h), one slab per
+  // (image, item tile) of the launch that stores the branch
+  if (P->act16 && P->pw4 && P->pw4_stats)
+    for (int k = 0; k < nu; ++k) {
+      UnitPlan& u = P->units[k];
+      if (u.d.kind != CSN_UNIT_GOCT || !u.pw4 || u.pw4l.empty()) continue;
+      int writers[CSN_MAX_BRANCH] = {0, 0, 0};
+      for (const UnitPlan::Pw4Launch& L : u.pw4l)
+        for (int j : {L.hi_out, L.lo_out})
+          if (j >= 0) ++writers[j];
+      for (const UnitPlan::Pw4Launch& L : u.pw4l) {
+        int twl, tx, ty;
+        pw4_tile_geo(*P, P->H >> (u.base_lvl + L.bl), P->W >> (u.base_lvl + L.bl), &twl, &tx, &ty);
+        const int64_t n = (int64_t)P->S * tx * ty;
+        if (n > (1 << 20) || !csn_pw4_has_stats(L.nth, L.ntl)) continue;
+        for (int j : {L.hi_out, L.lo_out}) {
+          if (j < 0 || u.d.cout[j] == 0 || ((u.pw4_old_mask >> j) & 1) || writers[j] != 1) continue;
+          u.pstats_off[j] = bl.alloc_ws((int64_t)u.d.cout[j] * n * 2 * sizeof(double));
+          u.pstats_n[j] = (int)n;
+        }
+      }
+    }
   P->scratch_bytes = scratch;
   P->scratch_off = bl.alloc_ws(scratch > 0 ? scratch : 256);
   P->wg_region_floats = wg_floats;

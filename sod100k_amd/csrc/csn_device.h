@@ -288,6 +288,49 @@ __device__ __forceinline__ double csn_shfl_xor(double v, int x) {
   return __shfl_xor(v, x, 64);
 #endif
 }
+// the float of lane (lane ^ X), X a power of two: inside a row of 16 lanes by DPP (quad_perm; row_shl:4 / row_shr:4 under bank masks;
+// row_ror:8), across rows by ds_bpermute
+template <int X>
+__device__ __forceinline__ float csn_lane_xor_f32(float v) {
+#ifdef CSN_EMU_LANES
+  return (float)csn_shfl_xor((double)v, X);
+#else
+  const int i = __float_as_int(v);
+  if (X == 1) return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0xB1, 0xf, 0xf, true));    // quad_perm:[1,0,3,2]
+  if (X == 2) return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0x4E, 0xf, 0xf, true));    // quad_perm:[2,3,0,1]
+  if (X == 4) {   // banks 0 / 2 of a row (lanes 0-3, 8-11) read lane + 4, banks 1 / 3 read lane - 4
+    int r = __builtin_amdgcn_update_dpp(0, i, 0x104, 0xf, 0x5, false);   // row_shl:4
+    r = __builtin_amdgcn_update_dpp(r, i, 0x114, 0xf, 0xa, false);       // row_shr:4
+    return __int_as_float(r);
+  }
+  if (X == 8) return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0x128, 0xf, 0xf, true));   // row_ror:8
+  return __shfl_xor(v, X, 64);
+#endif
+}
+// Sums over the wave of EIGHT per-lane values at once: in the stages X = 32, 16, 8 a lane keeps the values whose index parity equals
+// its bit X and adds the partner's copies (8 -> 4 -> 2 -> 1 values: 7 exchanges + additions), then a butterfly over the lanes that
+// share bits 5 .. 3 (3 more) -- 10 instead of 6 x 8.  Every lane ends with the wave's total of value 4 * bit3 + 2 * bit4 + bit5 of
+// its lane number.  One fixed summation tree per value: deterministic.
+template <int N, int X>
+__device__ __forceinline__ void csn_rs_stage(float* v, bool bit) {
+#pragma unroll
+  for (int j = 0; j < N / 2; ++j) {
+    const float keep = bit ? v[2 * j + 1] : v[2 * j];
+    const float send = bit ? v[2 * j] : v[2 * j + 1];
+    v[j] = keep + csn_lane_xor_f32<X>(send);
+  }
+}
+__device__ __forceinline__ float csn_wave_reduce_scatter8(float (&v)[8], int lane) {
+  csn_rs_stage<8, 32>(v, (lane & 32) != 0);
+  csn_rs_stage<4, 16>(v, (lane & 16) != 0);
+  csn_rs_stage<2, 8>(v, (lane & 8) != 0);
+  float t = v[0];
+  t += csn_lane_xor_f32<4>(t);
+  t += csn_lane_xor_f32<2>(t);
+  t += csn_lane_xor_f32<1>(t);
+  return t;
+}
+__device__ __forceinline__ int csn_rs8_index(int lane) { return ((lane & 8) >> 1) | ((lane & 16) >> 3) | ((lane & 32) >> 5); }
 // acc[i] += A[i] * b: A[i] = the `a` of lane (lane & ~3) + i, b the lane's own (v_mfma_f32_4x4x1_16b_f32)
 __device__ __forceinline__ csn_f4 csn_mfma_4x4x1(float a, float b, csn_f4 acc) {
 #ifdef CSN_EMU_LANES

@@ -227,8 +227,15 @@ struct Pw4Args {
   int32_t max_grid;
   int32_t a16;              // activation tensors are bfloat16 (raw launches of the bf16 train mode), else float
   Pw4Group grp[PW4_MAX_GROUPS];
+  // round 6 (raw launches over bfloat16 tensors): the BatchNorm statistics of the stored outputs from the epilogue -- per (channel,
+  // item tile) the wave's sums of z and z^2 (of the ROUNDED values, fp32 tree over the wave: exact for bfloat16 operands of one
+  // magnitude), slab = image * tiles + tile; bn_finalize sums the slabs in a fixed order.  bn_stats_kernel's pass over z is gone.
+  double* stats_h = nullptr;   // [OH][stats_stride][2] (null: none)
+  double* stats_l = nullptr;   // [OL][stats_stride][2]
+  int32_t stats_stride = 0;    // slabs per channel = B * tiles_x * tiles_y
 };
 bool csn_pw4_pick(int nth, int ntl, int* pnth, int* pntl);
+bool csn_pw4_has_stats(int nth, int ntl);
 int csn_launch_pw4(const Pw4Args& a, int raw, void* stream);
 
 // ---------------------------------------------------------------------------------------------
@@ -472,6 +479,7 @@ struct BnFinalizeArgs {
   int32_t C;
   int32_t S;
   int32_t nslab;      // set by the launcher; > 0 on entry: partials were written by the convolution kernel, that many per channel
+  int32_t pstride = 0;// slabs between two channels of `partial` (0: CSN_BN_NSLAB; pw4_kernel's own statistics: nslab)
 };
 struct BnApplyArgs {
   const float* z;     // raw conv output (kept for the backward pass)

@@ -130,6 +130,8 @@ struct UnitPlan {
   int64_t gap_off[3] = {-1, -1, -1};
   int64_t gapin_off[3] = {-1, -1, -1};   // depthwise unit, training: per-tile plane sums of an input that is never stored (virt_cons)
   int64_t bnred_off[3] = {-1, -1, -1};   // ... and the BatchNorm-backward sums of its producer, taken by this unit's backward kernel
+  int64_t pstats_off[3] = {-1, -1, -1};  // 1x1 unit on pw4_kernel, bf16 training: statistics partials its epilogue writes, [C][pstats_n][2]
+  int pstats_n[3] = {0, 0, 0};           // ... slabs per channel (image x item tile of the launch that stores the branch)
   int64_t dwwg_off[3] = {-1, -1, -1};    // depthwise unit, training: its own weight-gradient partials [C][NSLAB][9] (finalised by ONE
                                          // launch for all units at the end of csn_backward instead of one per unit and branch)
   int in_slot[3] = {-1, -1, -1};
@@ -210,6 +212,8 @@ struct csn_plan {
   bool pwq16 = true;          // CSN_PWQ16=0: 1x1 input-gradient launches of the bf16 step on pwq_kernel<bf16> (fp32 matrix instruction)
   bool pool_route = true;     // CSN_POOL_ROUTE=0: the 2x2 max-pool adjoint of the 1x1 units as its own read-modify-write pass over dx
                               // (maxpool2_bwd_add_pair_kernel) instead of pwq_kernel's epilogue (round 6; bit-identical in fp32, tests flip it)
+  bool pw4_stats = true;      // CSN_PW4_STATS=0: bn_stats_kernel's pass over the bf16 train forward's 1x1 outputs instead of pw4_kernel's
+                              // epilogue sums (round 6; tests flip it)
   bool ms_dx = true;          // CSN_MS_DX=0: MSBlock input gradients on the generic tap kernel (two launches) instead of ms_dx_kernel
   int c3q16 = 1;              // CSN_C3Q16=0: the bf16 step's 3x3 INPUT-GRADIENT launches on c3q_kernel<bf16> instead of c3q16_kernel (the
                               // forward launches always keep fp32 weights: bf16 weights there put z of the stride-2 units past the unit-local bound)
@@ -1027,6 +1031,7 @@ struct Ctx {
   bool side = false;  // backward: this context enqueues on the weight-gradient side lane (own partial buffers)
   bool a16 = false;   // bf16 train mode: every activation tensor in the workspace is bfloat16
   bool dw_stats = false;   // train-mode forward: depthwise units reduce their own BN statistics
+  bool pw4_stats = false;  // ... and this 1x1 unit's pw4_kernel launches theirs (bf16 mode, pw4_unit_stats)
   std::vector<GapTilesArgs>* gap_defer = nullptr;   // train-mode forward: |GAP| table jobs collected for one launch at the end
   const float* sc(const Epi& e) const { return P.packed + (raw ? P.ident.scale : e.scale); }
   const float* sh(const Epi& e) const { return P.packed + (raw ? P.ident.shift : e.shift); }
@@ -1204,6 +1209,23 @@ void fill_pass(const Ctx& c, const PwLaunchPlan& L, const PwPassPlan& pp, const 
   ps.scale = bn_out ? c.sc(pp.epi) : c.pk(pp.epi.scale);
   ps.shift = bn_out ? c.sh(pp.epi) : c.pk(pp.epi.shift);
   ps.alpha = bn_out ? c.al(pp.epi) : c.pk(pp.epi.alpha);
+}
+
+// item tiles of a pw4_kernel launch over an Hl x Wl low map: row segments, or 64 consecutive pixels where rows do not fill their tiles
+void pw4_tile_geo(const csn_plan& P, int Hl, int Wl, int* ptwl, int* ptx, int* pty) {
+  int twl = 0;
+  while (twl < P.pw4_twl && (1 << twl) < Wl) ++twl;
+  int tx = (Wl + (1 << twl) - 1) >> twl, ty = (Hl + (64 >> twl) - 1) / (64 >> twl);
+  if (P.pw4_flat && tx * ty > (Hl * Wl + 63) / 64) { twl = PW4_FLAT_TWL; tx = (Hl * Wl + 63) / 64; ty = 1; }
+  *ptwl = twl; *ptx = tx; *pty = ty;
+}
+// bf16 train forward: every output branch of the unit gets its statistics from pw4_kernel's epilogue (UnitPlan::pstats_off, laid
+// out by csn_plan_enable_training)
+bool pw4_unit_stats(const csn_plan& P, const UnitPlan& u) {
+  if (!P.pw4_stats || !P.pw4 || !u.pw4 || u.d.kind != CSN_UNIT_GOCT) return false;
+  for (int j = 0; j < u.d.n_out; ++j)
+    if (u.d.cout[j] > 0 && u.pstats_off[j] < 0) return false;
+  return true;
 }
 
 int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
@@ -1516,13 +1538,11 @@ int run_unit(const Ctx& c, const UnitPlan& u, const UnitPlan* next = nullptr) {
           if (L.use_x2 && L.lo_out < 0) { a.CL = 1; a.C2 = 1; }
 #endif
           a.Hl = P.H >> (u.base_lvl + L.bl); a.Wl = P.W >> (u.base_lvl + L.bl); a.B = S;
-          int twl = 0;
-          while (twl < P.pw4_twl && (1 << twl) < a.Wl) ++twl;
-          a.twl = twl;
-          a.tiles_x = (a.Wl + (1 << twl) - 1) >> twl;
-          a.tiles_y = (a.Hl + (64 >> twl) - 1) / (64 >> twl);
-          if (P.pw4_flat && a.tiles_x * a.tiles_y > (a.Hl * a.Wl + 63) / 64) {   // rows that do not fill their tiles: flat tiles
-            a.twl = PW4_FLAT_TWL; a.tiles_x = (a.Hl * a.Wl + 63) / 64; a.tiles_y = 1;
+          pw4_tile_geo(P, a.Hl, a.Wl, &a.twl, &a.tiles_x, &a.tiles_y);
+          if (c.raw && c.a16 && c.pw4_stats) {   // statistics of the stored outputs from the epilogue (forward_train_body skips bn_stats)
+            if (L.hi_out >= 0 && u.pstats_off[L.hi_out] >= 0) a.stats_h = reinterpret_cast<double*>(c.ws + u.pstats_off[L.hi_out]);
+            if (L.lo_out >= 0 && u.pstats_off[L.lo_out] >= 0) a.stats_l = reinterpret_cast<double*>(c.ws + u.pstats_off[L.lo_out]);
+            a.stats_stride = a.tiles_x * a.tiles_y * a.B;
           }
           a.ngroups = L.ng; a.gimg_floats = L.gimg; a.nth = L.nth; a.ntl = L.ntl;
           a.max_grid = P.pw4_grid; a.a16 = c.a16 ? 1 : 0;
@@ -1873,6 +1893,7 @@ int csn_plan_create(const csn_unit_desc* units, int32_t n_units, const csn_act_d
   if (std::getenv("CSN_PW4_NOQ")) P->pw4_no_q = true;
   if (const char* e = std::getenv("CSN_PW4_FLAT")) P->pw4_flat = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_POOL_ROUTE")) P->pool_route = std::atoi(e) != 0;
+  if (const char* e = std::getenv("CSN_PW4_STATS")) P->pw4_stats = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_ILB")) P->ilb = std::atoi(e) != 0;
   if (const char* e = std::getenv("CSN_DWB_FAST")) P->dwb_fast = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("CSN_DW_XL")) P->dw_xl = std::atoi(e) != 0;
@@ -2344,7 +2365,10 @@ static int forward_train_body(csn_plan* P, const float* x, float* y, void* works
     const UnitPlan& up = P->units[u];
     const csn_unit_desc& d = up.d;
     c.raw = d.kind != CSN_UNIT_CLS;
-    const bool stats_done = dw_unit_stats(*P, up);     // the depthwise kernel writes the statistics partials itself
+    const bool next_cls = u + 1 < nu && P->units[u + 1].d.kind == CSN_UNIT_CLS;   // (run_unit keeps that unit off pw4_kernel in train mode)
+    const bool pw4_st = c.a16 && !next_cls && pw4_unit_stats(*P, up);
+    c.pw4_stats = pw4_st;
+    const bool stats_done = pw4_st || dw_unit_stats(*P, up);   // the convolution kernel writes the statistics partials itself
     const int st = run_unit(c, up, nullptr);           // raw z of every output branch (no depthwise fusion)
     if (st != CSN_OK) return st;
     if (d.kind == CSN_UNIT_CLS) continue;
@@ -2360,7 +2384,8 @@ static int forward_train_body(csn_plan* P, const float* x, float* y, void* works
       BnStatsArgs sa; sa.z = z; sa.partial = part; sa.S = P->S; sa.C = d.cout[j]; sa.HW = hw; sa.a16 = c.a16 ? 1 : 0;
       if (!stats_done) LAUNCH_TRY(csn_launch_bn_stats(sa, stream));
       BnFinalizeArgs& fa = fas[nfa]; fa.partial = part; fa.arena = arena;
-      fa.nslab = stats_done ? dw_stats_slabs(*P, act.lvl) : 0;
+      fa.nslab = pw4_st ? up.pstats_n[j] : stats_done ? dw_stats_slabs(*P, act.lvl) : 0;
+      if (pw4_st) { fa.partial = reinterpret_cast<double*>(c.ws + up.pstats_off[j]); fa.pstride = up.pstats_n[j]; }
       fa.scale = P->packed + up.out_epi[j].scale; fa.shift = P->packed + up.out_epi[j].shift;
       fa.off_weight = d.bn[j].weight; fa.off_bias = d.bn[j].bias; fa.off_rmean = d.bn[j].running_mean;
       fa.off_rvar = d.bn[j].running_var; fa.count = (int64_t)P->S * hw; fa.C = d.cout[j]; fa.S = P->S;

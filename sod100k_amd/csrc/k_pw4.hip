@@ -24,6 +24,8 @@
 //     (shared inputs hit L1).  Channel counts are run-time (loops over batches of HB / LB channels, next batch's loads
 //     issued before the current batch is contracted); the tile counts are the template parameters.
 //   * HBM traffic = unit inputs once + outputs once; tiles are walked in the XCD-aware order of k_goct_pw.hip.
+#include <cstring>
+
 #include "pw4_common.h"
 
 // Three-branch units (CSFHead.fuse / fuse1x1, csnet.py:152-206) add a third input x2 at half the resolution of branch l; it
@@ -169,6 +171,22 @@ __device__ __forceinline__ void pw4_xq_channel(const typename csn_bufacc<AT>::r4
   for (int t = 0; t < NTL; ++t) pw4_mfma<NT4>(a, t, m, accl[t]);
 }
 
+// Statistics of one row tile of an item (Pw4Args::stats_h / stats_l): v = the lane's {sum, sum of squares} of its stored values
+// of the tile's four rows (2 i + {0, 1}; zeros for lanes outside the map).  The eight values are summed over the wave
+// (csn_wave_reduce_scatter8) and leave with one store by eight lanes: slab `tile` of channels c0 .. c0 + 3 of `tab` (C channels).
+__device__ __forceinline__ void pw4_stats_tile(double* tab, int c0, int C, int64_t stride, int tile, float (&v)[8], int lane) {
+  if (!tab) return;   // (uniform)
+#ifdef CSN_EMU_SEQ
+  // stand-in (the lanes are sequential fibers; the launcher has zeroed the tables): every lane adds its own values
+  for (int k = 0; k < 8; ++k)
+    if (c0 + (k >> 1) < C) tab[((int64_t)(c0 + (k >> 1)) * stride + tile) * 2 + (k & 1)] += (double)v[k];
+#else
+  const float tot = csn_wave_reduce_scatter8(v, lane);
+  const int k = csn_rs8_index(lane), c = c0 + (k >> 1);
+  if ((lane & 7) == 0 && c < C) tab[((int64_t)c * stride + tile) * 2 + (k & 1)] = (double)tot;
+#endif
+}
+
 }  // namespace
 
 // MODE 0: BN + PReLU epilogue, rows stored; 1 (RAW): plain sums stored; 2 (RED): BN + PReLU, rows reduced with red_w
@@ -179,6 +197,11 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
                                      // third input's staging registers: two waves from five row tiles on)
   constexpr bool RAW = MODE == 1, RED = MODE == 2;
   constexpr unsigned E = (unsigned)sizeof(AT);
+  // Pw4Args::stats_h / stats_l: raw launches over bfloat16 tensors, forms with a low output.  The sums are formed whenever the form
+  // has them (a run-time switch around the epilogue's statistics cost 30-80 registers: spills at the 168-register cap); only the
+  // stores depend on the pointers.  The high-only forms also stage the third input and have no registers to spare: their units'
+  // statistics stay with bn_stats_kernel (csn_pw4_has_stats)
+  constexpr bool STATS = RAW && E == 2 && NTL > 0;
   // load batches: the low-only form contracts ~2 MFMAs per loaded value and has few accumulators -- its batches are deep
   // (every batch is one exposed memory round trip per item)
   // (bfloat16: the deeper high batches for the two-output forms only -- the high-only forms, which also stage the third input, spill with them)
@@ -190,6 +213,7 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
   csn_fill_lds16(lds, a->wimg, (a->ngroups * a->gimg_floats) >> 2, tid);
   __syncthreads();
   const int lane = tid & 63, wave = pw4_uniform(tid >> 6);
+  constexpr bool do_stats = STATS;
   const int CH = a->CH, CL = a->CL, Hl = a->Hl, Wl = a->Wl, Wh = 2 * Wl;
   const unsigned csl = (unsigned)(Hl * Wl) * E, csh = csl * 4u;   // channel strides in bytes
   const int twl = a->twl;
@@ -408,12 +432,21 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
 #pragma unroll
       for (int t = 0; t < NTH; ++t) {
         if (t < nt) {
+          float stv[8];   // statistics: the lane's {sum, sum of squares} per row of the tile
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int r = 4 * t + i;
             float o[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) o[s] = RAW ? acch[s][t][i] : pw4_epi(acch[s][t][i], ep[4 * r], ep[4 * r + 1], ep[4 * r + 2]);
+            if constexpr (STATS) {
+              if (do_stats) {   // sums of the values as they are stored (rounded to bfloat16)
+                const float2 u0 = csn_bufacc<csn_bf16>::cv2(csn_pack_bf2(o[0], o[1])), u1 = csn_bufacc<csn_bf16>::cv2(csn_pack_bf2(o[2], o[3]));
+                const float s1 = (u0.x + u0.y) + (u1.x + u1.y);
+                const float s2 = fmaf(u0.x, u0.x, u0.y * u0.y) + fmaf(u1.x, u1.x, u1.y * u1.y);
+                stv[2 * i] = valid ? s1 : 0.f; stv[2 * i + 1] = valid ? s2 : 0.f;
+              }
+            }
             if (RED) {   // fused 1x1 consumer: accumulate red_w[row] * y per quad pixel, nothing is stored here
               const float rw = csn_const(a->red_w)[r0 + r];
 #pragma unroll
@@ -423,6 +456,9 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
             const unsigned so = (unsigned)(r0 + r) * csh;
             csn_bufacc<AT>::st2(ob, sv0, so, make_float2(o[0], o[1]));
             csn_bufacc<AT>::st2(ob, sv1, so, make_float2(o[2], o[3]));
+          }
+          if constexpr (STATS) {
+            if (do_stats) pw4_stats_tile(a->stats_h, r0 + 4 * t, a->OH, a->stats_stride, tile, stv, lane);
           }
         }
       }
@@ -439,11 +475,21 @@ void pw4_kernel(Pw4Args a_byval) {   // three waves per SIMD where the accumulat
 #pragma unroll
       for (int t = 0; t < NTL; ++t) {
         if (t < nt) {
+          float stv[8];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int r = 4 * t + i;
             const float o = RAW ? accl[t][i] : pw4_epi(accl[t][i], ep[4 * r], ep[4 * r + 1], ep[4 * r + 2]);
+            if constexpr (STATS) {
+              if (do_stats) {
+                const float u = csn_bufacc<csn_bf16>::cv1((unsigned)csn_f2bf(o));
+                stv[2 * i] = valid ? u : 0.f; stv[2 * i + 1] = valid ? u * u : 0.f;
+              }
+            }
             csn_bufacc<AT>::st1(ob, sv, (unsigned)(r0 + r) * csl, o);
+          }
+          if constexpr (STATS) {
+            if (do_stats) pw4_stats_tile(a->stats_l, r0 + 4 * t, a->OL, a->stats_stride, tile, stv, lane);
           }
         }
       }
@@ -477,6 +523,8 @@ template <int H> struct Pw4RedFn<H, 0> { static Pw4Fn get() { return pw4_kernel<
 static const Pw4Entry g_pw4_table[] = {PW4_INST_LIST(PW4_ENTRY)};
 
 // smallest instantiation that covers (nth, ntl) row tiles per group (ntl = 0 must stay 0: no low output), or {0, 0}
+bool csn_pw4_has_stats(int nth, int ntl) { (void)nth; return ntl > 0; }   // the forms whose bf16 raw launches carry Pw4Args::stats_*
+
 bool csn_pw4_pick(int nth, int ntl, int* pnth, int* pntl) {
   int best = -1, best_cost = 1 << 30;
   for (size_t i = 0; i < sizeof(g_pw4_table) / sizeof(g_pw4_table[0]); ++i) {
@@ -512,6 +560,11 @@ int csn_launch_pw4(const Pw4Args& a, int raw, void* stream) {
     if (st != 0) return st;
   }
 #endif
+#ifdef CSN_EMU_SEQ   // pw4_stats_out's stand-in accumulates
+  if (a.stats_h) std::memset(a.stats_h, 0, (size_t)a.OH * a.stats_stride * 2 * sizeof(double));
+  if (a.stats_l) std::memset(a.stats_l, 0, (size_t)a.OL * a.stats_stride * 2 * sizeof(double));
+#endif
+  if ((a.stats_h || a.stats_l) && (mode != 3 || !csn_pw4_has_stats(a.nth, a.ntl) || a.stats_stride != a.tiles_x * a.tiles_y * a.B)) return 1;
   CSN_LAUNCH(e->fn[mode], grid, dim3(CSN_BLOCK), lds, stream, a);
   return (int)hipGetLastError();
 }

@@ -112,15 +112,24 @@ __global__ __launch_bounds__(CSN_BLOCK) void bn_stats_kernel(BnStatsArgs a) {
   }
 }
 
+struct __attribute__((aligned(16))) BnD2 { double x, y; };   // one slab's {sum, sum of squares}: a 128-bit load
 // one block per channel: the slab partials are summed by the block (fixed order), thread 0 finishes
 __device__ __forceinline__ void bn_finalize_body(const BnFinalizeArgs& a, double* sm) {
   const int c = blockIdx.x;
   if (c >= a.C) return;   // (block-uniform: the multi-job launch is as wide as its widest job)
   double s1 = 0.0, s2 = 0.0;
-  for (int k = threadIdx.x; k < a.nslab; k += CSN_BLOCK) {
-    s1 += a.partial[((int64_t)c * BN_NSLAB + k) * 2 + 0];
-    s2 += a.partial[((int64_t)c * BN_NSLAB + k) * 2 + 1];
+  const int64_t ps = a.pstride > 0 ? a.pstride : BN_NSLAB;
+  // (eight slabs per trip in flight, added in slab order: pw4_kernel's own statistics are ~12,000 slabs per channel at batch 256)
+  const BnD2* pp = reinterpret_cast<const BnD2*>(a.partial) + (int64_t)c * ps;
+  int k = threadIdx.x;
+  for (; k + 7 * CSN_BLOCK < a.nslab; k += 8 * CSN_BLOCK) {
+    BnD2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = pp[k + u * CSN_BLOCK];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s1 += v[u].x; s2 += v[u].y; }
   }
+  for (; k < a.nslab; k += CSN_BLOCK) { s1 += pp[k].x; s2 += pp[k].y; }
   s1 = bn_block_sum(s1, sm);
   s2 = bn_block_sum(s2, sm);
   if (threadIdx.x != 0) return;

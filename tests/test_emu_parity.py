@@ -319,6 +319,28 @@ def test_emu_max_pool_adjoint_routed_in_the_input_gradient_launch(emu_lib, x2_ma
     assert torch.equal(flats["1"], flats["0"]), float((flats["1"] - flats["0"]).abs().max())
 
 
+def test_emu_bf16_statistics_from_the_contraction_epilogue(emu_lib, x2_manifest, monkeypatch):
+    """Round 6, bf16 train forward: pw4_kernel's epilogue leaves the BatchNorm statistics of its stored (rounded) outputs per
+    (channel, item tile) (Pw4Args::stats_h) instead of bn_stats_kernel's pass over z (CSN_PW4_STATS=0).  The same sums in another
+    order: logits, penalty and every gradient agree to summation-order accuracy (the running statistics ride in the parameter
+    arena and are compared as well)."""
+    out = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("CSN_PW4_STATS", sw)
+        m, sd = P.make_model(emu_lib, x2_manifest, CPU)
+        m.set_train_act_dtype("bf16")
+        m.train(); m.set_batchsize(2); m.clear_flops(); m.flops_hook(1.0)
+        x = torch.from_numpy(I.randn_batch(51, 2, 48, 80))
+        t = torch.from_numpy(I.binary_target(52, 2, 48, 80))
+        y, pen = m._train_forward_raw(x)
+        loss, dy = P.bce_and_grad(emu_lib, y, t)
+        out[sw] = (y.clone(), float(pen), m._train_backward_raw(x, dy, 1.5).clone())
+    ya, pa, ga = out["1"]; yb, pb, gb = out["0"]
+    assert (ya - yb).abs().max().item() <= 2e-3 * max(1.0, yb.abs().max().item())
+    assert abs(pa - pb) <= 1e-4 * max(1e-6, abs(pb))
+    assert (ga - gb).norm().item() <= 2e-2 * gb.norm().item()
+
+
 def test_emu_results_do_not_depend_on_the_tile_geometry(emu_lib, x2_manifest, monkeypatch):
     """pw4_kernel / c3q_kernel tiles as 16 x 4 blocks (CSN_PW4_TWL = CSN_C3Q_TWL = 4), as row segments (6 with CSN_PW4_FLAT=0, round 3)
     or as 64 consecutive pixels of the plane (flat tiles, the default where rows do not fill their tiles): the same per-pixel

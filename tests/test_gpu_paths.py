@@ -204,6 +204,25 @@ def test_gpu_lane_exchange_equals_loaded_halos_train(hip, x2_manifest, act_dtype
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("act_dtype,size", [("fp32", (48, 80)), ("bf16", 224)])
+def test_gpu_epilogue_routing_and_statistics_equal_their_own_passes(hip, x2_manifest, act_dtype, size):
+    """Round 6: pwq_kernel's epilogue routes the 2x2 max-pool adjoint (CSN_POOL_ROUTE) and, in the bf16 mode, pw4_kernel's epilogue
+    leaves the BatchNorm statistics of its outputs (CSN_PW4_STATS: wave sums by DPP / ds_bpermute) -- against the passes they replace
+    (maxpool2_bwd_add_pair_kernel, bn_stats_kernel).  fp32: the routing adds the same numbers in the same order: bit-identical;
+    bf16: one rounding less per routed gradient and another summation order of the statistics: bf16 rounding flips."""
+    lib, dev = hip
+    f1, g1 = P.train_backward_probes(lib, dev, x2_manifest, 2, size, act_dtype, {"CSN_POOL_ROUTE": "1", "CSN_PW4_STATS": "1"})
+    f0, g0 = P.train_backward_probes(lib, dev, x2_manifest, 2, size, act_dtype, {"CSN_POOL_ROUTE": "0", "CSN_PW4_STATS": "0"})
+    worst = max(float((g1[k].double() - g0[k].double()).norm() / (g0[k].double().norm() + 1e-30)) for k in g1)
+    rel = float((f1.double() - f0.double()).norm() / f0.double().norm())
+    print(f"{act_dtype} {size}: worst stored input gradient {worst:.2e}, flat gradient {rel:.2e}")
+    if act_dtype == "fp32":
+        assert torch.equal(f1, f0) and worst == 0.0
+    else:
+        assert worst < 2e-2 and rel < 2e-2
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape,env,fuse_cls", [((2, 224, 224), None, True), ((3, 224, 224), None, False),
                                                 ((2, 96, 160), {"CSN_HZ_RB": "3", "CSN_HZ_NT": "3/5", "CSN_HZ_HB": "4"}, False),
                                                 ((3, 16, 16), {"CSN_HZ_RB": "1", "CSN_HZ_NW": "16"}, True)])

@@ -7,6 +7,6 @@ TR="--steps 2 --warmup 1 --no-cpu-baseline --csf-batch 0 --no-latency-b1 --event
 rm -rf $O/trace_$TAG
 ( timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/trace_$TAG -o t -- python $R/bench.py $TR --train-net $NET ) > $O/trace_$TAG.log 2>&1
 cd $R
-python tools/train_step_breakdown.py $(find $O/trace_$TAG -name "*kernel_trace.csv" | head -1) 0 > $O/train_step_kernels_$TAG.md 2>&1
+python tools/train_step_breakdown.py $(find $O/trace_$TAG -name "*kernel_trace.csv" | head -1) 0 $O/train_step_launches_$TAG.txt > $O/train_step_kernels_$TAG.md 2>&1
 rm -rf $O/trace_$TAG
 grep -A16 "## bf16" $O/train_step_kernels_$TAG.md | head -24
