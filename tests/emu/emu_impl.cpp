@@ -3,6 +3,7 @@
 #include "hip_cpu_shim.h"
 
 #ifdef CSN_EMU_LANES
+#include "csn_device.h"   // kinds 11 / 12: the kernels' own helpers on the shim's lane operations
 // One wave executing ONE cross-lane instruction of the lane-exact mode, operands and results per lane -- the twin of
 // tests/emu/lane_probe.hip, which runs the real instruction on the GPU (tests/test_gpu_lane_ops.py compares the two bit for bit;
 // tests/test_emu_lanes.py compares this one with the instructions' matrix definitions).
@@ -35,6 +36,27 @@ extern "C" int csn_emu_lane_probe(int kind, const unsigned char* a, const unsign
         unsigned long long v; std::memcpy(&v, la, 8);
         v = csn_emu::lanes_shfl_xor64(v, (int)(ub & 63));
         std::memcpy(&d[0], &v, 8);
+        break;
+      }
+      case 11: {   // csn_lane_xor_f32: a = the float, b = X
+        float o = fa;
+        switch (ub) {
+          case 1: o = csn_lane_xor_f32<1>(fa); break;
+          case 2: o = csn_lane_xor_f32<2>(fa); break;
+          case 4: o = csn_lane_xor_f32<4>(fa); break;
+          case 8: o = csn_lane_xor_f32<8>(fa); break;
+          case 16: o = csn_lane_xor_f32<16>(fa); break;
+          case 32: o = csn_lane_xor_f32<32>(fa); break;
+          default: bad = 1;
+        }
+        d[0] = o;
+        break;
+      }
+      case 12: {   // csn_wave_reduce_scatter8 of acc[0 .. 7]
+        float v[8];
+        for (int i = 0; i < 8; ++i) v[i] = d[i];
+        d[0] = csn_wave_reduce_scatter8(v, (int)lane);
+        d[1] = (float)csn_rs8_index((int)lane);
         break;
       }
       default: bad = 1;

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../sod100k_amd/csrc/csn_device.h"   // kinds 11 / 12 run the kernels' own helpers (csn_lane_xor_f32, csn_wave_reduce_scatter8)
+
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16 __attribute__((ext_vector_type(16)));
 typedef short s4 __attribute__((ext_vector_type(4)));
@@ -51,6 +53,22 @@ __global__ __launch_bounds__(64) void lane_probe_kernel(int kind, const u4* a, c
   } else if (k == 10) {
     const double v = __shfl_xor(__hiloint2double((int)la.y, (int)la.x), (int)(lb.x & 63), 64);
     d[0] = __uint_as_float((unsigned)__double2loint(v)); d[1] = __uint_as_float((unsigned)__double2hiint(v));
+  } else if (k == 11) {   // the float of lane (lane ^ X), X = b.x: DPP inside a row of 16, ds_bpermute across rows (round 6)
+    const float v = __uint_as_float(la.x);
+    const unsigned X = lb.x;   // (uniform)
+    float o = v;
+    if (X == 1) o = csn_lane_xor_f32<1>(v);
+    else if (X == 2) o = csn_lane_xor_f32<2>(v);
+    else if (X == 4) o = csn_lane_xor_f32<4>(v);
+    else if (X == 8) o = csn_lane_xor_f32<8>(v);
+    else if (X == 16) o = csn_lane_xor_f32<16>(v);
+    else if (X == 32) o = csn_lane_xor_f32<32>(v);
+    d[0] = o;
+  } else if (k == 12) {   // wave sums of eight per-lane values (pw4_kernel's statistics): d[0] = total of value csn_rs8_index(lane)
+    float v[8];
+    for (int i = 0; i < 8; ++i) v[i] = d[i];
+    d[0] = csn_wave_reduce_scatter8(v, (int)lane);
+    d[1] = (float)csn_rs8_index((int)lane);
   }
   if (k >= 6 && k <= 8) d[0] = __uint_as_float(r);
   for (int i = 0; i < 16; ++i) acc_out[16 * lane + i] = d[i];

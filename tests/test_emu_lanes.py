@@ -122,6 +122,19 @@ def test_lanes_instruction_definitions(emu_lanes_lib):
         rb = np.zeros((64, 16), np.uint8); rb[:, 0] = x
         got = np.ascontiguousarray(L.probe(fn, 10, ra, rb, zero)[:, :2]).view(np.uint64)[:, 0]
         assert np.array_equal(got, v64[np.arange(64) ^ x])
+    # round 6: csn_lane_xor_f32 and the eight-value wave reduce-scatter of pw4_kernel's statistics (csn_device.h on the shim)
+    lanes = np.arange(64)
+    vf = rng.integers(-2 ** 20, 2 ** 20, size=64).astype(np.float32)
+    ra = np.zeros((64, 16), np.uint8); ra[:, :4] = vf.view(np.uint8).reshape(64, 4)
+    for x in (1, 2, 4, 8, 16, 32):
+        rb = np.zeros((64, 16), np.uint8); rb[:, 0] = x
+        assert np.array_equal(L.probe(fn, 11, ra, rb, zero)[:, 0], vf[lanes ^ x]), x
+    vals = rng.integers(-1000, 1001, size=(64, 8)).astype(np.float32)
+    acc = np.zeros((64, 16), np.float32); acc[:, :8] = vals
+    out = L.probe(fn, 12, none, none, acc)
+    idx = ((lanes & 8) >> 1) | ((lanes & 16) >> 3) | ((lanes & 32) >> 5)
+    assert np.array_equal(out[:, 1].astype(np.int64), idx)
+    assert np.array_equal(out[:, 0].astype(np.float64), vals.astype(np.float64).sum(axis=0)[idx])
 
 
 def test_lanes_csf_head(emu_lanes_lib, monkeypatch):

@@ -81,3 +81,27 @@ def test_gpu_shuffle_xor(gpu_probe, emu_probe):
         hw = np.ascontiguousarray(L.probe(gpu_probe, 10, ra, rb, zero)[:, :2]).view(np.uint64)[:, 0]
         emu = np.ascontiguousarray(L.probe(emu_probe, 10, ra, rb, zero)[:, :2]).view(np.uint64)[:, 0]
         assert np.array_equal(hw, emu) and np.array_equal(emu, v[np.arange(64) ^ x]), x
+
+
+def test_gpu_lane_xor_and_wave_reduce_scatter(gpu_probe, emu_probe):
+    """Round 6 (pw4_kernel's statistics epilogue): csn_lane_xor_f32 -- quad_perm for 1 / 2, row_shl:4 + row_shr:4 under bank masks
+    for 4, row_ror:8 for 8, ds_bpermute for 16 / 32 -- and csn_wave_reduce_scatter8 built on it, the kernels' own code
+    (csn_device.h) on one wave against their definitions.  Integer operands: every summation order is exact."""
+    rng = np.random.default_rng(11)
+    lanes = np.arange(64)
+    zero = np.zeros((64, 16), np.float32)
+    v = rng.integers(-2 ** 20, 2 ** 20, size=64).astype(np.float32)
+    ra = np.zeros((64, 16), np.uint8); ra[:, :4] = v.view(np.uint8).reshape(64, 4)
+    for x in (1, 2, 4, 8, 16, 32):
+        rb = np.zeros((64, 16), np.uint8); rb[:, 0] = x
+        hw, emu = L.probe(gpu_probe, 11, ra, rb, zero)[:, 0], L.probe(emu_probe, 11, ra, rb, zero)[:, 0]
+        assert np.array_equal(hw, v[lanes ^ x]) and np.array_equal(emu, hw), x
+    for _ in range(8):
+        vals = rng.integers(-1000, 1001, size=(64, 8)).astype(np.float32)
+        acc = np.zeros((64, 16), np.float32); acc[:, :8] = vals
+        z8 = np.zeros((64, 16), np.uint8)
+        out = L.probe(gpu_probe, 12, z8, z8, acc)
+        assert np.array_equal(L.probe(emu_probe, 12, z8, z8, acc)[:, :2], out[:, :2])
+        idx = ((lanes & 8) >> 1) | ((lanes & 16) >> 3) | ((lanes & 32) >> 5)
+        assert np.array_equal(out[:, 1].astype(np.int64), idx)
+        assert np.array_equal(out[:, 0].astype(np.float64), vals.astype(np.float64).sum(axis=0)[idx])
