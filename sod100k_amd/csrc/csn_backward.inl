@@ -35,6 +35,7 @@ struct DataLaunch {
   // cannot (not on pwq_kernel, width not a multiple of 4, CSN_POOL_ROUTE=0) leaves it to the routing kernel after the LAST direct chunk
   bool route = false;
   bool route_last = false;
+  bool pooled = false;   // a chunk of a pooled term's launch (to_tmp itself marks the LAST chunk only: the routing kernel follows it)
 };
 
 struct WgRowSrc {     // `n` consecutive channels, starting at c0, of the tensor (kind, idx) with ctot channels
@@ -75,6 +76,7 @@ void push_data(UnitBwd& ub, const PwLaunchPlan& L, const DataLaunch& proto) {
     DataLaunch dl = proto;
     dl.L = parts[k];
     dl.to_tmp = proto.to_tmp && k + 1 == parts.size();
+    dl.pooled = proto.to_tmp;
     dl.route_last = proto.route && !proto.to_tmp && k + 1 == parts.size();
     ub.data.push_back(dl);
   }
@@ -242,7 +244,7 @@ int plan_goct_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
     int npool = 0, jpool = -1;
     for (int j = i + 1; j < d.n_out; ++j)
       if (d.cout[j] > 0) { ++npool; jpool = j; }
-    const bool route = P.pool_route && ps.nsrc > 0 && npool == 1 && jpool == i + 1 && mode == PW_OWN;
+    const bool route = P.pool_route && ps.nsrc > 0 && npool == 1 && jpool == i + 1 && (mode == PW_OWN || mode == PW_TAPS);
     auto push_direct = [&]() {
       L.passes.push_back(ps);
       DataLaunch dl;
@@ -842,16 +844,19 @@ int run_unit_bwd(const BwdCtx& b, int ui, const float* dy) {
   bool fuse_br[CSN_MAX_BRANCH] = {false, false, false};
   for (int i = 0; i < d.n_in; ++i) {
     int n = 0;
-    bool ok = P.pw4 && bd.in[i] != nullptr && bd.tmp != nullptr;
+    bool ok = bd.in[i] != nullptr && bd.tmp != nullptr;
     for (const DataLaunch& dl : ub.data)
-      if (dl.i == i && dl.route && !dl.to_tmp) {
+      if (dl.i == i && dl.route && !dl.pooled) {
         ++n;
-        ok = ok && dl.L.pwq && dl.L.passes.size() == 1 && ((P.W >> dl.L.lvl) & 3) == 0 && ((P.H >> dl.L.lvl) & 1) == 0;
+        const int Wp = P.W >> dl.L.lvl, Hp = P.H >> dl.L.lvl;
+        const bool on_pwq = P.pw4 && dl.L.pwq && (Wp & 3) == 0 && (Hp & 1) == 0;                       // (launch_pw's own predicates)
+        const bool on_c3q = !dl.L.pwq && P.c3q && P.tiled3 && dl.L.c3q && !dl.L.c3q_z && (!c.a16 || c.raw) && (Wp & 1) == 0 && (Hp & 1) == 0;
+        ok = ok && dl.L.passes.size() == 1 && (on_pwq || on_c3q);
       }
     fuse_br[i] = ok && n > 0;
   }
   for (const DataLaunch& dl : ub.data) {
-    const bool fuse = dl.route && !dl.to_tmp && fuse_br[dl.i];
+    const bool fuse = dl.route && !dl.pooled && fuse_br[dl.i];
     PwBind bq = bd;
     if (fuse) { bq.route_x = bd.in[dl.i]; bq.route_t = bd.tmp; }
     const int st = launch_pw(c, dl.L, bq);

@@ -350,6 +350,10 @@ struct C3qArgs {
   int32_t hl;           // float tensors, flat tiles: 62 quads per tile in lanes 1 .. 62, lanes 0 / 63 load their neighbours' halo
                         // (tiles_x = ceil(quads / 62)); edge columns by lane exchange (k_c3q.hip C3qWin)
   int32_t grp_r0[PW4_MAX_GROUPS], grp_nt[PW4_MAX_GROUPS];   // first row / row tiles of every M group
+  // round 6, raw (gradient) launches: the adjoint of the 2x2 max-pool routed in the epilogue -- the lane's output quad IS the window:
+  // two loads of the pooled tensor's quad rows + one of the low-resolution gradient per output row (see PwqArgs::route_x)
+  const float* route_x = nullptr;   // the pooled tensor [B][out_ctot][H][W] (null: no routing)
+  const float* route_t = nullptr;   // the low-resolution gradient [B][out_ctot][H / 2][W / 2]
 };
 int csn_c3q_max_tiles(void);
 int csn_launch_c3q(const C3qArgs& a, int raw, void* stream);

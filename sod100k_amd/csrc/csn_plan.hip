@@ -1276,7 +1276,6 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
       return c.mark("pwq_kernel");
     }
   }
-  if (bd.route_x) { g_hip_err = "launch_pw: routed max-pool adjoint on a launch that is not pwq_kernel's"; return CSN_E_STATE; }
   if (P.c3q && P.tiled3 && L.c3q && (!c.a16 || c.raw)) {   // 3x3 forward pass: lane = output quad, operands from the load registers
     const PwPassPlan& pp = L.passes[0];
     bool ok = true;
@@ -1296,6 +1295,10 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
     float* ob = pp.out_kind == OUT_Z ? bd.zout : pp.out_kind == OUT_DX ? bd.dx[pp.out_branch] : pp.out_kind == OUT_TMP ? bd.tmp
                                                                                                 : bd.act[pp.out_branch];
     ok = ok && ob != nullptr && (pp.out_kind == OUT_Z || pp.out_kind == OUT_ACT || gradq) && !bd.red_w;
+    if (bd.route_x) {   // the max-pool adjoint in this launch's epilogue (the caller has checked c3q_route_ok)
+      ok = ok && pp.out_kind == OUT_DX && !L.c3q_z;
+      q.route_x = bd.route_x; q.route_t = bd.route_t;
+    }
     if (ok) {
       q.out = ob; q.out_c0 = pp.out_c0; q.out_ctot = pp.out_ctot; q.nrows = pp.nrows;
       q.ep = L.c3q_ep >= 0 ? c.pk(L.c3q_ep) : nullptr;
@@ -1321,6 +1324,7 @@ int launch_pw(const Ctx& c, const PwLaunchPlan& L, const PwBind& bd) {
       return c.mark("c3q_kernel");
     }
   }
+  if (bd.route_x) { g_hip_err = "launch_pw: routed max-pool adjoint on a launch that is neither pwq_kernel's nor c3q_kernel's"; return CSN_E_STATE; }
   if (P.tiled3 && csn_c3_eligible(a) && (!c.a16 || all_raw)) {   // 3x3 pass: LDS-tiled implicit GEMM
     LAUNCH_TRY(csn_launch_c3(a, all_raw ? 1 : 0, c.stream));
     return c.mark("goct_c3_kernel");

@@ -121,6 +121,23 @@ __device__ __forceinline__ void c3q_channel(const float (&v)[16], const float* w
 
 }  // namespace
 
+// The adjoint of the 2x2 max-pool routed in the epilogue of a raw (gradient) launch (C3qArgs::route_x, round 6): the lane's output
+// quad o = {(2y, 2x), (2y, 2x + 1), (2y + 1, 2x), (2y + 1, 2x + 1)} is exactly the window of low pixel (y, x); the gradient goes to
+// the window's FIRST maximum in that (row-major) order -- `v > best || v != v`, max_pool2d's rule as maxpool2_bwd_add_pair_kernel.
+template <typename AT>
+__device__ __forceinline__ void c3q_route(float (&o)[4], csn_buf xb, csn_buf tb, unsigned o0, unsigned o1, unsigned ot, unsigned sx, unsigned st) {
+  const float2 r0 = csn_bufacc<AT>::ld2(xb, o0, sx), r1 = csn_bufacc<AT>::ld2(xb, o1, sx);
+  const float t = csn_bufacc<AT>::ld1(tb, ot, st);
+  float best = r0.x; int bi = 0;
+  if (r0.y > best || r0.y != r0.y) { best = r0.y; bi = 1; }
+  if (r1.x > best || r1.x != r1.x) { best = r1.x; bi = 2; }
+  if (r1.y > best || r1.y != r1.y) { best = r1.y; bi = 3; }
+  if (bi == 0) o[0] += t;
+  if (bi == 1) o[1] += t;
+  if (bi == 2) o[2] += t;
+  if (bi == 3) o[3] += t;
+}
+
 // AT: element type of the activation tensors (float; csn_bf16 = the bf16 train mode's storage, RAW launches only)
 template <int NT, bool RAW, typename AT = float, bool HL = false>
 __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q_kernel(C3qArgs a_byval) {
@@ -255,6 +272,10 @@ __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q_kernel(C3qArgs a_byval
     const unsigned o0 = (unsigned)((2 * y) * W + 2 * x) * E, o1 = o0 + (unsigned)W * E;
     const unsigned sv0 = valid ? o0 : 0x80000000u, sv1 = valid ? o1 : 0x80000000u;
     const csn_buf ob = csn_make_buf_n(reinterpret_cast<char*>(a->out) + (int64_t)b * a->out_ctot * (int64_t)cs, (unsigned)a->out_ctot * cs);
+    const bool route = a->route_x != nullptr;   // (uniform; raw launches only)
+    const unsigned ort = (unsigned)(y * Wq + x) * E;
+    const csn_buf rxb = route ? csn_make_buf_n(reinterpret_cast<const char*>(a->route_x) + (int64_t)b * a->out_ctot * (int64_t)cs, (unsigned)a->out_ctot * cs) : ob;
+    const csn_buf rtb = route ? csn_make_buf_n(reinterpret_cast<const char*>(a->route_t) + (int64_t)b * a->out_ctot * (int64_t)(cs >> 2), (unsigned)a->out_ctot * (cs >> 2)) : ob;
     csn_cfp ep = csn_const(a->ep) + 4 * r0;
     unsigned oz[9];
     csn_buf zb = ob;
@@ -289,6 +310,7 @@ __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q_kernel(C3qArgs a_byval
             o[s] = RAW ? zsum : pw4_epi(zsum, ep[4 * r], ep[4 * r + 1], ep[4 * r + 2]);
           }
           const unsigned so = (unsigned)(a->out_c0 + r0 + r) * cs;
+          if (RAW && route) c3q_route<AT>(o, rxb, rtb, o0, o1, ort, so, so >> 2);
           csn_bufacc<AT>::st2(ob, sv0, so, make_float2(o[0], o[1]));
           csn_bufacc<AT>::st2(ob, sv1, so, make_float2(o[2], o[3]));
         }
@@ -461,6 +483,10 @@ __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q16_kernel(C3qArgs a_byv
     const unsigned o0 = (unsigned)((2 * y) * W + 2 * x) * E, o1 = o0 + (unsigned)W * E;
     const unsigned sv0 = valid ? o0 : 0x80000000u, sv1 = valid ? o1 : 0x80000000u;
     const csn_buf ob = csn_make_buf_n(reinterpret_cast<char*>(a->out) + (int64_t)b * a->out_ctot * (int64_t)cs, (unsigned)a->out_ctot * cs);
+    const bool route = a->route_x != nullptr;   // (uniform; raw launches only)
+    const unsigned ort = (unsigned)(y * Wq + x) * E;
+    const csn_buf rxb = route ? csn_make_buf_n(reinterpret_cast<const char*>(a->route_x) + (int64_t)b * a->out_ctot * (int64_t)cs, (unsigned)a->out_ctot * cs) : ob;
+    const csn_buf rtb = route ? csn_make_buf_n(reinterpret_cast<const char*>(a->route_t) + (int64_t)b * a->out_ctot * (int64_t)(cs >> 2), (unsigned)a->out_ctot * (cs >> 2)) : ob;
     unsigned oz[9];
     csn_buf zb = ob;
     const unsigned csz = cs >> 2;
@@ -488,8 +514,10 @@ __global__ __launch_bounds__(CSN_BLOCK, C3Q_OCC) void c3q16_kernel(C3qArgs a_byv
             pw4_up2_quad(zv, zq);
           }
           const unsigned so = (unsigned)(a->out_c0 + r0 + r) * cs;
-          csn_bufacc<AT>::st2(ob, sv0, so, make_float2(acc[0][t][i] + zq[0], acc[1][t][i] + zq[1]));
-          csn_bufacc<AT>::st2(ob, sv1, so, make_float2(acc[2][t][i] + zq[2], acc[3][t][i] + zq[3]));
+          float o[4] = {acc[0][t][i] + zq[0], acc[1][t][i] + zq[1], acc[2][t][i] + zq[2], acc[3][t][i] + zq[3]};
+          if (route) c3q_route<AT>(o, rxb, rtb, o0, o1, ort, so, so >> 2);
+          csn_bufacc<AT>::st2(ob, sv0, so, make_float2(o[0], o[1]));
+          csn_bufacc<AT>::st2(ob, sv1, so, make_float2(o[2], o[3]));
         }
       }
     }
@@ -532,6 +560,7 @@ int csn_launch_c3q(const C3qArgs& a, int raw, void* stream) {
   if (ast != 0) return ast;
 #endif
   if (a.a16 && !raw) return 1;   // bfloat16 tensors: train-mode (raw) launches only
+  if (a.route_x && (!raw || !a.route_t || a.z)) return 1;   // routing: gradient launches only
   if (a.a16 && a.mfma16) {
     int kg = 0;
     for (int s = 0; s < a.nsrc; ++s) kg += (a.src[s].C + 3) >> 2;
