@@ -30,7 +30,7 @@ struct DataLaunch {
   bool to_tmp = false;
   int pool_f = 0;     // to_tmp: max-pool factor of the routing kernel that follows
   int lvl_lo = 0;     // to_tmp: level of the temporary
-  // round 6 (`route`): the branch's ONE pooled term (factor 2) is contracted into the temporary FIRST (to_tmp chunks with route set: no
+  // round 6 (`route`): the branch's pooled term of factor 2 is contracted into the temporary FIRST (to_tmp chunks with route set: no
   // routing kernel behind them) and the direct launch's chunks route it in their epilogue (PwqArgs::route_x); a direct chunk that
   // cannot (not on pwq_kernel, width not a multiple of 4, CSN_POOL_ROUTE=0) leaves it to the routing kernel after the LAST direct chunk
   bool route = false;
@@ -241,10 +241,8 @@ int plan_goct_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
       ps.K += d.cout[j] * kk;
     }
     // one pooled term with factor 2 behind a direct launch of a 1x1 unit: temporary first, routed by the direct launch (DataLaunch::route)
-    int npool = 0, jpool = -1;
-    for (int j = i + 1; j < d.n_out; ++j)
-      if (d.cout[j] > 0) { ++npool; jpool = j; }
-    const bool route = P.pool_route && ps.nsrc > 0 && npool == 1 && jpool == i + 1 && (mode == PW_OWN || mode == PW_TAPS);
+    // (a second pooled term -- factor 4, CSFHead.fuse's first input -- keeps its routing kernel, behind the direct launch)
+    const bool route = P.pool_route && ps.nsrc > 0 && i + 1 < d.n_out && d.cout[i + 1] > 0 && (mode == PW_OWN || mode == PW_TAPS);
     auto push_direct = [&]() {
       L.passes.push_back(ps);
       DataLaunch dl;
@@ -270,11 +268,11 @@ int plan_goct_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
       pq.K = d.cout[j] * kk;
       Lp.passes.push_back(pq);
       DataLaunch dl;
-      dl.i = i; dl.to_tmp = true; dl.pool_f = 1 << (j - i); dl.lvl_lo = base + j; dl.route = route;
+      dl.i = i; dl.to_tmp = true; dl.pool_f = 1 << (j - i); dl.lvl_lo = base + j; dl.route = route && j == i + 1;
       push_data(ub, Lp, dl);
       tmp_bytes = std::max(tmp_bytes, bl.act_bytes(d.cin[i], base + j));
+      if (route && j == i + 1) push_direct();
     }
-    if (route) push_direct();
   }
   if (tmp_bytes > 0) ub.tmp_off = bw_alloc(ub, tmp_bytes);
   for (DataLaunch& dl : ub.data) {
