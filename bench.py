@@ -61,7 +61,7 @@ def cpu_baseline(man, batch=8, target_s=20.0):
     lc = O.load_layer_config_json(man)
     x = torch.from_numpy(I.randn_batch(0, batch))
     all_threads = torch.get_num_threads()
-    counts = sorted({1, min(8, all_threads), min(32, all_threads), all_threads})
+    counts = sorted({1, min(8, all_threads), min(16, all_threads), min(32, all_threads), all_threads})
 
     def loop(xx, budget, nmax):
         O.csnet_forward(lc, sd, xx)          # warm-up

@@ -19,9 +19,8 @@ EMU = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
 
 @pytest.fixture(scope="module")
 def gpu_probe():
-    so, src = os.path.join(EMU, "liblane_probe.so"), os.path.join(EMU, "lane_probe.hip")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", so, src], check=True)
+    import emu_build
+    so = emu_build.lane_probe_make()
     return L.bind(ctypes.CDLL(so), "lane_probe_run")
 
 

@@ -191,10 +191,9 @@ def test_gpu_train_step_well_conditioned(hip, x2_manifest):
     """well-conditioned state (gamma in [0.5, 1.5]); judged against fp64 with the fp32 oracle's own
     distance as the yardstick (its noise floor is 3e-3, so an absolute 1e-4 is unreachable for any fp32 implementation)."""
     lib, dev = hip
-    # (size 48 and the unit-local gate on four of the eight seeds: the fp64 / fp32 oracle runs on the host were 133 s of the suite's
-    # 590 at size 64 with all eight, VERDICT r5 weak #1d; the emulator twin keeps its own sizes)
-    print("rel-L2 vs fp64: kernels %.2e, fp32 oracle %.2e" % P.check_train_step_well_conditioned(
-        lib, dev, x2_manifest, B=2, size=48, local_seeds=(31, 51, 71, 91)))
+    # (size 64, the unit-local gate on all eight seeds: round 6 had cut this to size 48 / two seeds for the suite's time -- the time
+    # was the oracle on 128 host threads, tests/conftest.py; with the cap the whole test takes seconds)
+    print("rel-L2 vs fp64: kernels %.2e, fp32 oracle %.2e" % P.check_train_step_well_conditioned(lib, dev, x2_manifest, B=2, size=64))
 
 
 def test_gpu_resizes(hip):
