@@ -136,9 +136,15 @@ void csn_plan_destroy(csn_plan* plan);
  * CSN_OPT_SLICE_LANES [0]: with sub_batch < B, up to three batch slices run concurrently on the plan's stream lanes, each in
  * its own workspace region (set BEFORE csn_plan_workspace_bytes, which then reports that many regions); the per-launch
  * latency of the small maps of one slice is covered by the other slices' launches.  Results are identical to the
- * sequential slices (same kernels on the same data). */
+ * sequential slices (same kernels on the same data).
+ * CSN_OPT_INPUT_GRAD [0]: (round 6) csn_backward also forms the gradient w.r.t. the image batch x -- autograd's x.grad through
+ * csnet.py:365-387, which SURVEY 8(b) lists as csn_backward's `dx`.  The reference's callers never ask for it (train.py:203-216
+ * feeds images that do not require grad), so it is an option and not an argument: set BEFORE csn_plan_enable_training (it adds one
+ * gradient buffer of x's shape to the workspace); after csn_backward the gradient lies in the workspace at
+ * csn_plan_train_act_info(plan, 0).grad_offset_bytes[0], [B][3][H][W], float -- or bfloat16 under CSN_OPT_TRAIN_BF16 (`bf16`). */
 enum csn_option { CSN_OPT_FUSE_DW = 1, CSN_OPT_GRAPH = 2, CSN_OPT_FUSE_CLS = 3, CSN_OPT_TILED3 = 4, CSN_OPT_FUSE_ILB = 5,
-                  CSN_OPT_OVERLAP = 6, CSN_OPT_TRAIN_BF16 = 7, CSN_OPT_PW4 = 8, CSN_OPT_C3Q = 9, CSN_OPT_SLICE_LANES = 10 };
+                  CSN_OPT_OVERLAP = 6, CSN_OPT_TRAIN_BF16 = 7, CSN_OPT_PW4 = 8, CSN_OPT_C3Q = 9, CSN_OPT_SLICE_LANES = 10,
+                  CSN_OPT_INPUT_GRAD = 11 };
 int csn_plan_set_option(csn_plan* plan, int32_t option, int32_t value);
 
 size_t csn_plan_workspace_bytes(const csn_plan* plan);
@@ -192,7 +198,8 @@ int csn_plan_enable_training(csn_plan* plan);
  * convolution weight, BN weight/bias, PReLU weight and the cls bias is WRITTEN (not accumulated) there, other
  * positions are left untouched.  `pen_scale` = d loss / d (penalty sum) = FLOPS.WEIGHT / batchsize (train.py:91,210)
  * adds the dynamic-weight-decay term's gradient w.r.t. the BN weights of the hooked units (same flop_w table as the
- * forward call; y.detach() in Oct_bn_hook: no gradient through the activations).  No input gradient is produced. */
+ * forward call; y.detach() in Oct_bn_hook: no gradient through the activations).  The gradient w.r.t. x (SURVEY 8(b)'s `dx`) is
+ * formed on plans with CSN_OPT_INPUT_GRAD and left in the workspace (csn_plan_train_act_info(plan, 0).grad_offset_bytes[0]). */
 int csn_backward(csn_plan* plan, const float* x, const float* dy, void* workspace, const float* arena, float* grad,
                  int64_t arena_floats, const float* flop_w, float pen_scale, void* stream);
 

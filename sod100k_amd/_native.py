@@ -50,6 +50,7 @@ OPT_TRAIN_BF16 = 7
 OPT_PW4 = 8
 OPT_C3Q = 9
 OPT_SLICE_LANES = 10
+OPT_INPUT_GRAD = 11
 
 
 class ActDesc(C.Structure):

@@ -105,6 +105,10 @@ WgPlan make_wg(const PwLaunchPlan& L, const PwPassPlan& pp) {
   return w;
 }
 
+// an input branch gets a gradient when it is an activation of the net -- or the image batch itself under CSN_OPT_INPUT_GRAD
+// (autograd's x.grad: csn_train_act_info(0).grad_offset_bytes[0] after csn_backward)
+static inline bool wants_dx(const csn_plan& P, int act) { return act > 0 || (act == 0 && P.input_grad); }
+
 int plan_goct_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
   csn_plan& P = bl.P;
   const csn_unit_desc& d = u.d;
@@ -114,7 +118,7 @@ int plan_goct_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
   for (int i = 0; i < d.n_in; ++i) { ci_off[i] = cin_tot; cin_tot += d.cin[i]; }
   for (int j = 0; j < d.n_out; ++j) { co_off[j] = cout_tot; cout_tot += d.cout[j]; }
   const int ld = cin_tot * kk;
-  for (int i = 0; i < d.n_in; ++i) ub.need_dx[i] = d.cin[i] > 0 && d.in_act[i] > 0;
+  for (int i = 0; i < d.n_in; ++i) ub.need_dx[i] = d.cin[i] > 0 && wants_dx(P, d.in_act[i]);
   auto adj_index = [&](int j, int i) {
     for (size_t k = 0; k < ub.adj.size(); ++k)
       if (ub.adj[k].j == j && ub.adj[k].i == i) return (int)k;
@@ -295,7 +299,7 @@ int plan_dw_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
   const csn_unit_desc& d = u.d;
   for (int k = 0; k < d.n_in; ++k) {
     if (d.cout[k] == 0) continue;
-    ub.need_dx[k] = d.in_act[k] > 0;
+    ub.need_dx[k] = wants_dx(bl.P, d.in_act[k]);
     ub.dwf_w[k] = bl.alloc_packed((int64_t)d.cout[k] * 9);
     bl.job(CSN_PREP_FLIP9, d.cout[k] * 9, ub.dwf_w[k], d.w_off[k], -1, -1, -1, 100.0f);
   }
@@ -306,7 +310,7 @@ int plan_ms_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
   csn_plan& P = bl.P;
   const csn_unit_desc& d = u.d;
   const int cin = d.cin[0], cout = d.cout[0];
-  ub.need_dx[0] = d.in_act[0] > 0;
+  ub.need_dx[0] = wants_dx(P, d.in_act[0]);
   int cobase[CSN_NDIL], base = 0;
   for (int k = 0; k < CSN_NDIL; ++k) { cobase[k] = base; base += d.dil_ch[k]; }
   // weight gradient with the roles swapped: rows = the cin input channels (A = x), gathered = the dilated taps of the
@@ -388,7 +392,7 @@ int plan_ms_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
 int plan_cls_bwd(Builder& bl, UnitPlan& u, UnitBwd& ub) {
   csn_plan& P = bl.P;
   const csn_unit_desc& d = u.d;
-  ub.need_dx[0] = d.in_act[0] > 0;
+  ub.need_dx[0] = wants_dx(P, d.in_act[0]);
   {
     // dW[0][ci] = sum_p dlogit[p] * x[ci][p]: ONE row against 79 gathered channels would leave 15 of the 16 MFMA rows and
     // the wave-private kernel (K <= 64) unused -- swap the roles: rows = the input channels, gathered = the logit gradient
@@ -951,7 +955,7 @@ static int enable_training_impl(csn_plan* P) {
     UnitPlan& u = P->units[k];
     for (int i = 0; i < u.d.n_in; ++i) {
       const int a = u.d.in_act[i];
-      if (u.d.cin[i] == 0 || a <= 0) continue;
+      if (u.d.cin[i] == 0 || !wants_dx(*P, a)) continue;
       if (P->n_cons[a] >= 2) { g_hip_err = "an activation with more than two consumers"; return CSN_E_UNSUPPORTED; }
       u.in_slot[i] = P->n_cons[a]++;
       P->tg_off[a][u.in_slot[i]] = bl.alloc_act(P->acts[a].channels, P->acts[a].lvl);
@@ -1114,7 +1118,7 @@ int csn_plan_train_act_info(const csn_plan* P, int32_t id, csn_train_act_info* o
 int32_t csn_plan_unit_in_slot(const csn_plan* P, int32_t unit, int32_t branch) {
   if (!P || !P->train || unit < 0 || unit >= (int)P->units.size() || branch < 0 || branch >= CSN_MAX_BRANCH) return -1;
   const UnitPlan& u = P->units[unit];
-  if (branch >= u.d.n_in || u.d.cin[branch] == 0 || u.d.in_act[branch] <= 0) return -1;
+  if (branch >= u.d.n_in || u.d.cin[branch] == 0 || !wants_dx(*P, u.d.in_act[branch])) return -1;
   return u.in_slot[branch];
 }
 

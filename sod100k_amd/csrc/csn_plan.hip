@@ -183,6 +183,7 @@ struct csn_plan {
   bool fuse_cls = true;   // CSN_OPT_FUSE_CLS
   bool tiled3 = true;     // CSN_OPT_TILED3
   mutable int ws_regions_reported = 0;   // workspace regions the last csn_plan_workspace_bytes() call sized (0: never queried)
+  int input_grad = 0;     // CSN_OPT_INPUT_GRAD: csn_backward also leaves the gradient w.r.t. the image batch (set before csn_plan_enable_training)
   int slice_lanes = 0;    // CSN_OPT_SLICE_LANES: batch slices (sub_batch < B) run concurrently on the plan's stream lanes, each
                           // in its own workspace region
   bool c3q = true;        // CSN_OPT_C3Q: eval-mode 3x3 passes on c3q_kernel (k_c3q.hip)
@@ -2128,6 +2129,9 @@ int csn_plan_set_option(csn_plan* P, int32_t option, int32_t value) {
     case CSN_OPT_PW4: P->pw4 = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_C3Q: P->c3q = value != 0; drop_graph(P); return CSN_OK;
     case CSN_OPT_SLICE_LANES: P->slice_lanes = value != 0; drop_graph(P); return CSN_OK;
+    case CSN_OPT_INPUT_GRAD:
+      if (P->train) { g_hip_err = "CSN_OPT_INPUT_GRAD must be set before csn_plan_enable_training (it adds a gradient buffer)"; return CSN_E_STATE; }
+      P->input_grad = value != 0; return CSN_OK;
     case CSN_OPT_FUSE_ILB: P->ilb = value != 0; drop_graph(P); return CSN_OK;   // (round 5: ilb_kernel, k_ilb.hip)
     case CSN_OPT_OVERLAP: P->overlap = value != 0; P->overlap_bwd = value == 2; drop_graph(P); return CSN_OK;
     case CSN_OPT_TRAIN_BF16:

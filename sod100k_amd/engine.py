@@ -92,7 +92,7 @@ class Engine:
     def __init__(self, lib: C.CDLL, units: Sequence[N.UnitDesc], acts: Sequence[Tuple[int, int]],
                  B: int, H: int, W: int, device: torch.device, sub_batch: int = 0,
                  unit_names: Optional[Sequence[str]] = None, train: bool = False, slice_lanes: bool = False,
-                 train_bf16: bool = False):
+                 train_bf16: bool = False, input_grad: bool = False):
         self.lib = lib
         self.B, self.H, self.W = B, H, W
         self.sub_batch = sub_batch
@@ -106,9 +106,12 @@ class Engine:
                 "csn_plan_create")
         self.plan = plan
         self.train = bool(train)
+        self.input_grad = bool(train) and bool(input_grad)
         if self.train:      # z / gradient / scratch buffers + backward weight images (before the workspace query)
             if train_bf16:  # BEFORE the training buffers are laid out: every activation-typed region gets 2-byte elements
                 self.set_option(N.OPT_TRAIN_BF16, 1)
+            if input_grad:  # ... and so does the gradient buffer of the image batch (autograd's x.grad, CSN_OPT_INPUT_GRAD)
+                self.set_option(N.OPT_INPUT_GRAD, 1)
             N.check(lib, lib.csn_plan_enable_training(plan), "csn_plan_enable_training")
         if os.environ.get("CSN_TILED3") is not None:      # A/B switches for measurements
             self.set_option(N.OPT_TILED3, int(os.environ["CSN_TILED3"]))

@@ -476,7 +476,9 @@ class CSNet(nn.Module):
         if slice_lanes is None:
             slice_lanes = env == "1" or (env != "0" and x.shape[0] >= 32 and not self._sub_batch)
         lanes = bool(slice_lanes) and not train and x.is_cuda and x.shape[0] >= 2
-        key = (tuple(x.shape), x.device, bool(train), bf16, lanes)
+        # the gradient w.r.t. the image batch (x.requires_grad under autograd): a plan with one more gradient buffer (CSN_OPT_INPUT_GRAD)
+        input_grad = bool(train) and bool(getattr(self, "_want_input_grad", False))
+        key = (tuple(x.shape), x.device, bool(train), bf16, lanes, input_grad)
         eng = self._engines.get(key)
         if eng is not None:
             self._engines[key] = self._engines.pop(key)      # most recently used last
@@ -496,7 +498,7 @@ class CSNet(nn.Module):
             # (bf16: the option goes in before the training buffers are laid out, so that every activation-typed region of the
             # workspace has 2-byte elements -- 61 -> 31 GiB at batch 256)
             eng = Engine(lib, units, acts, B, H, W, x.device, sub_batch=sub_batch, unit_names=names, train=train,
-                         slice_lanes=lanes, train_bf16=bf16)
+                         slice_lanes=lanes, train_bf16=bf16, input_grad=input_grad)
             self._engines[key] = eng
         return eng
 
@@ -541,7 +543,7 @@ class CSNet(nn.Module):
         """Train-mode forward/backward on the device: batch-statistics BN with running-stat update
         (csnet.py:764,825,138), the dynamic-weight-decay penalty (csnet.py:391-410, read back through
         get_flops()) and, under autograd, the hand-written backward kernels (csn_backward)."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             params = [p for p in self.parameters()]
             y, pen = _CSNetTrainFn.apply(self, x, *params)
         else:
@@ -598,11 +600,10 @@ class _CSNetTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, x, *params):
-        if x.requires_grad:
-            # csn_backward (include/csnet_hip.h) has no input-gradient output: the first unit's dx is never formed (none of the
-            # reference's callers asks for it: train.py:203-216 feeds plain image batches).  Refuse rather than hand back None.
-            raise RuntimeError("CSNet (HIP): gradients with respect to the input are not provided by csn_backward; "
-                               "pass the image batch with requires_grad=False")
+        # x.requires_grad (autograd's x.grad; none of the reference's callers asks for it, train.py:203-216): the step runs on a plan
+        # with CSN_OPT_INPUT_GRAD, whose backward also forms the first unit's input gradient
+        ctx.input_grad = bool(x.requires_grad)
+        model._want_input_grad = ctx.input_grad
         y, pen = model._train_forward_raw(x, with_backward=True)
         ctx.model, ctx.x = model, x
         # backward reads z / activations / BN statistics of THIS forward from the plan's workspace: remember which
@@ -620,13 +621,16 @@ class _CSNetTrainFn(torch.autograd.Function):
         pen_scale = float(dpen) if dpen is not None else 0.0
         if dy is None:
             dy = torch.zeros((ctx.x.shape[0], 1) + tuple(ctx.x.shape[2:]), dtype=torch.float32, device=ctx.x.device)
+        model._want_input_grad = ctx.input_grad
         flat = model._train_backward_raw(ctx.x, dy, pen_scale)
+        dx = model.engine_for(ctx.x, train=True).train_probe(0, "grad0") if ctx.input_grad else None
+        model._want_input_grad = False      # (FusedTrainer and plain steps keep the plan without the extra buffer)
         offs = model._arena.offsets
         grads = []
         for name, p in model.named_parameters():
             o = offs[name]
             grads.append(flat[o:o + p.numel()].view(p.shape) if p.requires_grad else None)
-        return (None, None) + tuple(grads)
+        return (None, dx) + tuple(grads)
 
 
 # ---- dynamic weight decay hook (csnet.py:391-410) -----------------------------------------------------------

@@ -568,16 +568,47 @@ def check_autograd_seam(lib, device, manifest, B=2, size=32):
     m2._ensure_arena()
     opt = torch.optim.SGD(m2.parameters(), lr=0.0)
     reference_style_step(m2, opt, x, t, 3.0)
-    # csn_backward forms no input gradient: asking for one raises instead of silently returning None
-    import pytest
-    with pytest.raises(RuntimeError, match="gradients with respect to the input"):
-        m2(x.clone().requires_grad_(True))
+    # ... and with x.requires_grad the seam also returns autograd's x.grad (CSN_OPT_INPUT_GRAD: a plan with one more gradient buffer)
+    m3, sd3 = make_model(lib, manifest, device)
+    check_input_gradient_seam(m3, O.load_layer_config_json(manifest), sd3, x, t, flops_weight=3.0)
     offs = m2._arena.offsets
     for name, p in m2.named_parameters():
         assert p.grad is not None, name
         ref = flat[offs[name]:offs[name] + p.numel()].view(p.shape)
         # torch's BCE gradient differs from csn_bce_with_logits in the last bit: compare per tensor, not per element
         assert (p.grad - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-7, name     # fp32 sums of ~1e5 terms fed by a dy that differs in its last bit
+
+
+def check_input_gradient_seam(m, cfg, sd, x, t, flops_weight=3.0):
+    """SURVEY 8(b)'s `dx` of csn_backward: `model(x)` with x.requires_grad in train mode -> loss.backward() -> x.grad, against
+    autograd through the oracle in fp64 with the fp32 oracle's own distance from it as the yardstick (fp32 storage; the gradient
+    w.r.t. the image through ~60 batch-normalised layers in bf16 storage is noise in ANY implementation -- the bf16-emulating
+    oracle sits 1.0-1.4 relative L2 from the fp32 one -- so bf16 is checked unit-locally: check_train_units_local(input_grad=True))."""
+    B = x.shape[0]
+    m.train(); m.set_batchsize(B); m.clear_flops()
+    if flops_weight:
+        m.flops_hook(1.0)
+    xg = x.clone().requires_grad_(True)
+    y = m(xg)
+    loss = F.binary_cross_entropy_with_logits(y, t)
+    if flops_weight:
+        loss = loss + flops_weight * m.get_flops()
+    loss.backward()
+    m.clear_flops()
+    assert xg.grad is not None and xg.grad.shape == x.shape and xg.grad.dtype == torch.float32
+    assert not getattr(m, "_want_input_grad", False)          # plain steps go back to the plan without the extra buffer
+    kw = dict(expandflop=1.0, flops_weight=flops_weight, batchsize=B, lr=0.0, wd=0.0, use_penalty=bool(flops_weight))
+    refs = {}
+    for dt in (torch.float32, torch.float64):
+        xo = x.detach().cpu().to(dt).requires_grad_(True)
+        O.train_step(cfg, {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in sd.items()}, xo, t.detach().cpu().to(dt), **kw)
+        refs[dt] = xo.grad.double()
+    n64 = float(refs[torch.float64].norm())
+    mine = float((xg.grad.cpu().double() - refs[torch.float64]).norm()) / n64
+    ref32 = float((refs[torch.float32] - refs[torch.float64]).norm()) / n64
+    print(f"input gradient through the autograd seam: rel-L2 vs fp64 {mine:.2e} (fp32 oracle: {ref32:.2e})")
+    assert n64 > 0 and mine <= max(1e-3, 3.0 * ref32), (mine, ref32)
+    return mine, ref32
 
 
 def check_pre_post(lib, device, manifest):
@@ -635,6 +666,8 @@ def check_std_conv_network(lib, device, random_state):
     ref = np.array([float((r32["grads"][k].double() - g).norm() / (g.norm() + 1e-12)) for k, g in r64["grads"].items()])
     assert np.median(mine) <= 2 * np.median(ref) + 1e-6 and mine.max() <= 3 * ref.max() + 1e-5, (
         np.median(mine), np.median(ref), mine.max(), ref.max())
+    # x.grad: here the first unit is a Conv2dX100 std_conv (its input gradient = the x100 transposed taps on the image)
+    check_input_gradient_seam(m, cfg, sd, xd, t.to(device), flops_weight=0.0)
 
 
 def well_conditioned_state(manifest, seed=0):
@@ -818,11 +851,13 @@ def off_centre_state(manifest, seed=0, offset=50.0):
 
 
 def check_train_units_local(lib, device, manifest, B=2, size=64, act_dtype="bf16", state="shipped", flops_weight=3.0,
-                            tol_fwd=None, tol_bwd=None, seed=51, net=None):
+                            tol_fwd=None, tol_bwd=None, seed=51, net=None, input_grad=False):
     """Returns the worst relative L2 deviations {z, act, dz, dx, dparam} over all units.  net = (model, layer_config, state_dict):
-    a prebuilt network (e.g. the pruned one) instead of the manifest's."""
-    global _LOCAL_NET
+    a prebuilt network (e.g. the pruned one) instead of the manifest's.  input_grad: the plan also forms the gradient w.r.t. the
+    image batch (CSN_OPT_INPUT_GRAD; autograd's x.grad), checked as the first unit's dx."""
+    global _LOCAL_NET, _LOCAL_INPUT_GRAD
     _LOCAL_NET = net
+    _LOCAL_INPUT_GRAD = bool(input_grad)
     import contextlib
     bf16 = act_dtype == "bf16"
     # the depthwise backward forms dz on load and skips the BatchNorm backward's apply pass; CSN_DEBUG_DZ (read at plan creation)
@@ -835,6 +870,7 @@ def check_train_units_local(lib, device, manifest, B=2, size=64, act_dtype="bf16
 
 
 _LOCAL_NET = None
+_LOCAL_INPUT_GRAD = False
 
 
 def train_backward_probes(lib, device, manifest, B, size, act_dtype, env, seed=51, state="shipped", flops_weight=3.0):
@@ -902,8 +938,10 @@ def _check_train_units_local(lib, device, manifest, B, size, act_dtype, state, f
     x = torch.from_numpy(I.randn_batch(seed, B, hw[0], hw[1]))
     t = torch.from_numpy(I.binary_target(seed + 1, B, hw[0], hw[1]))
     xd, td = x.to(device), t.to(device)
+    m._want_input_grad = _LOCAL_INPUT_GRAD        # (the autograd seam sets this when x.requires_grad)
     y, pen = m._train_forward_raw(xd)
     eng = m.engine_for(xd, train=True)
+    assert eng.input_grad == _LOCAL_INPUT_GRAD
     units, acts, names = m.describe(m._arena.offsets)
     n_acts = len(acts)
     A = {0: (eng.train_probe(0, "act").cpu() if bf16 else x.clone())}
@@ -918,6 +956,9 @@ def _check_train_units_local(lib, device, manifest, B, size, act_dtype, state, f
     for a in range(1, n_acts):
         for s in range(eng.n_consumers(a)):
             G[(a, s)] = eng.train_probe(a, f"grad{s}").cpu()
+    if _LOCAL_INPUT_GRAD:
+        assert eng.n_consumers(0) == 1
+        G[(0, 0)] = eng.train_probe(0, "grad0").cpu()
     cfg = net_cfg if net_cfg is not None else O.load_layer_config_json(manifest)
     blocks = {b["name"]: b for b in O.block_table(cfg)}
     cfg3 = cfg[len(blocks):len(blocks) + 3]
@@ -970,7 +1011,7 @@ def _check_train_units_local(lib, device, manifest, B, size, act_dtype, state, f
             xs = []
             for i in range(n_in):
                 if u.cin[i] > 0:
-                    xs.append(A[int(u.in_act[i])].to(rdt).clone().requires_grad_(int(u.in_act[i]) > 0))
+                    xs.append(A[int(u.in_act[i])].to(rdt).clone().requires_grad_(int(u.in_act[i]) > 0 or _LOCAL_INPUT_GRAD))
                 else:
                     xs.append(None)
             loc = {k: (v.to(rdt) if v.is_floating_point() else v).clone() for k, v in sd.items() if k.startswith(name + ".")}
@@ -1060,7 +1101,7 @@ def _check_train_units_local(lib, device, manifest, B, size, act_dtype, state, f
                 note("dz", f"{name}[{j}]", DZ[int(u.out_act[j])], zs[q].grad, tol_bwd)
         for i in range(n_in):
             a = int(u.in_act[i])
-            if u.cin[i] > 0 and a > 0:
+            if u.cin[i] > 0 and (a > 0 or _LOCAL_INPUT_GRAD):
                 note("dx", f"{name}<-{i}", G[(a, eng.unit_in_slot(ui, i))], xs[i].grad, tol_bwd)
     assert not bad, f"{len(bad)} unit-local deviations over tolerance, worst first: {sorted(bad, key=lambda b: -b[2])[:8]}"
     assert sum(sum(v.values()) for _, v in kink_units) <= 16, f"too many PReLU kink elements re-branched: {kink_units}"

@@ -98,6 +98,18 @@ def test_emu_train_units_local(emu_lib, x2_manifest, act_dtype, B, size, state):
     print(P.check_train_units_local(emu_lib, CPU, x2_manifest, B=B, size=size, act_dtype=act_dtype, state=state))
 
 
+@pytest.mark.parametrize("act_dtype,env", [("fp32", {}), ("bf16", {}),
+                                           # the first unit's input gradient on the generic kernels (the round-4 switches off / unfused)
+                                           ("bf16", {"CSN_PWQ16": "0", "CSN_C3Q16": "0", "CSN_C3Q_BWD": "0", "CSN_POOL_ROUTE": "0"}),
+                                           ("fp32", {"CSN_C3Q_BWD": "0", "CSN_ADJ_FUSE": "0"})])
+def test_emu_input_gradient_unit_local(emu_lib, x2_manifest, monkeypatch, act_dtype, env):
+    """CSN_OPT_INPUT_GRAD (csn_backward's `dx`): the plan also forms the gradient w.r.t. the image batch; checked as the
+    first unit's dx inside the unit-local bounds, next to every other unit (whose results must not move)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    print(P.check_train_units_local(emu_lib, CPU, x2_manifest, B=2, size=48, act_dtype=act_dtype, state="shipped", input_grad=True))
+
+
 @pytest.mark.parametrize("act_dtype", ["fp32", "bf16"])
 def test_emu_train_units_local_badly_centred_channels(emu_lib, x2_manifest, act_dtype):
     """the fused depthwise backward forms dz = g sel - (B z + A) with the batch mean folded into A; on channels whose raw

@@ -216,6 +216,14 @@ def test_gpu_train_units_local(hip, x2_manifest, act_dtype, B, size, state):
     print(P.check_train_units_local(lib, dev, x2_manifest, B=B, size=size, act_dtype=act_dtype, state=state))
 
 
+@pytest.mark.parametrize("act_dtype,B,size,state", [("fp32", 2, 224, "well"), ("bf16", 4, 96, "shipped"), ("fp32", 3, 48, "shipped")])
+def test_gpu_input_gradient_unit_local(hip, x2_manifest, act_dtype, B, size, state):
+    """CSN_OPT_INPUT_GRAD (csn_backward's `dx`, autograd's x.grad): the first unit's input gradient inside the
+    unit-local bounds, every other unit unchanged."""
+    lib, dev = hip
+    print(P.check_train_units_local(lib, dev, x2_manifest, B=B, size=size, act_dtype=act_dtype, state=state, input_grad=True))
+
+
 def test_gpu_train_step_bf16(hip, x2_manifest):
     """bf16 activation storage, whole step: logits / loss / penalty / BN statistics against the oracle with the same storage
     points rounded through bf16 and against the plain fp32 oracle (~1e-2 relative)."""

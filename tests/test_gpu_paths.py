@@ -41,7 +41,7 @@ def test_gpu_unpruned_expand2_train_units_local(hip, x2_manifest, act_dtype):
     LOCALLY on the device's own tensors, fp32 and bf16 storage -- the sharp gate check_unpruned's whole-step yardstick is not."""
     lib, dev = hip
     net = P.unpruned_network(2.0, 40, seed=4)
-    worst = P.check_train_units_local(lib, dev, x2_manifest, B=2, size=64, act_dtype=act_dtype, net=net)
+    worst = P.check_train_units_local(lib, dev, x2_manifest, B=2, size=64, act_dtype=act_dtype, net=net, input_grad=(act_dtype == "bf16"))
     print(f"unpruned x2 unit-local [{act_dtype}] worst relative L2 per kind: {worst}")
 
 

@@ -118,4 +118,4 @@ def test_emu_unpruned_expand2_train_units_local(emu_lib, x2_manifest, act_dtype)
     """Every unit of the un-pruned expand-2 net judged locally (the GPU twin: tests/test_gpu_paths.py) -- the wide-channel launches
     (several M groups / row chunks) of the train step, forward and backward."""
     net = P.unpruned_network(2.0, 40, seed=4)
-    print(P.check_train_units_local(emu_lib, CPU, x2_manifest, B=2, size=32, act_dtype=act_dtype, net=net))
+    print(P.check_train_units_local(emu_lib, CPU, x2_manifest, B=2, size=32, act_dtype=act_dtype, net=net, input_grad=(act_dtype == "fp32")))
